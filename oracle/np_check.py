@@ -1,0 +1,164 @@
+"""Independent numpy / scipy restatements used to pin the C oracle.
+
+TEST INFRASTRUCTURE ONLY.  None of this is reference code: the reference ships no tests or
+fixtures, so these second, independently written derivations (brute-force sort for k-NN,
+numpy.linalg.svd for the DLT, complex-step / finite-difference Jacobians, a dense normal
+-equations LM step and scipy.optimize.least_squares optima) are what the oracle is checked
+against, and what tests/golden/*.npz are generated from (tests/golden/make_golden.py).
+"""
+import numpy as np
+
+
+# ---------------------------------------------------------------- matcher
+def knn2_bruteforce(q, t, norm="l2"):
+    """k=2 nearest train rows per query row with cv::batchDistance's ordering: ascending
+    (float distance, train index).  Returns idx (nq,2) int32 (-1 padded), dist (nq,2) float32."""
+    q = np.asarray(q)
+    t = np.asarray(t)
+    nq, nt = q.shape[0], t.shape[0]
+    idx = -np.ones((nq, 2), np.int32)
+    dist = np.full((nq, 2), np.finfo(np.float32).max, np.float32)
+    if nt == 0:
+        return idx, dist
+    for i in range(nq):
+        if norm == "hamming":
+            x = np.bitwise_xor(q[i][None, :], t)
+            d = np.unpackbits(x, axis=1).sum(axis=1).astype(np.float32)
+        else:
+            diff = q[i].astype(np.int64)[None, :] - t.astype(np.int64) if q.dtype == np.uint8 else None
+            if diff is not None:
+                s = (diff * diff).sum(axis=1)
+            else:
+                df = q[i].astype(np.float64)[None, :] - t.astype(np.float64)
+                s = (df * df).sum(axis=1)  # exact for integer-valued rows
+            d = np.sqrt(s.astype(np.float32)).astype(np.float32)
+        order = np.lexsort((np.arange(nt), d))  # stable: distance, then lower index
+        k = min(2, nt)
+        idx[i, :k] = order[:k]
+        dist[i, :k] = d[order[:k]]
+    return idx, dist
+
+
+def ratio_filter(idx, dist, ratio=0.8):
+    r = np.float32(ratio)
+    ok = (idx[:, 1] >= 0) & (dist[:, 0] <= r * dist[:, 1])
+    qi = np.nonzero(ok)[0].astype(np.int32)
+    return qi, idx[ok, 0].copy(), dist[ok, 0].copy()
+
+
+# ---------------------------------------------------------------- triangulation
+def triangulate_svd(P1, P2, K, xy1, xy2, max_err=6.0):
+    """DLT by numpy.linalg.svd, zero distortion.  Returns X, err (m,2) float64, keep."""
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    m = xy1.shape[0]
+    X = np.zeros((m, 3))
+    err = np.zeros((m, 2))
+    for i in range(m):
+        x1, y1 = (xy1[i, 0] - cx) / fx, (xy1[i, 1] - cy) / fy
+        x2, y2 = (xy2[i, 0] - cx) / fx, (xy2[i, 1] - cy) / fy
+        A = np.stack([x1 * P1[2] - P1[0], y1 * P1[2] - P1[1], x2 * P2[2] - P2[0], y2 * P2[2] - P2[1]])
+        v = np.linalg.svd(A)[2][3]
+        X[i] = v[:3] / v[3]
+        for j, (P, xy) in enumerate(((P1, xy1[i]), (P2, xy2[i]))):
+            p = P[:, :3] @ X[i] + P[:, 3]
+            u = np.array([fx * p[0] / p[2] + cx, fy * p[1] / p[2] + cy])
+            err[i, j] = np.linalg.norm(u - xy)
+    keep = ~((err[:, 0] > max_err) | (err[:, 1] > max_err))
+    return X, err, keep
+
+
+# ---------------------------------------------------------------- bundle adjustment
+def rotate_aa(aa, X):
+    """ceres::AngleAxisRotatePoint, both branches, generic over real/complex (complex-step)."""
+    th2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2]
+    if np.real(th2) > np.finfo(np.float64).eps:
+        th = np.sqrt(th2)
+        w = aa / th
+        c, s = np.cos(th), np.sin(th)
+        return X * c + np.cross(w, X) * s + w * (w @ X) * (1 - c)
+    return X + np.cross(aa, X)
+
+
+def residual(cam, X, focal, obs):
+    p = rotate_aa(cam[:3], X) + cam[3:]
+    return np.array([focal * p[0] / p[2] - obs[0], focal * p[1] / p[2] - obs[1]])
+
+
+def jacobian_complex_step(cam, X, focal, obs, h=1e-30):
+    """d r / d [cam(6), X(3), focal] by complex-step differentiation: exact to rounding."""
+    x0 = np.concatenate([cam, X, [focal]]).astype(np.complex128)
+    J = np.zeros((2, 10))
+    for j in range(10):
+        x = x0.copy()
+        x[j] += 1j * h
+        J[:, j] = np.imag(residual(x[:6], x[6:9], x[9], obs)) / h
+    return J
+
+
+def all_residuals(cams, pts, focal, obs_cam, obs_pt, obs_xy):
+    r = np.zeros((len(obs_cam), 2))
+    for o in range(len(obs_cam)):
+        r[o] = residual(cams[obs_cam[o]], pts[obs_pt[o]], focal, obs_xy[o])
+    return r
+
+
+def dense_jacobian(cams, pts, focal, obs_cam, obs_pt, obs_xy):
+    """Full dense J with column order [cams(6 each), focal, points(3 each)] -- small problems."""
+    nc, npt, no = len(cams), len(pts), len(obs_cam)
+    J = np.zeros((2 * no, 6 * nc + 1 + 3 * npt))
+    r = np.zeros(2 * no)
+    for o in range(no):
+        c, p = obs_cam[o], obs_pt[o]
+        Jo = jacobian_complex_step(cams[c], pts[p], focal, obs_xy[o])
+        J[2 * o:2 * o + 2, 6 * c:6 * c + 6] = Jo[:, :6]
+        J[2 * o:2 * o + 2, 6 * nc] = Jo[:, 9]
+        J[2 * o:2 * o + 2, 6 * nc + 1 + 3 * p:6 * nc + 4 + 3 * p] = Jo[:, 6:9]
+        r[2 * o:2 * o + 2] = residual(cams[c], pts[p], focal, obs_xy[o])
+    return J, r
+
+
+def reduced_system_dense(cams, pts, focal, obs_cam, obs_pt, obs_xy, radius=1e4):
+    """Ceres' first LM linear system by dense linear algebra: Jacobi scaling 1/(1+||col||),
+    LM diagonal clamp [1e-6,1e32], Schur complement onto [cams, focal].  Returns S, g, scale
+    (in the oracle's order [cams, points, focal]) and the full scaled-space step."""
+    nc, npt = len(cams), len(pts)
+    J, r = dense_jacobian(cams, pts, focal, obs_cam, obs_pt, obs_xy)
+    scale = 1.0 / (1.0 + np.linalg.norm(J, axis=0))
+    Js = J * scale
+    diag = np.clip((Js * Js).sum(axis=0), 1e-6, 1e32)
+    H = Js.T @ Js + np.diag(diag / radius)
+    b = Js.T @ r
+    nf = 6 * nc + 1
+    B, E, Cm = H[:nf, :nf], H[:nf, nf:], H[nf:, nf:]
+    Ci = np.linalg.inv(Cm)
+    S = B - E @ Ci @ E.T
+    g = b[:nf] - E @ Ci @ b[nf:]
+    step = -np.linalg.solve(H, b)
+    scale_orc = np.concatenate([scale[:6 * nc], scale[nf:], scale[6 * nc:nf]])
+    return S, g, scale_orc, step, 0.5 * float(r @ r)
+
+
+def solve_scipy(cams0, pts0, focal0, obs_cam, obs_pt, obs_xy, **kw):
+    """Independent optimum by scipy.optimize.least_squares (trust-region reflective)."""
+    from scipy.optimize import least_squares
+    from scipy.sparse import lil_matrix
+
+    nc, npt, no = len(cams0), len(pts0), len(obs_cam)
+
+    def unpack(x):
+        return x[:6 * nc].reshape(nc, 6), x[6 * nc:6 * nc + 3 * npt].reshape(npt, 3), x[-1]
+
+    def fun(x):
+        c, p, f = unpack(x)
+        return all_residuals(c, p, f, obs_cam, obs_pt, obs_xy).reshape(-1)
+
+    sp = lil_matrix((2 * no, 6 * nc + 3 * npt + 1), dtype=int)
+    for o in range(no):
+        sp[2 * o:2 * o + 2, 6 * obs_cam[o]:6 * obs_cam[o] + 6] = 1
+        sp[2 * o:2 * o + 2, 6 * nc + 3 * obs_pt[o]:6 * nc + 3 * obs_pt[o] + 3] = 1
+        sp[2 * o:2 * o + 2, -1] = 1
+    x0 = np.concatenate([np.ravel(cams0), np.ravel(pts0), [focal0]])
+    res = least_squares(fun, x0, jac_sparsity=sp, x_scale="jac", method="trf", ftol=1e-12, xtol=1e-12,
+                        gtol=1e-12, **kw)
+    c, p, f = unpack(res.x)
+    return c.copy(), p.copy(), float(f), float(res.cost)

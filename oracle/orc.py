@@ -1,0 +1,236 @@
+"""ctypes front-end of the CPU oracle (oracle/libsfm_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package.  PARITY UNPINNED (see sfm_oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libsfm_oracle.so")
+
+DTYPE_F32, DTYPE_U8 = 0, 1
+NORM_L2, NORM_HAMMING = 0, 1
+CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    srcs = [os.path.join(_HERE, f) for f in ("sfm_oracle_match.c", "sfm_oracle_ba.c", "sfm_oracle.h", "Makefile")]
+    if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs):
+        return _SO
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libsfm_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+class BaOpts(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_int),
+        ("max_time_s", C.c_double),
+        ("function_tolerance", C.c_double),
+        ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double),
+        ("initial_radius", C.c_double),
+        ("max_radius", C.c_double),
+        ("min_radius", C.c_double),
+        ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double),
+        ("max_lm_diagonal", C.c_double),
+        ("jacobi_scaling", C.c_int),
+        ("max_consecutive_invalid", C.c_int),
+        ("verbose", C.c_int),
+    ]
+
+
+class BaSummary(C.Structure):
+    _fields_ = [
+        ("termination", C.c_int),
+        ("iterations", C.c_int),
+        ("successful_steps", C.c_int),
+        ("initial_cost", C.c_double),
+        ("final_cost", C.c_double),
+        ("final_radius", C.c_double),
+        ("gradient_max_norm", C.c_double),
+        ("time_s", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        vp, ip, dp, fp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_float)
+        L.orc_match_knn2.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                     vp, vp, vp, vp, vp, vp, C.c_int]
+        L.orc_match_knn2.restype = C.c_int
+        L.orc_triangulate.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, vp, vp, vp]
+        L.orc_triangulate.restype = C.c_int
+        L.orc_ba_residual.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp, vp]
+        L.orc_ba_residual.restype = None
+        L.orc_ba_default_opts.argtypes = [C.POINTER(BaOpts)]
+        L.orc_ba_solve.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp,
+                                   C.POINTER(BaOpts), C.POINTER(BaSummary)]
+        L.orc_ba_solve.restype = C.c_int
+        L.orc_ba_reduced_system.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, C.c_double, vp, vp, vp,
+                                            C.c_double, vp, vp, vp, vp, vp]
+        L.orc_ba_reduced_system.restype = C.c_int
+        L.orc_ba_time_iterations.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, C.c_double, vp, vp, vp,
+                                             C.c_int, vp]
+        L.orc_ba_time_iterations.restype = C.c_double
+        for f in ("orc_rotmat_colmajor_to_angleaxis", "orc_angleaxis_to_rotmat_colmajor"):
+            getattr(L, f).argtypes = [vp, vp]
+            getattr(L, f).restype = None
+        L.orc_angleaxis_rotate_point.argtypes = [vp, vp, vp]
+        L.orc_angleaxis_rotate_point.restype = None
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def match_knn2(q, t, norm=NORM_L2, ratio=0.8, threads=1, want_knn=False):
+    """getMatching (src/Sfm.cpp:590-608).  q,t: (n,dim) float32 or uint8 arrays.
+    Returns (queryIdx, trainIdx, distance) [+ (knn_idx, knn_dist)]."""
+    q = np.ascontiguousarray(q)
+    t = np.ascontiguousarray(t)
+    assert q.dtype == t.dtype and q.dtype in (np.float32, np.uint8)
+    dim = q.shape[1] if q.ndim == 2 else t.shape[1]
+    nq, nt = q.shape[0], t.shape[0]
+    dtype = DTYPE_F32 if q.dtype == np.float32 else DTYPE_U8
+    oq = np.empty(max(nq, 1), np.int32)
+    ot = np.empty(max(nq, 1), np.int32)
+    od = np.empty(max(nq, 1), np.float32)
+    on = np.zeros(1, np.int32)
+    ki = np.empty((max(nq, 1), 2), np.int32)
+    kd = np.empty((max(nq, 1), 2), np.float32)
+    rc = lib().orc_match_knn2(_p(q), nq, _p(t), nt, dim, dtype, norm, ratio, _p(oq), _p(ot), _p(od), _p(on),
+                              _p(ki), _p(kd), threads)
+    if rc:
+        raise RuntimeError(f"orc_match_knn2 rc={rc}")
+    n = int(on[0])
+    out = (oq[:n].copy(), ot[:n].copy(), od[:n].copy())
+    if want_knn:
+        return out + (ki[:nq].copy(), kd[:nq].copy())
+    return out
+
+
+def triangulate(P1, P2, K, dist, xy1, xy2, max_err=6.0):
+    """triangulateViews numerics (src/Sfm.cpp:820-860).  Returns X (m,3), err (m,2) f32, keep (m,) u8."""
+    P1 = np.ascontiguousarray(P1, np.float64).reshape(12)
+    P2 = np.ascontiguousarray(P2, np.float64).reshape(12)
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    dist = np.ascontiguousarray(dist, np.float64).reshape(5)
+    xy1 = np.ascontiguousarray(xy1, np.float64).reshape(-1, 2)
+    xy2 = np.ascontiguousarray(xy2, np.float64).reshape(-1, 2)
+    m = xy1.shape[0]
+    X = np.empty((max(m, 1), 3), np.float64)
+    err = np.empty((max(m, 1), 2), np.float32)
+    keep = np.empty(max(m, 1), np.uint8)
+    rc = lib().orc_triangulate(_p(P1), _p(P2), _p(K), _p(dist), _p(xy1), _p(xy2), m, max_err, _p(X), _p(err),
+                               _p(keep))
+    if rc:
+        raise RuntimeError(f"orc_triangulate rc={rc}")
+    return X[:m], err[:m], keep[:m]
+
+
+def ba_residual(cam, X, focal, obs):
+    cam = np.ascontiguousarray(cam, np.float64)
+    X = np.ascontiguousarray(X, np.float64)
+    obs = np.ascontiguousarray(obs, np.float64)
+    r = np.empty(2)
+    Jc = np.empty((2, 6))
+    Jp = np.empty((2, 3))
+    Jf = np.empty(2)
+    lib().orc_ba_residual(_p(cam), _p(X), float(focal), _p(obs), _p(r), _p(Jc), _p(Jp), _p(Jf))
+    return r, Jc, Jp, Jf
+
+
+def default_opts(**kw):
+    o = BaOpts()
+    lib().orc_ba_default_opts(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def ba_solve(cams6, pts3, focal, obs_cam, obs_pt, obs_xy, opts=None):
+    """ceres::Solve as configured at src/BundleAdjustment.cpp:115-123.  Returns
+    (cams6, pts3, focal, summary) -- new arrays, inputs untouched."""
+    cams = np.array(cams6, np.float64, order="C").reshape(-1, 6)
+    pts = np.array(pts3, np.float64, order="C").reshape(-1, 3)
+    f = np.array([focal], np.float64)
+    oc = np.ascontiguousarray(obs_cam, np.int32)
+    op = np.ascontiguousarray(obs_pt, np.int32)
+    xy = np.ascontiguousarray(obs_xy, np.float64).reshape(-1, 2)
+    opts = opts or default_opts()
+    s = BaSummary()
+    rc = lib().orc_ba_solve(cams.shape[0], pts.shape[0], oc.shape[0], _p(cams), _p(pts), _p(f), _p(oc), _p(op),
+                            _p(xy), C.byref(opts), C.byref(s))
+    if rc:
+        raise RuntimeError(f"orc_ba_solve rc={rc}")
+    return cams, pts, float(f[0]), s
+
+
+def ba_reduced_system(cams6, pts3, focal, obs_cam, obs_pt, obs_xy, radius=1e4, scale=None):
+    cams = np.ascontiguousarray(cams6, np.float64).reshape(-1, 6)
+    pts = np.ascontiguousarray(pts3, np.float64).reshape(-1, 3)
+    oc = np.ascontiguousarray(obs_cam, np.int32)
+    op = np.ascontiguousarray(obs_pt, np.int32)
+    xy = np.ascontiguousarray(obs_xy, np.float64).reshape(-1, 2)
+    nc, npt = cams.shape[0], pts.shape[0]
+    dim = 6 * nc + 1
+    S = np.empty((dim, dim))
+    g = np.empty(dim)
+    cost = np.zeros(1)
+    sc_out = np.empty(6 * nc + 3 * npt + 1)
+    sc_in = np.ascontiguousarray(scale, np.float64) if scale is not None else None
+    rc = lib().orc_ba_reduced_system(nc, npt, oc.shape[0], _p(cams), _p(pts), float(focal), _p(oc), _p(op),
+                                     _p(xy), float(radius), _p(sc_in), _p(sc_out), _p(S), _p(g), _p(cost))
+    if rc:
+        raise RuntimeError(f"orc_ba_reduced_system rc={rc}")
+    return S, g, float(cost[0]), sc_out
+
+
+def ba_time_iterations(cams6, pts3, focal, obs_cam, obs_pt, obs_xy, iters):
+    cams = np.ascontiguousarray(cams6, np.float64).reshape(-1, 6)
+    pts = np.ascontiguousarray(pts3, np.float64).reshape(-1, 3)
+    oc = np.ascontiguousarray(obs_cam, np.int32)
+    op = np.ascontiguousarray(obs_pt, np.int32)
+    xy = np.ascontiguousarray(obs_xy, np.float64).reshape(-1, 2)
+    fc = np.zeros(1)
+    t = lib().orc_ba_time_iterations(cams.shape[0], pts.shape[0], oc.shape[0], _p(cams), _p(pts), float(focal),
+                                     _p(oc), _p(op), _p(xy), int(iters), _p(fc))
+    return float(t), float(fc[0])
+
+
+def rotmat_to_angleaxis(R):
+    """ceres::RotationMatrixToAngleAxis on a mathematical 3x3 R (row-major numpy)."""
+    Rc = np.ascontiguousarray(np.asarray(R, np.float64).T).reshape(9)  # column-major storage
+    aa = np.empty(3)
+    lib().orc_rotmat_colmajor_to_angleaxis(_p(Rc), _p(aa))
+    return aa
+
+
+def angleaxis_to_rotmat(aa):
+    aa = np.ascontiguousarray(aa, np.float64)
+    Rc = np.empty(9)
+    lib().orc_angleaxis_to_rotmat_colmajor(_p(aa), _p(Rc))
+    return Rc.reshape(3, 3).T.copy()
+
+
+def rotate_point(aa, X):
+    aa = np.ascontiguousarray(aa, np.float64)
+    X = np.ascontiguousarray(X, np.float64)
+    out = np.empty(3)
+    lib().orc_angleaxis_rotate_point(_p(aa), _p(X), _p(out))
+    return out

@@ -1,0 +1,305 @@
+/*
+ * sfm_oracle_match.c -- CPU restatement of the matcher and the two-view triangulation.
+ * TEST INFRASTRUCTURE ONLY (see sfm_oracle.h).  PARITY UNPINNED (no reference goldens exist).
+ *
+ * Follows:  reference src/Sfm.cpp:590-608 (getMatching), :694-711 (AlignedPoints),
+ *           :804-878 (triangulateViews)
+ * and the published algorithms of the libraries those lines call, at the versions pinned by
+ * the reference's CMakeLists.txt:46,58 (OpenCV 3.4.1): core/batch_distance.cpp (knn insertion
+ * list), calib3d/undistort.cpp (undistortPoints), calib3d/triangulate.cpp (4x4 DLT),
+ * core/lapack.cpp (JacobiSVDImpl_), calib3d/calibration.cpp (projectPoints).
+ */
+#include "sfm_oracle.h"
+#include <float.h>
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- distances (OpenCV core/stat.cpp normL2Sqr_/normHamming as used by batchDistance) ---- */
+
+/* f32 rows: float accumulation in 8 SIMD-style partial sums, fixed combine order.  OpenCV leaves
+ * the lane order unspecified; for integer-valued SIFT rows (every partial < 2^24) any order
+ * gives the same exact value. */
+static float l2_f32(const float* a, const float* b, int n) {
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int k = 0;
+  for (; k + 8 <= n; k += 8)
+    for (int l = 0; l < 8; ++l) {
+      float d = a[k + l] - b[k + l];
+      acc[l] += d * d;
+    }
+  for (int l = 0; k < n; ++k, ++l) {
+    float d = a[k] - b[k];
+    acc[l] += d * d;
+  }
+  float s = ((acc[0] + acc[4]) + (acc[2] + acc[6])) + ((acc[1] + acc[5]) + (acc[3] + acc[7]));
+  return sqrtf(s);
+}
+
+static float l2_u8(const uint8_t* a, const uint8_t* b, int n) {
+  int s = 0;
+  for (int k = 0; k < n; ++k) {
+    int d = (int)a[k] - (int)b[k];
+    s += d * d;
+  }
+  return sqrtf((float)s); /* batchDistL2_8u32f: std::sqrt((float)normL2Sqr) */
+}
+
+static int hamming_u8(const uint8_t* a, const uint8_t* b, int n) {
+  int s = 0, k = 0;
+  for (; k + 8 <= n; k += 8) {
+    uint64_t x, y;
+    memcpy(&x, a + k, 8);
+    memcpy(&y, b + k, 8);
+    s += __builtin_popcountll(x ^ y);
+  }
+  for (; k < n; ++k) s += __builtin_popcount((unsigned)(a[k] ^ b[k]));
+  return s;
+}
+
+/* K=2 insertion list of cv::batchDistance: strict '<' to enter, strict '>' while bubbling, so
+ * equal distances keep the lower train index in front and a candidate equal to the current
+ * 2nd-best does not replace it. */
+#define KNN2_INSERT(d, j, d0, i0, d1, i1) \
+  do {                                    \
+    if ((d) < (d1)) {                     \
+      if ((d0) > (d)) {                   \
+        (d1) = (d0);                      \
+        (i1) = (i0);                      \
+        (d0) = (d);                       \
+        (i0) = (j);                       \
+      } else {                            \
+        (d1) = (d);                       \
+        (i1) = (j);                       \
+      }                                   \
+    }                                     \
+  } while (0)
+
+int orc_match_knn2(const void* q, int nq, const void* t, int nt, int dim, int dtype, int norm,
+                   float ratio, int32_t* out_q, int32_t* out_t, float* out_dist, int32_t* out_n,
+                   int32_t* knn_idx, float* knn_dist, int threads) {
+  if (nq < 0 || nt < 0 || dim <= 0) return -1;
+  if (norm == ORC_NORM_HAMMING && dtype != ORC_DTYPE_U8) return -2;
+  int32_t* bi = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)(nq > 0 ? nq : 1));
+  float* bd = (float*)malloc(sizeof(float) * 2 * (size_t)(nq > 0 ? nq : 1));
+  if (!bi || !bd) return -3;
+  if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads)
+  for (int i = 0; i < nq; ++i) {
+    int32_t i0 = -1, i1 = -1;
+    if (norm == ORC_NORM_HAMMING) {
+      int d0 = INT_MAX, d1 = INT_MAX;
+      const uint8_t* a = (const uint8_t*)q + (size_t)i * dim;
+      for (int j = 0; j < nt; ++j) {
+        int d = hamming_u8(a, (const uint8_t*)t + (size_t)j * dim, dim);
+        KNN2_INSERT(d, j, d0, i0, d1, i1);
+      }
+      bd[2 * i] = i0 >= 0 ? (float)d0 : FLT_MAX;
+      bd[2 * i + 1] = i1 >= 0 ? (float)d1 : FLT_MAX;
+    } else {
+      float d0 = FLT_MAX, d1 = FLT_MAX;
+      if (dtype == ORC_DTYPE_F32) {
+        const float* a = (const float*)q + (size_t)i * dim;
+        for (int j = 0; j < nt; ++j) {
+          float d = l2_f32(a, (const float*)t + (size_t)j * dim, dim);
+          KNN2_INSERT(d, j, d0, i0, d1, i1);
+        }
+      } else {
+        const uint8_t* a = (const uint8_t*)q + (size_t)i * dim;
+        for (int j = 0; j < nt; ++j) {
+          float d = l2_u8(a, (const uint8_t*)t + (size_t)j * dim, dim);
+          KNN2_INSERT(d, j, d0, i0, d1, i1);
+        }
+      }
+      bd[2 * i] = d0;
+      bd[2 * i + 1] = d1;
+    }
+    bi[2 * i] = i0;
+    bi[2 * i + 1] = i1;
+  }
+  /* ratio test, src/Sfm.cpp:603-607; float multiply + float compare */
+  int n = 0;
+  for (int i = 0; i < nq; ++i) {
+    if (bi[2 * i + 1] < 0) continue; /* Nt < 2: reference reads out of bounds; emit nothing */
+    if (bd[2 * i] <= ratio * bd[2 * i + 1]) {
+      if (out_q) out_q[n] = i;
+      if (out_t) out_t[n] = bi[2 * i];
+      if (out_dist) out_dist[n] = bd[2 * i];
+      ++n;
+    }
+  }
+  if (out_n) *out_n = n;
+  if (knn_idx) memcpy(knn_idx, bi, sizeof(int32_t) * 2 * (size_t)nq);
+  if (knn_dist) memcpy(knn_dist, bd, sizeof(float) * 2 * (size_t)nq);
+  free(bi);
+  free(bd);
+  return 0;
+}
+
+/* ---- triangulation ---- */
+
+/* OpenCV core/lapack.cpp JacobiSVDImpl_<double> on At (n rows of length m), here m=n=4, giving
+ * Vt sorted by descending singular value; the DLT solution is Vt row 3. */
+static void jacobi_svd4_vt(double At[4][4], double W[4], double Vt[4][4]) {
+  const int n = 4, m = 4;
+  const double eps = DBL_EPSILON * 10;
+  for (int i = 0; i < n; ++i) {
+    double sd = 0;
+    for (int k = 0; k < m; ++k) sd += At[i][k] * At[i][k];
+    W[i] = sd;
+    for (int k = 0; k < n; ++k) Vt[i][k] = (i == k) ? 1.0 : 0.0;
+  }
+  const int max_iter = 30;
+  for (int iter = 0; iter < max_iter; ++iter) {
+    int changed = 0;
+    for (int i = 0; i < n - 1; ++i)
+      for (int j = i + 1; j < n; ++j) {
+        double* Ai = At[i];
+        double* Aj = At[j];
+        double a = W[i], p = 0, b = W[j];
+        for (int k = 0; k < m; ++k) p += Ai[k] * Aj[k];
+        if (fabs(p) <= eps * sqrt(a * b)) continue;
+        p *= 2;
+        double beta = a - b, gamma = hypot(p, beta), c, s;
+        if (beta < 0) {
+          double delta = (gamma - beta) * 0.5;
+          s = sqrt(delta / gamma);
+          c = p / (gamma * s * 2);
+        } else {
+          c = sqrt((gamma + beta) / (gamma * 2));
+          s = p / (gamma * c * 2);
+        }
+        a = b = 0;
+        for (int k = 0; k < m; ++k) {
+          double t0 = c * Ai[k] + s * Aj[k];
+          double t1 = -s * Ai[k] + c * Aj[k];
+          Ai[k] = t0;
+          Aj[k] = t1;
+          a += t0 * t0;
+          b += t1 * t1;
+        }
+        W[i] = a;
+        W[j] = b;
+        changed = 1;
+        double* Vi = Vt[i];
+        double* Vj = Vt[j];
+        for (int k = 0; k < n; ++k) {
+          double t0 = c * Vi[k] + s * Vj[k];
+          double t1 = -s * Vi[k] + c * Vj[k];
+          Vi[k] = t0;
+          Vj[k] = t1;
+        }
+      }
+    if (!changed) break;
+  }
+  for (int i = 0; i < n; ++i) {
+    double sd = 0;
+    for (int k = 0; k < m; ++k) sd += At[i][k] * At[i][k];
+    W[i] = sqrt(sd);
+  }
+  for (int i = 0; i < n - 1; ++i) {
+    int j = i;
+    for (int k = i + 1; k < n; ++k)
+      if (W[j] < W[k]) j = k;
+    if (i != j) {
+      double tw = W[i];
+      W[i] = W[j];
+      W[j] = tw;
+      for (int k = 0; k < m; ++k) {
+        double ta = At[i][k];
+        At[i][k] = At[j][k];
+        At[j][k] = ta;
+      }
+      for (int k = 0; k < n; ++k) {
+        double tv = Vt[i][k];
+        Vt[i][k] = Vt[j][k];
+        Vt[j][k] = tv;
+      }
+    }
+  }
+}
+
+/* calib3d undistortPoints without R/P: x=(u-cx)*(1/fx), then 5 fixed-point iterations
+ * (k1,k2,p1,p2,k3) -- exact no-op when every coefficient is zero (reference calibration,
+ * data/temple/camera_calibration_template.xml:17-19). */
+static void undistort_point(const double K[9], const double d[5], double u, double v, double* xo,
+                            double* yo) {
+  const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+  const double ifx = 1. / fx, ify = 1. / fy;
+  double x = (u - cx) * ifx, y = (v - cy) * ify;
+  const double x0 = x, y0 = y;
+  const double k1 = d[0], k2 = d[1], p1 = d[2], p2 = d[3], k3 = d[4];
+  for (int j = 0; j < 5; ++j) {
+    double r2 = x * x + y * y;
+    double icdist = 1. / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+    double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+    double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+    x = (x0 - deltaX) * icdist;
+    y = (y0 - deltaY) * icdist;
+  }
+  *xo = x;
+  *yo = y;
+}
+
+/* calib3d projectPoints with R (the R->rvec->R round trip of src/Sfm.cpp:836,843 is dropped:
+ * it perturbs R by ~1e-16), t, K, dist. */
+static void project_point(const double P[12], const double K[9], const double d[5],
+                          const double X[3], double* u, double* v) {
+  double x = P[0] * X[0] + P[1] * X[1] + P[2] * X[2] + P[3];
+  double y = P[4] * X[0] + P[5] * X[1] + P[6] * X[2] + P[7];
+  double z = P[8] * X[0] + P[9] * X[1] + P[10] * X[2] + P[11];
+  z = z ? 1. / z : 1;
+  x *= z;
+  y *= z;
+  const double k1 = d[0], k2 = d[1], p1 = d[2], p2 = d[3], k3 = d[4];
+  double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+  double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+  double cdist = 1 + k1 * r2 + k2 * r4 + k3 * r6;
+  double xd = x * cdist + p1 * a1 + p2 * a2;
+  double yd = y * cdist + p1 * a3 + p2 * a1;
+  *u = xd * K[0] + K[2];
+  *v = yd * K[4] + K[5];
+}
+
+int orc_triangulate(const double P1[12], const double P2[12], const double K[9],
+                    const double dist[5], const double* xy1, const double* xy2, int m,
+                    float max_err, double* X, float* err, uint8_t* keep) {
+  if (m < 0) return -1;
+  for (int i = 0; i < m; ++i) {
+    double x1, y1, x2, y2;
+    undistort_point(K, dist, xy1[2 * i], xy1[2 * i + 1], &x1, &y1); /* src/Sfm.cpp:820 */
+    undistort_point(K, dist, xy2[2 * i], xy2[2 * i + 1], &x2, &y2); /* src/Sfm.cpp:821 */
+    /* cv::triangulatePoints, src/Sfm.cpp:826 : A is 4x4, SVD works on At */
+    double A[4][4], At[4][4], W[4], Vt[4][4];
+    for (int k = 0; k < 4; ++k) {
+      A[0][k] = x1 * P1[8 + k] - P1[0 + k];
+      A[1][k] = y1 * P1[8 + k] - P1[4 + k];
+      A[2][k] = x2 * P2[8 + k] - P2[0 + k];
+      A[3][k] = y2 * P2[8 + k] - P2[4 + k];
+    }
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) At[c][r] = A[r][c];
+    jacobi_svd4_vt(At, W, Vt);
+    /* convertPointsFromHomogeneous, src/Sfm.cpp:833 */
+    double w = Vt[3][3];
+    double scale = w != 0 ? 1. / w : 1.;
+    double Xi[3] = {Vt[3][0] * scale, Vt[3][1] * scale, Vt[3][2] * scale};
+    X[3 * i] = Xi[0];
+    X[3 * i + 1] = Xi[1];
+    X[3 * i + 2] = Xi[2];
+    double u1, v1, u2, v2;
+    project_point(P1, K, dist, Xi, &u1, &v1); /* src/Sfm.cpp:840 */
+    project_point(P2, K, dist, Xi, &u2, &v2); /* src/Sfm.cpp:847 */
+    double dx1 = u1 - xy1[2 * i], dy1 = v1 - xy1[2 * i + 1];
+    double dx2 = u2 - xy2[2 * i], dy2 = v2 - xy2[2 * i + 1];
+    const float e1 = (float)sqrt(dx1 * dx1 + dy1 * dy1); /* src/Sfm.cpp:856 */
+    const float e2 = (float)sqrt(dx2 * dx2 + dy2 * dy2); /* src/Sfm.cpp:857 */
+    if (err) {
+      err[2 * i] = e1;
+      err[2 * i + 1] = e2;
+    }
+    keep[i] = !(max_err < e1 || max_err < e2); /* src/Sfm.cpp:859-860 */
+  }
+  return 0;
+}

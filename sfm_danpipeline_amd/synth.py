@@ -1,0 +1,123 @@
+"""Seeded synthetic workloads of the BASELINE.json configs.
+
+Pure numpy, no oracle and no GPU use: the same arrays feed the HIP path, the oracle (in tests)
+and the CPU-baseline leg of bench.py.
+"""
+import numpy as np
+
+
+def sift_image_set(n_images=50, n_feat=2000, dim=128, bank=20000, sigma=6.0, seed=1234):
+    """cfg2: integer-valued 0..255 float32 rows, as OpenCV SIFT emits (src/Sfm.cpp:315-327).
+    Image i draws n_feat distinct rows of a shared bank, adds round(N(0,sigma)), clamps, shuffles."""
+    rng = np.random.default_rng(seed)
+    W = rng.integers(0, 256, size=(bank, dim), dtype=np.int16)
+    out = []
+    for i in range(n_images):
+        r = np.random.default_rng(seed + 1 + i)
+        rows = r.choice(bank, size=n_feat, replace=False)
+        d = W[rows] + np.rint(r.normal(0.0, sigma, size=(n_feat, dim))).astype(np.int16)
+        d = np.clip(d, 0, 255)
+        r.shuffle(d, axis=0)
+        out.append(np.ascontiguousarray(d, dtype=np.float32))
+    return out
+
+
+def orb_image_set(n_images=500, n_feat=5000, nbytes=32, bank=100000, p_flip=0.04, seed=4321):
+    """cfg5: ORB-style 256-bit rows (n_feat x 32 uint8, src/Sfm.cpp:360-375 layout)."""
+    rng = np.random.default_rng(seed)
+    W = rng.integers(0, 256, size=(bank, nbytes), dtype=np.uint8)
+    out = []
+    for i in range(n_images):
+        r = np.random.default_rng(seed + 1 + i)
+        rows = r.choice(bank, size=n_feat, replace=False)
+        flips = np.packbits(r.random((n_feat, nbytes * 8)) < p_flip, axis=1)
+        out.append(np.ascontiguousarray(W[rows] ^ flips))
+    return out
+
+
+def all_pairs(n_images):
+    """The q<t loop of findBestPair (src/Sfm.cpp:511-512), in its iteration order."""
+    q, t = np.triu_indices(n_images, k=1)
+    return np.stack([q, t], axis=1).astype(np.int32)
+
+
+def _rodrigues_to_aa(R):
+    """Angle-axis of a rotation matrix (numpy; generator-side only)."""
+    c = (np.trace(R) - 1.0) / 2.0
+    c = min(1.0, max(-1.0, c))
+    th = np.arccos(c)
+    v = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    n = np.linalg.norm(v)
+    if n < 1e-12:
+        return np.zeros(3)
+    return v / n * th
+
+
+def ba_problem(n_cam=200, n_pt=100000, obs_per_pt=10, seed=777, focal=1520.0, noise_px=0.5,
+               pt_sigma=1e-2, cam_sigma=1e-3, focal_factor=1.01):
+    """cfg3/cfg4: cameras on a ring of radius 10 looking at the origin (+-5 % radial/height
+    jitter), points uniform in the unit ball, each observed by `obs_per_pt` consecutive cameras
+    starting at a uniformly drawn index; principal point already subtracted
+    (src/BundleAdjustment.cpp:94-97).  Returns a dict with the truth, the perturbed start and
+    the observation triples in the order the reference adds residual blocks (point-major,
+    ascending camera id inside a point -- std::map order, src/BundleAdjustment.cpp:87)."""
+    rng = np.random.default_rng(seed)
+    ang = 2 * np.pi * np.arange(n_cam) / n_cam
+    rad = 10.0 * (1 + rng.uniform(-0.05, 0.05, n_cam))
+    hgt = 10.0 * rng.uniform(-0.05, 0.05, n_cam)
+    C = np.stack([rad * np.cos(ang), hgt, rad * np.sin(ang)], axis=1)
+    cams = np.zeros((n_cam, 6))
+    Rs = np.zeros((n_cam, 3, 3))
+    for i in range(n_cam):
+        z = -C[i] / np.linalg.norm(C[i])
+        up = np.array([0.0, 1.0, 0.0])
+        x = np.cross(up, z)
+        x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        R = np.stack([x, y, z])
+        Rs[i] = R
+        cams[i, :3] = _rodrigues_to_aa(R)
+        cams[i, 3:] = -R @ C[i]
+    # points uniform in the unit ball
+    v = rng.normal(size=(n_pt, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    pts = v * rng.uniform(0, 1, (n_pt, 1)) ** (1.0 / 3.0)
+    start = rng.integers(0, n_cam, n_pt)
+    k = min(obs_per_pt, n_cam)
+    cam_idx = (start[:, None] + np.arange(k)[None, :]) % n_cam
+    cam_idx.sort(axis=1)  # std::map<const int,int> iteration order
+    obs_pt = np.repeat(np.arange(n_pt, dtype=np.int32), k)
+    obs_cam = cam_idx.reshape(-1).astype(np.int32)
+    P = np.einsum("oij,oj->oi", Rs[obs_cam], pts[obs_pt]) + cams[obs_cam, 3:]
+    xy = focal * P[:, :2] / P[:, 2:3] + rng.normal(0, noise_px, (obs_pt.size, 2))
+    cams0 = cams + rng.normal(0, cam_sigma, cams.shape)
+    pts0 = pts + rng.normal(0, pt_sigma, pts.shape)
+    return dict(n_cam=n_cam, n_pt=n_pt, n_obs=int(obs_pt.size), cams_true=cams, pts_true=pts,
+                focal_true=focal, cams0=cams0, pts0=pts0, focal0=focal * focal_factor,
+                obs_cam=obs_cam, obs_pt=obs_pt, obs_xy=np.ascontiguousarray(xy))
+
+
+def two_view_scene(m=500, seed=99, K=None, noise_px=0.3, outlier_frac=0.1):
+    """A seeded two-view scene for triangulateViews (src/Sfm.cpp:804-878): P1=[I|0] like the
+    reference's base pair (src/Sfm.cpp:432), P2 a small rotation + baseline."""
+    rng = np.random.default_rng(seed)
+    if K is None:
+        K = np.array([[1520.0, 0, 302.2], [0, 1520.0, 246.87], [0, 0, 1]])  # calibration xml:8-10
+    X = np.stack([rng.uniform(-1, 1, m), rng.uniform(-1, 1, m), rng.uniform(4, 8, m)], axis=1)
+    P1 = np.hstack([np.eye(3), np.zeros((3, 1))])
+    a = np.array([0.02, -0.15, 0.01])
+    th = np.linalg.norm(a)
+    k = a / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    P2 = np.hstack([R, np.array([[-1.0], [0.05], [0.1]])])
+
+    def proj(P):
+        p = X @ P[:, :3].T + P[:, 3]
+        return (p[:, :2] / p[:, 2:3]) @ K[:2, :2].T + K[:2, 2]
+
+    xy1 = proj(P1) + rng.normal(0, noise_px, (m, 2))
+    xy2 = proj(P2) + rng.normal(0, noise_px, (m, 2))
+    bad = rng.random(m) < outlier_frac
+    xy2[bad] += rng.uniform(-60, 60, (int(bad.sum()), 2))
+    return dict(P1=P1, P2=P2, K=K, dist=np.zeros(5), xy1=xy1, xy2=xy2, X_true=X)
