@@ -1,0 +1,181 @@
+/*
+ * sfmhip.h -- C ABI of the MI355X (gfx950) implementation of the feature-matching +
+ * triangulation + bundle-adjustment hot path of codebydant/sfM_danPipeline.
+ *
+ * This is the drop-in boundary.  The reference has no plugin / FFI
+ * layer: its boundary is three C++ member functions, which the host mirror in
+ * sfm_danpipeline_amd/csrc/host/ (Sfm.h, BundleAdjustment.h) keeps verbatim and forwards here:
+ *
+ *   StructFromMotion::getMatching      reference include/Sfm.h:89,  src/Sfm.cpp:590-608
+ *   StructFromMotion::triangulateViews reference include/Sfm.h:115-117, src/Sfm.cpp:804-878
+ *   BundleAdjustment::adjustBundle     reference include/BundleAdjustment.h:19-20,
+ *                                      src/BundleAdjustment.cpp:46-175
+ *
+ * Conventions: plain C types only; every function returns an int status (0 = ok, <0 = error,
+ * see sfmhip_error_string); no exceptions cross this boundary; the caller owns every buffer
+ * it passes; calls on one context are synchronous to the caller unless the name says
+ * `_async`; a context is bound to one HIP device and is not thread-safe (the reference is
+ * single-threaded, src/Sfm.cpp:9-109).  There is NO CPU fallback behind this ABI: without a
+ * gfx950 device sfmhip_init fails.
+ */
+#ifndef SFMHIP_H
+#define SFMHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFMHIP_VERSION 1
+
+/* status codes */
+enum {
+  SFMHIP_OK = 0,
+  SFMHIP_ERR_NO_DEVICE = -1,
+  SFMHIP_ERR_HIP = -2,       /* a HIP runtime call failed; sfmhip_last_hip_error() has the code */
+  SFMHIP_ERR_ARG = -3,
+  SFMHIP_ERR_ALLOC = -4,
+  SFMHIP_ERR_UNSUPPORTED = -5,
+  SFMHIP_ERR_STATE = -6,
+  SFMHIP_ERR_COMM = -7
+};
+
+/* descriptor element type of a cv::Mat row (reference include/Sfm.h:29, src/Sfm.cpp:326) */
+enum { SFMHIP_F32 = 0, SFMHIP_U8 = 1 };
+/* distance.  L2 is what the reference always uses (cv::NORM_L2, src/Sfm.cpp:593) -- also on
+ * binary ORB/AKAZE rows; HAMMING is cv::NORM_HAMMING as asked for by BASELINE.json cfg5. */
+enum { SFMHIP_L2 = 0, SFMHIP_HAMMING = 1 };
+
+typedef struct sfmhip_ctx sfmhip_ctx;
+typedef struct sfmhip_imageset sfmhip_imageset;
+typedef struct sfmhip_matchplan sfmhip_matchplan;
+typedef struct sfmhip_ba sfmhip_ba;
+
+/* ---- context ---- */
+int sfmhip_init(int device, sfmhip_ctx** out);
+/* same, but all work is enqueued on an existing hipStream_t (e.g. torch's current stream) */
+int sfmhip_init_on_stream(int device, void* hip_stream, sfmhip_ctx** out);
+void sfmhip_shutdown(sfmhip_ctx* ctx);
+int sfmhip_synchronize(sfmhip_ctx* ctx);
+const char* sfmhip_error_string(int status);
+int sfmhip_last_hip_error(void);
+int sfmhip_version(void);
+
+/* ---- getMatching: one pair, host buffers (reference src/Sfm.cpp:590-608) ----
+ * q,t: row-major descriptor matrices (nq x dim, nt x dim; dim = elements per row).
+ * Emits, in ascending queryIdx, knn[i][0] of every query with d0 <= ratio*d1 (float compare),
+ * k-NN ties broken towards the lower trainIdx exactly as cv::batchDistance does.
+ * out_q/out_t/out_dist: caller-allocated, nq entries each.  nt < 2 emits nothing. */
+int sfmhip_match_knn2(sfmhip_ctx* ctx, const void* q, int nq, const void* t, int nt, int dim,
+                      int dtype, int norm, float ratio, int32_t* out_q, int32_t* out_t,
+                      float* out_dist, int32_t* out_n);
+
+/* ---- all-pairs matching with descriptors resident in HBM (the findBestPair loop,
+ *      reference src/Sfm.cpp:511-515, as one batched launch) ---- */
+int sfmhip_imageset_create(sfmhip_ctx* ctx, int n_images, const int32_t* n_rows, int dim,
+                           int dtype, int norm, sfmhip_imageset** out);
+/* copy one image's descriptor matrix host -> HBM */
+int sfmhip_imageset_upload(sfmhip_imageset* set, int image, const void* host_rows);
+/* or adopt rows that already live in HBM (no copy; must stay valid while the set is used) */
+int sfmhip_imageset_adopt_device(sfmhip_imageset* set, int image, const void* device_rows);
+/* device pass over every image: integrality check, centring to i8 / bit expansion, row norms,
+ * tie-break key bases.  Asynchronous on the context's stream. */
+int sfmhip_imageset_prepare_async(sfmhip_imageset* set);
+void sfmhip_imageset_destroy(sfmhip_imageset* set);
+
+/* pairs: n_pairs x (queryImage, trainImage) int32, host memory */
+int sfmhip_matchplan_create(sfmhip_imageset* set, const int32_t* pairs, int n_pairs,
+                            sfmhip_matchplan** out);
+/* k-NN + ratio test + ordered compaction for every pair of the plan; results stay in HBM */
+int sfmhip_matchplan_run_async(sfmhip_matchplan* plan, float ratio);
+/* counts[n_pairs]; optional concatenated lists (capacity entries each, pair-major, ascending
+ * queryIdx inside a pair); *total receives the number of matches over all pairs. */
+int sfmhip_matchplan_fetch(sfmhip_matchplan* plan, int32_t* counts, int32_t* out_q,
+                           int32_t* out_t, float* out_dist, int64_t capacity, int64_t* total);
+/* raw k=2 lists of pair `pair`: idx[nq*2] (-1 padded), dist[nq*2] */
+int sfmhip_matchplan_fetch_knn(sfmhip_matchplan* plan, int pair, int32_t* idx, float* dist);
+/* seconds of device time of the last run's kernels, by stage (hipEvents on the ctx stream):
+ * [0]=prepare (last prepare_async) [1]=knn kernels [2]=compaction; and the knn-kernel count */
+int sfmhip_matchplan_last_timing(sfmhip_matchplan* plan, double seconds[3]);
+void sfmhip_matchplan_destroy(sfmhip_matchplan* plan);
+
+/* ---- triangulateViews numerics (reference src/Sfm.cpp:812-860) ----
+ * P1,P2: cv::Matx34d row-major; K 3x3 row-major; dist k1,k2,p1,p2,k3; xy1/xy2: m gathered
+ * pixel pairs (AlignedPoints, src/Sfm.cpp:694-711).  X: 3*m, keep: m (1 = both reprojection
+ * errors <= max_err as float), err: 2*m floats or NULL. */
+int sfmhip_triangulate(sfmhip_ctx* ctx, const double P1[12], const double P2[12],
+                       const double K[9], const double dist[5], const double* xy1,
+                       const double* xy2, int m, float max_err, double* X, float* err,
+                       uint8_t* keep);
+
+/* ---- adjustBundle solver core (reference src/BundleAdjustment.cpp:46-175) ---- */
+typedef struct {
+  int max_iterations;           /* 500   src/BundleAdjustment.cpp:118 */
+  double max_time_s;            /* 10    src/BundleAdjustment.cpp:120 ; <=0 disables */
+  double function_tolerance;    /* 1e-6  Ceres 1.13 defaults from here on */
+  double gradient_tolerance;    /* 1e-10 */
+  double parameter_tolerance;   /* 1e-8  */
+  double initial_radius;        /* 1e4   */
+  double max_radius;            /* 1e16  */
+  double min_radius;            /* 1e-32 */
+  double min_relative_decrease; /* 1e-3  */
+  double min_lm_diagonal;       /* 1e-6  */
+  double max_lm_diagonal;       /* 1e32  */
+  int jacobi_scaling;           /* 1     */
+  int max_consecutive_invalid;  /* 5     */
+  int verbose;
+} sfmhip_ba_opts;
+
+enum { SFMHIP_BA_CONVERGENCE = 0, SFMHIP_BA_NO_CONVERGENCE = 1, SFMHIP_BA_FAILURE = 2 };
+
+typedef struct {
+  int termination; /* SFMHIP_BA_*; the C++ wrapper writes results back only on CONVERGENCE
+                      (src/BundleAdjustment.cpp:126-129) */
+  int iterations;
+  int successful_steps;
+  double initial_cost;
+  double final_cost;
+  double final_radius;
+  double gradient_max_norm;
+  double time_s;
+} sfmhip_ba_summary;
+
+void sfmhip_ba_default_opts(sfmhip_ba_opts* o);
+
+/* One-shot: host buffers in, optimised parameters out (in place).  cams6: n_cam x
+ * (angle-axis 3, translation 3); pts3: n_pt x 3; one shared focal; one residual block per
+ * (obs_cam[o], obs_pt[o], obs_xy[2o..2o+1]) with the principal point already subtracted. */
+int sfmhip_ba_solve(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, double* cams6, double* pts3,
+                    double* focal, const int32_t* obs_cam, const int32_t* obs_pt,
+                    const double* obs_xy, const sfmhip_ba_opts* opts, sfmhip_ba_summary* summary);
+
+/* Persistent problem object (multi-GPU: every rank holds all cameras + focal and its own
+ * block of points with their observations; the per-iteration sum of the reduced camera
+ * system goes through `allreduce`, e.g. RCCL via torch.distributed). */
+typedef int (*sfmhip_allreduce_fn)(void* device_f64_buffer, size_t count, void* user);
+
+int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const int32_t* obs_cam,
+                     const int32_t* obs_pt, const double* obs_xy, sfmhip_ba** out);
+/* rank/world of the calling process; world==1 (the default) never calls fn.  The callback sums
+ * `count` doubles in place across ranks (ncclAllReduce(sum, ncclDouble) over xGMI) and must be
+ * ordered after the work already enqueued on the context's stream. */
+int sfmhip_ba_set_allreduce(sfmhip_ba* ba, sfmhip_allreduce_fn fn, void* user, int rank, int world);
+int sfmhip_ba_set_params(sfmhip_ba* ba, const double* cams6, const double* pts3, double focal);
+int sfmhip_ba_get_params(sfmhip_ba* ba, double* cams6, double* pts3, double* focal);
+int sfmhip_ba_run(sfmhip_ba* ba, const sfmhip_ba_opts* opts, sfmhip_ba_summary* summary);
+/* `iters` LM iterations (linearise + Schur eliminate + all-reduce + reduced solve +
+ * back-substitute + candidate cost, accept/reject as usual) without convergence tests */
+int sfmhip_ba_iterate(sfmhip_ba* ba, int iters, sfmhip_ba_summary* summary);
+/* One linearisation at the current parameters: reduced system of this rank's points,
+ * dim = 6*n_cam+1, S row-major full symmetric, before any all-reduce.  Test hook. */
+int sfmhip_ba_reduced_system(sfmhip_ba* ba, double radius, double* S, double* g, double* cost);
+/* device seconds of the last run/iterate by kernel group:
+ * [0]=linearise+eliminate [1]=allreduce [2]=reduced solve [3]=back-substitute+cost */
+int sfmhip_ba_last_timing(sfmhip_ba* ba, double seconds[4], int* launches);
+void sfmhip_ba_destroy(sfmhip_ba* ba);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

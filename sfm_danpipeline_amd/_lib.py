@@ -1,0 +1,144 @@
+"""ctypes binding of libsfmhip.so (include/sfmhip.h).  There is no fallback: if the library is
+missing or no gfx950 device is present, the product path raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libsfmhip.so")
+
+F32, U8 = 0, 1
+L2, HAMMING = 0, 1
+BA_CONVERGENCE, BA_NO_CONVERGENCE, BA_FAILURE = 0, 1, 2
+
+
+class SfmHipError(RuntimeError):
+    pass
+
+
+class BaOpts(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_int), ("max_time_s", C.c_double), ("function_tolerance", C.c_double),
+        ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double), ("initial_radius", C.c_double),
+        ("max_radius", C.c_double), ("min_radius", C.c_double), ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double), ("jacobi_scaling", C.c_int),
+        ("max_consecutive_invalid", C.c_int), ("verbose", C.c_int),
+    ]
+
+
+class BaSummary(C.Structure):
+    _fields_ = [
+        ("termination", C.c_int), ("iterations", C.c_int), ("successful_steps", C.c_int),
+        ("initial_cost", C.c_double), ("final_cost", C.c_double), ("final_radius", C.c_double),
+        ("gradient_max_norm", C.c_double), ("time_s", C.c_double),
+    ]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
+
+# every symbol include/sfmhip.h declares (tests check the built library exports all of them)
+SYMBOLS = [
+    "sfmhip_init", "sfmhip_init_on_stream", "sfmhip_shutdown", "sfmhip_synchronize", "sfmhip_error_string",
+    "sfmhip_last_hip_error", "sfmhip_version", "sfmhip_match_knn2", "sfmhip_imageset_create",
+    "sfmhip_imageset_upload", "sfmhip_imageset_adopt_device", "sfmhip_imageset_prepare_async",
+    "sfmhip_imageset_destroy", "sfmhip_matchplan_create", "sfmhip_matchplan_run_async", "sfmhip_matchplan_fetch",
+    "sfmhip_matchplan_fetch_knn", "sfmhip_matchplan_last_timing", "sfmhip_matchplan_destroy",
+    "sfmhip_triangulate", "sfmhip_ba_default_opts", "sfmhip_ba_solve", "sfmhip_ba_create",
+    "sfmhip_ba_set_allreduce", "sfmhip_ba_set_params", "sfmhip_ba_get_params", "sfmhip_ba_run",
+    "sfmhip_ba_iterate", "sfmhip_ba_reduced_system", "sfmhip_ba_last_timing", "sfmhip_ba_destroy",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libsfmhip.so and declare prototypes.  Raises if the extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise SfmHipError(f"{SO} is missing: run `python -m sfm_danpipeline_amd.build` "
+                          "(the HIP extension is the only implementation; there is no CPU fallback)")
+    L = C.CDLL(SO)
+    vp, i32, f64, cint = C.c_void_p, C.c_int32, C.c_double, C.c_int
+    L.sfmhip_init.argtypes = [cint, C.POINTER(vp)]
+    L.sfmhip_init_on_stream.argtypes = [cint, vp, C.POINTER(vp)]
+    L.sfmhip_shutdown.argtypes = [vp]
+    L.sfmhip_shutdown.restype = None
+    L.sfmhip_synchronize.argtypes = [vp]
+    L.sfmhip_error_string.argtypes = [cint]
+    L.sfmhip_error_string.restype = C.c_char_p
+    L.sfmhip_match_knn2.argtypes = [vp, vp, cint, vp, cint, cint, cint, cint, C.c_float, vp, vp, vp, vp]
+    L.sfmhip_imageset_create.argtypes = [vp, cint, vp, cint, cint, cint, C.POINTER(vp)]
+    L.sfmhip_imageset_upload.argtypes = [vp, cint, vp]
+    L.sfmhip_imageset_adopt_device.argtypes = [vp, cint, vp]
+    L.sfmhip_imageset_prepare_async.argtypes = [vp]
+    L.sfmhip_imageset_destroy.argtypes = [vp]
+    L.sfmhip_imageset_destroy.restype = None
+    L.sfmhip_matchplan_create.argtypes = [vp, vp, cint, C.POINTER(vp)]
+    L.sfmhip_matchplan_run_async.argtypes = [vp, C.c_float]
+    L.sfmhip_matchplan_fetch.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.POINTER(C.c_int64)]
+    L.sfmhip_matchplan_fetch_knn.argtypes = [vp, cint, vp, vp]
+    L.sfmhip_matchplan_last_timing.argtypes = [vp, vp]
+    L.sfmhip_matchplan_destroy.argtypes = [vp]
+    L.sfmhip_matchplan_destroy.restype = None
+    if hasattr(L, "sfmhip_triangulate"):
+        L.sfmhip_triangulate.argtypes = [vp, vp, vp, vp, vp, vp, vp, cint, C.c_float, vp, vp, vp]
+    if hasattr(L, "sfmhip_ba_solve"):
+        L.sfmhip_ba_default_opts.argtypes = [C.POINTER(BaOpts)]
+        L.sfmhip_ba_default_opts.restype = None
+        L.sfmhip_ba_solve.argtypes = [vp, cint, cint, cint, vp, vp, vp, vp, vp, vp, C.POINTER(BaOpts),
+                                      C.POINTER(BaSummary)]
+        L.sfmhip_ba_create.argtypes = [vp, cint, cint, cint, vp, vp, vp, C.POINTER(vp)]
+        L.sfmhip_ba_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp, cint, cint]
+        L.sfmhip_ba_set_params.argtypes = [vp, vp, vp, f64]
+        L.sfmhip_ba_get_params.argtypes = [vp, vp, vp, vp]
+        L.sfmhip_ba_run.argtypes = [vp, C.POINTER(BaOpts), C.POINTER(BaSummary)]
+        L.sfmhip_ba_iterate.argtypes = [vp, cint, C.POINTER(BaSummary)]
+        L.sfmhip_ba_reduced_system.argtypes = [vp, f64, vp, vp, vp]
+        L.sfmhip_ba_last_timing.argtypes = [vp, vp, vp]
+        L.sfmhip_ba_destroy.argtypes = [vp]
+        L.sfmhip_ba_destroy.restype = None
+    _lib = L
+    return L
+
+
+def check(rc, what="sfmhip"):
+    if rc != 0:
+        msg = lib().sfmhip_error_string(rc).decode()
+        raise SfmHipError(f"{what}: {msg} (status {rc}, hip error {lib().sfmhip_last_hip_error()})")
+
+
+class Context:
+    """One sfmhip context = one HIP device (+ optionally an existing stream, e.g. torch's)."""
+
+    def __init__(self, device=0, stream=None):
+        self.h = C.c_void_p()
+        if stream is None:
+            check(lib().sfmhip_init(device, C.byref(self.h)), "sfmhip_init")
+        else:
+            check(lib().sfmhip_init_on_stream(device, C.c_void_p(stream), C.byref(self.h)), "sfmhip_init_on_stream")
+        self.device = device
+
+    def synchronize(self):
+        check(lib().sfmhip_synchronize(self.h), "sfmhip_synchronize")
+
+    def close(self):
+        if self.h:
+            lib().sfmhip_shutdown(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default_ctx

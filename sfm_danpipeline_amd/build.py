@@ -1,0 +1,61 @@
+"""Builds libsfmhip.so (HIP kernels + C ABI, gfx950 only) in-tree with hipcc.
+
+hipcc cross-compiles without a GPU, so this runs in the dev container; the .so travels to the
+GPU box with the repository snapshot.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(HERE, "libsfmhip.so")
+SOURCES = ["context.hip", "match.hip", "triangulate.hip", "ba.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
+         "-Wno-unused-value", "-ffp-contract=off"]
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "sfmhip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return SO
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    cmd = [_hipcc()] + FLAGS + ["-o", SO] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO
+
+
+def build_host_demo(force=False):
+    """C++ host mirror (Sfm.h / BundleAdjustment.h call surface) + its self-test executable."""
+    host = os.path.join(CSRC, "host")
+    exe = os.path.join(HERE, "sfm_host_selftest")
+    srcs = [os.path.join(host, f) for f in ("Sfm.cpp", "BundleAdjustment.cpp", "selftest.cpp")]
+    if not all(os.path.exists(s) for s in srcs):
+        return None
+    if not force and os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(s) for s in srcs):
+        return exe
+    build()
+    cmd = ["g++", "-O2", "-std=c++14", "-I", os.path.join(HERE, "..", "include"), "-I", host, "-o", exe] + srcs + \
+          ["-L", HERE, "-lsfmhip", "-Wl,-rpath,$ORIGIN"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,1619 @@
+// ba.hip -- Levenberg-Marquardt bundle adjustment with a Schur-complement reduced camera solve
+// on gfx950 (MI355X).
+//
+// Replaces ceres::Solve(DENSE_SCHUR) as configured by BundleAdjustment::adjustBundle (reference
+// src/BundleAdjustment.cpp:115-123) for the cost functor SimpleReprojectionError
+// (src/BundleAdjustment.cpp:10-35): parameter blocks = camera (angle-axis 3 + translation 3),
+// point (3), one shared focal (1); residual 2 per observation; points are the eliminated
+// e-blocks, cameras + focal the reduced system of dimension 6*n_cam+1.
+//
+// Layout in HBM (DESIGN.md "BA"): everything f64.  Points are re-ordered once per problem so
+// that points observed by the same ascending camera list ("signature") are contiguous and cut
+// into chunks; the reduced matrix S is a dense (6Nc+1)^2 row-major array of which only the
+// upper triangle is formed (= a column-major lower triangle for the Cholesky kernels).
+//
+// Kernels per LM iteration:
+//   ba_eliminate<R>   one wave per chunk.  Lanes 0..n-1 linearise the point's n observations
+//                     (analytic Jacobian from per-camera R, dR/dw tables), shuffle-reduce the 3x3
+//                     point block, and publish T_o = (Jc^T Jp) C^-1/2 through LDS; then every lane
+//                     owns a 6x3 half-block of the camera-pair Gram  -sum_p T_a T_b^T and keeps it
+//                     in REGISTERS across all points of the chunk; one f64 atomic flush per chunk.
+//   ba_finalize       LM diagonal (clamped squared column norms / radius) onto S, gradient max.
+//   chol_panel/chol_update/chol_backsolve  dense blocked Cholesky of S with the rhs carried as
+//                     an extra row, then the transposed triangular solve.
+//   ba_cand_cams      candidate cameras / focal and their rotation tables.
+//   ba_backsub        per point: back-substitution, model cost change, candidate point,
+//                     candidate cost.
+// Multi-GPU: every rank holds all cameras and its own block of points; [S | g | F^T b |
+// diag | scalars] is summed by the caller's all-reduce (RCCL over xGMI) once per iteration,
+// every rank then solves the same reduced system and back-substitutes its own points.
+#include "common.h"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <vector>
+#include <float.h>
+
+namespace {
+
+constexpr int CAMD = 40;     // doubles per camera table: R[9] t[3] dR/dw[27] pad
+constexpr int NB = 64;       // Cholesky panel width
+constexpr int SC = 16;       // scalar slots at the tail of the all-reduce buffer (+ world)
+constexpr int FB_MAXN = 64;  // fallback kernel: max observations per point
+
+struct Chunk {
+  int sig_off;  // offset into sig_cams
+  int n;        // observations per point in this signature
+  int p0;       // first sorted point
+  int cnt;      // points in the chunk
+};
+
+struct BaDev {
+  // problem (sorted order)
+  int nc, np, no, dim, ld;
+  const int* optr;     // np+1
+  const int* ocam;     // no
+  const double2* oxy;  // no
+  // parameters
+  double* cams;    // nc*6
+  double* pts;     // np*3 (sorted)
+  double* focal;   // 1
+  double* camd;    // nc*CAMD
+  double* cams_c;  // candidates
+  double* pts_c;
+  double* focal_c;
+  double* camd_c;
+  // scaling / LM
+  double* scale_c;  // nc*6
+  double* scale_p;  // np*3
+  double* scale_f;  // 1
+  double* diag;     // dim (clamped)
+  // reduced system: red = [S dim*dim | g dim | gF dim | dc dim | sc SC+world]
+  double* red;
+  double* z;     // dim solution
+  double* red2;  // 16 scalars of the step evaluation
+  int* info;     // cholesky failure flag
+};
+
+__device__ __forceinline__ double* red_S(const BaDev& d) { return d.red; }
+__device__ __forceinline__ double* red_g(const BaDev& d) { return d.red + (size_t)d.dim * d.dim; }
+__device__ __forceinline__ double* red_gF(const BaDev& d) { return d.red + (size_t)d.dim * d.dim + d.dim; }
+__device__ __forceinline__ double* red_dc(const BaDev& d) { return d.red + (size_t)d.dim * d.dim + 2 * d.dim; }
+__device__ __forceinline__ double* red_sc(const BaDev& d) { return d.red + (size_t)d.dim * d.dim + 3 * d.dim; }
+
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_max_pos_f64(double* p, double v) {
+  // v >= 0: IEEE order == unsigned integer order
+  atomicMax((unsigned long long*)p, (unsigned long long)__double_as_longlong(v));
+}
+
+// ---------------------------------------------------------------- camera tables
+// R = dp/dX and dR/dw_j of ceres::AngleAxisRotatePoint, same theta^2 > eps branch as the
+// expression autodiff differentiates (src/BundleAdjustment.cpp:16).
+__device__ void cam_table(const double* cam, double* o, bool want_d) {
+  const double a0 = cam[0], a1 = cam[1], a2 = cam[2];
+  const double theta2 = a0 * a0 + a1 * a1 + a2 * a2;
+  double R[9], dR[27];
+  if (theta2 > DBL_EPSILON) {
+    const double theta = sqrt(theta2), c = cos(theta), s = sin(theta), ti = 1.0 / theta;
+    const double w[3] = {a0 * ti, a1 * ti, a2 * ti};
+    const double oc = 1.0 - c;
+    R[0] = c + oc * w[0] * w[0];
+    R[1] = -s * w[2] + oc * w[0] * w[1];
+    R[2] = s * w[1] + oc * w[0] * w[2];
+    R[3] = s * w[2] + oc * w[1] * w[0];
+    R[4] = c + oc * w[1] * w[1];
+    R[5] = -s * w[0] + oc * w[1] * w[2];
+    R[6] = -s * w[1] + oc * w[2] * w[0];
+    R[7] = s * w[0] + oc * w[2] * w[1];
+    R[8] = c + oc * w[2] * w[2];
+    if (want_d) {
+      for (int j = 0; j < 3; ++j) {
+        double dw[3];
+        for (int i = 0; i < 3; ++i) dw[i] = ((i == j ? 1.0 : 0.0) - w[i] * w[j]) * ti;
+        const double wj = w[j];
+        // d/dw_j [ c I + s [w]x + (1-c) w w^T ]
+        double* D = dR + 9 * j;
+        const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+        const double dK[9] = {0, -dw[2], dw[1], dw[2], 0, -dw[0], -dw[1], dw[0], 0};
+        for (int r = 0; r < 3; ++r)
+          for (int q = 0; q < 3; ++q) {
+            double v = c * wj * K[3 * r + q] + s * dK[3 * r + q] + s * wj * w[r] * w[q] +
+                       oc * (dw[r] * w[q] + w[r] * dw[q]);
+            if (r == q) v += -s * wj;
+            D[3 * r + q] = v;
+          }
+      }
+    }
+  } else {
+    R[0] = 1; R[1] = -a2; R[2] = a1;
+    R[3] = a2; R[4] = 1; R[5] = -a0;
+    R[6] = -a1; R[7] = a0; R[8] = 1;
+    if (want_d) {
+      for (int i = 0; i < 27; ++i) dR[i] = 0;
+      // dR/dw_0 = [e0]x, ...
+      dR[0 * 9 + 5] = -1; dR[0 * 9 + 7] = 1;
+      dR[1 * 9 + 2] = 1;  dR[1 * 9 + 6] = -1;
+      dR[2 * 9 + 1] = -1; dR[2 * 9 + 3] = 1;
+    }
+  }
+  for (int i = 0; i < 9; ++i) o[i] = R[i];
+  o[9] = cam[3];
+  o[10] = cam[4];
+  o[11] = cam[5];
+  if (want_d)
+    for (int i = 0; i < 27; ++i) o[12 + i] = dR[i];
+}
+
+__global__ void ba_cam_prep(const double* __restrict__ cams, double* __restrict__ camd, int nc, int want_d) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < nc) cam_table(cams + 6 * c, camd + (size_t)CAMD * c, want_d != 0);
+}
+
+// ---------------------------------------------------------------- per-observation linearisation
+struct ObsLin {
+  double r0, r1;
+  double Jc[12];  // 2x6 row-major
+  double Jp[6];   // 2x3
+  double Jf[2];
+};
+
+template <typename CP>
+__device__ __forceinline__ void obs_residual(CP cd, const double X[3], double focal, double ox, double oy,
+                                             double& r0, double& r1) {
+  const double px = cd[0] * X[0] + cd[1] * X[1] + cd[2] * X[2] + cd[9];
+  const double py = cd[3] * X[0] + cd[4] * X[1] + cd[5] * X[2] + cd[10];
+  const double pz = cd[6] * X[0] + cd[7] * X[1] + cd[8] * X[2] + cd[11];
+  const double xp = px / pz, yp = py / pz;
+  r0 = focal * xp - ox;
+  r1 = focal * yp - oy;
+}
+
+// unscaled Jacobian; sc/sp/sf (may be null -> 1) scale the columns
+template <typename CP>
+__device__ __forceinline__ void obs_linearize(CP cd, const double X[3], double focal, double ox, double oy,
+                                              const double* sc, const double* sp, double sf, ObsLin& o) {
+  const double px = cd[0] * X[0] + cd[1] * X[1] + cd[2] * X[2] + cd[9];
+  const double py = cd[3] * X[0] + cd[4] * X[1] + cd[5] * X[2] + cd[10];
+  const double pz = cd[6] * X[0] + cd[7] * X[1] + cd[8] * X[2] + cd[11];
+  const double xp = px / pz, yp = py / pz;
+  o.r0 = focal * xp - ox;
+  o.r1 = focal * yp - oy;
+  const double iz = 1.0 / pz;
+  const double d00 = focal * iz, d02 = -focal * xp * iz, d12 = -focal * yp * iz;  // dr/dp rows
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double dx = cd[12 + 9 * j + 0] * X[0] + cd[12 + 9 * j + 1] * X[1] + cd[12 + 9 * j + 2] * X[2];
+    const double dy = cd[12 + 9 * j + 3] * X[0] + cd[12 + 9 * j + 4] * X[1] + cd[12 + 9 * j + 5] * X[2];
+    const double dz = cd[12 + 9 * j + 6] * X[0] + cd[12 + 9 * j + 7] * X[1] + cd[12 + 9 * j + 8] * X[2];
+    const double s = sc ? sc[j] : 1.0;
+    o.Jc[j] = (d00 * dx + d02 * dz) * s;
+    o.Jc[6 + j] = (d00 * dy + d12 * dz) * s;
+  }
+  {
+    const double s3 = sc ? sc[3] : 1.0, s4 = sc ? sc[4] : 1.0, s5 = sc ? sc[5] : 1.0;
+    o.Jc[3] = d00 * s3;
+    o.Jc[4] = 0.0;
+    o.Jc[5] = d02 * s5;
+    o.Jc[9] = 0.0;
+    o.Jc[10] = d00 * s4;
+    o.Jc[11] = d12 * s5;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double s = sp ? sp[j] : 1.0;
+    o.Jp[j] = (d00 * cd[j] + d02 * cd[6 + j]) * s;
+    o.Jp[3 + j] = (d00 * cd[3 + j] + d12 * cd[6 + j]) * s;
+  }
+  o.Jf[0] = xp * sf;
+  o.Jf[1] = yp * sf;
+}
+
+// 3x3 SPD: inverse of the Cholesky factor (Li lower, C^-1 = Li^T Li); returns false if not PD
+__device__ __forceinline__ bool chol3_inv(const double C[6] /*00 10 11 20 21 22*/, double Li[6]) {
+  const double c00 = C[0], c10 = C[1], c11 = C[2], c20 = C[3], c21 = C[4], c22 = C[5];
+  if (!(c00 > 0)) return false;
+  const double l00 = sqrt(c00);
+  const double l10 = c10 / l00, l20 = c20 / l00;
+  const double d11 = c11 - l10 * l10;
+  if (!(d11 > 0)) return false;
+  const double l11 = sqrt(d11);
+  const double l21 = (c21 - l20 * l10) / l11;
+  const double d22 = c22 - l20 * l20 - l21 * l21;
+  if (!(d22 > 0)) return false;
+  const double l22 = sqrt(d22);
+  const double i00 = 1 / l00, i11 = 1 / l11, i22 = 1 / l22;
+  const double i10 = -l10 * i00 * i11;
+  const double i21 = -l21 * i11 * i22;
+  const double i20 = -(l20 * i00 + l21 * i10) * i22;
+  Li[0] = i00; Li[1] = i10; Li[2] = i11; Li[3] = i20; Li[4] = i21; Li[5] = i22;
+  return true;
+}
+
+// ---------------------------------------------------------------- Jacobi scaling (iteration 0)
+// one thread per point: unscaled squared column norms.  Points complete locally; cameras and
+// the focal accumulate into red_dc (summed across ranks before ba_make_scale).
+__global__ __launch_bounds__(256) void ba_colnorms(BaDev d, int jacobi) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  double xn2 = 0, f2 = 0;
+  if (p < d.np) {
+    const double X[3] = {d.pts[3 * p], d.pts[3 * p + 1], d.pts[3 * p + 2]};
+    const double focal = *d.focal;
+    double np2[3] = {0, 0, 0};
+    for (int k = d.optr[p]; k < d.optr[p + 1]; ++k) {
+      const int c = d.ocam[k];
+      const double2 xy = d.oxy[k];
+      ObsLin o;
+      obs_linearize(d.camd + (size_t)CAMD * c, X, focal, xy.x, xy.y, nullptr, nullptr, 1.0, o);
+      if (jacobi) {
+        double* dc = red_dc(d) + 6 * c;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) atomic_add_f64(dc + j, o.Jc[j] * o.Jc[j] + o.Jc[6 + j] * o.Jc[6 + j]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) np2[j] += o.Jp[j] * o.Jp[j] + o.Jp[3 + j] * o.Jp[3 + j];
+        f2 += o.Jf[0] * o.Jf[0] + o.Jf[1] * o.Jf[1];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      d.scale_p[3 * p + j] = jacobi ? 1.0 / (1.0 + sqrt(np2[j])) : 1.0;
+      xn2 += X[j] * X[j];
+    }
+  }
+  // block reduce f2, xn2
+  __shared__ double sh[2][4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    f2 += __shfl_down(f2, o);
+    xn2 += __shfl_down(xn2, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = f2;
+    sh[1][threadIdx.x >> 6] = xn2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomic_add_f64(red_dc(d) + 6 * d.nc, sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
+    atomic_add_f64(red_sc(d) + 1, sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+  }
+}
+
+__global__ void ba_make_scale(BaDev d, int jacobi) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double* dc = red_dc(d);
+  if (i < 6 * d.nc) d.scale_c[i] = jacobi ? 1.0 / (1.0 + sqrt(dc[i])) : 1.0;
+  if (i == 6 * d.nc) *d.scale_f = jacobi ? 1.0 / (1.0 + sqrt(dc[i])) : 1.0;
+}
+
+// ---------------------------------------------------------------- linearise + Schur eliminate
+// items of a signature with n observations: (n+1)^2 half-blocks (a, b, h, kind)
+//   kind 0: rows 0..5 of T_a  x  rows 3h..3h+2 of T_b  -> S block (cam_a, cam_b), cols 3h..
+//   kind 1: T_a x border rows (t_f, u)                 -> S[:, focal], g
+//   kind 2: border x border                            -> S[focal][focal], g[focal]
+__host__ __device__ inline unsigned pack_item(int a, int b, int h, int kind) {
+  return (unsigned)a | ((unsigned)b << 8) | ((unsigned)h << 16) | ((unsigned)kind << 24);
+}
+
+template <int R>
+__global__ __launch_bounds__(64) void ba_eliminate(BaDev d, const Chunk* __restrict__ chunks,
+                                                   const int* __restrict__ chunk_ids,
+                                                   const int* __restrict__ sig_cams,
+                                                   const unsigned* __restrict__ items,
+                                                   const int* __restrict__ item_off, double radius,
+                                                   double lm_lo, double lm_hi, int rank) {
+  constexpr int NMAX = (R == 1) ? 7 : 10;
+  __shared__ __attribute__((aligned(16))) double s_cam[NMAX * CAMD];
+  __shared__ __attribute__((aligned(16))) double s_T[(NMAX + 1) * 18];
+  const Chunk ch = chunks[chunk_ids[blockIdx.x]];
+  const int lane = threadIdx.x;
+  const int n = ch.n;
+  const int* cams = sig_cams + ch.sig_off;
+  const int dim = d.dim, fo = 6 * d.nc;
+  const bool is_obs = lane < n;
+  const int mycam = cams[is_obs ? lane : 0];
+
+  // camera tables of this signature -> LDS
+  for (int i = lane; i < n * CAMD; i += 64) s_cam[i] = d.camd[(size_t)CAMD * cams[i / CAMD] + (i % CAMD)];
+  double sc[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) sc[j] = d.scale_c[6 * mycam + j];
+  const double sf = *d.scale_f, focal = *d.focal;
+  const int n_items = (n + 1) * (n + 1);
+  unsigned item[R];
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) {
+    const int ii = rr * 64 + lane;
+    item[rr] = ii < n_items ? items[item_off[n] + ii] : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+
+  double acc[R][18];
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+    for (int e = 0; e < 18; ++e) acc[rr][e] = 0.0;
+  double Hcc[21], Hcf[6], gc[6];
+#pragma unroll
+  for (int e = 0; e < 21; ++e) Hcc[e] = 0.0;
+#pragma unroll
+  for (int e = 0; e < 6; ++e) Hcf[e] = gc[e] = 0.0;
+  double Hff = 0, gf = 0, cost = 0, gmax = 0;
+  int nfail = 0;
+  const double* cd = s_cam + (is_obs ? lane : 0) * CAMD;
+
+  for (int pi = 0; pi < ch.cnt; ++pi) {
+    const int p = ch.p0 + pi;
+    const double X[3] = {d.pts[3 * p], d.pts[3 * p + 1], d.pts[3 * p + 2]};
+    const double sp[3] = {d.scale_p[3 * p], d.scale_p[3 * p + 1], d.scale_p[3 * p + 2]};
+    ObsLin o;
+    {
+      const int k = d.optr[p] + (is_obs ? lane : 0);
+      const double2 xy = d.oxy[k];
+      obs_linearize(cd, X, focal, xy.x, xy.y, sc, sp, sf, o);
+    }
+    const double live = is_obs ? 1.0 : 0.0;
+    // point block C = sum Jp^T Jp (lower: 00 10 11 20 21 22), gp = Jp^T r, wf = Jp^T Jf
+    double red[12];
+    red[0] = live * (o.Jp[0] * o.Jp[0] + o.Jp[3] * o.Jp[3]);
+    red[1] = live * (o.Jp[1] * o.Jp[0] + o.Jp[4] * o.Jp[3]);
+    red[2] = live * (o.Jp[1] * o.Jp[1] + o.Jp[4] * o.Jp[4]);
+    red[3] = live * (o.Jp[2] * o.Jp[0] + o.Jp[5] * o.Jp[3]);
+    red[4] = live * (o.Jp[2] * o.Jp[1] + o.Jp[5] * o.Jp[4]);
+    red[5] = live * (o.Jp[2] * o.Jp[2] + o.Jp[5] * o.Jp[5]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      red[6 + a] = live * (o.Jp[a] * o.r0 + o.Jp[3 + a] * o.r1);
+      red[9 + a] = live * (o.Jp[a] * o.Jf[0] + o.Jp[3 + a] * o.Jf[1]);
+    }
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) red[e] += __shfl_xor(red[e], off, 16);
+    }
+    // every lane of row 0 now holds the sums; broadcast to the whole wave
+#pragma unroll
+    for (int e = 0; e < 12; ++e) red[e] = __shfl(red[e], 0);
+    // LM damping of the point block: D^2 = clamp(diag) / radius
+    double C[6] = {red[0], red[1], red[2], red[3], red[4], red[5]};
+    const double dg0 = fmin(fmax(C[0], lm_lo), lm_hi), dg1 = fmin(fmax(C[2], lm_lo), lm_hi),
+                 dg2 = fmin(fmax(C[5], lm_lo), lm_hi);
+    C[0] += dg0 / radius;
+    C[2] += dg1 / radius;
+    C[5] += dg2 / radius;
+    double Li[6];
+    const bool pd = chol3_inv(C, Li);
+    if (!pd) {
+      ++nfail;
+      Li[0] = Li[1] = Li[2] = Li[3] = Li[4] = Li[5] = 0;
+    }
+    // gradient of the point (unscaled) for the gradient tolerance
+    gmax = fmax(gmax, fmax(fabs(red[6] / sp[0]), fmax(fabs(red[7] / sp[1]), fabs(red[8] / sp[2]))));
+    __syncthreads();  // previous point's pair reads are done
+    if (is_obs) {
+      // W = Jc^T Jp (6x3); T = W Li^T : T[i][k] = sum_{a<=k} W[i][a] Li[k][a]
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const double w0 = o.Jc[i] * o.Jp[0] + o.Jc[6 + i] * o.Jp[3];
+        const double w1 = o.Jc[i] * o.Jp[1] + o.Jc[6 + i] * o.Jp[4];
+        const double w2 = o.Jc[i] * o.Jp[2] + o.Jc[6 + i] * o.Jp[5];
+        s_T[lane * 18 + 3 * i + 0] = w0 * Li[0];
+        s_T[lane * 18 + 3 * i + 1] = w0 * Li[1] + w1 * Li[2];
+        s_T[lane * 18 + 3 * i + 2] = w0 * Li[3] + w1 * Li[4] + w2 * Li[5];
+      }
+      // F^T F, F^T b of this observation's camera
+      int e = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = i; j < 6; ++j) Hcc[e++] += o.Jc[i] * o.Jc[j] + o.Jc[6 + i] * o.Jc[6 + j];
+        Hcf[i] += o.Jc[i] * o.Jf[0] + o.Jc[6 + i] * o.Jf[1];
+        gc[i] += o.Jc[i] * o.r0 + o.Jc[6 + i] * o.r1;
+      }
+      Hff += o.Jf[0] * o.Jf[0] + o.Jf[1] * o.Jf[1];
+      gf += o.Jf[0] * o.r0 + o.Jf[1] * o.r1;
+      cost += o.r0 * o.r0 + o.r1 * o.r1;
+    }
+    if (lane == 0) {
+      // border rows: t_f = Li wf, u = Li gp
+      double* b = s_T + n * 18;
+      b[0] = Li[0] * red[9];
+      b[1] = Li[1] * red[9] + Li[2] * red[10];
+      b[2] = Li[3] * red[9] + Li[4] * red[10] + Li[5] * red[11];
+      b[3] = Li[0] * red[6];
+      b[4] = Li[1] * red[6] + Li[2] * red[7];
+      b[5] = Li[3] * red[6] + Li[4] * red[7] + Li[5] * red[8];
+#pragma unroll
+      for (int e2 = 6; e2 < 18; ++e2) b[e2] = 0.0;
+    }
+    __syncthreads();
+    // camera-pair Gram, accumulated in registers over the chunk
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+      const unsigned itx = item[rr];
+      const int a = itx & 0xFF, b = (itx >> 8) & 0xFF, h = (itx >> 16) & 0xFF;
+      const double* Ta = s_T + (itx == 0xFFFFFFFFu ? 0 : a) * 18;
+      const double* Tb = s_T + (itx == 0xFFFFFFFFu ? 0 : b) * 18 + 9 * (itx == 0xFFFFFFFFu ? 0 : h);
+      double tb[9];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) tb[e] = Tb[e];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const double t0 = Ta[3 * i], t1 = Ta[3 * i + 1], t2 = Ta[3 * i + 2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[rr][3 * i + j] += t0 * tb[3 * j] + t1 * tb[3 * j + 1] + t2 * tb[3 * j + 2];
+      }
+    }
+  }
+
+  // ---- flush: one f64 atomic per accumulator per chunk
+  double* S = red_S(d);
+  double* g = red_g(d);
+  double* gF = red_gF(d);
+  double* dc = red_dc(d);
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) {
+    const unsigned itx = item[rr];
+    if (itx == 0xFFFFFFFFu) continue;
+    const int a = itx & 0xFF, b = (itx >> 8) & 0xFF, h = (itx >> 16) & 0xFF, kind = itx >> 24;
+    if (kind == 0) {
+      const int r0 = 6 * cams[a], c0 = 6 * cams[b] + 3 * h;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (r0 + i <= c0 + j) atomic_add_f64(S + (size_t)(r0 + i) * dim + c0 + j, -acc[rr][3 * i + j]);
+    } else if (kind == 1) {
+      const int r0 = 6 * cams[a];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        atomic_add_f64(S + (size_t)(r0 + i) * dim + fo, -acc[rr][3 * i + 0]);
+        atomic_add_f64(g + r0 + i, -acc[rr][3 * i + 1]);
+      }
+    } else {
+      atomic_add_f64(S + (size_t)fo * dim + fo, -acc[rr][0]);
+      atomic_add_f64(g + fo, -acc[rr][1]);
+    }
+  }
+  if (is_obs) {
+    const int r0 = 6 * mycam;
+    int e = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+      for (int j = i; j < 6; ++j) {
+        atomic_add_f64(S + (size_t)(r0 + i) * dim + r0 + j, Hcc[e]);
+        if (j == i) atomic_add_f64(dc + r0 + i, Hcc[e]);
+        ++e;
+      }
+      atomic_add_f64(S + (size_t)(r0 + i) * dim + fo, Hcf[i]);
+      atomic_add_f64(g + r0 + i, gc[i]);
+      atomic_add_f64(gF + r0 + i, gc[i]);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    Hff += __shfl_down(Hff, off);
+    gf += __shfl_down(gf, off);
+    cost += __shfl_down(cost, off);
+  }
+  if (lane == 0) {
+    atomic_add_f64(S + (size_t)fo * dim + fo, Hff);
+    atomic_add_f64(dc + fo, Hff);
+    atomic_add_f64(g + fo, gf);
+    atomic_add_f64(gF + fo, gf);
+    double* scv = red_sc(d);
+    atomic_add_f64(scv + 0, cost);
+    if (nfail) atomic_add_f64(scv + 2, (double)nfail);
+    atomic_max_pos_f64(scv + SC + rank, gmax);
+  }
+}
+
+// Generic path: one wave per point; any observation count up to FB_MAXN, cameras in any order,
+// repeated cameras allowed.  Per-point atomics (no accumulation across points).
+__global__ __launch_bounds__(64) void ba_eliminate_generic(BaDev d, const int* __restrict__ plist, double radius,
+                                                           double lm_lo, double lm_hi, int rank) {
+  __shared__ __attribute__((aligned(16))) double s_T[(FB_MAXN + 1) * 18];
+  __shared__ int s_cam[FB_MAXN];
+  const int p = plist[blockIdx.x];
+  const int lane = threadIdx.x;
+  const int k0 = d.optr[p], n = d.optr[p + 1] - k0;
+  const int dim = d.dim, fo = 6 * d.nc;
+  const bool is_obs = lane < n;
+  const int k = k0 + (is_obs ? lane : 0);
+  const int mycam = d.ocam[k];
+  if (is_obs) s_cam[lane] = mycam;
+  const double X[3] = {d.pts[3 * p], d.pts[3 * p + 1], d.pts[3 * p + 2]};
+  const double sp[3] = {d.scale_p[3 * p], d.scale_p[3 * p + 1], d.scale_p[3 * p + 2]};
+  const double sf = *d.scale_f, focal = *d.focal;
+  ObsLin o;
+  {
+    const double2 xy = d.oxy[k];
+    obs_linearize(d.camd + (size_t)CAMD * mycam, X, focal, xy.x, xy.y, d.scale_c + 6 * mycam, sp, sf, o);
+  }
+  const double live = is_obs ? 1.0 : 0.0;
+  double red[12];
+  red[0] = live * (o.Jp[0] * o.Jp[0] + o.Jp[3] * o.Jp[3]);
+  red[1] = live * (o.Jp[1] * o.Jp[0] + o.Jp[4] * o.Jp[3]);
+  red[2] = live * (o.Jp[1] * o.Jp[1] + o.Jp[4] * o.Jp[4]);
+  red[3] = live * (o.Jp[2] * o.Jp[0] + o.Jp[5] * o.Jp[3]);
+  red[4] = live * (o.Jp[2] * o.Jp[1] + o.Jp[5] * o.Jp[4]);
+  red[5] = live * (o.Jp[2] * o.Jp[2] + o.Jp[5] * o.Jp[5]);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    red[6 + a] = live * (o.Jp[a] * o.r0 + o.Jp[3 + a] * o.r1);
+    red[9 + a] = live * (o.Jp[a] * o.Jf[0] + o.Jp[3 + a] * o.Jf[1]);
+  }
+#pragma unroll
+  for (int e = 0; e < 12; ++e) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) red[e] += __shfl_xor(red[e], off);
+  }
+  double C[6] = {red[0], red[1], red[2], red[3], red[4], red[5]};
+  C[0] += fmin(fmax(C[0], lm_lo), lm_hi) / radius;
+  C[2] += fmin(fmax(C[2], lm_lo), lm_hi) / radius;
+  C[5] += fmin(fmax(C[5], lm_lo), lm_hi) / radius;
+  double Li[6];
+  const bool pd = chol3_inv(C, Li);
+  if (!pd) Li[0] = Li[1] = Li[2] = Li[3] = Li[4] = Li[5] = 0;
+  double* S = red_S(d);
+  double* g = red_g(d);
+  double* gF = red_gF(d);
+  double* dc = red_dc(d);
+  double* scv = red_sc(d);
+  if (is_obs) {
+    const int r0 = 6 * mycam;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double w0 = o.Jc[i] * o.Jp[0] + o.Jc[6 + i] * o.Jp[3];
+      const double w1 = o.Jc[i] * o.Jp[1] + o.Jc[6 + i] * o.Jp[4];
+      const double w2 = o.Jc[i] * o.Jp[2] + o.Jc[6 + i] * o.Jp[5];
+      s_T[lane * 18 + 3 * i + 0] = w0 * Li[0];
+      s_T[lane * 18 + 3 * i + 1] = w0 * Li[1] + w1 * Li[2];
+      s_T[lane * 18 + 3 * i + 2] = w0 * Li[3] + w1 * Li[4] + w2 * Li[5];
+#pragma unroll
+      for (int j = i; j < 6; ++j) {
+        const double v = o.Jc[i] * o.Jc[j] + o.Jc[6 + i] * o.Jc[6 + j];
+        atomic_add_f64(S + (size_t)(r0 + i) * dim + r0 + j, v);
+        if (j == i) atomic_add_f64(dc + r0 + i, v);
+      }
+      atomic_add_f64(S + (size_t)(r0 + i) * dim + fo, o.Jc[i] * o.Jf[0] + o.Jc[6 + i] * o.Jf[1]);
+      const double gi = o.Jc[i] * o.r0 + o.Jc[6 + i] * o.r1;
+      atomic_add_f64(g + r0 + i, gi);
+      atomic_add_f64(gF + r0 + i, gi);
+    }
+  }
+  double Hff = live * (o.Jf[0] * o.Jf[0] + o.Jf[1] * o.Jf[1]);
+  double gf = live * (o.Jf[0] * o.r0 + o.Jf[1] * o.r1);
+  double cost = live * (o.r0 * o.r0 + o.r1 * o.r1);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    Hff += __shfl_down(Hff, off);
+    gf += __shfl_down(gf, off);
+    cost += __shfl_down(cost, off);
+  }
+  double tf[3], u[3];
+  tf[0] = Li[0] * red[9];
+  tf[1] = Li[1] * red[9] + Li[2] * red[10];
+  tf[2] = Li[3] * red[9] + Li[4] * red[10] + Li[5] * red[11];
+  u[0] = Li[0] * red[6];
+  u[1] = Li[1] * red[6] + Li[2] * red[7];
+  u[2] = Li[3] * red[6] + Li[4] * red[7] + Li[5] * red[8];
+  if (lane == 0) {
+    atomic_add_f64(S + (size_t)fo * dim + fo, Hff - (tf[0] * tf[0] + tf[1] * tf[1] + tf[2] * tf[2]));
+    atomic_add_f64(dc + fo, Hff);
+    atomic_add_f64(g + fo, gf - (tf[0] * u[0] + tf[1] * u[1] + tf[2] * u[2]));
+    atomic_add_f64(gF + fo, gf);
+    atomic_add_f64(scv + 0, cost);
+    if (!pd) atomic_add_f64(scv + 2, 1.0);
+    const double gm = fmax(fabs(red[6] / sp[0]), fmax(fabs(red[7] / sp[1]), fabs(red[8] / sp[2])));
+    atomic_max_pos_f64(scv + SC + rank, gm);
+  }
+  __syncthreads();
+  if (is_obs) {  // border: S[cam][focal] -= T t_f ; g[cam] -= T u
+    const int r0 = 6 * mycam;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double* T = s_T + lane * 18 + 3 * i;
+      atomic_add_f64(S + (size_t)(r0 + i) * dim + fo, -(T[0] * tf[0] + T[1] * tf[1] + T[2] * tf[2]));
+      atomic_add_f64(g + r0 + i, -(T[0] * u[0] + T[1] * u[1] + T[2] * u[2]));
+    }
+  }
+  const int npairs = n * (n + 1) / 2;
+  for (int q = lane; q < npairs; q += 64) {
+    // q -> (a <= b)
+    int a = 0, rem = q;
+    while (rem >= n - a) {
+      rem -= n - a;
+      ++a;
+    }
+    const int b = a + rem;
+    const int ca = s_cam[a], cb = s_cam[b];
+    const double* Ta = s_T + a * 18;
+    const double* Tb = s_T + b * 18;
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) {
+        const double v = Ta[3 * i] * Tb[3 * j] + Ta[3 * i + 1] * Tb[3 * j + 1] + Ta[3 * i + 2] * Tb[3 * j + 2];
+        if (ca < cb) {
+          atomic_add_f64(S + (size_t)(6 * ca + i) * dim + 6 * cb + j, -v);
+        } else if (ca > cb) {
+          atomic_add_f64(S + (size_t)(6 * cb + j) * dim + 6 * ca + i, -v);
+        } else if (a == b) {
+          if (i <= j) atomic_add_f64(S + (size_t)(6 * ca + i) * dim + 6 * ca + j, -v);
+        } else {  // same camera twice in one point: M + M^T, upper part
+          if (i <= j) atomic_add_f64(S + (size_t)(6 * ca + i) * dim + 6 * ca + j, -v);
+          if (j <= i) atomic_add_f64(S + (size_t)(6 * ca + j) * dim + 6 * ca + i, -v);
+        }
+      }
+  }
+}
+
+// LM diagonal of the camera/focal columns onto S; gradient max over those columns
+__global__ __launch_bounds__(1024) void ba_finalize(BaDev d, double radius, double lm_lo, double lm_hi, int world,
+                                                    int add_diag) {
+  __shared__ double sh[16];
+  double* S = red_S(d);
+  const double* gF = red_gF(d);
+  const double* dc = red_dc(d);
+  double* scv = red_sc(d);
+  double gm = 0;
+  for (int i = threadIdx.x; i < d.dim; i += blockDim.x) {
+    const double v = fmin(fmax(dc[i], lm_lo), lm_hi);
+    d.diag[i] = v;
+    if (add_diag) S[(size_t)i * d.dim + i] += v / radius;
+    const double s = i < 6 * d.nc ? d.scale_c[i] : *d.scale_f;
+    gm = fmax(gm, fabs(gF[i] / s));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_down(gm, o));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = gm;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) gm = fmax(gm, sh[w]);
+    for (int r = 0; r < world; ++r) gm = fmax(gm, scv[SC + r]);
+    scv[3] = gm;  // gradient max norm (unscaled), all parameter blocks, all ranks
+  }
+}
+
+// ---------------------------------------------------------------- dense Cholesky (f64)
+// A is the row-major upper triangle of S == column-major lower triangle: L(r,c) = A[c*ld + r].
+// The rhs is carried as an extra row: y[c] plays L(n, c).
+#define LA(r, c) A[(size_t)(c) * ld + (r)]
+
+// panel step: factor the NBxNB diagonal block (every block redundantly, in LDS), then solve the
+// 64-row tile this block owns against it.  Block 0 owns the diagonal write-back and the rhs row.
+__global__ __launch_bounds__(256) void chol_panel(double* __restrict__ A, double* __restrict__ y, int n, int ld,
+                                                  int k0, int* __restrict__ info) {
+  __shared__ double sD[NB][NB + 1];
+  __shared__ double sX[NB][NB + 1];
+  const int nb = min(NB, n - k0);
+  const int tid = threadIdx.x;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e % NB, c = e / NB;
+    sD[r][c] = (r < nb && c < nb && r >= c) ? LA(k0 + r, k0 + c) : (r == c ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  // right-looking factorisation of sD (lower)
+  for (int j = 0; j < nb; ++j) {
+    const double djj = sD[j][j];
+    __syncthreads();
+    if (!(djj > 0.0)) {
+      if (blockIdx.x == 0 && tid == 0) atomicExch(info, k0 + j + 1);
+      return;  // uniform: every thread read the same djj
+    }
+    const double dj = sqrt(djj);
+    if (tid == 0) sD[j][j] = dj;
+    for (int r = j + 1 + tid; r < nb; r += 256) sD[r][j] /= dj;
+    __syncthreads();
+    // trailing update of columns j+1.. : element (r,c), r >= c > j
+    const int m = nb - j - 1;
+    for (int e = tid; e < m * m; e += 256) {
+      const int r = j + 1 + e / m, c = j + 1 + e % m;
+      if (r >= c) sD[r][c] -= sD[r][j] * sD[c][j];
+    }
+    __syncthreads();
+  }
+  // this block's rows
+  int r0, nr;
+  const bool is_rhs = blockIdx.x == 0;
+  if (is_rhs) {
+    r0 = 0;
+    nr = 1;
+    for (int e = tid; e < nb * nb; e += 256) {
+      const int r = e % nb, c = e / nb;
+      if (r >= c) LA(k0 + r, k0 + c) = sD[r][c];
+    }
+  } else {
+    r0 = k0 + nb + (blockIdx.x - 1) * NB;
+    nr = min(NB, n - r0);
+  }
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e % NB, c = e / NB;
+    double v = 0.0;
+    if (r < nr && c < nb) v = is_rhs ? y[k0 + c] : LA(r0 + r, k0 + c);
+    sX[r][c] = v;
+  }
+  __syncthreads();
+  // X <- X L^-T : column by column
+  for (int j = 0; j < nb; ++j) {
+    const double dj = sD[j][j];
+    for (int r = tid; r < nr; r += 256) sX[r][j] /= dj;
+    __syncthreads();
+    const int m = nb - j - 1;
+    for (int e = tid; e < nr * m; e += 256) {
+      const int r = e % nr, c = j + 1 + e / nr;
+      sX[r][c] -= sX[r][j] * sD[c][j];
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e % NB, c = e / NB;
+    if (r < nr && c < nb) {
+      if (is_rhs)
+        y[k0 + c] = sX[r][c];
+      else
+        LA(r0 + r, k0 + c) = sX[r][c];
+    }
+  }
+}
+
+// trailing update with the panel of step k0: tile (tr >= tc) of the remaining matrix, and one
+// extra tile row for the rhs.  64x64 outputs, K = nb, 4x4 outputs per thread.
+__global__ __launch_bounds__(256) void chol_update(double* __restrict__ A, double* __restrict__ y, int n, int ld,
+                                                   int k0, int ntile) {
+  __shared__ double sR[NB][NB + 1];  // rows of the tile-row block   [row][k]
+  __shared__ double sC[NB][NB + 1];  // rows of the tile-col block   [col][k]
+  const int nb = min(NB, n - k0);
+  const int base = k0 + nb;
+  // decode blockIdx -> (tr, tc), tr in [0, ntile] (ntile = rhs row), tc <= min(tr, ntile-1)
+  int tr = 0, rem = blockIdx.x;
+  while (true) {
+    const int w = min(tr + 1, ntile);
+    if (rem < w) break;
+    rem -= w;
+    ++tr;
+  }
+  const int tc = rem;
+  const bool is_rhs = tr == ntile;
+  const int rr0 = base + tr * NB, cc0 = base + tc * NB;
+  const int nr = is_rhs ? 1 : min(NB, n - rr0), ncol = min(NB, n - cc0);
+  const int tid = threadIdx.x;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e % NB, k = e / NB;
+    double vr = 0.0, vc = 0.0;
+    if (k < nb) {
+      if (r < nr) vr = is_rhs ? y[k0 + k] : LA(rr0 + r, k0 + k);
+      if (r < ncol) vc = LA(cc0 + r, k0 + k);
+    }
+    sR[r][k] = vr;
+    sC[r][k] = vc;
+  }
+  __syncthreads();
+  const int tx = tid % 16, ty = tid / 16;  // outputs rows ty*4.., cols tx*4..
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+  for (int k = 0; k < nb; ++k) {
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = sR[ty * 4 + i][k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = sC[tx * 4 + j][k];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = ty * 4 + i, c = tx * 4 + j;
+      if (r < nr && c < ncol) {
+        if (is_rhs)
+          y[cc0 + c] -= acc[i][j];
+        else if (rr0 + r >= cc0 + c)
+          LA(rr0 + r, cc0 + c) -= acc[i][j];
+      }
+    }
+}
+
+// L^T z = y, blocked from the last panel up; single workgroup.
+__global__ __launch_bounds__(1024) void chol_backsolve(const double* __restrict__ A, double* __restrict__ y,
+                                                       double* __restrict__ z, int n, int ld) {
+  __shared__ double sD[NB][NB + 1];
+  __shared__ double sz[NB];
+  const int tid = threadIdx.x;
+  const int nblk = (n + NB - 1) / NB;
+  for (int kb = nblk - 1; kb >= 0; --kb) {
+    const int k0 = kb * NB, nb = min(NB, n - k0);
+    for (int e = tid; e < NB * NB; e += 1024) {
+      const int r = e % NB, c = e / NB;
+      sD[r][c] = (r < nb && c < nb && r >= c) ? LA(k0 + r, k0 + c) : 0.0;
+    }
+    __syncthreads();
+    if (tid < 64) {  // one wave: lane i owns unknown i of the block
+      double yi = tid < nb ? y[k0 + tid] : 0.0;
+      for (int j = nb - 1; j >= 0; --j) {
+        const double zj = __shfl(yi, j) / sD[j][j];
+        if (tid == j) yi = zj;
+        if (tid < j) yi -= sD[j][tid] * zj;
+      }
+      if (tid < nb) {
+        sz[tid] = yi;
+        z[k0 + tid] = yi;
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < k0; c += 1024) {
+      double acc = 0.0;
+      for (int j = 0; j < nb; ++j) acc += LA(k0 + j, c) * sz[j];
+      y[c] -= acc;
+    }
+    __syncthreads();
+  }
+}
+#undef LA
+
+// ---------------------------------------------------------------- step application
+// candidate cameras / focal: x + (-z)*scale, their tables, and the camera part of the norms
+__global__ void ba_cand_cams(BaDev d, const unsigned char* __restrict__ cam_used, int rank) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  double sn2 = 0, cn2 = 0;
+  if (c < d.nc) {
+    double cam[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const double dl = -d.z[6 * c + j] * d.scale_c[6 * c + j];
+      cam[j] = d.cams[6 * c + j] + dl;
+      d.cams_c[6 * c + j] = cam[j];
+      if (cam_used[c]) {
+        sn2 += dl * dl;
+        cn2 += cam[j] * cam[j];
+      }
+    }
+    cam_table(cam, d.camd_c + (size_t)CAMD * c, true);
+  }
+  if (c == d.nc) {
+    const double dl = -d.z[6 * d.nc] * (*d.scale_f);
+    const double f = *d.focal + dl;
+    *d.focal_c = f;
+    sn2 += dl * dl;
+    cn2 += f * f;
+  }
+  if (rank == 0 && (sn2 != 0 || cn2 != 0)) {
+    atomic_add_f64(d.red2 + 2, sn2);
+    atomic_add_f64(d.red2 + 3, cn2);
+  }
+}
+
+// per point: back-substitute, model cost change, candidate point + candidate cost
+__global__ __launch_bounds__(256) void ba_backsub(BaDev d, double radius, double lm_lo, double lm_hi) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  double mcc = 0, cost_c = 0, sn2 = 0, cn2 = 0;
+  if (p < d.np) {
+    const double X[3] = {d.pts[3 * p], d.pts[3 * p + 1], d.pts[3 * p + 2]};
+    const double sp[3] = {d.scale_p[3 * p], d.scale_p[3 * p + 1], d.scale_p[3 * p + 2]};
+    const double sf = *d.scale_f, focal = *d.focal, focal_c = *d.focal_c;
+    const double zf = d.z[6 * d.nc];
+    const int k0 = d.optr[p], k1 = d.optr[p + 1];
+    double C[6] = {0, 0, 0, 0, 0, 0}, e[3] = {0, 0, 0};
+    for (int k = k0; k < k1; ++k) {
+      const int c = d.ocam[k];
+      const double2 xy = d.oxy[k];
+      ObsLin o;
+      obs_linearize(d.camd + (size_t)CAMD * c, X, focal, xy.x, xy.y, d.scale_c + 6 * c, sp, sf, o);
+      double s0 = o.r0 - o.Jf[0] * zf, s1 = o.r1 - o.Jf[1] * zf;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const double zj = d.z[6 * c + j];
+        s0 -= o.Jc[j] * zj;
+        s1 -= o.Jc[6 + j] * zj;
+      }
+      C[0] += o.Jp[0] * o.Jp[0] + o.Jp[3] * o.Jp[3];
+      C[1] += o.Jp[1] * o.Jp[0] + o.Jp[4] * o.Jp[3];
+      C[2] += o.Jp[1] * o.Jp[1] + o.Jp[4] * o.Jp[4];
+      C[3] += o.Jp[2] * o.Jp[0] + o.Jp[5] * o.Jp[3];
+      C[4] += o.Jp[2] * o.Jp[1] + o.Jp[5] * o.Jp[4];
+      C[5] += o.Jp[2] * o.Jp[2] + o.Jp[5] * o.Jp[5];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) e[a] += o.Jp[a] * s0 + o.Jp[3 + a] * s1;
+    }
+    C[0] += fmin(fmax(C[0], lm_lo), lm_hi) / radius;
+    C[2] += fmin(fmax(C[2], lm_lo), lm_hi) / radius;
+    C[5] += fmin(fmax(C[5], lm_lo), lm_hi) / radius;
+    double Li[6];
+    if (!chol3_inv(C, Li)) Li[0] = Li[1] = Li[2] = Li[3] = Li[4] = Li[5] = 0;
+    // y = C^-1 e = Li^T (Li e); step = -y
+    const double t0 = Li[0] * e[0], t1 = Li[1] * e[0] + Li[2] * e[1], t2 = Li[3] * e[0] + Li[4] * e[1] + Li[5] * e[2];
+    const double stp[3] = {-(Li[0] * t0 + Li[1] * t1 + Li[3] * t2), -(Li[2] * t1 + Li[4] * t2), -(Li[5] * t2)};
+    double Xc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double dl = stp[j] * sp[j];
+      Xc[j] = X[j] + dl;
+      d.pts_c[3 * p + j] = Xc[j];
+      sn2 += dl * dl;
+      cn2 += Xc[j] * Xc[j];
+    }
+    for (int k = k0; k < k1; ++k) {
+      const int c = d.ocam[k];
+      const double2 xy = d.oxy[k];
+      ObsLin o;
+      obs_linearize(d.camd + (size_t)CAMD * c, X, focal, xy.x, xy.y, d.scale_c + 6 * c, sp, sf, o);
+      double m0 = -o.Jf[0] * zf, m1 = -o.Jf[1] * zf;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const double zj = d.z[6 * c + j];
+        m0 -= o.Jc[j] * zj;
+        m1 -= o.Jc[6 + j] * zj;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        m0 += o.Jp[j] * stp[j];
+        m1 += o.Jp[3 + j] * stp[j];
+      }
+      mcc += m0 * (o.r0 + m0 / 2.0) + m1 * (o.r1 + m1 / 2.0);
+      double r0, r1;
+      obs_residual(d.camd_c + (size_t)CAMD * c, Xc, focal_c, xy.x, xy.y, r0, r1);
+      cost_c += r0 * r0 + r1 * r1;
+    }
+  }
+  __shared__ double sh[4][4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mcc += __shfl_down(mcc, o);
+    cost_c += __shfl_down(cost_c, o);
+    sn2 += __shfl_down(sn2, o);
+    cn2 += __shfl_down(cn2, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    const int w = threadIdx.x >> 6;
+    sh[0][w] = mcc;
+    sh[1][w] = cost_c;
+    sh[2][w] = sn2;
+    sh[3][w] = cn2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomic_add_f64(d.red2 + 0, sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+    atomic_add_f64(d.red2 + 1, sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
+    atomic_add_f64(d.red2 + 2, sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3]);
+    atomic_add_f64(d.red2 + 3, sh[3][0] + sh[3][1] + sh[3][2] + sh[3][3]);
+  }
+}
+
+__global__ void ba_cam_norm(BaDev d, const unsigned char* __restrict__ cam_used, double* out) {
+  // ||x||^2 over used cameras + focal (single block)
+  double s = 0;
+  for (int i = threadIdx.x; i < 6 * d.nc; i += blockDim.x)
+    if (cam_used[i / 6]) s += d.cams[i] * d.cams[i];
+  if (threadIdx.x == 0) s += (*d.focal) * (*d.focal);
+  __shared__ double sh[16];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
+    *out = s;
+  }
+}
+
+}  // namespace
+
+// ================================================================= host side
+struct sfmhip_ba {
+  sfmhip_ctx* ctx = nullptr;
+  int nc = 0, np_in = 0, no_in = 0;  // as given
+  int np = 0, no = 0;                // with >= 1 observation, sorted order
+  int dim = 0;
+  BaDev d{};
+  std::vector<int> perm;  // sorted point -> input point
+  std::vector<unsigned char> h_cam_used;
+  unsigned char* d_cam_used = nullptr;
+  bool cam_used_known = false;
+  // plan
+  Chunk* d_chunks = nullptr;
+  int* d_chunk_ids[2] = {nullptr, nullptr};
+  int n_chunk_ids[2] = {0, 0};
+  int* d_sig_cams = nullptr;
+  unsigned* d_items = nullptr;
+  int* d_item_off = nullptr;
+  int* d_fb_points = nullptr;
+  int n_fb = 0;
+  // device storage owned
+  std::vector<void*> allocs;
+  size_t red_count = 0;
+  double* h_sc = nullptr;  // pinned: scalars read back per iteration
+  // comm
+  sfmhip_allreduce_fn allreduce = nullptr;
+  void* allreduce_user = nullptr;
+  int rank = 0, world = 1;
+  // state
+  bool scale_ready = false;
+  std::vector<double> h_pts_unused;  // input points without observations keep their values
+  std::vector<double> h_pts_in;
+  double x_norm = 0;
+  // timing
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  double t_acc[4] = {0, 0, 0, 0};
+  int launches = 0;
+};
+
+template <typename T>
+static int ba_alloc(sfmhip_ba* b, T** p, size_t n) {
+  SFM_TRY(sfm_dev_alloc(p, n));
+  b->allocs.push_back((void*)*p);
+  return SFMHIP_OK;
+}
+
+extern "C" void sfmhip_ba_default_opts(sfmhip_ba_opts* o) {
+  if (!o) return;
+  o->max_iterations = 500;
+  o->max_time_s = 10.0;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->initial_radius = 1e4;
+  o->max_radius = 1e16;
+  o->min_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->jacobi_scaling = 1;
+  o->max_consecutive_invalid = 5;
+  o->verbose = 0;
+}
+
+extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const int32_t* obs_cam,
+                                const int32_t* obs_pt, const double* obs_xy, sfmhip_ba** out) {
+  if (!ctx || !out || n_cam <= 0 || n_pt < 0 || n_obs < 0) return SFMHIP_ERR_ARG;
+  if (n_obs && (!obs_cam || !obs_pt || !obs_xy)) return SFMHIP_ERR_ARG;
+  for (int o = 0; o < n_obs; ++o)
+    if (obs_cam[o] < 0 || obs_cam[o] >= n_cam || obs_pt[o] < 0 || obs_pt[o] >= n_pt) return SFMHIP_ERR_ARG;
+  SFM_HIP_TRY(hipSetDevice(ctx->device));
+  sfmhip_ba* b = new sfmhip_ba();
+  b->ctx = ctx;
+  b->nc = n_cam;
+  b->np_in = n_pt;
+  b->no_in = n_obs;
+  b->dim = 6 * n_cam + 1;
+  // ---- group observations by point, ascending camera inside a point (std::map order of
+  //      Point3D::idxImage, reference src/BundleAdjustment.cpp:87)
+  std::vector<int> cnt(n_pt + 1, 0);
+  for (int o = 0; o < n_obs; ++o) cnt[obs_pt[o] + 1]++;
+  for (int p = 0; p < n_pt; ++p) cnt[p + 1] += cnt[p];
+  std::vector<int> slot(n_obs), fill(n_pt, 0);
+  for (int o = 0; o < n_obs; ++o) slot[cnt[obs_pt[o]] + fill[obs_pt[o]]++] = o;
+  for (int p = 0; p < n_pt; ++p)
+    std::stable_sort(slot.begin() + cnt[p], slot.begin() + cnt[p + 1], [&](int x, int y) { return obs_cam[x] < obs_cam[y]; });
+  // ---- signature sort of the points that have observations
+  std::vector<int> order;
+  for (int p = 0; p < n_pt; ++p) {
+    const int n = cnt[p + 1] - cnt[p];
+    if (n > FB_MAXN) {
+      delete b;
+      return SFMHIP_ERR_UNSUPPORTED;  // more than FB_MAXN observations of one point
+    }
+    if (n > 0) order.push_back(p);
+  }
+  auto sig_less = [&](int x, int y) {
+    const int nx = cnt[x + 1] - cnt[x], ny = cnt[y + 1] - cnt[y];
+    if (nx != ny) return nx < ny;
+    for (int k = 0; k < nx; ++k) {
+      const int cx = obs_cam[slot[cnt[x] + k]], cy = obs_cam[slot[cnt[y] + k]];
+      if (cx != cy) return cx < cy;
+    }
+    return false;
+  };
+  std::stable_sort(order.begin(), order.end(), sig_less);
+  b->np = (int)order.size();
+  b->perm = order;
+  std::vector<int> optr(b->np + 1, 0), ocam;
+  std::vector<double> oxy;
+  ocam.reserve(n_obs);
+  oxy.reserve(2 * (size_t)n_obs);
+  b->h_cam_used.assign(n_cam, 0);
+  for (int sp = 0; sp < b->np; ++sp) {
+    const int p = order[sp];
+    for (int k = cnt[p]; k < cnt[p + 1]; ++k) {
+      const int o = slot[k];
+      ocam.push_back(obs_cam[o]);
+      oxy.push_back(obs_xy[2 * o]);
+      oxy.push_back(obs_xy[2 * o + 1]);
+      b->h_cam_used[obs_cam[o]] = 1;
+    }
+    optr[sp + 1] = (int)ocam.size();
+  }
+  b->no = (int)ocam.size();
+  // ---- chunks: runs of equal signature, strictly ascending cameras, n <= 10 -> register path
+  std::vector<Chunk> chunks;
+  std::vector<int> ids[2], sig_cams, fb;
+  const int target = std::max(8, std::min(64, (b->np + 2047) / 2048));
+  for (int sp = 0; sp < b->np;) {
+    int e = sp + 1;
+    while (e < b->np && !sig_less(order[sp], order[e]) && !sig_less(order[e], order[sp])) ++e;
+    const int n = optr[sp + 1] - optr[sp];
+    bool strict = true;
+    for (int k = 1; k < n; ++k) strict = strict && ocam[optr[sp] + k - 1] < ocam[optr[sp] + k];
+    if (n <= 10 && strict) {
+      const int so = (int)sig_cams.size();
+      for (int k = 0; k < n; ++k) sig_cams.push_back(ocam[optr[sp] + k]);
+      for (int q = sp; q < e; q += target) {
+        ids[n <= 7 ? 0 : 1].push_back((int)chunks.size());
+        chunks.push_back(Chunk{so, n, q, std::min(target, e - q)});
+      }
+    } else {
+      for (int q = sp; q < e; ++q) fb.push_back(q);
+    }
+    sp = e;
+  }
+  // ---- half-block item tables per n
+  std::vector<unsigned> items;
+  std::vector<int> item_off(12, 0);
+  for (int n = 1; n <= 10; ++n) {
+    item_off[n] = (int)items.size();
+    for (int a = 0; a < n; ++a)
+      for (int bb = a; bb < n; ++bb)
+        for (int h = 0; h < 2; ++h) items.push_back(pack_item(a, bb, h, 0));
+    for (int a = 0; a < n; ++a) items.push_back(pack_item(a, n, 0, 1));
+    items.push_back(pack_item(n, n, 0, 2));
+  }
+  // ---- device storage
+  BaDev& d = b->d;
+  d.nc = n_cam;
+  d.np = b->np;
+  d.no = b->no;
+  d.dim = b->dim;
+  d.ld = b->dim;
+  int rc = SFMHIP_OK;
+  int *d_optr = nullptr, *d_ocam = nullptr;
+  double2* d_oxy = nullptr;
+  b->red_count = (size_t)b->dim * b->dim + 3 * (size_t)b->dim + SC + 64;
+#define BA_A(ptr, n)                         \
+  if (rc == SFMHIP_OK) rc = ba_alloc(b, &(ptr), (size_t)(n))
+  BA_A(d_optr, b->np + 1);
+  BA_A(d_ocam, b->no);
+  BA_A(d_oxy, b->no);
+  BA_A(d.cams, 6 * n_cam);
+  BA_A(d.pts, 3 * (size_t)b->np);
+  BA_A(d.focal, 1);
+  BA_A(d.camd, (size_t)CAMD * n_cam);
+  BA_A(d.cams_c, 6 * n_cam);
+  BA_A(d.pts_c, 3 * (size_t)b->np);
+  BA_A(d.focal_c, 1);
+  BA_A(d.camd_c, (size_t)CAMD * n_cam);
+  BA_A(d.scale_c, 6 * n_cam);
+  BA_A(d.scale_p, 3 * (size_t)b->np);
+  BA_A(d.scale_f, 1);
+  BA_A(d.diag, b->dim);
+  BA_A(d.red, b->red_count);
+  BA_A(d.z, b->dim);
+  BA_A(d.red2, 16);
+  BA_A(d.info, 1);
+  BA_A(b->d_cam_used, n_cam);
+  BA_A(b->d_chunks, chunks.size());
+  BA_A(b->d_chunk_ids[0], ids[0].size());
+  BA_A(b->d_chunk_ids[1], ids[1].size());
+  BA_A(b->d_sig_cams, sig_cams.size());
+  BA_A(b->d_items, items.size());
+  BA_A(b->d_item_off, item_off.size());
+  BA_A(b->d_fb_points, fb.size());
+#undef BA_A
+  if (rc != SFMHIP_OK) {
+    sfmhip_ba_destroy(b);
+    return rc;
+  }
+  d.optr = d_optr;
+  d.ocam = d_ocam;
+  d.oxy = d_oxy;
+  b->n_chunk_ids[0] = (int)ids[0].size();
+  b->n_chunk_ids[1] = (int)ids[1].size();
+  b->n_fb = (int)fb.size();
+  auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+    return bytes ? hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+  };
+  SFM_HIP_TRY(up(d_optr, optr.data(), optr.size() * 4));
+  SFM_HIP_TRY(up(d_ocam, ocam.data(), ocam.size() * 4));
+  SFM_HIP_TRY(up(d_oxy, oxy.data(), oxy.size() * 8));
+  SFM_HIP_TRY(up(b->d_cam_used, b->h_cam_used.data(), n_cam));
+  SFM_HIP_TRY(up(b->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk)));
+  SFM_HIP_TRY(up(b->d_chunk_ids[0], ids[0].data(), ids[0].size() * 4));
+  SFM_HIP_TRY(up(b->d_chunk_ids[1], ids[1].data(), ids[1].size() * 4));
+  SFM_HIP_TRY(up(b->d_sig_cams, sig_cams.data(), sig_cams.size() * 4));
+  SFM_HIP_TRY(up(b->d_items, items.data(), items.size() * 4));
+  SFM_HIP_TRY(up(b->d_item_off, item_off.data(), item_off.size() * 4));
+  SFM_HIP_TRY(up(b->d_fb_points, fb.data(), fb.size() * 4));
+  SFM_HIP_TRY(hipHostMalloc((void**)&b->h_sc, sizeof(double) * (SC + 64 + 16), hipHostMallocDefault));
+  for (auto& e : b->ev) SFM_HIP_TRY(hipEventCreate(&e));
+  b->h_pts_in.assign(3 * (size_t)n_pt, 0.0);
+  *out = b;
+  return SFMHIP_OK;
+}
+
+extern "C" int sfmhip_ba_set_allreduce(sfmhip_ba* b, sfmhip_allreduce_fn fn, void* user, int rank, int world) {
+  if (!b || world < 1 || rank < 0 || rank >= world || world > 64) return SFMHIP_ERR_ARG;
+  if (world > 1 && !fn) return SFMHIP_ERR_ARG;
+  b->allreduce = fn;
+  b->allreduce_user = user;
+  b->rank = rank;
+  b->world = world;
+  return SFMHIP_OK;
+}
+
+extern "C" int sfmhip_ba_set_params(sfmhip_ba* b, const double* cams6, const double* pts3, double focal) {
+  if (!b || !cams6 || (!pts3 && b->np_in)) return SFMHIP_ERR_ARG;
+  SFM_HIP_TRY(hipSetDevice(b->ctx->device));
+  hipStream_t st = b->ctx->stream;
+  if (b->np_in) memcpy(b->h_pts_in.data(), pts3, sizeof(double) * 3 * (size_t)b->np_in);
+  std::vector<double> sorted(3 * (size_t)std::max(b->np, 1));
+  for (int sp = 0; sp < b->np; ++sp)
+    for (int j = 0; j < 3; ++j) sorted[3 * (size_t)sp + j] = pts3[3 * (size_t)b->perm[sp] + j];
+  SFM_HIP_TRY(hipMemcpyAsync(b->d.cams, cams6, sizeof(double) * 6 * b->nc, hipMemcpyHostToDevice, st));
+  if (b->np) SFM_HIP_TRY(hipMemcpyAsync(b->d.pts, sorted.data(), sizeof(double) * 3 * (size_t)b->np, hipMemcpyHostToDevice, st));
+  SFM_HIP_TRY(hipMemcpyAsync(b->d.focal, &focal, sizeof(double), hipMemcpyHostToDevice, st));
+  SFM_HIP_TRY(hipStreamSynchronize(st));
+  b->scale_ready = false;
+  return SFMHIP_OK;
+}
+
+extern "C" int sfmhip_ba_get_params(sfmhip_ba* b, double* cams6, double* pts3, double* focal) {
+  if (!b) return SFMHIP_ERR_ARG;
+  SFM_HIP_TRY(hipSetDevice(b->ctx->device));
+  hipStream_t st = b->ctx->stream;
+  std::vector<double> sorted(3 * (size_t)std::max(b->np, 1));
+  if (cams6) SFM_HIP_TRY(hipMemcpyAsync(cams6, b->d.cams, sizeof(double) * 6 * b->nc, hipMemcpyDeviceToHost, st));
+  if (pts3 && b->np) SFM_HIP_TRY(hipMemcpyAsync(sorted.data(), b->d.pts, sizeof(double) * 3 * (size_t)b->np, hipMemcpyDeviceToHost, st));
+  if (focal) SFM_HIP_TRY(hipMemcpyAsync(focal, b->d.focal, sizeof(double), hipMemcpyDeviceToHost, st));
+  SFM_HIP_TRY(hipStreamSynchronize(st));
+  if (pts3) {
+    memcpy(pts3, b->h_pts_in.data(), sizeof(double) * 3 * (size_t)b->np_in);  // points without observations
+    for (int sp = 0; sp < b->np; ++sp)
+      for (int j = 0; j < 3; ++j) pts3[3 * (size_t)b->perm[sp] + j] = sorted[3 * (size_t)sp + j];
+  }
+  return SFMHIP_OK;
+}
+
+// -------- building blocks of one LM iteration (all asynchronous on the context stream)
+static int ba_allreduce(sfmhip_ba* b, double* buf, size_t count) {
+  if (b->world <= 1) return SFMHIP_OK;
+  const int rc = b->allreduce(buf, count, b->allreduce_user);
+  return rc == 0 ? SFMHIP_OK : SFMHIP_ERR_COMM;
+}
+
+static int ba_prepare_scale(sfmhip_ba* b, int jacobi) {
+  hipStream_t st = b->ctx->stream;
+  BaDev& d = b->d;
+  const size_t tail = (size_t)b->dim * b->dim + 2 * (size_t)b->dim;  // dc | sc
+  SFM_HIP_TRY(hipMemsetAsync(d.red + tail, 0, sizeof(double) * ((size_t)b->dim + SC + 64), st));
+  hipLaunchKernelGGL(ba_cam_prep, dim3((b->nc + 63) / 64), dim3(64), 0, st, d.cams, d.camd, b->nc, 1);
+  if (b->np) hipLaunchKernelGGL(ba_colnorms, dim3((b->np + 255) / 256), dim3(256), 0, st, d, jacobi);
+  SFM_HIP_TRY(hipGetLastError());
+  SFM_TRY(ba_allreduce(b, d.red + tail, (size_t)b->dim + SC));
+  hipLaunchKernelGGL(ba_make_scale, dim3((b->dim + 255) / 256), dim3(256), 0, st, d, jacobi);
+  SFM_HIP_TRY(hipGetLastError());
+  // cameras observed by any rank: nonzero translation-column norm
+  std::vector<double> dc(b->dim + SC);
+  SFM_HIP_TRY(hipMemcpyAsync(dc.data(), d.red + tail, sizeof(double) * (b->dim + SC), hipMemcpyDeviceToHost, st));
+  SFM_HIP_TRY(hipStreamSynchronize(st));
+  if (jacobi || b->world > 1) {
+    if (jacobi)
+      for (int c = 0; c < b->nc; ++c) b->h_cam_used[c] = dc[6 * c + 3] > 0 ? 1 : 0;
+    SFM_HIP_TRY(hipMemcpyAsync(b->d_cam_used, b->h_cam_used.data(), b->nc, hipMemcpyHostToDevice, st));
+  }
+  const double pts_n2 = dc[b->dim + 1];
+  double* tmp = d.red2 + 8;
+  hipLaunchKernelGGL(ba_cam_norm, dim3(1), dim3(256), 0, st, d, b->d_cam_used, tmp);
+  double cam_n2 = 0;
+  SFM_HIP_TRY(hipMemcpyAsync(&cam_n2, tmp, sizeof(double), hipMemcpyDeviceToHost, st));
+  SFM_HIP_TRY(hipStreamSynchronize(st));
+  b->x_norm = std::sqrt(pts_n2 + cam_n2);
+  b->scale_ready = true;
+  return SFMHIP_OK;
+}
+
+// linearise at the current x + eliminate with `radius`; leaves [S|g|gF|dc|sc] summed over ranks
+static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_opts* o, bool add_diag) {
+  hipStream_t st = b->ctx->stream;
+  BaDev& d = b->d;
+  SFM_HIP_TRY(hipEventRecord(b->ev[0], st));
+  SFM_HIP_TRY(hipMemsetAsync(d.red, 0, sizeof(double) * b->red_count, st));
+  hipLaunchKernelGGL(ba_cam_prep, dim3((b->nc + 63) / 64), dim3(64), 0, st, d.cams, d.camd, b->nc, 1);
+  if (b->n_chunk_ids[0])
+    hipLaunchKernelGGL((ba_eliminate<1>), dim3(b->n_chunk_ids[0]), dim3(64), 0, st, d, b->d_chunks, b->d_chunk_ids[0],
+                       b->d_sig_cams, b->d_items, b->d_item_off, radius, o->min_lm_diagonal, o->max_lm_diagonal, b->rank);
+  if (b->n_chunk_ids[1])
+    hipLaunchKernelGGL((ba_eliminate<2>), dim3(b->n_chunk_ids[1]), dim3(64), 0, st, d, b->d_chunks, b->d_chunk_ids[1],
+                       b->d_sig_cams, b->d_items, b->d_item_off, radius, o->min_lm_diagonal, o->max_lm_diagonal, b->rank);
+  if (b->n_fb)
+    hipLaunchKernelGGL(ba_eliminate_generic, dim3(b->n_fb), dim3(64), 0, st, d, b->d_fb_points, radius,
+                       o->min_lm_diagonal, o->max_lm_diagonal, b->rank);
+  SFM_HIP_TRY(hipGetLastError());
+  b->launches += 2 + (b->n_chunk_ids[0] > 0) + (b->n_chunk_ids[1] > 0) + (b->n_fb > 0);
+  SFM_HIP_TRY(hipEventRecord(b->ev[1], st));
+  SFM_TRY(ba_allreduce(b, d.red, (size_t)b->dim * b->dim + 3 * (size_t)b->dim + SC + b->world));
+  SFM_HIP_TRY(hipEventRecord(b->ev[2], st));
+  hipLaunchKernelGGL(ba_finalize, dim3(1), dim3(1024), 0, st, d, radius, o->min_lm_diagonal, o->max_lm_diagonal,
+                     b->world, add_diag ? 1 : 0);
+  SFM_HIP_TRY(hipGetLastError());
+  b->launches += 1;
+  return SFMHIP_OK;
+}
+
+static int ba_reduced_solve(sfmhip_ba* b) {
+  hipStream_t st = b->ctx->stream;
+  BaDev& d = b->d;
+  const int n = b->dim;
+  double* A = d.red;
+  double* y = d.red + (size_t)n * n;  // g becomes y = L^-1 g
+  SFM_HIP_TRY(hipMemsetAsync(d.info, 0, sizeof(int), st));
+  for (int k0 = 0; k0 < n; k0 += NB) {
+    const int nb = std::min(NB, n - k0);
+    const int rem = n - k0 - nb;
+    const int ntile = (rem + NB - 1) / NB;
+    hipLaunchKernelGGL(chol_panel, dim3(1 + ntile), dim3(256), 0, st, A, y, n, d.ld, k0, d.info);
+    // tiles (tr>=tc) plus the rhs tile row
+    const int nblk = ntile * (ntile + 1) / 2 + ntile;
+    if (nblk > 0) hipLaunchKernelGGL(chol_update, dim3(nblk), dim3(256), 0, st, A, y, n, d.ld, k0, ntile);
+    b->launches += 1 + (nblk > 0);
+  }
+  hipLaunchKernelGGL(chol_backsolve, dim3(1), dim3(1024), 0, st, A, y, d.z, n, d.ld);
+  SFM_HIP_TRY(hipGetLastError());
+  b->launches += 1;
+  return SFMHIP_OK;
+}
+
+static int ba_step_eval(sfmhip_ba* b, double radius, const sfmhip_ba_opts* o) {
+  hipStream_t st = b->ctx->stream;
+  BaDev& d = b->d;
+  SFM_HIP_TRY(hipMemsetAsync(d.red2, 0, sizeof(double) * 8, st));
+  hipLaunchKernelGGL(ba_cand_cams, dim3((b->nc + 1 + 63) / 64), dim3(64), 0, st, d, b->d_cam_used, b->rank);
+  if (b->np)
+    hipLaunchKernelGGL(ba_backsub, dim3((b->np + 255) / 256), dim3(256), 0, st, d, radius, o->min_lm_diagonal,
+                       o->max_lm_diagonal);
+  SFM_HIP_TRY(hipGetLastError());
+  b->launches += 2;
+  SFM_TRY(ba_allreduce(b, d.red2, 8));
+  return SFMHIP_OK;
+}
+
+static void ba_swap_candidate(sfmhip_ba* b) {
+  std::swap(b->d.cams, b->d.cams_c);
+  std::swap(b->d.pts, b->d.pts_c);
+  std::swap(b->d.focal, b->d.focal_c);
+  std::swap(b->d.camd, b->d.camd_c);
+}
+
+struct IterScalars {
+  double cost, nfail, gmax;           // from the eliminate pass (at x)
+  double cost_c, mcc, step_n2, cand_n2;  // from the step evaluation
+  int info;
+};
+
+static int ba_read_scalars(sfmhip_ba* b, IterScalars* s, bool with_step) {
+  hipStream_t st = b->ctx->stream;
+  BaDev& d = b->d;
+  const size_t sc_off = (size_t)b->dim * b->dim + 3 * (size_t)b->dim;
+  SFM_HIP_TRY(hipMemcpyAsync(b->h_sc, d.red + sc_off, sizeof(double) * SC, hipMemcpyDeviceToHost, st));
+  if (with_step) {
+    SFM_HIP_TRY(hipMemcpyAsync(b->h_sc + SC, d.red2, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
+    SFM_HIP_TRY(hipMemcpyAsync(b->h_sc + SC + 8, d.info, sizeof(int), hipMemcpyDeviceToHost, st));
+  }
+  SFM_HIP_TRY(hipStreamSynchronize(st));
+  s->cost = 0.5 * b->h_sc[0];
+  s->nfail = b->h_sc[2];
+  s->gmax = b->h_sc[3];
+  if (with_step) {
+    s->cost_c = 0.5 * b->h_sc[SC + 0];
+    s->mcc = -b->h_sc[SC + 1];
+    s->step_n2 = b->h_sc[SC + 2];
+    s->cand_n2 = b->h_sc[SC + 3];
+    memcpy(&s->info, b->h_sc + SC + 8, sizeof(int));
+  }
+  return SFMHIP_OK;
+}
+
+static void ba_acc_timing(sfmhip_ba* b) {
+  float ms;
+  if (hipEventElapsedTime(&ms, b->ev[0], b->ev[1]) == hipSuccess) b->t_acc[0] += ms * 1e-3;
+  if (hipEventElapsedTime(&ms, b->ev[1], b->ev[2]) == hipSuccess) b->t_acc[1] += ms * 1e-3;
+  if (hipEventElapsedTime(&ms, b->ev[2], b->ev[3]) == hipSuccess) b->t_acc[2] += ms * 1e-3;
+  if (hipEventElapsedTime(&ms, b->ev[3], b->ev[4]) == hipSuccess) b->t_acc[3] += ms * 1e-3;
+}
+
+// TrustRegionMinimizer::Minimize (Ceres 1.13) + LevenbergMarquardtStrategy, host control loop.
+static int ba_minimize(sfmhip_ba* b, const sfmhip_ba_opts* o, sfmhip_ba_summary* sum, bool timing_only, int timing_iters) {
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
+  auto elapsed = [&]() { return std::chrono::duration<double>(clk::now() - t0).count(); };
+  hipStream_t st = b->ctx->stream;
+  SFM_HIP_TRY(hipSetDevice(b->ctx->device));
+  for (double& t : b->t_acc) t = 0;
+  b->launches = 0;
+  SFM_TRY(ba_prepare_scale(b, o->jacobi_scaling));
+  double radius = o->initial_radius, decrease_factor = 2.0;
+  int invalid = 0, iter = 0, nsucc = 0, term = SFMHIP_BA_NO_CONVERGENCE;
+  double x_norm = b->x_norm, cost = 0, gmax = 0;
+  bool have_lin = false;  // [S|g] of the current (x, radius) already on the device
+  IterScalars sc{};
+  // iteration 0: cost + gradient at x0 (the same pass also forms the first reduced system)
+  SFM_TRY(ba_linearize_eliminate(b, radius, o, true));
+  SFM_TRY(ba_read_scalars(b, &sc, false));
+  cost = sc.cost;
+  gmax = sc.gmax;
+  have_lin = true;
+  sum->initial_cost = cost;
+  if (!timing_only && gmax <= o->gradient_tolerance) {
+    term = SFMHIP_BA_CONVERGENCE;
+    goto done;
+  }
+  for (;;) {
+    if (timing_only) {
+      if (iter >= timing_iters) break;
+    } else {
+      if (iter >= o->max_iterations) break;
+      if (o->max_time_s > 0 && elapsed() >= o->max_time_s) break;
+      if (radius < o->min_radius) {
+        term = SFMHIP_BA_CONVERGENCE;
+        break;
+      }
+    }
+    ++iter;
+    if (!have_lin) SFM_TRY(ba_linearize_eliminate(b, radius, o, true));
+    have_lin = false;
+    SFM_TRY(ba_reduced_solve(b));
+    SFM_HIP_TRY(hipEventRecord(b->ev[3], st));
+    SFM_TRY(ba_step_eval(b, radius, o));
+    SFM_HIP_TRY(hipEventRecord(b->ev[4], st));
+    SFM_TRY(ba_read_scalars(b, &sc, true));
+    ba_acc_timing(b);
+    const bool finite = std::isfinite(sc.step_n2) && std::isfinite(sc.mcc) && std::isfinite(sc.cost_c);
+    const bool bad = sc.info != 0 || sc.nfail > 0 || !finite;
+    if (bad || !(sc.mcc > 0.0)) {  // HandleInvalidStep
+      if (++invalid >= o->max_consecutive_invalid && !timing_only) {
+        term = SFMHIP_BA_FAILURE;
+        break;
+      }
+      radius /= decrease_factor;
+      decrease_factor *= 2.0;
+      if (o->verbose) fprintf(stderr, "[sfmhip-ba] it %d invalid step (info %d), radius %.3e\n", iter, sc.info, radius);
+      continue;
+    }
+    invalid = 0;
+    const double step_norm = std::sqrt(sc.step_n2);
+    if (!timing_only) {
+      if (step_norm <= o->parameter_tolerance * (x_norm + o->parameter_tolerance)) {
+        term = SFMHIP_BA_CONVERGENCE;
+        break;
+      }
+      if (std::fabs(cost - sc.cost_c) <= o->function_tolerance * cost) {
+        term = SFMHIP_BA_CONVERGENCE;
+        break;
+      }
+    }
+    const double rho = (cost - sc.cost_c) / sc.mcc;
+    if (o->verbose)
+      fprintf(stderr, "[sfmhip-ba] it %d cost %.9e -> %.9e rho %.3e radius %.3e |step| %.3e\n", iter, cost, sc.cost_c,
+              rho, radius, step_norm);
+    if (rho > o->min_relative_decrease) {  // HandleSuccessfulStep
+      ba_swap_candidate(b);
+      x_norm = std::sqrt(sc.cand_n2);
+      ++nsucc;
+      const double q = 2.0 * rho - 1.0;
+      radius = radius / std::fmax(1.0 / 3.0, 1.0 - q * q * q);
+      radius = std::fmin(o->max_radius, radius);
+      decrease_factor = 2.0;
+      // re-linearise at the new x; with the new radius this is also the next reduced system
+      SFM_TRY(ba_linearize_eliminate(b, radius, o, true));
+      SFM_TRY(ba_read_scalars(b, &sc, false));
+      cost = sc.cost;
+      gmax = sc.gmax;
+      have_lin = true;
+      if (!timing_only && gmax <= o->gradient_tolerance) {
+        term = SFMHIP_BA_CONVERGENCE;
+        break;
+      }
+    } else {  // HandleUnsuccessfulStep
+      radius /= decrease_factor;
+      decrease_factor *= 2.0;
+    }
+  }
+done:
+  b->x_norm = x_norm;
+  sum->termination = term;
+  sum->iterations = iter;
+  sum->successful_steps = nsucc;
+  sum->final_cost = cost;
+  sum->final_radius = radius;
+  sum->gradient_max_norm = gmax;
+  sum->time_s = elapsed();
+  return SFMHIP_OK;
+}
+
+extern "C" int sfmhip_ba_run(sfmhip_ba* b, const sfmhip_ba_opts* opts, sfmhip_ba_summary* summary) {
+  if (!b) return SFMHIP_ERR_ARG;
+  sfmhip_ba_opts od;
+  if (!opts) {
+    sfmhip_ba_default_opts(&od);
+    opts = &od;
+  }
+  sfmhip_ba_summary s;
+  memset(&s, 0, sizeof s);
+  const int rc = ba_minimize(b, opts, &s, false, 0);
+  if (summary) *summary = s;
+  return rc;
+}
+
+extern "C" int sfmhip_ba_iterate(sfmhip_ba* b, int iters, sfmhip_ba_summary* summary) {
+  if (!b || iters < 0) return SFMHIP_ERR_ARG;
+  sfmhip_ba_opts o;
+  sfmhip_ba_default_opts(&o);
+  sfmhip_ba_summary s;
+  memset(&s, 0, sizeof s);
+  const int rc = ba_minimize(b, &o, &s, true, iters);
+  if (summary) *summary = s;
+  return rc;
+}
+
+extern "C" int sfmhip_ba_reduced_system(sfmhip_ba* b, double radius, double* S, double* g, double* cost) {
+  if (!b || !(radius > 0)) return SFMHIP_ERR_ARG;
+  SFM_HIP_TRY(hipSetDevice(b->ctx->device));
+  sfmhip_ba_opts o;
+  sfmhip_ba_default_opts(&o);
+  if (!b->scale_ready) SFM_TRY(ba_prepare_scale(b, o.jacobi_scaling));
+  // this rank's points only: no all-reduce, and the camera/focal LM diagonal (a global
+  // quantity) is added only when there is a single rank
+  const int world = b->world;
+  b->world = 1;
+  int rc = ba_linearize_eliminate(b, radius, &o, world == 1);
+  b->world = world;
+  SFM_TRY(rc);
+  hipStream_t st = b->ctx->stream;
+  const int n = b->dim;
+  if (S) {
+    SFM_HIP_TRY(hipMemcpyAsync(S, b->d.red, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, st));
+  }
+  if (g) SFM_HIP_TRY(hipMemcpyAsync(g, b->d.red + (size_t)n * n, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  double sc0 = 0;
+  SFM_HIP_TRY(hipMemcpyAsync(&sc0, b->d.red + (size_t)n * n + 3 * (size_t)n, sizeof(double), hipMemcpyDeviceToHost, st));
+  SFM_HIP_TRY(hipStreamSynchronize(st));
+  if (S)
+    for (int i = 0; i < n; ++i)
+      for (int j = i + 1; j < n; ++j) S[(size_t)j * n + i] = S[(size_t)i * n + j];
+  if (cost) *cost = 0.5 * sc0;
+  return SFMHIP_OK;
+}
+
+extern "C" int sfmhip_ba_last_timing(sfmhip_ba* b, double seconds[4], int* launches) {
+  if (!b || !seconds) return SFMHIP_ERR_ARG;
+  for (int i = 0; i < 4; ++i) seconds[i] = b->t_acc[i];
+  if (launches) *launches = b->launches;
+  return SFMHIP_OK;
+}
+
+extern "C" void sfmhip_ba_destroy(sfmhip_ba* b) {
+  if (!b) return;
+  hipSetDevice(b->ctx->device);
+  for (void* p : b->allocs) hipFree(p);
+  if (b->h_sc) hipHostFree(b->h_sc);
+  for (auto& e : b->ev)
+    if (e) hipEventDestroy(e);
+  delete b;
+}
+
+extern "C" int sfmhip_ba_solve(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, double* cams6, double* pts3,
+                               double* focal, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
+                               const sfmhip_ba_opts* opts, sfmhip_ba_summary* summary) {
+  if (!ctx || !cams6 || !focal) return SFMHIP_ERR_ARG;
+  sfmhip_ba* b = nullptr;
+  int rc = sfmhip_ba_create(ctx, n_cam, n_pt, n_obs, obs_cam, obs_pt, obs_xy, &b);
+  if (rc == SFMHIP_OK) rc = sfmhip_ba_set_params(b, cams6, pts3, *focal);
+  if (rc == SFMHIP_OK) rc = sfmhip_ba_run(b, opts, summary);
+  if (rc == SFMHIP_OK) rc = sfmhip_ba_get_params(b, cams6, pts3, focal);
+  sfmhip_ba_destroy(b);
+  return rc;
+}

@@ -1,0 +1,49 @@
+// common.h -- context object and error plumbing shared by the HIP translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/sfmhip.h"
+
+extern thread_local int g_sfmhip_last_hip_error;
+
+#define SFM_HIP_TRY(expr)                                                              \
+  do {                                                                                 \
+    hipError_t e__ = (expr);                                                           \
+    if (e__ != hipSuccess) {                                                           \
+      g_sfmhip_last_hip_error = (int)e__;                                              \
+      fprintf(stderr, "[sfmhip] %s:%d %s -> %s\n", __FILE__, __LINE__, #expr,          \
+              hipGetErrorString(e__));                                                 \
+      return SFMHIP_ERR_HIP;                                                           \
+    }                                                                                  \
+  } while (0)
+
+#define SFM_TRY(expr)            \
+  do {                           \
+    int rc__ = (expr);           \
+    if (rc__ != SFMHIP_OK) return rc__; \
+  } while (0)
+
+struct sfmhip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int n_cu = 0;
+  // reusable pinned + device scratch for the one-shot host-pointer entry points
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
+};
+
+int sfm_ctx_pinned(sfmhip_ctx* ctx, size_t bytes, void** out);
+
+template <typename T>
+static inline int sfm_dev_alloc(T** p, size_t n) {
+  void* v = nullptr;
+  hipError_t e = hipMalloc(&v, (n ? n : 1) * sizeof(T));
+  if (e != hipSuccess) {
+    g_sfmhip_last_hip_error = (int)e;
+    return SFMHIP_ERR_ALLOC;
+  }
+  *p = (T*)v;
+  return SFMHIP_OK;
+}

@@ -1,0 +1,86 @@
+// context.hip -- sfmhip context lifetime and error strings (include/sfmhip.h).
+#include "common.h"
+#include <string.h>
+
+thread_local int g_sfmhip_last_hip_error = 0;
+
+static int init_common(int device, hipStream_t stream, bool own, sfmhip_ctx** out) {
+  if (!out) return SFMHIP_ERR_ARG;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_sfmhip_last_hip_error = (int)e;
+    return SFMHIP_ERR_NO_DEVICE;  // no CPU fallback exists behind this ABI
+  }
+  if (device < 0 || device >= n) return SFMHIP_ERR_ARG;
+  SFM_HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  SFM_HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    fprintf(stderr, "[sfmhip] device %d is %s; this library ships gfx950 code objects only\n", device,
+            prop.gcnArchName);
+    return SFMHIP_ERR_UNSUPPORTED;
+  }
+  sfmhip_ctx* c = new sfmhip_ctx();
+  c->device = device;
+  c->n_cu = prop.multiProcessorCount;
+  if (own) {
+    SFM_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  } else {
+    c->stream = stream;
+  }
+  *out = c;
+  return SFMHIP_OK;
+}
+
+extern "C" int sfmhip_init(int device, sfmhip_ctx** out) { return init_common(device, nullptr, true, out); }
+
+extern "C" int sfmhip_init_on_stream(int device, void* hip_stream, sfmhip_ctx** out) {
+  return init_common(device, (hipStream_t)hip_stream, false, out);
+}
+
+extern "C" void sfmhip_shutdown(sfmhip_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  if (ctx->pinned) hipHostFree(ctx->pinned);
+  if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" int sfmhip_synchronize(sfmhip_ctx* ctx) {
+  if (!ctx) return SFMHIP_ERR_ARG;
+  SFM_HIP_TRY(hipSetDevice(ctx->device));
+  SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return SFMHIP_OK;
+}
+
+int sfm_ctx_pinned(sfmhip_ctx* ctx, size_t bytes, void** out) {
+  if (ctx->pinned_bytes < bytes) {
+    if (ctx->pinned) hipHostFree(ctx->pinned);
+    ctx->pinned = nullptr;
+    ctx->pinned_bytes = 0;
+    SFM_HIP_TRY(hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault));
+    ctx->pinned_bytes = bytes;
+  }
+  *out = ctx->pinned;
+  return SFMHIP_OK;
+}
+
+extern "C" const char* sfmhip_error_string(int status) {
+  switch (status) {
+    case SFMHIP_OK: return "ok";
+    case SFMHIP_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+    case SFMHIP_ERR_HIP: return "HIP runtime error";
+    case SFMHIP_ERR_ARG: return "invalid argument";
+    case SFMHIP_ERR_ALLOC: return "device allocation failed";
+    case SFMHIP_ERR_UNSUPPORTED: return "unsupported device or configuration";
+    case SFMHIP_ERR_STATE: return "object not in the required state";
+    case SFMHIP_ERR_COMM: return "all-reduce callback failed";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int sfmhip_last_hip_error(void) { return g_sfmhip_last_hip_error; }
+extern "C" int sfmhip_version(void) { return SFMHIP_VERSION; }
