@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on MI355X:
+    "image-pairs matched/sec + BA iterations/sec (200 cams, 100k pts, 1M obs)".
+
+One *step* = one pass of the hot path over one batch of synthetic input:
+  (a) matching:  prepare (f32 -> i8 tiles, norms) + all-pairs k=2 L2 matching + ratio test +
+                 ordered compaction of BASELINE cfg2 (50 images x 2000 SIFT-128 rows, 1225 pairs)
+                 with the f32 descriptors already resident in HBM;
+  (b) BA:        one full LM iteration of BASELINE cfg4 (200 cams / 100k points / 1M obs):
+                 linearise + Schur eliminate (+ all-reduce) + reduced solve + back-substitute +
+                 candidate cost.
+The two halves are timed as two regions of exactly K steps each, each bracketed by a barrier +
+device synchronisation; `value` is the matching throughput (pairs/s over all ranks),
+`ba_iterations_per_s` the BA rate, `ms_per_step` their sum per step.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL):
+  * matching is weak-scaled: independent units -- every rank matches the 1225 pairs of its own
+    50-image set, no collective on the data path;
+  * BA is the one cfg4 problem, points block-partitioned over the ranks, the reduced camera
+    system summed by one all-reduce per LM iteration (strong scaling; reported separately).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+I8_DENSE_PEAK_TOPS = 5000.0   # 2x the ~2.5 PF dense bf16 MFMA peak (MI355X_MICROARCH.md, Matrix cores)
+F32_MFMA_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=96, help="pairs of cfg2 timed on the host cores")
+    ap.add_argument("--cpu-ba-iters", type=int, default=8)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        torch.cuda.set_device(local_rank)
+    if world != args.gpus:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    from sfm_danpipeline_amd import _lib, bundle, matcher, sharding, synth
+
+    # all library work rides torch's current stream so that RCCL collectives order with it
+    stream = torch.cuda.current_stream(dev)
+    ctx = _lib.Context(local_rank, stream=stream.cuda_stream)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # ------------------------------------------------------------------ workload (synthetic, seeded)
+    n_img, n_feat, dim = 50, 2000, 128
+    imgs = synth.sift_image_set(n_img, n_feat, dim, seed=1234 + 1000 * rank)   # rank r: its own image set
+    pairs = synth.all_pairs(n_img)
+    d_imgs = [torch.from_numpy(a).to(dev) for a in imgs]                        # inputs resident in HBM
+    iset = matcher.ImageSet(n_rows=[n_feat] * n_img, dim=dim, dtype=_lib.F32, norm=_lib.L2, ctx=ctx)
+    for i, t in enumerate(d_imgs):
+        iset.adopt_device(i, t.data_ptr(), keepalive=t)
+    plan = matcher.MatchPlan(iset, pairs)
+
+    pb = synth.ba_problem(200, 100000, 10, seed=777)
+    loc = sharding.local_ba_problem(pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], pb["pts0"], rank, world)
+    ba = bundle.BaProblem(200, len(loc["pts"]), loc["obs_cam"], loc["obs_pt"], loc["obs_xy"], ctx=ctx)
+    if world > 1:
+        ba.set_allreduce(sharding.TorchAllReduce(device=dev), rank, world)
+    ba.set_params(pb["cams0"], loc["pts"], pb["focal0"])
+
+    def match_step():
+        iset.prepare_async()
+        plan.run_async(0.8)
+
+    # ------------------------------------------------------------------ warmup
+    for _ in range(max(args.warmup, 1)):
+        match_step()
+    ba.iterate(max(args.warmup, 1))
+    barrier()
+
+    # ------------------------------------------------------------------ timed: matching, K steps
+    knn_s = prep_s = comp_s = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        match_step()
+    barrier()
+    t_match = time.perf_counter() - t0
+    # per-kernel device time of the dominant kernel: HIP events recorded by the library on the
+    # stream the kernels run on, one extra step outside the timed region per sample
+    samples = []
+    for _ in range(min(args.steps, 10)):
+        match_step()
+        tm = plan.last_timing()          # synchronises on the recorded events
+        samples.append((tm["prepare_s"], tm["knn_s"], tm["compact_s"]))
+    prep_s, knn_s, comp_s = [float(np.mean([s[i] for s in samples])) for i in range(3)]
+    counts = plan.counts()
+
+    # ------------------------------------------------------------------ timed: BA, K iterations
+    barrier()
+    t0 = time.perf_counter()
+    ba_sum = ba.iterate(args.steps)
+    barrier()
+    t_ba = time.perf_counter() - t0
+    ba_t = ba.last_timing()
+
+    # max over ranks
+    if world > 1:
+        tt = torch.tensor([t_match, t_ba], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_match, t_ba = float(tt[0]), float(tt[1])
+        tot = torch.tensor([float(counts.sum())], device=dev, dtype=torch.float64)
+        dist.all_reduce(tot)
+        total_matches = int(tot[0])
+    else:
+        total_matches = int(counts.sum())
+
+    pairs_per_s = world * len(pairs) * args.steps / t_match
+    ba_it_per_s = args.steps / t_ba
+    ms_match = 1e3 * t_match / args.steps
+    ms_ba = 1e3 * t_ba / args.steps
+
+    # ------------------------------------------------------------------ rooflines
+    ops_per_pair = 2.0 * n_feat * n_feat * dim                     # 1.024 GOP per cfg2 pair
+    knn_tops = ops_per_pair * len(pairs) / knn_s / 1e12
+    roofline = {"kernel": "knn_mfma_kernel<KS=4,L2> (i8 MFMA 32x32x32 + fused top-2)", "bound": "mfma",
+                "achieved": round(knn_tops, 2), "peak": I8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
+                "frac": round(knn_tops / I8_DENSE_PEAK_TOPS, 4), "traffic": None,
+                "f32_equivalent_frac": round(knn_tops / F32_MFMA_PEAK_TFLOPS, 3),
+                "launch_ms": round(knn_s * 1e3, 4), "prepare_ms": round(prep_s * 1e3, 4),
+                "compact_ms": round(comp_s * 1e3, 4)}
+    n_obs_l, n_pt_l, n_cam = len(loc["obs_cam"]), len(loc["pts"]), 200
+    red_dim = 6 * n_cam + 1
+    ba_bytes = 3 * n_obs_l * 24 + 2 * n_pt_l * 24 + 2 * red_dim * red_dim * 8 + n_cam * 48   # section 8d
+    ba_stream_s = (ba_t["eliminate_s"] + ba_t["backsub_s"]) / max(args.steps, 1)
+    ba_gbs = ba_bytes / ba_stream_s / 1e9
+    roofline_ba = {"kernels": "ba_eliminate + ba_backsub (per LM iteration, this rank's shard)", "bound": "hbm",
+                   "achieved": round(ba_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(ba_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                   "eliminate_ms": round(1e3 * ba_t["eliminate_s"] / args.steps, 4),
+                   "allreduce_ms": round(1e3 * ba_t["allreduce_s"] / args.steps, 4),
+                   "reduced_solve_ms": round(1e3 * ba_t["solve_s"] / args.steps, 4),
+                   "backsub_cost_ms": round(1e3 * ba_t["backsub_s"] / args.steps, 4),
+                   "launches_per_iter": round(ba_t["launches"] / max(args.steps, 1), 1)}
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only)
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import orc   # the checker, timed as the reported host-CPU baseline ("port")
+        orc.build()
+        cores = os.cpu_count() or 1
+        # bounded sample: grow the pair count until the matcher leg is ~10 s of wall time
+        npairs, cpu_match_s, cpu_counts = min(args.cpu_pairs, len(pairs)), 0.0, None
+        while True:
+            t0 = time.perf_counter()
+            cpu_counts = orc.match_many(imgs, pairs[:npairs], threads=cores)
+            cpu_match_s = time.perf_counter() - t0
+            if cpu_match_s >= 5.0 or npairs == len(pairs):
+                break
+            npairs = min(len(pairs), max(npairs * 2, int(npairs * 10.0 / max(cpu_match_s, 1e-3))))
+        assert np.array_equal(cpu_counts, counts[:npairs]), "CPU baseline and GPU match counts differ"
+        cpu_ba_s, _ = orc.ba_time_iterations(pb["cams0"], pb["pts0"], pb["focal0"], pb["obs_cam"], pb["obs_pt"],
+                                             pb["obs_xy"], args.cpu_ba_iters)
+        cpu_pairs_s = npairs / cpu_match_s
+        cpu_ba_its = args.cpu_ba_iters / cpu_ba_s
+        cpu_step_ms = 1e3 * (len(pairs) / cpu_pairs_s + 1.0 / cpu_ba_its)
+        cpu_baseline = {"value": round(cpu_pairs_s, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
+                        "sample": f"first {npairs} of the 1225 cfg2 pairs, oracle matcher parallel over pairs x rows on "
+                                  f"{cores} threads ({cpu_match_s:.1f} s); {args.cpu_ba_iters} LM iterations of cfg4 "
+                                  f"on 1 thread like Ceres' default ({cpu_ba_s:.1f} s)",
+                        "ba_iterations_per_s": round(cpu_ba_its, 4), "ba_cores": 1,
+                        "ms_per_step_extrapolated": round(cpu_step_ms, 1),
+                        "gpu_over_cpu_step": round(cpu_step_ms / (ms_match + ms_ba), 1)}
+
+    if rank == 0:
+        out = {
+            "metric": "image-pairs matched/sec + BA iterations/sec (200 cams, 100k pts, 1M obs)",
+            "value": round(pairs_per_s, 1), "unit": "pairs/s",
+            "ba_iterations_per_s": round(ba_it_per_s, 2),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_match + ms_ba, 4), "ms_match_sweep": round(ms_match, 4),
+            "ms_ba_iteration": round(ms_ba, 4),
+            "higher_is_better": True, "scaling": "weak", "ba_scaling": "strong",
+            "vs_baseline": None, "dtype": "i8", "ba_dtype": "f64", "data": "synthetic",
+            "config": {"workload": "cfg2 all-pairs L2 knn-2 + ratio (50 img x 2000 SIFT-128, 1225 pairs/GPU) "
+                                   "+ cfg4 BA LM iteration (200 cams / 100k pts / 1M obs)",
+                       "pairs_per_gpu": int(len(pairs)), "matches_found": total_matches,
+                       "ba_points_per_gpu": int(n_pt_l), "ba_obs_per_gpu": int(n_obs_l),
+                       "ba_cost": [ba_sum.initial_cost, ba_sum.final_cost],
+                       "parallelism": f"pairs x{world} (weak), BA points/{world} + all-reduce"},
+            "roofline": roofline, "roofline_ba": roofline_ba, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

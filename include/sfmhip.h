@@ -165,7 +165,9 @@ int sfmhip_ba_set_params(sfmhip_ba* ba, const double* cams6, const double* pts3,
 int sfmhip_ba_get_params(sfmhip_ba* ba, double* cams6, double* pts3, double* focal);
 int sfmhip_ba_run(sfmhip_ba* ba, const sfmhip_ba_opts* opts, sfmhip_ba_summary* summary);
 /* `iters` LM iterations (linearise + Schur eliminate + all-reduce + reduced solve +
- * back-substitute + candidate cost, accept/reject as usual) without convergence tests */
+ * back-substitute + candidate cost, accept/reject as usual) without convergence tests.
+ * Resumable: the first call after set_params linearises and computes the Jacobi scaling,
+ * later calls continue the same trust-region state. */
 int sfmhip_ba_iterate(sfmhip_ba* ba, int iters, sfmhip_ba_summary* summary);
 /* One linearisation at the current parameters: reduced system of this rank's points,
  * dim = 6*n_cam+1, S row-major full symmetric, before any all-reduce.  Test hook. */

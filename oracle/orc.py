@@ -71,6 +71,8 @@ def lib():
         L.orc_match_knn2.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                      vp, vp, vp, vp, vp, vp, C.c_int]
         L.orc_match_knn2.restype = C.c_int
+        L.orc_match_many.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp]
+        L.orc_match_many.restype = C.c_int
         L.orc_triangulate.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, vp, vp, vp]
         L.orc_triangulate.restype = C.c_int
         L.orc_ba_residual.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp, vp]
@@ -122,6 +124,21 @@ def match_knn2(q, t, norm=NORM_L2, ratio=0.8, threads=1, want_knn=False):
     if want_knn:
         return out + (ki[:nq].copy(), kd[:nq].copy())
     return out
+
+
+def match_many(imgs, pairs, norm=NORM_L2, ratio=0.8, threads=1):
+    """Match counts of many pairs in one call (parallel over pairs x query rows)."""
+    imgs = [np.ascontiguousarray(a) for a in imgs]
+    dtype = DTYPE_F32 if imgs[0].dtype == np.float32 else DTYPE_U8
+    ptrs = (C.c_void_p * len(imgs))(*[a.ctypes.data for a in imgs])
+    n_rows = np.array([a.shape[0] for a in imgs], np.int32)
+    pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    counts = np.zeros(max(len(pairs), 1), np.int32)
+    rc = lib().orc_match_many(ptrs, _p(n_rows), imgs[0].shape[1], dtype, norm, _p(pairs), len(pairs), ratio, threads,
+                              _p(counts))
+    if rc:
+        raise RuntimeError(f"orc_match_many rc={rc}")
+    return counts[:len(pairs)]
 
 
 def triangulate(P1, P2, K, dist, xy1, xy2, max_err=6.0):

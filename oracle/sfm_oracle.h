@@ -33,6 +33,11 @@ int orc_match_knn2(const void* q, int nq, const void* t, int nt, int dim, int dt
                    float ratio, int32_t* out_q, int32_t* out_t, float* out_dist, int32_t* out_n,
                    int32_t* knn_idx, float* knn_dist, int threads);
 
+/* the same for a list of pairs, parallel over (pair, query row); counts[p] = #matches of pair p.
+ * CPU-baseline leg of bench.py. */
+int orc_match_many(const void* const* imgs, const int32_t* n_rows, int dim, int dtype, int norm,
+                   const int32_t* pairs, int n_pairs, float ratio, int threads, int32_t* counts);
+
 /* reference: src/Sfm.cpp:804-878 (triangulateViews): undistortPoints (dist==0 path and the
  * 5-iteration path), cv::triangulatePoints 4x4 DLT, convertPointsFromHomogeneous,
  * projectPoints in both views, float 6 px filter.  xy1/xy2 are the already-gathered pixel

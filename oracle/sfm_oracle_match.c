@@ -85,7 +85,7 @@ int orc_match_knn2(const void* q, int nq, const void* t, int nt, int dim, int dt
   float* bd = (float*)malloc(sizeof(float) * 2 * (size_t)(nq > 0 ? nq : 1));
   if (!bi || !bd) return -3;
   if (threads < 1) threads = 1;
-#pragma omp parallel for schedule(dynamic, 16) num_threads(threads)
+#pragma omp parallel for schedule(static) num_threads(threads)
   for (int i = 0; i < nq; ++i) {
     int32_t i0 = -1, i1 = -1;
     if (norm == ORC_NORM_HAMMING) {
@@ -134,6 +134,57 @@ int orc_match_knn2(const void* q, int nq, const void* t, int nt, int dim, int dt
   if (knn_dist) memcpy(knn_dist, bd, sizeof(float) * 2 * (size_t)nq);
   free(bi);
   free(bd);
+  return 0;
+}
+
+/* Many pairs in one call, parallel over (pair, query row) so that every host core has work:
+ * the CPU-baseline leg of bench.py.  counts[p] = matches of pair p (ratio-filtered). */
+int orc_match_many(const void* const* imgs, const int32_t* n_rows, int dim, int dtype, int norm,
+                   const int32_t* pairs, int n_pairs, float ratio, int threads, int32_t* counts) {
+  if (n_pairs < 0 || dim <= 0) return -1;
+  if (threads < 1) threads = 1;
+  int64_t* off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_pairs + 1));
+  if (!off) return -3;
+  off[0] = 0;
+  for (int p = 0; p < n_pairs; ++p) off[p + 1] = off[p] + n_rows[pairs[2 * p]];
+  const int64_t total = off[n_pairs];
+  for (int p = 0; p < n_pairs; ++p) counts[p] = 0;
+  const size_t esz = dtype == ORC_DTYPE_F32 ? 4 : 1;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(threads)
+  for (int64_t w = 0; w < total; ++w) {
+    int lo = 0, hi = n_pairs - 1; /* pair of work item w */
+    while (lo < hi) {
+      int mid = (lo + hi + 1) / 2;
+      if (off[mid] <= w) lo = mid; else hi = mid - 1;
+    }
+    const int p = lo, i = (int)(w - off[p]);
+    const int qi = pairs[2 * p], ti = pairs[2 * p + 1], nt = n_rows[ti];
+    const unsigned char* q = (const unsigned char*)imgs[qi] + (size_t)i * dim * esz;
+    const unsigned char* t = (const unsigned char*)imgs[ti];
+    int32_t i0 = -1, i1 = -1;
+    int pass = 0;
+    if (norm == ORC_NORM_HAMMING) {
+      int d0 = INT_MAX, d1 = INT_MAX;
+      for (int j = 0; j < nt; ++j) {
+        int d = hamming_u8(q, t + (size_t)j * dim, dim);
+        KNN2_INSERT(d, j, d0, i0, d1, i1);
+      }
+      pass = i1 >= 0 && (float)d0 <= ratio * (float)d1;
+    } else {
+      float d0 = FLT_MAX, d1 = FLT_MAX;
+      for (int j = 0; j < nt; ++j) {
+        float d = dtype == ORC_DTYPE_F32 ? l2_f32((const float*)q, (const float*)(t + (size_t)j * dim * 4), dim)
+                                         : l2_u8(q, t + (size_t)j * dim, dim);
+        KNN2_INSERT(d, j, d0, i0, d1, i1);
+      }
+      pass = i1 >= 0 && d0 <= ratio * d1;
+    }
+    if (pass) {
+#pragma omp atomic
+      counts[p]++;
+    }
+  }
+  free(off);
   return 0;
 }
 

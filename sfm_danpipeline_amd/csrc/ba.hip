@@ -1006,8 +1006,16 @@ __global__ void ba_cam_norm(BaDev d, const unsigned char* __restrict__ cam_used,
 }  // namespace
 
 // ================================================================= host side
+struct LmState {
+  bool started = false, have_lin = false;
+  double radius = 1e4, decrease_factor = 2.0;
+  int invalid = 0, iter = 0, nsucc = 0;
+  double x_norm = 0, cost = 0, initial_cost = 0, gmax = 0;
+};
+
 struct sfmhip_ba {
   sfmhip_ctx* ctx = nullptr;
+  LmState lm;
   int nc = 0, np_in = 0, no_in = 0;  // as given
   int np = 0, no = 0;                // with >= 1 observation, sorted order
   int dim = 0;
@@ -1258,6 +1266,7 @@ extern "C" int sfmhip_ba_set_params(sfmhip_ba* b, const double* cams6, const dou
   SFM_HIP_TRY(hipMemcpyAsync(b->d.focal, &focal, sizeof(double), hipMemcpyHostToDevice, st));
   SFM_HIP_TRY(hipStreamSynchronize(st));
   b->scale_ready = false;
+  b->lm.started = false;
   return SFMHIP_OK;
 }
 
@@ -1426,137 +1435,161 @@ static void ba_acc_timing(sfmhip_ba* b) {
 }
 
 // TrustRegionMinimizer::Minimize (Ceres 1.13) + LevenbergMarquardtStrategy, host control loop.
-static int ba_minimize(sfmhip_ba* b, const sfmhip_ba_opts* o, sfmhip_ba_summary* sum, bool timing_only, int timing_iters) {
-  using clk = std::chrono::steady_clock;
-  const auto t0 = clk::now();
-  auto elapsed = [&]() { return std::chrono::duration<double>(clk::now() - t0).count(); };
-  hipStream_t st = b->ctx->stream;
+// The loop state lives in the sfmhip_ba object so that sfmhip_ba_iterate can be called one
+// iteration at a time (bench.py interleaves it with matching sweeps).
+static int ba_begin(sfmhip_ba* b, const sfmhip_ba_opts* o) {
   SFM_HIP_TRY(hipSetDevice(b->ctx->device));
   for (double& t : b->t_acc) t = 0;
   b->launches = 0;
   SFM_TRY(ba_prepare_scale(b, o->jacobi_scaling));
-  double radius = o->initial_radius, decrease_factor = 2.0;
-  int invalid = 0, iter = 0, nsucc = 0, term = SFMHIP_BA_NO_CONVERGENCE;
-  double x_norm = b->x_norm, cost = 0, gmax = 0;
-  bool have_lin = false;  // [S|g] of the current (x, radius) already on the device
-  IterScalars sc{};
+  LmState& s = b->lm;
+  s = LmState();
+  s.radius = o->initial_radius;
+  s.x_norm = b->x_norm;
   // iteration 0: cost + gradient at x0 (the same pass also forms the first reduced system)
-  SFM_TRY(ba_linearize_eliminate(b, radius, o, true));
+  IterScalars sc{};
+  SFM_TRY(ba_linearize_eliminate(b, s.radius, o, true));
   SFM_TRY(ba_read_scalars(b, &sc, false));
-  cost = sc.cost;
-  gmax = sc.gmax;
-  have_lin = true;
-  sum->initial_cost = cost;
-  if (!timing_only && gmax <= o->gradient_tolerance) {
-    term = SFMHIP_BA_CONVERGENCE;
-    goto done;
-  }
-  for (;;) {
-    if (timing_only) {
-      if (iter >= timing_iters) break;
-    } else {
-      if (iter >= o->max_iterations) break;
-      if (o->max_time_s > 0 && elapsed() >= o->max_time_s) break;
-      if (radius < o->min_radius) {
-        term = SFMHIP_BA_CONVERGENCE;
-        break;
-      }
-    }
-    ++iter;
-    if (!have_lin) SFM_TRY(ba_linearize_eliminate(b, radius, o, true));
-    have_lin = false;
-    SFM_TRY(ba_reduced_solve(b));
-    SFM_HIP_TRY(hipEventRecord(b->ev[3], st));
-    SFM_TRY(ba_step_eval(b, radius, o));
-    SFM_HIP_TRY(hipEventRecord(b->ev[4], st));
-    SFM_TRY(ba_read_scalars(b, &sc, true));
-    ba_acc_timing(b);
-    const bool finite = std::isfinite(sc.step_n2) && std::isfinite(sc.mcc) && std::isfinite(sc.cost_c);
-    const bool bad = sc.info != 0 || sc.nfail > 0 || !finite;
-    if (bad || !(sc.mcc > 0.0)) {  // HandleInvalidStep
-      if (++invalid >= o->max_consecutive_invalid && !timing_only) {
-        term = SFMHIP_BA_FAILURE;
-        break;
-      }
-      radius /= decrease_factor;
-      decrease_factor *= 2.0;
-      if (o->verbose) fprintf(stderr, "[sfmhip-ba] it %d invalid step (info %d), radius %.3e\n", iter, sc.info, radius);
-      continue;
-    }
-    invalid = 0;
-    const double step_norm = std::sqrt(sc.step_n2);
-    if (!timing_only) {
-      if (step_norm <= o->parameter_tolerance * (x_norm + o->parameter_tolerance)) {
-        term = SFMHIP_BA_CONVERGENCE;
-        break;
-      }
-      if (std::fabs(cost - sc.cost_c) <= o->function_tolerance * cost) {
-        term = SFMHIP_BA_CONVERGENCE;
-        break;
-      }
-    }
-    const double rho = (cost - sc.cost_c) / sc.mcc;
-    if (o->verbose)
-      fprintf(stderr, "[sfmhip-ba] it %d cost %.9e -> %.9e rho %.3e radius %.3e |step| %.3e\n", iter, cost, sc.cost_c,
-              rho, radius, step_norm);
-    if (rho > o->min_relative_decrease) {  // HandleSuccessfulStep
-      ba_swap_candidate(b);
-      x_norm = std::sqrt(sc.cand_n2);
-      ++nsucc;
-      const double q = 2.0 * rho - 1.0;
-      radius = radius / std::fmax(1.0 / 3.0, 1.0 - q * q * q);
-      radius = std::fmin(o->max_radius, radius);
-      decrease_factor = 2.0;
-      // re-linearise at the new x; with the new radius this is also the next reduced system
-      SFM_TRY(ba_linearize_eliminate(b, radius, o, true));
-      SFM_TRY(ba_read_scalars(b, &sc, false));
-      cost = sc.cost;
-      gmax = sc.gmax;
-      have_lin = true;
-      if (!timing_only && gmax <= o->gradient_tolerance) {
-        term = SFMHIP_BA_CONVERGENCE;
-        break;
-      }
-    } else {  // HandleUnsuccessfulStep
-      radius /= decrease_factor;
-      decrease_factor *= 2.0;
-    }
-  }
-done:
-  b->x_norm = x_norm;
-  sum->termination = term;
-  sum->iterations = iter;
-  sum->successful_steps = nsucc;
-  sum->final_cost = cost;
-  sum->final_radius = radius;
-  sum->gradient_max_norm = gmax;
-  sum->time_s = elapsed();
+  s.cost = s.initial_cost = sc.cost;
+  s.gmax = sc.gmax;
+  s.have_lin = true;
+  s.started = true;
   return SFMHIP_OK;
+}
+
+// one LM iteration; *stop receives the termination type once a stopping rule fires (-1 else)
+static int ba_one_iteration(sfmhip_ba* b, const sfmhip_ba_opts* o, bool timing_only, int* stop) {
+  hipStream_t st = b->ctx->stream;
+  LmState& s = b->lm;
+  IterScalars sc{};
+  *stop = -1;
+  ++s.iter;
+  if (!s.have_lin) SFM_TRY(ba_linearize_eliminate(b, s.radius, o, true));
+  s.have_lin = false;
+  SFM_TRY(ba_reduced_solve(b));
+  SFM_HIP_TRY(hipEventRecord(b->ev[3], st));
+  SFM_TRY(ba_step_eval(b, s.radius, o));
+  SFM_HIP_TRY(hipEventRecord(b->ev[4], st));
+  SFM_TRY(ba_read_scalars(b, &sc, true));
+  ba_acc_timing(b);
+  const bool finite = std::isfinite(sc.step_n2) && std::isfinite(sc.mcc) && std::isfinite(sc.cost_c);
+  const bool bad = sc.info != 0 || sc.nfail > 0 || !finite;
+  if (bad || !(sc.mcc > 0.0)) {  // HandleInvalidStep
+    if (++s.invalid >= o->max_consecutive_invalid && !timing_only) {
+      *stop = SFMHIP_BA_FAILURE;
+      return SFMHIP_OK;
+    }
+    s.radius /= s.decrease_factor;
+    s.decrease_factor *= 2.0;
+    if (o->verbose) fprintf(stderr, "[sfmhip-ba] it %d invalid step (info %d), radius %.3e\n", s.iter, sc.info, s.radius);
+    return SFMHIP_OK;
+  }
+  s.invalid = 0;
+  const double step_norm = std::sqrt(sc.step_n2);
+  if (!timing_only) {
+    if (step_norm <= o->parameter_tolerance * (s.x_norm + o->parameter_tolerance)) {
+      *stop = SFMHIP_BA_CONVERGENCE;  // ParameterToleranceReached: candidate not taken
+      return SFMHIP_OK;
+    }
+    if (std::fabs(s.cost - sc.cost_c) <= o->function_tolerance * s.cost) {
+      *stop = SFMHIP_BA_CONVERGENCE;  // FunctionToleranceReached: candidate not taken
+      return SFMHIP_OK;
+    }
+  }
+  const double rho = (s.cost - sc.cost_c) / sc.mcc;
+  if (o->verbose)
+    fprintf(stderr, "[sfmhip-ba] it %d cost %.9e -> %.9e rho %.3e radius %.3e |step| %.3e\n", s.iter, s.cost, sc.cost_c,
+            rho, s.radius, step_norm);
+  if (rho > o->min_relative_decrease) {  // HandleSuccessfulStep
+    ba_swap_candidate(b);
+    s.x_norm = std::sqrt(sc.cand_n2);
+    ++s.nsucc;
+    const double q = 2.0 * rho - 1.0;
+    s.radius = s.radius / std::fmax(1.0 / 3.0, 1.0 - q * q * q);
+    s.radius = std::fmin(o->max_radius, s.radius);
+    s.decrease_factor = 2.0;
+    // re-linearise at the new x; with the new radius this is also the next reduced system
+    SFM_TRY(ba_linearize_eliminate(b, s.radius, o, true));
+    SFM_TRY(ba_read_scalars(b, &sc, false));
+    s.cost = sc.cost;
+    s.gmax = sc.gmax;
+    s.have_lin = true;
+    if (!timing_only && s.gmax <= o->gradient_tolerance) *stop = SFMHIP_BA_CONVERGENCE;
+  } else {  // HandleUnsuccessfulStep
+    s.radius /= s.decrease_factor;
+    s.decrease_factor *= 2.0;
+  }
+  return SFMHIP_OK;
+}
+
+static void ba_fill_summary(sfmhip_ba* b, int term, double time_s, sfmhip_ba_summary* sum) {
+  const LmState& s = b->lm;
+  b->x_norm = s.x_norm;
+  sum->termination = term;
+  sum->iterations = s.iter;
+  sum->successful_steps = s.nsucc;
+  sum->initial_cost = s.initial_cost;
+  sum->final_cost = s.cost;
+  sum->final_radius = s.radius;
+  sum->gradient_max_norm = s.gmax;
+  sum->time_s = time_s;
 }
 
 extern "C" int sfmhip_ba_run(sfmhip_ba* b, const sfmhip_ba_opts* opts, sfmhip_ba_summary* summary) {
   if (!b) return SFMHIP_ERR_ARG;
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
+  auto elapsed = [&]() { return std::chrono::duration<double>(clk::now() - t0).count(); };
   sfmhip_ba_opts od;
   if (!opts) {
     sfmhip_ba_default_opts(&od);
     opts = &od;
   }
-  sfmhip_ba_summary s;
-  memset(&s, 0, sizeof s);
-  const int rc = ba_minimize(b, opts, &s, false, 0);
-  if (summary) *summary = s;
-  return rc;
+  sfmhip_ba_summary sm;
+  memset(&sm, 0, sizeof sm);
+  SFM_TRY(ba_begin(b, opts));
+  LmState& s = b->lm;
+  int term = SFMHIP_BA_NO_CONVERGENCE;
+  if (s.gmax <= opts->gradient_tolerance) {
+    term = SFMHIP_BA_CONVERGENCE;
+  } else {
+    for (;;) {
+      if (s.iter >= opts->max_iterations) break;                            // NO_CONVERGENCE
+      if (opts->max_time_s > 0 && elapsed() >= opts->max_time_s) break;     // NO_CONVERGENCE
+      if (s.radius < opts->min_radius) {
+        term = SFMHIP_BA_CONVERGENCE;
+        break;
+      }
+      int stop = -1;
+      SFM_TRY(ba_one_iteration(b, opts, false, &stop));
+      if (stop >= 0) {
+        term = stop;
+        break;
+      }
+    }
+  }
+  s.started = false;  // a finished solve is not resumable
+  ba_fill_summary(b, term, elapsed(), &sm);
+  if (summary) *summary = sm;
+  return SFMHIP_OK;
 }
 
 extern "C" int sfmhip_ba_iterate(sfmhip_ba* b, int iters, sfmhip_ba_summary* summary) {
   if (!b || iters < 0) return SFMHIP_ERR_ARG;
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
   sfmhip_ba_opts o;
   sfmhip_ba_default_opts(&o);
-  sfmhip_ba_summary s;
-  memset(&s, 0, sizeof s);
-  const int rc = ba_minimize(b, &o, &s, true, iters);
-  if (summary) *summary = s;
-  return rc;
+  sfmhip_ba_summary sm;
+  memset(&sm, 0, sizeof sm);
+  if (!b->lm.started) SFM_TRY(ba_begin(b, &o));
+  for (int i = 0; i < iters; ++i) {
+    int stop = -1;
+    SFM_TRY(ba_one_iteration(b, &o, true, &stop));
+  }
+  ba_fill_summary(b, SFMHIP_BA_NO_CONVERGENCE, std::chrono::duration<double>(clk::now() - t0).count(), &sm);
+  if (summary) *summary = sm;
+  return SFMHIP_OK;
 }
 
 extern "C" int sfmhip_ba_reduced_system(sfmhip_ba* b, double radius, double* S, double* g, double* cost) {

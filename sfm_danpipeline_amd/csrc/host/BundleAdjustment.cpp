@@ -1,0 +1,132 @@
+// BundleAdjustment.cpp -- adjustBundle over the sfmhip C ABI.  Mirrors the policies of the
+// reference's src/BundleAdjustment.cpp:46-175; the solve itself runs on the MI355X.
+#include "BundleAdjustment.h"
+#include <cfloat>
+#include <cmath>
+#include <iostream>
+#include "hip_backend.h"
+#include "sfmhip.h"
+
+namespace {
+
+// ceres::RotationMatrixToAngleAxis of the rotation part of a pose (R(i,j) = pose(i,j))
+void pose_to_angle_axis(const cv::Matx34d& P, double aa[3]) {
+  double q[4];
+  const double trace = P(0, 0) + P(1, 1) + P(2, 2);
+  if (trace >= 0.0) {
+    double t = std::sqrt(trace + 1.0);
+    q[0] = 0.5 * t;
+    t = 0.5 / t;
+    q[1] = (P(2, 1) - P(1, 2)) * t;
+    q[2] = (P(0, 2) - P(2, 0)) * t;
+    q[3] = (P(1, 0) - P(0, 1)) * t;
+  } else {
+    int i = 0;
+    if (P(1, 1) > P(0, 0)) i = 1;
+    if (P(2, 2) > P(i, i)) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double t = std::sqrt(P(i, i) - P(j, j) - P(k, k) + 1.0);
+    q[i + 1] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (P(k, j) - P(j, k)) * t;
+    q[j + 1] = (P(j, i) + P(i, j)) * t;
+    q[k + 1] = (P(k, i) + P(i, k)) * t;
+  }
+  const double s2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  double k = 2.0;
+  if (s2 > 0.0) {
+    const double st = std::sqrt(s2), ct = q[0];
+    k = 2.0 * ((ct < 0.0) ? std::atan2(-st, -ct) : std::atan2(st, ct)) / st;
+  }
+  aa[0] = q[1] * k;
+  aa[1] = q[2] * k;
+  aa[2] = q[3] * k;
+}
+
+// ceres::AngleAxisToRotationMatrix into the rotation part of a pose
+void angle_axis_to_pose(const double aa[3], cv::Matx34d& P) {
+  const double theta2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+  if (theta2 > DBL_EPSILON) {
+    const double theta = std::sqrt(theta2);
+    const double wx = aa[0] / theta, wy = aa[1] / theta, wz = aa[2] / theta;
+    const double c = std::cos(theta), s = std::sin(theta);
+    P(0, 0) = c + wx * wx * (1.0 - c);
+    P(1, 0) = wz * s + wx * wy * (1.0 - c);
+    P(2, 0) = -wy * s + wx * wz * (1.0 - c);
+    P(0, 1) = wx * wy * (1.0 - c) - wz * s;
+    P(1, 1) = c + wy * wy * (1.0 - c);
+    P(2, 1) = wx * s + wy * wz * (1.0 - c);
+    P(0, 2) = wy * s + wx * wz * (1.0 - c);
+    P(1, 2) = -wx * s + wy * wz * (1.0 - c);
+    P(2, 2) = c + wz * wz * (1.0 - c);
+  } else {
+    P(0, 0) = 1.0;    P(0, 1) = -aa[2]; P(0, 2) = aa[1];
+    P(1, 0) = aa[2];  P(1, 1) = 1.0;    P(1, 2) = -aa[0];
+    P(2, 0) = -aa[1]; P(2, 1) = aa[0];  P(2, 2) = 1.0;
+  }
+}
+
+}  // namespace
+
+void BundleAdjustment::adjustBundle(std::vector<Point3D>& pointCloud, std::vector<cv::Matx34d>& cameraPoses,
+                                    Intrinsics& intrinsics,
+                                    const std::vector<std::vector<cv::Point2d>>& image2dFeatures) {
+  const int n_cam = (int)cameraPoses.size(), n_pt = (int)pointCloud.size();
+  std::vector<double> cams6(6 * (size_t)n_cam, 0.0);
+  std::vector<char> empty(n_cam, 0);
+  for (int i = 0; i < n_cam; ++i) {
+    const cv::Matx34d& pose = cameraPoses[i];
+    if (pose(0, 0) == 0 && pose(1, 1) == 0 && pose(2, 2) == 0) {  // unregistered view
+      empty[i] = 1;
+      continue;
+    }
+    pose_to_angle_axis(pose, &cams6[6 * (size_t)i]);
+    for (int r = 0; r < 3; ++r) cams6[6 * (size_t)i + 3 + r] = pose(r, 3);
+  }
+  double focal = intrinsics.K.at<double>(0, 0);
+  const double cx = intrinsics.K.at<double>(0, 2), cy = intrinsics.K.at<double>(1, 2);
+  std::vector<double> pts3(3 * (size_t)n_pt);
+  std::vector<int32_t> obs_cam, obs_pt;
+  std::vector<double> obs_xy;
+  for (int i = 0; i < n_pt; ++i) {
+    const Point3D& p = pointCloud[i];
+    pts3[3 * (size_t)i] = p.pt.x;
+    pts3[3 * (size_t)i + 1] = p.pt.y;
+    pts3[3 * (size_t)i + 2] = p.pt.z;
+    for (const auto& kv : p.idxImage) {  // (view, 2-D feature index)
+      const cv::Point2d& f = image2dFeatures[kv.first][kv.second];
+      obs_cam.push_back(kv.first);
+      obs_pt.push_back(i);
+      obs_xy.push_back(f.x - cx);  // the optimiser does not know the principal point
+      obs_xy.push_back(f.y - cy);
+    }
+  }
+  sfmhip_ba_opts opts;
+  sfmhip_ba_default_opts(&opts);  // DENSE_SCHUR LM, 500 iterations, 10 s
+  sfmhip_ba_summary summary;
+  const int rc = sfmhip_ba_solve(sfm_hip_context(), n_cam, n_pt, (int)obs_cam.size(), cams6.data(), pts3.data(), &focal,
+                                 obs_cam.data(), obs_pt.data(), obs_xy.data(), &opts, &summary);
+  if (rc != SFMHIP_OK) {
+    std::cerr << "Bundle adjustment failed: " << sfmhip_error_string(rc) << std::endl;
+    return;
+  }
+  std::cout << "Bundle adjustment: iterations " << summary.iterations << ", cost " << summary.initial_cost << " -> "
+            << summary.final_cost << ", " << summary.time_s << " s" << std::endl;
+  if (summary.termination != SFMHIP_BA_CONVERGENCE) {
+    std::cerr << "Bundle adjustment failed." << std::endl;  // results are discarded, inputs untouched
+    return;
+  }
+  intrinsics.K.at<double>(0, 0) = focal;
+  intrinsics.K.at<double>(1, 1) = focal;
+  for (int i = 0; i < n_cam; ++i) {
+    if (empty[i]) continue;
+    cv::Matx34d& pose = cameraPoses[i];
+    angle_axis_to_pose(&cams6[6 * (size_t)i], pose);
+    for (int r = 0; r < 3; ++r) pose(r, 3) = cams6[6 * (size_t)i + 3 + r];
+  }
+  for (int i = 0; i < n_pt; ++i) {
+    pointCloud[i].pt.x = pts3[3 * (size_t)i];
+    pointCloud[i].pt.y = pts3[3 * (size_t)i + 1];
+    pointCloud[i].pt.z = pts3[3 * (size_t)i + 2];
+  }
+}

@@ -1,0 +1,48 @@
+// Sfm.h -- the hot-path part of the reference's StructFromMotion (include/Sfm.h:15-35,89,
+// 107-117): same member names, same method signatures.  Everything above the hot path
+// (image loading, feature extraction, RANSAC pose, PMVS/PCL post-processing) is out of scope
+//  and is replaced by the loader methods at the bottom.
+#pragma once
+#include <set>
+#include <string>
+#include "BundleAdjustment.h"
+
+class StructFromMotion {
+ private:
+  std::vector<cv::Matx34d> nCameraPoses;
+  Intrinsics cameraMatrix;
+  float NN_MATCH_RATIO;
+  std::vector<std::vector<cv::KeyPoint>> imagesKeypoints;
+  std::vector<cv::Mat> imagesDescriptors;
+  std::vector<std::vector<cv::Point2d>> imagesPts2D;
+  int detector;
+
+ public:
+  std::vector<Point3D> nReconstructionCloud;
+
+  StructFromMotion() : NN_MATCH_RATIO(0.8f), detector(1) {}
+
+  // reference include/Sfm.h:89, src/Sfm.cpp:590-608
+  void getMatching(const int& queryImage, const int& trainImage, Matching* goodMatches);
+  // reference include/Sfm.h:107-111, src/Sfm.cpp:694-711
+  void AlignedPointsFromMatch(const Points2d& queryImg, const Points2d& trainImg, const Matching& matches,
+                              Points2d& alignedL, Points2d& alignedR);
+  void AlignedPoints(const Points2d& queryImg, const Points2d& trainImg, const Matching& matches, Points2d& alignedL,
+                     Points2d& alignedR, std::vector<int>& idLeftOrigen, std::vector<int>& idRightOrigen);
+  // reference include/Sfm.h:115-117, src/Sfm.cpp:804-878
+  bool triangulateViews(const Points2d& left, const Points2d& right, const cv::Matx34d& P1, const cv::Matx34d& P2,
+                        const Matching& matches, const Intrinsics& matrixK, const std::pair<int, int>& imagePair,
+                        std::vector<Point3D>& pointcloud);
+  // reference src/Sfm.cpp:883-888 is a stub whose call names a member that no longer exists;
+  // wired here with imagesPts2D, the member of the required type
+  void adjustCurrentBundle();
+
+  // ---- stand-ins for the out-of-scope front end: hand the pipeline state in directly
+  void setDescriptors(const std::vector<cv::Mat>& d) { imagesDescriptors = d; }
+  void setPoints2D(const std::vector<std::vector<cv::Point2d>>& p) { imagesPts2D = p; }
+  void setCameraMatrix(const Intrinsics& k) { cameraMatrix = k; }
+  void setCameraPoses(const std::vector<cv::Matx34d>& p) { nCameraPoses = p; }
+  const std::vector<cv::Matx34d>& cameraPoses() const { return nCameraPoses; }
+  const Intrinsics& intrinsics() const { return cameraMatrix; }
+  void setMatchRatio(float r) { NN_MATCH_RATIO = r; }
+};

@@ -1,0 +1,64 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/sfmhip.h declares; the
+product path fails loudly without a GPU instead of falling back to anything."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from sfm_danpipeline_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def so():
+    return build.build()
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "sfmhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(sfmhip_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_symbols() == sorted(_lib.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(so):
+    L = ctypes.CDLL(so)
+    missing = [s for s in _declared_symbols() if not hasattr(L, s)]
+    assert not missing, missing
+
+
+def test_version_and_error_strings(so):
+    L = _lib.lib()
+    assert L.sfmhip_version() == 1
+    for code in (0, -1, -2, -3, -4, -5, -6, -7, -99):
+        assert L.sfmhip_error_string(code)
+
+
+def test_default_ba_options_match_the_reference(so):
+    o = _lib.BaOpts()
+    _lib.lib().sfmhip_ba_default_opts(ctypes.byref(o))
+    assert o.max_iterations == 500 and o.max_time_s == 10.0  # src/BundleAdjustment.cpp:118,120
+    assert (o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance) == (1e-6, 1e-10, 1e-8)
+    assert (o.initial_radius, o.min_relative_decrease, o.min_lm_diagonal, o.max_lm_diagonal) == (1e4, 1e-3, 1e-6, 1e32)
+
+
+def test_no_gpu_means_loud_failure_not_fallback(so):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.SfmHipError):
+        _lib.Context(0)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "sfm_danpipeline_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "from oracle" not in text and "import oracle" not in text and "sfm_oracle" not in text, f

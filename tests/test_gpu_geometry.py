@@ -1,0 +1,199 @@
+"""GPU: triangulation and bundle adjustment through the C ABI against the oracle / goldens."""
+import numpy as np
+import pytest
+
+from sfm_danpipeline_amd import _lib, bundle, synth, triangulate
+
+pytestmark = pytest.mark.gpu
+
+# f64 results of the two implementations differ by rounding only (different but equivalent
+# operation order in hypot / Jacobian assembly): stated tolerances
+TRI_ATOL = 1e-11          # 3-D points, scene scale ~1..10
+BA_PARAM_RTOL = 1e-6      # optimised cameras / points / focal at Ceres' default tolerances
+BA_COST_RTOL = 1e-9
+
+
+def test_triangulate_golden(ctx, golden):
+    g = golden["triangulate"]
+    X, err, keep = triangulate.triangulate_points(g["P1"], g["P2"], g["K"], g["dist"], g["xy1"], g["xy2"], ctx=ctx)
+    assert np.array_equal(keep.astype(bool), g["keep"])
+    assert np.allclose(X, g["X"], rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("m", [1, 63, 64, 65, 5000])
+def test_triangulate_vs_oracle(ctx, orc, m):
+    sc = synth.two_view_scene(m, seed=m)
+    X, err, keep = triangulate.triangulate_points(sc["P1"], sc["P2"], sc["K"], sc["dist"], sc["xy1"], sc["xy2"], ctx=ctx)
+    Xo, erro, keepo = orc.triangulate(sc["P1"], sc["P2"], sc["K"], sc["dist"], sc["xy1"], sc["xy2"])
+    assert np.array_equal(keep, keepo)                      # bit-exact visibility
+    assert np.abs(X - Xo).max() < TRI_ATOL
+    assert np.allclose(err, erro, rtol=1e-6, atol=1e-6)
+
+
+def test_triangulate_with_distortion_and_empty(ctx, orc):
+    sc = synth.two_view_scene(300, seed=2)
+    dist = np.array([-0.05, 0.01, 1e-4, -2e-4, 0.001])
+    X, err, keep = triangulate.triangulate_points(sc["P1"], sc["P2"], sc["K"], dist, sc["xy1"], sc["xy2"], ctx=ctx)
+    Xo, erro, keepo = orc.triangulate(sc["P1"], sc["P2"], sc["K"], dist, sc["xy1"], sc["xy2"])
+    assert np.array_equal(keep, keepo) and np.abs(X - Xo).max() < 1e-9
+    X, err, keep = triangulate.triangulate_points(sc["P1"], sc["P2"], sc["K"], dist, np.zeros((0, 2)), np.zeros((0, 2)), ctx=ctx)
+    assert X.shape == (0, 3) and keep.shape == (0,)
+
+
+def test_triangulate_views_builds_two_view_tracks(ctx, orc):
+    sc = synth.two_view_scene(200, seed=5)
+    mq = np.arange(200)[::-1].copy()
+    mt = np.arange(200)[::-1].copy()
+    cloud = triangulate.triangulate_views(sc["xy1"], sc["xy2"], sc["P1"], sc["P2"], mq, mt, sc["K"], sc["dist"], (3, 7), ctx=ctx)
+    Xo, erro, keepo = orc.triangulate(sc["P1"], sc["P2"], sc["K"], sc["dist"], sc["xy1"][mq], sc["xy2"][mt])
+    kept = np.nonzero(keepo)[0]
+    assert len(cloud) == len(kept)
+    for p, i in zip(cloud, kept):                                 # match order, src/Sfm.cpp:862-873
+        assert p["idxImage"] == {3: int(mq[i]), 7: int(mt[i])}
+        assert p["pt2D"][3] == tuple(sc["xy1"][mq[i]]) and p["pt2D"][7] == tuple(sc["xy2"][mt[i]])
+
+
+def _ba_args(pb):
+    return pb["cams0"], pb["pts0"], pb["focal0"], pb["obs_cam"], pb["obs_pt"], pb["obs_xy"]
+
+
+def test_reduced_system_golden(ctx, golden):
+    g = golden["ba"]
+    prob = bundle.BaProblem(len(g["cams0"]), len(g["pts0"]), g["obs_cam"], g["obs_pt"], g["obs_xy"], ctx=ctx)
+    prob.set_params(g["cams0"], g["pts0"], float(g["focal0"]))
+    S, gg, cost = prob.reduced_system(1e4)
+    assert abs(cost - float(g["cost0"])) < 1e-9 * cost
+    assert np.abs(S - g["S"]).max() < 1e-11 * np.abs(g["S"]).max()
+    assert np.abs(gg - g["g"]).max() < 1e-10 * np.abs(g["g"]).max()
+
+
+@pytest.mark.parametrize("nc,npt,k,seed", [(6, 60, 4, 5), (9, 400, 2, 6), (20, 2000, 10, 7), (12, 500, 12, 8),
+                                           (10, 300, 7, 9), (10, 300, 8, 10)])
+def test_reduced_system_vs_oracle(ctx, orc, nc, npt, k, seed):
+    pb = synth.ba_problem(nc, npt, k, seed=seed)
+    prob = bundle.BaProblem(nc, npt, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
+    prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+    for radius in (1e4, 3.0):
+        S, g, cost = prob.reduced_system(radius)
+        So, go, costo, _ = orc.ba_reduced_system(*_ba_args(pb), radius=radius)
+        assert abs(cost - costo) <= 1e-12 * costo
+        assert np.abs(S - So).max() <= 1e-11 * np.abs(So).max()
+        assert np.abs(g - go).max() <= 1e-10 * np.abs(go).max()
+
+
+def test_mixed_signatures_unsorted_and_repeated_cameras(ctx, orc):
+    """Ragged tracks, shuffled observation order, a camera seen twice by one point, an
+    unobserved camera and an unobserved point."""
+    rng = np.random.default_rng(4)
+    pb = synth.ba_problem(9, 250, 6, seed=11)
+    keep = rng.random(pb["n_obs"]) < 0.7
+    keep[:6] = True
+    oc, op, xy = pb["obs_cam"][keep], pb["obs_pt"][keep], pb["obs_xy"][keep]
+    sel = ~((oc == 8) | (op == 17))                  # camera 8 and point 17 lose every observation
+    oc, op, xy = oc[sel], op[sel], xy[sel]
+    oc = np.concatenate([oc, oc[:1]])                # point op[0] sees camera oc[0] twice
+    op = np.concatenate([op, op[:1]])
+    xy = np.concatenate([xy, xy[:1] + 0.3])
+    perm = rng.permutation(len(oc))
+    oc, op, xy = oc[perm], op[perm], xy[perm]
+    prob = bundle.BaProblem(9, 250, oc, op, xy, ctx=ctx)
+    prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+    S, g, cost = prob.reduced_system(1e4)
+    So, go, costo, _ = orc.ba_reduced_system(pb["cams0"], pb["pts0"], pb["focal0"], oc, op, xy, radius=1e4)
+    assert abs(cost - costo) <= 1e-12 * costo
+    assert np.abs(S - So).max() <= 1e-11 * np.abs(So).max() and np.abs(g - go).max() <= 1e-10 * np.abs(go).max()
+    c, p, f, s = bundle.ba_solve(pb["cams0"], pb["pts0"], pb["focal0"], oc, op, xy, opts=bundle.default_opts(max_time_s=0.0), ctx=ctx)
+    co, po, fo, so = orc.ba_solve(pb["cams0"], pb["pts0"], pb["focal0"], oc, op, xy, orc.default_opts(max_time_s=0.0))
+    assert (s.termination, s.iterations, s.successful_steps) == (so.termination, so.iterations, so.successful_steps)
+    assert np.array_equal(p[17], pb["pts0"][17]) and np.array_equal(c[8], pb["cams0"][8])   # untouched blocks
+    assert np.allclose(c, co, rtol=BA_PARAM_RTOL, atol=1e-9) and np.allclose(p, po, rtol=BA_PARAM_RTOL, atol=1e-9)
+
+
+@pytest.mark.parametrize("nc,npt,k,seed", [(6, 60, 4, 5), (20, 2000, 10, 7), (50, 20000, 10, 777)])
+def test_solve_matches_oracle_trajectory(ctx, orc, nc, npt, k, seed):
+    pb = synth.ba_problem(nc, npt, k, seed=seed)            # (50, 20000, 10, 777) is BASELINE cfg3
+    c, p, f, s = bundle.ba_solve(*_ba_args(pb), opts=bundle.default_opts(max_time_s=0.0), ctx=ctx)
+    co, po, fo, so = orc.ba_solve(*_ba_args(pb), opts=orc.default_opts(max_time_s=0.0))
+    assert (s.termination, s.iterations, s.successful_steps) == (so.termination, so.iterations, so.successful_steps)
+    assert abs(s.initial_cost - so.initial_cost) <= 1e-12 * so.initial_cost
+    assert abs(s.final_cost - so.final_cost) <= BA_COST_RTOL * so.final_cost
+    assert np.allclose(c, co, rtol=BA_PARAM_RTOL, atol=1e-9)
+    assert np.allclose(p, po, rtol=BA_PARAM_RTOL, atol=1e-9)
+    assert abs(f - fo) <= BA_PARAM_RTOL * fo
+
+
+def test_noise_free_scene_converges_to_zero_cost(ctx):
+    pb = synth.ba_problem(8, 300, 5, seed=3, noise_px=0.0)
+    c, p, f, s = bundle.ba_solve(*_ba_args(pb), ctx=ctx, opts=bundle.default_opts(
+        max_time_s=0.0, function_tolerance=1e-16, parameter_tolerance=1e-16, max_iterations=200))
+    assert s.final_cost < 1e-12 * s.initial_cost
+
+
+def test_termination_policies(ctx):
+    pb = synth.ba_problem(6, 80, 4, seed=9)
+    _, _, _, s = bundle.ba_solve(*_ba_args(pb), ctx=ctx, opts=bundle.default_opts(
+        max_time_s=0.0, max_iterations=1, function_tolerance=0.0, parameter_tolerance=0.0))
+    assert s.termination == _lib.BA_NO_CONVERGENCE and s.iterations == 1
+    _, _, _, s = bundle.ba_solve(*_ba_args(pb), ctx=ctx, opts=bundle.default_opts(max_time_s=1e-9, function_tolerance=0.0,
+                                                                                   parameter_tolerance=0.0))
+    assert s.termination == _lib.BA_NO_CONVERGENCE          # the 10 s rule, src/BundleAdjustment.cpp:120
+
+
+def test_adjust_bundle_end_to_end(ctx, orc):
+    """The adjustBundle drop-in on reference-shaped containers, device solver vs oracle solver."""
+    import copy
+    from tests.test_host_logic import _orc_solver, _scene
+    pb, cloud, poses, K, feats = _scene(n_cam=7, n_pt=150, k=4, seed=33)
+    cloud2, poses2, K2 = copy.deepcopy(cloud), copy.deepcopy(poses), K.copy()
+    s = bundle.adjust_bundle(cloud, poses, K, feats, ctx=ctx)
+    s2 = bundle.adjust_bundle(cloud2, poses2, K2, feats, solver=_orc_solver(orc))
+    assert s.termination == s2.termination == _lib.BA_CONVERGENCE
+    assert abs(K[0, 0] - K2[0, 0]) <= BA_PARAM_RTOL * K2[0, 0]
+    assert np.allclose([q["pt"] for q in cloud], [q["pt"] for q in cloud2], rtol=BA_PARAM_RTOL, atol=1e-9)
+    assert all(np.allclose(a, b, rtol=BA_PARAM_RTOL, atol=1e-9) for a, b in zip(poses, poses2))
+
+
+def test_allreduce_hook_with_a_mirrored_rank(ctx):
+    """The N>1 data path on one device: a fake 2-rank job whose all-reduce doubles the buffer
+    (= a second rank holding an identical point block) must walk the same LM iterates as one
+    rank solving the problem with every point duplicated."""
+    import torch
+    from sfm_danpipeline_amd import sharding
+    pb = synth.ba_problem(10, 1500, 6, seed=15)
+    view = sharding.TorchAllReduce(device=f"cuda:{ctx.device}")
+    calls = []
+
+    def mirrored(ptr, count):
+        ctx.synchronize()
+        view._view(ptr, count).mul_(2.0)
+        torch.cuda.synchronize()
+        calls.append(count)
+
+    two = bundle.BaProblem(10, 1500, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
+    two.set_allreduce(mirrored, 0, 2)
+    two.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+    s2 = two.iterate(4)
+    dup = bundle.BaProblem(10, 3000, np.concatenate([pb["obs_cam"]] * 2),
+                           np.concatenate([pb["obs_pt"], pb["obs_pt"] + 1500]), np.concatenate([pb["obs_xy"]] * 2), ctx=ctx)
+    dup.set_params(pb["cams0"], np.concatenate([pb["pts0"]] * 2), pb["focal0"])
+    s1 = dup.iterate(4)
+    dim = 6 * 10 + 1
+    assert dim * dim + 3 * dim + 16 + 2 in calls and 8 in calls     # [S|g|F^T b|diag|scalars] and the step scalars
+    assert s1.successful_steps == s2.successful_steps
+    assert abs(s1.initial_cost - s2.initial_cost) <= 1e-12 * s1.initial_cost
+    assert abs(s1.final_cost - s2.final_cost) <= 1e-9 * s1.final_cost
+    c2, p2, f2 = two.get_params()
+    c1, p1, f1 = dup.get_params()
+    assert np.allclose(c1, c2, rtol=1e-9, atol=1e-12) and np.allclose(p1[:1500], p2, rtol=1e-9, atol=1e-12)
+    assert abs(f1 - f2) <= 1e-9 * f1
+
+
+def test_cfg4_iterations_decrease_cost(ctx):
+    """BASELINE cfg4 shape (200 cams / 100k points / 1M obs): LM iterations run and descend."""
+    pb = synth.ba_problem(200, 100000, 10, seed=777)
+    prob = bundle.BaProblem(200, 100000, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
+    prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+    s = prob.iterate(3)
+    s2 = prob.iterate(3)
+    assert s2.iterations == 6 and s2.final_cost <= s.final_cost < s.initial_cost
+    assert np.isfinite(s2.final_cost)

@@ -1,0 +1,143 @@
+"""GPU: the HIP matcher through the C ABI against the oracle, the golden vectors, and -- at the
+BASELINE cfg2 size -- size-independent properties."""
+import numpy as np
+import pytest
+
+from sfm_danpipeline_amd import _lib, matcher, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _plan(ctx, imgs, pairs, norm=_lib.L2):
+    s = matcher.ImageSet(imgs, norm=norm, ctx=ctx)
+    s.prepare_async()
+    pl = matcher.MatchPlan(s, pairs)
+    pl.run_async(0.8)
+    return s, pl
+
+
+def _assert_pair(orc, pl, p, q, t, norm):
+    ki, kd = pl.fetch_knn(p)
+    r = orc.match_knn2(q, t, norm=(orc.NORM_HAMMING if norm == _lib.HAMMING else orc.NORM_L2), want_knn=True, threads=8)
+    assert np.array_equal(ki, r[3])
+    assert np.array_equal(kd.view(np.uint32), r[4].view(np.uint32))
+    a = pl.fetch_pair(p)
+    assert np.array_equal(a[0], r[0]) and np.array_equal(a[1], r[1])
+    assert np.array_equal(a[2].view(np.uint32), r[2].view(np.uint32))
+
+
+def test_golden_l2(ctx, golden):
+    g = golden["match_l2"]
+    for name in g["names"]:
+        for cast in (np.uint8, np.float32):
+            q, t = g[f"{name}_q"].astype(cast), g[f"{name}_t"].astype(cast)
+            mq, mt, md = matcher.get_matching(q, t, ctx=ctx)          # the getMatching drop-in
+            assert np.array_equal(mq, g[f"{name}_mq"]) and np.array_equal(mt, g[f"{name}_mt"]), name
+            assert np.array_equal(md.view(np.uint32), g[f"{name}_md"].view(np.uint32)), name
+            if q.shape[0] and t.shape[0]:
+                s, pl = _plan(ctx, [q, t], [[0, 1]])
+                ki, kd = pl.fetch_knn(0)
+                assert np.array_equal(ki, g[f"{name}_idx"]), name
+                assert np.array_equal(kd.view(np.uint32), g[f"{name}_dist"].view(np.uint32)), name
+
+
+def test_golden_hamming_and_reference_literal_l2(ctx, golden):
+    g = golden["match_hamming"]
+    for name in g["names"]:
+        q, t = g[f"{name}_q"], g[f"{name}_t"]
+        mq, mt, md = matcher.get_matching(q, t, norm=_lib.HAMMING, ctx=ctx)
+        assert np.array_equal(mq, g[f"{name}_mq"]) and np.array_equal(mt, g[f"{name}_mt"])
+        assert np.array_equal(md, g[f"{name}_md"])
+        s, pl = _plan(ctx, [q, t], [[0, 1]], _lib.L2)  # cv::NORM_L2 on CV_8U rows, src/Sfm.cpp:593
+        ki, kd = pl.fetch_knn(0)
+        assert np.array_equal(ki, g[f"{name}_l2idx"])
+        assert np.array_equal(kd.view(np.uint32), g[f"{name}_l2dist"].view(np.uint32))
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 2), (33, 257), (700, 700), (300, 2049), (64, 32)])
+def test_sift_shapes_vs_oracle(ctx, orc, nq, nt):
+    imgs = synth.sift_image_set(2, max(nq, nt), 128, bank=max(nq, nt) + 200, seed=nq * 7 + nt)
+    q, t = imgs[0][:nq], imgs[1][:nt]
+    s, pl = _plan(ctx, [q, t], [[0, 1]])
+    _assert_pair(orc, pl, 0, q, t, _lib.L2)
+
+
+def test_extreme_values_take_the_exact_fixup_path(ctx, orc):
+    rng = np.random.default_rng(3)
+    q = (rng.integers(0, 2, (200, 128)) * 255).astype(np.float32)
+    t = (rng.integers(0, 2, (300, 128)) * 255).astype(np.float32)   # s ~ 4.2M: sqrtf collisions
+    s, pl = _plan(ctx, [q, t], [[0, 1]])
+    _assert_pair(orc, pl, 0, q, t, _lib.L2)
+
+
+def test_non_integer_rows_use_the_exact_kernel(ctx, orc):
+    imgs = synth.sift_image_set(3, 200, 128, bank=300, seed=5)
+    mixed = [imgs[0] + 0.25, imgs[1], imgs[2]]        # one non-integer image poisons only its pairs
+    s, pl = _plan(ctx, mixed, [[0, 1], [1, 2], [2, 0]])
+    for p, (a, b) in enumerate([(0, 1), (1, 2), (2, 0)]):
+        _assert_pair(orc, pl, p, mixed[a], mixed[b], _lib.L2)
+
+
+@pytest.mark.parametrize("dim", [32, 61, 64, 96, 200, 300])
+def test_other_descriptor_widths(ctx, orc, dim):
+    rng = np.random.default_rng(dim)
+    q = rng.integers(0, 256, (150, dim), dtype=np.uint8)
+    t = rng.integers(0, 256, (170, dim), dtype=np.uint8)
+    s, pl = _plan(ctx, [q, t], [[0, 1]])
+    _assert_pair(orc, pl, 0, q, t, _lib.L2)
+
+
+def test_hamming_vs_oracle_and_ragged_set(ctx, orc):
+    orbs = synth.orb_image_set(4, 900, bank=1200, seed=8)
+    ragged = [orbs[0], orbs[1][:513], orbs[2][:2], orbs[3][:0]]
+    pairs = [[0, 1], [1, 0], [0, 2], [2, 1], [0, 3], [3, 0]]
+    s, pl = _plan(ctx, ragged, pairs, _lib.HAMMING)
+    for p, (a, b) in enumerate(pairs):
+        if len(ragged[a]) and len(ragged[b]):
+            _assert_pair(orc, pl, p, ragged[a], ragged[b], _lib.HAMMING)
+    assert pl.counts()[4] == 0 and pl.counts()[5] == 0
+
+
+def test_batched_plan_equals_single_pair_calls(ctx):
+    imgs = synth.sift_image_set(6, 400, 128, bank=600, seed=9)
+    pairs = synth.all_pairs(6)
+    s, pl = _plan(ctx, imgs, pairs)
+    cnt, oq, ot, od = pl.fetch()
+    off = 0
+    for p, (a, b) in enumerate(pairs):
+        mq, mt, md = matcher.get_matching(imgs[a], imgs[b], ctx=ctx)
+        n = cnt[p]
+        assert n == len(mq) and np.array_equal(oq[off:off + n], mq) and np.array_equal(ot[off:off + n], mt)
+        assert np.array_equal(od[off:off + n], md)
+        off += n
+
+
+def test_cfg2_full_size_properties(ctx, orc):
+    """BASELINE cfg2 (50 x 2000 x SIFT-128, 1225 pairs): determinism, ordering, planted-match
+    recovery, and three pairs bit-checked against the oracle."""
+    imgs = synth.sift_image_set()
+    pairs = synth.all_pairs(len(imgs))
+    s, pl = _plan(ctx, imgs, pairs)
+    cnt, oq, ot, od = pl.fetch()
+    s.prepare_async()
+    pl.run_async(0.8)
+    cnt2, oq2, ot2, od2 = pl.fetch()
+    assert np.array_equal(cnt, cnt2) and np.array_equal(oq, oq2) and np.array_equal(ot, ot2) and np.array_equal(od, od2)
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    for p in range(len(pairs)):
+        qs = oq[off[p]:off[p + 1]]
+        assert np.all(np.diff(qs) > 0)                     # ascending queryIdx inside a pair
+        assert len(np.unique(ot[off[p]:off[p + 1]])) >= 0.9 * cnt[p]
+    assert 150 < cnt.mean() < 260                          # ~10 % of 2000 rows are shared per pair
+    assert od.max() < 400                                  # true matches sit at ~sigma*sqrt(2*128)
+    for p in (0, 611, 1224):
+        _assert_pair(orc, pl, p, imgs[pairs[p, 0]], imgs[pairs[p, 1]], _lib.L2)
+
+
+def test_train_permutation_property(ctx):
+    """Permuting train rows permutes trainIdx and nothing else (no ties in this data)."""
+    imgs = synth.sift_image_set(2, 1500, 128, bank=2500, seed=12)
+    perm = np.random.default_rng(0).permutation(1500)
+    a = matcher.get_matching(imgs[0], imgs[1], ctx=ctx)
+    b = matcher.get_matching(imgs[0], imgs[1][perm], ctx=ctx)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], perm[b[1]]) and np.array_equal(a[2], b[2])
