@@ -39,7 +39,6 @@
 namespace {
 
 constexpr int CAMD = 40;     // doubles per camera table: R[9] t[3] dR/dw[27] pad
-constexpr int NB = 64;       // Cholesky panel width
 constexpr int SC = 16;       // scalar slots at the tail of the all-reduce buffer (+ world)
 constexpr int FB_MAXN = 64;  // fallback kernel: max observations per point
 
@@ -73,6 +72,7 @@ struct BaDev {
   // reduced system: red = [S dim*dim | g dim | gF dim | dc dim | sc SC+world]
   double* red;
   double* z;     // dim solution
+  double* dinv;  // dim: 1 / diag(L)
   double* red2;  // 16 scalars of the step evaluation
   int* info;     // cholesky failure flag
 };
@@ -677,181 +677,254 @@ __global__ __launch_bounds__(1024) void ba_finalize(BaDev d, double radius, doub
 }
 
 // ---------------------------------------------------------------- dense Cholesky (f64)
-// A is the row-major upper triangle of S == column-major lower triangle: L(r,c) = A[c*ld + r].
-// The rhs is carried as an extra row: y[c] plays L(n, c).
+// A is the row-major upper triangle of S == column-major lower triangle: L(r,c) = A[c*ld + r],
+// r >= c.  The rhs g is carried as one extra row (tile row index nt) so that y = L^-1 g falls out
+// of the factorisation; chol_backsolve then solves L^T z = y.
+//
+// One launch per 32-column panel (right-looking, update of the previous panel fused in):
+// launch k applies the pending rank-32 update of panel k-1 to every remaining tile (ti >= tj
+// >= k, one wave per 32x32 tile, lane = tile row, registers = tile columns, the two half-waves
+// split the columns by parity) and, for the tiles of block column k, goes on to factor: each of
+// those waves redundantly updates + factors the 32x32 diagonal tile in registers (no
+// inter-workgroup dependency inside a launch) and solves its own tile against it.
 #define LA(r, c) A[(size_t)(c) * ld + (r)]
+constexpr int CB = 32;
+constexpr int CBP = 34;  // LDS row pitch in doubles (keeps ds_read_b128 16-byte aligned)
 
-// panel step: factor the NBxNB diagonal block (every block redundantly, in LDS), then solve the
-// 64-row tile this block owns against it.  Block 0 owns the diagonal write-back and the rhs row.
-__global__ __launch_bounds__(256) void chol_panel(double* __restrict__ A, double* __restrict__ y, int n, int ld,
-                                                  int k0, int* __restrict__ info) {
-  __shared__ double sD[NB][NB + 1];
-  __shared__ double sX[NB][NB + 1];
-  const int nb = min(NB, n - k0);
-  const int tid = threadIdx.x;
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e % NB, c = e / NB;
-    sD[r][c] = (r < nb && c < nb && r >= c) ? LA(k0 + r, k0 + c) : (r == c ? 1.0 : 0.0);
-  }
-  __syncthreads();
-  // right-looking factorisation of sD (lower)
-  for (int j = 0; j < nb; ++j) {
-    const double djj = sD[j][j];
-    __syncthreads();
-    if (!(djj > 0.0)) {
-      if (blockIdx.x == 0 && tid == 0) atomicExch(info, k0 + j + 1);
-      return;  // uniform: every thread read the same djj
-    }
-    const double dj = sqrt(djj);
-    if (tid == 0) sD[j][j] = dj;
-    for (int r = j + 1 + tid; r < nb; r += 256) sD[r][j] /= dj;
-    __syncthreads();
-    // trailing update of columns j+1.. : element (r,c), r >= c > j
-    const int m = nb - j - 1;
-    for (int e = tid; e < m * m; e += 256) {
-      const int r = j + 1 + e / m, c = j + 1 + e % m;
-      if (r >= c) sD[r][c] -= sD[r][j] * sD[c][j];
-    }
-    __syncthreads();
-  }
-  // this block's rows
-  int r0, nr;
-  const bool is_rhs = blockIdx.x == 0;
-  if (is_rhs) {
-    r0 = 0;
-    nr = 1;
-    for (int e = tid; e < nb * nb; e += 256) {
-      const int r = e % nb, c = e / nb;
-      if (r >= c) LA(k0 + r, k0 + c) = sD[r][c];
-    }
+__device__ __forceinline__ double rsqrt_f64(double d) {
+  double r = __builtin_amdgcn_rsq(d);
+  r = r * (1.5 - 0.5 * d * r * r);
+  r = r * (1.5 - 0.5 * d * r * r);
+  return r;
+}
+
+__global__ __launch_bounds__(64) void chol_step(double* __restrict__ A, double* __restrict__ y,
+                                                double* __restrict__ dinv, int n, int ld, int k,
+                                                int* __restrict__ info) {
+  // tiles are staged through LDS with rolled, coalesced loops (few address registers) and
+  // moved into register rows with static-offset ds_reads
+  __shared__ __attribute__((aligned(16))) double sT[CB * CBP];  // own tile            [row][col]
+  __shared__ __attribute__((aligned(16))) double sR[CB * CBP];  // my rows of panel k-1 [row][kk]
+  __shared__ __attribute__((aligned(16))) double sL[CB * CBP];  // block-tj rows of panel k-1 [c][kk]
+  __shared__ __attribute__((aligned(16))) double sD[CB * CBP];  // diagonal tile / L_kk
+  const int nt = (n + CB - 1) / CB;
+  const int m = nt - k;  // remaining tile rows (the rhs row comes on top)
+  // block -> tile: the m+1 tiles of block column k first (they carry the factorisation)
+  int ti_rel, tj_rel;
+  if ((int)blockIdx.x <= m) {
+    ti_rel = blockIdx.x;
+    tj_rel = 0;
   } else {
-    r0 = k0 + nb + (blockIdx.x - 1) * NB;
-    nr = min(NB, n - r0);
-  }
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e % NB, c = e / NB;
-    double v = 0.0;
-    if (r < nr && c < nb) v = is_rhs ? y[k0 + c] : LA(r0 + r, k0 + c);
-    sX[r][c] = v;
-  }
-  __syncthreads();
-  // X <- X L^-T : column by column
-  for (int j = 0; j < nb; ++j) {
-    const double dj = sD[j][j];
-    for (int r = tid; r < nr; r += 256) sX[r][j] /= dj;
-    __syncthreads();
-    const int m = nb - j - 1;
-    for (int e = tid; e < nr * m; e += 256) {
-      const int r = e % nr, c = j + 1 + e / nr;
-      sX[r][c] -= sX[r][j] * sD[c][j];
+    int t = blockIdx.x - (m + 1);
+    ti_rel = 1;
+    while (true) {
+      const int w = ti_rel < m ? ti_rel : m - 1;  // tj_rel in 1..min(ti_rel, m-1)
+      if (t < w) break;
+      t -= w;
+      ++ti_rel;
     }
-    __syncthreads();
+    tj_rel = 1 + t;
   }
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e % NB, c = e / NB;
-    if (r < nr && c < nb) {
-      if (is_rhs)
-        y[k0 + c] = sX[r][c];
-      else
-        LA(r0 + r, k0 + c) = sX[r][c];
-    }
-  }
-}
+  const bool is_rhs = ti_rel == m;
+  const bool critical = tj_rel == 0;
+  const int lane = threadIdx.x, rr = lane & 31, half = lane >> 5;
+  const int r0 = (k + ti_rel) * CB, c0 = (k + tj_rel) * CB, p0 = (k - 1) * CB;
 
-// trailing update with the panel of step k0: tile (tr >= tc) of the remaining matrix, and one
-// extra tile row for the rhs.  64x64 outputs, K = nb, 4x4 outputs per thread.
-__global__ __launch_bounds__(256) void chol_update(double* __restrict__ A, double* __restrict__ y, int n, int ld,
-                                                   int k0, int ntile) {
-  __shared__ double sR[NB][NB + 1];  // rows of the tile-row block   [row][k]
-  __shared__ double sC[NB][NB + 1];  // rows of the tile-col block   [col][k]
-  const int nb = min(NB, n - k0);
-  const int base = k0 + nb;
-  // decode blockIdx -> (tr, tc), tr in [0, ntile] (ntile = rhs row), tc <= min(tr, ntile-1)
-  int tr = 0, rem = blockIdx.x;
-  while (true) {
-    const int w = min(tr + 1, ntile);
-    if (rem < w) break;
-    rem -= w;
-    ++tr;
-  }
-  const int tc = rem;
-  const bool is_rhs = tr == ntile;
-  const int rr0 = base + tr * NB, cc0 = base + tc * NB;
-  const int nr = is_rhs ? 1 : min(NB, n - rr0), ncol = min(NB, n - cc0);
-  const int tid = threadIdx.x;
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e % NB, k = e / NB;
-    double vr = 0.0, vc = 0.0;
-    if (k < nb) {
-      if (r < nr) vr = is_rhs ? y[k0 + k] : LA(rr0 + r, k0 + k);
-      if (r < ncol) vc = LA(cc0 + r, k0 + k);
+  // ---- global -> LDS (branch-free: clamped addresses + selects; is_rhs/critical/k are uniform)
+  const int nm1 = n - 1;
+#pragma unroll 2
+  for (int e = lane; e < CB * CB; e += 64) {
+    const int r = e & 31, c = e >> 5;
+    const int gr = r0 + r, gc = c0 + c;
+    const int cr = gr < nm1 ? gr : nm1, cc = gc < nm1 ? gc : nm1;
+    double v;
+    if (is_rhs) {
+      v = (r == 0 && gc < n) ? y[cc] : 0.0;
+    } else {
+      const double raw = LA(cr, cc);
+      v = (gr < n && gc < n) ? (gr >= gc ? raw : 0.0) : (gr == gc ? 1.0 : 0.0);  // identity padding
     }
-    sR[r][k] = vr;
-    sC[r][k] = vc;
+    sT[r * CBP + c] = v;
+    if (k > 0) {
+      const int pc = p0 + c;  // always < n
+      const double a = is_rhs ? (r == 0 ? y[pc] : 0.0) : (gr < n ? LA(cr, pc) : 0.0);
+      const int lr = c0 + r, clr = lr < nm1 ? lr : nm1;
+      const double b = lr < n ? LA(clr, pc) : 0.0;
+      sR[r * CBP + c] = a;
+      sL[r * CBP + c] = b;
+    }
+    if (critical && ti_rel != 0) {
+      const int dr = c0 + r, cdr = dr < nm1 ? dr : nm1;
+      const double raw = LA(cdr, cc);
+      sD[r * CBP + c] = (dr < n && gc < n) ? (dr >= gc ? raw : 0.0) : (dr == gc ? 1.0 : 0.0);
+    }
   }
   __syncthreads();
-  const int tx = tid % 16, ty = tid / 16;  // outputs rows ty*4.., cols tx*4..
-  double acc[4][4];
+
+  // ---- pending update of panel k-1: T -= Lr * Lc^T, the half-waves split the columns
+  if (k > 0) {
+    double Lr[CB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int kk = 0; kk < CB; kk += 2) {
+      const double2 a = *(const double2*)(sR + rr * CBP + kk);
+      Lr[kk] = a.x;
+      Lr[kk + 1] = a.y;
+    }
+    // rolled over the 16 columns of this half-wave (a full unroll makes hipcc hoist every LDS
+    // read of the tile and spill); each lane updates its own elements of sT in place
+#pragma unroll 1
+    for (int i = 0; i < 16; ++i) {
+      const double* bc = sL + (2 * i + half) * CBP;
+      double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-  for (int k = 0; k < nb; ++k) {
-    double a[4], b[4];
+      for (int kk = 0; kk < CB; kk += 2) {
+        const double2 b = *(const double2*)(bc + kk);
+        acc0 += Lr[kk] * b.x;
+        acc1 += Lr[kk + 1] * b.y;
+      }
+      sT[rr * CBP + 2 * i + half] -= acc0 + acc1;
+    }
+    if (critical && ti_rel != 0) {  // the diagonal tile gets the same update: Lk = rows of block k
+      double Lk[CB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = sR[ty * 4 + i][k];
+      for (int kk = 0; kk < CB; kk += 2) {
+        const double2 a = *(const double2*)(sL + rr * CBP + kk);
+        Lk[kk] = a.x;
+        Lk[kk + 1] = a.y;
+      }
+#pragma unroll 1
+      for (int i = 0; i < 16; ++i) {
+        const double* bc = sL + (2 * i + half) * CBP;
+        double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = sC[tx * 4 + j][k];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = ty * 4 + i, c = tx * 4 + j;
-      if (r < nr && c < ncol) {
-        if (is_rhs)
-          y[cc0 + c] -= acc[i][j];
-        else if (rr0 + r >= cc0 + c)
-          LA(rr0 + r, cc0 + c) -= acc[i][j];
+        for (int kk = 0; kk < CB; kk += 2) {
+          const double2 b = *(const double2*)(bc + kk);
+          acc0 += Lk[kk] * b.x;
+          acc1 += Lk[kk + 1] * b.y;
+        }
+        sD[rr * CBP + 2 * i + half] -= acc0 + acc1;
       }
     }
+    __syncthreads();
+  }
+
+  if (critical) {
+    // ---- factor the diagonal tile in registers (lane rr = row, both half-waves alike)
+    const double* dsrc = (ti_rel == 0) ? sT : sD;
+    double D[CB];
+#pragma unroll
+    for (int c = 0; c < CB; c += 2) {
+      const double2 a = *(const double2*)(dsrc + rr * CBP + c);
+      D[c] = a.x;
+      D[c + 1] = a.y;
+    }
+    bool bad = false;  // 1/diag goes to sR[CB + j] (read back by the panel solve / the owner)
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+      const double djj = __shfl(D[j], j);
+      bad |= !(djj > 0.0);
+      const double r = rsqrt_f64(djj);
+      if (lane == 0) sR[CB + j] = r;
+      double l = D[j] * r;
+      if (rr == j) l = djj * r;
+      D[j] = l;
+      if (j + 1 < CB) {
+        __syncthreads();
+        if (half == 0) sR[rr] = l;  // pivot column, broadcast through LDS
+        __syncthreads();
+#pragma unroll
+        for (int c = j + 1; c < CB; ++c) D[c] -= l * sR[c];
+      }
+    }
+    if (bad && ti_rel == 0 && lane == 0) atomicExch(info, k * CB + 1);  // the host discards the step
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+      for (int c = 0; c < CB; ++c) sD[rr * CBP + c] = (c <= rr) ? D[c] : 0.0;  // L_kk
+    }
+    __syncthreads();
+    if (ti_rel == 0) {
+      // the diagonal tile's owner publishes L_kk and 1/diag
+#pragma unroll 2
+      for (int e = lane; e < CB * CB; e += 64) {
+        const int r = e & 31, c = e >> 5;
+        if (r >= c && r0 + r < n) LA(r0 + r, c0 + c) = sD[r * CBP + c];
+      }
+      if (lane < CB && c0 + lane < n) dinv[c0 + lane] = sR[CB + lane];
+      return;
+    }
+    // ---- panel tile (or the rhs row): X = T L_kk^-T.  Row rr of T stays in LDS (sT), L_kk is
+    // broadcast from sD, 1/diag from sR; rolled loops (no register arrays -> no spills).  Both
+    // half-waves compute and store identical values.
+    double* tr = sT + rr * CBP;
+#pragma unroll 1
+    for (int j = 0; j < CB; ++j) {
+      const double* lj = sD + j * CBP;
+      double acc0 = tr[j], acc1 = 0.0;
+      int c = 0;
+#pragma unroll 4
+      for (; c + 1 < j; c += 2) {
+        const double2 b = *(const double2*)(lj + c);
+        const double2 t = *(const double2*)(tr + c);
+        acc0 -= t.x * b.x;
+        acc1 -= t.y * b.y;
+      }
+      if (c < j) acc0 -= tr[c] * lj[c];
+      tr[j] = (acc0 + acc1) * sR[CB + j];
+    }
+    __syncthreads();
+  }
+
+  // ---- LDS -> global
+#pragma unroll 2
+  for (int e = lane; e < CB * CB; e += 64) {
+    const int r = e & 31, c = e >> 5;
+    const int gr = r0 + r, gc = c0 + c;
+    if (gc >= n) continue;
+    if (is_rhs) {
+      if (r == 0) y[gc] = sT[c];
+    } else if (gr < n && gr >= gc) {
+      LA(gr, gc) = sT[r * CBP + c];
+    }
+  }
 }
 
-// L^T z = y, blocked from the last panel up; single workgroup.
+// L^T z = y.  U = L^T is upper triangular and row-major in this storage (U[i][j] = A[i*ld + j]).
+// Single workgroup, 32-row blocks from the bottom: one wave solves the diagonal block with
+// shuffles, then every thread folds the block's solution into the rows above.
 __global__ __launch_bounds__(1024) void chol_backsolve(const double* __restrict__ A, double* __restrict__ y,
-                                                       double* __restrict__ z, int n, int ld) {
-  __shared__ double sD[NB][NB + 1];
-  __shared__ double sz[NB];
+                                                       const double* __restrict__ dinv, double* __restrict__ z,
+                                                       int n, int ld) {
+  __shared__ double sz[CB];
   const int tid = threadIdx.x;
-  const int nblk = (n + NB - 1) / NB;
-  for (int kb = nblk - 1; kb >= 0; --kb) {
-    const int k0 = kb * NB, nb = min(NB, n - k0);
-    for (int e = tid; e < NB * NB; e += 1024) {
-      const int r = e % NB, c = e / NB;
-      sD[r][c] = (r < nb && c < nb && r >= c) ? LA(k0 + r, k0 + c) : 0.0;
+  const int nt = (n + CB - 1) / CB;
+  for (int kb = nt - 1; kb >= 0; --kb) {
+    const int k0 = kb * CB;
+    if (tid < 64) {
+      const int i = tid & 31, gi = k0 + i;
+      double u[CB];
+#pragma unroll
+      for (int j = 0; j < CB; ++j) u[j] = (gi < n && k0 + j < n && j > i) ? A[(size_t)gi * ld + k0 + j] : 0.0;
+      double yi = gi < n ? y[gi] : 0.0;
+      const double di = gi < n ? dinv[gi] : 0.0;
+#pragma unroll
+      for (int j = CB - 1; j >= 0; --j) {
+        const double zj = __shfl(yi * di, j);
+        if (i == j) yi = zj;
+        if (i < j) yi -= u[j] * zj;
+      }
+      if (tid < CB) {
+        sz[i] = yi;
+        if (gi < n) z[gi] = yi;
+      }
     }
     __syncthreads();
-    if (tid < 64) {  // one wave: lane i owns unknown i of the block
-      double yi = tid < nb ? y[k0 + tid] : 0.0;
-      for (int j = nb - 1; j >= 0; --j) {
-        const double zj = __shfl(yi, j) / sD[j][j];
-        if (tid == j) yi = zj;
-        if (tid < j) yi -= sD[j][tid] * zj;
-      }
-      if (tid < nb) {
-        sz[tid] = yi;
-        z[k0 + tid] = yi;
-      }
-    }
-    __syncthreads();
-    for (int c = tid; c < k0; c += 1024) {
+    for (int i = tid; i < k0; i += 1024) {
+      const double* ui = A + (size_t)i * ld + k0;
       double acc = 0.0;
-      for (int j = 0; j < nb; ++j) acc += LA(k0 + j, c) * sz[j];
-      y[c] -= acc;
+#pragma unroll
+      for (int j = 0; j < CB; ++j) acc += (k0 + j < n ? ui[j] : 0.0) * sz[j];
+      y[i] -= acc;
     }
     __syncthreads();
   }
@@ -1201,6 +1274,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   BA_A(d.diag, b->dim);
   BA_A(d.red, b->red_count);
   BA_A(d.z, b->dim);
+  BA_A(d.dinv, b->dim);
   BA_A(d.red2, 16);
   BA_A(d.info, 1);
   BA_A(b->d_cam_used, n_cam);
@@ -1360,19 +1434,15 @@ static int ba_reduced_solve(sfmhip_ba* b) {
   double* A = d.red;
   double* y = d.red + (size_t)n * n;  // g becomes y = L^-1 g
   SFM_HIP_TRY(hipMemsetAsync(d.info, 0, sizeof(int), st));
-  for (int k0 = 0; k0 < n; k0 += NB) {
-    const int nb = std::min(NB, n - k0);
-    const int rem = n - k0 - nb;
-    const int ntile = (rem + NB - 1) / NB;
-    hipLaunchKernelGGL(chol_panel, dim3(1 + ntile), dim3(256), 0, st, A, y, n, d.ld, k0, d.info);
-    // tiles (tr>=tc) plus the rhs tile row
-    const int nblk = ntile * (ntile + 1) / 2 + ntile;
-    if (nblk > 0) hipLaunchKernelGGL(chol_update, dim3(nblk), dim3(256), 0, st, A, y, n, d.ld, k0, ntile);
-    b->launches += 1 + (nblk > 0);
+  const int nt = (n + CB - 1) / CB;
+  for (int k = 0; k < nt; ++k) {
+    const int m = nt - k;
+    const int nblk = m * (m + 1) / 2 + m;
+    hipLaunchKernelGGL(chol_step, dim3(nblk), dim3(64), 0, st, A, y, d.dinv, n, d.ld, k, d.info);
   }
-  hipLaunchKernelGGL(chol_backsolve, dim3(1), dim3(1024), 0, st, A, y, d.z, n, d.ld);
+  hipLaunchKernelGGL(chol_backsolve, dim3(1), dim3(1024), 0, st, A, y, d.dinv, d.z, n, d.ld);
   SFM_HIP_TRY(hipGetLastError());
-  b->launches += 1;
+  b->launches += nt + 1;
   return SFMHIP_OK;
 }
 
