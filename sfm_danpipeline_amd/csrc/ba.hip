@@ -69,7 +69,8 @@ struct BaDev {
   double* scale_p;  // np*3
   double* scale_f;  // 1
   double* diag;     // dim (clamped)
-  // reduced system: red = [S dim*dim | g dim | gF dim | dc dim | sc SC+world]
+  // reduced system: red = [S ld*ld | g ld | gF ld | dc ld | sc SC+world], ld = dim rounded up
+  // to 32 (row stride of S; the padded diagonal is 1, everything else in the padding 0)
   double* red;
   double* z;     // dim solution
   double* dinv;  // dim: 1 / diag(L)
@@ -78,10 +79,10 @@ struct BaDev {
 };
 
 __device__ __forceinline__ double* red_S(const BaDev& d) { return d.red; }
-__device__ __forceinline__ double* red_g(const BaDev& d) { return d.red + (size_t)d.dim * d.dim; }
-__device__ __forceinline__ double* red_gF(const BaDev& d) { return d.red + (size_t)d.dim * d.dim + d.dim; }
-__device__ __forceinline__ double* red_dc(const BaDev& d) { return d.red + (size_t)d.dim * d.dim + 2 * d.dim; }
-__device__ __forceinline__ double* red_sc(const BaDev& d) { return d.red + (size_t)d.dim * d.dim + 3 * d.dim; }
+__device__ __forceinline__ double* red_g(const BaDev& d) { return d.red + (size_t)d.ld * d.ld; }
+__device__ __forceinline__ double* red_gF(const BaDev& d) { return d.red + (size_t)d.ld * d.ld + d.ld; }
+__device__ __forceinline__ double* red_dc(const BaDev& d) { return d.red + (size_t)d.ld * d.ld + 2 * d.ld; }
+__device__ __forceinline__ double* red_sc(const BaDev& d) { return d.red + (size_t)d.ld * d.ld + 3 * d.ld; }
 
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void atomic_max_pos_f64(double* p, double v) {
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(64) void ba_eliminate(BaDev d, const Chunk* __restr
   const int lane = threadIdx.x;
   const int n = ch.n;
   const int* cams = sig_cams + ch.sig_off;
-  const int dim = d.dim, fo = 6 * d.nc;
+  const int dim = d.ld /* row stride of S */, fo = 6 * d.nc;
   const bool is_obs = lane < n;
   const int mycam = cams[is_obs ? lane : 0];
 
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(64) void ba_eliminate_generic(BaDev d, const int* _
   const int p = plist[blockIdx.x];
   const int lane = threadIdx.x;
   const int k0 = d.optr[p], n = d.optr[p + 1] - k0;
-  const int dim = d.dim, fo = 6 * d.nc;
+  const int dim = d.ld /* row stride of S */, fo = 6 * d.nc;
   const bool is_obs = lane < n;
   const int k = k0 + (is_obs ? lane : 0);
   const int mycam = d.ocam[k];
@@ -661,10 +662,11 @@ __global__ __launch_bounds__(1024) void ba_finalize(BaDev d, double radius, doub
   for (int i = threadIdx.x; i < d.dim; i += blockDim.x) {
     const double v = fmin(fmax(dc[i], lm_lo), lm_hi);
     d.diag[i] = v;
-    if (add_diag) S[(size_t)i * d.dim + i] += v / radius;
+    if (add_diag) S[(size_t)i * d.ld + i] += v / radius;
     const double s = i < 6 * d.nc ? d.scale_c[i] : *d.scale_f;
     gm = fmax(gm, fabs(gF[i] / s));
   }
+  for (int i = d.dim + threadIdx.x; i < d.ld; i += blockDim.x) S[(size_t)i * d.ld + i] = 1.0;  // padding
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_down(gm, o));
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = gm;
@@ -678,18 +680,25 @@ __global__ __launch_bounds__(1024) void ba_finalize(BaDev d, double radius, doub
 
 // ---------------------------------------------------------------- dense Cholesky (f64)
 // A is the row-major upper triangle of S == column-major lower triangle: L(r,c) = A[c*ld + r],
-// r >= c.  The rhs g is carried as one extra row (tile row index nt) so that y = L^-1 g falls out
-// of the factorisation; chol_backsolve then solves L^T z = y.
+// r >= c, so a column of L is contiguous.  ld = dim rounded up to 32 (identity on the padded
+// diagonal), so no tile needs a bounds check.  The rhs g is carried as one extra tile row
+// (row 0 of tile row nt, kept in y) so that y = L^-1 g falls out of the factorisation;
+// chol_backsolve then solves L^T z = y.
 //
-// One launch per 32-column panel (right-looking, update of the previous panel fused in):
-// launch k applies the pending rank-32 update of panel k-1 to every remaining tile (ti >= tj
-// >= k, one wave per 32x32 tile, lane = tile row, registers = tile columns, the two half-waves
-// split the columns by parity) and, for the tiles of block column k, goes on to factor: each of
-// those waves redundantly updates + factors the 32x32 diagonal tile in registers (no
-// inter-workgroup dependency inside a launch) and solves its own tile against it.
-#define LA(r, c) A[(size_t)(c) * ld + (r)]
+// One launch per 32-column panel (right-looking, the update of the previous panel fused in).
+// Launch k, one 2-wave workgroup per remaining tile (ti >= tj >= k):
+//   * tiles right of block column k only take the pending rank-32 update of panel k-1:
+//     T -= L(ti,k-1) L(tj,k-1)^T on v_mfma_f64_16x16x4_f64, operands straight from global
+//     memory (16 contiguous doubles per k index), each wave one 16-column half of the tile;
+//   * the tiles of block column k carry the factorisation, with no inter-workgroup dependency
+//     inside the launch: wave 0 updates + factors the diagonal tile (every such workgroup
+//     redundantly: POTRF in registers, row per lane, pivot and next-column terms by
+//     v_readlane, the rest of the column broadcast through LDS), wave 1 updates the
+//     workgroup's own tile and solves it against L_kk (row per lane), trailing the
+//     factorisation by one 8-column block (4 workgroup barriers).
 constexpr int CB = 32;
-constexpr int CBP = 34;  // LDS row pitch in doubles (keeps ds_read_b128 16-byte aligned)
+constexpr int CBP = 34;  // LDS row pitch in doubles: 16-byte aligned rows, conflict-free tile writes
+typedef double v4d __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double rsqrt_f64(double d) {
   double r = __builtin_amdgcn_rsq(d);
@@ -698,16 +707,25 @@ __device__ __forceinline__ double rsqrt_f64(double d) {
   return r;
 }
 
-__global__ __launch_bounds__(64) void chol_step(double* __restrict__ A, double* __restrict__ y,
-                                                double* __restrict__ dinv, int n, int ld, int k,
-                                                int* __restrict__ info) {
-  // tiles are staged through LDS with rolled, coalesced loops (few address registers) and
-  // moved into register rows with static-offset ds_reads
-  __shared__ __attribute__((aligned(16))) double sT[CB * CBP];  // own tile            [row][col]
-  __shared__ __attribute__((aligned(16))) double sR[CB * CBP];  // my rows of panel k-1 [row][kk]
-  __shared__ __attribute__((aligned(16))) double sL[CB * CBP];  // block-tj rows of panel k-1 [c][kk]
-  __shared__ __attribute__((aligned(16))) double sD[CB * CBP];  // diagonal tile / L_kk
-  const int nt = (n + CB - 1) / CB;
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+// P[c][r] -= sum_kk Lc[c][kk] * Lr[r][kk] for the 16x16 sub-tiles (ci, ri) of a 32x32 tile.
+// MFMA roles: A operand = Lc (lane: row c = lane&15, k = lane>>4), B operand = Lr (col r =
+// lane&15), so that the result's lane index is the memory-contiguous tile row r and its 4
+// registers are tile columns c = (lane>>4) + 4g.
+#define CHOL_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0)
+
+__global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double* __restrict__ y,
+                                                 double* __restrict__ dinv, int ld, int nt, int k,
+                                                 int* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) double sD[CB * CBP];   // updated diagonal tile [row][col]
+  __shared__ __attribute__((aligned(16))) double sT[CB * CBP];   // updated own tile      [row][col]
+  __shared__ __attribute__((aligned(16))) double sLr[CB * CBP];  // L_kk [row][col]
+  __shared__ double sdi[CB];                                     // 1 / diag(L_kk)
   const int m = nt - k;  // remaining tile rows (the rhs row comes on top)
   // block -> tile: the m+1 tiles of block column k first (they carry the factorisation)
   int ti_rel, tj_rel;
@@ -726,210 +744,251 @@ __global__ __launch_bounds__(64) void chol_step(double* __restrict__ A, double* 
     tj_rel = 1 + t;
   }
   const bool is_rhs = ti_rel == m;
-  const bool critical = tj_rel == 0;
-  const int lane = threadIdx.x, rr = lane & 31, half = lane >> 5;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j16 = lane & 15, q = lane >> 4;
   const int r0 = (k + ti_rel) * CB, c0 = (k + tj_rel) * CB, p0 = (k - 1) * CB;
+  const bool rlane = j16 == 0;  // the rhs tile row has one real row: tile row 0
 
-  // ---- global -> LDS (branch-free: clamped addresses + selects; is_rhs/critical/k are uniform)
-  const int nm1 = n - 1;
-#pragma unroll 2
-  for (int e = lane; e < CB * CB; e += 64) {
-    const int r = e & 31, c = e >> 5;
-    const int gr = r0 + r, gc = c0 + c;
-    const int cr = gr < nm1 ? gr : nm1, cc = gc < nm1 ? gc : nm1;
-    double v;
-    if (is_rhs) {
-      v = (r == 0 && gc < n) ? y[cc] : 0.0;
-    } else {
-      const double raw = LA(cr, cc);
-      v = (gr < n && gc < n) ? (gr >= gc ? raw : 0.0) : (gr == gc ? 1.0 : 0.0);  // identity padding
-    }
-    sT[r * CBP + c] = v;
-    if (k > 0) {
-      const int pc = p0 + c;  // always < n
-      const double a = is_rhs ? (r == 0 ? y[pc] : 0.0) : (gr < n ? LA(cr, pc) : 0.0);
-      const int lr = c0 + r, clr = lr < nm1 ? lr : nm1;
-      const double b = lr < n ? LA(clr, pc) : 0.0;
-      sR[r * CBP + c] = a;
-      sL[r * CBP + c] = b;
-    }
-    if (critical && ti_rel != 0) {
-      const int dr = c0 + r, cdr = dr < nm1 ? dr : nm1;
-      const double raw = LA(cdr, cc);
-      sD[r * CBP + c] = (dr < n && gc < n) ? (dr >= gc ? raw : 0.0) : (dr == gc ? 1.0 : 0.0);
-    }
-  }
-  __syncthreads();
+  // element (tile row r, column index col) of the workgroup's tile row: L(r0+r, col) or, for the
+  // rhs row, y[col] on tile row 0 and zero elsewhere
+  auto ld_row = [&](int r, int col) -> double {
+    if (is_rhs) return r == 0 ? y[col] : 0.0;
+    return A[(size_t)col * ld + r0 + r];
+  };
 
-  // ---- pending update of panel k-1: T -= Lr * Lc^T, the half-waves split the columns
-  if (k > 0) {
-    double Lr[CB];
+  if (tj_rel != 0) {
+    // ---------------- trailing tile: pending update of panel k-1 only (k >= 1 here)
+    const int ci = wave;
+    double a[8], b[2][8];
+    v4d acc[2];
 #pragma unroll
-    for (int kk = 0; kk < CB; kk += 2) {
-      const double2 a = *(const double2*)(sR + rr * CBP + kk);
-      Lr[kk] = a.x;
-      Lr[kk + 1] = a.y;
+    for (int ks = 0; ks < 8; ++ks) {
+      const int kk = p0 + 4 * ks + q;
+      a[ks] = -A[(size_t)kk * ld + c0 + 16 * ci + j16];
+      b[0][ks] = ld_row(j16, kk);
+      b[1][ks] = ld_row(16 + j16, kk);
     }
-    // rolled over the 16 columns of this half-wave (a full unroll makes hipcc hoist every LDS
-    // read of the tile and spill); each lane updates its own elements of sT in place
-#pragma unroll 1
-    for (int i = 0; i < 16; ++i) {
-      const double* bc = sL + (2 * i + half) * CBP;
-      double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-      for (int kk = 0; kk < CB; kk += 2) {
-        const double2 b = *(const double2*)(bc + kk);
-        acc0 += Lr[kk] * b.x;
-        acc1 += Lr[kk + 1] * b.y;
-      }
-      sT[rr * CBP + 2 * i + half] -= acc0 + acc1;
+    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[ri][g] = ld_row(16 * ri + j16, c0 + 16 * ci + q + 4 * g);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      CHOL_MFMA(acc[0], a[ks], b[0][ks]);
+      CHOL_MFMA(acc[1], a[ks], b[1][ks]);
     }
-    if (critical && ti_rel != 0) {  // the diagonal tile gets the same update: Lk = rows of block k
-      double Lk[CB];
 #pragma unroll
-      for (int kk = 0; kk < CB; kk += 2) {
-        const double2 a = *(const double2*)(sL + rr * CBP + kk);
-        Lk[kk] = a.x;
-        Lk[kk + 1] = a.y;
-      }
-#pragma unroll 1
-      for (int i = 0; i < 16; ++i) {
-        const double* bc = sL + (2 * i + half) * CBP;
-        double acc0 = 0.0, acc1 = 0.0;
+    for (int ri = 0; ri < 2; ++ri)
 #pragma unroll
-        for (int kk = 0; kk < CB; kk += 2) {
-          const double2 b = *(const double2*)(bc + kk);
-          acc0 += Lk[kk] * b.x;
-          acc1 += Lk[kk + 1] * b.y;
+      for (int g = 0; g < 4; ++g) {
+        const int col = c0 + 16 * ci + q + 4 * g;
+        if (is_rhs) {
+          if (ri == 0 && rlane) y[col] = acc[ri][g];
+        } else {
+          A[(size_t)col * ld + r0 + 16 * ri + j16] = acc[ri][g];
         }
-        sD[rr * CBP + 2 * i + half] -= acc0 + acc1;
       }
-    }
-    __syncthreads();
+    return;
   }
 
-  if (critical) {
-    // ---- factor the diagonal tile in registers (lane rr = row, both half-waves alike)
-    const double* dsrc = (ti_rel == 0) ? sT : sD;
-    double D[CB];
+  // ---------------- block column k: update, factor the diagonal tile, solve the own tile
+  const bool owner = ti_rel == 0;
+  const int i = lane & 31;  // row of the tile handled by this lane in the row-per-lane phases
+  if (wave == 0 || !owner) {
+    // wave 0: diagonal tile (rows c0..); wave 1: own tile (rows r0.. / the rhs row)
+    const bool diag = wave == 0;
+    double a[2][8], b[2][8];
+    v4d acc[2][2];  // [ci][ri]
+    if (k > 0) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int kk = p0 + 4 * ks + q;
+        a[0][ks] = -A[(size_t)kk * ld + c0 + j16];
+        a[1][ks] = -A[(size_t)kk * ld + c0 + 16 + j16];
+        if (!diag) {
+          b[0][ks] = ld_row(j16, kk);
+          b[1][ks] = ld_row(16 + j16, kk);
+        }
+      }
+    }
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = c0 + 16 * ci + q + 4 * g;
+          acc[ci][ri][g] = diag ? A[(size_t)col * ld + c0 + 16 * ri + j16] : ld_row(16 * ri + j16, col);
+        }
+    if (k > 0) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+          for (int ri = 0; ri < 2; ++ri) CHOL_MFMA(acc[ci][ri], a[ci][ks], diag ? -a[ri][ks] : b[ri][ks]);
+    }
+    double* dst = diag ? sD : sT;
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[(16 * ri + j16) * CBP + 16 * ci + q + 4 * g] = acc[ci][ri][g];
+  }
+  // (each wave reads back only what it wrote itself: LDS operations of one wave stay in order)
+
+  if (wave == 0) {
+    // ---- POTRF of the diagonal tile: lane i = row i (both half-waves alike)
+    double d[CB];
 #pragma unroll
     for (int c = 0; c < CB; c += 2) {
-      const double2 a = *(const double2*)(dsrc + rr * CBP + c);
-      D[c] = a.x;
-      D[c + 1] = a.y;
+      const double2 v = *(const double2*)(sD + i * CBP + c);
+      d[c] = v.x;
+      d[c + 1] = v.y;
     }
-    bool bad = false;  // 1/diag goes to sR[CB + j] (read back by the panel solve / the owner)
+    // left-looking inside the tile: column j first takes the products with the finished columns
+    // (row j of L broadcast from LDS, the newest column through v_readlane so that the pivot
+    // chain does not wait for an LDS round trip), then pivot -> rsq -> scale.  Lanes 32..63
+    // mirror lanes 0..31 (same values to the same LDS addresses).
+    bool bad = false;
 #pragma unroll
     for (int j = 0; j < CB; ++j) {
-      const double djj = __shfl(D[j], j);
+      double acc0 = d[j], acc1 = 0.0;
+#pragma unroll
+      for (int c = 0; c + 1 < j - 1; c += 2) {
+        acc0 -= d[c] * sLr[j * CBP + c];
+        acc1 -= d[c + 1] * sLr[j * CBP + c + 1];
+      }
+      if (j >= 2 && ((j - 1) & 1)) acc0 -= d[j - 2] * sLr[j * CBP + j - 2];
+      if (j >= 1) acc1 -= d[j - 1] * readlane_f64(d[j - 1], j);
+      const double v = acc0 + acc1;
+      const double djj = readlane_f64(v, j);
       bad |= !(djj > 0.0);
       const double r = rsqrt_f64(djj);
-      if (lane == 0) sR[CB + j] = r;
-      double l = D[j] * r;
-      if (rr == j) l = djj * r;
-      D[j] = l;
-      if (j + 1 < CB) {
-        __syncthreads();
-        if (half == 0) sR[rr] = l;  // pivot column, broadcast through LDS
-        __syncthreads();
-#pragma unroll
-        for (int c = j + 1; c < CB; ++c) D[c] -= l * sR[c];
-      }
+      const double l = i >= j ? v * r : 0.0;  // lane j: djj * r = sqrt(djj)
+      d[j] = l;
+      sLr[i * CBP + j] = l;
+      sdi[j] = r;
+      __builtin_amdgcn_sched_barrier(0);  // keep the columns in order
+      if ((j & 7) == 7) __syncthreads();
     }
-    if (bad && ti_rel == 0 && lane == 0) atomicExch(info, k * CB + 1);  // the host discards the step
-    __syncthreads();
-    if (half == 0) {
-#pragma unroll
-      for (int c = 0; c < CB; ++c) sD[rr * CBP + c] = (c <= rr) ? D[c] : 0.0;  // L_kk
-    }
-    __syncthreads();
-    if (ti_rel == 0) {
+    if (owner) {
       // the diagonal tile's owner publishes L_kk and 1/diag
-#pragma unroll 2
-      for (int e = lane; e < CB * CB; e += 64) {
-        const int r = e & 31, c = e >> 5;
-        if (r >= c && r0 + r < n) LA(r0 + r, c0 + c) = sD[r * CBP + c];
+      if (bad && lane == 0) atomicExch(info, k * CB + 1);  // the host discards the step
+      if (lane < CB) {
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+          if (c <= i) A[(size_t)(c0 + c) * ld + c0 + i] = d[c];
+        dinv[c0 + i] = sdi[i];
       }
-      if (lane < CB && c0 + lane < n) dinv[c0 + lane] = sR[CB + lane];
-      return;
     }
-    // ---- panel tile (or the rhs row): X = T L_kk^-T.  Row rr of T stays in LDS (sT), L_kk is
-    // broadcast from sD, 1/diag from sR; rolled loops (no register arrays -> no spills).  Both
-    // half-waves compute and store identical values.
-    double* tr = sT + rr * CBP;
-#pragma unroll 1
-    for (int j = 0; j < CB; ++j) {
-      const double* lj = sD + j * CBP;
-      double acc0 = tr[j], acc1 = 0.0;
-      int c = 0;
-#pragma unroll 4
-      for (; c + 1 < j; c += 2) {
-        const double2 b = *(const double2*)(lj + c);
-        const double2 t = *(const double2*)(tr + c);
-        acc0 -= t.x * b.x;
-        acc1 -= t.y * b.y;
+  } else {
+    // ---- own tile (or the rhs row): X = T L_kk^-T, lane i = row i, one 8-column block behind
+    double t[CB];
+    if (!owner) {
+#pragma unroll
+      for (int c = 0; c < CB; c += 2) {
+        const double2 v = *(const double2*)(sT + i * CBP + c);
+        t[c] = v.x;
+        t[c + 1] = v.y;
       }
-      if (c < j) acc0 -= tr[c] * lj[c];
-      tr[j] = (acc0 + acc1) * sR[CB + j];
     }
-    __syncthreads();
-  }
-
-  // ---- LDS -> global
-#pragma unroll 2
-  for (int e = lane; e < CB * CB; e += 64) {
-    const int r = e & 31, c = e >> 5;
-    const int gr = r0 + r, gc = c0 + c;
-    if (gc >= n) continue;
-    if (is_rhs) {
-      if (r == 0) y[gc] = sT[c];
-    } else if (gr < n && gr >= gc) {
-      LA(gr, gc) = sT[r * CBP + c];
+#pragma unroll
+    for (int jb = 0; jb < CB / 8; ++jb) {
+      __syncthreads();
+      if (!owner) {
+#pragma unroll
+        for (int j = 8 * jb; j < 8 * jb + 8; ++j) {
+          double acc0 = t[j], acc1 = 0.0;
+#pragma unroll
+          for (int c = 0; c + 1 < j; c += 2) {
+            acc0 -= t[c] * sLr[j * CBP + c];
+            acc1 -= t[c + 1] * sLr[j * CBP + c + 1];
+          }
+          if (j & 1) acc0 -= t[j - 1] * sLr[j * CBP + j - 1];
+          t[j] = (acc0 + acc1) * sdi[j];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if (!owner) {
+      if (is_rhs) {
+        if (lane == 0) {
+#pragma unroll
+          for (int c = 0; c < CB; ++c) y[c0 + c] = t[c];
+        }
+      } else if (lane < CB) {
+#pragma unroll
+        for (int c = 0; c < CB; ++c) A[(size_t)(c0 + c) * ld + r0 + i] = t[c];
+      }
     }
   }
 }
+#undef CHOL_MFMA
 
-// L^T z = y.  U = L^T is upper triangular and row-major in this storage (U[i][j] = A[i*ld + j]).
-// Single workgroup, 32-row blocks from the bottom: one wave solves the diagonal block with
-// shuffles, then every thread folds the block's solution into the rows above.
-__global__ __launch_bounds__(1024) void chol_backsolve(const double* __restrict__ A, double* __restrict__ y,
+// L^T z = y.  U = L^T is upper triangular and row-major in this storage (U[i][j] = A[i*ld + j]),
+// so row i of U is contiguous.  Single workgroup of 16 waves, 32-row blocks from the bottom,
+// left-looking: wave w owns rows 2w, 2w+1 of the block and forms y_i - sum_{j beyond the block}
+// U[i][j] z[j] with coalesced 16-byte loads (the loads of the next block are issued before the
+// current block's triangular solve: they do not depend on z); wave 0 then solves the 32x32
+// diagonal block by back-substitution with v_readlane broadcasts.
+__global__ __launch_bounds__(1024) void chol_backsolve(const double* __restrict__ A, const double* __restrict__ y,
                                                        const double* __restrict__ dinv, double* __restrict__ z,
-                                                       int n, int ld) {
-  __shared__ double sz[CB];
-  const int tid = threadIdx.x;
-  const int nt = (n + CB - 1) / CB;
+                                                       int ld, int nt) {
+  extern __shared__ __attribute__((aligned(16))) double sz[];  // ld doubles: the solution so far
+  __shared__ double srhs[CB];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 31;
   for (int kb = nt - 1; kb >= 0; --kb) {
     const int k0 = kb * CB;
-    if (tid < 64) {
-      const int i = tid & 31, gi = k0 + i;
-      double u[CB];
+    const int jbeg = k0 + CB;  // first column beyond the block (multiple of 32)
+    double u[CB], di = 0.0;  // wave 0: its row of the diagonal block, fetched ahead of the solve
+    if (wave == 0) {
 #pragma unroll
-      for (int j = 0; j < CB; ++j) u[j] = (gi < n && k0 + j < n && j > i) ? A[(size_t)gi * ld + k0 + j] : 0.0;
-      double yi = gi < n ? y[gi] : 0.0;
-      const double di = gi < n ? dinv[gi] : 0.0;
+      for (int j = 0; j < CB; ++j) u[j] = A[(size_t)(k0 + i) * ld + k0 + j];
+      di = dinv[k0 + i];
+    }
+    // ---- rows k0+2w, k0+2w+1: dot products with the known part of z
+    double part[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int gi = k0 + 2 * wave + rr;
+      const double* ui = A + (size_t)gi * ld;
+      double acc0 = 0.0, acc1 = 0.0;
+      for (int j = jbeg + 2 * lane; j < ld; j += 128) {
+        const double2 u = *(const double2*)(ui + j);
+        const double2 zz = *(const double2*)(sz + j);
+        acc0 += u.x * zz.x;
+        acc1 += u.y * zz.y;
+      }
+      double acc = acc0 + acc1;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      part[rr] = acc;
+    }
+    if (lane == 0) {
+      srhs[2 * wave] = y[k0 + 2 * wave] - part[0];
+      srhs[2 * wave + 1] = y[k0 + 2 * wave + 1] - part[1];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // ---- diagonal block: lane i = row i
+      double yi = srhs[i];
 #pragma unroll
       for (int j = CB - 1; j >= 0; --j) {
-        const double zj = __shfl(yi * di, j);
+        const double zj = readlane_f64(yi * di, j);
         if (i == j) yi = zj;
         if (i < j) yi -= u[j] * zj;
       }
-      if (tid < CB) {
-        sz[i] = yi;
-        if (gi < n) z[gi] = yi;
+      if (lane < CB) {
+        sz[k0 + i] = yi;
+        z[k0 + i] = yi;
       }
-    }
-    __syncthreads();
-    for (int i = tid; i < k0; i += 1024) {
-      const double* ui = A + (size_t)i * ld + k0;
-      double acc = 0.0;
-#pragma unroll
-      for (int j = 0; j < CB; ++j) acc += (k0 + j < n ? ui[j] : 0.0) * sz[j];
-      y[i] -= acc;
     }
     __syncthreads();
   }
 }
-#undef LA
 
 // ---------------------------------------------------------------- step application
 // candidate cameras / focal: x + (-z)*scale, their tables, and the camera part of the norms
@@ -1091,7 +1150,8 @@ struct sfmhip_ba {
   LmState lm;
   int nc = 0, np_in = 0, no_in = 0;  // as given
   int np = 0, no = 0;                // with >= 1 observation, sorted order
-  int dim = 0;
+  int dim = 0, ld = 0;
+  size_t ssz = 0;  // ld*ld: doubles of the S part of `red`
   BaDev d{};
   std::vector<int> perm;  // sorted point -> input point
   std::vector<unsigned char> h_cam_used;
@@ -1163,6 +1223,8 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   b->np_in = n_pt;
   b->no_in = n_obs;
   b->dim = 6 * n_cam + 1;
+  b->ld = (b->dim + CB - 1) / CB * CB;
+  b->ssz = (size_t)b->ld * b->ld;
   // ---- group observations by point, ascending camera inside a point (std::map order of
   //      Point3D::idxImage, reference src/BundleAdjustment.cpp:87)
   std::vector<int> cnt(n_pt + 1, 0);
@@ -1250,11 +1312,11 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   d.np = b->np;
   d.no = b->no;
   d.dim = b->dim;
-  d.ld = b->dim;
+  d.ld = b->ld;
   int rc = SFMHIP_OK;
   int *d_optr = nullptr, *d_ocam = nullptr;
   double2* d_oxy = nullptr;
-  b->red_count = (size_t)b->dim * b->dim + 3 * (size_t)b->dim + SC + 64;
+  b->red_count = b->ssz + 3 * (size_t)b->ld + SC + 64;
 #define BA_A(ptr, n)                         \
   if (rc == SFMHIP_OK) rc = ba_alloc(b, &(ptr), (size_t)(n))
   BA_A(d_optr, b->np + 1);
@@ -1271,10 +1333,10 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   BA_A(d.scale_c, 6 * n_cam);
   BA_A(d.scale_p, 3 * (size_t)b->np);
   BA_A(d.scale_f, 1);
-  BA_A(d.diag, b->dim);
+  BA_A(d.diag, b->ld);
   BA_A(d.red, b->red_count);
-  BA_A(d.z, b->dim);
-  BA_A(d.dinv, b->dim);
+  BA_A(d.z, b->ld);
+  BA_A(d.dinv, b->ld);
   BA_A(d.red2, 16);
   BA_A(d.info, 1);
   BA_A(b->d_cam_used, n_cam);
@@ -1371,24 +1433,24 @@ static int ba_allreduce(sfmhip_ba* b, double* buf, size_t count) {
 static int ba_prepare_scale(sfmhip_ba* b, int jacobi) {
   hipStream_t st = b->ctx->stream;
   BaDev& d = b->d;
-  const size_t tail = (size_t)b->dim * b->dim + 2 * (size_t)b->dim;  // dc | sc
-  SFM_HIP_TRY(hipMemsetAsync(d.red + tail, 0, sizeof(double) * ((size_t)b->dim + SC + 64), st));
+  const size_t tail = b->ssz + 2 * (size_t)b->ld;  // dc | sc
+  SFM_HIP_TRY(hipMemsetAsync(d.red + tail, 0, sizeof(double) * ((size_t)b->ld + SC + 64), st));
   hipLaunchKernelGGL(ba_cam_prep, dim3((b->nc + 63) / 64), dim3(64), 0, st, d.cams, d.camd, b->nc, 1);
   if (b->np) hipLaunchKernelGGL(ba_colnorms, dim3((b->np + 255) / 256), dim3(256), 0, st, d, jacobi);
   SFM_HIP_TRY(hipGetLastError());
-  SFM_TRY(ba_allreduce(b, d.red + tail, (size_t)b->dim + SC));
+  SFM_TRY(ba_allreduce(b, d.red + tail, (size_t)b->ld + SC));
   hipLaunchKernelGGL(ba_make_scale, dim3((b->dim + 255) / 256), dim3(256), 0, st, d, jacobi);
   SFM_HIP_TRY(hipGetLastError());
   // cameras observed by any rank: nonzero translation-column norm
-  std::vector<double> dc(b->dim + SC);
-  SFM_HIP_TRY(hipMemcpyAsync(dc.data(), d.red + tail, sizeof(double) * (b->dim + SC), hipMemcpyDeviceToHost, st));
+  std::vector<double> dc(b->ld + SC);
+  SFM_HIP_TRY(hipMemcpyAsync(dc.data(), d.red + tail, sizeof(double) * (b->ld + SC), hipMemcpyDeviceToHost, st));
   SFM_HIP_TRY(hipStreamSynchronize(st));
   if (jacobi || b->world > 1) {
     if (jacobi)
       for (int c = 0; c < b->nc; ++c) b->h_cam_used[c] = dc[6 * c + 3] > 0 ? 1 : 0;
     SFM_HIP_TRY(hipMemcpyAsync(b->d_cam_used, b->h_cam_used.data(), b->nc, hipMemcpyHostToDevice, st));
   }
-  const double pts_n2 = dc[b->dim + 1];
+  const double pts_n2 = dc[b->ld + 1];
   double* tmp = d.red2 + 8;
   hipLaunchKernelGGL(ba_cam_norm, dim3(1), dim3(256), 0, st, d, b->d_cam_used, tmp);
   double cam_n2 = 0;
@@ -1418,7 +1480,7 @@ static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_o
   SFM_HIP_TRY(hipGetLastError());
   b->launches += 2 + (b->n_chunk_ids[0] > 0) + (b->n_chunk_ids[1] > 0) + (b->n_fb > 0);
   SFM_HIP_TRY(hipEventRecord(b->ev[1], st));
-  SFM_TRY(ba_allreduce(b, d.red, (size_t)b->dim * b->dim + 3 * (size_t)b->dim + SC + b->world));
+  SFM_TRY(ba_allreduce(b, d.red, b->ssz + 3 * (size_t)b->ld + SC + b->world));
   SFM_HIP_TRY(hipEventRecord(b->ev[2], st));
   hipLaunchKernelGGL(ba_finalize, dim3(1), dim3(1024), 0, st, d, radius, o->min_lm_diagonal, o->max_lm_diagonal,
                      b->world, add_diag ? 1 : 0);
@@ -1430,17 +1492,16 @@ static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_o
 static int ba_reduced_solve(sfmhip_ba* b) {
   hipStream_t st = b->ctx->stream;
   BaDev& d = b->d;
-  const int n = b->dim;
   double* A = d.red;
-  double* y = d.red + (size_t)n * n;  // g becomes y = L^-1 g
+  double* y = d.red + b->ssz;  // g becomes y = L^-1 g
   SFM_HIP_TRY(hipMemsetAsync(d.info, 0, sizeof(int), st));
-  const int nt = (n + CB - 1) / CB;
+  const int nt = b->ld / CB;
   for (int k = 0; k < nt; ++k) {
     const int m = nt - k;
-    const int nblk = m * (m + 1) / 2 + m;
-    hipLaunchKernelGGL(chol_step, dim3(nblk), dim3(64), 0, st, A, y, d.dinv, n, d.ld, k, d.info);
+    const int nblk = k == 0 ? m + 1 : m * (m + 1) / 2 + m;  // launch 0 has no pending update
+    hipLaunchKernelGGL(chol_step, dim3(nblk), dim3(128), 0, st, A, y, d.dinv, d.ld, nt, k, d.info);
   }
-  hipLaunchKernelGGL(chol_backsolve, dim3(1), dim3(1024), 0, st, A, y, d.dinv, d.z, n, d.ld);
+  hipLaunchKernelGGL(chol_backsolve, dim3(1), dim3(1024), sizeof(double) * b->ld, st, A, y, d.dinv, d.z, d.ld, nt);
   SFM_HIP_TRY(hipGetLastError());
   b->launches += nt + 1;
   return SFMHIP_OK;
@@ -1476,7 +1537,7 @@ struct IterScalars {
 static int ba_read_scalars(sfmhip_ba* b, IterScalars* s, bool with_step) {
   hipStream_t st = b->ctx->stream;
   BaDev& d = b->d;
-  const size_t sc_off = (size_t)b->dim * b->dim + 3 * (size_t)b->dim;
+  const size_t sc_off = b->ssz + 3 * (size_t)b->ld;
   SFM_HIP_TRY(hipMemcpyAsync(b->h_sc, d.red + sc_off, sizeof(double) * SC, hipMemcpyDeviceToHost, st));
   if (with_step) {
     SFM_HIP_TRY(hipMemcpyAsync(b->h_sc + SC, d.red2, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
@@ -1678,11 +1739,12 @@ extern "C" int sfmhip_ba_reduced_system(sfmhip_ba* b, double radius, double* S, 
   hipStream_t st = b->ctx->stream;
   const int n = b->dim;
   if (S) {
-    SFM_HIP_TRY(hipMemcpyAsync(S, b->d.red, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, st));
+    SFM_HIP_TRY(hipMemcpy2DAsync(S, sizeof(double) * n, b->d.red, sizeof(double) * b->ld, sizeof(double) * n, n,
+                                 hipMemcpyDeviceToHost, st));
   }
-  if (g) SFM_HIP_TRY(hipMemcpyAsync(g, b->d.red + (size_t)n * n, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  if (g) SFM_HIP_TRY(hipMemcpyAsync(g, b->d.red + b->ssz, sizeof(double) * n, hipMemcpyDeviceToHost, st));
   double sc0 = 0;
-  SFM_HIP_TRY(hipMemcpyAsync(&sc0, b->d.red + (size_t)n * n + 3 * (size_t)n, sizeof(double), hipMemcpyDeviceToHost, st));
+  SFM_HIP_TRY(hipMemcpyAsync(&sc0, b->d.red + b->ssz + 3 * (size_t)b->ld, sizeof(double), hipMemcpyDeviceToHost, st));
   SFM_HIP_TRY(hipStreamSynchronize(st));
   if (S)
     for (int i = 0; i < n; ++i)
