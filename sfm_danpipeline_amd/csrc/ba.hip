@@ -13,14 +13,17 @@
 // upper triangle is formed (= a column-major lower triangle for the Cholesky kernels).
 //
 // Kernels per LM iteration:
-//   ba_eliminate<R>   one wave per chunk.  Lanes 0..n-1 linearise the point's n observations
-//                     (analytic Jacobian from per-camera R, dR/dw tables), shuffle-reduce the 3x3
-//                     point block, and publish T_o = (Jc^T Jp) C^-1/2 through LDS; then every lane
-//                     owns a 6x3 half-block of the camera-pair Gram  -sum_p T_a T_b^T and keeps it
-//                     in REGISTERS across all points of the chunk; one f64 atomic flush per chunk.
+//   ba_cam_blocks     F^T F part of the reduced system (camera 6x6 blocks, focal border, F^T b,
+//                     cost) from a camera-major copy of the observations.
+//   ba_eliminate_mfma<NB>  Schur correction.  A workgroup owns a run of points of one signature;
+//                     16 lanes linearise the (<=10) observations of a point (4 points per wave
+//                     and iteration), DPP-reduce the 3x3 point block, publish
+//                     T_o = (Jc^T Jp) C^-1/2 as 3 rows of a 12 x 64 LDS panel, and the wave adds
+//                     the panel's Gram matrix on v_mfma_f64_16x16x4_f64; one f64 atomic scatter
+//                     into S per workgroup.
 //   ba_finalize       LM diagonal (clamped squared column norms / radius) onto S, gradient max.
-//   chol_panel/chol_update/chol_backsolve  dense blocked Cholesky of S with the rhs carried as
-//                     an extra row, then the transposed triangular solve.
+//   chol_step/chol_backsolve  dense blocked Cholesky of S with the rhs carried as an extra
+//                     row, then the transposed triangular solve.
 //   ba_cand_cams      candidate cameras / focal and their rotation tables.
 //   ba_backsub        per point: back-substitution, model cost change, candidate point,
 //                     candidate cost.
@@ -88,6 +91,42 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtom
 __device__ __forceinline__ void atomic_max_pos_f64(double* p, double v) {
   // v >= 0: IEEE order == unsigned integer order
   atomicMax((unsigned long long*)p, (unsigned long long)__double_as_longlong(v));
+}
+
+// ---------------------------------------------------------------- small f64 helpers
+typedef double v4d __attribute__((ext_vector_type(4)));  // accumulator of v_mfma_f64_16x16x4_f64
+// v_rcp_f64 / v_rsq_f64 give ~24 bits; two Newton steps bring them to rounding level (the BA
+// kernels are tolerance-level f64).
+__device__ __forceinline__ double rcp_f64(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return r;
+}
+__device__ __forceinline__ double rsqrt_f64(double d) {
+  double r = __builtin_amdgcn_rsq(d);
+  r = r * (1.5 - 0.5 * d * r * r);
+  r = r * (1.5 - 0.5 * d * r * r);
+  return r;
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// sum over each row of 16 lanes, every lane of the row receives the (bitwise identical) total
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);  // row_half_mirror
+  v += dpp_f64<0x140>(v);  // row_mirror
+  return v;
 }
 
 // ---------------------------------------------------------------- camera tables
@@ -167,7 +206,8 @@ __device__ __forceinline__ void obs_residual(CP cd, const double X[3], double fo
   const double px = cd[0] * X[0] + cd[1] * X[1] + cd[2] * X[2] + cd[9];
   const double py = cd[3] * X[0] + cd[4] * X[1] + cd[5] * X[2] + cd[10];
   const double pz = cd[6] * X[0] + cd[7] * X[1] + cd[8] * X[2] + cd[11];
-  const double xp = px / pz, yp = py / pz;
+  const double iz = rcp_f64(pz);
+  const double xp = px * iz, yp = py * iz;
   r0 = focal * xp - ox;
   r1 = focal * yp - oy;
 }
@@ -179,10 +219,10 @@ __device__ __forceinline__ void obs_linearize(CP cd, const double X[3], double f
   const double px = cd[0] * X[0] + cd[1] * X[1] + cd[2] * X[2] + cd[9];
   const double py = cd[3] * X[0] + cd[4] * X[1] + cd[5] * X[2] + cd[10];
   const double pz = cd[6] * X[0] + cd[7] * X[1] + cd[8] * X[2] + cd[11];
-  const double xp = px / pz, yp = py / pz;
+  const double iz = rcp_f64(pz);
+  const double xp = px * iz, yp = py * iz;
   o.r0 = focal * xp - ox;
   o.r1 = focal * yp - oy;
-  const double iz = 1.0 / pz;
   const double d00 = focal * iz, d02 = -focal * xp * iz, d12 = -focal * yp * iz;  // dr/dp rows
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -212,25 +252,22 @@ __device__ __forceinline__ void obs_linearize(CP cd, const double X[3], double f
   o.Jf[1] = yp * sf;
 }
 
-// 3x3 SPD: inverse of the Cholesky factor (Li lower, C^-1 = Li^T Li); returns false if not PD
+// 3x3 SPD: inverse of the Cholesky factor (Li lower, C^-1 = Li^T Li); returns false if not PD.
+// Division-free: the three pivots go through rsqrt.
 __device__ __forceinline__ bool chol3_inv(const double C[6] /*00 10 11 20 21 22*/, double Li[6]) {
   const double c00 = C[0], c10 = C[1], c11 = C[2], c20 = C[3], c21 = C[4], c22 = C[5];
-  if (!(c00 > 0)) return false;
-  const double l00 = sqrt(c00);
-  const double l10 = c10 / l00, l20 = c20 / l00;
+  const double i00 = rsqrt_f64(c00);
+  const double l10 = c10 * i00, l20 = c20 * i00;
   const double d11 = c11 - l10 * l10;
-  if (!(d11 > 0)) return false;
-  const double l11 = sqrt(d11);
-  const double l21 = (c21 - l20 * l10) / l11;
+  const double i11 = rsqrt_f64(d11);
+  const double l21 = (c21 - l20 * l10) * i11;
   const double d22 = c22 - l20 * l20 - l21 * l21;
-  if (!(d22 > 0)) return false;
-  const double l22 = sqrt(d22);
-  const double i00 = 1 / l00, i11 = 1 / l11, i22 = 1 / l22;
+  const double i22 = rsqrt_f64(d22);
   const double i10 = -l10 * i00 * i11;
   const double i21 = -l21 * i11 * i22;
   const double i20 = -(l20 * i00 + l21 * i10) * i22;
   Li[0] = i00; Li[1] = i10; Li[2] = i11; Li[3] = i20; Li[4] = i21; Li[5] = i22;
-  return true;
+  return (c00 > 0) && (d11 > 0) && (d22 > 0);
 }
 
 // ---------------------------------------------------------------- Jacobi scaling (iteration 0)
@@ -289,230 +326,290 @@ __global__ void ba_make_scale(BaDev d, int jacobi) {
 }
 
 // ---------------------------------------------------------------- linearise + Schur eliminate
-// items of a signature with n observations: (n+1)^2 half-blocks (a, b, h, kind)
-//   kind 0: rows 0..5 of T_a  x  rows 3h..3h+2 of T_b  -> S block (cam_a, cam_b), cols 3h..
-//   kind 1: T_a x border rows (t_f, u)                 -> S[:, focal], g
-//   kind 2: border x border                            -> S[focal][focal], g[focal]
-__host__ __device__ inline unsigned pack_item(int a, int b, int h, int kind) {
-  return (unsigned)a | ((unsigned)b << 8) | ((unsigned)h << 16) | ((unsigned)kind << 24);
-}
+// The reduced system splits into S = F^T F + D^2 - sum_p (F_p^T E_p) C_p^-1 (E_p^T F_p):
+//   * ba_cam_blocks   forms the F^T F part (per-camera 6x6 blocks, the focal border, F^T b,
+//                     the cost) from a camera-major copy of the observations, one workgroup
+//                     per (camera, slice): every block is owned by few workgroups, 36 atomics
+//                     per workgroup;
+//   * ba_eliminate_mfma<NB>  forms the Schur correction.  Points with the same ascending camera
+//                     list ("signature", n cameras) are contiguous and cut into chunks; with
+//                     M_p = [T_0^T .. T_{n-1}^T | t_f | u]  (3 x (6n+2),  T_o = (Jc_o^T Jp_o) C_p^-1/2,
+//                     t_f = C_p^-1/2 Jp^T Jf, u = C_p^-1/2 Jp^T r) the chunk's contribution is the
+//                     Gram matrix sum_p M_p^T M_p, a (6n+2)^2 <= 64^2 dense block that every
+//                     wave accumulates on v_mfma_f64_16x16x4_f64 (4 points = 12 rows = 3 k-steps
+//                     per iteration, upper tiles only) and the workgroup scatters into S once.
+constexpr int MP = 80;  // LDS row pitch (doubles) of a wave's M panel: the 4 k-rows of one
+                        // fragment read sit 160 dwords apart -> disjoint banks
 
-template <int R>
-__global__ __launch_bounds__(64) void ba_eliminate(BaDev d, const Chunk* __restrict__ chunks,
-                                                   const int* __restrict__ chunk_ids,
-                                                   const int* __restrict__ sig_cams,
-                                                   const unsigned* __restrict__ items,
-                                                   const int* __restrict__ item_off, double radius,
-                                                   double lm_lo, double lm_hi, int rank) {
-  constexpr int NMAX = (R == 1) ? 7 : 10;
-  __shared__ __attribute__((aligned(16))) double s_cam[NMAX * CAMD];
-  __shared__ __attribute__((aligned(16))) double s_T[(NMAX + 1) * 18];
+struct CamLds {  // camera table transposed in LDS: element e of camera slot o at [e*16 + o]
+  const double* base;
+  __device__ __forceinline__ double operator[](int e) const { return base[e * 16]; }
+};
+
+template <int NB>
+__global__ __launch_bounds__(256, 2) void ba_eliminate_mfma(BaDev d, const Chunk* __restrict__ chunks,
+                                                         const int* __restrict__ chunk_ids,
+                                                         const int* __restrict__ sig_cams, double inv_radius,
+                                                         double lm_lo, double lm_hi, int rank) {
+  constexpr int NT = NB * (NB + 1) / 2;
+  __shared__ __attribute__((aligned(16))) double s_cam[CAMD * 16];
+  __shared__ __attribute__((aligned(16))) double s_M[4 * 12 * MP];  // also the cross-wave reduction buffer
+  __shared__ int s_gidx[64];  // local Gram index -> row/column of S; -2: the rhs column u; -1: padding
   const Chunk ch = chunks[chunk_ids[blockIdx.x]];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = ch.n;
   const int* cams = sig_cams + ch.sig_off;
-  const int dim = d.ld /* row stride of S */, fo = 6 * d.nc;
-  const bool is_obs = lane < n;
-  const int mycam = cams[is_obs ? lane : 0];
-
-  // camera tables of this signature -> LDS
-  for (int i = lane; i < n * CAMD; i += 64) s_cam[i] = d.camd[(size_t)CAMD * cams[i / CAMD] + (i % CAMD)];
-  double sc[6];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) sc[j] = d.scale_c[6 * mycam + j];
-  const double sf = *d.scale_f, focal = *d.focal;
-  const int n_items = (n + 1) * (n + 1);
-  unsigned item[R];
-#pragma unroll
-  for (int rr = 0; rr < R; ++rr) {
-    const int ii = rr * 64 + lane;
-    item[rr] = ii < n_items ? items[item_off[n] + ii] : 0xFFFFFFFFu;
+  const int sld = d.ld, fo = 6 * d.nc;
+  for (int idx = tid; idx < n * CAMD; idx += 256) {
+    const int o = idx / CAMD, e = idx - o * CAMD;
+    s_cam[e * 16 + o] = d.camd[(size_t)CAMD * cams[o] + e];
   }
+  for (int idx = tid; idx < 4 * 12 * MP; idx += 256) s_M[idx] = 0.0;
+  if (tid < 64) {
+    int gi = -1;
+    if (tid < 6 * n) gi = 6 * cams[tid / 6] + tid % 6;
+    else if (tid == 6 * n) gi = fo;
+    else if (tid == 6 * n + 1) gi = -2;
+    s_gidx[tid] = gi;
+  }
+  const int o = lane & 15, q = lane >> 4;
+  const bool valid_o = o < n;
+  const int oc = valid_o ? o : 0;  // idle lanes shadow observation 0 (finite data), masked out below
+  double sc[6];
+  {
+    const int cam = cams[oc];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) sc[j] = d.scale_c[6 * cam + j];
+  }
+  const double sf = *d.scale_f, focal = *d.focal;
+  const int kobs0 = d.optr[ch.p0];
   __syncthreads();
 
-  double acc[R][18];
+  v4d acc[NT];
 #pragma unroll
-  for (int rr = 0; rr < R; ++rr)
-#pragma unroll
-    for (int e = 0; e < 18; ++e) acc[rr][e] = 0.0;
-  double Hcc[21], Hcf[6], gc[6];
-#pragma unroll
-  for (int e = 0; e < 21; ++e) Hcc[e] = 0.0;
-#pragma unroll
-  for (int e = 0; e < 6; ++e) Hcf[e] = gc[e] = 0.0;
-  double Hff = 0, gf = 0, cost = 0, gmax = 0;
+  for (int t = 0; t < NT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+  double gmax = 0.0;
   int nfail = 0;
-  const double* cd = s_cam + (is_obs ? lane : 0) * CAMD;
+  double* Mw = s_M + wave * (12 * MP);
+  const CamLds cd{s_cam + oc};
+  const int frow = lane >> 4, fcol = lane & 15;
 
-  for (int pi = 0; pi < ch.cnt; ++pi) {
-    const int p = ch.p0 + pi;
+  for (int quad = wave; 4 * quad < ch.cnt; quad += 4) {
+    const int pi = 4 * quad + q;
+    const bool pv = pi < ch.cnt;
+    const int pl = pv ? pi : ch.cnt - 1;
+    const int p = ch.p0 + pl;
     const double X[3] = {d.pts[3 * p], d.pts[3 * p + 1], d.pts[3 * p + 2]};
     const double sp[3] = {d.scale_p[3 * p], d.scale_p[3 * p + 1], d.scale_p[3 * p + 2]};
-    ObsLin o;
+    ObsLin ol;
     {
-      const int k = d.optr[p] + (is_obs ? lane : 0);
-      const double2 xy = d.oxy[k];
-      obs_linearize(cd, X, focal, xy.x, xy.y, sc, sp, sf, o);
+      const double2 xy = d.oxy[kobs0 + pl * n + oc];
+      obs_linearize(cd, X, focal, xy.x, xy.y, sc, sp, sf, ol);
     }
-    const double live = is_obs ? 1.0 : 0.0;
+    const double live = (pv && valid_o) ? 1.0 : 0.0;
     // point block C = sum Jp^T Jp (lower: 00 10 11 20 21 22), gp = Jp^T r, wf = Jp^T Jf
     double red[12];
-    red[0] = live * (o.Jp[0] * o.Jp[0] + o.Jp[3] * o.Jp[3]);
-    red[1] = live * (o.Jp[1] * o.Jp[0] + o.Jp[4] * o.Jp[3]);
-    red[2] = live * (o.Jp[1] * o.Jp[1] + o.Jp[4] * o.Jp[4]);
-    red[3] = live * (o.Jp[2] * o.Jp[0] + o.Jp[5] * o.Jp[3]);
-    red[4] = live * (o.Jp[2] * o.Jp[1] + o.Jp[5] * o.Jp[4]);
-    red[5] = live * (o.Jp[2] * o.Jp[2] + o.Jp[5] * o.Jp[5]);
+    red[0] = live * (ol.Jp[0] * ol.Jp[0] + ol.Jp[3] * ol.Jp[3]);
+    red[1] = live * (ol.Jp[1] * ol.Jp[0] + ol.Jp[4] * ol.Jp[3]);
+    red[2] = live * (ol.Jp[1] * ol.Jp[1] + ol.Jp[4] * ol.Jp[4]);
+    red[3] = live * (ol.Jp[2] * ol.Jp[0] + ol.Jp[5] * ol.Jp[3]);
+    red[4] = live * (ol.Jp[2] * ol.Jp[1] + ol.Jp[5] * ol.Jp[4]);
+    red[5] = live * (ol.Jp[2] * ol.Jp[2] + ol.Jp[5] * ol.Jp[5]);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      red[6 + a] = live * (o.Jp[a] * o.r0 + o.Jp[3 + a] * o.r1);
-      red[9 + a] = live * (o.Jp[a] * o.Jf[0] + o.Jp[3 + a] * o.Jf[1]);
+      red[6 + a] = live * (ol.Jp[a] * ol.r0 + ol.Jp[3 + a] * ol.r1);
+      red[9 + a] = live * (ol.Jp[a] * ol.Jf[0] + ol.Jp[3 + a] * ol.Jf[1]);
     }
 #pragma unroll
-    for (int e = 0; e < 12; ++e) {
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) red[e] += __shfl_xor(red[e], off, 16);
-    }
-    // every lane of row 0 now holds the sums; broadcast to the whole wave
-#pragma unroll
-    for (int e = 0; e < 12; ++e) red[e] = __shfl(red[e], 0);
+    for (int e = 0; e < 12; ++e) red[e] = row16_sum(red[e]);
     // LM damping of the point block: D^2 = clamp(diag) / radius
     double C[6] = {red[0], red[1], red[2], red[3], red[4], red[5]};
-    const double dg0 = fmin(fmax(C[0], lm_lo), lm_hi), dg1 = fmin(fmax(C[2], lm_lo), lm_hi),
-                 dg2 = fmin(fmax(C[5], lm_lo), lm_hi);
-    C[0] += dg0 / radius;
-    C[2] += dg1 / radius;
-    C[5] += dg2 / radius;
+    C[0] += fmin(fmax(C[0], lm_lo), lm_hi) * inv_radius;
+    C[2] += fmin(fmax(C[2], lm_lo), lm_hi) * inv_radius;
+    C[5] += fmin(fmax(C[5], lm_lo), lm_hi) * inv_radius;
     double Li[6];
     const bool pd = chol3_inv(C, Li);
     if (!pd) {
-      ++nfail;
+      if (pv && o == 0) ++nfail;
       Li[0] = Li[1] = Li[2] = Li[3] = Li[4] = Li[5] = 0;
     }
+    const double pvf = pv ? 1.0 : 0.0;
     // gradient of the point (unscaled) for the gradient tolerance
-    gmax = fmax(gmax, fmax(fabs(red[6] / sp[0]), fmax(fabs(red[7] / sp[1]), fabs(red[8] / sp[2]))));
-    __syncthreads();  // previous point's pair reads are done
-    if (is_obs) {
-      // W = Jc^T Jp (6x3); T = W Li^T : T[i][k] = sum_{a<=k} W[i][a] Li[k][a]
+    gmax = fmax(gmax, pvf * fmax(fabs(red[6] * rcp_f64(sp[0])), fmax(fabs(red[7] * rcp_f64(sp[1])), fabs(red[8] * rcp_f64(sp[2])))));
+    if (valid_o) {
+      // W = Jc^T Jp (6x3); T = W Li^T : T[i][k] = sum_{a<=k} W[i][a] Li[k][a]; row k of the panel
+      double* row0 = Mw + (3 * q) * MP + 6 * o;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        const double w0 = o.Jc[i] * o.Jp[0] + o.Jc[6 + i] * o.Jp[3];
-        const double w1 = o.Jc[i] * o.Jp[1] + o.Jc[6 + i] * o.Jp[4];
-        const double w2 = o.Jc[i] * o.Jp[2] + o.Jc[6 + i] * o.Jp[5];
-        s_T[lane * 18 + 3 * i + 0] = w0 * Li[0];
-        s_T[lane * 18 + 3 * i + 1] = w0 * Li[1] + w1 * Li[2];
-        s_T[lane * 18 + 3 * i + 2] = w0 * Li[3] + w1 * Li[4] + w2 * Li[5];
+        const double w0 = live * (ol.Jc[i] * ol.Jp[0] + ol.Jc[6 + i] * ol.Jp[3]);
+        const double w1 = live * (ol.Jc[i] * ol.Jp[1] + ol.Jc[6 + i] * ol.Jp[4]);
+        const double w2 = live * (ol.Jc[i] * ol.Jp[2] + ol.Jc[6 + i] * ol.Jp[5]);
+        row0[i] = w0 * Li[0];
+        row0[MP + i] = w0 * Li[1] + w1 * Li[2];
+        row0[2 * MP + i] = w0 * Li[3] + w1 * Li[4] + w2 * Li[5];
       }
-      // F^T F, F^T b of this observation's camera
-      int e = 0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-#pragma unroll
-        for (int j = i; j < 6; ++j) Hcc[e++] += o.Jc[i] * o.Jc[j] + o.Jc[6 + i] * o.Jc[6 + j];
-        Hcf[i] += o.Jc[i] * o.Jf[0] + o.Jc[6 + i] * o.Jf[1];
-        gc[i] += o.Jc[i] * o.r0 + o.Jc[6 + i] * o.r1;
-      }
-      Hff += o.Jf[0] * o.Jf[0] + o.Jf[1] * o.Jf[1];
-      gf += o.Jf[0] * o.r0 + o.Jf[1] * o.r1;
-      cost += o.r0 * o.r0 + o.r1 * o.r1;
     }
-    if (lane == 0) {
-      // border rows: t_f = Li wf, u = Li gp
-      double* b = s_T + n * 18;
-      b[0] = Li[0] * red[9];
-      b[1] = Li[1] * red[9] + Li[2] * red[10];
-      b[2] = Li[3] * red[9] + Li[4] * red[10] + Li[5] * red[11];
-      b[3] = Li[0] * red[6];
-      b[4] = Li[1] * red[6] + Li[2] * red[7];
-      b[5] = Li[3] * red[6] + Li[4] * red[7] + Li[5] * red[8];
-#pragma unroll
-      for (int e2 = 6; e2 < 18; ++e2) b[e2] = 0.0;
+    if (o == 0) {
+      // border columns: t_f = Li wf, u = Li gp
+      double* b0 = Mw + (3 * q) * MP + 6 * n;
+      b0[0] = pvf * (Li[0] * red[9]);
+      b0[MP] = pvf * (Li[1] * red[9] + Li[2] * red[10]);
+      b0[2 * MP] = pvf * (Li[3] * red[9] + Li[4] * red[10] + Li[5] * red[11]);
+      b0[1] = pvf * (Li[0] * red[6]);
+      b0[MP + 1] = pvf * (Li[1] * red[6] + Li[2] * red[7]);
+      b0[2 * MP + 1] = pvf * (Li[3] * red[6] + Li[4] * red[7] + Li[5] * red[8]);
     }
-    __syncthreads();
-    // camera-pair Gram, accumulated in registers over the chunk
+    // Gram update: the same fragment serves as A (M^T tile) and B (M tile) operand
 #pragma unroll
-    for (int rr = 0; rr < R; ++rr) {
-      const unsigned itx = item[rr];
-      const int a = itx & 0xFF, b = (itx >> 8) & 0xFF, h = (itx >> 16) & 0xFF;
-      const double* Ta = s_T + (itx == 0xFFFFFFFFu ? 0 : a) * 18;
-      const double* Tb = s_T + (itx == 0xFFFFFFFFu ? 0 : b) * 18 + 9 * (itx == 0xFFFFFFFFu ? 0 : h);
-      double tb[9];
+    for (int ks = 0; ks < 3; ++ks) {
+      double fr[NB];
 #pragma unroll
-      for (int e = 0; e < 9; ++e) tb[e] = Tb[e];
+      for (int blk = 0; blk < NB; ++blk) fr[blk] = Mw[(4 * ks + frow) * MP + 16 * blk + fcol];
+      int t = 0;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const double t0 = Ta[3 * i], t1 = Ta[3 * i + 1], t2 = Ta[3 * i + 2];
+      for (int ti = 0; ti < NB; ++ti)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc[rr][3 * i + j] += t0 * tb[3 * j] + t1 * tb[3 * j + 1] + t2 * tb[3 * j + 2];
-      }
+        for (int tj = ti; tj < NB; ++tj, ++t)
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[ti], fr[tj], acc[t], 0, 0, 0);
     }
   }
 
-  // ---- flush: one f64 atomic per accumulator per chunk
-  double* S = red_S(d);
-  double* g = red_g(d);
-  double* gF = red_gF(d);
-  double* dc = red_dc(d);
+  // ---- cross-wave sum of the Gram tiles (s_M is free now), then one scatter into S per chunk
+  __syncthreads();
+#pragma unroll 1
+  for (int w = 1; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int rr = 0; rr < R; ++rr) {
-    const unsigned itx = item[rr];
-    if (itx == 0xFFFFFFFFu) continue;
-    const int a = itx & 0xFF, b = (itx >> 8) & 0xFF, h = (itx >> 16) & 0xFF, kind = itx >> 24;
-    if (kind == 0) {
-      const int r0 = 6 * cams[a], c0 = 6 * cams[b] + 3 * h;
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-          if (r0 + i <= c0 + j) atomic_add_f64(S + (size_t)(r0 + i) * dim + c0 + j, -acc[rr][3 * i + j]);
-    } else if (kind == 1) {
-      const int r0 = 6 * cams[a];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        atomic_add_f64(S + (size_t)(r0 + i) * dim + fo, -acc[rr][3 * i + 0]);
-        atomic_add_f64(g + r0 + i, -acc[rr][3 * i + 1]);
-      }
-    } else {
-      atomic_add_f64(S + (size_t)fo * dim + fo, -acc[rr][0]);
-      atomic_add_f64(g + fo, -acc[rr][1]);
+        for (int g = 0; g < 4; ++g) s_M[(t * 4 + g) * 64 + lane] = acc[t][g];
     }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[t][g] += s_M[(t * 4 + g) * 64 + lane];
+    }
+    __syncthreads();
   }
-  if (is_obs) {
-    const int r0 = 6 * mycam;
+  double* scv = red_sc(d);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    gmax = fmax(gmax, __shfl_down(gmax, off));
+    nfail += __shfl_down(nfail, off);
+  }
+  if (lane == 0) {
+    if (nfail) atomic_add_f64(scv + 2, (double)nfail);
+    atomic_max_pos_f64(scv + SC + rank, gmax);
+  }
+  if (wave == 0) {
+    double* S = red_S(d);
+    double* g = red_g(d);
+    int t = 0;
+#pragma unroll
+    for (int ti = 0; ti < NB; ++ti)
+#pragma unroll
+      for (int tj = ti; tj < NB; ++tj, ++t) {
+        const int lc = 16 * tj + fcol;
+        const int gc = s_gidx[lc];
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+          const int lr = 16 * ti + frow + 4 * gg;
+          const int gr = s_gidx[lr];
+          if (gr < 0 || lr > lc) continue;
+          if (gc >= 0) atomic_add_f64(S + (size_t)gr * sld + gc, -acc[t][gg]);
+          else if (gc == -2) atomic_add_f64(g + gr, -acc[t][gg]);
+        }
+      }
+  }
+}
+
+// F^T F part of the reduced system from the camera-major observation list: thread per
+// observation, register accumulation of the camera's 6x6 block (upper, 21), the focal border
+// (6), F^T b (6), and the scalars Jf^2, Jf r, r^2; block-reduced, 36 atomics per workgroup.
+__global__ __launch_bounds__(256) void ba_cam_blocks(BaDev d, const int* __restrict__ cptr,
+                                                     const int* __restrict__ cpt,
+                                                     const double2* __restrict__ cxy, int nsplit) {
+  __shared__ double sh[4][36];
+  const int c = blockIdx.x / nsplit, part = blockIdx.x - c * nsplit;
+  const int k0 = cptr[c], k1 = cptr[c + 1];
+  const int len = k1 - k0;
+  const int per = (len + nsplit - 1) / nsplit;
+  const int kb = k0 + part * per, ke = min(k1, kb + per);
+  double a[36];
+#pragma unroll
+  for (int e = 0; e < 36; ++e) a[e] = 0.0;
+  const double* cd = d.camd + (size_t)CAMD * c;
+  const double* scp = d.scale_c + 6 * c;
+  const double sf = *d.scale_f, focal = *d.focal;
+  for (int k = kb + threadIdx.x; k < ke; k += 256) {
+    const int p = cpt[k];
+    const double2 xy = cxy[k];
+    const double X[3] = {d.pts[3 * p], d.pts[3 * p + 1], d.pts[3 * p + 2]};
+    const double sp[3] = {d.scale_p[3 * p], d.scale_p[3 * p + 1], d.scale_p[3 * p + 2]};
+    ObsLin o;
+    obs_linearize(cd, X, focal, xy.x, xy.y, scp, sp, sf, o);
     int e = 0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
 #pragma unroll
-      for (int j = i; j < 6; ++j) {
-        atomic_add_f64(S + (size_t)(r0 + i) * dim + r0 + j, Hcc[e]);
-        if (j == i) atomic_add_f64(dc + r0 + i, Hcc[e]);
-        ++e;
-      }
-      atomic_add_f64(S + (size_t)(r0 + i) * dim + fo, Hcf[i]);
-      atomic_add_f64(g + r0 + i, gc[i]);
-      atomic_add_f64(gF + r0 + i, gc[i]);
+      for (int j = i; j < 6; ++j) a[e++] += o.Jc[i] * o.Jc[j] + o.Jc[6 + i] * o.Jc[6 + j];
+      a[21 + i] += o.Jc[i] * o.Jf[0] + o.Jc[6 + i] * o.Jf[1];
+      a[27 + i] += o.Jc[i] * o.r0 + o.Jc[6 + i] * o.r1;
     }
+    a[33] += o.Jf[0] * o.Jf[0] + o.Jf[1] * o.Jf[1];
+    a[34] += o.Jf[0] * o.r0 + o.Jf[1] * o.r1;
+    a[35] += o.r0 * o.r0 + o.r1 * o.r1;
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    Hff += __shfl_down(Hff, off);
-    gf += __shfl_down(gf, off);
-    cost += __shfl_down(cost, off);
+  for (int e = 0; e < 36; ++e) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a[e] += __shfl_down(a[e], off);
   }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) {
-    atomic_add_f64(S + (size_t)fo * dim + fo, Hff);
-    atomic_add_f64(dc + fo, Hff);
-    atomic_add_f64(g + fo, gf);
-    atomic_add_f64(gF + fo, gf);
-    double* scv = red_sc(d);
-    atomic_add_f64(scv + 0, cost);
-    if (nfail) atomic_add_f64(scv + 2, (double)nfail);
-    atomic_max_pos_f64(scv + SC + rank, gmax);
+#pragma unroll
+    for (int e = 0; e < 36; ++e) sh[wave][e] = a[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < 36 && len > 0) {
+    const int e = threadIdx.x;
+    const double v = sh[0][e] + sh[1][e] + sh[2][e] + sh[3][e];
+    double* S = red_S(d);
+    double* g = red_g(d);
+    double* gF = red_gF(d);
+    double* dc = red_dc(d);
+    const int sld = d.ld, fo = 6 * d.nc, r0 = 6 * c;
+    if (e < 21) {
+      int i = 0, rem = e;
+      while (rem >= 6 - i) {
+        rem -= 6 - i;
+        ++i;
+      }
+      const int j = i + rem;
+      atomic_add_f64(S + (size_t)(r0 + i) * sld + r0 + j, v);
+      if (i == j) atomic_add_f64(dc + r0 + i, v);
+    } else if (e < 27) {
+      atomic_add_f64(S + (size_t)(r0 + e - 21) * sld + fo, v);
+    } else if (e < 33) {
+      atomic_add_f64(g + r0 + e - 27, v);
+      atomic_add_f64(gF + r0 + e - 27, v);
+    } else if (e == 33) {
+      atomic_add_f64(S + (size_t)fo * sld + fo, v);
+      atomic_add_f64(dc + fo, v);
+    } else if (e == 34) {
+      atomic_add_f64(g + fo, v);
+      atomic_add_f64(gF + fo, v);
+    } else {
+      atomic_add_f64(red_sc(d) + 0, v);
+    }
   }
 }
 
-// Generic path: one wave per point; any observation count up to FB_MAXN, cameras in any order,
-// repeated cameras allowed.  Per-point atomics (no accumulation across points).
+// Generic path of the Schur correction: one wave per point; any observation count up to FB_MAXN,
+// cameras in any order, repeated cameras allowed.  Per-point atomics (no accumulation across
+// points).  The F^T F part of these points comes from ba_cam_blocks like everyone else's.
 __global__ __launch_bounds__(64) void ba_eliminate_generic(BaDev d, const int* __restrict__ plist, double radius,
                                                            double lm_lo, double lm_hi, int rank) {
   __shared__ __attribute__((aligned(16))) double s_T[(FB_MAXN + 1) * 18];
@@ -560,11 +657,8 @@ __global__ __launch_bounds__(64) void ba_eliminate_generic(BaDev d, const int* _
   if (!pd) Li[0] = Li[1] = Li[2] = Li[3] = Li[4] = Li[5] = 0;
   double* S = red_S(d);
   double* g = red_g(d);
-  double* gF = red_gF(d);
-  double* dc = red_dc(d);
   double* scv = red_sc(d);
   if (is_obs) {
-    const int r0 = 6 * mycam;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const double w0 = o.Jc[i] * o.Jp[0] + o.Jc[6 + i] * o.Jp[3];
@@ -573,26 +667,7 @@ __global__ __launch_bounds__(64) void ba_eliminate_generic(BaDev d, const int* _
       s_T[lane * 18 + 3 * i + 0] = w0 * Li[0];
       s_T[lane * 18 + 3 * i + 1] = w0 * Li[1] + w1 * Li[2];
       s_T[lane * 18 + 3 * i + 2] = w0 * Li[3] + w1 * Li[4] + w2 * Li[5];
-#pragma unroll
-      for (int j = i; j < 6; ++j) {
-        const double v = o.Jc[i] * o.Jc[j] + o.Jc[6 + i] * o.Jc[6 + j];
-        atomic_add_f64(S + (size_t)(r0 + i) * dim + r0 + j, v);
-        if (j == i) atomic_add_f64(dc + r0 + i, v);
-      }
-      atomic_add_f64(S + (size_t)(r0 + i) * dim + fo, o.Jc[i] * o.Jf[0] + o.Jc[6 + i] * o.Jf[1]);
-      const double gi = o.Jc[i] * o.r0 + o.Jc[6 + i] * o.r1;
-      atomic_add_f64(g + r0 + i, gi);
-      atomic_add_f64(gF + r0 + i, gi);
     }
-  }
-  double Hff = live * (o.Jf[0] * o.Jf[0] + o.Jf[1] * o.Jf[1]);
-  double gf = live * (o.Jf[0] * o.r0 + o.Jf[1] * o.r1);
-  double cost = live * (o.r0 * o.r0 + o.r1 * o.r1);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    Hff += __shfl_down(Hff, off);
-    gf += __shfl_down(gf, off);
-    cost += __shfl_down(cost, off);
   }
   double tf[3], u[3];
   tf[0] = Li[0] * red[9];
@@ -602,11 +677,8 @@ __global__ __launch_bounds__(64) void ba_eliminate_generic(BaDev d, const int* _
   u[1] = Li[1] * red[6] + Li[2] * red[7];
   u[2] = Li[3] * red[6] + Li[4] * red[7] + Li[5] * red[8];
   if (lane == 0) {
-    atomic_add_f64(S + (size_t)fo * dim + fo, Hff - (tf[0] * tf[0] + tf[1] * tf[1] + tf[2] * tf[2]));
-    atomic_add_f64(dc + fo, Hff);
-    atomic_add_f64(g + fo, gf - (tf[0] * u[0] + tf[1] * u[1] + tf[2] * u[2]));
-    atomic_add_f64(gF + fo, gf);
-    atomic_add_f64(scv + 0, cost);
+    atomic_add_f64(S + (size_t)fo * dim + fo, -(tf[0] * tf[0] + tf[1] * tf[1] + tf[2] * tf[2]));
+    atomic_add_f64(g + fo, -(tf[0] * u[0] + tf[1] * u[1] + tf[2] * u[2]));
     if (!pd) atomic_add_f64(scv + 2, 1.0);
     const double gm = fmax(fabs(red[6] / sp[0]), fmax(fabs(red[7] / sp[1]), fabs(red[8] / sp[2])));
     atomic_max_pos_f64(scv + SC + rank, gm);
@@ -698,20 +770,6 @@ __global__ __launch_bounds__(1024) void ba_finalize(BaDev d, double radius, doub
 //     factorisation by one 8-column block (4 workgroup barriers).
 constexpr int CB = 32;
 constexpr int CBP = 34;  // LDS row pitch in doubles: 16-byte aligned rows, conflict-free tile writes
-typedef double v4d __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ double rsqrt_f64(double d) {
-  double r = __builtin_amdgcn_rsq(d);
-  r = r * (1.5 - 0.5 * d * r * r);
-  r = r * (1.5 - 0.5 * d * r * r);
-  return r;
-}
-
-__device__ __forceinline__ double readlane_f64(double v, int l) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-  return __hiloint2double(hi, lo);
-}
 
 // P[c][r] -= sum_kk Lc[c][kk] * Lr[r][kk] for the 16x16 sub-tiles (ci, ri) of a 32x32 tile.
 // MFMA roles: A operand = Lc (lane: row c = lane&15, k = lane>>4), B operand = Lr (col r =
@@ -1159,11 +1217,13 @@ struct sfmhip_ba {
   bool cam_used_known = false;
   // plan
   Chunk* d_chunks = nullptr;
-  int* d_chunk_ids[2] = {nullptr, nullptr};
-  int n_chunk_ids[2] = {0, 0};
+  int* d_chunk_ids[4] = {nullptr, nullptr, nullptr, nullptr};  // by Gram width class NB-1
+  int n_chunk_ids[4] = {0, 0, 0, 0};
   int* d_sig_cams = nullptr;
-  unsigned* d_items = nullptr;
-  int* d_item_off = nullptr;
+  int* d_cptr = nullptr;  // camera-major observation list: cptr[nc+1], cpt[no], cxy[no]
+  int* d_cpt = nullptr;
+  double2* d_cxy = nullptr;
+  int cam_split = 1;
   int* d_fb_points = nullptr;
   int n_fb = 0;
   // device storage owned
@@ -1273,10 +1333,11 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
     optr[sp + 1] = (int)ocam.size();
   }
   b->no = (int)ocam.size();
-  // ---- chunks: runs of equal signature, strictly ascending cameras, n <= 10 -> register path
+  // ---- chunks: runs of equal signature with strictly ascending cameras, n <= 10 -> MFMA path,
+  //      classed by the width of the local Gram matrix: NB = ceil((6n+2)/16) column blocks
   std::vector<Chunk> chunks;
-  std::vector<int> ids[2], sig_cams, fb;
-  const int target = std::max(8, std::min(64, (b->np + 2047) / 2048));
+  std::vector<int> ids[4], sig_cams, fb;
+  const int target = std::max(32, std::min(512, (b->np + 767) / 768));  // points per workgroup
   for (int sp = 0; sp < b->np;) {
     int e = sp + 1;
     while (e < b->np && !sig_less(order[sp], order[e]) && !sig_less(order[e], order[sp])) ++e;
@@ -1286,25 +1347,33 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
     if (n <= 10 && strict) {
       const int so = (int)sig_cams.size();
       for (int k = 0; k < n; ++k) sig_cams.push_back(ocam[optr[sp] + k]);
-      for (int q = sp; q < e; q += target) {
-        ids[n <= 7 ? 0 : 1].push_back((int)chunks.size());
-        chunks.push_back(Chunk{so, n, q, std::min(target, e - q)});
+      const int nb = (6 * n + 2 + 15) / 16;
+      const int parts = (e - sp + target - 1) / target;
+      for (int q = 0; q < parts; ++q) {
+        const int lo = sp + (int)((long long)(e - sp) * q / parts), hi = sp + (int)((long long)(e - sp) * (q + 1) / parts);
+        ids[nb - 1].push_back((int)chunks.size());
+        chunks.push_back(Chunk{so, n, lo, hi - lo});
       }
     } else {
       for (int q = sp; q < e; ++q) fb.push_back(q);
     }
     sp = e;
   }
-  // ---- half-block item tables per n
-  std::vector<unsigned> items;
-  std::vector<int> item_off(12, 0);
-  for (int n = 1; n <= 10; ++n) {
-    item_off[n] = (int)items.size();
-    for (int a = 0; a < n; ++a)
-      for (int bb = a; bb < n; ++bb)
-        for (int h = 0; h < 2; ++h) items.push_back(pack_item(a, bb, h, 0));
-    for (int a = 0; a < n; ++a) items.push_back(pack_item(a, n, 0, 1));
-    items.push_back(pack_item(n, n, 0, 2));
+  // ---- camera-major copy of the observations (sorted point index, xy) for ba_cam_blocks
+  std::vector<int> cptr(n_cam + 1, 0), cpt(b->no);
+  std::vector<double> cxy(2 * (size_t)b->no);
+  {
+    for (int k = 0; k < b->no; ++k) cptr[ocam[k] + 1]++;
+    for (int c = 0; c < n_cam; ++c) cptr[c + 1] += cptr[c];
+    std::vector<int> fillc(cptr.begin(), cptr.end() - 1);
+    for (int sp = 0; sp < b->np; ++sp)
+      for (int k = optr[sp]; k < optr[sp + 1]; ++k) {
+        const int dst = fillc[ocam[k]]++;
+        cpt[dst] = sp;
+        cxy[2 * (size_t)dst] = oxy[2 * (size_t)k];
+        cxy[2 * (size_t)dst + 1] = oxy[2 * (size_t)k + 1];
+      }
+    b->cam_split = std::max(1, std::min(64, 1024 / std::max(n_cam, 1)));
   }
   // ---- device storage
   BaDev& d = b->d;
@@ -1341,11 +1410,11 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   BA_A(d.info, 1);
   BA_A(b->d_cam_used, n_cam);
   BA_A(b->d_chunks, chunks.size());
-  BA_A(b->d_chunk_ids[0], ids[0].size());
-  BA_A(b->d_chunk_ids[1], ids[1].size());
+  for (int c = 0; c < 4; ++c) BA_A(b->d_chunk_ids[c], ids[c].size());
   BA_A(b->d_sig_cams, sig_cams.size());
-  BA_A(b->d_items, items.size());
-  BA_A(b->d_item_off, item_off.size());
+  BA_A(b->d_cptr, cptr.size());
+  BA_A(b->d_cpt, cpt.size());
+  BA_A(b->d_cxy, cpt.size());
   BA_A(b->d_fb_points, fb.size());
 #undef BA_A
   if (rc != SFMHIP_OK) {
@@ -1355,8 +1424,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   d.optr = d_optr;
   d.ocam = d_ocam;
   d.oxy = d_oxy;
-  b->n_chunk_ids[0] = (int)ids[0].size();
-  b->n_chunk_ids[1] = (int)ids[1].size();
+  for (int c = 0; c < 4; ++c) b->n_chunk_ids[c] = (int)ids[c].size();
   b->n_fb = (int)fb.size();
   auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
     return bytes ? hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
@@ -1366,11 +1434,11 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   SFM_HIP_TRY(up(d_oxy, oxy.data(), oxy.size() * 8));
   SFM_HIP_TRY(up(b->d_cam_used, b->h_cam_used.data(), n_cam));
   SFM_HIP_TRY(up(b->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk)));
-  SFM_HIP_TRY(up(b->d_chunk_ids[0], ids[0].data(), ids[0].size() * 4));
-  SFM_HIP_TRY(up(b->d_chunk_ids[1], ids[1].data(), ids[1].size() * 4));
+  for (int c = 0; c < 4; ++c) SFM_HIP_TRY(up(b->d_chunk_ids[c], ids[c].data(), ids[c].size() * 4));
   SFM_HIP_TRY(up(b->d_sig_cams, sig_cams.data(), sig_cams.size() * 4));
-  SFM_HIP_TRY(up(b->d_items, items.data(), items.size() * 4));
-  SFM_HIP_TRY(up(b->d_item_off, item_off.data(), item_off.size() * 4));
+  SFM_HIP_TRY(up(b->d_cptr, cptr.data(), cptr.size() * 4));
+  SFM_HIP_TRY(up(b->d_cpt, cpt.data(), cpt.size() * 4));
+  SFM_HIP_TRY(up(b->d_cxy, cxy.data(), cxy.size() * 8));
   SFM_HIP_TRY(up(b->d_fb_points, fb.data(), fb.size() * 4));
   SFM_HIP_TRY(hipHostMalloc((void**)&b->h_sc, sizeof(double) * (SC + 64 + 16), hipHostMallocDefault));
   for (auto& e : b->ev) SFM_HIP_TRY(hipEventCreate(&e));
@@ -1468,17 +1536,30 @@ static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_o
   SFM_HIP_TRY(hipEventRecord(b->ev[0], st));
   SFM_HIP_TRY(hipMemsetAsync(d.red, 0, sizeof(double) * b->red_count, st));
   hipLaunchKernelGGL(ba_cam_prep, dim3((b->nc + 63) / 64), dim3(64), 0, st, d.cams, d.camd, b->nc, 1);
-  if (b->n_chunk_ids[0])
-    hipLaunchKernelGGL((ba_eliminate<1>), dim3(b->n_chunk_ids[0]), dim3(64), 0, st, d, b->d_chunks, b->d_chunk_ids[0],
-                       b->d_sig_cams, b->d_items, b->d_item_off, radius, o->min_lm_diagonal, o->max_lm_diagonal, b->rank);
-  if (b->n_chunk_ids[1])
-    hipLaunchKernelGGL((ba_eliminate<2>), dim3(b->n_chunk_ids[1]), dim3(64), 0, st, d, b->d_chunks, b->d_chunk_ids[1],
-                       b->d_sig_cams, b->d_items, b->d_item_off, radius, o->min_lm_diagonal, o->max_lm_diagonal, b->rank);
+  const double inv_radius = 1.0 / radius;
+  int nl = 0;
+  if (b->no) {
+    hipLaunchKernelGGL(ba_cam_blocks, dim3(b->nc * b->cam_split), dim3(256), 0, st, d, b->d_cptr, b->d_cpt, b->d_cxy,
+                       b->cam_split);
+    ++nl;
+  }
+#define BA_ELIM(NB)                                                                                                   \
+  if (b->n_chunk_ids[NB - 1]) {                                                                                       \
+    hipLaunchKernelGGL((ba_eliminate_mfma<NB>), dim3(b->n_chunk_ids[NB - 1]), dim3(256), 0, st, d, b->d_chunks,       \
+                       b->d_chunk_ids[NB - 1], b->d_sig_cams, inv_radius, o->min_lm_diagonal, o->max_lm_diagonal,     \
+                       b->rank);                                                                                      \
+    ++nl;                                                                                                             \
+  }
+  BA_ELIM(1)
+  BA_ELIM(2)
+  BA_ELIM(3)
+  BA_ELIM(4)
+#undef BA_ELIM
   if (b->n_fb)
     hipLaunchKernelGGL(ba_eliminate_generic, dim3(b->n_fb), dim3(64), 0, st, d, b->d_fb_points, radius,
                        o->min_lm_diagonal, o->max_lm_diagonal, b->rank);
   SFM_HIP_TRY(hipGetLastError());
-  b->launches += 2 + (b->n_chunk_ids[0] > 0) + (b->n_chunk_ids[1] > 0) + (b->n_fb > 0);
+  b->launches += 2 + nl + (b->n_fb > 0);
   SFM_HIP_TRY(hipEventRecord(b->ev[1], st));
   SFM_TRY(ba_allreduce(b, d.red, b->ssz + 3 * (size_t)b->ld + SC + b->world));
   SFM_HIP_TRY(hipEventRecord(b->ev[2], st));
