@@ -294,19 +294,44 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const ImgDev* __restri
     frags(sb, 0, a, bs);
     v16i acc0 = chain(a, 0), acc1;
 
-    // one train tile (cur) against both query tiles; prefetches tile tl+1 into (nxt) and starts
-    // its first MFMA chain before the second insertion
+    // one train tile (cur) against both query tiles; prefetches tile tl+1 into (nxt)
+    // MFMA and VALU of one wave do not overlap by themselves: a wave stalls in-order on the
+    // matrix pipe while it issues a dependent chain, and two identical waves on a SIMD lock
+    // into the same phase (measured: time = MFMA + VALU, scripts/ubench/valu_rate.hip).  So the
+    // 4 MFMAs of the next unit are spread through the 48 insertion ops of the current one
+    // (1 MFMA : 12 VALU >= 32 cycles apart: the chain never waits for the pipe).
+#define SFM_INTERLEAVE(with_ds)                                                      \
+  do {                                                                               \
+    _Pragma("unroll") for (int sg = 0; sg < KS; ++sg) {                              \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
+      if (with_ds) __builtin_amdgcn_sched_group_barrier(0x100, (KS + 4 + KS - 1) / KS, 0); \
+      __builtin_amdgcn_sched_group_barrier(0x002, 48 / KS, 0);                       \
+    }                                                                                \
+  } while (0)
+    // (KS == 8 keeps the two phases apart: its fragments leave no registers for the overlap.)
 #define SFM_TILE_BODY(tl, ca, cb, na, nb_)      \
   do {                                          \
-    acc1 = chain(ca, 1);                        \
-    frags(sb, (tl) + 1, na, nb_);               \
-    __builtin_amdgcn_sched_barrier(0);          \
-    insert(acc0, cb, 0);                        \
-    __builtin_amdgcn_sched_barrier(0);          \
-    acc0 = chain(na, 0);                        \
-    __builtin_amdgcn_sched_barrier(0);          \
-    insert(acc1, cb, 1);                        \
-    __builtin_amdgcn_sched_barrier(0);          \
+    if constexpr (KS <= 4) {                    \
+      acc1 = chain(ca, 1);                      \
+      frags(sb, (tl) + 1, na, nb_);             \
+      insert(acc0, cb, 0);                      \
+      SFM_INTERLEAVE(true);                     \
+      __builtin_amdgcn_sched_barrier(0);        \
+      acc0 = chain(na, 0);                      \
+      insert(acc1, cb, 1);                      \
+      SFM_INTERLEAVE(false);                    \
+      __builtin_amdgcn_sched_barrier(0);        \
+    } else {                                    \
+      acc1 = chain(ca, 1);                      \
+      frags(sb, (tl) + 1, na, nb_);             \
+      __builtin_amdgcn_sched_barrier(0);        \
+      insert(acc0, cb, 0);                      \
+      __builtin_amdgcn_sched_barrier(0);        \
+      acc0 = chain(na, 0);                      \
+      __builtin_amdgcn_sched_barrier(0);        \
+      insert(acc1, cb, 1);                      \
+      __builtin_amdgcn_sched_barrier(0);        \
+    }                                           \
   } while (0)
 
     // next stage: global -> registers, half a stage ahead of the LDS write.  Past the last
@@ -359,6 +384,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const ImgDev* __restri
     insert(acc1, bn, 1);
     asm volatile("" : "+v"(k0[1]), "+v"(k1[1]));
 #undef SFM_TILE_BODY
+#undef SFM_INTERLEAVE
     if (PIECES > 1) {
       *(v4i*)(nb + HALF * 4096 + tid * 16) = stg0;
       if (HALF > 1) *(v4i*)(nb + (HALF + 1) * 4096 + tid * 16) = stg1;
