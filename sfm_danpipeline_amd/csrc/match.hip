@@ -129,8 +129,10 @@ __global__ void prepare_kernel(const ImgDev* __restrict__ imgs, const int* __res
       const int nbits = dim * 8;
       b = valid ? (((unsigned)nbits << (IB - 1)) | jl) : (((unsigned)(nbits + 1) << IB) | jl);
     } else {
+      // +RB*16384 (KOFF of the k-NN kernel): keys stay non-negative without the query norm;
+      // the largest value, padding rows, is RB*65280 + 3 < 2^24 for RB <= 256
       const unsigned nt_inv = (unsigned)(RB * 48896 + 2);
-      b = ((valid ? (unsigned)n2 + 1u : nt_inv + 1u) << IB) | jl;
+      b = ((valid ? (unsigned)n2 + 1u : nt_inv + 1u) + (unsigned)(RB * 16384)) << IB | jl;
     }
     I.base[row] = b;
     I.nq[row] = valid ? n2 : 0;
@@ -188,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const ImgDev* __restri
                                                           int2* __restrict__ fix_items) {
   constexpr int NC = 2 * KS;
   constexpr int RB = 32 * KS;
+  constexpr int KOFF = RB * 16384;  // >= any ||q||^2 of centred i8 rows
   constexpr int STAGE_ROW_BYTES = SR * RB;
   constexpr int STAGE_BYTES = STAGE_ROW_BYTES + SR * 4;
   constexpr int TILES = SR / TILE_ROWS;
@@ -205,7 +208,9 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const ImgDev* __restri
   const int nqt = (Q.n_rows + TILE_ROWS - 1) / TILE_ROWS;
   const int qt[2] = {it.qtile0 + 2 * wave, it.qtile0 + 2 * wave + 1};
 
-  // key = base - 2^(IB+1) * (dot + cq)  (L2)   |   base - 2^(IB-1) * dot  (Hamming).
+  // key = base - 2^(IB+1) * dot  (L2)   |   base - 2^(IB-1) * dot  (Hamming).  The query's own
+  // norm is the same for every train row, so it stays out of the keys (added back when the
+  // winners are emitted); base carries +KOFF so that keys stay non-negative without it.
   // The multiplier is made opaque so that hipcc keeps one v_mad_i32_i24 per element instead of
   // strength-reducing it into a shift and a subtract.
   int mul;
@@ -213,17 +218,14 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const ImgDev* __restri
 
   // query fragments (B operand): lane (r,h) holds bytes [32ks+16h, +16) of query row r
   v4i bq[2][KS];
-  v16i cin[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int t = qt[u] < nqt ? qt[u] : (nqt > 0 ? nqt - 1 : 0);
     g_v4i_p src = (g_v4i_p)(Q.tiles + (size_t)t * (TILE_ROWS * RB));
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) bq[u][ks] = src[chunk_pos<NC>(r, 2 * ks + h)];
-    const int cq = (MODE == 0) ? -(((g_i32_p)Q.nq)[t * TILE_ROWS + r] >> 1) : 0;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) cin[u][e] = cq;
   }
+  const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
   // per-lane LDS byte offsets of the A fragments inside a tile, and of the key bases
   int aoff[KS];
@@ -243,157 +245,133 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const ImgDev* __restri
   const int nstages = T.n_pad / SR;
   const int tid = threadIdx.x;
 
-  // stage 0: straight copy (the tile image is already in LDS order)
-  {
-    g_v4i_p src = (g_v4i_p)T.tiles;
+  // Stage copy: the tile image is already in LDS order, so a stage is a linear copy; LDS-DMA
+  // (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs, no ds_write) moves it.
+  auto stage_copy = [&](int stage, unsigned char* dstb) {
+    const unsigned char* src = (const unsigned char*)T.tiles + (size_t)stage * STAGE_ROW_BYTES;
 #pragma unroll
-    for (int i = 0; i < PIECES; ++i) *(v4i*)(lds + i * 4096 + tid * 16) = src[i * 256 + tid];
-    if (tid < SR) *(unsigned*)(lds + STAGE_ROW_BYTES + tid * 4) = ((g_u32_p)T.base)[tid];
-  }
+    for (int i = 0; i < PIECES; ++i)
+      __builtin_amdgcn_global_load_lds((const SFM_GLOBAL void*)(src + (size_t)(i * 256 + tid) * 16),
+                                       (__attribute__((address_space(3))) void*)(dstb + i * 4096 + wave * 1024), 16, 0, 0);
+    if (wave < SR / 64)
+      __builtin_amdgcn_global_load_lds((const SFM_GLOBAL void*)(T.base + (size_t)stage * SR + tid),
+                                       (__attribute__((address_space(3))) void*)(dstb + STAGE_ROW_BYTES + wave * 256), 4, 0, 0);
+  };
+  stage_copy(0, lds);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  auto chain = [&](const v4i (&a)[KS], int u) -> v16i {
-    v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], bq[u][0], cin[u], 0, 0, 0);
-#pragma unroll
-    for (int ks = 1; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks], bq[u][ks], acc, 0, 0, 0);
-    return acc;
+  // one step of the MFMA chain of (fragments fr, query tile u): ks-th K slice
+#define SFM_MFMA(ACC, FR, u, ks) \
+  ACC = __builtin_amdgcn_mfma_i32_32x32x32_i8(FR[ks], bq[u][ks], (ks) == 0 ? zero16 : ACC, 0, 0, 0)
+  // top-2 insertion of accumulator element e of query tile u
+#define SFM_INS(ACC, BS, u, e)                                                             \
+  do {                                                                                     \
+    const unsigned key_ = (unsigned)__mul24(ACC[e], mul) + BS[e];            /* v_mad_i32_i24 */ \
+    const unsigned n1_ = umax_(umin_(k0[u], k1[u]), umin_(umax_(k0[u], k1[u]), key_)); /* v_med3_u32 */ \
+    k0[u] = umin_(k0[u], key_);                                                            \
+    k1[u] = n1_;                                                                           \
+    asm volatile("" : "+v"(k0[u]), "+v"(k1[u])); /* no min/max re-association across elements */ \
+  } while (0)
+  auto ld_afrag = [&](const unsigned char* sb, int tl, int ks) -> v4i {
+    const int4 x = *(const int4*)(sb + tl * (TILE_ROWS * RB) + aoff[ks]);
+    return v4i{x.x, x.y, x.z, x.w};
   };
-  auto insert = [&](const v16i& acc, const unsigned (&bs)[16], int u) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const unsigned key = (unsigned)__mul24(acc[e], mul) + bs[e];                         // v_mad_i32_i24
-      const unsigned n1 = umax_(umin_(k0[u], k1[u]), umin_(umax_(k0[u], k1[u]), key));  // v_med3_u32
-      k0[u] = umin_(k0[u], key);
-      k1[u] = n1;
-    }
+  auto ld_bases = [&](const unsigned char* sb, int tl, int gq, unsigned (&bs)[16]) {
+    const uint4 x = *(const uint4*)(sb + boff + (tl * TILE_ROWS + 8 * gq) * 4);
+    bs[4 * gq] = x.x;
+    bs[4 * gq + 1] = x.y;
+    bs[4 * gq + 2] = x.z;
+    bs[4 * gq + 3] = x.w;
   };
-  auto frags = [&](const unsigned char* sb, int tl, v4i (&a)[KS], unsigned (&bs)[16]) {
+
+  // MFMA and VALU of a SIMD do not overlap here: the epilogue is VALU-issue-bound (3 ops per
+  // distance: scripts/ubench/valu_rate.hip measures time = VALU issue + 8 cycles per MFMA whatever
+  // the interleave), and a wave that issues a dependent MFMA chain back to back stalls in order
+  // on the matrix pipe.  So per train tile the 2*KS MFMAs of the NEXT tile (both query tiles)
+  // are spread one per group through the 96 insertion ops of the CURRENT tile, the insertions of
+  // the two query tiles alternate (two independent dependency chains per wave), and the LDS
+  // fragment / key-base reads of the tile after ride along.  Groups are pinned by sched_barrier.
+  constexpr int MPG = (KS + 3) / 4;  // MFMAs per group and query tile
+#define SFM_GROUP(g_, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, do_mfma, do_frag)              \
+  do {                                                                                         \
+    if (do_mfma) {                                                                             \
+      _Pragma("unroll") for (int j_ = 0; j_ < MPG; ++j_) {                                     \
+        const int ks_ = ((g_) & 3) * MPG + j_;                                                 \
+        if (ks_ < KS) {                                                                        \
+          if ((g_) < 4) SFM_MFMA(NA0, FN, 0, ks_);                                             \
+          else SFM_MFMA(NA1, FN, 1, ks_);                                                      \
+        }                                                                                      \
+      }                                                                                        \
+      if ((g_) >= 4) ld_bases(SB, (tl) + 1, (g_) - 4, BN);                                     \
+      else if (do_frag) {                                                                      \
+        _Pragma("unroll") for (int j_ = 0; j_ < MPG; ++j_)                                     \
+          if ((g_) * MPG + j_ < KS) FNN[(g_) * MPG + j_] = ld_afrag(SB, (tl) + 2, (g_) * MPG + j_); \
+      }                                                                                        \
+    }                                                                                          \
+    SFM_INS(CA0, BC, 0, 2 * (g_));                                                             \
+    SFM_INS(CA1, BC, 1, 2 * (g_));                                                             \
+    SFM_INS(CA0, BC, 0, 2 * (g_) + 1);                                                         \
+    SFM_INS(CA1, BC, 1, 2 * (g_) + 1);                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+  } while (0)
+#define SFM_BODY(SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_)                        \
+  do {                                                                                         \
+    SFM_GROUP(0, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
+    SFM_GROUP(1, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
+    SFM_GROUP(2, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
+    SFM_GROUP(3, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
+    SFM_GROUP(4, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
+    SFM_GROUP(5, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
+    SFM_GROUP(6, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
+    SFM_GROUP(7, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
+  } while (0)
+
+  // fragments ping-pong between fa / fb, key bases between ba / bb, accumulators between
+  // (A0, A1) and (B0, B1): tile tl inserts from one pair while tile tl+1 accumulates in the
+  // other.  The pipeline runs across stages: one workgroup barrier per stage, placed before the
+  // stage's last tile body, whose MFMAs already read tile 0 of the next stage.
+  static_assert(TILES == 4 || TILES == 8, "stage = 4 or 8 train tiles");
+  v4i fa[KS], fb[KS];
+  unsigned ba[16], bb[16];
+  v16i A0, A1, B0, B1;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int4 x = *(const int4*)(sb + tl * (TILE_ROWS * RB) + aoff[ks]);
-      a[ks] = v4i{x.x, x.y, x.z, x.w};
-    }
+  for (int ks = 0; ks < KS; ++ks) fa[ks] = ld_afrag(lds, 0, ks);
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      const uint4 x = *(const uint4*)(sb + boff + (tl * TILE_ROWS + 8 * gq) * 4);
-      bs[4 * gq] = x.x;
-      bs[4 * gq + 1] = x.y;
-      bs[4 * gq + 2] = x.z;
-      bs[4 * gq + 3] = x.w;
-    }
-  };
+  for (int gq = 0; gq < 4; ++gq) ld_bases(lds, 0, gq, ba);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) SFM_MFMA(A0, fa, 0, ks);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) SFM_MFMA(A1, fa, 1, ks);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) fb[ks] = ld_afrag(lds, 1, ks);
+  __builtin_amdgcn_sched_barrier(0);
 
   for (int s = 0; s < nstages; ++s) {
     const unsigned char* sb = lds + (s & 1) * STAGE_BYTES;
     unsigned char* nb = lds + ((s & 1) ^ 1) * STAGE_BYTES;
     const bool more = s + 1 < nstages;
+    // the other buffer was last read before the previous stage's barrier: refill it now
+    if (more) stage_copy(s + 1, nb);
 
-    // fragments ping-pong between (a,bs) and (an,bn); acc0/acc1 are the two chains in flight
-    v4i a[KS], an[KS];
-    unsigned bs[16], bn[16];
-    frags(sb, 0, a, bs);
-    v16i acc0 = chain(a, 0), acc1;
-
-    // one train tile (cur) against both query tiles; prefetches tile tl+1 into (nxt)
-    // MFMA and VALU of one wave do not overlap by themselves: a wave stalls in-order on the
-    // matrix pipe while it issues a dependent chain, and two identical waves on a SIMD lock
-    // into the same phase (measured: time = MFMA + VALU, scripts/ubench/valu_rate.hip).  So the
-    // 4 MFMAs of the next unit are spread through the 48 insertion ops of the current one
-    // (1 MFMA : 12 VALU >= 32 cycles apart: the chain never waits for the pipe).
-#define SFM_INTERLEAVE(with_ds)                                                      \
-  do {                                                                               \
-    _Pragma("unroll") for (int sg = 0; sg < KS; ++sg) {                              \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
-      if (with_ds) __builtin_amdgcn_sched_group_barrier(0x100, (KS + 4 + KS - 1) / KS, 0); \
-      __builtin_amdgcn_sched_group_barrier(0x002, 48 / KS, 0);                       \
-    }                                                                                \
-  } while (0)
-    // (KS == 8 keeps the two phases apart: its fragments leave no registers for the overlap.)
-#define SFM_TILE_BODY(tl, ca, cb, na, nb_)      \
-  do {                                          \
-    if constexpr (KS <= 4) {                    \
-      acc1 = chain(ca, 1);                      \
-      frags(sb, (tl) + 1, na, nb_);             \
-      insert(acc0, cb, 0);                      \
-      SFM_INTERLEAVE(true);                     \
-      __builtin_amdgcn_sched_barrier(0);        \
-      acc0 = chain(na, 0);                      \
-      insert(acc1, cb, 1);                      \
-      SFM_INTERLEAVE(false);                    \
-      __builtin_amdgcn_sched_barrier(0);        \
-    } else {                                    \
-      acc1 = chain(ca, 1);                      \
-      frags(sb, (tl) + 1, na, nb_);             \
-      __builtin_amdgcn_sched_barrier(0);        \
-      insert(acc0, cb, 0);                      \
-      __builtin_amdgcn_sched_barrier(0);        \
-      acc0 = chain(na, 0);                      \
-      __builtin_amdgcn_sched_barrier(0);        \
-      insert(acc1, cb, 1);                      \
-      __builtin_amdgcn_sched_barrier(0);        \
-    }                                           \
-  } while (0)
-
-    // next stage: global -> registers, half a stage ahead of the LDS write.  Past the last
-    // stage the copy is repeated from the current one (harmless, keeps the code branch-free).
-    g_v4i_p nsrc = (g_v4i_p)((const unsigned char*)T.tiles + (size_t)(more ? s + 1 : s) * STAGE_ROW_BYTES);
-    v4i stg0, stg1, stg2, stg3;  // named registers: an indexed array ends up in scratch
-    stg0 = nsrc[tid];
-    if (HALF > 1) stg1 = nsrc[256 + tid];
-    if (HALF > 2) {
-      stg2 = nsrc[2 * 256 + tid];
-      stg3 = nsrc[3 * 256 + tid];
+    SFM_BODY(sb, 0, A0, A1, B0, B1, fb, fa, ba, bb, true, true);
+    SFM_BODY(sb, 1, B0, B1, A0, A1, fa, fb, bb, ba, true, true);
+    if (TILES == 8) {
+      SFM_BODY(sb, 2, A0, A1, B0, B1, fb, fa, ba, bb, true, true);
+      SFM_BODY(sb, 3, B0, B1, A0, A1, fa, fb, bb, ba, true, true);
+      SFM_BODY(sb, 4, A0, A1, B0, B1, fb, fa, ba, bb, true, true);
+      SFM_BODY(sb, 5, B0, B1, A0, A1, fa, fb, bb, ba, true, true);
     }
-    const unsigned stg_base = ((g_u32_p)T.base)[(size_t)(more ? s + 1 : s) * SR + (tid < SR ? tid : 0)];
-
-    // trip counts are made opaque: a loop hipcc can fully unroll turns into straight-line code
-    // whose insertions get sunk below the later MFMA chains (every accumulator live -> spills)
-    int n1 = TILES / 4, n2 = TILES / 4 - 1;
-    asm volatile("" : "+s"(n1), "+s"(n2));
-#pragma unroll 1
-    for (int i = 0, tl = 0; i < n1; ++i, tl += 2) {
-      SFM_TILE_BODY(tl, a, bs, an, bn);
-      SFM_TILE_BODY(tl + 1, an, bn, a, bs);
+    // tile TILES-2: its MFMAs take the last tile of this stage; nothing of this stage left to prefetch
+    SFM_BODY(sb, TILES - 2, A0, A1, B0, B1, fb, fa, ba, bb, true, false);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the next stage has landed
+    __syncthreads();
+    // tile TILES-1: MFMAs on tile 0 of the next stage (fragments fetched now), prefetch of its tile 1
+    if (more) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) fa[ks] = ld_afrag(nb, 0, ks);
     }
-    *(v4i*)(nb + tid * 16) = stg0;
-    if (HALF > 1) *(v4i*)(nb + 4096 + tid * 16) = stg1;
-    if (HALF > 2) {
-      *(v4i*)(nb + 2 * 4096 + tid * 16) = stg2;
-      *(v4i*)(nb + 3 * 4096 + tid * 16) = stg3;
-    }
-    if (PIECES > 1) {
-      stg0 = nsrc[HALF * 256 + tid];
-      if (HALF > 1) stg1 = nsrc[(HALF + 1) * 256 + tid];
-      if (HALF > 2) {
-        stg2 = nsrc[(HALF + 2) * 256 + tid];
-        stg3 = nsrc[(HALF + 3) * 256 + tid];
-      }
-    }
-#pragma unroll 1
-    for (int i = 0, tl = TILES / 2; i < n2; ++i, tl += 2) {
-      SFM_TILE_BODY(tl, a, bs, an, bn);
-      SFM_TILE_BODY(tl + 1, an, bn, a, bs);
-    }
-    SFM_TILE_BODY(TILES - 2, a, bs, an, bn);
-    asm volatile("" : "+v"(k0[0]), "+v"(k1[0]), "+v"(k0[1]), "+v"(k1[1]));
-    // last tile of the stage: nothing to prefetch
-    acc1 = chain(an, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    insert(acc0, bn, 0);
-    asm volatile("" : "+v"(k0[0]), "+v"(k1[0]));
-    insert(acc1, bn, 1);
-    asm volatile("" : "+v"(k0[1]), "+v"(k1[1]));
-#undef SFM_TILE_BODY
-#undef SFM_INTERLEAVE
-    if (PIECES > 1) {
-      *(v4i*)(nb + HALF * 4096 + tid * 16) = stg0;
-      if (HALF > 1) *(v4i*)(nb + (HALF + 1) * 4096 + tid * 16) = stg1;
-      if (HALF > 2) {
-        *(v4i*)(nb + (HALF + 2) * 4096 + tid * 16) = stg2;
-        *(v4i*)(nb + (HALF + 3) * 4096 + tid * 16) = stg3;
-      }
-    }
-    if (tid < SR) *(unsigned*)(nb + STAGE_ROW_BYTES + tid * 4) = stg_base;
+    SFM_BODY(nb, -1, B0, B1, A0, A1, fa, fb, bb, ba, more, more);
     // tie-break chunk boundary: fold the 8-bit-indexed keys into the running (distance, row)
     if (((s + 1) * SR) % CHUNK_ROWS == 0) {
       const int cb = ((s * SR) / CHUNK_ROWS) * CHUNK_ROWS;
@@ -403,8 +381,11 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const ImgDev* __restri
         k0[u] = k1[u] = KEY_EMPTY;
       }
     }
-    __syncthreads();
   }
+#undef SFM_BODY
+#undef SFM_GROUP
+#undef SFM_INS
+#undef SFM_MFMA
 
   // merge the two half-waves (rows 4h.. of each 8-row group) and emit
 #pragma unroll
@@ -440,9 +421,9 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const ImgDev* __restri
     if (h == 0 && qt[u] < nqt && q < Q.n_rows) {
       int s0i, s1i;
       if (MODE == 0) {
-        const int par = ((g_i32_p)Q.nq)[q] & 1;
-        s0i = (int)m.s0 - 1 + par;
-        s1i = (int)m.s1 - 1 + par;
+        const int adj = ((g_i32_p)Q.nq)[q] - 1 - KOFF;  // key >> IB = ||t||^2 + 1 + KOFF - 2 q.t
+        s0i = (int)m.s0 + adj;
+        s1i = (int)m.s1 + adj;
       } else {
         s0i = (int)m.s0;
         s1i = (int)m.s1;
