@@ -986,66 +986,104 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
 #undef CHOL_MFMA
 
 // L^T z = y.  U = L^T is upper triangular and row-major in this storage (U[i][j] = A[i*ld + j]),
-// so row i of U is contiguous.  Single workgroup of 16 waves, 32-row blocks from the bottom,
-// left-looking: wave w owns rows 2w, 2w+1 of the block and forms y_i - sum_{j beyond the block}
-// U[i][j] z[j] with coalesced 16-byte loads (the loads of the next block are issued before the
-// current block's triangular solve: they do not depend on z); wave 0 then solves the 32x32
-// diagonal block by back-substitution with v_readlane broadcasts.
-__global__ __launch_bounds__(1024) void chol_backsolve(const double* __restrict__ A, const double* __restrict__ y,
-                                                       const double* __restrict__ dinv, double* __restrict__ z,
-                                                       int ld, int nt) {
-  extern __shared__ __attribute__((aligned(16))) double sz[];  // ld doubles: the solution so far
+// so row i of U is contiguous.  Block rows are taken in groups of GB (256 rows) from the bottom:
+//   chol_backsolve_group  one workgroup of 8 waves walks the group's 32-row blocks upwards,
+//                         left-looking inside the group: wave w owns rows 4w..4w+3 of the block and
+//                         forms y_i - sum_j U[i][j] z[j] over the group's later columns (the rows
+//                         are fetched one block ahead: they do not depend on z); wave 0 then solves
+//                         the 32x32 diagonal block with v_readlane broadcasts;
+//   chol_backsolve_gemv   folds the group's solution into y of every row above the group, one
+//                         wave per row (coalesced 2 KB row segments), all CUs.
+// A single workgroup pulling the whole triangle (5.8 MB at cfg4) is bound by one CU's load
+// bandwidth; the grouping leaves it 1/GB of the triangle.
+constexpr int GB = 8;
+
+__global__ __launch_bounds__(512) void chol_backsolve_group(const double* __restrict__ A, const double* __restrict__ y,
+                                                             const double* __restrict__ dinv, double* __restrict__ z,
+                                                             int ld, int kb_lo, int kb_hi) {
+  __shared__ __attribute__((aligned(16))) double sz[GB * CB];  // z of the group's columns
   __shared__ double srhs[CB];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = lane & 31;
-  for (int kb = nt - 1; kb >= 0; --kb) {
-    const int k0 = kb * CB;
-    const int jbeg = k0 + CB;  // first column beyond the block (multiple of 32)
-    double u[CB], di = 0.0;  // wave 0: its row of the diagonal block, fetched ahead of the solve
+  const int c_lo = kb_lo * CB, c_hi = kb_hi * CB;
+  double2 pre[4][2];  // this wave's four rows of the current block, columns beyond the block
+  double u[CB], di = 0.0;  // wave 0: its row of the diagonal block
+  auto preload = [&](int kb) {
+    const int k0 = kb * CB, jbeg = k0 + CB;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const double* ui = A + (size_t)(k0 + 4 * wave + rr) * ld;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int j = jbeg + 2 * lane + 128 * it;
+        pre[rr][it] = j < c_hi ? *(const double2*)(ui + j) : make_double2(0.0, 0.0);
+      }
+    }
     if (wave == 0) {
 #pragma unroll
       for (int j = 0; j < CB; ++j) u[j] = A[(size_t)(k0 + i) * ld + k0 + j];
       di = dinv[k0 + i];
     }
-    // ---- rows k0+2w, k0+2w+1: dot products with the known part of z
-    double part[2];
+  };
+  preload(kb_hi - 1);
+  for (int kb = kb_hi - 1; kb >= kb_lo; --kb) {
+    const int k0 = kb * CB, jbeg = k0 + CB;
+    double part[4];
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const int gi = k0 + 2 * wave + rr;
-      const double* ui = A + (size_t)gi * ld;
-      double acc0 = 0.0, acc1 = 0.0;
-      for (int j = jbeg + 2 * lane; j < ld; j += 128) {
-        const double2 u = *(const double2*)(ui + j);
-        const double2 zz = *(const double2*)(sz + j);
-        acc0 += u.x * zz.x;
-        acc1 += u.y * zz.y;
+    for (int rr = 0; rr < 4; ++rr) {
+      double acc = 0.0;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int j = jbeg + 2 * lane + 128 * it;
+        if (j < c_hi) {
+          const double2 zz = *(const double2*)(sz + (j - c_lo));
+          acc += pre[rr][it].x * zz.x + pre[rr][it].y * zz.y;
+        }
       }
-      double acc = acc0 + acc1;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
       part[rr] = acc;
     }
-    if (lane == 0) {
-      srhs[2 * wave] = y[k0 + 2 * wave] - part[0];
-      srhs[2 * wave + 1] = y[k0 + 2 * wave + 1] - part[1];
-    }
+    if (lane < 4) srhs[4 * wave + lane] = y[k0 + 4 * wave + lane] - (lane == 0 ? part[0] : lane == 1 ? part[1] : lane == 2 ? part[2] : part[3]);
+    double uc[CB];
+    const double dic = di;
+#pragma unroll
+    for (int j = 0; j < CB; ++j) uc[j] = u[j];
+    if (kb > kb_lo) preload(kb - 1);  // in flight during the triangular solve below
     __syncthreads();
     if (wave == 0) {
       // ---- diagonal block: lane i = row i
       double yi = srhs[i];
 #pragma unroll
       for (int j = CB - 1; j >= 0; --j) {
-        const double zj = readlane_f64(yi * di, j);
+        const double zj = readlane_f64(yi * dic, j);
         if (i == j) yi = zj;
-        if (i < j) yi -= u[j] * zj;
+        if (i < j) yi -= uc[j] * zj;
       }
       if (lane < CB) {
-        sz[k0 + i] = yi;
+        sz[k0 - c_lo + i] = yi;
         z[k0 + i] = yi;
       }
     }
     __syncthreads();
   }
+}
+
+// y[i] -= sum_{j in [c_lo, c_hi)} U[i][j] z[j] for the rows above the group, one wave per row
+__global__ __launch_bounds__(256) void chol_backsolve_gemv(const double* __restrict__ A, double* __restrict__ y,
+                                                           const double* __restrict__ z, int ld, int c_lo, int c_hi) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= c_lo) return;
+  const double* ui = A + (size_t)row * ld;
+  double acc = 0.0;
+  for (int j = c_lo + 2 * lane; j < c_hi; j += 128) {
+    const double2 uu = *(const double2*)(ui + j);
+    const double2 zz = *(const double2*)(z + j);
+    acc += uu.x * zz.x + uu.y * zz.y;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) y[row] -= acc;
 }
 
 // ---------------------------------------------------------------- step application
@@ -1582,9 +1620,18 @@ static int ba_reduced_solve(sfmhip_ba* b) {
     const int nblk = k == 0 ? m + 1 : m * (m + 1) / 2 + m;  // launch 0 has no pending update
     hipLaunchKernelGGL(chol_step, dim3(nblk), dim3(128), 0, st, A, y, d.dinv, d.ld, nt, k, d.info);
   }
-  hipLaunchKernelGGL(chol_backsolve, dim3(1), dim3(1024), sizeof(double) * b->ld, st, A, y, d.dinv, d.z, d.ld, nt);
+  int nbs = 0;
+  for (int hi = nt; hi > 0; hi -= GB) {
+    const int lo = std::max(0, hi - GB);
+    hipLaunchKernelGGL(chol_backsolve_group, dim3(1), dim3(512), 0, st, A, y, d.dinv, d.z, d.ld, lo, hi);
+    ++nbs;
+    if (lo > 0) {
+      hipLaunchKernelGGL(chol_backsolve_gemv, dim3((lo * CB + 3) / 4), dim3(256), 0, st, A, y, d.z, d.ld, lo * CB, hi * CB);
+      ++nbs;
+    }
+  }
   SFM_HIP_TRY(hipGetLastError());
-  b->launches += nt + 1;
+  b->launches += nt + nbs;
   return SFMHIP_OK;
 }
 

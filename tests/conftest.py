@@ -4,6 +4,14 @@ import sys
 import numpy as np
 import pytest
 
+# torch ships its own ROCm runtime: load it BEFORE libsfmhip.so pulls in the system libamdhip64,
+# or a later `import torch` in the same process no longer finds the GPU ("No HIP GPUs are
+# available").  bench.py imports torch first for the same reason.
+try:
+    import torch  # noqa: F401
+except ImportError:  # the C ABI itself does not need torch
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
