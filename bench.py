@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 I8_DENSE_PEAK_TOPS = 5000.0   # 2x the ~2.5 PF dense bf16 MFMA peak (MI355X_MICROARCH.md, Matrix cores)
 F32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
+VALU_PEAK_TLANEOPS = 78.6        # 256 CU x 128 lanes x 2.4 GHz
 
 
 def main():
@@ -142,12 +143,34 @@ def main():
     ms_ba = 1e3 * t_ba / args.steps
 
     # ------------------------------------------------------------------ rooflines
+    # HBM traffic per launch comes from rocprofv3 PMC passes of this same command (FETCH_SIZE /
+    # WRITE_SIZE in separate passes, gfx950 correction 2x on FETCH_SIZE), condensed by
+    # scripts/pmc_summary.py and committed under profiles/: bench.py cannot collect counters itself.
+    traffic = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            traffic = json.load(fh)
+    except (OSError, ValueError):
+        pass
+
+    def hbm_bytes(key):
+        v = traffic.get(key, {}).get("hbm_bytes_per_launch")
+        return int(v) if v is not None else None
+
     ops_per_pair = 2.0 * n_feat * n_feat * dim                     # 1.024 GOP per cfg2 pair
     knn_tops = ops_per_pair * len(pairs) / knn_s / 1e12
+    # secondary limiter: the fused top-2 epilogue, 3 VALU lane-ops per distance
+    # (v_mad_i32_i24 + v_med3_u32 + v_min_u32) against 256 CU x 128 lanes x 2.4 GHz
+    valu_tlops = 3.0 * n_feat * n_feat * len(pairs) / knn_s / 1e12
     roofline = {"kernel": "knn_mfma_kernel<KS=4,L2> (i8 MFMA 32x32x32 + fused top-2)", "bound": "mfma",
                 "achieved": round(knn_tops, 2), "peak": I8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
-                "frac": round(knn_tops / I8_DENSE_PEAK_TOPS, 4), "traffic": None,
+                "frac": round(knn_tops / I8_DENSE_PEAK_TOPS, 4), "traffic": hbm_bytes("knn_mfma_kernel"),
                 "f32_equivalent_frac": round(knn_tops / F32_MFMA_PEAK_TFLOPS, 3),
+                "valu_epilogue": {"achieved": round(valu_tlops, 2), "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
+                                  "frac": round(valu_tlops / VALU_PEAK_TLANEOPS, 4),
+                                  "note": "min/max/med3/mad24 issue at 4 cycles per wave64 op on gfx950 "
+                                          "(scripts/ubench/op_rate.hip): the epilogue, not the MFMA pipe, "
+                                          "bounds this kernel"},
                 "launch_ms": round(knn_s * 1e3, 4), "prepare_ms": round(prep_s * 1e3, 4),
                 "compact_ms": round(comp_s * 1e3, 4)}
     n_obs_l, n_pt_l, n_cam = len(loc["obs_cam"]), len(loc["pts"]), 200
@@ -155,14 +178,18 @@ def main():
     ba_bytes = 3 * n_obs_l * 24 + 2 * n_pt_l * 24 + 2 * red_dim * red_dim * 8 + n_cam * 48   # section 8d
     ba_stream_s = (ba_t["eliminate_s"] + ba_t["backsub_s"]) / max(args.steps, 1)
     ba_gbs = ba_bytes / ba_stream_s / 1e9
-    roofline_ba = {"kernels": "ba_eliminate + ba_backsub (per LM iteration, this rank's shard)", "bound": "hbm",
-                   "achieved": round(ba_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": round(ba_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+    tr_ba = [hbm_bytes(k) for k in ("ba_cam_blocks", "ba_eliminate_mfma", "ba_backsub")]
+    roofline_ba = {"kernels": "ba_cam_blocks + ba_eliminate_mfma + ba_backsub (per LM iteration, this rank's shard)",
+                   "bound": "hbm", "achieved": round(ba_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(ba_gbs / HBM_PEAK_GBS, 4),
+                   "traffic": sum(tr_ba) if all(t is not None for t in tr_ba) else None,
                    "eliminate_ms": round(1e3 * ba_t["eliminate_s"] / args.steps, 4),
                    "allreduce_ms": round(1e3 * ba_t["allreduce_s"] / args.steps, 4),
                    "reduced_solve_ms": round(1e3 * ba_t["solve_s"] / args.steps, 4),
                    "backsub_cost_ms": round(1e3 * ba_t["backsub_s"] / args.steps, 4),
-                   "launches_per_iter": round(ba_t["launches"] / max(args.steps, 1), 1)}
+                   "launches_per_iter": round(ba_t["launches"] / max(args.steps, 1), 1),
+                   "note": "latency-bound: 38 dependent Cholesky panels + a 1216-row back substitution "
+                           "dominate the iteration (DESIGN.md section 3)"}
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only)
     cpu_baseline = None

@@ -76,7 +76,8 @@ struct BaDev {
   // to 32 (row stride of S; the padded diagonal is 1, everything else in the padding 0)
   double* red;
   double* z;     // dim solution
-  double* dinv;  // dim: 1 / diag(L)
+  double* dinv;  // ld: 1 / diag(L)
+  double* linv;  // ld*32: inverse of every diagonal tile of L, transposed ([k][col][row])
   double* red2;  // 16 scalars of the step evaluation
   int* info;     // cholesky failure flag
 };
@@ -778,8 +779,8 @@ constexpr int CBP = 34;  // LDS row pitch in doubles: 16-byte aligned rows, conf
 #define CHOL_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0)
 
 __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double* __restrict__ y,
-                                                 double* __restrict__ dinv, int ld, int nt, int k,
-                                                 int* __restrict__ info) {
+                                                 double* __restrict__ dinv, double* __restrict__ linv, int ld,
+                                                 int nt, int k, int* __restrict__ info) {
   __shared__ __attribute__((aligned(16))) double sD[CB * CBP];   // updated diagonal tile [row][col]
   __shared__ __attribute__((aligned(16))) double sT[CB * CBP];   // updated own tile      [row][col]
   __shared__ __attribute__((aligned(16))) double sLr[CB * CBP];  // L_kk [row][col]
@@ -909,22 +910,29 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
     // (row j of L broadcast from LDS, the newest column through v_readlane so that the pivot
     // chain does not wait for an LDS round trip), then pivot -> rsq -> scale.  Lanes 32..63
     // mirror lanes 0..31 (same values to the same LDS addresses).
+    // Software-pipelined: while column j's pivot chain (readlane -> rsq -> scale) runs, the
+    // products of column j+1 with the columns before j are formed, so that the next chain starts
+    // with one FMA.
     bool bad = false;
+    double pre = d[0];
 #pragma unroll
     for (int j = 0; j < CB; ++j) {
-      double acc0 = d[j], acc1 = 0.0;
-#pragma unroll
-      for (int c = 0; c + 1 < j - 1; c += 2) {
-        acc0 -= d[c] * sLr[j * CBP + c];
-        acc1 -= d[c + 1] * sLr[j * CBP + c + 1];
-      }
-      if (j >= 2 && ((j - 1) & 1)) acc0 -= d[j - 2] * sLr[j * CBP + j - 2];
-      if (j >= 1) acc1 -= d[j - 1] * readlane_f64(d[j - 1], j);
-      const double v = acc0 + acc1;
+      double v = pre;
+      if (j >= 1) v -= d[j - 1] * readlane_f64(d[j - 1], j);
       const double djj = readlane_f64(v, j);
       bad |= !(djj > 0.0);
       const double r = rsqrt_f64(djj);
       const double l = i >= j ? v * r : 0.0;  // lane j: djj * r = sqrt(djj)
+      if (j + 1 < CB) {
+        double acc0 = d[j + 1], acc1 = 0.0;
+#pragma unroll
+        for (int c = 0; c + 1 < j; c += 2) {
+          acc0 -= d[c] * sLr[(j + 1) * CBP + c];
+          acc1 -= d[c + 1] * sLr[(j + 1) * CBP + c + 1];
+        }
+        if (j & 1) acc0 -= d[j - 1] * sLr[(j + 1) * CBP + j - 1];
+        pre = acc0 + acc1;
+      }
       d[j] = l;
       sLr[i * CBP + j] = l;
       sdi[j] = r;
@@ -943,6 +951,8 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
     }
   } else {
     // ---- own tile (or the rhs row): X = T L_kk^-T, lane i = row i, one 8-column block behind
+    // (the diagonal tile's owner solves the identity instead: X = L_kk^-T, kept for the
+    // backward substitution, whose diagonal solves then are plain 32x32 products)
     double t[CB];
     if (!owner) {
 #pragma unroll
@@ -951,11 +961,14 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
         t[c] = v.x;
         t[c + 1] = v.y;
       }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CB; ++c) t[c] = c == i ? 1.0 : 0.0;
     }
 #pragma unroll
     for (int jb = 0; jb < CB / 8; ++jb) {
       __syncthreads();
-      if (!owner) {
+      {
 #pragma unroll
         for (int j = 8 * jb; j < 8 * jb + 8; ++j) {
           double acc0 = t[j], acc1 = 0.0;
@@ -970,16 +983,19 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
         }
       }
     }
-    if (!owner) {
-      if (is_rhs) {
-        if (lane == 0) {
+    if (owner) {
+      if (lane < CB) {
 #pragma unroll
-          for (int c = 0; c < CB; ++c) y[c0 + c] = t[c];
-        }
-      } else if (lane < CB) {
-#pragma unroll
-        for (int c = 0; c < CB; ++c) A[(size_t)(c0 + c) * ld + r0 + i] = t[c];
+        for (int c = 0; c < CB; ++c) linv[(size_t)(c0 + c) * CB + i] = t[c];  // (L_kk^-T)[i][c], column-major
       }
+    } else if (is_rhs) {
+      if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < CB; ++c) y[c0 + c] = t[c];
+      }
+    } else if (lane < CB) {
+#pragma unroll
+      for (int c = 0; c < CB; ++c) A[(size_t)(c0 + c) * ld + r0 + i] = t[c];
     }
   }
 }
@@ -999,15 +1015,15 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
 constexpr int GB = 8;
 
 __global__ __launch_bounds__(512) void chol_backsolve_group(const double* __restrict__ A, const double* __restrict__ y,
-                                                             const double* __restrict__ dinv, double* __restrict__ z,
+                                                             const double* __restrict__ linv, double* __restrict__ z,
                                                              int ld, int kb_lo, int kb_hi) {
   __shared__ __attribute__((aligned(16))) double sz[GB * CB];  // z of the group's columns
-  __shared__ double srhs[CB];
+  __shared__ __attribute__((aligned(16))) double srhs[CB];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = lane & 31;
   const int c_lo = kb_lo * CB, c_hi = kb_hi * CB;
   double2 pre[4][2];  // this wave's four rows of the current block, columns beyond the block
-  double u[CB], di = 0.0;  // wave 0: its row of the diagonal block
+  double u[CB];  // wave 0: its row of L_kk^-T
   auto preload = [&](int kb) {
     const int k0 = kb * CB, jbeg = k0 + CB;
 #pragma unroll
@@ -1021,8 +1037,7 @@ __global__ __launch_bounds__(512) void chol_backsolve_group(const double* __rest
     }
     if (wave == 0) {
 #pragma unroll
-      for (int j = 0; j < CB; ++j) u[j] = A[(size_t)(k0 + i) * ld + k0 + j];
-      di = dinv[k0 + i];
+      for (int j = 0; j < CB; ++j) u[j] = linv[(size_t)(k0 + j) * CB + i];
     }
   };
   preload(kb_hi - 1);
@@ -1046,23 +1061,22 @@ __global__ __launch_bounds__(512) void chol_backsolve_group(const double* __rest
     }
     if (lane < 4) srhs[4 * wave + lane] = y[k0 + 4 * wave + lane] - (lane == 0 ? part[0] : lane == 1 ? part[1] : lane == 2 ? part[2] : part[3]);
     double uc[CB];
-    const double dic = di;
 #pragma unroll
     for (int j = 0; j < CB; ++j) uc[j] = u[j];
-    if (kb > kb_lo) preload(kb - 1);  // in flight during the triangular solve below
+    if (kb > kb_lo) preload(kb - 1);  // in flight during the diagonal product below
     __syncthreads();
     if (wave == 0) {
-      // ---- diagonal block: lane i = row i
-      double yi = srhs[i];
+      // ---- diagonal block: z = L_kk^-T rhs, lane i = row i, rhs broadcast from LDS
+      double z0 = 0.0, z1 = 0.0;
 #pragma unroll
-      for (int j = CB - 1; j >= 0; --j) {
-        const double zj = readlane_f64(yi * dic, j);
-        if (i == j) yi = zj;
-        if (i < j) yi -= uc[j] * zj;
+      for (int j = 0; j < CB; j += 2) {
+        z0 += uc[j] * srhs[j];
+        z1 += uc[j + 1] * srhs[j + 1];
       }
+      const double zi = z0 + z1;
       if (lane < CB) {
-        sz[k0 - c_lo + i] = yi;
-        z[k0 + i] = yi;
+        sz[k0 - c_lo + i] = zi;
+        z[k0 + i] = zi;
       }
     }
     __syncthreads();
@@ -1375,7 +1389,29 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   //      classed by the width of the local Gram matrix: NB = ceil((6n+2)/16) column blocks
   std::vector<Chunk> chunks;
   std::vector<int> ids[4], sig_cams, fb;
-  const int target = std::max(32, std::min(512, (b->np + 767) / 768));  // points per workgroup
+  // points per workgroup: 2 workgroups of 4 waves are resident per CU (register-bound), so the
+  // launch runs in rounds of 512 workgroups; pick the run length that minimises
+  // rounds x (run length + fixed per-workgroup cost, ~40 points' worth of prologue + scatter)
+  int target = 64;
+  {
+    std::vector<int> gsz;
+    for (int sp = 0; sp < b->np;) {
+      int e = sp + 1;
+      while (e < b->np && !sig_less(order[sp], order[e]) && !sig_less(order[e], order[sp])) ++e;
+      gsz.push_back(e - sp);
+      sp = e;
+    }
+    double best = 1e300;
+    for (int t = 32; t <= 512; t += 4) {
+      long long w = 0;
+      for (int g : gsz) w += (g + t - 1) / t;
+      const double cost = (double)((w + 511) / 512) * (t + 40);
+      if (cost < best) {
+        best = cost;
+        target = t;
+      }
+    }
+  }
   for (int sp = 0; sp < b->np;) {
     int e = sp + 1;
     while (e < b->np && !sig_less(order[sp], order[e]) && !sig_less(order[e], order[sp])) ++e;
@@ -1444,6 +1480,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   BA_A(d.red, b->red_count);
   BA_A(d.z, b->ld);
   BA_A(d.dinv, b->ld);
+  BA_A(d.linv, (size_t)b->ld * CB);
   BA_A(d.red2, 16);
   BA_A(d.info, 1);
   BA_A(b->d_cam_used, n_cam);
@@ -1618,12 +1655,12 @@ static int ba_reduced_solve(sfmhip_ba* b) {
   for (int k = 0; k < nt; ++k) {
     const int m = nt - k;
     const int nblk = k == 0 ? m + 1 : m * (m + 1) / 2 + m;  // launch 0 has no pending update
-    hipLaunchKernelGGL(chol_step, dim3(nblk), dim3(128), 0, st, A, y, d.dinv, d.ld, nt, k, d.info);
+    hipLaunchKernelGGL(chol_step, dim3(nblk), dim3(128), 0, st, A, y, d.dinv, d.linv, d.ld, nt, k, d.info);
   }
   int nbs = 0;
   for (int hi = nt; hi > 0; hi -= GB) {
     const int lo = std::max(0, hi - GB);
-    hipLaunchKernelGGL(chol_backsolve_group, dim3(1), dim3(512), 0, st, A, y, d.dinv, d.z, d.ld, lo, hi);
+    hipLaunchKernelGGL(chol_backsolve_group, dim3(1), dim3(512), 0, st, A, y, d.linv, d.z, d.ld, lo, hi);
     ++nbs;
     if (lo > 0) {
       hipLaunchKernelGGL(chol_backsolve_gemv, dim3((lo * CB + 3) / 4), dim3(256), 0, st, A, y, d.z, d.ld, lo * CB, hi * CB);
