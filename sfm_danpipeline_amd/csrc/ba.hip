@@ -768,7 +768,22 @@ __global__ __launch_bounds__(1024) void ba_finalize(BaDev d, double radius, doub
 //     redundantly: POTRF in registers, row per lane, pivot and next-column terms by
 //     v_readlane, the rest of the column broadcast through LDS), wave 1 updates the
 //     workgroup's own tile and solves it against L_kk (row per lane), trailing the
-//     factorisation by one 8-column block (4 workgroup barriers).
+//     factorisation by one 4-column block (progress flag in LDS; the factorising wave never waits).
+#ifdef SFM_CHOL_STAMPS
+// diagnostic build only (scripts/chol_stamps.py): s_memtime at the phase boundaries of the panel
+// workgroup ti_rel == 1 of launch k == 4, written to a buffer nothing else reads
+__device__ unsigned long long g_chol_stamps[16];
+#define CHOL_STAMP(slot)                                                                        \
+  do {                                                                                          \
+    if (k == 4 && ti_rel == 1 && tj_rel == 0 && lane == 0) {                                    \
+      unsigned long long t_;                                                                    \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+      g_chol_stamps[slot] = t_;                                                                 \
+    }                                                                                           \
+  } while (0)
+#else
+#define CHOL_STAMP(slot)
+#endif
 constexpr int CB = 32;
 constexpr int CBP = 34;  // LDS row pitch in doubles: 16-byte aligned rows, conflict-free tile writes
 
@@ -785,6 +800,7 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
   __shared__ __attribute__((aligned(16))) double sT[CB * CBP];   // updated own tile      [row][col]
   __shared__ __attribute__((aligned(16))) double sLr[CB * CBP];  // L_kk [row][col]
   __shared__ double sdi[CB];                                     // 1 / diag(L_kk)
+  __shared__ int s_prog;                                         // columns of L_kk finished so far
   const int m = nt - k;  // remaining tile rows (the rhs row comes on top)
   // block -> tile: the m+1 tiles of block column k first (they carry the factorisation)
   int ti_rel, tj_rel;
@@ -807,6 +823,9 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
   const int j16 = lane & 15, q = lane >> 4;
   const int r0 = (k + ti_rel) * CB, c0 = (k + tj_rel) * CB, p0 = (k - 1) * CB;
   const bool rlane = j16 == 0;  // the rhs tile row has one real row: tile row 0
+  if (threadIdx.x == 0) s_prog = 0;
+  __syncthreads();
+  CHOL_STAMP(wave == 0 ? 0 : 8);
 
   // element (tile row r, column index col) of the workgroup's tile row: L(r0+r, col) or, for the
   // rhs row, y[col] on tile row 0 and zero elsewhere
@@ -879,6 +898,10 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
           const int col = c0 + 16 * ci + q + 4 * g;
           acc[ci][ri][g] = diag ? A[(size_t)col * ld + c0 + 16 * ri + j16] : ld_row(16 * ri + j16, col);
         }
+#ifdef SFM_CHOL_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    CHOL_STAMP(wave == 0 ? 1 : 9);
     if (k > 0) {
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks)
@@ -896,6 +919,7 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
         for (int g = 0; g < 4; ++g) dst[(16 * ri + j16) * CBP + 16 * ci + q + 4 * g] = acc[ci][ri][g];
   }
   // (each wave reads back only what it wrote itself: LDS operations of one wave stay in order)
+  CHOL_STAMP(wave == 0 ? 2 : 10);
 
   if (wave == 0) {
     // ---- POTRF of the diagonal tile: lane i = row i (both half-waves alike)
@@ -910,9 +934,11 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
     // (row j of L broadcast from LDS, the newest column through v_readlane so that the pivot
     // chain does not wait for an LDS round trip), then pivot -> rsq -> scale.  Lanes 32..63
     // mirror lanes 0..31 (same values to the same LDS addresses).
-    // Software-pipelined: while column j's pivot chain (readlane -> rsq -> scale) runs, the
-    // products of column j+1 with the columns before j are formed, so that the next chain starts
-    // with one FMA.
+    // Software-pipelined: the products of column j+1 with the columns before j are formed in
+    // the shadow of column j's pivot chain (readlane -> rsq -> two Newton steps -> scale), so the
+    // next chain starts with one FMA.  (Measured, scripts/ubench/op_rate64: a lone wave issues
+    // an f64 op every ~5.4 cycles, 8.4 when dependent, v_rsq_f64 16: the ~60 instructions of a
+    // column, not the chain, set its ~450 cycles.)
     bool bad = false;
     double pre = d[0];
 #pragma unroll
@@ -924,21 +950,28 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
       const double r = rsqrt_f64(djj);
       const double l = i >= j ? v * r : 0.0;  // lane j: djj * r = sqrt(djj)
       if (j + 1 < CB) {
-        double acc0 = d[j + 1], acc1 = 0.0;
+        double pa[4] = {d[j + 1], 0.0, 0.0, 0.0};
 #pragma unroll
         for (int c = 0; c + 1 < j; c += 2) {
-          acc0 -= d[c] * sLr[(j + 1) * CBP + c];
-          acc1 -= d[c + 1] * sLr[(j + 1) * CBP + c + 1];
+          const double2 x = *(const double2*)(sLr + (j + 1) * CBP + c);
+          pa[c & 3] -= d[c] * x.x;
+          pa[(c + 1) & 3] -= d[c + 1] * x.y;
         }
-        if (j & 1) acc0 -= d[j - 1] * sLr[(j + 1) * CBP + j - 1];
-        pre = acc0 + acc1;
+        if (j & 1) pa[(j - 1) & 3] -= d[j - 1] * sLr[(j + 1) * CBP + j - 1];
+        pre = (pa[0] + pa[1]) + (pa[2] + pa[3]);
       }
       d[j] = l;
       sLr[i * CBP + j] = l;
       sdi[j] = r;
       __builtin_amdgcn_sched_barrier(0);  // keep the columns in order
-      if ((j & 7) == 7) __syncthreads();
+      // progress flag for the solving wave (LDS operations of one wave stay in order, so the
+      // columns are in LDS before the flag); the factorising wave never waits for anybody
+      if ((j & 3) == 3) {
+        asm volatile("" ::: "memory");
+        *(volatile int*)&s_prog = j + 1;
+      }
     }
+    CHOL_STAMP(3);
     if (owner) {
       // the diagonal tile's owner publishes L_kk and 1/diag
       if (bad && lane == 0) atomicExch(info, k * CB + 1);  // the host discards the step
@@ -953,6 +986,7 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
     // ---- own tile (or the rhs row): X = T L_kk^-T, lane i = row i, one 8-column block behind
     // (the diagonal tile's owner solves the identity instead: X = L_kk^-T, kept for the
     // backward substitution, whose diagonal solves then are plain 32x32 products)
+    const unsigned prog_addr = (unsigned)(size_t)(__attribute__((address_space(3))) int*)&s_prog;
     double t[CB];
     if (!owner) {
 #pragma unroll
@@ -966,23 +1000,41 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
       for (int c = 0; c < CB; ++c) t[c] = c == i ? 1.0 : 0.0;
     }
 #pragma unroll
-    for (int jb = 0; jb < CB / 8; ++jb) {
-      __syncthreads();
+    for (int jb = 0; jb < CB / 4; ++jb) {
+      {
+        // wait until the factorising wave has published 4*jb+4 columns: one opaque asm block (a
+        // C loop here splits the unrolled solve into basic blocks and the allocator spills)
+        int seen_;
+        asm volatile(
+            "1:\n\t"
+            "ds_read_b32 %0, %1\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_cmp_lt_i32 vcc, %0, %2\n\t"
+            "s_cbranch_vccz 2f\n\t"
+            "s_sleep 1\n\t"
+            "s_branch 1b\n\t"
+            "2:\n\t"
+            : "=&v"(seen_)
+            : "v"(prog_addr), "v"(4 * jb + 4)
+            : "vcc", "memory");
+      }
       {
 #pragma unroll
-        for (int j = 8 * jb; j < 8 * jb + 8; ++j) {
-          double acc0 = t[j], acc1 = 0.0;
+        for (int j = 4 * jb; j < 4 * jb + 4; ++j) {
+          double ta[4] = {t[j], 0.0, 0.0, 0.0};
 #pragma unroll
           for (int c = 0; c + 1 < j; c += 2) {
-            acc0 -= t[c] * sLr[j * CBP + c];
-            acc1 -= t[c + 1] * sLr[j * CBP + c + 1];
+            const double2 x = *(const double2*)(sLr + j * CBP + c);
+            ta[c & 3] -= t[c] * x.x;
+            ta[(c + 1) & 3] -= t[c + 1] * x.y;
           }
-          if (j & 1) acc0 -= t[j - 1] * sLr[j * CBP + j - 1];
-          t[j] = (acc0 + acc1) * sdi[j];
+          if (j & 1) ta[(j - 1) & 3] -= t[j - 1] * sLr[j * CBP + j - 1];
+          t[j] = ((ta[0] + ta[1]) + (ta[2] + ta[3])) * sdi[j];
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
+    CHOL_STAMP(11);
     if (owner) {
       if (lane < CB) {
 #pragma unroll
@@ -997,6 +1049,7 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
 #pragma unroll
       for (int c = 0; c < CB; ++c) A[(size_t)(c0 + c) * ld + r0 + i] = t[c];
     }
+    CHOL_STAMP(12);
   }
 }
 #undef CHOL_MFMA
@@ -1303,6 +1356,12 @@ static int ba_alloc(sfmhip_ba* b, T** p, size_t n) {
   b->allocs.push_back((void*)*p);
   return SFMHIP_OK;
 }
+
+#ifdef SFM_CHOL_STAMPS
+extern "C" int sfmhip_debug_chol_stamps(unsigned long long* out16) {
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_chol_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" void sfmhip_ba_default_opts(sfmhip_ba_opts* o) {
   if (!o) return;
