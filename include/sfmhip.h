@@ -109,6 +109,25 @@ int sfmhip_triangulate(sfmhip_ctx* ctx, const double P1[12], const double P2[12]
                        const double* xy2, int m, float max_err, double* X, float* err,
                        uint8_t* keep);
 
+/* ---- incremental-loop glue next to the hot path ----
+ * find2D3DMatches, the 2D-3D association (reference src/Sfm.cpp:1047-1090).  The cloud's tracks
+ * (Point3D::idxImage, a std::map ordered by view) come as CSR: entries trk_ptr[p]..trk_ptr[p+1]-1
+ * of (trk_view, trk_feat), ascending view.  For every cloud point, in cloud order: its feature
+ * in done_view, then the FIRST match (match order) whose queryIdx (done_view < new_view) or
+ * trainIdx (otherwise) is that feature; emits (cloud index, feature index in the new view).
+ * out_cloud/out_feat: n_cloud entries each. */
+int sfmhip_find_2d3d(sfmhip_ctx* ctx, const int32_t* trk_ptr, const int32_t* trk_view,
+                     const int32_t* trk_feat, int n_cloud, int done_view, int new_view,
+                     const int32_t* match_q, const int32_t* match_t, int n_match,
+                     int32_t* out_cloud, int32_t* out_feat, int32_t* n_out);
+/* mergeNewPoints (reference src/Sfm.cpp:1212-1244): new point i is appended iff no point
+ * already in the cloud -- the existing ones and the new points appended before it -- lies closer
+ * than min_dist (cv::norm of the difference in double, against the float literal promoted to
+ * double).  accept: n_new bytes (1 = appended). */
+int sfmhip_merge_new_points(sfmhip_ctx* ctx, const double* cloud_xyz, int n_cloud,
+                            const double* new_xyz, int n_new, float min_dist, uint8_t* accept,
+                            int32_t* n_accepted);
+
 /* ---- adjustBundle solver core (reference src/BundleAdjustment.cpp:46-175) ---- */
 typedef struct {
   int max_iterations;           /* 500   src/BundleAdjustment.cpp:118 */

@@ -19,7 +19,8 @@ CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("sfm_oracle_match.c", "sfm_oracle_ba.c", "sfm_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("sfm_oracle_match.c", "sfm_oracle_ba.c", "sfm_oracle_incr.c",
+                                             "sfm_oracle.h", "Makefile")]
     if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs):
         return _SO
     subprocess.check_call(["make", "-C", _HERE, "-B", "libsfm_oracle.so"], stdout=subprocess.DEVNULL)
@@ -92,6 +93,10 @@ def lib():
             getattr(L, f).restype = None
         L.orc_angleaxis_rotate_point.argtypes = [vp, vp, vp]
         L.orc_angleaxis_rotate_point.restype = None
+        L.orc_find_2d3d.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp]
+        L.orc_find_2d3d.restype = C.c_int
+        L.orc_merge_new_points.argtypes = [vp, C.c_int, vp, C.c_int, C.c_float, vp, vp]
+        L.orc_merge_new_points.restype = C.c_int
         _lib = L
     return _lib
 
@@ -251,3 +256,32 @@ def rotate_point(aa, X):
     out = np.empty(3)
     lib().orc_angleaxis_rotate_point(_p(aa), _p(X), _p(out))
     return out
+
+
+def find_2d3d(trk_ptr, trk_view, trk_feat, done_view, new_view, match_q, match_t):
+    """find2D3DMatches association (reference src/Sfm.cpp:1047-1090): cloud tracks as CSR.
+    Returns (cloud indices, feature indices in the new view), in cloud order."""
+    trk_ptr = np.ascontiguousarray(trk_ptr, np.int32)
+    trk_view = np.ascontiguousarray(trk_view, np.int32)
+    trk_feat = np.ascontiguousarray(trk_feat, np.int32)
+    mq = np.ascontiguousarray(match_q, np.int32)
+    mt = np.ascontiguousarray(match_t, np.int32)
+    n_cloud = len(trk_ptr) - 1
+    oc = np.zeros(max(n_cloud, 1), np.int32)
+    of = np.zeros(max(n_cloud, 1), np.int32)
+    n = C.c_int32(0)
+    rc = lib().orc_find_2d3d(_p(trk_ptr), _p(trk_view), _p(trk_feat), n_cloud, int(done_view), int(new_view),
+                             _p(mq), _p(mt), len(mq), _p(oc), _p(of), C.byref(n))
+    assert rc == 0
+    return oc[:n.value].copy(), of[:n.value].copy()
+
+
+def merge_new_points(cloud_xyz, new_xyz, min_dist=0.01):
+    """mergeNewPoints (reference src/Sfm.cpp:1212-1244): accept flags of the new points."""
+    cloud = np.ascontiguousarray(cloud_xyz, np.float64).reshape(-1, 3)
+    new = np.ascontiguousarray(new_xyz, np.float64).reshape(-1, 3)
+    acc = np.zeros(max(len(new), 1), np.uint8)
+    n = C.c_int32(0)
+    rc = lib().orc_merge_new_points(_p(cloud), len(cloud), _p(new), len(new), C.c_float(min_dist), _p(acc), C.byref(n))
+    assert rc == 0
+    return acc[:len(new)].astype(bool), n.value

@@ -114,6 +114,15 @@ double orc_ba_time_iterations(int n_cam, int n_pt, int n_obs, const double* cams
                               const int32_t* obs_pt, const double* obs_xy, int iters,
                               double* final_cost);
 
+/* find2D3DMatches association (src/Sfm.cpp:1047-1090) and mergeNewPoints (src/Sfm.cpp:1212-1244):
+ * see sfm_oracle_incr.c */
+int orc_find_2d3d(const int32_t* trk_ptr, const int32_t* trk_view, const int32_t* trk_feat,
+                  int n_cloud, int done_view, int new_view, const int32_t* match_q,
+                  const int32_t* match_t, int n_match, int32_t* out_cloud, int32_t* out_feat,
+                  int32_t* n_out);
+int orc_merge_new_points(const double* cloud_xyz, int n_cloud, const double* new_xyz, int n_new,
+                         float min_dist, uint8_t* accept, int32_t* n_accepted);
+
 #ifdef __cplusplus
 }
 #endif

@@ -272,27 +272,24 @@ __device__ __forceinline__ bool chol3_inv(const double C[6] /*00 10 11 20 21 22*
 }
 
 // ---------------------------------------------------------------- Jacobi scaling (iteration 0)
-// one thread per point: unscaled squared column norms.  Points complete locally; cameras and
-// the focal accumulate into red_dc (summed across ranks before ba_make_scale).
-__global__ __launch_bounds__(256) void ba_colnorms(BaDev d, int jacobi) {
+// one thread per point: unscaled squared column norms of the point's three columns (complete
+// locally) and ||x||^2 of the points.  The camera and focal columns come from ba_cam_blocks in
+// its norms-only mode (into red_dc, summed across ranks before ba_make_scale).
+__global__ __launch_bounds__(256) void ba_point_norms(BaDev d, int jacobi) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  double xn2 = 0, f2 = 0;
+  double xn2 = 0;
   if (p < d.np) {
     const double X[3] = {d.pts[3 * p], d.pts[3 * p + 1], d.pts[3 * p + 2]};
-    const double focal = *d.focal;
     double np2[3] = {0, 0, 0};
-    for (int k = d.optr[p]; k < d.optr[p + 1]; ++k) {
-      const int c = d.ocam[k];
-      const double2 xy = d.oxy[k];
-      ObsLin o;
-      obs_linearize(d.camd + (size_t)CAMD * c, X, focal, xy.x, xy.y, nullptr, nullptr, 1.0, o);
-      if (jacobi) {
-        double* dc = red_dc(d) + 6 * c;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) atomic_add_f64(dc + j, o.Jc[j] * o.Jc[j] + o.Jc[6 + j] * o.Jc[6 + j]);
+    if (jacobi) {
+      const double focal = *d.focal;
+      for (int k = d.optr[p]; k < d.optr[p + 1]; ++k) {
+        const int c = d.ocam[k];
+        const double2 xy = d.oxy[k];
+        ObsLin o;
+        obs_linearize(d.camd + (size_t)CAMD * c, X, focal, xy.x, xy.y, nullptr, nullptr, 1.0, o);
 #pragma unroll
         for (int j = 0; j < 3; ++j) np2[j] += o.Jp[j] * o.Jp[j] + o.Jp[3 + j] * o.Jp[3 + j];
-        f2 += o.Jf[0] * o.Jf[0] + o.Jf[1] * o.Jf[1];
       }
     }
 #pragma unroll
@@ -301,22 +298,12 @@ __global__ __launch_bounds__(256) void ba_colnorms(BaDev d, int jacobi) {
       xn2 += X[j] * X[j];
     }
   }
-  // block reduce f2, xn2
-  __shared__ double sh[2][4];
+  __shared__ double sh[4];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    f2 += __shfl_down(f2, o);
-    xn2 += __shfl_down(xn2, o);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    sh[0][threadIdx.x >> 6] = f2;
-    sh[1][threadIdx.x >> 6] = xn2;
-  }
+  for (int o = 32; o > 0; o >>= 1) xn2 += __shfl_down(xn2, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = xn2;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    atomic_add_f64(red_dc(d) + 6 * d.nc, sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
-    atomic_add_f64(red_sc(d) + 1, sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
-  }
+  if (threadIdx.x == 0) atomic_add_f64(red_sc(d) + 1, sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
 __global__ void ba_make_scale(BaDev d, int jacobi) {
@@ -531,7 +518,8 @@ __global__ __launch_bounds__(256, 2) void ba_eliminate_mfma(BaDev d, const Chunk
 // (6), F^T b (6), and the scalars Jf^2, Jf r, r^2; block-reduced, 36 atomics per workgroup.
 __global__ __launch_bounds__(256) void ba_cam_blocks(BaDev d, const int* __restrict__ cptr,
                                                      const int* __restrict__ cpt,
-                                                     const double2* __restrict__ cxy, int nsplit) {
+                                                     const double2* __restrict__ cxy, int nsplit,
+                                                     int norms_only /* unscaled diagonal into dc only */) {
   __shared__ double sh[4][36];
   const int c = blockIdx.x / nsplit, part = blockIdx.x - c * nsplit;
   const int k0 = cptr[c], k1 = cptr[c + 1];
@@ -542,13 +530,18 @@ __global__ __launch_bounds__(256) void ba_cam_blocks(BaDev d, const int* __restr
 #pragma unroll
   for (int e = 0; e < 36; ++e) a[e] = 0.0;
   const double* cd = d.camd + (size_t)CAMD * c;
-  const double* scp = d.scale_c + 6 * c;
-  const double sf = *d.scale_f, focal = *d.focal;
+  const double* scp = norms_only ? nullptr : d.scale_c + 6 * c;
+  const double sf = norms_only ? 1.0 : *d.scale_f, focal = *d.focal;
   for (int k = kb + threadIdx.x; k < ke; k += 256) {
     const int p = cpt[k];
     const double2 xy = cxy[k];
     const double X[3] = {d.pts[3 * p], d.pts[3 * p + 1], d.pts[3 * p + 2]};
-    const double sp[3] = {d.scale_p[3 * p], d.scale_p[3 * p + 1], d.scale_p[3 * p + 2]};
+    double sp[3] = {1.0, 1.0, 1.0};
+    if (!norms_only) {
+      sp[0] = d.scale_p[3 * p];
+      sp[1] = d.scale_p[3 * p + 1];
+      sp[2] = d.scale_p[3 * p + 2];
+    }
     ObsLin o;
     obs_linearize(cd, X, focal, xy.x, xy.y, scp, sp, sf, o);
     int e = 0;
@@ -582,7 +575,15 @@ __global__ __launch_bounds__(256) void ba_cam_blocks(BaDev d, const int* __restr
     double* gF = red_gF(d);
     double* dc = red_dc(d);
     const int sld = d.ld, fo = 6 * d.nc, r0 = 6 * c;
-    if (e < 21) {
+    if (norms_only) {
+      int i = 0, rem = e;
+      while (e < 21 && rem >= 6 - i) {
+        rem -= 6 - i;
+        ++i;
+      }
+      if (e < 21 && rem == 0) atomic_add_f64(dc + r0 + i, v);
+      if (e == 33) atomic_add_f64(dc + fo, v);
+    } else if (e < 21) {
       int i = 0, rem = e;
       while (rem >= 6 - i) {
         rem -= 6 - i;
@@ -1638,7 +1639,10 @@ static int ba_prepare_scale(sfmhip_ba* b, int jacobi) {
   const size_t tail = b->ssz + 2 * (size_t)b->ld;  // dc | sc
   SFM_HIP_TRY(hipMemsetAsync(d.red + tail, 0, sizeof(double) * ((size_t)b->ld + SC + 64), st));
   hipLaunchKernelGGL(ba_cam_prep, dim3((b->nc + 63) / 64), dim3(64), 0, st, d.cams, d.camd, b->nc, 1);
-  if (b->np) hipLaunchKernelGGL(ba_colnorms, dim3((b->np + 255) / 256), dim3(256), 0, st, d, jacobi);
+  if (b->np) hipLaunchKernelGGL(ba_point_norms, dim3((b->np + 255) / 256), dim3(256), 0, st, d, jacobi);
+  if (b->no && jacobi)
+    hipLaunchKernelGGL(ba_cam_blocks, dim3(b->nc * b->cam_split), dim3(256), 0, st, d, b->d_cptr, b->d_cpt, b->d_cxy,
+                       b->cam_split, 1);
   SFM_HIP_TRY(hipGetLastError());
   SFM_TRY(ba_allreduce(b, d.red + tail, (size_t)b->ld + SC));
   hipLaunchKernelGGL(ba_make_scale, dim3((b->dim + 255) / 256), dim3(256), 0, st, d, jacobi);
@@ -1674,7 +1678,7 @@ static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_o
   int nl = 0;
   if (b->no) {
     hipLaunchKernelGGL(ba_cam_blocks, dim3(b->nc * b->cam_split), dim3(256), 0, st, d, b->d_cptr, b->d_cpt, b->d_cxy,
-                       b->cam_split);
+                       b->cam_split, 0);
     ++nl;
   }
 #define BA_ELIM(NB)                                                                                                   \

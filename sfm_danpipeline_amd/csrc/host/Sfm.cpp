@@ -18,6 +18,13 @@ sfmhip_ctx* sfm_hip_context() {
 }
 
 void StructFromMotion::getMatching(const int& idx_query, const int& idx_train, Matching* goodMatches) {
+  if (pairCacheOn) {
+    auto it = pairCache.find(std::make_pair(idx_query, idx_train));
+    if (it != pairCache.end()) {
+      goodMatches->insert(goodMatches->end(), it->second.begin(), it->second.end());  // appends, like :605
+      return;
+    }
+  }
   const cv::Mat& q = imagesDescriptors.at(idx_query);
   const cv::Mat& t = imagesDescriptors.at(idx_train);
   if (q.rows == 0) return;
@@ -89,4 +96,124 @@ bool StructFromMotion::triangulateViews(const Points2d& query, const Points2d& t
 
 void StructFromMotion::adjustCurrentBundle() {
   BundleAdjustment::adjustBundle(nReconstructionCloud, nCameraPoses, cameraMatrix, imagesPts2D);
+}
+
+void StructFromMotion::matchAllPairs() {
+  const int n = (int)imagesDescriptors.size();
+  pairCache.clear();
+  pairCacheOn = false;
+  if (n < 2) return;
+  const cv::Mat& d0 = imagesDescriptors[0];
+  for (const cv::Mat& d : imagesDescriptors)
+    if (d.cols != d0.cols || d.type() != d0.type()) return;  // mixed descriptor kinds: per-pair calls only
+  std::vector<int32_t> rows(n), pairs;
+  for (int i = 0; i < n; ++i) rows[i] = imagesDescriptors[i].rows;
+  for (int q = 0; q < n - 1; ++q)
+    for (int t = q + 1; t < n; ++t) {  // the loop order of src/Sfm.cpp:511-512
+      pairs.push_back(q);
+      pairs.push_back(t);
+    }
+  sfmhip_ctx* ctx = sfm_hip_context();
+  sfmhip_imageset* set = nullptr;
+  sfmhip_matchplan* plan = nullptr;
+  int rc = sfmhip_imageset_create(ctx, n, rows.data(), d0.cols, d0.type() == CV_32F ? SFMHIP_F32 : SFMHIP_U8, SFMHIP_L2, &set);
+  for (int i = 0; rc == SFMHIP_OK && i < n; ++i)
+    if (rows[i] > 0) rc = sfmhip_imageset_upload(set, i, imagesDescriptors[i].ptr());
+  if (rc == SFMHIP_OK) rc = sfmhip_imageset_prepare_async(set);
+  const int n_pairs = (int)pairs.size() / 2;
+  if (rc == SFMHIP_OK) rc = sfmhip_matchplan_create(set, pairs.data(), n_pairs, &plan);
+  if (rc == SFMHIP_OK) rc = sfmhip_matchplan_run_async(plan, NN_MATCH_RATIO);
+  std::vector<int32_t> counts(n_pairs);
+  int64_t total = 0;
+  if (rc == SFMHIP_OK) rc = sfmhip_matchplan_fetch(plan, counts.data(), nullptr, nullptr, nullptr, 0, &total);
+  std::vector<int32_t> oq((size_t)total + 1), ot((size_t)total + 1);
+  std::vector<float> od((size_t)total + 1);
+  if (rc == SFMHIP_OK) rc = sfmhip_matchplan_fetch(plan, counts.data(), oq.data(), ot.data(), od.data(), total, &total);
+  if (rc == SFMHIP_OK) {
+    size_t off = 0;
+    for (int p = 0; p < n_pairs; ++p) {
+      Matching& m = pairCache[std::make_pair((int)pairs[2 * p], (int)pairs[2 * p + 1])];
+      for (int i = 0; i < counts[p]; ++i, ++off) m.push_back(cv::DMatch(oq[off], ot[off], od[off]));
+    }
+    pairCacheOn = true;
+  } else {
+    std::cerr << "matchAllPairs: " << sfmhip_error_string(rc) << std::endl;
+  }
+  sfmhip_matchplan_destroy(plan);
+  sfmhip_imageset_destroy(set);
+}
+
+void StructFromMotion::find2D3DMatches(const int& NEW_VIEW, std::vector<cv::Point3d>& points3D,
+                                       std::vector<cv::Point2d>& points2D, Matching& bestMatches, int& DONEVIEW) {
+  points3D.clear();
+  points2D.clear();
+  int bestNumMatches = 0;
+  Matching bestMatch;
+  for (int doneView : nDoneViews) {  // src/Sfm.cpp:1020-1042
+    const int queryImage = NEW_VIEW < doneView ? NEW_VIEW : doneView;
+    const int trainImage = NEW_VIEW < doneView ? doneView : NEW_VIEW;
+    Matching match;
+    getMatching(queryImage, trainImage, &match);
+    const int numMatches = (int)match.size();
+    if (numMatches > bestNumMatches) {
+      bestMatch = match;
+      bestNumMatches = numMatches;
+      DONEVIEW = doneView;
+    }
+  }
+  bestMatches = bestMatch;
+  if (bestMatch.empty() || nReconstructionCloud.empty()) return;
+  // cloud tracks as CSR (std::map order), matches as two index arrays
+  std::vector<int32_t> ptr(nReconstructionCloud.size() + 1, 0), views, feats, mq, mt;
+  for (size_t i = 0; i < nReconstructionCloud.size(); ++i) {
+    for (const auto& kv : nReconstructionCloud[i].idxImage) {
+      views.push_back(kv.first);
+      feats.push_back(kv.second);
+    }
+    ptr[i + 1] = (int32_t)views.size();
+  }
+  for (const cv::DMatch& m : bestMatch) {
+    mq.push_back(m.queryIdx);
+    mt.push_back(m.trainIdx);
+  }
+  std::vector<int32_t> oc(nReconstructionCloud.size()), of(nReconstructionCloud.size());
+  int32_t n = 0;
+  const int rc = sfmhip_find_2d3d(sfm_hip_context(), ptr.data(), views.data(), feats.data(), (int)nReconstructionCloud.size(),
+                                  DONEVIEW, NEW_VIEW, mq.data(), mt.data(), (int)mq.size(), oc.data(), of.data(), &n);
+  if (rc != SFMHIP_OK) {
+    std::cerr << "find2D3DMatches: " << sfmhip_error_string(rc) << std::endl;
+    return;
+  }
+  const std::vector<cv::Point2d>& newViewFeatures = imagesPts2D.at(NEW_VIEW);
+  for (int i = 0; i < n; ++i) {
+    points2D.push_back(newViewFeatures.at(of[i]));  // :1078-1079
+    points3D.push_back(nReconstructionCloud[oc[i]].pt);
+  }
+}
+
+void StructFromMotion::mergeNewPoints(const std::vector<Point3D>& newPointCloud) {
+  if (newPointCloud.empty()) return;
+  const float MERGE_CLOUD_POINT_MIN_MATCH_DISTANCE = 0.01;  // src/Sfm.cpp:1216
+  static_assert(sizeof(cv::Point3d) == 3 * sizeof(double), "Point3d must be three packed doubles");
+  std::vector<double> cloud(3 * nReconstructionCloud.size()), fresh(3 * newPointCloud.size());
+  for (size_t i = 0; i < nReconstructionCloud.size(); ++i) {
+    cloud[3 * i] = nReconstructionCloud[i].pt.x;
+    cloud[3 * i + 1] = nReconstructionCloud[i].pt.y;
+    cloud[3 * i + 2] = nReconstructionCloud[i].pt.z;
+  }
+  for (size_t i = 0; i < newPointCloud.size(); ++i) {
+    fresh[3 * i] = newPointCloud[i].pt.x;
+    fresh[3 * i + 1] = newPointCloud[i].pt.y;
+    fresh[3 * i + 2] = newPointCloud[i].pt.z;
+  }
+  std::vector<uint8_t> accept(newPointCloud.size());
+  int32_t n = 0;
+  const int rc = sfmhip_merge_new_points(sfm_hip_context(), cloud.data(), (int)nReconstructionCloud.size(), fresh.data(),
+                                         (int)newPointCloud.size(), MERGE_CLOUD_POINT_MIN_MATCH_DISTANCE, accept.data(), &n);
+  if (rc != SFMHIP_OK) {
+    std::cerr << "mergeNewPoints: " << sfmhip_error_string(rc) << std::endl;
+    return;
+  }
+  for (size_t i = 0; i < newPointCloud.size(); ++i)
+    if (accept[i]) nReconstructionCloud.push_back(newPointCloud[i]);  // no track merging: :1225-1240
 }

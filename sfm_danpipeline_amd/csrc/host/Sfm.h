@@ -3,6 +3,7 @@
 // (image loading, feature extraction, RANSAC pose, PMVS/PCL post-processing) is out of scope
 //  and is replaced by the loader methods at the bottom.
 #pragma once
+#include <map>
 #include <set>
 #include <string>
 #include "BundleAdjustment.h"
@@ -16,11 +17,17 @@ class StructFromMotion {
   std::vector<cv::Mat> imagesDescriptors;
   std::vector<std::vector<cv::Point2d>> imagesPts2D;
   int detector;
+  std::set<int> nDoneViews;  // reference include/Sfm.h:24-25
+  std::set<int> nGoodViews;
+  // pair-match cache: getMatching is a pure function of two descriptor
+  // matrices and the reference calls it ~1.5 N^2 times for N(N-1)/2 distinct pairs
+  std::map<std::pair<int, int>, Matching> pairCache;
+  bool pairCacheOn;
 
  public:
   std::vector<Point3D> nReconstructionCloud;
 
-  StructFromMotion() : NN_MATCH_RATIO(0.8f), detector(1) {}
+  StructFromMotion() : NN_MATCH_RATIO(0.8f), detector(1), pairCacheOn(false) {}
 
   // reference include/Sfm.h:89, src/Sfm.cpp:590-608
   void getMatching(const int& queryImage, const int& trainImage, Matching* goodMatches);
@@ -33,6 +40,15 @@ class StructFromMotion {
   bool triangulateViews(const Points2d& left, const Points2d& right, const cv::Matx34d& P1, const cv::Matx34d& P2,
                         const Matching& matches, const Intrinsics& matrixK, const std::pair<int, int>& imagePair,
                         std::vector<Point3D>& pointcloud);
+  // reference include/Sfm.h:135-137, src/Sfm.cpp:1011-1095: best done view by match count, then the
+  // 2D-3D association of the cloud against that view's matches
+  void find2D3DMatches(const int& NEW_VIEW, std::vector<cv::Point3d>& points3D, std::vector<cv::Point2d>& points2D,
+                       Matching& bestMatches, int& DONEVIEW);
+  // reference include/Sfm.h:150, src/Sfm.cpp:1212-1244
+  void mergeNewPoints(const std::vector<Point3D>& newPointCloud);
+  // The all-pairs loop of findBestPair (src/Sfm.cpp:511-515) as ONE batched device launch; fills
+  // the pair cache that getMatching then serves from (identical results, pair order q<t).
+  void matchAllPairs();
   // reference src/Sfm.cpp:883-888 is a stub whose call names a member that no longer exists;
   // wired here with imagesPts2D, the member of the required type
   void adjustCurrentBundle();
@@ -45,4 +61,8 @@ class StructFromMotion {
   const std::vector<cv::Matx34d>& cameraPoses() const { return nCameraPoses; }
   const Intrinsics& intrinsics() const { return cameraMatrix; }
   void setMatchRatio(float r) { NN_MATCH_RATIO = r; }
+  void setDoneViews(const std::set<int>& v) { nDoneViews = v; }
+  void setGoodViews(const std::set<int>& v) { nGoodViews = v; }
+  void clearPairCache() { pairCache.clear(); pairCacheOn = false; }
+  size_t pairCacheSize() const { return pairCache.size(); }
 };

@@ -6,6 +6,11 @@
 //        BA block: i32 n_cam, n_cam x f64 pose[12] | i32 n_pt, per point: f64 xyz[3], i32 n, n x (i32 view, i32 feat)
 //   out: matches of pair (0,1): i32 n, n x (i32 q, i32 t, f32 d)
 //        cloud of triangulateViews(0,1): i32 n, n x (f64 xyz[3], i32 q, i32 t)
+//        matches of pair (0,1) again, served by the pair cache after matchAllPairs(): same layout
+//        find2D3DMatches(NEW_VIEW=1) with done views {0} on that cloud: i32 DONEVIEW, i32 n,
+//              n x (f64 xyz[3], f64 xy[2])
+//        mergeNewPoints(cloud shifted by (0,0,0.004) ++ cloud shifted by (5,0,0) ++ the same again):
+//              i32 cloud size before, i32 after, then (after-before) x f64 xyz[3] of the appended points
 //        after adjustCurrentBundle: f64 K[9], n_cam x f64 pose[12], n_pt x f64 xyz[3]
 #include <cstdio>
 #include <cstdlib>
@@ -80,6 +85,50 @@ int main(int argc, char** argv) {
     const int q = p.idxImage.at(0), t = p.idxImage.at(1);
     fwrite(&q, 4, 1, o);
     fwrite(&t, 4, 1, o);
+  }
+  // ---- pair cache: one batched launch, then getMatching is served from it
+  sfm.matchAllPairs();
+  Matching cached;
+  sfm.getMatching(0, 1, &cached);
+  n = (int)cached.size();
+  fwrite(&n, 4, 1, o);
+  for (const cv::DMatch& m : cached) {
+    fwrite(&m.queryIdx, 4, 1, o);
+    fwrite(&m.trainIdx, 4, 1, o);
+    fwrite(&m.distance, 4, 1, o);
+  }
+  // ---- find2D3DMatches / mergeNewPoints on the triangulated cloud
+  sfm.nReconstructionCloud = cloud;
+  std::set<int> done;
+  done.insert(0);
+  sfm.setDoneViews(done);
+  std::vector<cv::Point3d> p3;
+  std::vector<cv::Point2d> p2;
+  Matching best;
+  int DONEVIEW = -1;
+  sfm.find2D3DMatches(1, p3, p2, best, DONEVIEW);
+  n = (int)p3.size();
+  fwrite(&DONEVIEW, 4, 1, o);
+  fwrite(&n, 4, 1, o);
+  for (int i = 0; i < n; ++i) {
+    fwrite(&p3[i].x, 8, 3, o);
+    fwrite(&p2[i].x, 8, 2, o);
+  }
+  {
+    std::vector<Point3D> fresh;
+    for (int rep = 0; rep < 3; ++rep)
+      for (const Point3D& p : cloud) {
+        Point3D q = p;
+        if (rep == 0) q.pt.z += 0.004;
+        else q.pt.x += 5.0;
+        fresh.push_back(q);
+      }
+    const int before = (int)sfm.nReconstructionCloud.size();
+    sfm.mergeNewPoints(fresh);
+    const int after = (int)sfm.nReconstructionCloud.size();
+    fwrite(&before, 4, 1, o);
+    fwrite(&after, 4, 1, o);
+    for (int i = before; i < after; ++i) fwrite(&sfm.nReconstructionCloud[i].pt.x, 8, 3, o);
   }
   // ---- adjustCurrentBundle on the BA block
   const int n_cam = rd<int>(f);

@@ -121,3 +121,30 @@ def two_view_scene(m=500, seed=99, K=None, noise_px=0.3, outlier_frac=0.1):
     bad = rng.random(m) < outlier_frac
     xy2[bad] += rng.uniform(-60, 60, (int(bad.sum()), 2))
     return dict(P1=P1, P2=P2, K=K, dist=np.zeros(5), xy1=xy1, xy2=xy2, X_true=X)
+
+
+def random_tracks_and_matches(n_cloud, n_views, n_matches, seed=0, done_view=0, n_feat=400):
+    """Cloud tracks ({view: feature} per point, 1..4 views each) and a match list (q, t) between
+    done_view and another view; features of done_view repeat on the train side so that the
+    'first match wins' rule of find2D3DMatches (reference src/Sfm.cpp:1061-1084) is exercised."""
+    rng = np.random.default_rng(seed)
+    cloud = []
+    for _ in range(n_cloud):
+        k = int(rng.integers(1, 5))
+        views = rng.choice(n_views, size=k, replace=False)
+        cloud.append({int(v): int(rng.integers(0, n_feat)) for v in views})
+    q = rng.permutation(n_feat)[:n_matches]                  # queryIdx: unique, ascending like getMatching
+    q.sort()
+    t = rng.integers(0, n_feat // 2, n_matches)              # trainIdx: repeats
+    return cloud, [(int(a), int(b)) for a, b in zip(q, t)]
+
+
+def tracks_to_csr(cloud):
+    ptr = np.zeros(len(cloud) + 1, np.int32)
+    views, feats = [], []
+    for i, tr in enumerate(cloud):
+        for v in sorted(tr):
+            views.append(v)
+            feats.append(tr[v])
+        ptr[i + 1] = len(views)
+    return ptr, np.asarray(views, np.int32), np.asarray(feats, np.int32)

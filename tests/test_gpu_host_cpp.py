@@ -72,6 +72,26 @@ def test_cpp_host_classes_end_to_end(tmp_path, orc):
     kept = np.nonzero(keepo)[0]
     assert n2 == len(kept) and np.array_equal(c["q"], rq[kept]) and np.array_equal(c["t"], rt[kept])  # tracks
     assert np.abs(c["X"] - Xo[kept]).max() < 1e-10
+    # pair cache: the batched all-pairs launch serves getMatching with identical results
+    n3 = struct.unpack_from("<i", raw, pos)[0]; pos += 4
+    mc = np.frombuffer(raw, dtype=m.dtype, count=n3, offset=pos); pos += 12 * n3
+    assert n3 == n and np.array_equal(mc, m)
+    # find2D3DMatches(NEW_VIEW=1, done {0}) against the oracle's literal loops
+    done_view, n4 = struct.unpack_from("<ii", raw, pos); pos += 8
+    f23 = np.frombuffer(raw, dtype=np.dtype([("X", "<f8", 3), ("xy", "<f8", 2)]), count=n4, offset=pos); pos += 40 * n4
+    assert done_view == 0
+    trk_ptr = np.arange(0, 2 * n2 + 1, 2, dtype=np.int32)
+    trk_views = np.tile(np.array([0, 1], np.int32), n2)
+    trk_feats = np.stack([c["q"], c["t"]], 1).reshape(-1).astype(np.int32)
+    oc, of = orc.find_2d3d(trk_ptr, trk_views, trk_feats, 0, 1, rq, rt)
+    assert n4 == len(oc) and np.array_equal(f23["X"], c["X"][oc]) and np.array_equal(f23["xy"], xy1[of])
+    # mergeNewPoints
+    before, after = struct.unpack_from("<ii", raw, pos); pos += 8
+    added = np.frombuffer(raw, "<f8", 3 * (after - before), pos).reshape(-1, 3); pos += 24 * (after - before)
+    fresh = np.concatenate([c["X"] + [0, 0, 0.004], c["X"] + [5.0, 0, 0], c["X"] + [5.0, 0, 0]])
+    acc, nacc = orc.merge_new_points(c["X"], fresh)
+    assert before == n2 and after - before == nacc and np.array_equal(added, fresh[acc])
+    assert not acc[:n2].any() and not acc[2 * n2:].any()         # too close / duplicates of appended points
     Kout = np.frombuffer(raw, "<f8", 9, pos).reshape(3, 3); pos += 72
     poses_out = np.frombuffer(raw, "<f8", 12 * len(poses), pos).reshape(-1, 3, 4); pos += 96 * len(poses)
     pts_out = np.frombuffer(raw, "<f8", 3 * len(cloud), pos).reshape(-1, 3)
