@@ -1304,6 +1304,7 @@ __global__ void ba_cam_norm(BaDev d, const unsigned char* __restrict__ cam_used,
 // ================================================================= host side
 struct LmState {
   bool started = false, have_lin = false;
+  bool lin_unread = false;  // cost / gradient of the enqueued linearisation not read back yet
   double radius = 1e4, decrease_factor = 2.0;
   int invalid = 0, iter = 0, nsucc = 0;
   double x_norm = 0, cost = 0, initial_cost = 0, gmax = 0;
@@ -1831,6 +1832,19 @@ static int ba_one_iteration(sfmhip_ba* b, const sfmhip_ba_opts* o, bool timing_o
   SFM_HIP_TRY(hipEventRecord(b->ev[4], st));
   SFM_TRY(ba_read_scalars(b, &sc, true));
   ba_acc_timing(b);
+  if (s.lin_unread) {
+    // the linearisation enqueued after the last accepted step is read together with this step's
+    // scalars (one host synchronisation per iteration); Ceres tests the gradient tolerance right
+    // after accepting a step, so a converged gradient discards the step evaluated above
+    s.lin_unread = false;
+    s.cost = sc.cost;
+    s.gmax = sc.gmax;
+    if (!timing_only && s.gmax <= o->gradient_tolerance) {
+      --s.iter;
+      *stop = SFMHIP_BA_CONVERGENCE;
+      return SFMHIP_OK;
+    }
+  }
   const bool finite = std::isfinite(sc.step_n2) && std::isfinite(sc.mcc) && std::isfinite(sc.cost_c);
   const bool bad = sc.info != 0 || sc.nfail > 0 || !finite;
   if (bad || !(sc.mcc > 0.0)) {  // HandleInvalidStep
@@ -1867,17 +1881,28 @@ static int ba_one_iteration(sfmhip_ba* b, const sfmhip_ba_opts* o, bool timing_o
     s.radius = s.radius / std::fmax(1.0 / 3.0, 1.0 - q * q * q);
     s.radius = std::fmin(o->max_radius, s.radius);
     s.decrease_factor = 2.0;
-    // re-linearise at the new x; with the new radius this is also the next reduced system
+    // re-linearise at the new x; with the new radius this is also the next reduced system.
+    // Enqueued only: its cost / gradient come back with the next iteration's scalars.
     SFM_TRY(ba_linearize_eliminate(b, s.radius, o, true));
-    SFM_TRY(ba_read_scalars(b, &sc, false));
-    s.cost = sc.cost;
-    s.gmax = sc.gmax;
+    s.cost = sc.cost_c;  // provisional (same residuals, other summation order)
     s.have_lin = true;
-    if (!timing_only && s.gmax <= o->gradient_tolerance) *stop = SFMHIP_BA_CONVERGENCE;
+    s.lin_unread = true;
   } else {  // HandleUnsuccessfulStep
     s.radius /= s.decrease_factor;
     s.decrease_factor *= 2.0;
   }
+  return SFMHIP_OK;
+}
+
+// cost / gradient of a linearisation that is still only enqueued
+static int ba_flush_lin(sfmhip_ba* b) {
+  LmState& s = b->lm;
+  if (!s.lin_unread) return SFMHIP_OK;
+  IterScalars sc{};
+  SFM_TRY(ba_read_scalars(b, &sc, false));
+  s.cost = sc.cost;
+  s.gmax = sc.gmax;
+  s.lin_unread = false;
   return SFMHIP_OK;
 }
 
@@ -1927,6 +1952,8 @@ extern "C" int sfmhip_ba_run(sfmhip_ba* b, const sfmhip_ba_opts* opts, sfmhip_ba
       }
     }
   }
+  SFM_TRY(ba_flush_lin(b));
+  if (term == SFMHIP_BA_NO_CONVERGENCE && s.gmax <= opts->gradient_tolerance) term = SFMHIP_BA_CONVERGENCE;
   s.started = false;  // a finished solve is not resumable
   ba_fill_summary(b, term, elapsed(), &sm);
   if (summary) *summary = sm;
@@ -1946,6 +1973,7 @@ extern "C" int sfmhip_ba_iterate(sfmhip_ba* b, int iters, sfmhip_ba_summary* sum
     int stop = -1;
     SFM_TRY(ba_one_iteration(b, &o, true, &stop));
   }
+  SFM_TRY(ba_flush_lin(b));
   ba_fill_summary(b, SFMHIP_BA_NO_CONVERGENCE, std::chrono::duration<double>(clk::now() - t0).count(), &sm);
   if (summary) *summary = sm;
   return SFMHIP_OK;
