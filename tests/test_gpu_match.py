@@ -141,3 +141,33 @@ def test_train_permutation_property(ctx):
     a = matcher.get_matching(imgs[0], imgs[1], ctx=ctx)
     b = matcher.get_matching(imgs[0], imgs[1][perm], ctx=ctx)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], perm[b[1]]) and np.array_equal(a[2], b[2])
+
+
+def test_cfg5_orb_shard_properties(ctx, orc):
+    """BASELINE cfg5 (500 x 5000 x ORB-256 bit, Hamming): one rank's share of the 124 750 pairs under
+    the 8-way pair sharding -- determinism, ordering, planted-match recovery, and three pairs
+    bit-checked against the oracle."""
+    import time
+    from sfm_danpipeline_amd import sharding
+    imgs = synth.orb_image_set()
+    pairs = synth.all_pairs(len(imgs))
+    shards = sharding.shard_pairs(pairs, [len(a) for a in imgs], 8)
+    mine = pairs[shards[0]]
+    assert 124750 // 8 - 5 <= len(mine) <= 124750 // 8 + 5
+    t0 = time.time()
+    s, pl = _plan(ctx, imgs, mine, _lib.HAMMING)
+    cnt, oq, ot, od = pl.fetch()
+    dt = time.time() - t0
+    s.prepare_async()
+    pl.run_async(0.8)
+    cnt2, oq2, ot2, od2 = pl.fetch()
+    assert np.array_equal(cnt, cnt2) and np.array_equal(oq, oq2) and np.array_equal(ot, ot2) and np.array_equal(od, od2)
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    for p in range(0, len(mine), 97):
+        assert np.all(np.diff(oq[off[p]:off[p + 1]]) > 0)  # ascending queryIdx inside a pair
+    # two images share ~5000*5000/100000 = 250 bank rows; their copies differ in ~2*0.04*256 = 20 bits,
+    # impostors in ~128: the ratio test keeps the shared rows
+    assert 150 < cnt.mean() < 350 and od.max() < 110 and np.all(od == np.round(od))
+    for p in (0, len(mine) // 2, len(mine) - 1):
+        _assert_pair(orc, pl, p, imgs[mine[p, 0]], imgs[mine[p, 1]], _lib.HAMMING)
+    print(f"[cfg5 shard] {len(mine)} pairs incl. upload + first run: {dt:.2f} s")
