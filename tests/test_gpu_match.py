@@ -171,3 +171,20 @@ def test_cfg5_orb_shard_properties(ctx, orc):
     for p in (0, len(mine) // 2, len(mine) - 1):
         _assert_pair(orc, pl, p, imgs[mine[p, 0]], imgs[mine[p, 1]], _lib.HAMMING)
     print(f"[cfg5 shard] {len(mine)} pairs incl. upload + first run: {dt:.2f} s")
+
+
+@pytest.mark.parametrize("nq,nt,levels,seed", [(300, 700, 1, 1), (65, 513, 2, 2), (1000, 1031, 3, 3)])
+def test_heavy_ties_across_tiles_and_chunks(ctx, orc, nq, nt, levels, seed):
+    """Rows from very few distinct values: thousands of exact distance ties per query, spread over
+    32-row tiles, the two half-waves and the 256-row key chunks.  The k-NN lists must follow
+    cv::batchDistance's rule (lower train index first) bit for bit."""
+    rng = np.random.default_rng(seed)
+    q = (rng.integers(0, levels + 1, (nq, 128)) * 60).astype(np.float32)
+    t = (rng.integers(0, levels + 1, (nt, 128)) * 60).astype(np.float32)
+    t[nt // 2:] = t[: nt - nt // 2]                       # every row has a twin 300+ rows later
+    s, pl = _plan(ctx, [q, t], [[0, 1]])
+    _assert_pair(orc, pl, 0, q, t, _lib.L2)
+    orb = rng.integers(0, 2, (nt, 32)).astype(np.uint8) * 255   # bytes 0x00 / 0xFF only
+    qb = rng.integers(0, 2, (nq, 32)).astype(np.uint8) * 255
+    s2, pl2 = _plan(ctx, [qb, orb], [[0, 1]], _lib.HAMMING)
+    _assert_pair(orc, pl2, 0, qb, orb, _lib.HAMMING)
