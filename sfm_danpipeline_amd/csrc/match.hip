@@ -97,18 +97,50 @@ __global__ void prepare_kernel(const ImgDev* __restrict__ imgs, const int* __res
       v[e] = (valid && k < nbits) ? (((bits >> e) & 1u) ? 1 : -1) : 0;
     }
   } else {
+    // the lane's 16 elements: four 16-byte loads (f32) / one (u8) when the chunk lies inside the
+    // row and is 16-byte aligned -- the case of every real descriptor width; element loads otherwise
+    float fv[16];
+    unsigned char bv[16];
+    const bool full = valid && c * 16 + 16 <= dim;
+    if (KIND == KIND_F32_L2) {
+      const float* src = (const float*)I.raw + (size_t)row * dim + c * 16;
+      if (full && (((size_t)src) & 15) == 0) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const SFM_GLOBAL v4f* s4 = (const SFM_GLOBAL v4f*)src;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const v4f x = s4[g4];
+          fv[4 * g4] = x[0];
+          fv[4 * g4 + 1] = x[1];
+          fv[4 * g4 + 2] = x[2];
+          fv[4 * g4 + 3] = x[3];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) fv[e] = (valid && c * 16 + e < dim) ? src[e] : 128.f;
+      }
+    } else {
+      const unsigned char* src = (const unsigned char*)I.raw + (size_t)row * dim + c * 16;
+      if (full && (((size_t)src) & 15) == 0) {
+        const v4i x = *(g_v4i_p)src;
+        memcpy(bv, &x, 16);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bv[e] = (valid && c * 16 + e < dim) ? src[e] : 128;
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int k = c * 16 + e;
       int x = 128;  // centred value 0 for padding
       if (valid && k < dim) {
         if (KIND == KIND_F32_L2) {
-          const float f = ((const float*)I.raw)[(size_t)row * dim + k];
+          const float f = fv[e];
           ok = ok && (f == rintf(f)) && (f >= 0.f) && (f <= 255.f);
           x = (int)f;
           x = x < 0 ? 0 : (x > 255 ? 255 : x);
         } else {
-          x = ((const unsigned char*)I.raw)[(size_t)row * dim + k];
+          x = bv[e];
         }
       }
       const int cv = x - 128;
