@@ -871,6 +871,7 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
   }
 
   // ---------------- block column k: update, factor the diagonal tile, solve the own tile
+  __builtin_amdgcn_s_setprio(3);  // these waves are the launch's critical path; trailing tiles are filler
   const bool owner = ti_rel == 0;
   const int i = lane & 31;  // row of the tile handled by this lane in the row-per-lane phases
   if (wave == 0 || !owner) {
