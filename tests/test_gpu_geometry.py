@@ -197,3 +197,29 @@ def test_cfg4_iterations_decrease_cost(ctx):
     s2 = prob.iterate(3)
     assert s2.iterations == 6 and s2.final_cost <= s.final_cost < s.initial_cost
     assert np.isfinite(s2.final_cost)
+
+
+def test_degenerate_problems_do_not_crash(ctx, orc):
+    """No observations at all, a point nobody observes, cameras nobody uses, one observation only:
+    the solver must return the oracle's verdict (or at least terminate cleanly) on all of them."""
+    pb = synth.ba_problem(5, 40, 3, seed=21)
+    cams, pts, f = pb["cams0"], pb["pts0"], pb["focal0"]
+    e_i, e_f = np.zeros(0, np.int32), np.zeros((0, 2))
+    c, p, ff, s = bundle.ba_solve(cams, pts, f, e_i, e_i, e_f, ctx=ctx)                     # nothing to fit
+    assert np.array_equal(c, cams) and np.array_equal(p, pts) and ff == f and s.initial_cost == 0.0
+    c, p, ff, s = bundle.ba_solve(cams, np.zeros((0, 3)), f, e_i, e_i, e_f, ctx=ctx)        # no points either
+    assert s.initial_cost == 0.0
+    # drop every observation of camera 4 and of point 7: unused blocks keep their values
+    keep = (pb["obs_cam"] != 4) & (pb["obs_pt"] != 7)
+    args = (cams, pts, f, pb["obs_cam"][keep], pb["obs_pt"][keep], pb["obs_xy"][keep])
+    c, p, ff, s = bundle.ba_solve(*args, opts=bundle.default_opts(max_time_s=0.0), ctx=ctx)
+    co, po, fo, so = orc.ba_solve(*args, opts=orc.default_opts(max_time_s=0.0))
+    assert (s.termination, s.iterations) == (so.termination, so.iterations)
+    assert np.array_equal(c[4], cams[4]) and np.array_equal(p[7], pts[7])
+    assert np.allclose(c, co, rtol=1e-6, atol=1e-9) and np.allclose(p, po, rtol=1e-6, atol=1e-9)
+    # a single observation: rank-deficient everywhere but the LM diagonal keeps it solvable
+    one = (cams, pts, f, pb["obs_cam"][:1], pb["obs_pt"][:1], pb["obs_xy"][:1])
+    c, p, ff, s = bundle.ba_solve(*one, opts=bundle.default_opts(max_time_s=0.0, max_iterations=20), ctx=ctx)
+    co, po, fo, so = orc.ba_solve(*one, opts=orc.default_opts(max_time_s=0.0, max_iterations=20))
+    assert s.termination == so.termination and np.isfinite(s.final_cost)
+    assert abs(s.final_cost - so.final_cost) <= 1e-6 * max(so.final_cost, 1e-12) + 1e-12
