@@ -1058,83 +1058,135 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
 
 // L^T z = y.  U = L^T is upper triangular and row-major in this storage (U[i][j] = A[i*ld + j]),
 // so row i of U is contiguous.  Block rows are taken in groups of GB (256 rows) from the bottom:
-//   chol_backsolve_group  one workgroup of 8 waves walks the group's 32-row blocks upwards,
-//                         left-looking inside the group: wave w owns rows 4w..4w+3 of the block and
-//                         forms y_i - sum_j U[i][j] z[j] over the group's later columns (the rows
-//                         are fetched one block ahead: they do not depend on z); wave 0 then solves
-//                         the 32x32 diagonal block with v_readlane broadcasts;
+//   chol_backsolve_group  one workgroup of 8 waves per group: a chain wave (32x32 products with
+//                         the diagonal tiles' inverses) and seven owner waves that fold finished
+//                         blocks into the ones further up (see the kernel);
 //   chol_backsolve_gemv   folds the group's solution into y of every row above the group, one
 //                         wave per row (coalesced 2 KB row segments), all CUs.
 // A single workgroup pulling the whole triangle (5.8 MB at cfg4) is bound by one CU's load
 // bandwidth; the grouping leaves it 1/GB of the triangle.
 constexpr int GB = 8;
 
+// Bounded LDS spin (one opaque asm block, see chol_step): until *flag >= need.
+__device__ __forceinline__ void lds_wait_ge(const int* flag, int need) {
+  const unsigned addr = (unsigned)(size_t)(const __attribute__((address_space(3))) int*)flag;
+  int seen_, budget_ = 1 << 20;
+  asm volatile(
+      "1:\n\t"
+      "ds_read_b32 %0, %2\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_cmp_lt_i32 vcc, %0, %3\n\t"
+      "s_cbranch_vccz 2f\n\t"
+      "s_sub_u32 %1, %1, 1\n\t"
+      "s_cmp_eq_u32 %1, 0\n\t"
+      "s_cbranch_scc1 2f\n\t"
+      "s_sleep 1\n\t"
+      "s_branch 1b\n\t"
+      "2:\n\t"
+      : "=&v"(seen_), "+s"(budget_)
+      : "v"(addr), "v"(need)
+      : "vcc", "scc", "memory");
+}
+
+// One workgroup of 8 waves per group of GB block rows.  All waves first stage what the chain
+// will need -- the inverses of the group's diagonal tiles and the tiles right above the diagonal,
+// 16 KB per block -- into LDS.  Wave 0 then is the dependency chain: for each block from the
+// bottom, z_b = L_bb^-T y_b (a 32x32 product) and the fold of z_b into the block right above.
+// Waves 1..7 own the other targets: the owner of block b folds the solutions of the blocks two
+// or more below into y_b as the chain publishes them, and hands y_b to the chain just before
+// it is needed.  Lane = row of the target block; hand-offs go through LDS flags.
 __global__ __launch_bounds__(512) void chol_backsolve_group(const double* __restrict__ A, const double* __restrict__ y,
                                                              const double* __restrict__ linv, double* __restrict__ z,
                                                              int ld, int kb_lo, int kb_hi) {
-  __shared__ __attribute__((aligned(16))) double sz[GB * CB];  // z of the group's columns
-  __shared__ __attribute__((aligned(16))) double srhs[CB];
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // [GB][CB*CB] inverses | [GB][CB*CB] adjacent tiles
+  __shared__ __attribute__((aligned(16))) double s_z[GB][CB];    // published by the chain
+  __shared__ __attribute__((aligned(16))) double s_y[GB][CB];    // published by the owners
+  __shared__ __attribute__((aligned(16))) double s_tmp[CB];
+  __shared__ int s_zready[GB], s_ydone[GB];
+  double* s_inv = s_dyn;                  // [b][j*CB + i] = (L_bb^-T)[i][j]
+  double* s_adj = s_dyn + GB * CB * CB;   // [b][r*CB + i] = L(row r of block b, column i of block b-1)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = lane & 31;
-  const int c_lo = kb_lo * CB, c_hi = kb_hi * CB;
-  double2 pre[4][2];  // this wave's four rows of the current block, columns beyond the block
-  double u[CB];  // wave 0: its row of L_kk^-T
-  auto preload = [&](int kb) {
-    const int k0 = kb * CB, jbeg = k0 + CB;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const double* ui = A + (size_t)(k0 + 4 * wave + rr) * ld;
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int j = jbeg + 2 * lane + 128 * it;
-        pre[rr][it] = j < c_hi ? *(const double2*)(ui + j) : make_double2(0.0, 0.0);
-      }
+  const int nb = kb_hi - kb_lo;
+  if (tid < GB) {
+    s_zready[tid] = 0;
+    s_ydone[tid] = 0;
+  }
+  for (int e = tid; e < nb * CB * CB / 2; e += 512) {  // 16-byte pieces
+    const int b = e / (CB * CB / 2), w = e % (CB * CB / 2);
+    const int k0 = (kb_lo + b) * CB;
+    *(double2*)(s_inv + b * CB * CB + 2 * w) = *(const double2*)(linv + (size_t)k0 * CB + 2 * w);
+    if (b > 0) {
+      const int c = w % CB, r = 2 * (w / CB);  // column c of block b-1, rows r, r+1 of block b (conflict-free LDS writes)
+      const double2 v = *(const double2*)(A + (size_t)(k0 - CB + c) * ld + k0 + r);
+      s_adj[b * CB * CB + r * CB + c] = v.x;
+      s_adj[b * CB * CB + (r + 1) * CB + c] = v.y;
     }
-    if (wave == 0) {
-#pragma unroll
-      for (int j = 0; j < CB; ++j) u[j] = linv[(size_t)(k0 + j) * CB + i];
-    }
-  };
-  preload(kb_hi - 1);
-  for (int kb = kb_hi - 1; kb >= kb_lo; --kb) {
-    const int k0 = kb * CB, jbeg = k0 + CB;
-    double part[4];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      double acc = 0.0;
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int j = jbeg + 2 * lane + 128 * it;
-        if (j < c_hi) {
-          const double2 zz = *(const double2*)(sz + (j - c_lo));
-          acc += pre[rr][it].x * zz.x + pre[rr][it].y * zz.y;
-        }
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-      part[rr] = acc;
-    }
-    if (lane < 4) srhs[4 * wave + lane] = y[k0 + 4 * wave + lane] - (lane == 0 ? part[0] : lane == 1 ? part[1] : lane == 2 ? part[2] : part[3]);
-    double uc[CB];
-#pragma unroll
-    for (int j = 0; j < CB; ++j) uc[j] = u[j];
-    if (kb > kb_lo) preload(kb - 1);  // in flight during the diagonal product below
-    __syncthreads();
-    if (wave == 0) {
-      // ---- diagonal block: z = L_kk^-T rhs, lane i = row i, rhs broadcast from LDS
+  }
+  __syncthreads();
+  if (wave == 0) {
+    // ---- the chain
+    double adj = 0.0;
+    for (int b = nb - 1; b >= 0; --b) {
+      const double* inv = s_inv + b * CB * CB + i;
+      lds_wait_ge(&s_ydone[b], 1);
+      const double yv = s_y[b][i] - adj;
+      if (lane < CB) s_tmp[i] = yv;
       double z0 = 0.0, z1 = 0.0;
 #pragma unroll
       for (int j = 0; j < CB; j += 2) {
-        z0 += uc[j] * srhs[j];
-        z1 += uc[j + 1] * srhs[j + 1];
+        const double2 t = *(const double2*)(s_tmp + j);
+        z0 += inv[j * CB] * t.x;
+        z1 += inv[(j + 1) * CB] * t.y;
       }
       const double zi = z0 + z1;
       if (lane < CB) {
-        sz[k0 - c_lo + i] = zi;
-        z[k0 + i] = zi;
+        s_z[b][i] = zi;
+        z[(size_t)(kb_lo + b) * CB + i] = zi;
+      }
+      asm volatile("" ::: "memory");
+      *(volatile int*)&s_zready[b] = 1;
+      if (b > 0) {
+        const double* ad = s_adj + b * CB * CB + i;
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < CB; r += 2) {
+          const double2 t = *(const double2*)(&s_z[b][r]);
+          a0 += ad[r * CB] * t.x;
+          a1 += ad[(r + 1) * CB] * t.y;
+        }
+        adj = a0 + a1;
       }
     }
-    __syncthreads();
+    return;
+  }
+  // ---- owners: wave w owns the targets b with 1 + b % 7 == w
+  for (int b = nb - 1; b >= 0; --b) {
+    if (1 + b % 7 != wave) continue;
+    const int c0 = (kb_lo + b) * CB;
+    double yacc = y[c0 + i];
+    for (int sblk = nb - 1; sblk >= b + 2; --sblk) {
+      const int r0 = (kb_lo + sblk) * CB;
+      double col[CB];  // column i of tile (sblk, b): fetched before waiting for z
+#pragma unroll
+      for (int r = 0; r < CB; r += 2) {
+        const double2 v = *(const double2*)(A + (size_t)(c0 + i) * ld + r0 + r);
+        col[r] = v.x;
+        col[r + 1] = v.y;
+      }
+      lds_wait_ge(&s_zready[sblk], 1);
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int r = 0; r < CB; r += 2) {
+        const double2 t = *(const double2*)(&s_z[sblk][r]);
+        a0 += col[r] * t.x;
+        a1 += col[r + 1] * t.y;
+      }
+      yacc -= a0 + a1;
+    }
+    if (lane < CB) s_y[b][i] = yacc;
+    asm volatile("" ::: "memory");
+    *(volatile int*)&s_ydone[b] = 1;
   }
 }
 
@@ -1723,9 +1775,15 @@ static int ba_reduced_solve(sfmhip_ba* b) {
     hipLaunchKernelGGL(chol_step, dim3(nblk), dim3(128), 0, st, A, y, d.dinv, d.linv, d.ld, nt, k, d.info);
   }
   int nbs = 0;
+  constexpr int kBsLds = 2 * GB * CB * CB * (int)sizeof(double);  // 128 KiB of dynamic LDS
+  static bool bs_attr = false;
+  if (!bs_attr) {
+    SFM_HIP_TRY(hipFuncSetAttribute((const void*)chol_backsolve_group, hipFuncAttributeMaxDynamicSharedMemorySize, kBsLds));
+    bs_attr = true;
+  }
   for (int hi = nt; hi > 0; hi -= GB) {
     const int lo = std::max(0, hi - GB);
-    hipLaunchKernelGGL(chol_backsolve_group, dim3(1), dim3(512), 0, st, A, y, d.linv, d.z, d.ld, lo, hi);
+    hipLaunchKernelGGL(chol_backsolve_group, dim3(1), dim3(512), kBsLds, st, A, y, d.linv, d.z, d.ld, lo, hi);
     ++nbs;
     if (lo > 0) {
       hipLaunchKernelGGL(chol_backsolve_gemv, dim3((lo * CB + 3) / 4), dim3(256), 0, st, A, y, d.z, d.ld, lo * CB, hi * CB);
