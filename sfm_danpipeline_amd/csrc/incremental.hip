@@ -109,24 +109,28 @@ __device__ __forceinline__ double dist2(const double* a, double qx, double qy, d
   return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));  // cv::norm's order
 }
 
-// far[i] = 1 iff no point of the existing cloud is closer than r to new point i
-__global__ __launch_bounds__(BLK) void far_from_cloud_kernel(const double* __restrict__ cloud, int n_cloud,
-                                                             const double* __restrict__ pts, int n_new, double thr,
-                                                             unsigned char* __restrict__ far) {
+// near[i] = 1 iff some point of the existing cloud is closer than r to new point i.  Grid =
+// (blocks of 256 new points) x (slices of CLOUD_SLICE cloud points), so that a few hundred new
+// points against a large cloud still fill the chip; slices only ever store 1 (idempotent).
+constexpr int CLOUD_SLICE = 1024;
+__global__ __launch_bounds__(BLK) void near_cloud_kernel(const double* __restrict__ cloud, int n_cloud,
+                                                         const double* __restrict__ pts, int n_new, double thr,
+                                                         unsigned char* __restrict__ near) {
   __shared__ double s_c[BLK * 3];
   const int i = blockIdx.x * BLK + threadIdx.x;
   const int ii = i < n_new ? i : 0;
   const double qx = pts[3 * (size_t)ii], qy = pts[3 * (size_t)ii + 1], qz = pts[3 * (size_t)ii + 2];
+  const int lo = blockIdx.y * CLOUD_SLICE, hi = min(n_cloud, lo + CLOUD_SLICE);
   bool found = false;
-  for (int base = 0; base < n_cloud; base += BLK) {
-    const int m = min(BLK, n_cloud - base);
+  for (int base = lo; base < hi; base += BLK) {
+    const int m = min(BLK, hi - base);
     __syncthreads();
     for (int e = threadIdx.x; e < 3 * m; e += BLK) s_c[e] = cloud[3 * (size_t)base + e];
     __syncthreads();
     if (!found)
       for (int j = 0; j < m; ++j) found = found || dist2(s_c + 3 * j, qx, qy, qz) <= thr;
   }
-  if (i < n_new) far[i] = found ? 0 : 1;
+  if (i < n_new && found) near[i] = 1;
 }
 
 // One relaxation sweep of the in-order dependency among the new points: state 0 = undecided,
@@ -153,9 +157,9 @@ __global__ __launch_bounds__(BLK) void resolve_kernel(const double* __restrict__
   else state[i] = 1;
 }
 
-__global__ void init_state_kernel(const unsigned char* __restrict__ far, unsigned char* __restrict__ state, int n) {
+__global__ void init_state_kernel(const unsigned char* __restrict__ near, unsigned char* __restrict__ state, int n) {
   const int i = blockIdx.x * BLK + threadIdx.x;
-  if (i < n) state[i] = far[i] ? 0 : 2;
+  if (i < n) state[i] = near[i] ? 2 : 0;
 }
 
 struct DevBuf {  // frees on scope exit
@@ -261,7 +265,10 @@ extern "C" int sfmhip_merge_new_points(sfmhip_ctx* ctx, const double* cloud_xyz,
   if (n_cloud) SFM_HIP_TRY(hipMemcpyAsync(d_cloud, cloud_xyz, sizeof(double) * 3 * (size_t)n_cloud, hipMemcpyHostToDevice, st));
   SFM_HIP_TRY(hipMemcpyAsync(d_new, new_xyz, sizeof(double) * 3 * (size_t)n_new, hipMemcpyHostToDevice, st));
   const int nblk = (n_new + BLK - 1) / BLK;
-  hipLaunchKernelGGL(far_from_cloud_kernel, dim3(nblk), dim3(BLK), 0, st, d_cloud, n_cloud, d_new, n_new, thr, d_far);
+  SFM_HIP_TRY(hipMemsetAsync(d_far, 0, (size_t)n_new, st));
+  if (n_cloud)
+    hipLaunchKernelGGL(near_cloud_kernel, dim3(nblk, (n_cloud + CLOUD_SLICE - 1) / CLOUD_SLICE), dim3(BLK), 0, st, d_cloud,
+                       n_cloud, d_new, n_new, thr, d_far);
   hipLaunchKernelGGL(init_state_kernel, dim3(nblk), dim3(BLK), 0, st, d_far, d_state, n_new);
   SFM_HIP_TRY(hipGetLastError());
   // sweeps until every point is decided: each sweep decides at least the first undecided point
