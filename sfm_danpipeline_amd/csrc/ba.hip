@@ -794,37 +794,18 @@ constexpr int CBP = 34;  // LDS row pitch in doubles: 16-byte aligned rows, conf
 // registers are tile columns c = (lane>>4) + 4g.
 #define CHOL_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0)
 
-__global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double* __restrict__ y,
-                                                 double* __restrict__ dinv, double* __restrict__ linv, int ld,
-                                                 int nt, int k, int* __restrict__ info) {
-  __shared__ __attribute__((aligned(16))) double sD[CB * CBP];   // updated diagonal tile [row][col]
-  __shared__ __attribute__((aligned(16))) double sT[CB * CBP];   // updated own tile      [row][col]
-  __shared__ __attribute__((aligned(16))) double sLr[CB * CBP];  // L_kk [row][col]
-  __shared__ double sdi[CB];                                     // 1 / diag(L_kk)
-  __shared__ int s_prog;                                         // columns of L_kk finished so far
-  const int m = nt - k;  // remaining tile rows (the rhs row comes on top)
-  // block -> tile: the m+1 tiles of block column k first (they carry the factorisation)
-  int ti_rel, tj_rel;
-  if ((int)blockIdx.x <= m) {
-    ti_rel = blockIdx.x;
-    tj_rel = 0;
-  } else {
-    int t = blockIdx.x - (m + 1);
-    ti_rel = 1;
-    while (true) {
-      const int w = ti_rel < m ? ti_rel : m - 1;  // tj_rel in 1..min(ti_rel, m-1)
-      if (t < w) break;
-      t -= w;
-      ++ti_rel;
-    }
-    tj_rel = 1 + t;
-  }
-  const bool is_rhs = ti_rel == m;
+template <bool RHS>
+__device__ __forceinline__ void chol_body(double* __restrict__ A, double* __restrict__ y, double* __restrict__ dinv,
+                                          double* __restrict__ linv, int ld, int nt, int k, int* __restrict__ info,
+                                          int ti_rel, int tj_rel, double* sD, double* sT, double* sLr, double* sdi,
+                                          int* s_prog_p) {
+  const int m = nt - k;
+  constexpr bool is_rhs = RHS;  // the rhs tile row is its own instantiation: plain loads for everybody else
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j16 = lane & 15, q = lane >> 4;
   const int r0 = (k + ti_rel) * CB, c0 = (k + tj_rel) * CB, p0 = (k - 1) * CB;
   const bool rlane = j16 == 0;  // the rhs tile row has one real row: tile row 0
-  if (threadIdx.x == 0) s_prog = 0;
+  if (threadIdx.x == 0) (*s_prog_p) = 0;
   __syncthreads();
   CHOL_STAMP(wave == 0 ? 0 : 8);
 
@@ -871,7 +852,10 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
   }
 
   // ---------------- block column k: update, factor the diagonal tile, solve the own tile
-  __builtin_amdgcn_s_setprio(3);  // these waves are the launch's critical path; trailing tiles are filler
+  // the factorising wave is the launch's critical path: it outranks the solving wave that trails
+  // it (and polls its progress through LDS), and both outrank the trailing-tile filler
+  if (wave == 0) __builtin_amdgcn_s_setprio(3);
+  else __builtin_amdgcn_s_setprio(1);
   const bool owner = ti_rel == 0;
   const int i = lane & 31;  // row of the tile handled by this lane in the row-per-lane phases
   if (wave == 0 || !owner) {
@@ -970,7 +954,7 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
       // columns are in LDS before the flag); the factorising wave never waits for anybody
       if ((j & 3) == 3) {
         asm volatile("" ::: "memory");
-        *(volatile int*)&s_prog = j + 1;
+        *(volatile int*)&(*s_prog_p) = j + 1;
       }
     }
     CHOL_STAMP(3);
@@ -988,7 +972,7 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
     // ---- own tile (or the rhs row): X = T L_kk^-T, lane i = row i, one 8-column block behind
     // (the diagonal tile's owner solves the identity instead: X = L_kk^-T, kept for the
     // backward substitution, whose diagonal solves then are plain 32x32 products)
-    const unsigned prog_addr = (unsigned)(size_t)(__attribute__((address_space(3))) int*)&s_prog;
+    const unsigned prog_addr = (unsigned)(size_t)(__attribute__((address_space(3))) int*)&(*s_prog_p);
     double t[CB];
     if (!owner) {
 #pragma unroll
@@ -1013,7 +997,7 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
             "s_waitcnt lgkmcnt(0)\n\t"
             "v_cmp_lt_i32 vcc, %0, %2\n\t"
             "s_cbranch_vccz 2f\n\t"
-            "s_sleep 1\n\t"
+            "s_sleep 4\n\t"
             "s_branch 1b\n\t"
             "2:\n\t"
             : "=&v"(seen_)
@@ -1053,6 +1037,35 @@ __global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double*
     }
     CHOL_STAMP(12);
   }
+}
+
+__global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double* __restrict__ y,
+                                                 double* __restrict__ dinv, double* __restrict__ linv, int ld,
+                                                 int nt, int k, int* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) double sD[CB * CBP];   // updated diagonal tile [row][col]
+  __shared__ __attribute__((aligned(16))) double sT[CB * CBP];   // updated own tile      [row][col]
+  __shared__ __attribute__((aligned(16))) double sLr[CB * CBP];  // L_kk [row][col]
+  __shared__ double sdi[CB];                                     // 1 / diag(L_kk)
+  __shared__ int s_prog;                                         // columns of L_kk finished so far
+  const int m = nt - k;  // remaining tile rows (the rhs row comes on top)
+  // block -> tile: the m+1 tiles of block column k first (they carry the factorisation)
+  int ti_rel, tj_rel;
+  if ((int)blockIdx.x <= m) {
+    ti_rel = blockIdx.x;
+    tj_rel = 0;
+  } else {
+    int t = blockIdx.x - (m + 1);
+    ti_rel = 1;
+    while (true) {
+      const int w = ti_rel < m ? ti_rel : m - 1;  // tj_rel in 1..min(ti_rel, m-1)
+      if (t < w) break;
+      t -= w;
+      ++ti_rel;
+    }
+    tj_rel = 1 + t;
+  }
+  if (ti_rel == m) chol_body<true>(A, y, dinv, linv, ld, nt, k, info, ti_rel, tj_rel, sD, sT, sLr, sdi, &s_prog);
+  else chol_body<false>(A, y, dinv, linv, ld, nt, k, info, ti_rel, tj_rel, sD, sT, sLr, sdi, &s_prog);
 }
 #undef CHOL_MFMA
 
