@@ -36,6 +36,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <thread>
 #include <vector>
 #include <float.h>
 
@@ -1418,6 +1419,23 @@ struct sfmhip_ba {
   int launches = 0;
 };
 
+// fn(lo, hi) over [0, n) on up to 8 host threads (problem set-up only)
+template <typename F>
+static void host_parallel_for(int n, F fn) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int nth = (int)std::max(1u, std::min(8u, hw ? hw : 1u));
+  if (n < 20000 || nth == 1) {
+    fn(0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nth; ++t) {
+    const int lo = (int)((long long)n * t / nth), hi = (int)((long long)n * (t + 1) / nth);
+    th.emplace_back([=, &fn]() { fn(lo, hi); });
+  }
+  for (auto& x : th) x.join();
+}
+
 template <typename T>
 static int ba_alloc(sfmhip_ba* b, T** p, size_t n) {
   SFM_TRY(sfm_dev_alloc(p, n));
@@ -1456,6 +1474,14 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   for (int o = 0; o < n_obs; ++o)
     if (obs_cam[o] < 0 || obs_cam[o] >= n_cam || obs_pt[o] < 0 || obs_pt[o] >= n_pt) return SFMHIP_ERR_ARG;
   SFM_HIP_TRY(hipSetDevice(ctx->device));
+  const bool prof_ = getenv("SFMHIP_PROFILE_CREATE") != nullptr;
+  auto tp_ = std::chrono::steady_clock::now();
+  auto lap_ = [&](const char* what) {
+    if (!prof_) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[sfmhip_ba_create] %-22s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tp_).count());
+    tp_ = now;
+  };
   sfmhip_ba* b = new sfmhip_ba();
   b->ctx = ctx;
   b->nc = n_cam;
@@ -1471,47 +1497,98 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   for (int p = 0; p < n_pt; ++p) cnt[p + 1] += cnt[p];
   std::vector<int> slot(n_obs), fill(n_pt, 0);
   for (int o = 0; o < n_obs; ++o) slot[cnt[obs_pt[o]] + fill[obs_pt[o]]++] = o;
-  for (int p = 0; p < n_pt; ++p)
-    std::stable_sort(slot.begin() + cnt[p], slot.begin() + cnt[p + 1], [&](int x, int y) { return obs_cam[x] < obs_cam[y]; });
-  // ---- signature sort of the points that have observations
-  std::vector<int> order;
-  for (int p = 0; p < n_pt; ++p) {
-    const int n = cnt[p + 1] - cnt[p];
-    if (n > FB_MAXN) {
-      delete b;
-      return SFMHIP_ERR_UNSUPPORTED;  // more than FB_MAXN observations of one point
+  for (int p = 0; p < n_pt; ++p) {  // stable insertion sort: a point has a handful of observations
+    for (int i = cnt[p] + 1; i < cnt[p + 1]; ++i) {
+      const int v = slot[i], cv = obs_cam[v];
+      int j = i - 1;
+      for (; j >= cnt[p] && obs_cam[slot[j]] > cv; --j) slot[j + 1] = slot[j];
+      slot[j + 1] = v;
     }
-    if (n > 0) order.push_back(p);
   }
-  auto sig_less = [&](int x, int y) {
-    const int nx = cnt[x + 1] - cnt[x], ny = cnt[y + 1] - cnt[y];
-    if (nx != ny) return nx < ny;
-    for (int k = 0; k < nx; ++k) {
-      const int cx = obs_cam[slot[cnt[x] + k]], cy = obs_cam[slot[cnt[y] + k]];
-      if (cx != cy) return cx < cy;
+  // the point's ascending camera list, flat, and a hash of it: the signature sort below compares
+  // (length, hash) first and walks the lists only on equal hashes
+  std::vector<int> scam(n_obs);
+  std::vector<uint64_t> sig_hash(n_pt, 0);
+  for (int p = 0; p < n_pt; ++p) {
+    uint64_t h = 1469598103934665603ull;
+    for (int k = cnt[p]; k < cnt[p + 1]; ++k) {
+      scam[k] = obs_cam[slot[k]];
+      h = (h ^ (uint64_t)(uint32_t)scam[k]) * 1099511628211ull;
     }
-    return false;
+    sig_hash[p] = h;
+  }
+  lap_("group by point");
+  // ---- group the points that have observations by signature (their ascending camera list): a
+  //      hash table assigns run ids in order of first appearance, a counting sort makes the runs
+  //      contiguous (stable: ascending point index inside a run)
+  auto sig_equal = [&](int x, int y) {  // x, y: input point indices
+    const int nx = cnt[x + 1] - cnt[x];
+    if (nx != cnt[y + 1] - cnt[y] || sig_hash[x] != sig_hash[y]) return false;
+    for (int k = 0; k < nx; ++k)
+      if (scam[cnt[x] + k] != scam[cnt[y] + k]) return false;
+    return true;
   };
-  std::stable_sort(order.begin(), order.end(), sig_less);
+  std::vector<int> run_of(n_pt, -1), run_rep, run_cnt;
+  {
+    size_t cap = 64;
+    while (cap < 2 * (size_t)n_pt + 16) cap <<= 1;
+    std::vector<int> table(cap, -1);  // open addressing: run id, keyed by the signature hash
+    for (int p = 0; p < n_pt; ++p) {
+      const int n = cnt[p + 1] - cnt[p];
+      if (n > FB_MAXN) {
+        delete b;
+        return SFMHIP_ERR_UNSUPPORTED;  // more than FB_MAXN observations of one point
+      }
+      if (n == 0) continue;
+      size_t slot_i = (size_t)(sig_hash[p] ^ (sig_hash[p] >> 29)) & (cap - 1);
+      for (;; slot_i = (slot_i + 1) & (cap - 1)) {
+        const int r = table[slot_i];
+        if (r < 0) {
+          table[slot_i] = (int)run_rep.size();
+          run_of[p] = (int)run_rep.size();
+          run_rep.push_back(p);
+          run_cnt.push_back(1);
+          break;
+        }
+        if (sig_equal(run_rep[r], p)) {
+          run_of[p] = r;
+          ++run_cnt[r];
+          break;
+        }
+      }
+    }
+  }
+  std::vector<int> run_start(run_rep.size() + 1, 0);
+  for (size_t r = 0; r < run_rep.size(); ++r) run_start[r + 1] = run_start[r] + run_cnt[r];
+  std::vector<int> order(run_start.back());
+  {
+    std::vector<int> fillr(run_start.begin(), run_start.end() - 1);
+    for (int p = 0; p < n_pt; ++p)
+      if (run_of[p] >= 0) order[fillr[run_of[p]]++] = p;
+  }
   b->np = (int)order.size();
   b->perm = order;
-  std::vector<int> optr(b->np + 1, 0), ocam;
-  std::vector<double> oxy;
-  ocam.reserve(n_obs);
-  oxy.reserve(2 * (size_t)n_obs);
+  std::vector<int> optr(b->np + 1, 0);
+  for (int sp = 0; sp < b->np; ++sp) optr[sp + 1] = optr[sp] + (cnt[order[sp] + 1] - cnt[order[sp]]);
+  b->no = optr[b->np];
+  std::vector<int> ocam(b->no);
+  std::vector<double> oxy(2 * (size_t)b->no);
   b->h_cam_used.assign(n_cam, 0);
-  for (int sp = 0; sp < b->np; ++sp) {
-    const int p = order[sp];
-    for (int k = cnt[p]; k < cnt[p + 1]; ++k) {
-      const int o = slot[k];
-      ocam.push_back(obs_cam[o]);
-      oxy.push_back(obs_xy[2 * o]);
-      oxy.push_back(obs_xy[2 * o + 1]);
-      b->h_cam_used[obs_cam[o]] = 1;
+  // the gather of a million observations is a cache-miss chain on one core: split it over a few
+  host_parallel_for(b->np, [&](int lo, int hi) {
+    for (int sp = lo; sp < hi; ++sp) {
+      const int p = order[sp];
+      int w = optr[sp];
+      for (int k = cnt[p]; k < cnt[p + 1]; ++k, ++w) {
+        const int o = slot[k];
+        ocam[w] = obs_cam[o];
+        oxy[2 * (size_t)w] = obs_xy[2 * (size_t)o];
+        oxy[2 * (size_t)w + 1] = obs_xy[2 * (size_t)o + 1];
+      }
     }
-    optr[sp + 1] = (int)ocam.size();
-  }
-  b->no = (int)ocam.size();
+  });
+  for (int k = 0; k < b->no; ++k) b->h_cam_used[ocam[k]] = 1;
+  lap_("signature sort + csr");
   // ---- chunks: runs of equal signature with strictly ascending cameras, n <= 10 -> MFMA path,
   //      classed by the width of the local Gram matrix: NB = ceil((6n+2)/16) column blocks
   std::vector<Chunk> chunks;
@@ -1520,14 +1597,10 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   // launch runs in rounds of 512 workgroups; pick the run length that minimises
   // rounds x (run length + fixed per-workgroup cost, ~40 points' worth of prologue + scatter)
   int target = 64;
+  const std::vector<int>& gstart = run_start;  // first sorted point of every run, + np
   {
     std::vector<int> gsz;
-    for (int sp = 0; sp < b->np;) {
-      int e = sp + 1;
-      while (e < b->np && !sig_less(order[sp], order[e]) && !sig_less(order[e], order[sp])) ++e;
-      gsz.push_back(e - sp);
-      sp = e;
-    }
+    for (size_t gi = 0; gi + 1 < gstart.size(); ++gi) gsz.push_back(gstart[gi + 1] - gstart[gi]);
     double best = 1e300;
     for (int t = 32; t <= 512; t += 4) {
       long long w = 0;
@@ -1539,9 +1612,8 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
       }
     }
   }
-  for (int sp = 0; sp < b->np;) {
-    int e = sp + 1;
-    while (e < b->np && !sig_less(order[sp], order[e]) && !sig_less(order[e], order[sp])) ++e;
+  for (size_t gi = 0; gi + 1 < gstart.size(); ++gi) {
+    const int sp = gstart[gi], e = gstart[gi + 1];
     const int n = optr[sp + 1] - optr[sp];
     bool strict = true;
     for (int k = 1; k < n; ++k) strict = strict && ocam[optr[sp] + k - 1] < ocam[optr[sp] + k];
@@ -1558,8 +1630,8 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
     } else {
       for (int q = sp; q < e; ++q) fb.push_back(q);
     }
-    sp = e;
   }
+  lap_("chunks");
   // ---- camera-major copy of the observations (sorted point index, xy) for ba_cam_blocks
   std::vector<int> cptr(n_cam + 1, 0), cpt(b->no);
   std::vector<double> cxy(2 * (size_t)b->no);
@@ -1576,6 +1648,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
       }
     b->cam_split = std::max(1, std::min(64, 1024 / std::max(n_cam, 1)));
   }
+  lap_("camera-major copy");
   // ---- device storage
   BaDev& d = b->d;
   d.nc = n_cam;
@@ -1631,6 +1704,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
     return bytes ? hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
   };
+  lap_("hipMalloc x27");
   SFM_HIP_TRY(up(d_optr, optr.data(), optr.size() * 4));
   SFM_HIP_TRY(up(d_ocam, ocam.data(), ocam.size() * 4));
   SFM_HIP_TRY(up(d_oxy, oxy.data(), oxy.size() * 8));
@@ -1642,9 +1716,11 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   SFM_HIP_TRY(up(b->d_cpt, cpt.data(), cpt.size() * 4));
   SFM_HIP_TRY(up(b->d_cxy, cxy.data(), cxy.size() * 8));
   SFM_HIP_TRY(up(b->d_fb_points, fb.data(), fb.size() * 4));
+  lap_("uploads");
   SFM_HIP_TRY(hipHostMalloc((void**)&b->h_sc, sizeof(double) * (SC + 64 + 16), hipHostMallocDefault));
   for (auto& e : b->ev) SFM_HIP_TRY(hipEventCreate(&e));
   b->h_pts_in.assign(3 * (size_t)n_pt, 0.0);
+  lap_("pinned + events");
   *out = b;
   return SFMHIP_OK;
 }
