@@ -342,18 +342,19 @@ __global__ __launch_bounds__(256, 2) void ba_eliminate_mfma(BaDev d, const Chunk
                                                          double lm_lo, double lm_hi, int rank) {
   constexpr int NT = NB * (NB + 1) / 2;
   __shared__ __attribute__((aligned(16))) double s_cam[CAMD * 16];
-  __shared__ __attribute__((aligned(16))) double s_M[4 * 12 * MP];  // also the cross-wave reduction buffer
+  extern __shared__ __attribute__((aligned(16))) double s_M[];  // nw x 12 x MP panels; also the cross-wave reduction buffer
   __shared__ int s_gidx[64];  // local Gram index -> row/column of S; -2: the rhs column u; -1: padding
+  const int nw = blockDim.x >> 6;  // 4 waves for long runs, 1 for runs of a few points (unstructured visibility)
   const Chunk ch = chunks[chunk_ids[blockIdx.x]];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = ch.n;
   const int* cams = sig_cams + ch.sig_off;
   const int sld = d.ld, fo = 6 * d.nc;
-  for (int idx = tid; idx < n * CAMD; idx += 256) {
+  for (int idx = tid; idx < n * CAMD; idx += (int)blockDim.x) {
     const int o = idx / CAMD, e = idx - o * CAMD;
     s_cam[e * 16 + o] = d.camd[(size_t)CAMD * cams[o] + e];
   }
-  for (int idx = tid; idx < 4 * 12 * MP; idx += 256) s_M[idx] = 0.0;
+  for (int idx = tid; idx < nw * 12 * MP; idx += (int)blockDim.x) s_M[idx] = 0.0;
   if (tid < 64) {
     int gi = -1;
     if (tid < 6 * n) gi = 6 * cams[tid / 6] + tid % 6;
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void ba_eliminate_mfma(BaDev d, const Chunk
   const CamLds cd{s_cam + oc};
   const int frow = lane >> 4, fcol = lane & 15;
 
-  for (int quad = wave; 4 * quad < ch.cnt; quad += 4) {
+  for (int quad = wave; 4 * quad < ch.cnt; quad += nw) {
     const int pi = 4 * quad + q;
     const bool pv = pi < ch.cnt;
     const int pl = pv ? pi : ch.cnt - 1;
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void ba_eliminate_mfma(BaDev d, const Chunk
   // ---- cross-wave sum of the Gram tiles (s_M is free now), then one scatter into S per chunk
   __syncthreads();
 #pragma unroll 1
-  for (int w = 1; w < 4; ++w) {
+  for (int w = 1; w < nw; ++w) {
     if (wave == w) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -1391,8 +1392,8 @@ struct sfmhip_ba {
   bool cam_used_known = false;
   // plan
   Chunk* d_chunks = nullptr;
-  int* d_chunk_ids[4] = {nullptr, nullptr, nullptr, nullptr};  // by Gram width class NB-1
-  int n_chunk_ids[4] = {0, 0, 0, 0};
+  int* d_chunk_ids[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int n_chunk_ids[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [NB-1]: 4-wave workgroups (long runs), [4 + NB-1]: 1-wave (short runs)
   int* d_sig_cams = nullptr;
   int* d_cptr = nullptr;  // camera-major observation list: cptr[nc+1], cpt[no], cxy[no]
   int* d_cpt = nullptr;
@@ -1592,7 +1593,8 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   // ---- chunks: runs of equal signature with strictly ascending cameras, n <= 10 -> MFMA path,
   //      classed by the width of the local Gram matrix: NB = ceil((6n+2)/16) column blocks
   std::vector<Chunk> chunks;
-  std::vector<int> ids[4], sig_cams, fb;
+  std::vector<int> ids[8], sig_cams, fb;
+  constexpr int SHORT_RUN = 12;  // runs of at most this many points go to one-wave workgroups
   // points per workgroup: 2 workgroups of 4 waves are resident per CU (register-bound), so the
   // launch runs in rounds of 512 workgroups; pick the run length that minimises
   // rounds x (run length + fixed per-workgroup cost, ~40 points' worth of prologue + scatter)
@@ -1600,7 +1602,8 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   const std::vector<int>& gstart = run_start;  // first sorted point of every run, + np
   {
     std::vector<int> gsz;
-    for (size_t gi = 0; gi + 1 < gstart.size(); ++gi) gsz.push_back(gstart[gi + 1] - gstart[gi]);
+    for (size_t gi = 0; gi + 1 < gstart.size(); ++gi)
+      if (gstart[gi + 1] - gstart[gi] > SHORT_RUN) gsz.push_back(gstart[gi + 1] - gstart[gi]);
     double best = 1e300;
     for (int t = 32; t <= 512; t += 4) {
       long long w = 0;
@@ -1621,11 +1624,16 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
       const int so = (int)sig_cams.size();
       for (int k = 0; k < n; ++k) sig_cams.push_back(ocam[optr[sp] + k]);
       const int nb = (6 * n + 2 + 15) / 16;
-      const int parts = (e - sp + target - 1) / target;
-      for (int q = 0; q < parts; ++q) {
-        const int lo = sp + (int)((long long)(e - sp) * q / parts), hi = sp + (int)((long long)(e - sp) * (q + 1) / parts);
-        ids[nb - 1].push_back((int)chunks.size());
-        chunks.push_back(Chunk{so, n, lo, hi - lo});
+      if (e - sp <= SHORT_RUN) {
+        ids[4 + nb - 1].push_back((int)chunks.size());
+        chunks.push_back(Chunk{so, n, sp, e - sp});
+      } else {
+        const int parts = (e - sp + target - 1) / target;
+        for (int q = 0; q < parts; ++q) {
+          const int lo = sp + (int)((long long)(e - sp) * q / parts), hi = sp + (int)((long long)(e - sp) * (q + 1) / parts);
+          ids[nb - 1].push_back((int)chunks.size());
+          chunks.push_back(Chunk{so, n, lo, hi - lo});
+        }
       }
     } else {
       for (int q = sp; q < e; ++q) fb.push_back(q);
@@ -1685,7 +1693,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   BA_A(d.info, 1);
   BA_A(b->d_cam_used, n_cam);
   BA_A(b->d_chunks, chunks.size());
-  for (int c = 0; c < 4; ++c) BA_A(b->d_chunk_ids[c], ids[c].size());
+  for (int c = 0; c < 8; ++c) BA_A(b->d_chunk_ids[c], ids[c].size());
   BA_A(b->d_sig_cams, sig_cams.size());
   BA_A(b->d_cptr, cptr.size());
   BA_A(b->d_cpt, cpt.size());
@@ -1699,7 +1707,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   d.optr = d_optr;
   d.ocam = d_ocam;
   d.oxy = d_oxy;
-  for (int c = 0; c < 4; ++c) b->n_chunk_ids[c] = (int)ids[c].size();
+  for (int c = 0; c < 8; ++c) b->n_chunk_ids[c] = (int)ids[c].size();
   b->n_fb = (int)fb.size();
   auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
     return bytes ? hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
@@ -1710,7 +1718,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   SFM_HIP_TRY(up(d_oxy, oxy.data(), oxy.size() * 8));
   SFM_HIP_TRY(up(b->d_cam_used, b->h_cam_used.data(), n_cam));
   SFM_HIP_TRY(up(b->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk)));
-  for (int c = 0; c < 4; ++c) SFM_HIP_TRY(up(b->d_chunk_ids[c], ids[c].data(), ids[c].size() * 4));
+  for (int c = 0; c < 8; ++c) SFM_HIP_TRY(up(b->d_chunk_ids[c], ids[c].data(), ids[c].size() * 4));
   SFM_HIP_TRY(up(b->d_sig_cams, sig_cams.data(), sig_cams.size() * 4));
   SFM_HIP_TRY(up(b->d_cptr, cptr.data(), cptr.size() * 4));
   SFM_HIP_TRY(up(b->d_cpt, cpt.data(), cpt.size() * 4));
@@ -1825,10 +1833,12 @@ static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_o
     ++nl;
   }
 #define BA_ELIM(NB)                                                                                                   \
-  if (b->n_chunk_ids[NB - 1]) {                                                                                       \
-    hipLaunchKernelGGL((ba_eliminate_mfma<NB>), dim3(b->n_chunk_ids[NB - 1]), dim3(256), 0, st, d, b->d_chunks,       \
-                       b->d_chunk_ids[NB - 1], b->d_sig_cams, inv_radius, o->min_lm_diagonal, o->max_lm_diagonal,     \
-                       b->rank);                                                                                      \
+  for (int cls = 0; cls < 2; ++cls) {                                                                                 \
+    const int li = 4 * cls + NB - 1, nthreads = cls ? 64 : 256;                                                       \
+    if (!b->n_chunk_ids[li]) continue;                                                                                \
+    hipLaunchKernelGGL((ba_eliminate_mfma<NB>), dim3(b->n_chunk_ids[li]), dim3(nthreads),                             \
+                       sizeof(double) * (nthreads / 64) * 12 * MP, st, d, b->d_chunks, b->d_chunk_ids[li],            \
+                       b->d_sig_cams, inv_radius, o->min_lm_diagonal, o->max_lm_diagonal, b->rank);                   \
     ++nl;                                                                                                             \
   }
   BA_ELIM(1)
