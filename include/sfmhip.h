@@ -87,6 +87,10 @@ void sfmhip_imageset_destroy(sfmhip_imageset* set);
 /* pairs: n_pairs x (queryImage, trainImage) int32, host memory */
 int sfmhip_matchplan_create(sfmhip_imageset* set, const int32_t* pairs, int n_pairs,
                             sfmhip_matchplan** out);
+/* point an existing plan at another pair list (n_pairs <= the count it was created with): the
+ * device buffers are reused, e.g. a one-pair plan serving every getMatching(q,t) call over a
+ * resident image set (reference src/Sfm.cpp:426,977,1031) */
+int sfmhip_matchplan_set_pairs(sfmhip_matchplan* plan, const int32_t* pairs, int n_pairs);
 /* k-NN + ratio test + ordered compaction for every pair of the plan; results stay in HBM */
 int sfmhip_matchplan_run_async(sfmhip_matchplan* plan, float ratio);
 /* counts[n_pairs]; optional concatenated lists (capacity entries each, pair-major, ascending

@@ -12,6 +12,15 @@ t0 = time.perf_counter(); n = 50
 for _ in range(n):
     mq, mt, md = matcher.get_matching(imgs[0], imgs[1], ctx=ctx)
 print(f"getMatching 2000x2000 SIFT-128, host buffers in/out: {(time.perf_counter()-t0)/n*1e3:.3f} ms per call, {len(mq)} matches")
+iset = matcher.ImageSet(imgs, ctx=ctx)
+iset.prepare_async()
+one = matcher.MatchPlan(iset, [[0, 1]])
+for _ in range(3):
+    one.set_pairs([[0, 1]]); one.run_async(0.8); one.fetch()
+t0 = time.perf_counter()
+for i in range(n):
+    one.set_pairs([[i & 1, 1 - (i & 1)]]); one.run_async(0.8); c, q_, t_, d_ = one.fetch()
+print(f"getMatching over a resident set (set_pairs + run + fetch): {(time.perf_counter()-t0)/n*1e3:.3f} ms per call")
 sc = synth.two_view_scene(500, seed=1)
 for _ in range(3):
     triangulate.triangulate_points(sc["P1"], sc["P2"], sc["K"], sc["dist"], sc["xy1"], sc["xy2"], ctx=ctx)

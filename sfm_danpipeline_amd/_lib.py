@@ -40,7 +40,7 @@ SYMBOLS = [
     "sfmhip_init", "sfmhip_init_on_stream", "sfmhip_shutdown", "sfmhip_synchronize", "sfmhip_error_string",
     "sfmhip_last_hip_error", "sfmhip_version", "sfmhip_match_knn2", "sfmhip_imageset_create",
     "sfmhip_imageset_upload", "sfmhip_imageset_adopt_device", "sfmhip_imageset_prepare_async",
-    "sfmhip_imageset_destroy", "sfmhip_matchplan_create", "sfmhip_matchplan_run_async", "sfmhip_matchplan_fetch",
+    "sfmhip_imageset_destroy", "sfmhip_matchplan_create", "sfmhip_matchplan_set_pairs", "sfmhip_matchplan_run_async", "sfmhip_matchplan_fetch",
     "sfmhip_matchplan_fetch_knn", "sfmhip_matchplan_last_timing", "sfmhip_matchplan_destroy",
     "sfmhip_triangulate", "sfmhip_find_2d3d", "sfmhip_merge_new_points", "sfmhip_ba_default_opts", "sfmhip_ba_solve", "sfmhip_ba_create",
     "sfmhip_ba_set_allreduce", "sfmhip_ba_set_params", "sfmhip_ba_get_params", "sfmhip_ba_run",
@@ -67,6 +67,7 @@ def lib():
     L.sfmhip_synchronize.argtypes = [vp]
     L.sfmhip_error_string.argtypes = [cint]
     L.sfmhip_error_string.restype = C.c_char_p
+    L.sfmhip_matchplan_set_pairs.argtypes = [vp, vp, cint]
     L.sfmhip_find_2d3d.argtypes = [vp, vp, vp, vp, cint, cint, cint, vp, vp, cint, vp, vp, vp]
     L.sfmhip_merge_new_points.argtypes = [vp, vp, cint, vp, cint, C.c_float, vp, vp]
     L.sfmhip_match_knn2.argtypes = [vp, vp, cint, vp, cint, cint, cint, cint, C.c_float, vp, vp, vp, vp]

@@ -31,15 +31,47 @@ void StructFromMotion::getMatching(const int& idx_query, const int& idx_train, M
   std::vector<int32_t> oq(q.rows), ot(q.rows);
   std::vector<float> od(q.rows);
   int32_t n = 0;
-  // cv::NORM_L2 whatever the descriptor type, like the reference (src/Sfm.cpp:593)
-  const int rc = sfmhip_match_knn2(sfm_hip_context(), q.ptr(), q.rows, t.ptr(), t.rows, q.cols,
-                                   q.type() == CV_32F ? SFMHIP_F32 : SFMHIP_U8, SFMHIP_L2, NN_MATCH_RATIO, oq.data(),
-                                   ot.data(), od.data(), &n);
+  int rc = SFMHIP_OK;
+  // every image uploaded and prepared once; cv::NORM_L2 whatever the descriptor type, like the
+  // reference (src/Sfm.cpp:593)
+  bool uniform = true;
+  for (const cv::Mat& d : imagesDescriptors) uniform = uniform && d.cols == q.cols && d.type() == q.type();
+  if (uniform) {
+    sfmhip_ctx* ctx = sfm_hip_context();
+    if (!devSet) {
+      std::vector<int32_t> rows;
+      for (const cv::Mat& d : imagesDescriptors) rows.push_back(d.rows);
+      rc = sfmhip_imageset_create(ctx, (int)rows.size(), rows.data(), q.cols, q.type() == CV_32F ? SFMHIP_F32 : SFMHIP_U8,
+                                  SFMHIP_L2, &devSet);
+      for (size_t i = 0; rc == SFMHIP_OK && i < rows.size(); ++i)
+        if (rows[i] > 0) rc = sfmhip_imageset_upload(devSet, (int)i, imagesDescriptors[i].ptr());
+      if (rc == SFMHIP_OK) rc = sfmhip_imageset_prepare_async(devSet);
+      const int32_t first[2] = {idx_query, idx_train};
+      if (rc == SFMHIP_OK) rc = sfmhip_matchplan_create(devSet, first, 1, &devPlan);
+    }
+    const int32_t pr[2] = {idx_query, idx_train};
+    if (rc == SFMHIP_OK) rc = sfmhip_matchplan_set_pairs(devPlan, pr, 1);
+    if (rc == SFMHIP_OK) rc = sfmhip_matchplan_run_async(devPlan, NN_MATCH_RATIO);
+    int64_t tot = 0;
+    if (rc == SFMHIP_OK) rc = sfmhip_matchplan_fetch(devPlan, &n, oq.data(), ot.data(), od.data(), q.rows, &tot);
+    if (rc != SFMHIP_OK) releaseDeviceSet();
+  } else {
+    rc = sfmhip_match_knn2(sfm_hip_context(), q.ptr(), q.rows, t.ptr(), t.rows, q.cols,
+                           q.type() == CV_32F ? SFMHIP_F32 : SFMHIP_U8, SFMHIP_L2, NN_MATCH_RATIO, oq.data(), ot.data(),
+                           od.data(), &n);
+  }
   if (rc != SFMHIP_OK) {
     std::cerr << "getMatching: " << sfmhip_error_string(rc) << std::endl;
     return;
   }
   for (int i = 0; i < n; ++i) goodMatches->push_back(cv::DMatch(oq[i], ot[i], od[i]));  // appends
+}
+
+void StructFromMotion::releaseDeviceSet() {
+  if (devPlan) sfmhip_matchplan_destroy(devPlan);
+  if (devSet) sfmhip_imageset_destroy(devSet);
+  devPlan = nullptr;
+  devSet = nullptr;
 }
 
 void StructFromMotion::AlignedPointsFromMatch(const Points2d& queryImg, const Points2d& trainImg, const Matching& matches,

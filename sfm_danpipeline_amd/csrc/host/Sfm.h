@@ -7,6 +7,7 @@
 #include <set>
 #include <string>
 #include "BundleAdjustment.h"
+#include "sfmhip.h"
 
 class StructFromMotion {
  private:
@@ -23,11 +24,19 @@ class StructFromMotion {
   // matrices and the reference calls it ~1.5 N^2 times for N(N-1)/2 distinct pairs
   std::map<std::pair<int, int>, Matching> pairCache;
   bool pairCacheOn;
+  // descriptors resident in HBM + a reusable one-pair plan: a getMatching call that misses the
+  // cache costs one kernel sequence instead of two uploads and a dozen allocations
+  sfmhip_imageset* devSet;
+  sfmhip_matchplan* devPlan;
+  void releaseDeviceSet();
 
  public:
   std::vector<Point3D> nReconstructionCloud;
 
-  StructFromMotion() : NN_MATCH_RATIO(0.8f), detector(1), pairCacheOn(false) {}
+  StructFromMotion() : NN_MATCH_RATIO(0.8f), detector(1), pairCacheOn(false), devSet(nullptr), devPlan(nullptr) {}
+  ~StructFromMotion() { releaseDeviceSet(); }
+  StructFromMotion(const StructFromMotion&) = delete;
+  StructFromMotion& operator=(const StructFromMotion&) = delete;
 
   // reference include/Sfm.h:89, src/Sfm.cpp:590-608
   void getMatching(const int& queryImage, const int& trainImage, Matching* goodMatches);
@@ -54,7 +63,11 @@ class StructFromMotion {
   void adjustCurrentBundle();
 
   // ---- stand-ins for the out-of-scope front end: hand the pipeline state in directly
-  void setDescriptors(const std::vector<cv::Mat>& d) { imagesDescriptors = d; }
+  void setDescriptors(const std::vector<cv::Mat>& d) {
+    imagesDescriptors = d;
+    releaseDeviceSet();
+    clearPairCache();
+  }
   void setPoints2D(const std::vector<std::vector<cv::Point2d>>& p) { imagesPts2D = p; }
   void setCameraMatrix(const Intrinsics& k) { cameraMatrix = k; }
   void setCameraPoses(const std::vector<cv::Matx34d>& p) { nCameraPoses = p; }

@@ -696,6 +696,8 @@ struct sfmhip_imageset {
 struct sfmhip_matchplan {
   sfmhip_imageset* set;
   int n_pairs, n_items, maxq;
+  int cap_pairs = 0;
+  size_t cap_items = 0;
   std::vector<int> h_pairs;
   int2* d_pairs = nullptr;
   WorkItem* d_items = nullptr;
@@ -867,56 +869,65 @@ extern "C" void sfmhip_imageset_destroy(sfmhip_imageset* s) {
   delete s;
 }
 
-extern "C" int sfmhip_matchplan_create(sfmhip_imageset* s, const int32_t* pairs, int n_pairs, sfmhip_matchplan** out) {
-  if (!s || !out || n_pairs < 0 || (n_pairs && !pairs)) return SFMHIP_ERR_ARG;
-  SFM_HIP_TRY(hipSetDevice(s->ctx->device));
+// work list: one workgroup per (pair, block of 8 query tiles).  Ordered so that the blocks a
+// round-robin dispatcher puts on one XCD (equal index mod 8) walk the same train image
+// together: train images are dealt to the 8 groups, each group sorted by train image.
+static void build_work_items(const sfmhip_imageset* s, const int32_t* pairs, int n_pairs, std::vector<WorkItem>& items) {
+  std::vector<WorkItem> lanes[8];
+  std::vector<int> order(n_pairs);
+  for (int p = 0; p < n_pairs; ++p) order[p] = p;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pairs[2 * a + 1] < pairs[2 * b + 1]; });
+  size_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int cur_t = -1, cur_lane = 0;
+  for (int p : order) {
+    const int qi = pairs[2 * p], ti = pairs[2 * p + 1];
+    if (s->n_rows[ti] < 1 || s->n_rows[qi] == 0) continue;  // nt==1 still has a 1-NN list
+    if (ti != cur_t) {
+      cur_t = ti;
+      cur_lane = (int)(std::min_element(load, load + 8) - load);
+    }
+    const int nqt = (s->n_rows[qi] + TILE_ROWS - 1) / TILE_ROWS;
+    for (int t0 = 0; t0 < nqt; t0 += 8) {
+      lanes[cur_lane].push_back(WorkItem{p, t0});
+      load[cur_lane] += (size_t)s->n_pad[ti];
+    }
+  }
+  items.clear();
+  size_t mx = 0;
+  for (auto& l : lanes) mx = std::max(mx, l.size());
+  // interleave; shorter lanes are padded by stealing from the longest so the list stays dense
+  std::vector<size_t> pos(8, 0);
+  for (size_t i = 0; i < mx; ++i)
+    for (int x = 0; x < 8; ++x)
+      if (pos[x] < lanes[x].size()) items.push_back(lanes[x][pos[x]++]);
+}
+
+static int plan_check_pairs(const sfmhip_imageset* s, const int32_t* pairs, int n_pairs) {
   for (int p = 0; p < n_pairs; ++p)
     if (pairs[2 * p] < 0 || pairs[2 * p] >= s->n_images || pairs[2 * p + 1] < 0 || pairs[2 * p + 1] >= s->n_images)
       return SFMHIP_ERR_ARG;
+  return SFMHIP_OK;
+}
+
+extern "C" int sfmhip_matchplan_create(sfmhip_imageset* s, const int32_t* pairs, int n_pairs, sfmhip_matchplan** out) {
+  if (!s || !out || n_pairs < 0 || (n_pairs && !pairs)) return SFMHIP_ERR_ARG;
+  SFM_HIP_TRY(hipSetDevice(s->ctx->device));
+  SFM_TRY(plan_check_pairs(s, pairs, n_pairs));
   sfmhip_matchplan* pl = new sfmhip_matchplan();
   pl->set = s;
   pl->n_pairs = n_pairs;
+  pl->cap_pairs = std::max(n_pairs, 1);
   pl->maxq = std::max(s->maxq, 1);
   pl->h_pairs.assign(pairs, pairs + 2 * (size_t)n_pairs);
-  // work list: one workgroup per (pair, block of 8 query tiles).  Ordered so that the blocks a
-  // round-robin dispatcher puts on one XCD (equal index mod 8) walk the same train image
-  // together: train images are dealt to the 8 groups, each group sorted by train image.
-  std::vector<WorkItem> lanes[8];
-  {
-    std::vector<int> order(n_pairs);
-    for (int p = 0; p < n_pairs; ++p) order[p] = p;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pairs[2 * a + 1] < pairs[2 * b + 1]; });
-    size_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int cur_t = -1, cur_lane = 0;
-    for (int p : order) {
-      const int qi = pairs[2 * p], ti = pairs[2 * p + 1];
-      if (s->n_rows[ti] < 1 || s->n_rows[qi] == 0) continue;  // nt==1 still has a 1-NN list
-      if (ti != cur_t) {
-        cur_t = ti;
-        cur_lane = (int)(std::min_element(load, load + 8) - load);
-      }
-      const int nqt = (s->n_rows[qi] + TILE_ROWS - 1) / TILE_ROWS;
-      for (int t0 = 0; t0 < nqt; t0 += 8) {
-        lanes[cur_lane].push_back(WorkItem{p, t0});
-        load[cur_lane] += (size_t)s->n_pad[ti];
-      }
-    }
-  }
   std::vector<WorkItem> items;
-  {
-    size_t mx = 0;
-    for (auto& l : lanes) mx = std::max(mx, l.size());
-    // interleave; shorter lanes are padded by stealing from the longest so the list stays dense
-    std::vector<size_t> pos(8, 0);
-    for (size_t i = 0; i < mx; ++i)
-      for (int x = 0; x < 8; ++x)
-        if (pos[x] < lanes[x].size()) items.push_back(lanes[x][pos[x]++]);
-  }
+  build_work_items(s, pairs, n_pairs, items);
   pl->n_items = (int)items.size();
+  // room for any pair list of up to cap_pairs pairs (sfmhip_matchplan_set_pairs)
+  pl->cap_items = (size_t)pl->cap_pairs * (size_t)(((pl->maxq + TILE_ROWS - 1) / TILE_ROWS + 7) / 8);
   int rc = SFMHIP_OK;
-  const size_t slots = (size_t)std::max(n_pairs, 1) * pl->maxq;
-  if ((rc = sfm_dev_alloc(&pl->d_pairs, (size_t)n_pairs)) || (rc = sfm_dev_alloc(&pl->d_items, items.size())) ||
-      (rc = sfm_dev_alloc(&pl->d_knn, slots)) || (rc = sfm_dev_alloc(&pl->d_counts, (size_t)n_pairs)) ||
+  const size_t slots = (size_t)pl->cap_pairs * pl->maxq;
+  if ((rc = sfm_dev_alloc(&pl->d_pairs, (size_t)pl->cap_pairs)) || (rc = sfm_dev_alloc(&pl->d_items, pl->cap_items)) ||
+      (rc = sfm_dev_alloc(&pl->d_knn, slots)) || (rc = sfm_dev_alloc(&pl->d_counts, (size_t)pl->cap_pairs)) ||
       (rc = sfm_dev_alloc(&pl->d_out_q, slots)) || (rc = sfm_dev_alloc(&pl->d_out_t, slots)) ||
       (rc = sfm_dev_alloc(&pl->d_out_d, slots)) || (rc = sfm_dev_alloc(&pl->d_fix_count, (size_t)1)) ||
       (rc = sfm_dev_alloc(&pl->d_fix_items, (size_t)FIX_CAP))) {
@@ -925,9 +936,33 @@ extern "C" int sfmhip_matchplan_create(sfmhip_imageset* s, const int32_t* pairs,
   }
   if (n_pairs) SFM_HIP_TRY(hipMemcpy(pl->d_pairs, pairs, sizeof(int2) * n_pairs, hipMemcpyHostToDevice));
   if (!items.empty()) SFM_HIP_TRY(hipMemcpy(pl->d_items, items.data(), sizeof(WorkItem) * items.size(), hipMemcpyHostToDevice));
-  SFM_HIP_TRY(hipMemset(pl->d_counts, 0, sizeof(int) * std::max(n_pairs, 1)));
+  SFM_HIP_TRY(hipMemset(pl->d_counts, 0, sizeof(int) * pl->cap_pairs));
   for (auto& e : pl->ev) SFM_HIP_TRY(hipEventCreate(&e));
   *out = pl;
+  return SFMHIP_OK;
+}
+
+// Re-target a plan at another pair list (at most as many pairs as it was created with): the
+// device buffers are reused, so a one-pair plan serves every getMatching call of a session.
+extern "C" int sfmhip_matchplan_set_pairs(sfmhip_matchplan* pl, const int32_t* pairs, int n_pairs) {
+  if (!pl || n_pairs < 0 || (n_pairs && !pairs) || n_pairs > pl->cap_pairs) return SFMHIP_ERR_ARG;
+  sfmhip_imageset* s = pl->set;
+  SFM_HIP_TRY(hipSetDevice(s->ctx->device));
+  SFM_TRY(plan_check_pairs(s, pairs, n_pairs));
+  std::vector<WorkItem> items;
+  build_work_items(s, pairs, n_pairs, items);
+  if (items.size() > pl->cap_items) return SFMHIP_ERR_STATE;
+  hipStream_t st = s->ctx->stream;
+  SFM_HIP_TRY(hipStreamSynchronize(st));  // a previous run may still read the old lists
+  pl->n_pairs = n_pairs;
+  pl->n_items = (int)items.size();
+  pl->h_pairs.assign(pairs, pairs + 2 * (size_t)n_pairs);
+  if (n_pairs) SFM_HIP_TRY(hipMemcpyAsync(pl->d_pairs, pairs, sizeof(int2) * n_pairs, hipMemcpyHostToDevice, st));
+  if (!items.empty())
+    SFM_HIP_TRY(hipMemcpyAsync(pl->d_items, items.data(), sizeof(WorkItem) * items.size(), hipMemcpyHostToDevice, st));
+  SFM_HIP_TRY(hipMemsetAsync(pl->d_counts, 0, sizeof(int) * pl->cap_pairs, st));
+  SFM_HIP_TRY(hipStreamSynchronize(st));  // items / pairs are host temporaries
+  pl->timed = false;
   return SFMHIP_OK;
 }
 

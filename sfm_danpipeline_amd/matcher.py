@@ -98,6 +98,12 @@ class MatchPlan:
         check(lib().sfmhip_matchplan_create(image_set.h, self.pairs.ctypes.data, self.n_pairs, C.byref(self.h)),
               "sfmhip_matchplan_create")
 
+    def set_pairs(self, pairs):
+        """Re-target the plan (at most as many pairs as it was created with); buffers are reused."""
+        self.pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        self.n_pairs = self.pairs.shape[0]
+        check(lib().sfmhip_matchplan_set_pairs(self.h, self.pairs.ctypes.data, self.n_pairs), "sfmhip_matchplan_set_pairs")
+
     def run_async(self, ratio=NN_MATCH_RATIO):
         check(lib().sfmhip_matchplan_run_async(self.h, ratio), "sfmhip_matchplan_run_async")
 

@@ -188,3 +188,24 @@ def test_heavy_ties_across_tiles_and_chunks(ctx, orc, nq, nt, levels, seed):
     qb = rng.integers(0, 2, (nq, 32)).astype(np.uint8) * 255
     s2, pl2 = _plan(ctx, [qb, orb], [[0, 1]], _lib.HAMMING)
     _assert_pair(orc, pl2, 0, qb, orb, _lib.HAMMING)
+
+
+def test_one_pair_plan_retargeted_over_a_resident_set(ctx):
+    """sfmhip_matchplan_set_pairs: a one-pair plan pointed at each pair in turn (the getMatching
+    drop-in over descriptors resident in HBM) returns what the batched all-pairs plan returns."""
+    imgs = synth.sift_image_set(5, 700, 128, bank=1000, seed=21)
+    imgs[3] = imgs[3][:130]                               # ragged
+    pairs = np.array([[a, b] for a in range(5) for b in range(5) if a != b], np.int32)
+    s, pl = _plan(ctx, imgs, pairs)
+    cnt, oq, ot, od = pl.fetch()
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    one = matcher.MatchPlan(s, pairs[:1])
+    for p in np.random.default_rng(0).permutation(len(pairs)):
+        one.set_pairs(pairs[p:p + 1])
+        one.run_async(0.8)
+        c1, q1, t1, d1 = one.fetch()
+        assert c1[0] == cnt[p]
+        assert np.array_equal(q1, oq[off[p]:off[p + 1]]) and np.array_equal(t1, ot[off[p]:off[p + 1]])
+        assert np.array_equal(d1, od[off[p]:off[p + 1]])
+    with pytest.raises(Exception):
+        one.set_pairs(pairs[:2])                          # more pairs than the plan was created for
