@@ -1,0 +1,16 @@
+"""Ad-hoc GPU check (run through gpurun): 20 LM iterations at three problem sizes, cost trajectory
+and per-phase timing (the reduced solve is solve_s) -- the quick A/B while working on chol_step2."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from sfm_danpipeline_amd import synth, bundle, _lib
+
+ctx = _lib.default_context()
+for (nc, npt, k) in ((7, 400, 5), (50, 20000, 10), (200, 100000, 10)):
+    pb = synth.ba_problem(nc, npt, k, seed=777)
+    prob = bundle.BaProblem(nc, npt, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
+    for rep in range(3):
+        prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+        t0 = time.time(); s = prob.iterate(20); dt = time.time() - t0
+    print(f"{nc}/{npt}: 20 iterations {dt*1e3:.2f} ms -> {20/dt:.1f} it/s; cost {s.initial_cost:.12e} -> {s.final_cost:.12e}; succ {s.successful_steps}; {prob.last_timing()}", flush=True)
+    prob.close()

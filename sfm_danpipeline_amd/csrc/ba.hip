@@ -22,8 +22,8 @@
 //                     the panel's Gram matrix on v_mfma_f64_16x16x4_f64; one f64 atomic scatter
 //                     into S per workgroup.
 //   ba_finalize       LM diagonal (clamped squared column norms / radius) onto S, gradient max.
-//   chol_step/chol_backsolve  dense blocked Cholesky of S with the rhs carried as an extra
-//                     row, then the transposed triangular solve.
+//   chol_step2/chol_backsolve  dense blocked Cholesky of S (two 32-column panels per launch) with
+//                     the rhs carried as an extra row, then the transposed triangular solve.
 //   ba_cand_cams      candidate cameras / focal and their rotation tables.
 //   ba_backsub        per point: back-substitution, model cost change, candidate point,
 //                     candidate cost.
@@ -756,36 +756,15 @@ __global__ __launch_bounds__(1024) void ba_finalize(BaDev d, double radius, doub
 
 // ---------------------------------------------------------------- dense Cholesky (f64)
 // A is the row-major upper triangle of S == column-major lower triangle: L(r,c) = A[c*ld + r],
-// r >= c, so a column of L is contiguous.  ld = dim rounded up to 32 (identity on the padded
-// diagonal), so no tile needs a bounds check.  The rhs g is carried as one extra tile row
-// (row 0 of tile row nt, kept in y) so that y = L^-1 g falls out of the factorisation;
-// chol_backsolve then solves L^T z = y.
-//
-// One launch per 32-column panel (right-looking, the update of the previous panel fused in).
-// Launch k, one 2-wave workgroup per remaining tile (ti >= tj >= k):
-//   * tiles right of block column k only take the pending rank-32 update of panel k-1:
-//     T -= L(ti,k-1) L(tj,k-1)^T on v_mfma_f64_16x16x4_f64, operands straight from global
-//     memory (16 contiguous doubles per k index), each wave one 16-column half of the tile;
-//   * the tiles of block column k carry the factorisation, with no inter-workgroup dependency
-//     inside the launch: wave 0 updates + factors the diagonal tile (every such workgroup
-//     redundantly: POTRF in registers, row per lane, pivot and next-column terms by
-//     v_readlane, the rest of the column broadcast through LDS), wave 1 updates the
-//     workgroup's own tile and solves it against L_kk (row per lane), trailing the
-//     factorisation by one 4-column block (progress flag in LDS; the factorising wave never waits).
+// r >= c, so a column of L is contiguous.  ld = dim rounded up to 64 (identity on the padded
+// diagonal), so no tile needs a bounds check and the 32-column panels come in pairs.  The rhs g
+// is carried as one extra tile row (row 0 of tile row nt, kept in y) so that y = L^-1 g falls out
+// of the factorisation; chol_backsolve then solves L^T z = y.  Right-looking, one launch per two
+// panels (chol_step2 below), no dependency between workgroups inside a launch.
 #ifdef SFM_CHOL_STAMPS
-// diagnostic build only (scripts/chol_stamps.py): s_memtime at the phase boundaries of the panel
-// workgroup ti_rel == 1 of launch k == 4, written to a buffer nothing else reads
-__device__ unsigned long long g_chol_stamps[16];
-#define CHOL_STAMP(slot)                                                                        \
-  do {                                                                                          \
-    if (k == 4 && ti_rel == 1 && tj_rel == 0 && lane == 0) {                                    \
-      unsigned long long t_;                                                                    \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
-      g_chol_stamps[slot] = t_;                                                                 \
-    }                                                                                           \
-  } while (0)
-#else
-#define CHOL_STAMP(slot)
+// diagnostic build only (scripts/chol_stamps.py): s_memtime at the phase boundaries of one panel
+// workgroup, written to a buffer nothing else reads
+__device__ unsigned long long g_chol_stamps[32];
 #endif
 constexpr int CB = 32;
 constexpr int CBP = 34;  // LDS row pitch in doubles: 16-byte aligned rows, conflict-free tile writes
@@ -796,294 +775,9 @@ constexpr int CBP = 34;  // LDS row pitch in doubles: 16-byte aligned rows, conf
 // registers are tile columns c = (lane>>4) + 4g.
 #define CHOL_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0)
 
-template <bool RHS>
-__device__ __forceinline__ void chol_body(double* __restrict__ A, double* __restrict__ y, double* __restrict__ dinv,
-                                          double* __restrict__ linv, int ld, int nt, int k, int* __restrict__ info,
-                                          int ti_rel, int tj_rel, double* sD, double* sT, double* sLr, double* sdi,
-                                          int* s_prog_p) {
-  const int m = nt - k;
-  constexpr bool is_rhs = RHS;  // the rhs tile row is its own instantiation: plain loads for everybody else
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int j16 = lane & 15, q = lane >> 4;
-  const int r0 = (k + ti_rel) * CB, c0 = (k + tj_rel) * CB, p0 = (k - 1) * CB;
-  const bool rlane = j16 == 0;  // the rhs tile row has one real row: tile row 0
-  if (threadIdx.x == 0) (*s_prog_p) = 0;
-  __syncthreads();
-  CHOL_STAMP(wave == 0 ? 0 : 8);
-
-  // element (tile row r, column index col) of the workgroup's tile row: L(r0+r, col) or, for the
-  // rhs row, y[col] on tile row 0 and zero elsewhere
-  auto ld_row = [&](int r, int col) -> double {
-    if (is_rhs) return r == 0 ? y[col] : 0.0;
-    return A[(size_t)col * ld + r0 + r];
-  };
-
-  if (tj_rel != 0) {
-    // ---------------- trailing tile: pending update of panel k-1 only (k >= 1 here)
-    const int ci = wave;
-    double a[8], b[2][8];
-    v4d acc[2];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const int kk = p0 + 4 * ks + q;
-      a[ks] = -A[(size_t)kk * ld + c0 + 16 * ci + j16];
-      b[0][ks] = ld_row(j16, kk);
-      b[1][ks] = ld_row(16 + j16, kk);
-    }
-#pragma unroll
-    for (int ri = 0; ri < 2; ++ri)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) acc[ri][g] = ld_row(16 * ri + j16, c0 + 16 * ci + q + 4 * g);
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      CHOL_MFMA(acc[0], a[ks], b[0][ks]);
-      CHOL_MFMA(acc[1], a[ks], b[1][ks]);
-    }
-#pragma unroll
-    for (int ri = 0; ri < 2; ++ri)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int col = c0 + 16 * ci + q + 4 * g;
-        if (is_rhs) {
-          if (ri == 0 && rlane) y[col] = acc[ri][g];
-        } else {
-          A[(size_t)col * ld + r0 + 16 * ri + j16] = acc[ri][g];
-        }
-      }
-    return;
-  }
-
-  // ---------------- block column k: update, factor the diagonal tile, solve the own tile
-  // the factorising wave is the launch's critical path: it outranks the solving wave that trails
-  // it (and polls its progress through LDS), and both outrank the trailing-tile filler
-  if (wave == 0) __builtin_amdgcn_s_setprio(3);
-  else __builtin_amdgcn_s_setprio(1);
-  const bool owner = ti_rel == 0;
-  const int i = lane & 31;  // row of the tile handled by this lane in the row-per-lane phases
-  if (wave == 0 || !owner) {
-    // wave 0: diagonal tile (rows c0..); wave 1: own tile (rows r0.. / the rhs row)
-    const bool diag = wave == 0;
-    double a[2][8], b[2][8];
-    v4d acc[2][2];  // [ci][ri]
-    if (k > 0) {
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const int kk = p0 + 4 * ks + q;
-        a[0][ks] = -A[(size_t)kk * ld + c0 + j16];
-        a[1][ks] = -A[(size_t)kk * ld + c0 + 16 + j16];
-        if (!diag) {
-          b[0][ks] = ld_row(j16, kk);
-          b[1][ks] = ld_row(16 + j16, kk);
-        }
-      }
-    }
-#pragma unroll
-    for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-      for (int ri = 0; ri < 2; ++ri)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int col = c0 + 16 * ci + q + 4 * g;
-          acc[ci][ri][g] = diag ? A[(size_t)col * ld + c0 + 16 * ri + j16] : ld_row(16 * ri + j16, col);
-        }
-#ifdef SFM_CHOL_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    CHOL_STAMP(wave == 0 ? 1 : 9);
-    if (k > 0) {
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-        for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-          for (int ri = 0; ri < 2; ++ri) CHOL_MFMA(acc[ci][ri], a[ci][ks], diag ? -a[ri][ks] : b[ri][ks]);
-    }
-    double* dst = diag ? sD : sT;
-#pragma unroll
-    for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-      for (int ri = 0; ri < 2; ++ri)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) dst[(16 * ri + j16) * CBP + 16 * ci + q + 4 * g] = acc[ci][ri][g];
-  }
-  // (each wave reads back only what it wrote itself: LDS operations of one wave stay in order)
-  CHOL_STAMP(wave == 0 ? 2 : 10);
-
-  if (wave == 0) {
-    // ---- POTRF of the diagonal tile: lane i = row i (both half-waves alike)
-    double d[CB];
-#pragma unroll
-    for (int c = 0; c < CB; c += 2) {
-      const double2 v = *(const double2*)(sD + i * CBP + c);
-      d[c] = v.x;
-      d[c + 1] = v.y;
-    }
-    // left-looking inside the tile: column j first takes the products with the finished columns
-    // (row j of L broadcast from LDS, the newest column through v_readlane so that the pivot
-    // chain does not wait for an LDS round trip), then pivot -> rsq -> scale.  Lanes 32..63
-    // mirror lanes 0..31 (same values to the same LDS addresses).
-    // Software-pipelined: the products of column j+1 with the columns before j are formed in
-    // the shadow of column j's pivot chain (readlane -> rsq -> two Newton steps -> scale), so the
-    // next chain starts with one FMA.  (Measured, scripts/ubench/op_rate64: a lone wave issues
-    // an f64 op every ~5.4 cycles, 8.4 when dependent, v_rsq_f64 16: the ~60 instructions of a
-    // column, not the chain, set its ~450 cycles.)
-    bool bad = false;
-    double pre = d[0];
-#pragma unroll
-    for (int j = 0; j < CB; ++j) {
-      double v = pre;
-      if (j >= 1) v -= d[j - 1] * readlane_f64(d[j - 1], j);
-      const double djj = readlane_f64(v, j);
-      bad |= !(djj > 0.0);
-      const double r = rsqrt_f64(djj);
-      const double l = i >= j ? v * r : 0.0;  // lane j: djj * r = sqrt(djj)
-      if (j + 1 < CB) {
-        double pa[4] = {d[j + 1], 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int c = 0; c + 1 < j; c += 2) {
-          const double2 x = *(const double2*)(sLr + (j + 1) * CBP + c);
-          pa[c & 3] -= d[c] * x.x;
-          pa[(c + 1) & 3] -= d[c + 1] * x.y;
-        }
-        if (j & 1) pa[(j - 1) & 3] -= d[j - 1] * sLr[(j + 1) * CBP + j - 1];
-        pre = (pa[0] + pa[1]) + (pa[2] + pa[3]);
-      }
-      d[j] = l;
-      sLr[i * CBP + j] = l;
-      sdi[j] = r;
-      __builtin_amdgcn_sched_barrier(0);  // keep the columns in order
-      // progress flag for the solving wave (LDS operations of one wave stay in order, so the
-      // columns are in LDS before the flag); the factorising wave never waits for anybody
-      if ((j & 3) == 3) {
-        asm volatile("" ::: "memory");
-        *(volatile int*)&(*s_prog_p) = j + 1;
-      }
-    }
-    CHOL_STAMP(3);
-    if (owner) {
-      // the diagonal tile's owner publishes L_kk and 1/diag
-      if (bad && lane == 0) atomicExch(info, k * CB + 1);  // the host discards the step
-      if (lane < CB) {
-#pragma unroll
-        for (int c = 0; c < CB; ++c)
-          if (c <= i) A[(size_t)(c0 + c) * ld + c0 + i] = d[c];
-        dinv[c0 + i] = sdi[i];
-      }
-    }
-  } else {
-    // ---- own tile (or the rhs row): X = T L_kk^-T, lane i = row i, one 8-column block behind
-    // (the diagonal tile's owner solves the identity instead: X = L_kk^-T, kept for the
-    // backward substitution, whose diagonal solves then are plain 32x32 products)
-    const unsigned prog_addr = (unsigned)(size_t)(__attribute__((address_space(3))) int*)&(*s_prog_p);
-    double t[CB];
-    if (!owner) {
-#pragma unroll
-      for (int c = 0; c < CB; c += 2) {
-        const double2 v = *(const double2*)(sT + i * CBP + c);
-        t[c] = v.x;
-        t[c + 1] = v.y;
-      }
-    } else {
-#pragma unroll
-      for (int c = 0; c < CB; ++c) t[c] = c == i ? 1.0 : 0.0;
-    }
-#pragma unroll
-    for (int jb = 0; jb < CB / 4; ++jb) {
-      {
-        // wait until the factorising wave has published 4*jb+4 columns: one opaque asm block (a
-        // C loop here splits the unrolled solve into basic blocks and the allocator spills)
-        int seen_;
-        asm volatile(
-            "1:\n\t"
-            "ds_read_b32 %0, %1\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "v_cmp_lt_i32 vcc, %0, %2\n\t"
-            "s_cbranch_vccz 2f\n\t"
-            "s_sleep 4\n\t"
-            "s_branch 1b\n\t"
-            "2:\n\t"
-            : "=&v"(seen_)
-            : "v"(prog_addr), "v"(4 * jb + 4)
-            : "vcc", "memory");
-      }
-      {
-#pragma unroll
-        for (int j = 4 * jb; j < 4 * jb + 4; ++j) {
-          double ta[4] = {t[j], 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int c = 0; c + 1 < j; c += 2) {
-            const double2 x = *(const double2*)(sLr + j * CBP + c);
-            ta[c & 3] -= t[c] * x.x;
-            ta[(c + 1) & 3] -= t[c + 1] * x.y;
-          }
-          if (j & 1) ta[(j - 1) & 3] -= t[j - 1] * sLr[j * CBP + j - 1];
-          t[j] = ((ta[0] + ta[1]) + (ta[2] + ta[3])) * sdi[j];
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-    CHOL_STAMP(11);
-    if (owner) {
-      if (lane < CB) {
-#pragma unroll
-        for (int c = 0; c < CB; ++c) linv[(size_t)(c0 + c) * CB + i] = t[c];  // (L_kk^-T)[i][c], column-major
-      }
-    } else if (is_rhs) {
-      if (lane == 0) {
-#pragma unroll
-        for (int c = 0; c < CB; ++c) y[c0 + c] = t[c];
-      }
-    } else if (lane < CB) {
-#pragma unroll
-      for (int c = 0; c < CB; ++c) A[(size_t)(c0 + c) * ld + r0 + i] = t[c];
-    }
-    CHOL_STAMP(12);
-  }
-}
-
-__global__ __launch_bounds__(128) void chol_step(double* __restrict__ A, double* __restrict__ y,
-                                                 double* __restrict__ dinv, double* __restrict__ linv, int ld,
-                                                 int nt, int k, int* __restrict__ info) {
-  __shared__ __attribute__((aligned(16))) double sD[CB * CBP];   // updated diagonal tile [row][col]
-  __shared__ __attribute__((aligned(16))) double sT[CB * CBP];   // updated own tile      [row][col]
-  __shared__ __attribute__((aligned(16))) double sLr[CB * CBP];  // L_kk [row][col]
-  __shared__ double sdi[CB];                                     // 1 / diag(L_kk)
-  __shared__ int s_prog;                                         // columns of L_kk finished so far
-  const int m = nt - k;  // remaining tile rows (the rhs row comes on top)
-  // block -> tile: the m+1 tiles of block column k first (they carry the factorisation)
-  int ti_rel, tj_rel;
-  if ((int)blockIdx.x <= m) {
-    ti_rel = blockIdx.x;
-    tj_rel = 0;
-  } else {
-    int t = blockIdx.x - (m + 1);
-    ti_rel = 1;
-    while (true) {
-      const int w = ti_rel < m ? ti_rel : m - 1;  // tj_rel in 1..min(ti_rel, m-1)
-      if (t < w) break;
-      t -= w;
-      ++ti_rel;
-    }
-    tj_rel = 1 + t;
-  }
-  if (ti_rel == m) chol_body<true>(A, y, dinv, linv, ld, nt, k, info, ti_rel, tj_rel, sD, sT, sLr, sdi, &s_prog);
-  else chol_body<false>(A, y, dinv, linv, ld, nt, k, info, ti_rel, tj_rel, sD, sT, sLr, sdi, &s_prog);
-}
-#undef CHOL_MFMA
-
-// L^T z = y.  U = L^T is upper triangular and row-major in this storage (U[i][j] = A[i*ld + j]),
-// so row i of U is contiguous.  Block rows are taken in groups of GB (256 rows) from the bottom:
-//   chol_backsolve_group  one workgroup of 8 waves per group: a chain wave (32x32 products with
-//                         the diagonal tiles' inverses) and seven owner waves that fold finished
-//                         blocks into the ones further up (see the kernel);
-//   chol_backsolve_gemv   folds the group's solution into y of every row above the group, one
-//                         wave per row (coalesced 2 KB row segments), all CUs.
-// A single workgroup pulling the whole triangle (5.8 MB at cfg4) is bound by one CU's load
-// bandwidth; the grouping leaves it 1/GB of the triangle.
-constexpr int GB = 8;
-
-// Bounded LDS spin (one opaque asm block, see chol_step): until *flag >= need.
-__device__ __forceinline__ void lds_wait_ge(const int* flag, int need) {
+// Bounded LDS spin, until *flag >= need: one opaque asm block (a C loop splits the unrolled block
+// steps that call it into basic blocks, and the register allocator spills).
+__device__ __forceinline__ int lds_wait_ge(const int* flag, int need) {
   const unsigned addr = (unsigned)(size_t)(const __attribute__((address_space(3))) int*)flag;
   int seen_, budget_ = 1 << 20;
   asm volatile(
@@ -1101,7 +795,749 @@ __device__ __forceinline__ void lds_wait_ge(const int* flag, int need) {
       : "=&v"(seen_), "+s"(budget_)
       : "v"(addr), "v"(need)
       : "vcc", "scc", "memory");
+  return seen_;  // (what the counter read: callers catching up on several steps need not poll again)
 }
+
+// ------------------------------------------------------------------------------------------
+// chol_step2: TWO 32-column panels (a = 2*k2, b = a+1) per launch.  Every tile is kept up to date
+// except for the two panels of the previous launch ("pending", K = 64), which each launch folds in
+// as it reads a tile.  A launch is latency-bound: ~4k cycles of global-memory round trip, then two
+// dependent 32x32 factorisations of ~8k cycles each on ONE wave, with the solves of the workgroup's
+// tile row trailing them; everything else is arranged around that chain.
+//
+// Inside the panel workgroup everything is a rank-4 block step on tiles held in REGISTERS in the
+// MFMA accumulator layout (lane = tile row mod 16 + 16*(column mod 4), 4 registers = columns
+// q, q+4, q+8, q+12 of a 16x16 sub-tile), because v_mfma_f64_16x16x4_f64 has K = 4:
+//   block step of POTRF  the block's four columns go through LDS into row-per-lane registers,
+//                        are factored there (pivots by v_readlane), written back as L, re-read
+//                        in operand layout, and folded into the columns still to come with one
+//                        MFMA per live sub-tile (chol2_potrf_blocks, ~1k cycles);
+//   block step of TRSM   the same against a finished block of L (published through LDS with a
+//                        progress counter), X = T L^-T (chol2_trsm_blocks, ~0.8k cycles);
+//   U2                   D_bb -= Y Y^T and T_b -= X_a Y^T, one MFMA per sub-tile per finished block
+//                        of Y (and X_a), so that the second panel's tiles are final ~one block
+//                        step after the first panel's solves end.
+// Panel workgroup (11 waves; roles and their SIMDs in chol2_panel), for tile row r of the block
+// column (the owner: rows a and b; every workgroup factors D_aa and D_bb redundantly):
+//   D_aa <- global minus pending, operands straight from global memory (the chain starts here);
+//   the pending panels' rows of block rows a, b and r are staged in LDS once (C2_OFF_PAB/PRW) and
+//   every other fold (D_ba = tile(b,a), T_a = tile(r,a), D_bb, T_b = tile(r,b)) takes its operands
+//   from there; POTRF(D_aa) | Y = D_ba L_aa^-T (= L_ba) and X_a = T_a L_aa^-T trailing it | U2 |
+//   POTRF(D_bb) | X_b = T_b L_bb^-T trailing it.  The owner solves the identity instead of T_a, T_b
+//   (L^-T, kept for the backward substitution) and stores L_aa, L_ba, L_bb, 1/diag.
+// f64 MFMA throughput (16 FMA/clock/SIMD on gfx950, no more than the vector ALU) is what the
+// first half of a launch is short of: the folds are ordered per SIMD by hand (priorities do not
+// order the MFMAs of co-resident waves) and the right column halves of D_bb and T_b, which the
+// second factorisation and solve need four block steps later, are folded by wave 0 after its own
+// factorisation.
+// All hand-offs are LDS counters (one writer lane, bounded spins); LDS operations of one wave
+// execute in order, so data written before a counter update is visible to whoever saw the update.
+// Trailing workgroups (one wave per tile, four tiles each) fold the pending panels into the tiles
+// right of the block column.
+constexpr int C2_WAVES = 11;
+enum { F_PROG_A = 0, F_PROG_B, F_CNT_DAA, F_CNT_TA, F_CNT_DBA, F_YPROG, F_XPROG, F_STAGED, F_DBB_HI, F_TB_HI, F_DBA_S3, F_COUNT };
+// dynamic LDS of chol_step2 (doubles): five tiles | 1/diag of both panels | the pending panels' rows
+// of the block rows a and b (64 rows x 64 columns, [column][row], pitch PAB) and of the own tile row
+// (32 x 64, pitch PRW) | the counters.  The pitches put the four k-slices of an MFMA operand read
+// (lanes 16 apart) on disjoint banks.
+constexpr int C2_PAB = 80, C2_PRW = 48;
+constexpr int C2_OFF_SDI = 5 * CB * CBP, C2_OFF_PAB = C2_OFF_SDI + 2 * CB, C2_OFF_PRW = C2_OFF_PAB + 64 * C2_PAB,
+              C2_OFF_FLAG = C2_OFF_PRW + 64 * C2_PRW, C2_LDS_BYTES = (C2_OFF_FLAG + 8) * 8;
+static_assert(F_COUNT <= 16, "the counters have 8 doubles of LDS");
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// (explicitly LDS-typed: through a generic pointer these become flat, system-scope operations)
+typedef __attribute__((address_space(3))) int lds_int;
+__device__ __forceinline__ void lds_flag_set(int* flag, int v) {
+  asm volatile("" ::: "memory");
+  *(volatile lds_int*)flag = v;
+}
+__device__ __forceinline__ void lds_flag_add(int* flag, int lane) {
+  asm volatile("" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add((lds_int*)flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+}
+
+// d[k] = p[k * st], k = 0..N-1, by pointer increments: written as p[k * st] every address costs a
+// 64-bit multiply-add (quarter rate), and a wave spends longer forming addresses than the loads
+// take to come back.  The pin keeps the optimiser from re-deriving the products.
+typedef __attribute__((address_space(1))) double gbl_double;  // (through the pin a generic pointer would load flat)
+template <int N>
+__device__ __forceinline__ void ld_strided(double* d, const double* p_, size_t st) {
+  const gbl_double* p = (const gbl_double*)p_;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    d[k] = *p;
+    p += st;
+    asm volatile("" : "+v"(p));
+  }
+}
+
+// acc -= sum_ks a[ks] (x) b[ks], four partial accumulators
+__device__ __forceinline__ void chol2_fold_regs(v4d& acc, const double (&a)[16], const double (&b)[16]) {
+  v4d p1 = {0.0, 0.0, 0.0, 0.0}, p2 = p1, p3 = p1;
+#pragma unroll
+  for (int ks = 0; ks < 16; ks += 4) {
+    CHOL_MFMA(acc, -a[ks], b[ks]);
+    CHOL_MFMA(p1, -a[ks + 1], b[ks + 1]);
+    CHOL_MFMA(p2, -a[ks + 2], b[ks + 2]);
+    CHOL_MFMA(p3, -a[ks + 3], b[ks + 3]);
+  }
+  acc += (p1 + p2) + p3;
+}
+// acc -= sum over the 64 pending columns of (column operand) x (row operand), both staged in LDS:
+// pa / pb point at the lane's element of k-slice 0 (row index + lane&15 added, + (lane>>4) * pitch)
+// (four partial accumulators: a dependent v_mfma_f64_16x16x4_f64 issues every ~120 cycles, an
+// independent one every 64)
+__device__ __forceinline__ void chol2_fold(v4d& acc, const double* pa, int pitch_a, const double* pb, int pitch_b) {
+  double a[16], b[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    a[ks] = pa[4 * ks * pitch_a];
+    b[ks] = pb[4 * ks * pitch_b];
+  }
+  chol2_fold_regs(acc, a, b);
+}
+// 16x16 sub-tile s (ci = s&1 column half, ri = s>>1 row half) of the tile at M(rb.., cb..), from global memory
+__device__ __forceinline__ v4d chol2_tile(const double* __restrict__ A, int ld, int rb, int cb, int s, int lane) {
+  const int j16 = lane & 15, q = lane >> 4, ci = s & 1, ri = s >> 1;
+  double t[4];
+  ld_strided<4>(t, A + (size_t)(cb + 16 * ci + q) * ld + rb + 16 * ri + j16, 4 * (size_t)ld);
+  return v4d{t[0], t[1], t[2], t[3]};
+}
+// the same of the rhs tile row: y[cb..] on tile row 0, zero elsewhere
+__device__ __forceinline__ v4d chol2_tile_rhs(const double* __restrict__ y, int cb, int s, int lane) {
+  const int j16 = lane & 15, q = lane >> 4, ci = s & 1, ri = s >> 1;
+  v4d t;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) t[g] = ri == 0 && j16 == 0 ? y[cb + 16 * ci + q + 4 * g] : 0.0;
+  return t;
+}
+
+__device__ __forceinline__ void chol2_put(double* dst, int s, int lane, v4d acc) {
+  const int j16 = lane & 15, q = lane >> 4, ci = s & 1, ri = s >> 1;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) dst[(16 * ri + j16) * CBP + 16 * ci + q + 4 * g] = acc[g];
+}
+__device__ __forceinline__ v4d chol2_get(const double* src, int s, int lane) {
+  const int j16 = lane & 15, q = lane >> 4, ci = s & 1, ri = s >> 1;
+  v4d acc;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) acc[g] = src[(16 * ri + j16) * CBP + 16 * ci + q + 4 * g];
+  return acc;
+}
+
+#ifdef SFM_CHOL_STAMPS
+// branch-free (a conditional stamp splits the unrolled chains into basic blocks and the register
+// allocator spills): every panel workgroup stamps, all but one into a dump buffer
+__device__ unsigned long long g_chol_dump[32];
+#define C2_STAMP(slot)                                                                          \
+  do {                                                                                          \
+    unsigned long long t_;                                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
+    ((k2 == 2 && blockIdx.x == 1) ? g_chol_stamps : g_chol_dump)[slot] = t_;                    \
+  } while (0)
+#else
+#define C2_STAMP(slot)
+#endif
+// keeps the optimiser from enumerating which of the LDS tiles an offset selects (it would
+// materialise every tile address of the unrolled loops as a scalar constant, and spill them)
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// POTRF of a 32x32 tile whose lower sub-tiles are in acc (MFMA layout: [0] = (rows 0-15, cols 0-15),
+// [1] = (rows 16-31, cols 0-15), [2] = (rows 16-31, cols 16-31)), eight block steps of four columns.
+// sD receives L (row-major, zeros above the diagonal), sdi 1/diag, *prog the number of finished
+// blocks; gL / gdinv (owner only, else null) the copies in global memory.
+// late (if any): sub-tile [2] arrives at block step 4 -- *late counts to 1 when another wave has left the
+// part of it that does not depend on this factorisation in the tile's LDS home, to be added.
+__device__ __forceinline__ void chol2_potrf_blocks(v4d (&acc)[3], double* sD, double* sdi, int* prog, bool& bad,
+                                                   int lane, double* gL, int ld, double* gdinv, const int* late) {
+  const int i = lane & 31, j16 = lane & 15, q = lane >> 4;
+  double* const rowp = sD + i * CBP;       // row-per-lane view (both half-waves alike)
+  double* const op0 = sD + j16 * CBP + q;  // operand / accumulator view, rows 0..15
+  double* const op1 = op0 + 16 * CBP;      //                             rows 16..31
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const int c = 4 * b, g = b & 3;
+    if (b == 4 && late) {
+      lds_wait_ge(late, 1);
+      const v4d hi4 = chol2_get(sD, 3, lane);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) acc[2][g4] += hi4[g4];
+    }
+    // the block's columns: accumulator layout -> LDS -> row per lane
+    if (b < 4) {
+      op0[c] = acc[0][g];
+      op1[c] = acc[1][g];
+    } else {
+      op1[c] = acc[2][g];
+    }
+    const v2d lo = *(const v2d*)(rowp + c), hi = *(const v2d*)(rowp + c + 2);
+    double v[4] = {lo.x, lo.y, hi.x, hi.y}, l[4], r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double djj = readlane_f64(v[k], c + k);
+      bad |= !(djj > 0.0);
+      r[k] = rsqrt_f64(djj);
+      l[k] = i >= c + k ? v[k] * r[k] : 0.0;  // lane c+k: djj * r = sqrt(djj)
+#pragma unroll
+      for (int m = k + 1; m < 4; ++m) v[m] -= l[k] * readlane_f64(l[k], c + m);
+    }
+    *(v2d*)(rowp + c) = v2d{l[0], l[1]};
+    *(v2d*)(rowp + c + 2) = v2d{l[2], l[3]};
+    *(v2d*)(sdi + c) = v2d{r[0], r[1]};
+    *(v2d*)(sdi + c + 2) = v2d{r[2], r[3]};
+    lds_flag_set(prog, b + 1);
+    if (gL && lane < CB) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (i >= c + k) gL[(size_t)(c + k) * ld + i] = l[k];
+      if (i < 4) gdinv[c + i] = i == 0 ? r[0] : i == 1 ? r[1] : i == 2 ? r[2] : r[3];
+    }
+    if (b < 7) {
+      // fold the block into the columns still to come
+      const double L0 = op0[c], L1 = op1[c];
+      if (b < 3) {
+        CHOL_MFMA(acc[0], -L0, L0);
+        CHOL_MFMA(acc[1], -L0, L1);
+      }
+      CHOL_MFMA(acc[2], -L1, L1);
+    }
+  }
+}
+
+// X = T L^-T for a 32x32 tile T in acc (MFMA layout, [2*ci + ri]), trailing the factorisation of L
+// block by block through *prog.  sT is the tile's LDS home: scratch for the layout changes, and
+// X when done (row-major); *oflag (if any) counts its finished blocks; out/stride/on: the copy in
+// global memory (column c of the lane's row goes to out[c * stride]); late: see chol2_potrf_blocks
+// (here sub-tiles [2] and [3], the right column half).
+__device__ __forceinline__ void chol2_trsm_blocks(v4d (&acc)[4], double* sT, const double* sL, const double* sdi,
+                                                  const int* prog, int* oflag, double* out, size_t stride, bool on,
+                                                  int lane, const int* late) {
+  const int i = lane & 31, j16 = lane & 15, q = lane >> 4;
+  double* const rowp = sT + i * CBP;
+  double* const op0 = sT + j16 * CBP + q;
+  double* const op1 = op0 + 16 * CBP;
+  const double* const lop0 = sL + j16 * CBP + q;
+  const double* const lop1 = lop0 + 16 * CBP;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const int c = 4 * b, g = b & 3, cb = b >> 2;
+    if (b == 4 && late) {  // (as in chol2_potrf_blocks: the right column half arrives late)
+      lds_wait_ge(late, 1);
+      const v4d h2 = chol2_get(sT, 1, lane), h3 = chol2_get(sT, 3, lane);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        acc[2][g4] += h2[g4];
+        acc[3][g4] += h3[g4];
+      }
+    }
+    op0[c] = acc[2 * cb][g];
+    op1[c] = acc[2 * cb + 1][g];
+    const v2d lo = *(const v2d*)(rowp + c), hi = *(const v2d*)(rowp + c + 2);
+    lds_wait_ge(prog, b + 1);
+    // the 4x4 diagonal block of L and 1/diag (wave-uniform addresses: LDS broadcasts)
+    const double l10 = sL[(c + 1) * CBP + c];
+    const v2d l2 = *(const v2d*)(sL + (c + 2) * CBP + c);
+    const v2d l3 = *(const v2d*)(sL + (c + 3) * CBP + c);
+    const double l32 = sL[(c + 3) * CBP + c + 2];
+    const v2d r01 = *(const v2d*)(sdi + c), r23 = *(const v2d*)(sdi + c + 2);
+    double La0 = 0.0, La1 = 0.0;
+    if (b < 7) {
+      if (b < 3) La0 = -lop0[c];
+      La1 = -lop1[c];
+    }
+    const double x0 = lo.x * r01.x;
+    const double x1 = (lo.y - x0 * l10) * r01.y;
+    const double x2 = (hi.x - x0 * l2.x - x1 * l2.y) * r23.x;
+    const double x3 = (hi.y - x0 * l3.x - x1 * l3.y - x2 * l32) * r23.y;
+    *(v2d*)(rowp + c) = v2d{x0, x1};
+    *(v2d*)(rowp + c + 2) = v2d{x2, x3};
+    if (oflag) lds_flag_set(oflag, b + 1);
+    if (on) {
+      out[(size_t)(c + 0) * stride] = x0;
+      out[(size_t)(c + 1) * stride] = x1;
+      out[(size_t)(c + 2) * stride] = x2;
+      out[(size_t)(c + 3) * stride] = x3;
+    }
+    if (b < 7) {
+      const double X0 = op0[c], X1 = op1[c];
+      if (b < 3) {
+        CHOL_MFMA(acc[0], La0, X0);
+        CHOL_MFMA(acc[1], La0, X1);
+      }
+      CHOL_MFMA(acc[2], La1, X0);
+      CHOL_MFMA(acc[3], La1, X1);
+    }
+  }
+}
+
+template <bool RHS>
+__device__ __forceinline__ void chol2_panel(double* __restrict__ A, double* __restrict__ y, double* __restrict__ dinv,
+                                            double* __restrict__ linv, int ld, int k2, int* __restrict__ info,
+                                            bool owner, int r0, double* sAll) {
+  constexpr int T = CB * CBP;
+  double* const sdi_all = sAll + C2_OFF_SDI;
+  double* const sPab = sAll + C2_OFF_PAB;
+  double* const sPrw = sAll + C2_OFF_PRW;
+  int* const s_flag = (int*)(sAll + C2_OFF_FLAG);
+  double* const sDa = sAll;          // D_aa -> L_aa   [row][col]
+  double* const sTa = sAll + T;      // tile(r,a) -> X_a
+  double* const sYb = sAll + 2 * T;  // tile(b,a) -> Y = L_ba
+  //                  sAll + 3 * T      L_bb
+  //                  sAll + 4 * T      scratch of the second solve -> X_b
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, j16 = lane & 15, q = lane >> 4;
+  const int a0 = 2 * k2 * CB, b0 = a0 + CB, p0 = a0 - 2 * CB;
+  const bool pend = k2 > 0;
+  // Roles (wave -> SIMD is wave mod 4, and a SIMD that is folding -- back-to-back f64 MFMAs, 64
+  // cycles each -- lets a co-resident wave issue one VALU instruction per MFMA: the chain (wave 0)
+  // keeps SIMD 0 to itself, the two first-panel solves share SIMD 2 with D_ba folds only, which
+  // they wait for anyway, and the bulk of the folding goes to SIMDs 1 and 3):
+  //   0  D_aa s0, POTRF(D_aa)      1  D_aa s3, T_a s2 s3        2  D_aa s2, Y = D_ba L_aa^-T
+  //   3  D_bb, U2, POTRF(D_bb)     5  T_b, U2, X_b              6  D_ba s0, X_a = T_a L_aa^-T
+  //   7  D_ba s2, T_a s0 s1        9  D_ba s3                   10 D_ba s1          (4, 8: staging only)
+  const int dba_s = wave == 6 ? 0 : wave == 10 ? 1 : wave == 7 ? 2 : wave == 9 ? 3 : -1;
+  const int ta_s = owner ? -1 : wave == 7 ? 0 : wave == 1 ? 2 : -1;  // folds T_a sub-tiles ta_s, ta_s + 1
+  auto own_tile = [&](int cb, int s) -> v4d {  // sub-tile s of the own tile row at columns cb..
+    return RHS ? chol2_tile_rhs(y, cb, s, lane) : chol2_tile(A, ld, r0, cb, s, lane);
+  };
+  if (threadIdx.x < F_COUNT) s_flag[threadIdx.x] = 0;
+  __syncthreads();
+  if (wave == 0) C2_STAMP(0);
+  const double* const opab = sPab + q * C2_PAB + j16;  // the lane's element of k-slice 0, row 0
+  const double* const oprw = sPrw + q * C2_PRW + j16;
+  v4d t0, t1, t2, t3;  // the tiles go straight into the accumulators of the waves that fold them
+  if (wave < 3) {
+    // ---- the diagonal tile's lower sub-tiles, operands straight from global memory: the chain
+    // starts on them, one round trip and no hand-off
+    const int s = wave == 0 ? 0 : wave == 1 ? 3 : 2, ci = s & 1, ri = s >> 1;
+    const size_t st = 4 * (size_t)ld;
+    __builtin_amdgcn_s_setprio(3);
+    t0 = chol2_tile(A, ld, a0, a0, s, lane);
+    double a[16], b[16];
+    if (pend) {
+      ld_strided<16>(a, A + (size_t)(p0 + q) * ld + a0 + 16 * ci + j16, st);
+      ld_strided<16>(b, A + (size_t)(p0 + q) * ld + a0 + 16 * ri + j16, st);
+    }
+    if (ta_s >= 0) {
+      t1 = own_tile(a0, ta_s);
+      t2 = own_tile(a0, ta_s + 1);
+    }
+    // (what waves 0 and 2 fold once their first-panel work is done, see below)
+    if (wave == 0 && !owner) {
+      t2 = own_tile(b0, 1);  // T_b (ci 1, ri 0)
+      t3 = own_tile(b0, 3);  // T_b (ci 1, ri 1)
+    }
+    if (wave == 0) t1 = chol2_tile(A, ld, b0, b0, 3, lane);  // D_bb (ci 1, ri 1)
+    if (pend) chol2_fold_regs(t0, a, b);
+    chol2_put(sDa, s, lane, t0);
+    lds_flag_add(&s_flag[F_CNT_DAA], lane);
+    if (wave == 0) C2_STAMP(1);
+  } else {
+    // ---- waves 3..10 stage the pending panels' rows once per workgroup (every other job needs two
+    // of the three row blocks; loaded per job from global memory the workgroup moves 4x the bytes
+    // and the vector memory pipe, not the factorisation, sets the pace).  16 bytes per lane,
+    // coalesced, all loads in flight before the first LDS write.
+    const int tid = threadIdx.x - 3 * 64;  // 0..511
+    v2d pab[4], prw[2];
+    if (pend) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int c = tid + 512 * it, col = c >> 5, pr = c & 31;
+        pab[it] = *(const v2d*)(A + (size_t)(p0 + col) * ld + a0 + 2 * pr);
+      }
+      if (RHS) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int c = tid + 512 * it, col = c >> 4, pr = c & 15;
+          prw[it] = v2d{pr ? 0.0 : y[p0 + col], 0.0};
+        }
+      } else if (!owner) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int c = tid + 512 * it, col = c >> 4, pr = c & 15;
+          prw[it] = *(const v2d*)(A + (size_t)(p0 + col) * ld + r0 + 2 * pr);
+        }
+      }
+    }
+    // (the tile loads are issued before the waits of the LDS writes)
+    if (wave == 3) {
+      t0 = chol2_tile(A, ld, b0, b0, 0, lane);
+      t1 = chol2_tile(A, ld, b0, b0, 2, lane);
+    } else if (wave == 5) {
+      if (!owner) {
+        t0 = own_tile(b0, 0);  // (ci 0, ri 0)
+        t1 = own_tile(b0, 2);  // (ci 0, ri 1)
+      }
+    } else if (dba_s >= 0) {
+      t0 = chol2_tile(A, ld, b0, a0, dba_s, lane);
+      if (ta_s >= 0) {
+        t1 = own_tile(a0, ta_s);
+        t2 = own_tile(a0, ta_s + 1);
+      }
+    }
+    if (pend) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int c = tid + 512 * it, col = c >> 5, pr = c & 31;
+        *(v2d*)(sPab + col * C2_PAB + 2 * pr) = pab[it];
+      }
+      if (RHS || !owner) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int c = tid + 512 * it, col = c >> 4, pr = c & 15;
+          *(v2d*)(sPrw + col * C2_PRW + 2 * pr) = prw[it];
+        }
+      }
+    }
+    lds_flag_add(&s_flag[F_STAGED], lane);
+    if (wave == 4 || wave == 8) return;
+  }
+
+  // ---- the folds that go through LDS tiles: D_ba (the solves spin on it), then T_a
+  if (dba_s >= 0 || ta_s >= 0) {
+    lds_wait_ge(&s_flag[F_STAGED], 8);
+    if (dba_s >= 0) {
+      __builtin_amdgcn_s_setprio(3);
+      if (pend) chol2_fold(t0, opab + 16 * (dba_s & 1), C2_PAB, opab + 32 + 16 * (dba_s >> 1), C2_PAB);
+      chol2_put(sYb, dba_s, lane, t0);
+      lds_flag_add(&s_flag[F_CNT_DBA], lane);
+      if (dba_s == 3) lds_flag_add(&s_flag[F_DBA_S3], lane);
+      C2_STAMP(16 + dba_s);
+    }
+    if (ta_s >= 0) {
+      __builtin_amdgcn_s_setprio(2);
+      // (priorities do not order MFMAs: D_ba, which Y waits for, goes first on each SIMD -- wave 7
+      // has just done its own, wave 1 lets wave 9 finish)
+      if (wave == 1) lds_wait_ge(&s_flag[F_DBA_S3], 1);
+      if (pend) {
+        // (ta_s is even: the two sub-tiles are the column halves of row half ta_s >> 1)
+        chol2_fold(t1, opab, C2_PAB, oprw + 16 * (ta_s >> 1), C2_PRW);
+        chol2_fold(t2, opab + 16, C2_PAB, oprw + 16 * (ta_s >> 1), C2_PRW);
+      }
+      chol2_put(sTa, ta_s, lane, t1);
+      chol2_put(sTa, ta_s + 1, lane, t2);
+      if (lane == 0) __hip_atomic_fetch_add((lds_int*)&s_flag[F_CNT_TA], 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      C2_STAMP(20 + ta_s);
+    }
+  }
+
+  if (wave == 0 || wave == 3) {
+    // ---- the factorisations: wave 0 the first panel's, wave 3 the second panel's
+    const int pass = wave == 3;
+    if (pass) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(3);
+    v4d acc[3];
+    if (pass) {
+      // D_bb minus the pending panels (the three lower sub-tiles share their operands) ...
+      // (only the left column half here: the factorisation needs sub-tile (1,1) four block steps
+      // later, and wave 2 folds it when Y is done -- f64 MFMA throughput, 16 FMA/clock/SIMD, is
+      // what the first half of the launch is short of)
+      acc[0] = t0, acc[1] = t1;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[2][g] = 0.0;
+      if (pend) {
+        // (priorities do not order the MFMAs of co-resident waves: the first panel's folds go first)
+        lds_wait_ge(&s_flag[owner ? F_CNT_DBA : F_CNT_TA], 4);
+        C2_STAMP(15);
+        double Lb[2][16];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) Lb[h][ks] = opab[32 + 16 * h + 4 * ks * C2_PAB];
+        v4d p0 = {0.0, 0.0, 0.0, 0.0}, p1 = p0;
+#pragma unroll
+        for (int ks = 0; ks < 16; ks += 2) {
+          CHOL_MFMA(acc[0], -Lb[0][ks], Lb[0][ks]);
+          CHOL_MFMA(acc[1], -Lb[0][ks], Lb[1][ks]);
+          CHOL_MFMA(p0, -Lb[0][ks + 1], Lb[0][ks + 1]);
+          CHOL_MFMA(p1, -Lb[0][ks + 1], Lb[1][ks + 1]);
+        }
+        acc[0] += p0;
+        acc[1] += p1;
+      }
+      C2_STAMP(23);
+      // ... minus Y Y^T, block by block as wave 2 finishes them
+      const double* const y0 = sYb + j16 * CBP + q;
+      const double* const y1 = y0 + 16 * CBP;
+      int seen = 0;
+#pragma unroll 1
+      for (int b = 0; b < 8; ++b) {
+        if (seen <= b) seen = __builtin_amdgcn_readfirstlane(lds_wait_ge(&s_flag[F_YPROG], b + 1));
+        const double Y0 = y0[4 * b], Y1 = y1[4 * b];
+        CHOL_MFMA(acc[0], -Y0, Y0);
+        CHOL_MFMA(acc[1], -Y0, Y1);
+      }
+      __builtin_amdgcn_s_setprio(3);
+      C2_STAMP(3);
+    } else {
+      lds_wait_ge(&s_flag[F_CNT_DAA], 3);
+      acc[0] = chol2_get(sDa, 0, lane);
+      acc[1] = chol2_get(sDa, 2, lane);
+      acc[2] = chol2_get(sDa, 3, lane);
+    }
+    bool bad = false;
+    const int c0 = pass ? b0 : a0;
+    chol2_potrf_blocks(acc, sAll + opaque(pass * 3 * T), sdi_all + opaque(pass * CB), s_flag + opaque(F_PROG_A + pass),
+                       bad, lane, owner ? A + (size_t)c0 * ld + c0 : nullptr, ld, dinv + c0,
+                       pass ? &s_flag[F_DBB_HI] : nullptr);
+    C2_STAMP(pass ? 4 : 2);
+    if (owner && bad && lane == 0) atomicExch(info, c0 + 1);  // the host discards the step
+    if (!pass) {
+      // ---- wave 0, its factorisation done (SIMD 0 has nothing else to do, and folding anywhere else
+      // would slow a solve down): sub-tile (1,1) of D_bb (minus the pending panels, minus Y Y^T),
+      // left in L_bb's LDS home for wave 3 to pick up at block step 4
+      __builtin_amdgcn_s_setprio(1);
+      if (pend) {
+        double Lb[16];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) Lb[ks] = opab[32 + 16 + 4 * ks * C2_PAB];
+        chol2_fold_regs(t1, Lb, Lb);
+      }
+      lds_wait_ge(&s_flag[F_YPROG], 8);
+      const double* const yh = sYb + (16 + j16) * CBP + q;
+      v4d p0 = {0.0, 0.0, 0.0, 0.0}, p1 = p0, p2 = p0;
+#pragma unroll
+      for (int b = 0; b < 8; b += 4) {
+        const double Ya = yh[4 * b], Yb = yh[4 * b + 4], Yc = yh[4 * b + 8], Yd = yh[4 * b + 12];
+        CHOL_MFMA(t1, -Ya, Ya);
+        CHOL_MFMA(p0, -Yb, Yb);
+        CHOL_MFMA(p1, -Yc, Yc);
+        CHOL_MFMA(p2, -Yd, Yd);
+      }
+      t1 += (p0 + p1) + p2;
+      chol2_put(sAll + 3 * T, 3, lane, t1);
+      lds_flag_add(&s_flag[F_DBB_HI], lane);
+      C2_STAMP(14);
+    }
+    if (!pass && !owner) {
+      // ---- ... then the right column half of T_b (minus the pending panels, minus X_a Y^T), left in
+      // the second solve's LDS home for wave 5 to pick up at block step 4
+      if (pend) {
+        double Lb[16], Lr[2][16];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          Lb[ks] = opab[32 + 16 + 4 * ks * C2_PAB];
+          Lr[0][ks] = oprw[4 * ks * C2_PRW];
+          Lr[1][ks] = oprw[16 + 4 * ks * C2_PRW];
+        }
+        v4d p0 = {0.0, 0.0, 0.0, 0.0}, p1 = p0;
+#pragma unroll
+        for (int ks = 0; ks < 16; ks += 2) {
+          CHOL_MFMA(t2, -Lb[ks], Lr[0][ks]);
+          CHOL_MFMA(t3, -Lb[ks], Lr[1][ks]);
+          CHOL_MFMA(p0, -Lb[ks + 1], Lr[0][ks + 1]);
+          CHOL_MFMA(p1, -Lb[ks + 1], Lr[1][ks + 1]);
+        }
+        t2 += p0;
+        t3 += p1;
+      }
+      const double* const y1 = sYb + (16 + j16) * CBP + q;
+      const double* const x0 = sTa + j16 * CBP + q;
+      int seen_y = 0, seen_x = 0;
+#pragma unroll 1
+      for (int b = 0; b < 8; ++b) {
+        if (seen_y <= b) seen_y = __builtin_amdgcn_readfirstlane(lds_wait_ge(&s_flag[F_YPROG], b + 1));
+        if (seen_x <= b) seen_x = __builtin_amdgcn_readfirstlane(lds_wait_ge(&s_flag[F_XPROG], b + 1));
+        const double Y1 = -y1[4 * b], X0 = x0[4 * b], X1 = x0[16 * CBP + 4 * b];
+        CHOL_MFMA(t2, Y1, X0);
+        CHOL_MFMA(t3, Y1, X1);
+      }
+      chol2_put(sAll + 4 * T, 1, lane, t2);
+      chol2_put(sAll + 4 * T, 3, lane, t3);
+      lds_flag_add(&s_flag[F_TB_HI], lane);
+      C2_STAMP(13);
+    }
+  } else if (wave == 2 || wave == 6 || wave == 5) {
+    // ---- the solves: wave 2 tile (b,a) against L_aa (-> Y), wave 6 the own tile against L_aa, wave 5
+    // the own tile against L_bb after U2 (owner, waves 6 and 5: the identity -> L^-T)
+    const int pass = wave == 5;
+    if (pass) __builtin_amdgcn_s_setprio(0);
+    else if (wave == 2) __builtin_amdgcn_s_setprio(3);  // Y gates the second factorisation
+    else __builtin_amdgcn_s_setprio(2);
+    const bool ident = owner && wave != 2;
+    v4d acc[4];
+    if (ident) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[s][g] = (s == 0 || s == 3) && j16 == q + 4 * g ? 1.0 : 0.0;
+    } else if (pass) {
+      // T_b minus the pending panels ...
+      // (the left column half; wave 0 folds the right one when its factorisation is done)
+      acc[0] = t0, acc[1] = t1;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[2][g] = acc[3][g] = 0.0;
+      if (pend) {
+        lds_wait_ge(&s_flag[F_CNT_TA], 4);  // (as for D_bb)
+        double Lb[16], Lr[2][16];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          Lb[ks] = opab[32 + 4 * ks * C2_PAB];
+          Lr[0][ks] = oprw[4 * ks * C2_PRW];
+          Lr[1][ks] = oprw[16 + 4 * ks * C2_PRW];
+        }
+        v4d p0 = {0.0, 0.0, 0.0, 0.0}, p1 = p0;
+#pragma unroll
+        for (int ks = 0; ks < 16; ks += 2) {
+          CHOL_MFMA(acc[0], -Lb[ks], Lr[0][ks]);
+          CHOL_MFMA(acc[1], -Lb[ks], Lr[1][ks]);
+          CHOL_MFMA(p0, -Lb[ks + 1], Lr[0][ks + 1]);
+          CHOL_MFMA(p1, -Lb[ks + 1], Lr[1][ks + 1]);
+        }
+        acc[0] += p0;
+        acc[1] += p1;
+      }
+      // ... minus X_a Y^T, block by block as waves 6 and 2 finish them
+      const double* const y0 = sYb + j16 * CBP + q;
+      const double* const x0 = sTa + j16 * CBP + q;
+      int seen_y = 0, seen_x = 0;
+#pragma unroll 1
+      for (int b = 0; b < 8; ++b) {
+        if (seen_y <= b) seen_y = __builtin_amdgcn_readfirstlane(lds_wait_ge(&s_flag[F_YPROG], b + 1));
+        if (seen_x <= b) seen_x = __builtin_amdgcn_readfirstlane(lds_wait_ge(&s_flag[F_XPROG], b + 1));
+        const double Y0 = -y0[4 * b], X0 = x0[4 * b], X1 = x0[16 * CBP + 4 * b];
+        CHOL_MFMA(acc[0], Y0, X0);
+        CHOL_MFMA(acc[1], Y0, X1);
+      }
+      __builtin_amdgcn_s_setprio(2);
+    } else {
+      const double* src = wave == 2 ? sYb : sTa;
+      lds_wait_ge(s_flag + opaque(wave == 2 ? F_CNT_DBA : F_CNT_TA), 4);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[2 * (s & 1) + (s >> 1)] = chol2_get(src, s, lane);
+    }
+    const int c0 = pass ? b0 : a0;
+    double* out;  // base and column stride of the copy in global memory
+    size_t stride;
+    bool on = lane < CB;
+    if (wave == 2) {
+      out = A + (size_t)a0 * ld + b0 + i, stride = ld, on = on && owner;
+    } else if (owner) {
+      out = linv + (size_t)c0 * CB + i, stride = CB;  // (L_kk^-T)[i][c], column-major
+    } else if (RHS) {
+      out = y + c0, stride = 1, on = lane == 0;
+    } else {
+      out = A + (size_t)c0 * ld + r0 + i, stride = ld;
+    }
+    C2_STAMP(wave == 6 ? 6 : wave == 2 ? 11 : 9);
+    chol2_trsm_blocks(acc, sAll + opaque(wave == 2 ? 2 * T : T + pass * 3 * T), sAll + opaque(pass * 3 * T),
+                      sdi_all + opaque(pass * CB), s_flag + opaque(F_PROG_A + pass),
+                      wave == 5 ? nullptr : s_flag + opaque(wave == 2 ? F_YPROG : F_XPROG), out, stride, on, lane,
+                      pass && !owner ? &s_flag[F_TB_HI] : nullptr);
+    C2_STAMP(wave == 6 ? 7 : wave == 2 ? 12 : 10);
+  }
+}
+
+__global__ __launch_bounds__(C2_WAVES * 64) void chol_step2(double* __restrict__ A, double* __restrict__ y,
+                                                            double* __restrict__ dinv, double* __restrict__ linv,
+                                                            int ld, int nt, int k2, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double sAll[];  // C2_LDS_BYTES, see C2_OFF_*
+  const int m2 = nt - 2 * k2 - 2;  // tile rows below the two panels (the rhs row comes on top)
+  const int npanel = m2 + 2;       // owner, m2 tile rows, rhs
+  if ((int)blockIdx.x < npanel) {
+    const bool owner = blockIdx.x == 0;
+    const int r0 = (2 * k2 + 1 + (int)blockIdx.x) * CB;
+    if ((int)blockIdx.x == npanel - 1)
+      chol2_panel<true>(A, y, dinv, linv, ld, k2, info, false, r0, sAll);
+    else
+      chol2_panel<false>(A, y, dinv, linv, ld, k2, info, owner, r0, sAll);
+    return;
+  }
+  // ---- trailing tiles (k2 >= 1), one wave each (its four sub-tiles share the operands): tile row
+  // ti_rel in [0, m2] (m2 = rhs) has min(ti_rel + 1, m2) tiles
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave >= 4) return;  // one wave per SIMD: a tile is 64 MFMAs
+  int t = ((int)blockIdx.x - npanel) * 4 + wave;
+  if (t >= m2 * (m2 + 1) / 2 + m2) return;
+  int ti_rel = 0;
+  while (true) {
+    const int w = ti_rel < m2 ? ti_rel + 1 : m2;
+    if (t < w) break;
+    t -= w;
+    ++ti_rel;
+  }
+  const int c0 = (2 * k2 + 2) * CB;
+  const int rb = c0 + ti_rel * CB, cb = c0 + t * CB, p0 = (2 * k2 - 2) * CB;
+  const int j16 = lane & 15, q = lane >> 4;
+  double a[2][16], b[2][16];
+  v4d acc[4];  // [2 * ci + ri]
+  if (ti_rel == m2) {
+    // the rhs row: y[cb..] -= y[pending] L(cb.., pending)^T, tile row 0 only
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int kk = p0 + 4 * ks + q;
+      a[0][ks] = -A[(size_t)kk * ld + cb + j16];
+      a[1][ks] = -A[(size_t)kk * ld + cb + 16 + j16];
+      b[0][ks] = j16 == 0 ? y[kk] : 0.0;
+    }
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[ci][g] = j16 == 0 ? y[cb + 16 * ci + q + 4 * g] : 0.0;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      CHOL_MFMA(acc[0], a[0][ks], b[0][ks]);
+      CHOL_MFMA(acc[1], a[1][ks], b[0][ks]);
+    }
+    if (j16 == 0) {
+#pragma unroll
+      for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) y[cb + 16 * ci + q + 4 * g] = acc[ci][g];
+    }
+    return;
+  }
+  const size_t st = 4 * (size_t)ld;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    ld_strided<16>(a[h], A + (size_t)(p0 + q) * ld + cb + 16 * h + j16, st);
+    ld_strided<16>(b[h], A + (size_t)(p0 + q) * ld + rb + 16 * h + j16, st);
+  }
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri) {
+      double t4[4];
+      ld_strided<4>(t4, A + (size_t)(cb + 16 * ci + q) * ld + rb + 16 * ri + j16, st);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[2 * ci + ri][g] = t4[g];
+    }
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    CHOL_MFMA(acc[0], -a[0][ks], b[0][ks]);
+    CHOL_MFMA(acc[1], -a[0][ks], b[1][ks]);
+    CHOL_MFMA(acc[2], -a[1][ks], b[0][ks]);
+    CHOL_MFMA(acc[3], -a[1][ks], b[1][ks]);
+  }
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri) {
+      gbl_double* pt = (gbl_double*)(A + (size_t)(cb + 16 * ci + q) * ld + rb + 16 * ri + j16);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        *pt = acc[2 * ci + ri][g];
+        pt += st;
+        asm volatile("" : "+v"(pt));
+      }
+    }
+}
+#undef CHOL_MFMA
+
+// L^T z = y.  U = L^T is upper triangular and row-major in this storage (U[i][j] = A[i*ld + j]),
+// so row i of U is contiguous.  Block rows are taken in groups of GB (256 rows) from the bottom:
+//   chol_backsolve_group  one workgroup of 8 waves per group: a chain wave (32x32 products with
+//                         the diagonal tiles' inverses) and seven owner waves that fold finished
+//                         blocks into the ones further up (see the kernel);
+//   chol_backsolve_gemv   folds the group's solution into y of every row above the group, one
+//                         wave per row (coalesced 2 KB row segments), all CUs.
+// A single workgroup pulling the whole triangle (5.8 MB at cfg4) is bound by one CU's load
+// bandwidth; the grouping leaves it 1/GB of the triangle.
+constexpr int GB = 8;
 
 // One workgroup of 8 waves per group of GB block rows.  All waves first stage what the chain
 // will need -- the inverses of the group's diagonal tiles and the tiles right above the diagonal,
@@ -1446,7 +1882,7 @@ static int ba_alloc(sfmhip_ba* b, T** p, size_t n) {
 
 #ifdef SFM_CHOL_STAMPS
 extern "C" int sfmhip_debug_chol_stamps(unsigned long long* out16) {
-  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_chol_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -2;
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_chol_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -2;
 }
 #endif
 
@@ -1489,7 +1925,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   b->np_in = n_pt;
   b->no_in = n_obs;
   b->dim = 6 * n_cam + 1;
-  b->ld = (b->dim + CB - 1) / CB * CB;
+  b->ld = (b->dim + 2 * CB - 1) / (2 * CB) * (2 * CB);  // chol_step2 takes two 32-column panels per launch
   b->ssz = (size_t)b->ld * b->ld;
   // ---- group observations by point, ascending camera inside a point (std::map order of
   //      Point3D::idxImage, reference src/BundleAdjustment.cpp:87)
@@ -1868,10 +2304,19 @@ static int ba_reduced_solve(sfmhip_ba* b) {
   double* y = d.red + b->ssz;  // g becomes y = L^-1 g
   SFM_HIP_TRY(hipMemsetAsync(d.info, 0, sizeof(int), st));
   const int nt = b->ld / CB;
-  for (int k = 0; k < nt; ++k) {
-    const int m = nt - k;
-    const int nblk = k == 0 ? m + 1 : m * (m + 1) / 2 + m;  // launch 0 has no pending update
-    hipLaunchKernelGGL(chol_step, dim3(nblk), dim3(128), 0, st, A, y, d.dinv, d.linv, d.ld, nt, k, d.info);
+  int nchol = 0;
+  {
+    static bool c2_attr = false;
+    if (!c2_attr) {
+      SFM_HIP_TRY(hipFuncSetAttribute((const void*)chol_step2, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS_BYTES));
+      c2_attr = true;
+    }
+    for (int k2 = 0; 2 * k2 < nt; ++k2, ++nchol) {
+      const int m2 = nt - 2 * k2 - 2;
+      const int ntrail = k2 == 0 ? 0 : m2 * (m2 + 1) / 2 + m2;  // launch 0 has no pending update
+      hipLaunchKernelGGL(chol_step2, dim3(m2 + 2 + (ntrail + 3) / 4), dim3(C2_WAVES * 64), C2_LDS_BYTES, st, A, y, d.dinv,
+                         d.linv, d.ld, nt, k2, d.info);
+    }
   }
   int nbs = 0;
   constexpr int kBsLds = 2 * GB * CB * CB * (int)sizeof(double);  // 128 KiB of dynamic LDS
@@ -1890,7 +2335,7 @@ static int ba_reduced_solve(sfmhip_ba* b) {
     }
   }
   SFM_HIP_TRY(hipGetLastError());
-  b->launches += nt + nbs;
+  b->launches += nchol + nbs;
   return SFMHIP_OK;
 }
 
