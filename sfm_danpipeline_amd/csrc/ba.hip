@@ -1538,50 +1538,100 @@ __global__ __launch_bounds__(C2_WAVES * 64) void chol_step2(double* __restrict__
 // A single workgroup pulling the whole triangle (5.8 MB at cfg4) is bound by one CU's load
 // bandwidth; the grouping leaves it 1/GB of the triangle.
 constexpr int GB = 8;
+constexpr int BS_ADJ = CB * CBP;  // an adjacent tile in LDS, as in global memory ([column][row]) with the padded pitch
 
 // One workgroup of 8 waves per group of GB block rows.  All waves first stage what the chain
 // will need -- the inverses of the group's diagonal tiles and the tiles right above the diagonal,
 // 16 KB per block -- into LDS.  Wave 0 then is the dependency chain: for each block from the
 // bottom, z_b = L_bb^-T y_b (a 32x32 product) and the fold of z_b into the block right above.
-// Waves 1..7 own the other targets: the owner of block b folds the solutions of the blocks two
-// or more below into y_b as the chain publishes them, and hands y_b to the chain just before
-// it is needed.  Lane = row of the target block; hand-offs go through LDS flags.
+// Waves 1..7 fold the solutions of the blocks two or more below into the targets: one task per
+// tile (source block s, target block b <= s-2), a half-wave each (lane = column of the tile =
+// row of the target), at most four tasks per wave.  Every task's tile column (256 contiguous
+// bytes per lane) is loaded when the kernel starts -- fetched on demand, one global round trip
+// per tile put ~6 round trips in front of the top block's right-hand side -- and tasks are dealt
+// in the order the chain needs them (source from the bottom, then target from the bottom).  A
+// task waits for z_s, adds its 32-term products to the target's sum (LDS f64 atomic) and counts
+// itself on the target; the chain waits for the count.  All hand-offs go through LDS.
 __global__ __launch_bounds__(512) void chol_backsolve_group(const double* __restrict__ A, const double* __restrict__ y,
                                                              const double* __restrict__ linv, double* __restrict__ z,
                                                              int ld, int kb_lo, int kb_hi) {
-  extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // [GB][CB*CB] inverses | [GB][CB*CB] adjacent tiles
-  __shared__ __attribute__((aligned(16))) double s_z[GB][CB];    // published by the chain
-  __shared__ __attribute__((aligned(16))) double s_y[GB][CB];    // published by the owners
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // [GB][CB*CB] inverses | [GB][BS_ADJ] adjacent tiles
+  __shared__ __attribute__((aligned(16))) double s_z[GB][CB];     // published by the chain
+  __shared__ __attribute__((aligned(16))) double s_fold[GB][CB];  // sum over the tasks of a target
   __shared__ __attribute__((aligned(16))) double s_tmp[CB];
-  __shared__ int s_zready[GB], s_ydone[GB];
+  __shared__ int s_zready[GB], s_cnt[GB];
   double* s_inv = s_dyn;                  // [b][j*CB + i] = (L_bb^-T)[i][j]
-  double* s_adj = s_dyn + GB * CB * CB;   // [b][r*CB + i] = L(row r of block b, column i of block b-1)
+  double* s_adj = s_dyn + GB * CB * CB;   // [b][i*CBP + r] = L(row r of block b, column i of block b-1)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = lane & 31;
   const int nb = kb_hi - kb_lo;
   if (tid < GB) {
     s_zready[tid] = 0;
-    s_ydone[tid] = 0;
+    s_cnt[tid] = 0;
   }
-  for (int e = tid; e < nb * CB * CB / 2; e += 512) {  // 16-byte pieces
-    const int b = e / (CB * CB / 2), w = e % (CB * CB / 2);
-    const int k0 = (kb_lo + b) * CB;
-    *(double2*)(s_inv + b * CB * CB + 2 * w) = *(const double2*)(linv + (size_t)k0 * CB + 2 * w);
-    if (b > 0) {
-      const int c = w % CB, r = 2 * (w / CB);  // column c of block b-1, rows r, r+1 of block b (conflict-free LDS writes)
-      const double2 v = *(const double2*)(A + (size_t)(k0 - CB + c) * ld + k0 + r);
-      s_adj[b * CB * CB + r * CB + c] = v.x;
-      s_adj[b * CB * CB + (r + 1) * CB + c] = v.y;
+  if (tid < GB * CB) (&s_fold[0][0])[tid] = 0.0;
+  // ---- the tasks of this half-wave: rounds 0, 1; task t -> (source sb, target tb), dealt by
+  // source from the bottom, then target from the bottom
+  const int ntask = (nb - 1) * (nb - 2) / 2;
+  int t_sb[2], t_tb[2];
+  double col[2][CB];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    int t = wave == 0 ? ntask : 2 * ((wave - 1) + 7 * r) + (lane >> 5);
+    t_sb[r] = -1, t_tb[r] = 0;
+    if (t < ntask) {
+      int sb = nb - 1;
+      while (t >= sb - 1) {
+        t -= sb - 1;
+        --sb;
+      }
+      t_sb[r] = sb;
+      t_tb[r] = sb - 2 - t;
+      const double* src = A + (size_t)((kb_lo + t_tb[r]) * CB + i) * ld + (kb_lo + sb) * CB;
+#pragma unroll
+      for (int k = 0; k < CB; k += 2) {
+        const double2 v = *(const double2*)(src + k);
+        col[r][k] = v.x;
+        col[r][k + 1] = v.y;
+      }
+    }
+  }
+  double yreg[GB];  // the chain's right-hand sides
+  if (wave == 0) {
+#pragma unroll
+    for (int b = 0; b < GB; ++b) yreg[b] = b < nb ? y[(kb_lo + b) * CB + i] : 0.0;
+  }
+  {
+    // staging, 16-byte pieces, one block per step: every load is issued before the first LDS write
+    // (a rolled loop here waits out one global round trip per block: 8 x ~2 us)
+    double2 vi[GB], va[GB];
+    const int c = tid >> 4, rp = tid & 15;  // adjacent tile: column c of block b-1, rows 2rp, 2rp+1 of block b
+    // (branch-free: steps past the group's last block repeat it)
+#pragma unroll
+    for (int b = 0; b < GB; ++b) {
+      const int k0 = (kb_lo + (b < nb ? b : nb - 1)) * CB;
+      vi[b] = *(const double2*)(linv + (size_t)k0 * CB + 2 * tid);
+      if (b > 0) va[b] = *(const double2*)(A + (size_t)(k0 - CB + c) * ld + k0 + 2 * rp);
+    }
+#pragma unroll
+    for (int b = 0; b < GB; ++b) {
+      const int bq = b < nb ? b : nb - 1;
+      *(double2*)(s_inv + bq * CB * CB + 2 * tid) = vi[b];
+      if (b > 0) *(double2*)(s_adj + bq * BS_ADJ + c * CBP + 2 * rp) = va[b];
     }
   }
   __syncthreads();
   if (wave == 0) {
     // ---- the chain
     double adj = 0.0;
-    for (int b = nb - 1; b >= 0; --b) {
+#pragma unroll
+    for (int bb = GB - 1; bb >= 0; --bb) {
+      if (bb >= nb) continue;
+      const int b = bb;
       const double* inv = s_inv + b * CB * CB + i;
-      lds_wait_ge(&s_ydone[b], 1);
-      const double yv = s_y[b][i] - adj;
+      const int need = nb - 2 - b;
+      if (need > 0) lds_wait_ge(&s_cnt[b], need);
+      const double yv = yreg[bb] - s_fold[b][i] - adj;
       if (lane < CB) s_tmp[i] = yv;
       double z0 = 0.0, z1 = 0.0;
 #pragma unroll
@@ -1598,46 +1648,39 @@ __global__ __launch_bounds__(512) void chol_backsolve_group(const double* __rest
       asm volatile("" ::: "memory");
       *(volatile int*)&s_zready[b] = 1;
       if (b > 0) {
-        const double* ad = s_adj + b * CB * CB + i;
+        const double* ad = s_adj + b * BS_ADJ + i * CBP;
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
         for (int r = 0; r < CB; r += 2) {
           const double2 t = *(const double2*)(&s_z[b][r]);
-          a0 += ad[r * CB] * t.x;
-          a1 += ad[(r + 1) * CB] * t.y;
+          const double2 l = *(const double2*)(ad + r);
+          a0 += l.x * t.x;
+          a1 += l.y * t.y;
         }
         adj = a0 + a1;
       }
     }
     return;
   }
-  // ---- owners: wave w owns the targets b with 1 + b % 7 == w
-  for (int b = nb - 1; b >= 0; --b) {
-    if (1 + b % 7 != wave) continue;
-    const int c0 = (kb_lo + b) * CB;
-    double yacc = y[c0 + i];
-    for (int sblk = nb - 1; sblk >= b + 2; --sblk) {
-      const int r0 = (kb_lo + sblk) * CB;
-      double col[CB];  // column i of tile (sblk, b): fetched before waiting for z
+  // ---- the folds
 #pragma unroll
-      for (int r = 0; r < CB; r += 2) {
-        const double2 v = *(const double2*)(A + (size_t)(c0 + i) * ld + r0 + r);
-        col[r] = v.x;
-        col[r + 1] = v.y;
-      }
-      lds_wait_ge(&s_zready[sblk], 1);
-      double a0 = 0.0, a1 = 0.0;
+  for (int r = 0; r < 2; ++r) {
+    const bool on = t_sb[r] >= 0;
+    const int sb = on ? t_sb[r] : nb - 1, tb = t_tb[r];
+    lds_wait_ge(&s_zready[sb], 1);  // (per-lane flag address: the two half-waves wait for their own source)
+    double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-      for (int r = 0; r < CB; r += 2) {
-        const double2 t = *(const double2*)(&s_z[sblk][r]);
-        a0 += col[r] * t.x;
-        a1 += col[r + 1] * t.y;
-      }
-      yacc -= a0 + a1;
+    for (int k = 0; k < CB; k += 2) {
+      const double2 t = *(const double2*)(&s_z[sb][k]);
+      a0 += col[r][k] * t.x;
+      a1 += col[r][k + 1] * t.y;
     }
-    if (lane < CB) s_y[b][i] = yacc;
-    asm volatile("" ::: "memory");
-    *(volatile int*)&s_ydone[b] = 1;
+    if (on) {
+      __hip_atomic_fetch_add((__attribute__((address_space(3))) double*)&s_fold[tb][i], a0 + a1, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("" ::: "memory");
+      if (i == 0) __hip_atomic_fetch_add((lds_int*)&s_cnt[tb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
   }
 }
 
@@ -2319,7 +2362,7 @@ static int ba_reduced_solve(sfmhip_ba* b) {
     }
   }
   int nbs = 0;
-  constexpr int kBsLds = 2 * GB * CB * CB * (int)sizeof(double);  // 128 KiB of dynamic LDS
+  constexpr int kBsLds = GB * (CB * CB + BS_ADJ) * (int)sizeof(double);  // 132 KiB of dynamic LDS
   static bool bs_attr = false;
   if (!bs_attr) {
     SFM_HIP_TRY(hipFuncSetAttribute((const void*)chol_backsolve_group, hipFuncAttributeMaxDynamicSharedMemorySize, kBsLds));
