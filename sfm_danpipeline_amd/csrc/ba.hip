@@ -2146,7 +2146,10 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   int rc = SFMHIP_OK;
   int *d_optr = nullptr, *d_ocam = nullptr;
   double2* d_oxy = nullptr;
-  b->red_count = b->ssz + 3 * (size_t)b->ld + SC + 64;
+  // [S | g | F^T b | diag | SC scalars + one slot per rank (<= 64) | the step evaluation's 8 sums, a
+  // scratch double, the factorisation's status]: the tail past the all-reduced part is zeroed with
+  // the rest at every linearisation and comes back to the host in the same copy as the scalars
+  b->red_count = b->ssz + 3 * (size_t)b->ld + SC + 64 + 16;
 #define BA_A(ptr, n)                         \
   if (rc == SFMHIP_OK) rc = ba_alloc(b, &(ptr), (size_t)(n))
   BA_A(d_optr, b->np + 1);
@@ -2168,8 +2171,10 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   BA_A(d.z, b->ld);
   BA_A(d.dinv, b->ld);
   BA_A(d.linv, (size_t)b->ld * CB);
-  BA_A(d.red2, 16);
-  BA_A(d.info, 1);
+  if (rc == SFMHIP_OK) {
+    d.red2 = d.red + b->ssz + 3 * (size_t)b->ld + SC + 64;
+    d.info = (int*)(d.red2 + 9);
+  }
   BA_A(b->d_cam_used, n_cam);
   BA_A(b->d_chunks, chunks.size());
   for (int c = 0; c < 8; ++c) BA_A(b->d_chunk_ids[c], ids[c].size());
@@ -2345,7 +2350,6 @@ static int ba_reduced_solve(sfmhip_ba* b) {
   BaDev& d = b->d;
   double* A = d.red;
   double* y = d.red + b->ssz;  // g becomes y = L^-1 g
-  SFM_HIP_TRY(hipMemsetAsync(d.info, 0, sizeof(int), st));
   const int nt = b->ld / CB;
   int nchol = 0;
   {
@@ -2385,7 +2389,6 @@ static int ba_reduced_solve(sfmhip_ba* b) {
 static int ba_step_eval(sfmhip_ba* b, double radius, const sfmhip_ba_opts* o) {
   hipStream_t st = b->ctx->stream;
   BaDev& d = b->d;
-  SFM_HIP_TRY(hipMemsetAsync(d.red2, 0, sizeof(double) * 8, st));
   hipLaunchKernelGGL(ba_cand_cams, dim3((b->nc + 1 + 63) / 64), dim3(64), 0, st, d, b->d_cam_used, b->rank);
   if (b->np)
     hipLaunchKernelGGL(ba_backsub, dim3((b->np + 255) / 256), dim3(256), 0, st, d, radius, o->min_lm_diagonal,
@@ -2413,21 +2416,20 @@ static int ba_read_scalars(sfmhip_ba* b, IterScalars* s, bool with_step) {
   hipStream_t st = b->ctx->stream;
   BaDev& d = b->d;
   const size_t sc_off = b->ssz + 3 * (size_t)b->ld;
-  SFM_HIP_TRY(hipMemcpyAsync(b->h_sc, d.red + sc_off, sizeof(double) * SC, hipMemcpyDeviceToHost, st));
-  if (with_step) {
-    SFM_HIP_TRY(hipMemcpyAsync(b->h_sc + SC, d.red2, sizeof(double) * 8, hipMemcpyDeviceToHost, st));
-    SFM_HIP_TRY(hipMemcpyAsync(b->h_sc + SC + 8, d.info, sizeof(int), hipMemcpyDeviceToHost, st));
-  }
+  // one copy: the linearisation's scalars and (past the per-rank slots) the step evaluation's
+  SFM_HIP_TRY(hipMemcpyAsync(b->h_sc, d.red + sc_off, sizeof(double) * (with_step ? SC + 64 + 16 : SC),
+                             hipMemcpyDeviceToHost, st));
   SFM_HIP_TRY(hipStreamSynchronize(st));
   s->cost = 0.5 * b->h_sc[0];
   s->nfail = b->h_sc[2];
   s->gmax = b->h_sc[3];
   if (with_step) {
-    s->cost_c = 0.5 * b->h_sc[SC + 0];
-    s->mcc = -b->h_sc[SC + 1];
-    s->step_n2 = b->h_sc[SC + 2];
-    s->cand_n2 = b->h_sc[SC + 3];
-    memcpy(&s->info, b->h_sc + SC + 8, sizeof(int));
+    const double* step = b->h_sc + SC + 64;
+    s->cost_c = 0.5 * step[0];
+    s->mcc = -step[1];
+    s->step_n2 = step[2];
+    s->cand_n2 = step[3];
+    memcpy(&s->info, step + 9, sizeof(int));
   }
   return SFMHIP_OK;
 }
