@@ -109,7 +109,10 @@ def test_mixed_signatures_unsorted_and_repeated_cameras(ctx, orc):
     assert np.allclose(c, co, rtol=BA_PARAM_RTOL, atol=1e-9) and np.allclose(p, po, rtol=BA_PARAM_RTOL, atol=1e-9)
 
 
-@pytest.mark.parametrize("nc,npt,k,seed", [(6, 60, 4, 5), (20, 2000, 10, 7), (50, 20000, 10, 777)])
+# reduced system of 6*nc+1 columns in 32-column tiles, padded to an even count: 2, 4, 6, 10, 18 tiles
+# (one, two, three ... two-panel launches; the backward substitution in groups of 8 tiles: 8+2, 8+8+2)
+@pytest.mark.parametrize("nc,npt,k,seed", [(6, 60, 4, 5), (11, 600, 5, 11), (20, 2000, 10, 7), (27, 1500, 6, 27),
+                                           (43, 2500, 6, 43), (86, 4000, 6, 86), (50, 20000, 10, 777)])
 def test_solve_matches_oracle_trajectory(ctx, orc, nc, npt, k, seed):
     pb = synth.ba_problem(nc, npt, k, seed=seed)            # (50, 20000, 10, 777) is BASELINE cfg3
     c, p, f, s = bundle.ba_solve(*_ba_args(pb), opts=bundle.default_opts(max_time_s=0.0), ctx=ctx)
