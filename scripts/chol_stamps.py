@@ -28,6 +28,7 @@ if __name__ == "__main__":
     _lib.SO = SO
     from sfm_danpipeline_amd import bundle, synth
     ctx = _lib.default_context()
+    ctx.set_timing(True)
     pb = synth.ba_problem(200, 100000, 10, seed=777)
     prob = bundle.BaProblem(200, 100000, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
     prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])

@@ -12,5 +12,10 @@ for (nc, npt, k) in ((7, 400, 5), (50, 20000, 10), (200, 100000, 10)):
     for rep in range(3):
         prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
         t0 = time.time(); s = prob.iterate(20); dt = time.time() - t0
-    print(f"{nc}/{npt}: 20 iterations {dt*1e3:.2f} ms -> {20/dt:.1f} it/s; cost {s.initial_cost:.12e} -> {s.final_cost:.12e}; succ {s.successful_steps}; {prob.last_timing()}", flush=True)
+    ctx.set_timing(True)                 # stage breakdown: a second pass with the events on
+    prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+    prob.iterate(20)
+    tm = {k: (round(v * 1e3 / 20, 4) if k != "launches" else v) for k, v in prob.last_timing().items()}
+    ctx.set_timing(False)
+    print(f"{nc}/{npt}: 20 iterations {dt*1e3:.2f} ms -> {20/dt:.1f} it/s; cost {s.initial_cost:.12e} -> {s.final_cost:.12e}; succ {s.successful_steps}; per-iteration ms with stage timing on: {tm}", flush=True)
     prob.close()

@@ -7,6 +7,8 @@ from sfm_danpipeline_amd import synth, bundle, _lib
 
 ctx = _lib.default_context()
 
+ctx.set_timing(True)
+
 def check_problem(nc, npt, k, seed, tag, run=True):
     pb = synth.ba_problem(nc, npt, k, seed=seed)
     args = (pb["cams0"], pb["pts0"], pb["focal0"], pb["obs_cam"], pb["obs_pt"], pb["obs_xy"])

@@ -7,6 +7,8 @@ from oracle import orc
 from sfm_danpipeline_amd import synth, matcher, _lib
 
 ctx = _lib.default_context()
+
+ctx.set_timing(True)
 ok_all = True
 
 def cmp_pair(q, t, norm, tag):

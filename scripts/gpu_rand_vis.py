@@ -4,6 +4,7 @@ import numpy as np
 import torch
 from sfm_danpipeline_amd import synth, bundle, _lib
 ctx = _lib.default_context()
+ctx.set_timing(True)
 pb = synth.ba_problem(200, 20000, 10, seed=3)
 rng = np.random.default_rng(0)
 # random visibility: each point seen by 10 random distinct cameras (keep xy consistent by re-projecting is overkill: timing only)

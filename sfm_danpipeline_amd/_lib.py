@@ -37,7 +37,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
 
 # every symbol include/sfmhip.h declares (tests check the built library exports all of them)
 SYMBOLS = [
-    "sfmhip_init", "sfmhip_init_on_stream", "sfmhip_shutdown", "sfmhip_synchronize", "sfmhip_error_string",
+    "sfmhip_init", "sfmhip_init_on_stream", "sfmhip_shutdown", "sfmhip_synchronize", "sfmhip_set_timing", "sfmhip_error_string",
     "sfmhip_last_hip_error", "sfmhip_version", "sfmhip_match_knn2", "sfmhip_imageset_create",
     "sfmhip_imageset_upload", "sfmhip_imageset_adopt_device", "sfmhip_imageset_prepare_async",
     "sfmhip_imageset_destroy", "sfmhip_matchplan_create", "sfmhip_matchplan_set_pairs", "sfmhip_matchplan_run_async", "sfmhip_matchplan_fetch",
@@ -65,6 +65,7 @@ def lib():
     L.sfmhip_shutdown.argtypes = [vp]
     L.sfmhip_shutdown.restype = None
     L.sfmhip_synchronize.argtypes = [vp]
+    L.sfmhip_set_timing.argtypes = [vp, C.c_int]
     L.sfmhip_error_string.argtypes = [cint]
     L.sfmhip_error_string.restype = C.c_char_p
     L.sfmhip_matchplan_set_pairs.argtypes = [vp, vp, cint]
@@ -124,6 +125,11 @@ class Context:
 
     def synchronize(self):
         check(lib().sfmhip_synchronize(self.h), "sfmhip_synchronize")
+
+    def set_timing(self, enable):
+        """Record hipEvents between the stages of a run (MatchPlan.last_timing / BaProblem.last_timing);
+        off by default: each event costs a few microseconds of stream bubble."""
+        check(lib().sfmhip_set_timing(self.h, int(bool(enable))), "sfmhip_set_timing")
 
     def close(self):
         if self.h:

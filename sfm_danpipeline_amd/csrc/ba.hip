@@ -1896,6 +1896,7 @@ struct sfmhip_ba {
   // timing
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   double t_acc[4] = {0, 0, 0, 0};
+  bool ev_on[5] = {false, false, false, false, false};  // recorded since the last ba_acc_timing
   int launches = 0;
 };
 
@@ -2306,7 +2307,10 @@ static int ba_prepare_scale(sfmhip_ba* b, int jacobi) {
 static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_opts* o, bool add_diag) {
   hipStream_t st = b->ctx->stream;
   BaDev& d = b->d;
-  SFM_HIP_TRY(hipEventRecord(b->ev[0], st));
+  if (b->ctx->timing) {
+    SFM_HIP_TRY(hipEventRecord(b->ev[0], st));
+    b->ev_on[0] = true;
+  }
   SFM_HIP_TRY(hipMemsetAsync(d.red, 0, sizeof(double) * b->red_count, st));
   hipLaunchKernelGGL(ba_cam_prep, dim3((b->nc + 63) / 64), dim3(64), 0, st, d.cams, d.camd, b->nc, 1);
   const double inv_radius = 1.0 / radius;
@@ -2335,9 +2339,15 @@ static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_o
                        o->min_lm_diagonal, o->max_lm_diagonal, b->rank);
   SFM_HIP_TRY(hipGetLastError());
   b->launches += 2 + nl + (b->n_fb > 0);
-  SFM_HIP_TRY(hipEventRecord(b->ev[1], st));
+  if (b->ctx->timing) {
+    SFM_HIP_TRY(hipEventRecord(b->ev[1], st));
+    b->ev_on[1] = true;
+  }
   SFM_TRY(ba_allreduce(b, d.red, b->ssz + 3 * (size_t)b->ld + SC + b->world));
-  SFM_HIP_TRY(hipEventRecord(b->ev[2], st));
+  if (b->ctx->timing) {
+    SFM_HIP_TRY(hipEventRecord(b->ev[2], st));
+    b->ev_on[2] = true;
+  }
   hipLaunchKernelGGL(ba_finalize, dim3(1), dim3(1024), 0, st, d, radius, o->min_lm_diagonal, o->max_lm_diagonal,
                      b->world, add_diag ? 1 : 0);
   SFM_HIP_TRY(hipGetLastError());
@@ -2434,12 +2444,14 @@ static int ba_read_scalars(sfmhip_ba* b, IterScalars* s, bool with_step) {
   return SFMHIP_OK;
 }
 
+// (after the iteration's stream synchronisation; only events recorded since the last call -- timing
+// can be switched on between a linearisation and the iteration that uses it)
 static void ba_acc_timing(sfmhip_ba* b) {
   float ms;
-  if (hipEventElapsedTime(&ms, b->ev[0], b->ev[1]) == hipSuccess) b->t_acc[0] += ms * 1e-3;
-  if (hipEventElapsedTime(&ms, b->ev[1], b->ev[2]) == hipSuccess) b->t_acc[1] += ms * 1e-3;
-  if (hipEventElapsedTime(&ms, b->ev[2], b->ev[3]) == hipSuccess) b->t_acc[2] += ms * 1e-3;
-  if (hipEventElapsedTime(&ms, b->ev[3], b->ev[4]) == hipSuccess) b->t_acc[3] += ms * 1e-3;
+  for (int k = 0; k < 4; ++k)
+    if (b->ev_on[k] && b->ev_on[k + 1] && hipEventElapsedTime(&ms, b->ev[k], b->ev[k + 1]) == hipSuccess)
+      b->t_acc[k] += ms * 1e-3;
+  for (bool& on : b->ev_on) on = false;
 }
 
 // TrustRegionMinimizer::Minimize (Ceres 1.13) + LevenbergMarquardtStrategy, host control loop.
@@ -2475,9 +2487,15 @@ static int ba_one_iteration(sfmhip_ba* b, const sfmhip_ba_opts* o, bool timing_o
   if (!s.have_lin) SFM_TRY(ba_linearize_eliminate(b, s.radius, o, true));
   s.have_lin = false;
   SFM_TRY(ba_reduced_solve(b));
-  SFM_HIP_TRY(hipEventRecord(b->ev[3], st));
+  if (b->ctx->timing) {
+    SFM_HIP_TRY(hipEventRecord(b->ev[3], st));
+    b->ev_on[3] = true;
+  }
   SFM_TRY(ba_step_eval(b, s.radius, o));
-  SFM_HIP_TRY(hipEventRecord(b->ev[4], st));
+  if (b->ctx->timing) {
+    SFM_HIP_TRY(hipEventRecord(b->ev[4], st));
+    b->ev_on[4] = true;
+  }
   SFM_TRY(ba_read_scalars(b, &sc, true));
   ba_acc_timing(b);
   if (s.lin_unread) {

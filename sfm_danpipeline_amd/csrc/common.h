@@ -28,6 +28,7 @@ struct sfmhip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  bool timing = false;  // record hipEvents between the stages of a run (sfmhip_set_timing)
   int n_cu = 0;
   // reusable pinned + device scratch for the one-shot host-pointer entry points
   void* pinned = nullptr;

@@ -56,6 +56,12 @@ extern "C" int sfmhip_synchronize(sfmhip_ctx* ctx) {
   return SFMHIP_OK;
 }
 
+extern "C" int sfmhip_set_timing(sfmhip_ctx* ctx, int enable) {
+  if (!ctx) return SFMHIP_ERR_ARG;
+  ctx->timing = enable != 0;
+  return SFMHIP_OK;
+}
+
 int sfm_ctx_pinned(sfmhip_ctx* ctx, size_t bytes, void** out) {
   if (ctx->pinned_bytes < bytes) {
     if (ctx->pinned) hipHostFree(ctx->pinned);

@@ -835,7 +835,8 @@ extern "C" int sfmhip_imageset_prepare_async(sfmhip_imageset* s) {
     SFM_HIP_TRY(hipStreamSynchronize(st));
     s->imgs_dirty = false;
   }
-  SFM_HIP_TRY(hipEventRecord(s->ev_prep0, st));
+  const bool timing = s->ctx->timing;
+  if (timing) SFM_HIP_TRY(hipEventRecord(s->ev_prep0, st));
   SFM_HIP_TRY(hipMemsetAsync(s->d_nonintegral, 0, s->n_images * sizeof(int), st));
   if (s->total_tiles > 0) {
     switch (s->ks) {
@@ -847,8 +848,8 @@ extern "C" int sfmhip_imageset_prepare_async(sfmhip_imageset* s) {
     }
     SFM_HIP_TRY(hipGetLastError());
   }
-  SFM_HIP_TRY(hipEventRecord(s->ev_prep1, st));
-  s->prep_timed = true;
+  if (timing) SFM_HIP_TRY(hipEventRecord(s->ev_prep1, st));
+  s->prep_timed = timing;
   return SFMHIP_OK;
 }
 
@@ -986,7 +987,8 @@ extern "C" int sfmhip_matchplan_run_async(sfmhip_matchplan* pl, float ratio) {
   sfmhip_imageset* s = pl->set;
   SFM_HIP_TRY(hipSetDevice(s->ctx->device));
   hipStream_t st = s->ctx->stream;
-  SFM_HIP_TRY(hipEventRecord(pl->ev[0], st));
+  const bool timing = s->ctx->timing;
+  if (timing) SFM_HIP_TRY(hipEventRecord(pl->ev[0], st));
   if (pl->n_pairs > 0) {
     SFM_HIP_TRY(hipMemsetAsync(pl->d_fix_count, 0, sizeof(int), st));
     const bool mfma = s->ks != 0;
@@ -1015,14 +1017,14 @@ extern "C" int sfmhip_matchplan_run_async(sfmhip_matchplan* pl, float ratio) {
                          s->d_nonintegral, force_all, s->dim, pl->d_knn, pl->maxq, pl->d_fix_count, pl->d_fix_items);
     SFM_HIP_TRY(hipGetLastError());
   }
-  SFM_HIP_TRY(hipEventRecord(pl->ev[1], st));
+  if (timing) SFM_HIP_TRY(hipEventRecord(pl->ev[1], st));
   if (pl->n_pairs > 0) {
     hipLaunchKernelGGL(compact_kernel, dim3(pl->n_pairs), dim3(256), 0, st, s->d_imgs, pl->d_pairs, pl->d_knn, pl->maxq,
                        ratio, pl->d_counts, pl->d_out_q, pl->d_out_t, pl->d_out_d);
     SFM_HIP_TRY(hipGetLastError());
   }
-  SFM_HIP_TRY(hipEventRecord(pl->ev[2], st));
-  pl->timed = true;
+  if (timing) SFM_HIP_TRY(hipEventRecord(pl->ev[2], st));
+  pl->timed = timing;
   return SFMHIP_OK;
 }
 

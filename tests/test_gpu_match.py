@@ -209,3 +209,25 @@ def test_one_pair_plan_retargeted_over_a_resident_set(ctx):
         assert np.array_equal(d1, od[off[p]:off[p + 1]])
     with pytest.raises(Exception):
         one.set_pairs(pairs[:2])                          # more pairs than the plan was created for
+
+
+def test_stage_timing_is_opt_in(ctx):
+    rng = np.random.default_rng(5)
+    descs = [rng.integers(0, 256, size=(300, 128)).astype(np.float32) for _ in range(3)]
+    iset = matcher.ImageSet(descs, ctx=ctx)
+    plan = matcher.MatchPlan(iset, [(0, 1), (0, 2), (1, 2)])
+    try:
+        ctx.set_timing(False)
+        iset.prepare_async()
+        plan.run_async(0.8)
+        ctx.synchronize()
+        assert all(v == 0 for v in plan.last_timing().values())
+        ctx.set_timing(True)
+        iset.prepare_async()
+        plan.run_async(0.8)
+        tm = plan.last_timing()
+        assert tm["knn_s"] > 0 and tm["prepare_s"] > 0 and tm["compact_s"] > 0
+    finally:
+        ctx.set_timing(False)
+        plan.close()
+        iset.close()
