@@ -32,6 +32,7 @@
 // every rank then solves the same reduced system and back-substitutes its own points.
 #include "common.h"
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -1883,7 +1884,9 @@ struct sfmhip_ba {
   // device storage owned
   std::vector<void*> allocs;
   size_t red_count = 0;
-  double* h_sc = nullptr;  // pinned: scalars read back per iteration
+  double* h_sc = nullptr;  // pinned: scalars read back per iteration (+ the sequence number of ba_publish)
+  double* h_sc_dev = nullptr;  // the same buffer as the device sees it
+  double h_seq = 0.0;
   // comm
   sfmhip_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
@@ -2210,7 +2213,9 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   SFM_HIP_TRY(up(b->d_cxy, cxy.data(), cxy.size() * 8));
   SFM_HIP_TRY(up(b->d_fb_points, fb.data(), fb.size() * 4));
   lap_("uploads");
-  SFM_HIP_TRY(hipHostMalloc((void**)&b->h_sc, sizeof(double) * (SC + 64 + 16), hipHostMallocDefault));
+  SFM_HIP_TRY(hipHostMalloc((void**)&b->h_sc, sizeof(double) * (SC + 64 + 16 + 1), hipHostMallocDefault));
+  SFM_HIP_TRY(hipHostGetDevicePointer((void**)&b->h_sc_dev, b->h_sc, 0));
+  b->h_sc[SC + 64 + 16] = 0.0;
   for (auto& e : b->ev) SFM_HIP_TRY(hipEventCreate(&e));
   b->h_pts_in.assign(3 * (size_t)n_pt, 0.0);
   lap_("pinned + events");
@@ -2422,14 +2427,45 @@ struct IterScalars {
   int info;
 };
 
+// The iteration's scalars (the linearisation's and, past the per-rank slots, the step evaluation's)
+// go to the host in one piece: a one-workgroup kernel writes them into the pinned buffer and then a
+// sequence number behind them; the host spins on the sequence number.  (A blit + hipStreamSynchronize
+// costs ~15 us more per iteration: copy-kernel launch, completion interrupt, wake-up.)
+constexpr int H_SC_N = SC + 64 + 16;
+__global__ __launch_bounds__(128) void ba_publish(const double* __restrict__ src, double* __restrict__ host, double seq) {
+  const int i = threadIdx.x;
+  if (i < H_SC_N) host[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (i == 0) {
+    *(volatile double*)(host + H_SC_N) = seq;
+    __threadfence_system();
+  }
+}
+
 static int ba_read_scalars(sfmhip_ba* b, IterScalars* s, bool with_step) {
   hipStream_t st = b->ctx->stream;
   BaDev& d = b->d;
   const size_t sc_off = b->ssz + 3 * (size_t)b->ld;
-  // one copy: the linearisation's scalars and (past the per-rank slots) the step evaluation's
-  SFM_HIP_TRY(hipMemcpyAsync(b->h_sc, d.red + sc_off, sizeof(double) * (with_step ? SC + 64 + 16 : SC),
-                             hipMemcpyDeviceToHost, st));
-  SFM_HIP_TRY(hipStreamSynchronize(st));
+  b->h_seq += 1.0;
+  hipLaunchKernelGGL(ba_publish, dim3(1), dim3(128), 0, st, d.red + sc_off, b->h_sc_dev, b->h_seq);
+  SFM_HIP_TRY(hipGetLastError());
+  {
+    volatile double* flag = b->h_sc + H_SC_N;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (*flag != b->h_seq) {
+      if ((++spins & 0xFFF) == 0 &&
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.02) {
+        // long-running iteration (or a fault on the stream): fall back to the blocking wait, which
+        // also surfaces asynchronous errors
+        SFM_HIP_TRY(hipStreamSynchronize(st));
+        if (*flag != b->h_seq) return SFMHIP_ERR_HIP;
+        break;
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
   s->cost = 0.5 * b->h_sc[0];
   s->nfail = b->h_sc[2];
   s->gmax = b->h_sc[3];
