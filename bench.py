@@ -52,10 +52,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # (one rank per GPU; the modulo only matters for the functional check of the N>1 path on a
+    # single-GPU box: SFMHIP_BENCH_BACKEND=gloo lets two ranks share device 0, which RCCL refuses)
+    local_rank %= max(torch.cuda.device_count(), 1)
+    backend = os.environ.get("SFMHIP_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(local_rank)
     if world != args.gpus:
