@@ -180,8 +180,9 @@ def test_allreduce_hook_with_a_mirrored_rank(ctx):
                            np.concatenate([pb["obs_pt"], pb["obs_pt"] + 1500]), np.concatenate([pb["obs_xy"]] * 2), ctx=ctx)
     dup.set_params(pb["cams0"], np.concatenate([pb["pts0"]] * 2), pb["focal0"])
     s1 = dup.iterate(4)
-    ld = (6 * 10 + 1 + 31) // 32 * 32                                # row stride of S: dim rounded up to 32
-    assert ld * ld + 3 * ld + 16 + 2 in calls and 8 in calls         # [S|g|F^T b|diag|scalars] and the step scalars
+    ld = (6 * 10 + 1 + 63) // 64 * 64                                # row stride of S: dim rounded up to 64
+    # [packed upper triangle of S | g | F^T b | diag | scalars + rank slots] and the step scalars
+    assert ld * (ld + 1) // 2 + 3 * ld + 16 + 2 in calls and 8 in calls
     assert s1.successful_steps == s2.successful_steps
     assert abs(s1.initial_cost - s2.initial_cost) <= 1e-12 * s1.initial_cost
     assert abs(s1.final_cost - s2.final_cost) <= 1e-9 * s1.final_cost
