@@ -1905,20 +1905,28 @@ struct sfmhip_ba {
 };
 
 // fn(lo, hi) over [0, n) on up to 8 host threads (problem set-up only)
-template <typename F>
-static void host_parallel_for(int n, F fn) {
+static int host_threads(int n) {
   const unsigned hw = std::thread::hardware_concurrency();
-  const int nth = (int)std::max(1u, std::min(8u, hw ? hw : 1u));
-  if (n < 20000 || nth == 1) {
-    fn(0, n);
+  const int nth = (int)std::max(1u, std::min(16u, hw ? hw : 1u));
+  return n < 20000 ? 1 : nth;
+}
+// fn(t, lo, hi): thread t of host_threads(n) takes [lo, hi)
+template <typename F>
+static void host_parallel_for_t(int n, int nth, F fn) {
+  if (nth <= 1) {
+    fn(0, 0, n);
     return;
   }
   std::vector<std::thread> th;
   for (int t = 0; t < nth; ++t) {
     const int lo = (int)((long long)n * t / nth), hi = (int)((long long)n * (t + 1) / nth);
-    th.emplace_back([=, &fn]() { fn(lo, hi); });
+    th.emplace_back([=, &fn]() { fn(t, lo, hi); });
   }
   for (auto& x : th) x.join();
+}
+template <typename F>
+static void host_parallel_for(int n, F fn) {
+  host_parallel_for_t(n, host_threads(n), [&](int, int lo, int hi) { fn(lo, hi); });
 }
 
 template <typename T>
@@ -1982,26 +1990,28 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   for (int p = 0; p < n_pt; ++p) cnt[p + 1] += cnt[p];
   std::vector<int> slot(n_obs), fill(n_pt, 0);
   for (int o = 0; o < n_obs; ++o) slot[cnt[obs_pt[o]] + fill[obs_pt[o]]++] = o;
-  for (int p = 0; p < n_pt; ++p) {  // stable insertion sort: a point has a handful of observations
-    for (int i = cnt[p] + 1; i < cnt[p + 1]; ++i) {
-      const int v = slot[i], cv = obs_cam[v];
-      int j = i - 1;
-      for (; j >= cnt[p] && obs_cam[slot[j]] > cv; --j) slot[j + 1] = slot[j];
-      slot[j + 1] = v;
-    }
-  }
-  // the point's ascending camera list, flat, and a hash of it: the signature sort below compares
+  // per point (a few host threads: every pass over a million observations is a cache-miss chain on
+  // one core): stable insertion sort -- a point has a handful of observations --, then the point's
+  // ascending camera list, flat, and a hash of it: the signature grouping below compares
   // (length, hash) first and walks the lists only on equal hashes
   std::vector<int> scam(n_obs);
   std::vector<uint64_t> sig_hash(n_pt, 0);
-  for (int p = 0; p < n_pt; ++p) {
-    uint64_t h = 1469598103934665603ull;
-    for (int k = cnt[p]; k < cnt[p + 1]; ++k) {
-      scam[k] = obs_cam[slot[k]];
-      h = (h ^ (uint64_t)(uint32_t)scam[k]) * 1099511628211ull;
+  host_parallel_for(n_pt, [&](int plo, int phi) {
+    for (int p = plo; p < phi; ++p) {
+      for (int i = cnt[p] + 1; i < cnt[p + 1]; ++i) {
+        const int v = slot[i], cv = obs_cam[v];
+        int j = i - 1;
+        for (; j >= cnt[p] && obs_cam[slot[j]] > cv; --j) slot[j + 1] = slot[j];
+        slot[j + 1] = v;
+      }
+      uint64_t h = 1469598103934665603ull;
+      for (int k = cnt[p]; k < cnt[p + 1]; ++k) {
+        scam[k] = obs_cam[slot[k]];
+        h = (h ^ (uint64_t)(uint32_t)scam[k]) * 1099511628211ull;
+      }
+      sig_hash[p] = h;
     }
-    sig_hash[p] = h;
-  }
+  });
   lap_("group by point");
   // ---- group the points that have observations by signature (their ascending camera list): a
   //      hash table assigns run ids in order of first appearance, a counting sort makes the runs
@@ -2128,16 +2138,33 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   std::vector<int> cptr(n_cam + 1, 0), cpt(b->no);
   std::vector<double> cxy(2 * (size_t)b->no);
   {
-    for (int k = 0; k < b->no; ++k) cptr[ocam[k] + 1]++;
-    for (int c = 0; c < n_cam; ++c) cptr[c + 1] += cptr[c];
-    std::vector<int> fillc(cptr.begin(), cptr.end() - 1);
-    for (int sp = 0; sp < b->np; ++sp)
-      for (int k = optr[sp]; k < optr[sp + 1]; ++k) {
-        const int dst = fillc[ocam[k]]++;
-        cpt[dst] = sp;
-        cxy[2 * (size_t)dst] = oxy[2 * (size_t)k];
-        cxy[2 * (size_t)dst + 1] = oxy[2 * (size_t)k + 1];
+    // stable counting sort by camera, the sorted points split over the host threads: per-thread
+    // counts, offsets by (camera, thread), then every thread scatters into its own ranges
+    const int nth = host_threads(b->np);
+    std::vector<int> tcnt((size_t)nth * n_cam, 0);
+    host_parallel_for_t(b->np, nth, [&](int t, int lo, int hi) {
+      int* c = tcnt.data() + (size_t)t * n_cam;
+      for (int k = optr[lo]; k < optr[hi]; ++k) c[ocam[k]]++;
+    });
+    for (int c = 0; c < n_cam; ++c) {
+      int run = cptr[c];
+      for (int t = 0; t < nth; ++t) {
+        const int v = tcnt[(size_t)t * n_cam + c];
+        tcnt[(size_t)t * n_cam + c] = run;
+        run += v;
       }
+      cptr[c + 1] = run;
+    }
+    host_parallel_for_t(b->np, nth, [&](int t, int lo, int hi) {
+      int* fillc = tcnt.data() + (size_t)t * n_cam;
+      for (int sp = lo; sp < hi; ++sp)
+        for (int k = optr[sp]; k < optr[sp + 1]; ++k) {
+          const int dst = fillc[ocam[k]]++;
+          cpt[dst] = sp;
+          cxy[2 * (size_t)dst] = oxy[2 * (size_t)k];
+          cxy[2 * (size_t)dst + 1] = oxy[2 * (size_t)k + 1];
+        }
+    });
     b->cam_split = std::max(1, std::min(64, 1024 / std::max(n_cam, 1)));
   }
   lap_("camera-major copy");
