@@ -125,6 +125,20 @@ def test_solve_matches_oracle_trajectory(ctx, orc, nc, npt, k, seed):
     assert abs(f - fo) <= BA_PARAM_RTOL * fo
 
 
+def test_cfg4_sized_reduced_system_matches_oracle_iterates(ctx, orc):
+    """200 cameras (BASELINE cfg4's reduced system: 1201 columns = 38 tiles, 19 two-panel launches,
+    five back-substitution groups) with a fifth of cfg4's points: three LM iterations, iterate by
+    iterate against the oracle."""
+    pb = synth.ba_problem(200, 20000, 10, seed=778)
+    opts = dict(max_time_s=0.0, max_iterations=3)
+    c, p, f, s = bundle.ba_solve(*_ba_args(pb), opts=bundle.default_opts(**opts), ctx=ctx)
+    co, po, fo, so = orc.ba_solve(*_ba_args(pb), opts=orc.default_opts(**opts))
+    assert (s.termination, s.iterations, s.successful_steps) == (so.termination, so.iterations, so.successful_steps)
+    assert abs(s.final_cost - so.final_cost) <= BA_COST_RTOL * so.final_cost
+    assert np.allclose(c, co, rtol=BA_PARAM_RTOL, atol=1e-9) and np.allclose(p, po, rtol=BA_PARAM_RTOL, atol=1e-9)
+    assert abs(f - fo) <= BA_PARAM_RTOL * fo
+
+
 def test_noise_free_scene_converges_to_zero_cost(ctx):
     pb = synth.ba_problem(8, 300, 5, seed=3, noise_px=0.0)
     c, p, f, s = bundle.ba_solve(*_ba_args(pb), ctx=ctx, opts=bundle.default_opts(
