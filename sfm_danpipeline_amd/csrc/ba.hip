@@ -22,8 +22,9 @@
 //                     the panel's Gram matrix on v_mfma_f64_16x16x4_f64; one f64 atomic scatter
 //                     into S per workgroup.
 //   ba_finalize       LM diagonal (clamped squared column norms / radius) onto S, gradient max.
-//   chol_step2/chol_backsolve  dense blocked Cholesky of S (two 32-column panels per launch) with
-//                     the rhs carried as an extra row, then the transposed triangular solve.
+//   chol_step2        dense blocked Cholesky of S (two 32-column panels per launch) with the rhs
+//                     carried as an extra row (y = L^-1 g) and the identity as nt extra tile rows
+//                     (X = L^-T); chol_apply_inverse then forms z = X y.
 //   ba_cand_cams      candidate cameras / focal and their rotation tables.
 //   ba_backsub        per point: back-substitution, model cost change, candidate point,
 //                     candidate cost.
@@ -78,8 +79,7 @@ struct BaDev {
   // to 32 (row stride of S; the padded diagonal is 1, everything else in the padding 0)
   double* red;
   double* z;     // dim solution
-  double* dinv;  // ld: 1 / diag(L)
-  double* linv;  // ld*32: inverse of every diagonal tile of L, transposed ([k][col][row])
+  double* xinv;  // ld x ld, column-major like S's triangle: the identity on entry to the factorisation, L^-T after it
   double* red2;  // 16 scalars of the step evaluation
   int* info;     // cholesky failure flag
 };
@@ -752,6 +752,10 @@ __global__ __launch_bounds__(1024) void ba_finalize(BaDev d, double radius, doub
     gm = fmax(gm, fabs(gF[i] / s));
   }
   for (int i = d.dim + threadIdx.x; i < d.ld; i += blockDim.x) S[(size_t)i * d.ld + i] = 1.0;  // padding
+  for (int i = threadIdx.x; i < d.ld; i += blockDim.x) {
+    d.xinv[(size_t)i * d.ld + i] = 1.0;  // (zeroed with the rest of the buffer at the linearisation)
+    d.z[i] = 0.0;                        // chol_apply_inverse accumulates
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_down(gm, o));
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = gm;
@@ -768,7 +772,9 @@ __global__ __launch_bounds__(1024) void ba_finalize(BaDev d, double radius, doub
 // r >= c, so a column of L is contiguous.  ld = dim rounded up to 64 (identity on the padded
 // diagonal), so no tile needs a bounds check and the 32-column panels come in pairs.  The rhs g
 // is carried as one extra tile row (row 0 of tile row nt, kept in y) so that y = L^-1 g falls out
-// of the factorisation; chol_backsolve then solves L^T z = y.  Right-looking, one launch per two
+// of the factorisation.  The identity rides along the same way as nt more tile rows, X <- X L^-T, so
+// that the backward substitution L^T z = y -- a second 1216-step dependency chain, 80 us of grouped
+// kernels before -- is one product z = X y (chol_apply_inverse, ~6 us).  Right-looking, one launch per two
 // panels (chol_step2 below), no dependency between workgroups inside a launch.
 #ifdef SFM_CHOL_STAMPS
 // diagnostic build only (scripts/chol_stamps.py): s_memtime at the phase boundaries of one panel
@@ -832,8 +838,8 @@ __device__ __forceinline__ int lds_wait_ge(const int* flag, int need) {
 //   the pending panels' rows of block rows a, b and r are staged in LDS once (C2_OFF_PAB/PRW) and
 //   every other fold (D_ba = tile(b,a), T_a = tile(r,a), D_bb, T_b = tile(r,b)) takes its operands
 //   from there; POTRF(D_aa) | Y = D_ba L_aa^-T (= L_ba) and X_a = T_a L_aa^-T trailing it | U2 |
-//   POTRF(D_bb) | X_b = T_b L_bb^-T trailing it.  The owner solves the identity instead of T_a, T_b
-//   (L^-T, kept for the backward substitution) and stores L_aa, L_ba, L_bb, 1/diag.
+//   POTRF(D_bb) | X_b = T_b L_bb^-T trailing it.  The owner has no tile row of its own; it stores L_aa,
+//   L_ba, L_bb.  The row blocks 0..b of X (see chol_step2) are further tile rows like any other.
 // f64 MFMA throughput (16 FMA/clock/SIMD on gfx950, no more than the vector ALU) is what the
 // first half of a launch is short of: the folds are ordered per SIMD by hand (priorities do not
 // order the MFMAs of co-resident waves) and the right column halves of D_bb and T_b, which the
@@ -959,11 +965,11 @@ __device__ __forceinline__ int opaque(int v) {
 // POTRF of a 32x32 tile whose lower sub-tiles are in acc (MFMA layout: [0] = (rows 0-15, cols 0-15),
 // [1] = (rows 16-31, cols 0-15), [2] = (rows 16-31, cols 16-31)), eight block steps of four columns.
 // sD receives L (row-major; above the diagonal: unspecified), sdi 1/diag, *prog the number of finished
-// blocks; gL / gdinv (owner only, else null) the copies in global memory.
+// blocks; gL (owner only, else null) the copy in global memory.
 // late (if any): sub-tile [2] arrives at block step 4 -- *late counts to 1 when another wave has left the
 // part of it that does not depend on this factorisation in the tile's LDS home, to be added.
 __device__ __forceinline__ void chol2_potrf_blocks(v4d (&acc)[3], double* sD, double* sdi, int* prog, bool& bad,
-                                                   int lane, double* gL, int ld, double* gdinv, const int* late) {
+                                                   int lane, double* gL, int ld, const int* late) {
   const int i = lane & 31, j16 = lane & 15, q = lane >> 4;
   double* const rowp = sD + i * CBP;       // row-per-lane view (both half-waves alike)
   double* const op0 = sD + j16 * CBP + q;  // operand / accumulator view, rows 0..15
@@ -1006,7 +1012,6 @@ __device__ __forceinline__ void chol2_potrf_blocks(v4d (&acc)[3], double* sD, do
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (i >= c + k) gL[(size_t)(c + k) * ld + i] = l[k];
-      if (i < 4) gdinv[c + i] = i == 0 ? r[0] : i == 1 ? r[1] : i == 2 ? r[2] : r[3];
     }
     if (b < 7) {
       // fold the block into the columns still to come
@@ -1087,9 +1092,8 @@ __device__ __forceinline__ void chol2_trsm_blocks(v4d (&acc)[4], double* sT, con
 }
 
 template <bool RHS>
-__device__ __forceinline__ void chol2_panel(double* __restrict__ A, double* __restrict__ y, double* __restrict__ dinv,
-                                            double* __restrict__ linv, int ld, int k2, int* __restrict__ info,
-                                            bool owner, int r0, double* sAll) {
+__device__ __forceinline__ void chol2_panel(double* __restrict__ A, double* __restrict__ y, double* __restrict__ Arow,
+                                            int ld, int k2, int* __restrict__ info, bool owner, int r0, double* sAll) {
   constexpr int T = CB * CBP;
   double* const sdi_all = sAll + C2_OFF_SDI;
   double* const sPab = sAll + C2_OFF_PAB;
@@ -1113,7 +1117,7 @@ __device__ __forceinline__ void chol2_panel(double* __restrict__ A, double* __re
   const int dba_s = wave == 6 ? 0 : wave == 10 ? 1 : wave == 7 ? 2 : wave == 9 ? 3 : -1;
   const int ta_s = owner ? -1 : wave == 7 ? 0 : wave == 1 ? 2 : -1;  // folds T_a sub-tiles ta_s, ta_s + 1
   auto own_tile = [&](int cb, int s) -> v4d {  // sub-tile s of the own tile row at columns cb..
-    return RHS ? chol2_tile_rhs(y, cb, s, lane) : chol2_tile(A, ld, r0, cb, s, lane);
+    return RHS ? chol2_tile_rhs(y, cb, s, lane) : chol2_tile(Arow, ld, r0, cb, s, lane);
   };
   if (threadIdx.x < F_COUNT) s_flag[threadIdx.x] = 0;
   __syncthreads();
@@ -1170,7 +1174,7 @@ __device__ __forceinline__ void chol2_panel(double* __restrict__ A, double* __re
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
           const int c = tid + 512 * it, col = c >> 4, pr = c & 15;
-          prw[it] = *(const v2d*)(A + (size_t)(p0 + col) * ld + r0 + 2 * pr);
+          prw[it] = *(const v2d*)(Arow + (size_t)(p0 + col) * ld + r0 + 2 * pr);
         }
       }
     }
@@ -1293,7 +1297,7 @@ __device__ __forceinline__ void chol2_panel(double* __restrict__ A, double* __re
     bool bad = false;
     const int c0 = pass ? b0 : a0;
     chol2_potrf_blocks(acc, sAll + opaque(pass * 3 * T), sdi_all + opaque(pass * CB), s_flag + opaque(F_PROG_A + pass),
-                       bad, lane, owner ? A + (size_t)c0 * ld + c0 : nullptr, ld, dinv + c0,
+                       bad, lane, owner ? A + (size_t)c0 * ld + c0 : nullptr, ld,
                        pass ? &s_flag[F_DBB_HI] : nullptr);
     C2_STAMP(pass ? 4 : 2);
     if (owner && bad && lane == 0) atomicExch(info, c0 + 1);  // the host discards the step
@@ -1364,19 +1368,14 @@ __device__ __forceinline__ void chol2_panel(double* __restrict__ A, double* __re
     }
   } else if (wave == 2 || wave == 6 || wave == 5) {
     // ---- the solves: wave 2 tile (b,a) against L_aa (-> Y), wave 6 the own tile against L_aa, wave 5
-    // the own tile against L_bb after U2 (owner, waves 6 and 5: the identity -> L^-T)
+    // the own tile against L_bb after U2
     const int pass = wave == 5;
     if (pass) __builtin_amdgcn_s_setprio(0);
     else if (wave == 2) __builtin_amdgcn_s_setprio(3);  // Y gates the second factorisation
     else __builtin_amdgcn_s_setprio(2);
-    const bool ident = owner && wave != 2;
+    if (owner && wave != 2) return;  // (the owner has no tile row of its own: rows a, b are the panels)
     v4d acc[4];
-    if (ident) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[s][g] = (s == 0 || s == 3) && j16 == q + 4 * g ? 1.0 : 0.0;
-    } else if (pass) {
+    if (pass) {
       // T_b minus the pending panels ...
       // (the left column half; wave 0 folds the right one when its factorisation is done)
       acc[0] = t0, acc[1] = t1;
@@ -1427,12 +1426,10 @@ __device__ __forceinline__ void chol2_panel(double* __restrict__ A, double* __re
     bool on = lane < CB;
     if (wave == 2) {
       out = A + (size_t)a0 * ld + b0 + i, stride = ld, on = on && owner;
-    } else if (owner) {
-      out = linv + (size_t)c0 * CB + i, stride = CB;  // (L_kk^-T)[i][c], column-major
     } else if (RHS) {
       out = y + c0, stride = 1, on = lane == 0;
     } else {
-      out = A + (size_t)c0 * ld + r0 + i, stride = ld;
+      out = Arow + (size_t)c0 * ld + r0 + i, stride = ld;
     }
     C2_STAMP(wave == 6 ? 6 : wave == 2 ? 11 : 9);
     chol2_trsm_blocks(acc, sAll + opaque(wave == 2 ? 2 * T : T + pass * 3 * T), sAll + opaque(pass * 3 * T),
@@ -1444,39 +1441,60 @@ __device__ __forceinline__ void chol2_panel(double* __restrict__ A, double* __re
 }
 
 __global__ __launch_bounds__(C2_WAVES * 64) void chol_step2(double* __restrict__ A, double* __restrict__ y,
-                                                            double* __restrict__ dinv, double* __restrict__ linv,
-                                                            int ld, int nt, int k2, int* __restrict__ info) {
+                                                            double* __restrict__ X, int ld, int nt, int k2,
+                                                            int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double sAll[];  // C2_LDS_BYTES, see C2_OFF_*
   const int m2 = nt - 2 * k2 - 2;  // tile rows below the two panels (the rhs row comes on top)
   const int npanel = m2 + 2;       // owner, m2 tile rows, rhs
-  if ((int)blockIdx.x < npanel) {
+  const int nx = 2 * k2 + 2;       // rows 0..b of the identity block X (see below) take part as tile rows
+  if ((int)blockIdx.x < npanel + nx) {
+    if ((int)blockIdx.x >= npanel) {
+      // X starts as the identity and rides along as nt more tile rows: X <- X L^-T, i.e. L^-T when the
+      // factorisation ends, and the backward substitution becomes the product z = X y.  (Row block
+      // r' is all zero left of column block r' and untouched until its own panel: rows 0..b here.)
+      chol2_panel<false>(A, y, X, ld, k2, info, false, ((int)blockIdx.x - npanel) * CB, sAll);
+      return;
+    }
     const bool owner = blockIdx.x == 0;
     const int r0 = (2 * k2 + 1 + (int)blockIdx.x) * CB;
     if ((int)blockIdx.x == npanel - 1)
-      chol2_panel<true>(A, y, dinv, linv, ld, k2, info, false, r0, sAll);
+      chol2_panel<true>(A, y, A, ld, k2, info, false, r0, sAll);
     else
-      chol2_panel<false>(A, y, dinv, linv, ld, k2, info, owner, r0, sAll);
+      chol2_panel<false>(A, y, A, ld, k2, info, owner, r0, sAll);
     return;
   }
   // ---- trailing tiles (k2 >= 1), one wave each (its four sub-tiles share the operands): tile row
-  // ti_rel in [0, m2] (m2 = rhs) has min(ti_rel + 1, m2) tiles
+  // ti_rel in [0, m2] (m2 = rhs) has min(ti_rel + 1, m2) tiles; then the tiles of X: rows 0..a-1 (the
+  // rows that are nonzero in the pending panels) x the m2 column blocks right of the panels
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (wave >= 4) return;  // one wave per SIMD: a tile is 64 MFMAs
-  int t = ((int)blockIdx.x - npanel) * 4 + wave;
-  if (t >= m2 * (m2 + 1) / 2 + m2) return;
+  int t = ((int)blockIdx.x - npanel - nx) * 4 + wave;
+  const int ntrail = m2 * (m2 + 1) / 2 + m2;
+  if (t >= ntrail + 2 * k2 * m2) return;
   int ti_rel = 0;
-  while (true) {
-    const int w = ti_rel < m2 ? ti_rel + 1 : m2;
-    if (t < w) break;
-    t -= w;
-    ++ti_rel;
+  const double* Rrow = A;  // the tile's row space
+  double* Wrow = A;
+  int rb_x = -1;
+  if (t >= ntrail) {
+    t -= ntrail;
+    rb_x = (t / m2) * CB;
+    t %= m2;
+    Rrow = X;
+    Wrow = X;
+  } else {
+    while (true) {
+      const int w = ti_rel < m2 ? ti_rel + 1 : m2;
+      if (t < w) break;
+      t -= w;
+      ++ti_rel;
+    }
   }
   const int c0 = (2 * k2 + 2) * CB;
-  const int rb = c0 + ti_rel * CB, cb = c0 + t * CB, p0 = (2 * k2 - 2) * CB;
+  const int rb = rb_x >= 0 ? rb_x : c0 + ti_rel * CB, cb = c0 + t * CB, p0 = (2 * k2 - 2) * CB;
   const int j16 = lane & 15, q = lane >> 4;
   double a[2][16], b[2][16];
   v4d acc[4];  // [2 * ci + ri]
-  if (ti_rel == m2) {
+  if (rb_x < 0 && ti_rel == m2) {
     // the rhs row: y[cb..] -= y[pending] L(cb.., pending)^T, tile row 0 only
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
@@ -1506,14 +1524,14 @@ __global__ __launch_bounds__(C2_WAVES * 64) void chol_step2(double* __restrict__
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     ld_strided<16>(a[h], A + (size_t)(p0 + q) * ld + cb + 16 * h + j16, st);
-    ld_strided<16>(b[h], A + (size_t)(p0 + q) * ld + rb + 16 * h + j16, st);
+    ld_strided<16>(b[h], Rrow + (size_t)(p0 + q) * ld + rb + 16 * h + j16, st);
   }
 #pragma unroll
   for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
     for (int ri = 0; ri < 2; ++ri) {
       double t4[4];
-      ld_strided<4>(t4, A + (size_t)(cb + 16 * ci + q) * ld + rb + 16 * ri + j16, st);
+      ld_strided<4>(t4, Rrow + (size_t)(cb + 16 * ci + q) * ld + rb + 16 * ri + j16, st);
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[2 * ci + ri][g] = t4[g];
     }
@@ -1528,7 +1546,7 @@ __global__ __launch_bounds__(C2_WAVES * 64) void chol_step2(double* __restrict__
   for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
     for (int ri = 0; ri < 2; ++ri) {
-      gbl_double* pt = (gbl_double*)(A + (size_t)(cb + 16 * ci + q) * ld + rb + 16 * ri + j16);
+      gbl_double* pt = (gbl_double*)(Wrow + (size_t)(cb + 16 * ci + q) * ld + rb + 16 * ri + j16);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         *pt = acc[2 * ci + ri][g];
@@ -1539,177 +1557,28 @@ __global__ __launch_bounds__(C2_WAVES * 64) void chol_step2(double* __restrict__
 }
 #undef CHOL_MFMA
 
-// L^T z = y.  U = L^T is upper triangular and row-major in this storage (U[i][j] = A[i*ld + j]),
-// so row i of U is contiguous.  Block rows are taken in groups of GB (256 rows) from the bottom:
-//   chol_backsolve_group  one workgroup of 8 waves per group: a chain wave (32x32 products with
-//                         the diagonal tiles' inverses) and seven owner waves that fold finished
-//                         blocks into the ones further up (see the kernel);
-//   chol_backsolve_gemv   folds the group's solution into y of every row above the group, one
-//                         wave per row (coalesced 2 KB row segments), all CUs.
-// A single workgroup pulling the whole triangle (5.8 MB at cfg4) is bound by one CU's load
-// bandwidth; the grouping leaves it 1/GB of the triangle.
-constexpr int GB = 8;
-constexpr int BS_ADJ = CB * CBP;  // an adjacent tile in LDS, as in global memory ([column][row]) with the padded pitch
-
-// One workgroup of 8 waves per group of GB block rows.  All waves first stage what the chain
-// will need -- the inverses of the group's diagonal tiles and the tiles right above the diagonal,
-// 16 KB per block -- into LDS.  Wave 0 then is the dependency chain: for each block from the
-// bottom, z_b = L_bb^-T y_b (a 32x32 product) and the fold of z_b into the block right above.
-// Waves 1..7 fold the solutions of the blocks two or more below into the targets: one task per
-// tile (source block s, target block b <= s-2), a half-wave each (lane = column of the tile =
-// row of the target), at most four tasks per wave.  Every task's tile column (256 contiguous
-// bytes per lane) is loaded when the kernel starts -- fetched on demand, one global round trip
-// per tile put ~6 round trips in front of the top block's right-hand side -- and tasks are dealt
-// in the order the chain needs them (source from the bottom, then target from the bottom).  A
-// task waits for z_s, adds its 32-term products to the target's sum (LDS f64 atomic) and counts
-// itself on the target; the chain waits for the count.  All hand-offs go through LDS.
-__global__ __launch_bounds__(512) void chol_backsolve_group(const double* __restrict__ A, const double* __restrict__ y,
-                                                             const double* __restrict__ linv, double* __restrict__ z,
-                                                             int ld, int kb_lo, int kb_hi) {
-  extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // [GB][CB*CB] inverses | [GB][BS_ADJ] adjacent tiles
-  __shared__ __attribute__((aligned(16))) double s_z[GB][CB];     // published by the chain
-  __shared__ __attribute__((aligned(16))) double s_fold[GB][CB];  // sum over the tasks of a target
-  __shared__ __attribute__((aligned(16))) double s_tmp[CB];
-  __shared__ int s_zready[GB], s_cnt[GB];
-  double* s_inv = s_dyn;                  // [b][j*CB + i] = (L_bb^-T)[i][j]
-  double* s_adj = s_dyn + GB * CB * CB;   // [b][i*CBP + r] = L(row r of block b, column i of block b-1)
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int i = lane & 31;
-  const int nb = kb_hi - kb_lo;
-  if (tid < GB) {
-    s_zready[tid] = 0;
-    s_cnt[tid] = 0;
-  }
-  if (tid < GB * CB) (&s_fold[0][0])[tid] = 0.0;
-  // ---- the tasks of this half-wave: rounds 0, 1; task t -> (source sb, target tb), dealt by
-  // source from the bottom, then target from the bottom
-  const int ntask = (nb - 1) * (nb - 2) / 2;
-  int t_sb[2], t_tb[2];
-  double col[2][CB];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    int t = wave == 0 ? ntask : 2 * ((wave - 1) + 7 * r) + (lane >> 5);
-    t_sb[r] = -1, t_tb[r] = 0;
-    if (t < ntask) {
-      int sb = nb - 1;
-      while (t >= sb - 1) {
-        t -= sb - 1;
-        --sb;
-      }
-      t_sb[r] = sb;
-      t_tb[r] = sb - 2 - t;
-      const double* src = A + (size_t)((kb_lo + t_tb[r]) * CB + i) * ld + (kb_lo + sb) * CB;
-#pragma unroll
-      for (int k = 0; k < CB; k += 2) {
-        const double2 v = *(const double2*)(src + k);
-        col[r][k] = v.x;
-        col[r][k + 1] = v.y;
-      }
-    }
-  }
-  double yreg[GB];  // the chain's right-hand sides
-  if (wave == 0) {
-#pragma unroll
-    for (int b = 0; b < GB; ++b) yreg[b] = b < nb ? y[(kb_lo + b) * CB + i] : 0.0;
-  }
-  {
-    // staging, 16-byte pieces, one block per step: every load is issued before the first LDS write
-    // (a rolled loop here waits out one global round trip per block: 8 x ~2 us)
-    double2 vi[GB], va[GB];
-    const int c = tid >> 4, rp = tid & 15;  // adjacent tile: column c of block b-1, rows 2rp, 2rp+1 of block b
-    // (branch-free: steps past the group's last block repeat it)
-#pragma unroll
-    for (int b = 0; b < GB; ++b) {
-      const int k0 = (kb_lo + (b < nb ? b : nb - 1)) * CB;
-      vi[b] = *(const double2*)(linv + (size_t)k0 * CB + 2 * tid);
-      if (b > 0) va[b] = *(const double2*)(A + (size_t)(k0 - CB + c) * ld + k0 + 2 * rp);
-    }
-#pragma unroll
-    for (int b = 0; b < GB; ++b) {
-      const int bq = b < nb ? b : nb - 1;
-      *(double2*)(s_inv + bq * CB * CB + 2 * tid) = vi[b];
-      if (b > 0) *(double2*)(s_adj + bq * BS_ADJ + c * CBP + 2 * rp) = va[b];
-    }
-  }
-  __syncthreads();
-  if (wave == 0) {
-    // ---- the chain
-    double adj = 0.0;
-#pragma unroll
-    for (int bb = GB - 1; bb >= 0; --bb) {
-      if (bb >= nb) continue;
-      const int b = bb;
-      const double* inv = s_inv + b * CB * CB + i;
-      const int need = nb - 2 - b;
-      if (need > 0) lds_wait_ge(&s_cnt[b], need);
-      const double yv = yreg[bb] - s_fold[b][i] - adj;
-      if (lane < CB) s_tmp[i] = yv;
-      double z0 = 0.0, z1 = 0.0;
-#pragma unroll
-      for (int j = 0; j < CB; j += 2) {
-        const double2 t = *(const double2*)(s_tmp + j);
-        z0 += inv[j * CB] * t.x;
-        z1 += inv[(j + 1) * CB] * t.y;
-      }
-      const double zi = z0 + z1;
-      if (lane < CB) {
-        s_z[b][i] = zi;
-        z[(size_t)(kb_lo + b) * CB + i] = zi;
-      }
-      asm volatile("" ::: "memory");
-      *(volatile int*)&s_zready[b] = 1;
-      if (b > 0) {
-        const double* ad = s_adj + b * BS_ADJ + i * CBP;
-        double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-        for (int r = 0; r < CB; r += 2) {
-          const double2 t = *(const double2*)(&s_z[b][r]);
-          const double2 l = *(const double2*)(ad + r);
-          a0 += l.x * t.x;
-          a1 += l.y * t.y;
-        }
-        adj = a0 + a1;
-      }
-    }
-    return;
-  }
-  // ---- the folds
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const bool on = t_sb[r] >= 0;
-    const int sb = on ? t_sb[r] : nb - 1, tb = t_tb[r];
-    lds_wait_ge(&s_zready[sb], 1);  // (per-lane flag address: the two half-waves wait for their own source)
-    double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-    for (int k = 0; k < CB; k += 2) {
-      const double2 t = *(const double2*)(&s_z[sb][k]);
-      a0 += col[r][k] * t.x;
-      a1 += col[r][k + 1] * t.y;
-    }
-    if (on) {
-      __hip_atomic_fetch_add((__attribute__((address_space(3))) double*)&s_fold[tb][i], a0 + a1, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_WORKGROUP);
-      asm volatile("" ::: "memory");
-      if (i == 0) __hip_atomic_fetch_add((lds_int*)&s_cnt[tb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-  }
-}
-
-// y[i] -= sum_{j in [c_lo, c_hi)} U[i][j] z[j] for the rows above the group, one wave per row
-__global__ __launch_bounds__(256) void chol_backsolve_gemv(const double* __restrict__ A, double* __restrict__ y,
-                                                           const double* __restrict__ z, int ld, int c_lo, int c_hi) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= c_lo) return;
-  const double* ui = A + (size_t)row * ld;
+// z = L^-T y = X y.  X (column-major like A: X(i, j) = X[j*ld + i]) is upper triangular by 32x32
+// tiles; one workgroup per (tile row, group of XG column tiles): thread (row i of the tile, column
+// slice) sums its columns, the eight slices are added through LDS, one atomic per row and workgroup.
+constexpr int XG = 4;
+__global__ __launch_bounds__(256) void chol_apply_inverse(const double* __restrict__ X, const double* __restrict__ y,
+                                                         double* __restrict__ z, int ld, int nt) {
+  __shared__ double s_part[8][CB];
+  const int tr = blockIdx.x, cg = blockIdx.y;
+  const int c_lo = std::max(tr, cg * XG) * CB, c_hi = std::min(nt, (cg + 1) * XG) * CB;
+  if (c_lo >= c_hi) return;
+  const int i = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const double* xr = X + tr * CB + i;
   double acc = 0.0;
-  for (int j = c_lo + 2 * lane; j < c_hi; j += 128) {
-    const double2 uu = *(const double2*)(ui + j);
-    const double2 zz = *(const double2*)(z + j);
-    acc += uu.x * zz.x + uu.y * zz.y;
-  }
+  for (int j = c_lo + sl; j < c_hi; j += 8) acc += xr[(size_t)j * ld] * y[j];
+  s_part[sl][i] = acc;
+  __syncthreads();
+  if (sl == 0) {
+    double v = 0.0;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  if (lane == 0) y[row] -= acc;
+    for (int k = 0; k < 8; ++k) v += s_part[k][i];
+    atomic_add_f64(z + tr * CB + i, v);
+  }
 }
 
 // ---------------------------------------------------------------- step application
@@ -2191,7 +2060,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   // [S | g | F^T b | diag | SC scalars + one slot per rank (<= 64) | the step evaluation's 8 sums, a
   // scratch double, the factorisation's status]: the tail past the all-reduced part is zeroed with
   // the rest at every linearisation and comes back to the host in the same copy as the scalars
-  b->red_count = b->ssz + 3 * (size_t)b->ld + SC + 64 + 16;
+  b->red_count = b->ssz + 3 * (size_t)b->ld + SC + 64 + 16 + b->ssz;  // ... | X (chol_step2), zeroed with the rest
 #define BA_A(ptr, n)                         \
   if (rc == SFMHIP_OK) rc = ba_alloc(b, &(ptr), (size_t)(n))
   BA_A(d_optr, b->np + 1);
@@ -2211,11 +2080,10 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   BA_A(d.diag, b->ld);
   BA_A(d.red, b->red_count);
   BA_A(d.z, b->ld);
-  BA_A(d.dinv, b->ld);
-  BA_A(d.linv, (size_t)b->ld * CB);
   if (rc == SFMHIP_OK) {
     d.red2 = d.red + b->ssz + 3 * (size_t)b->ld + SC + 64;
     d.info = (int*)(d.red2 + 9);
+    d.xinv = d.red2 + 16;
   }
   BA_A(b->d_cam_used, n_cam);
   BA_A(b->d_chunks, chunks.size());
@@ -2448,27 +2316,15 @@ static int ba_reduced_solve(sfmhip_ba* b) {
     }
     for (int k2 = 0; 2 * k2 < nt; ++k2, ++nchol) {
       const int m2 = nt - 2 * k2 - 2;
-      const int ntrail = k2 == 0 ? 0 : m2 * (m2 + 1) / 2 + m2;  // launch 0 has no pending update
-      hipLaunchKernelGGL(chol_step2, dim3(m2 + 2 + (ntrail + 3) / 4), dim3(C2_WAVES * 64), C2_LDS_BYTES, st, A, y, d.dinv,
-                         d.linv, d.ld, nt, k2, d.info);
+      // launch 0 has no pending update; later launches: the tiles right of the panels, and those of X
+      const int ntrail = k2 == 0 ? 0 : m2 * (m2 + 1) / 2 + m2 + 2 * k2 * m2;
+      hipLaunchKernelGGL(chol_step2, dim3(m2 + 2 + 2 * k2 + 2 + (ntrail + 3) / 4), dim3(C2_WAVES * 64), C2_LDS_BYTES, st, A,
+                         y, d.xinv, d.ld, nt, k2, d.info);
     }
   }
-  int nbs = 0;
-  constexpr int kBsLds = GB * (CB * CB + BS_ADJ) * (int)sizeof(double);  // 132 KiB of dynamic LDS
-  static bool bs_attr = false;
-  if (!bs_attr) {
-    SFM_HIP_TRY(hipFuncSetAttribute((const void*)chol_backsolve_group, hipFuncAttributeMaxDynamicSharedMemorySize, kBsLds));
-    bs_attr = true;
-  }
-  for (int hi = nt; hi > 0; hi -= GB) {
-    const int lo = std::max(0, hi - GB);
-    hipLaunchKernelGGL(chol_backsolve_group, dim3(1), dim3(512), kBsLds, st, A, y, d.linv, d.z, d.ld, lo, hi);
-    ++nbs;
-    if (lo > 0) {
-      hipLaunchKernelGGL(chol_backsolve_gemv, dim3((lo * CB + 3) / 4), dim3(256), 0, st, A, y, d.z, d.ld, lo * CB, hi * CB);
-      ++nbs;
-    }
-  }
+  // z = L^-T y = X y
+  hipLaunchKernelGGL(chol_apply_inverse, dim3(nt, (nt + XG - 1) / XG), dim3(256), 0, st, d.xinv, y, d.z, d.ld, nt);
+  const int nbs = 1;
   SFM_HIP_TRY(hipGetLastError());
   b->launches += nchol + nbs;
   return SFMHIP_OK;
