@@ -44,6 +44,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=96, help="pairs of cfg2 timed on the host cores")
     ap.add_argument("--cpu-ba-iters", type=int, default=8)
+    ap.add_argument("--match-streams", type=int, default=1, choices=(1, 2),
+                    help="2: consecutive batches alternate between two resident buffers on two HIP streams "
+                         "(+5 %% pairs/s; per-kernel durations of overlapping launches are then not comparable "
+                         "with the single-launch figure the roofline uses, hence not the default)")
     args = ap.parse_args()
 
     import torch
@@ -85,10 +89,10 @@ def main():
     n_img, n_feat, dim = 50, 2000, 128
     imgs = synth.sift_image_set(n_img, n_feat, dim, seed=1234 + 1000 * rank)   # rank r: its own image set
     pairs = synth.all_pairs(n_img)
-    # Consecutive batches alternate between two resident buffers on two HIP streams (two contexts): the
-    # tail of one sweep and the small prepare / compaction kernels of the next overlap.  Every step is
-    # still one full prepare + knn + ratio/compaction pass over one batch of 1225 pairs.
-    N_STREAMS = 2
+    # --match-streams 2: consecutive batches alternate between two resident buffers on two HIP streams
+    # (two contexts): the tail of one sweep and the small prepare / compaction kernels of the next
+    # overlap.  Every step is one full prepare + knn + ratio/compaction pass over one batch of 1225 pairs.
+    N_STREAMS = args.match_streams
     side_stream = torch.cuda.Stream(dev)
     ctxs = [ctx, _lib.Context(local_rank, stream=side_stream.cuda_stream)]
     isets, plans, d_keep = [], [], []
@@ -221,7 +225,7 @@ def main():
                    "backsub_cost_ms": round(1e3 * ba_t["backsub_s"] / args.steps, 4),
                    "launches_per_iter": round(ba_t["launches"] / max(args.steps, 1), 1),
                    "note": "latency-bound: the 1216-column dependency chain of the reduced system's Cholesky (19 "
-                           "two-panel launches) and its back substitution dominate the iteration (DESIGN.md section 3)"}
+                           "two-panel launches) dominates the iteration (DESIGN.md section 3)"}
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only)
     cpu_baseline = None
@@ -268,8 +272,8 @@ def main():
                        "ba_points_per_gpu": int(n_pt_l), "ba_obs_per_gpu": int(n_obs_l),
                        "ba_cost": [ba_sum.initial_cost, ba_sum.final_cost],
                        "match_streams": N_STREAMS,
-                       "parallelism": f"pairs x{world} (weak; consecutive batches alternate between {N_STREAMS} HIP "
-                                      f"streams per GPU), BA points/{world} + all-reduce"},
+                       "parallelism": f"pairs x{world} (weak" + (f"; consecutive batches alternate between {N_STREAMS} HIP "
+                                      "streams per GPU" if N_STREAMS > 1 else "") + f"), BA points/{world} + all-reduce"},
             "roofline": roofline, "roofline_ba": roofline_ba, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
