@@ -70,7 +70,8 @@ __device__ __forceinline__ unsigned umax_(unsigned a, unsigned b) { return a > b
 // ---------------------------------------------------------------- prepare
 template <int KS, int KIND>
 __global__ void prepare_kernel(const ImgDev* __restrict__ imgs, const int* __restrict__ tile_img,
-                               const int* __restrict__ tile_first, int dim, int* __restrict__ nonintegral) {
+                               const int* __restrict__ tile_first, int dim, int* __restrict__ nonintegral,
+                               int gen) {
   constexpr int NC = 2 * KS;
   constexpr int RB = 32 * KS;
   const int img = tile_img[blockIdx.x];
@@ -169,7 +170,7 @@ __global__ void prepare_kernel(const ImgDev* __restrict__ imgs, const int* __res
     I.base[row] = b;
     I.nq[row] = valid ? n2 : 0;
   }
-  if (KIND == KIND_F32_L2 && !ok) nonintegral[img] = 1;
+  if (KIND == KIND_F32_L2 && !ok) nonintegral[img] = gen;  // (stamped with the prepare pass: no clearing between passes)
 }
 
 // ---------------------------------------------------------------- MFMA k-NN kernel
@@ -216,7 +217,7 @@ template <int KS, int MODE, int SR>
 __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const ImgDev* __restrict__ imgs,
                                                           const int2* __restrict__ pairs,
                                                           const WorkItem* __restrict__ items,
-                                                          const int* __restrict__ nonintegral,
+                                                          const int* __restrict__ nonintegral, int gen,
                                                           int4* __restrict__ knn, int maxq,
                                                           int* __restrict__ fix_count,
                                                           int2* __restrict__ fix_items) {
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const ImgDev* __restri
 
   const WorkItem it = items[blockIdx.x];
   const int2 pr = pairs[it.pair];
-  if (nonintegral[pr.x] | nonintegral[pr.y]) return;  // left to the exact kernel
+  if ((nonintegral[pr.x] == gen) | (nonintegral[pr.y] == gen)) return;  // left to the exact kernel
   const ImgDev Q = imgs[pr.x];
   const ImgDev T = imgs[pr.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -602,7 +603,7 @@ __device__ void exact_query(const ImgDev& Q, const ImgDev& T, int q, int dim, in
 template <int KIND>
 __global__ __launch_bounds__(256) void knn_exact_kernel(const ImgDev* __restrict__ imgs,
                                                         const int2* __restrict__ pairs, int n_pairs,
-                                                        const int* __restrict__ nonintegral,
+                                                        const int* __restrict__ nonintegral, int gen,
                                                         int force_all, int dim,
                                                         int4* __restrict__ knn, int maxq,
                                                         const int* __restrict__ fix_count,
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(256) void knn_exact_kernel(const ImgDev* __restrict
   const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
   for (int p = blockIdx.x; p < n_pairs; p += gridDim.x) {
     const int2 pr = pairs[p];
-    if (!(force_all | nonintegral[pr.x] | nonintegral[pr.y])) continue;
+    if (!(force_all | (nonintegral[pr.x] == gen) | (nonintegral[pr.y] == gen))) continue;
     const ImgDev Q = imgs[pr.x], T = imgs[pr.y];
     for (int q = wave; q < Q.n_rows; q += wpb) exact_query<KIND>(Q, T, q, dim, &knn[(size_t)p * maxq + q]);
   }
@@ -632,10 +633,13 @@ __global__ __launch_bounds__(256) void compact_kernel(const ImgDev* __restrict__
                                                       const int4* __restrict__ knn, int maxq,
                                                       float ratio, int* __restrict__ counts,
                                                       int* __restrict__ out_q, int* __restrict__ out_t,
-                                                      float* __restrict__ out_d) {
+                                                      float* __restrict__ out_d, int* __restrict__ fix_count) {
   __shared__ int wsum[4];
   __shared__ int running;
   const int p = blockIdx.x;
+  // the fix-up list of this run has been consumed (knn_exact_kernel ran before this kernel): clear
+  // its counter for the plan's next run here instead of with a memset node in front of every run
+  if (blockIdx.x == 0 && threadIdx.x == 0) *fix_count = 0;
   const int2 pr = pairs[p];
   const int nq = imgs[pr.x].n_rows, nt = imgs[pr.y].n_rows;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -686,7 +690,8 @@ struct sfmhip_imageset {
   int* d_nq = nullptr;
   int* d_tile_img = nullptr;
   int* d_tile_first = nullptr;
-  int* d_nonintegral = nullptr;
+  int* d_nonintegral = nullptr;  // per image: the number (gen) of the prepare pass that found non-integer f32 values
+  int gen = 0;
   int total_tiles = 0, maxq = 0;
   bool imgs_dirty = true;
   hipEvent_t ev_prep0 = nullptr, ev_prep1 = nullptr;
@@ -769,7 +774,7 @@ extern "C" int sfmhip_imageset_create(sfmhip_ctx* ctx, int n_images, const int32
   }
   SFM_HIP_TRY(hipMemcpy(s->d_tile_img, tile_img.data(), tile_img.size() * sizeof(int), hipMemcpyHostToDevice));
   SFM_HIP_TRY(hipMemcpy(s->d_tile_first, tile_first.data(), tile_first.size() * sizeof(int), hipMemcpyHostToDevice));
-  SFM_HIP_TRY(hipMemset(s->d_nonintegral, 0, n_images * sizeof(int)));
+  SFM_HIP_TRY(hipMemset(s->d_nonintegral, 0xFF, n_images * sizeof(int)));  // -1: set by no prepare pass
   s->h_imgs.resize(n_images);
   s->owned_raw.assign(n_images, nullptr);
   size_t off = 0;
@@ -817,11 +822,11 @@ static void launch_prepare(sfmhip_imageset* s) {
   const dim3 grid(s->total_tiles), block(32 * 2 * KS);
   hipStream_t st = s->ctx->stream;
   if (s->kind == KIND_F32_L2)
-    hipLaunchKernelGGL((prepare_kernel<KS, KIND_F32_L2>), grid, block, 0, st, s->d_imgs, s->d_tile_img, s->d_tile_first, s->dim, s->d_nonintegral);
+    hipLaunchKernelGGL((prepare_kernel<KS, KIND_F32_L2>), grid, block, 0, st, s->d_imgs, s->d_tile_img, s->d_tile_first, s->dim, s->d_nonintegral, s->gen);
   else if (s->kind == KIND_U8_L2)
-    hipLaunchKernelGGL((prepare_kernel<KS, KIND_U8_L2>), grid, block, 0, st, s->d_imgs, s->d_tile_img, s->d_tile_first, s->dim, s->d_nonintegral);
+    hipLaunchKernelGGL((prepare_kernel<KS, KIND_U8_L2>), grid, block, 0, st, s->d_imgs, s->d_tile_img, s->d_tile_first, s->dim, s->d_nonintegral, s->gen);
   else
-    hipLaunchKernelGGL((prepare_kernel<KS, KIND_U8_HAMMING>), grid, block, 0, st, s->d_imgs, s->d_tile_img, s->d_tile_first, s->dim, s->d_nonintegral);
+    hipLaunchKernelGGL((prepare_kernel<KS, KIND_U8_HAMMING>), grid, block, 0, st, s->d_imgs, s->d_tile_img, s->d_tile_first, s->dim, s->d_nonintegral, s->gen);
 }
 
 extern "C" int sfmhip_imageset_prepare_async(sfmhip_imageset* s) {
@@ -837,7 +842,7 @@ extern "C" int sfmhip_imageset_prepare_async(sfmhip_imageset* s) {
   }
   const bool timing = s->ctx->timing;
   if (timing) SFM_HIP_TRY(hipEventRecord(s->ev_prep0, st));
-  SFM_HIP_TRY(hipMemsetAsync(s->d_nonintegral, 0, s->n_images * sizeof(int), st));
+  ++s->gen;  // the non-integral flags carry the number of the pass that set them
   if (s->total_tiles > 0) {
     switch (s->ks) {
       case 1: launch_prepare<1>(s); break;
@@ -938,6 +943,7 @@ extern "C" int sfmhip_matchplan_create(sfmhip_imageset* s, const int32_t* pairs,
   if (n_pairs) SFM_HIP_TRY(hipMemcpy(pl->d_pairs, pairs, sizeof(int2) * n_pairs, hipMemcpyHostToDevice));
   if (!items.empty()) SFM_HIP_TRY(hipMemcpy(pl->d_items, items.data(), sizeof(WorkItem) * items.size(), hipMemcpyHostToDevice));
   SFM_HIP_TRY(hipMemset(pl->d_counts, 0, sizeof(int) * pl->cap_pairs));
+  SFM_HIP_TRY(hipMemset(pl->d_fix_count, 0, sizeof(int)));  // (every run leaves it cleared: compact_kernel)
   for (auto& e : pl->ev) SFM_HIP_TRY(hipEventCreate(&e));
   *out = pl;
   return SFMHIP_OK;
@@ -977,7 +983,7 @@ static int launch_knn(sfmhip_matchplan* pl) {
     attr_set = true;
   }
   hipLaunchKernelGGL((knn_mfma_kernel<KS, MODE, SR>), dim3(pl->n_items), dim3(256), LDS, s->ctx->stream, s->d_imgs,
-                     pl->d_pairs, pl->d_items, s->d_nonintegral, pl->d_knn, pl->maxq, pl->d_fix_count, pl->d_fix_items);
+                     pl->d_pairs, pl->d_items, s->d_nonintegral, s->gen, pl->d_knn, pl->maxq, pl->d_fix_count, pl->d_fix_items);
   SFM_HIP_TRY(hipGetLastError());
   return SFMHIP_OK;
 }
@@ -990,7 +996,6 @@ extern "C" int sfmhip_matchplan_run_async(sfmhip_matchplan* pl, float ratio) {
   const bool timing = s->ctx->timing;
   if (timing) SFM_HIP_TRY(hipEventRecord(pl->ev[0], st));
   if (pl->n_pairs > 0) {
-    SFM_HIP_TRY(hipMemsetAsync(pl->d_fix_count, 0, sizeof(int), st));
     const bool mfma = s->ks != 0;
     if (mfma && pl->n_items > 0) {
       if (s->kind == KIND_U8_HAMMING) {
@@ -1008,19 +1013,19 @@ extern "C" int sfmhip_matchplan_run_async(sfmhip_matchplan* pl, float ratio) {
     const int grid = std::min(std::max(pl->n_pairs, 256), 2048);
     if (s->kind == KIND_F32_L2)
       hipLaunchKernelGGL((knn_exact_kernel<KIND_F32_L2>), dim3(grid), dim3(256), 0, st, s->d_imgs, pl->d_pairs, pl->n_pairs,
-                         s->d_nonintegral, force_all, s->dim, pl->d_knn, pl->maxq, pl->d_fix_count, pl->d_fix_items);
+                         s->d_nonintegral, s->gen, force_all, s->dim, pl->d_knn, pl->maxq, pl->d_fix_count, pl->d_fix_items);
     else if (s->kind == KIND_U8_L2)
       hipLaunchKernelGGL((knn_exact_kernel<KIND_U8_L2>), dim3(grid), dim3(256), 0, st, s->d_imgs, pl->d_pairs, pl->n_pairs,
-                         s->d_nonintegral, force_all, s->dim, pl->d_knn, pl->maxq, pl->d_fix_count, pl->d_fix_items);
+                         s->d_nonintegral, s->gen, force_all, s->dim, pl->d_knn, pl->maxq, pl->d_fix_count, pl->d_fix_items);
     else
       hipLaunchKernelGGL((knn_exact_kernel<KIND_U8_HAMMING>), dim3(grid), dim3(256), 0, st, s->d_imgs, pl->d_pairs, pl->n_pairs,
-                         s->d_nonintegral, force_all, s->dim, pl->d_knn, pl->maxq, pl->d_fix_count, pl->d_fix_items);
+                         s->d_nonintegral, s->gen, force_all, s->dim, pl->d_knn, pl->maxq, pl->d_fix_count, pl->d_fix_items);
     SFM_HIP_TRY(hipGetLastError());
   }
   if (timing) SFM_HIP_TRY(hipEventRecord(pl->ev[1], st));
   if (pl->n_pairs > 0) {
     hipLaunchKernelGGL(compact_kernel, dim3(pl->n_pairs), dim3(256), 0, st, s->d_imgs, pl->d_pairs, pl->d_knn, pl->maxq,
-                       ratio, pl->d_counts, pl->d_out_q, pl->d_out_t, pl->d_out_d);
+                       ratio, pl->d_counts, pl->d_out_q, pl->d_out_t, pl->d_out_d, pl->d_fix_count);
     SFM_HIP_TRY(hipGetLastError());
   }
   if (timing) SFM_HIP_TRY(hipEventRecord(pl->ev[2], st));
