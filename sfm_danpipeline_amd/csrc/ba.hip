@@ -1442,7 +1442,7 @@ __device__ __forceinline__ void chol2_panel(double* __restrict__ A, double* __re
 
 __global__ __launch_bounds__(C2_WAVES * 64) void chol_step2(double* __restrict__ A, double* __restrict__ y,
                                                             double* __restrict__ X, int ld, int nt, int k2,
-                                                            int* __restrict__ info) {
+                                                            int tiles_per_wg, int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double sAll[];  // C2_LDS_BYTES, see C2_OFF_*
   const int m2 = nt - 2 * k2 - 2;  // tile rows below the two panels (the rhs row comes on top)
   const int npanel = m2 + 2;       // owner, m2 tile rows, rhs
@@ -1467,8 +1467,10 @@ __global__ __launch_bounds__(C2_WAVES * 64) void chol_step2(double* __restrict__
   // ti_rel in [0, m2] (m2 = rhs) has min(ti_rel + 1, m2) tiles; then the tiles of X: rows 0..a-1 (the
   // rows that are nonzero in the pending panels) x the m2 column blocks right of the panels
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (wave >= 4) return;  // one wave per SIMD: a tile is 64 MFMAs
-  int t = ((int)blockIdx.x - npanel - nx) * 4 + wave;
+  // (four tiles per workgroup -- one wave per SIMD: a tile is 64 MFMAs -- while that fits one round of
+  // workgroups on the device; every workgroup of this kernel holds a CU's LDS)
+  if (wave >= tiles_per_wg) return;
+  int t = ((int)blockIdx.x - npanel - nx) * tiles_per_wg + wave;
   const int ntrail = m2 * (m2 + 1) / 2 + m2;
   if (t >= ntrail + 2 * k2 * m2) return;
   int ti_rel = 0;
@@ -2318,8 +2320,11 @@ static int ba_reduced_solve(sfmhip_ba* b) {
       const int m2 = nt - 2 * k2 - 2;
       // launch 0 has no pending update; later launches: the tiles right of the panels, and those of X
       const int ntrail = k2 == 0 ? 0 : m2 * (m2 + 1) / 2 + m2 + 2 * k2 * m2;
-      hipLaunchKernelGGL(chol_step2, dim3(m2 + 2 + 2 * k2 + 2 + (ntrail + 3) / 4), dim3(C2_WAVES * 64), C2_LDS_BYTES, st, A,
-                         y, d.xinv, d.ld, nt, k2, d.info);
+      const int npan = m2 + 2 + 2 * k2 + 2;
+      int tpw = 4;  // trailing tiles per workgroup: the fewest that keep the launch to one round of workgroups
+      while (tpw < C2_WAVES && npan + (ntrail + tpw - 1) / tpw > b->ctx->n_cu) ++tpw;
+      hipLaunchKernelGGL(chol_step2, dim3(npan + (ntrail + tpw - 1) / tpw), dim3(C2_WAVES * 64), C2_LDS_BYTES, st, A, y,
+                         d.xinv, d.ld, nt, k2, tpw, d.info);
     }
   }
   // z = L^-T y = X y
