@@ -1775,6 +1775,8 @@ struct sfmhip_ba {
   int rank = 0, world = 1;
   // state
   bool scale_ready = false;
+  bool camd_valid = false;  // d.camd holds the tables of d.cams (set_params invalidates; an accepted step swaps in
+                            // the candidate's tables, which ba_cand_cams built in full)
   std::vector<double> h_pts_unused;  // input points without observations keep their values
   std::vector<double> h_pts_in;
   double x_norm = 0;
@@ -2158,6 +2160,7 @@ extern "C" int sfmhip_ba_set_params(sfmhip_ba* b, const double* cams6, const dou
   SFM_HIP_TRY(hipMemcpyAsync(b->d.focal, &focal, sizeof(double), hipMemcpyHostToDevice, st));
   SFM_HIP_TRY(hipStreamSynchronize(st));
   b->scale_ready = false;
+  b->camd_valid = false;
   b->lm.started = false;
   return SFMHIP_OK;
 }
@@ -2214,6 +2217,7 @@ static int ba_prepare_scale(sfmhip_ba* b, int jacobi) {
   const size_t tail = b->ssz + 2 * (size_t)b->ld;  // dc | sc
   SFM_HIP_TRY(hipMemsetAsync(d.red + tail, 0, sizeof(double) * ((size_t)b->ld + SC + 64), st));
   hipLaunchKernelGGL(ba_cam_prep, dim3((b->nc + 63) / 64), dim3(64), 0, st, d.cams, d.camd, b->nc, 1);
+  b->camd_valid = true;
   if (b->np) hipLaunchKernelGGL(ba_point_norms, dim3((b->np + 255) / 256), dim3(256), 0, st, d, jacobi);
   if (b->no && jacobi)
     hipLaunchKernelGGL(ba_cam_blocks, dim3(b->nc * b->cam_split), dim3(256), 0, st, d, b->d_cptr, b->d_cpt, b->d_cxy,
@@ -2251,7 +2255,11 @@ static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_o
     b->ev_on[0] = true;
   }
   SFM_HIP_TRY(hipMemsetAsync(d.red, 0, sizeof(double) * b->red_count, st));
-  hipLaunchKernelGGL(ba_cam_prep, dim3((b->nc + 63) / 64), dim3(64), 0, st, d.cams, d.camd, b->nc, 1);
+  if (!b->camd_valid) {
+    hipLaunchKernelGGL(ba_cam_prep, dim3((b->nc + 63) / 64), dim3(64), 0, st, d.cams, d.camd, b->nc, 1);
+    b->camd_valid = true;
+    b->launches += 1;
+  }
   const double inv_radius = 1.0 / radius;
   int nl = 0;
   if (b->no) {
@@ -2277,7 +2285,7 @@ static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_o
     hipLaunchKernelGGL(ba_eliminate_generic, dim3(b->n_fb), dim3(64), 0, st, d, b->d_fb_points, radius,
                        o->min_lm_diagonal, o->max_lm_diagonal, b->rank);
   SFM_HIP_TRY(hipGetLastError());
-  b->launches += 2 + nl + (b->n_fb > 0);
+  b->launches += 1 + nl + (b->n_fb > 0);
   if (b->ctx->timing) {
     SFM_HIP_TRY(hipEventRecord(b->ev[1], st));
     b->ev_on[1] = true;
