@@ -6,17 +6,26 @@
 //
 // Design (DESIGN.md section "K1/K2"):
 //  * prepare pass: every image becomes an i8 "tile image" (32-row tiles already laid out in the
-//    XOR-swizzled order the LDS wants, so staging is a linear copy), plus per-row norms and
-//    per-row tie-break key bases.  SIFT rows (integers 0..255 held in f32) are centred to
-//    x-128; binary rows are expanded to +-1 so Hamming = (nbits - dot)/2.
-//  * knn kernel: 32x32x32 i8 MFMA, trains on the M side (rows -> accumulator registers),
-//    queries on the N side (one query per lane).  Exact integer distances; each accumulator
-//    element is folded into a 32-bit key (distance << 8 | row-in-chunk) with one v_mad_i32_i24
-//    and inserted into a per-lane top-2 with v_med3_u32 + v_min_u32: 3 VALU ops per distance.
-//    Keys order by (distance, lower train index) = cv::batchDistance's insertion rule.
-//  * exact kernel: f32 rows that are not integer-valued, and the rare queries whose 2nd-best
-//    squared distance is >= 2^22 (where sqrtf can merge neighbouring integers), are redone by
-//    a VALU kernel that orders by (sqrtf(s), index) like OpenCV does.
+//    XOR-swizzled order the LDS wants, so staging is a linear copy).  SIFT rows (integers 0..255
+//    held in f32) are centred to x-128; binary rows are expanded to +-1.  L2 images are stored
+//    in PARITY ORDER: rows whose centred squared norm is odd first, then (from a tile boundary)
+//    the even ones, original order inside each class; perm[] maps a position back to the row.
+//  * k-NN kernel: 32x32x32 i8 MFMA, trains on the M side (rows -> accumulator registers),
+//    queries on the N side (one query per lane).  With c = ceil(||t||^2/2) fed through the MFMA's
+//    C operand the accumulator IS h = q.t - c, and d = ||q||^2 - 2h - (||t||^2 odd): larger h is a
+//    smaller distance, equal h means the odd-norm row is closer by one -- which is why odd rows
+//    come first: the order cv::batchDistance inserts by, (distance, lower train index), becomes
+//    (h descending, position ascending) and no per-distance key has to be built.
+//    Per lane the epilogue keeps VALUES only, in two structures that between them separate any
+//    two rows: the maximum of every accumulator slot over all train tiles (one v_max3_i32 per two
+//    distances) and the top-2 of the per-tile maxima, tagged with their tile (a v_max3_i32 tree):
+//    19 VALU ops per 32x32 tile instead of 48.  The best two rows of a lane lie in
+//    (top-2 tiles) x (slots whose maximum reaches the second-best value); that handful of
+//    candidates is recomputed exactly at the end of the sweep (v_dot4_i32_i8) and ranked.
+//  * exact kernel: f32 rows that are not integer-valued are redone by a VALU kernel that orders
+//    by (sqrtf(s), index) like OpenCV does; so are, inside the compaction kernel, the rare
+//    queries whose 2nd-best squared distance is >= 2^22 (where sqrtf can merge neighbouring
+//    integers) -- they are flagged in-band, so there is no list that could overflow.
 //  * compaction kernel: ratio test (float multiply + compare) and order-preserving compaction.
 #include "common.h"
 #include <vector>
@@ -31,10 +40,12 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 enum { KIND_F32_L2 = 0, KIND_U8_L2 = 1, KIND_U8_HAMMING = 2 };
 
 constexpr int TILE_ROWS = 32;
-constexpr int CHUNK_ROWS = 256;  // rows per tie-break chunk: 8 index bits in the key
-constexpr int IB = 8;
-constexpr unsigned KEY_EMPTY = 0xFFFFFFFFu;
-constexpr int FIX_CAP = 1 << 20;
+constexpr int HPAD = -(1 << 23);     // h of padding rows and of empty structures; real rows: h > -2^23
+constexpr int TAG_BITS = 8;          // tile tag in the low bits of a tile-maximum key
+constexpr int EPOCH_TILES = 1 << TAG_BITS;  // train tiles per epoch (8192 rows): structures are resolved per epoch
+constexpr int TAG_MASK = EPOCH_TILES - 1;
+constexpr int FIX_FLAG = 1 << 30;    // in knn[].y: redo this query exactly (sqrtf merge range)
+constexpr int DIST_EMPTY = 0x7FFFFFFF;
 
 // Pointers read out of the ImgDev records are generic to the compiler (flat_load, which also
 // ties up lgkmcnt next to the LDS reads); these casts tell it they are global memory.
@@ -45,9 +56,12 @@ typedef const SFM_GLOBAL int* g_i32_p;
 
 struct ImgDev {
   const void* raw;  // descriptor rows as handed over (f32 or u8), HBM
-  int8_t* tiles;    // [n_pad/32][32][KS*32] swizzled i8
-  unsigned* base;   // [n_pad] key base of the row in its train role
-  int* nq;          // [n_pad] squared norm of the centred row (query role)
+  int8_t* tiles;    // [n_pad/32][32][KS*32] swizzled i8, rows in position order
+  int* cin;         // [n_pad] MFMA C input of the row in its train role: -ceil(||t||^2/2), HPAD for padding
+  int* nq;          // [n_pad] squared norm of the centred row
+  int* perm;        // [n_pad] position -> original row (-1: padding)
+  int* par;         // [n_pad] scratch of the prepare pass: parity of the row's norm, by original row
+  int* nodd;        // [1] positions of the odd class (a multiple of 32), written by the order pass
   int n_rows;
   int n_pad;
 };
@@ -64,10 +78,105 @@ __host__ __device__ constexpr int chunk_pos(int r, int c) {
   constexpr int SH = (NC == 16) ? 0 : (NC == 8) ? 1 : (NC == 4) ? 2 : 3;
   return r * NC + (c ^ ((r >> SH) & (NC - 1)));
 }
-__device__ __forceinline__ unsigned umin_(unsigned a, unsigned b) { return a < b ? a : b; }
-__device__ __forceinline__ unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ int imax3(int a, int b, int c) { return max(max(a, b), c); }       // v_max3_i32
+__device__ __forceinline__ int imed3(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }  // v_med3_i32
 
 // ---------------------------------------------------------------- prepare
+// Pass 1 (L2 kinds): parity of every row's centred squared norm = parity of the sum of its
+// elements, by original row.  32 lanes per row.
+template <int KIND>
+__global__ __launch_bounds__(256) void parity_kernel(const ImgDev* __restrict__ imgs, const int* __restrict__ tile_img,
+                                                     const int* __restrict__ tile_first, int dim) {
+  const int img = tile_img[blockIdx.x];
+  const int tile = blockIdx.x - tile_first[img];
+  const ImgDev I = imgs[img];
+  const int l = threadIdx.x & 31;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int row = tile * TILE_ROWS + rr * 8 + (threadIdx.x >> 5);
+    int s = 0;
+    if (row < I.n_rows) {
+      if (KIND == KIND_F32_L2) {
+        const float* src = (const float*)I.raw + (size_t)row * dim;
+        for (int k = l; k < dim; k += 32) {
+          const float f = src[k];
+          int x = (int)f;
+          x = x < 0 ? 0 : (x > 255 ? 255 : x);
+          s ^= x;
+        }
+      } else {
+        const unsigned char* src = (const unsigned char*)I.raw + (size_t)row * dim;
+        for (int k = l; k < dim; k += 32) s ^= src[k];
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) s ^= __shfl_xor(s, o);
+    if (l == 0 && row < I.n_pad) I.par[row] = (row < I.n_rows) ? (s & 1) : 0;
+  }
+}
+
+// Pass 2: positions.  One workgroup per image: odd rows first (original order), padded to a
+// tile boundary, then the even rows.  by_parity == 0 (Hamming): identity.
+__global__ __launch_bounds__(256) void order_kernel(const ImgDev* __restrict__ imgs, int by_parity) {
+  __shared__ int wsum[4];
+  __shared__ int run_odd, run_even, n_odd_pad_s;
+  const ImgDev I = imgs[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int p = threadIdx.x; p < I.n_pad; p += 256) I.perm[p] = (!by_parity && p < I.n_rows) ? p : -1;
+  if (!by_parity) {
+    if (threadIdx.x == 0) *I.nodd = 0;
+    return;
+  }
+  // count the odd rows
+  int c = 0;
+  for (int r = threadIdx.x; r < I.n_rows; r += 256) c += I.par[r];
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) c += __shfl_xor(c, o);
+  if (lane == 0) wsum[wave] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int n_odd = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    n_odd_pad_s = (n_odd + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
+    *I.nodd = n_odd_pad_s;
+    run_odd = 0;
+    run_even = 0;
+  }
+  __syncthreads();
+  const int n_odd_pad = n_odd_pad_s;
+  for (int r0 = 0; r0 < I.n_rows; r0 += 256) {
+    const int r = r0 + threadIdx.x;
+    const bool valid = r < I.n_rows;
+    const bool odd = valid && I.par[r];
+    const unsigned long long bo = __ballot(odd), bv = __ballot(valid);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) wsum[wave] = __popcll(bo) | (__popcll(bv) << 16);
+    __syncthreads();
+    int odd_before = run_odd, valid_before = 0;
+    for (int w = 0; w < wave; ++w) {
+      odd_before += wsum[w] & 0xFFFF;
+      valid_before += wsum[w] >> 16;
+    }
+    const int my_odd = odd_before + __popcll(bo & below);
+    const int my_valid = valid_before + __popcll(bv & below);
+    if (valid) {
+      const int even_before = run_even + (my_valid - (my_odd - run_odd));
+      I.perm[odd ? my_odd : n_odd_pad + even_before] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int so = 0, sv = 0;
+      for (int w = 0; w < 4; ++w) {
+        so += wsum[w] & 0xFFFF;
+        sv += wsum[w] >> 16;
+      }
+      run_odd += so;
+      run_even += sv - so;
+    }
+    __syncthreads();
+  }
+}
+
+// Pass 3: tile image, C inputs and norms, in position order.
 template <int KS, int KIND>
 __global__ void prepare_kernel(const ImgDev* __restrict__ imgs, const int* __restrict__ tile_img,
                                const int* __restrict__ tile_first, int dim, int* __restrict__ nonintegral,
@@ -78,8 +187,9 @@ __global__ void prepare_kernel(const ImgDev* __restrict__ imgs, const int* __res
   const int tile = blockIdx.x - tile_first[img];
   const ImgDev I = imgs[img];
   const int r = threadIdx.x / NC, c = threadIdx.x % NC;
-  const int row = tile * TILE_ROWS + r;
-  const bool valid = row < I.n_rows;
+  const int pos = tile * TILE_ROWS + r;
+  const int row = I.perm[pos];
+  const bool valid = row >= 0;
   signed char v[16];
   int n2 = 0;
   bool ok = true;
@@ -104,7 +214,7 @@ __global__ void prepare_kernel(const ImgDev* __restrict__ imgs, const int* __res
     unsigned char bv[16];
     const bool full = valid && c * 16 + 16 <= dim;
     if (KIND == KIND_F32_L2) {
-      const float* src = (const float*)I.raw + (size_t)row * dim + c * 16;
+      const float* src = (const float*)I.raw + (size_t)(valid ? row : 0) * dim + c * 16;
       if (full && (((size_t)src) & 15) == 0) {
         typedef float v4f __attribute__((ext_vector_type(4)));
         const SFM_GLOBAL v4f* s4 = (const SFM_GLOBAL v4f*)src;
@@ -121,7 +231,7 @@ __global__ void prepare_kernel(const ImgDev* __restrict__ imgs, const int* __res
         for (int e = 0; e < 16; ++e) fv[e] = (valid && c * 16 + e < dim) ? src[e] : 128.f;
       }
     } else {
-      const unsigned char* src = (const unsigned char*)I.raw + (size_t)row * dim + c * 16;
+      const unsigned char* src = (const unsigned char*)I.raw + (size_t)(valid ? row : 0) * dim + c * 16;
       if (full && (((size_t)src) & 15) == 0) {
         const v4i x = *(g_v4i_p)src;
         memcpy(bv, &x, 16);
@@ -156,79 +266,92 @@ __global__ void prepare_kernel(const ImgDev* __restrict__ imgs, const int* __res
   int4* dst = (int4*)(I.tiles + (size_t)tile * (TILE_ROWS * RB)) + chunk_pos<NC>(r, c);
   *dst = out;
   if (c == 0) {
-    const unsigned jl = (unsigned)(row & (CHUNK_ROWS - 1));
-    unsigned b;
-    if (KIND == KIND_U8_HAMMING) {
-      const int nbits = dim * 8;
-      b = valid ? (((unsigned)nbits << (IB - 1)) | jl) : (((unsigned)(nbits + 1) << IB) | jl);
-    } else {
-      // +RB*16384 (KOFF of the k-NN kernel): keys stay non-negative without the query norm;
-      // the largest value, padding rows, is RB*65280 + 3 < 2^24 for RB <= 256
-      const unsigned nt_inv = (unsigned)(RB * 48896 + 2);
-      b = ((valid ? (unsigned)n2 + 1u : nt_inv + 1u) + (unsigned)(RB * 16384)) << IB | jl;
-    }
-    I.base[row] = b;
-    I.nq[row] = valid ? n2 : 0;
+    int ci;
+    if (KIND == KIND_U8_HAMMING) ci = valid ? 0 : HPAD;     // h = q.t = nbits - 2 hamming
+    else ci = valid ? -((n2 + 1) >> 1) : HPAD;              // h = q.t - ceil(||t||^2 / 2)
+    I.cin[pos] = ci;
+    I.nq[pos] = valid ? n2 : 0;
   }
   if (KIND == KIND_F32_L2 && !ok) nonintegral[img] = gen;  // (stamped with the prepare pass: no clearing between passes)
 }
 
 // ---------------------------------------------------------------- MFMA k-NN kernel
-struct Top2 {
-  unsigned s0, s1;  // key >> IB of best / 2nd best (0xFFFFFFFF = empty)
-  int j0, j1;       // their train rows
+struct Best2 {  // exact (squared distance, original train row) of the best two; DIST_EMPTY = none
+  int d0, i0, d1, i1;
 };
-
-__device__ __forceinline__ void chunk_merge(Top2& g, unsigned k0, unsigned k1, int cb) {
-  // candidates of a later chunk: on equal distance the earlier (already held) row wins
-  const unsigned ns0 = k0 >> IB, ns1 = k1 >> IB;
-  const int nj0 = cb + (int)(k0 & (CHUNK_ROWS - 1)), nj1 = cb + (int)(k1 & (CHUNK_ROWS - 1));
-  const bool e0 = (k0 == KEY_EMPTY), e1 = (k1 == KEY_EMPTY);
-  const unsigned a0 = e0 ? KEY_EMPTY : ns0, a1 = e1 ? KEY_EMPTY : ns1;
-  if (a0 < g.s0) {
-    if (a1 < g.s0) {
-      g.s1 = a1;
-      g.j1 = nj1;
-    } else {
-      g.s1 = g.s0;
-      g.j1 = g.j0;
-    }
-    g.s0 = a0;
-    g.j0 = nj0;
-  } else if (a0 < g.s1) {
-    g.s1 = a0;
-    g.j1 = nj0;
+__device__ __forceinline__ bool lex_less(int da, int ia, int db, int ib) { return da < db || (da == db && ia < ib); }
+__device__ __forceinline__ void best2_insert(Best2& b, int d, int i) {
+  if (lex_less(d, i, b.d0, b.i0)) {
+    b.d1 = b.d0;
+    b.i1 = b.i0;
+    b.d0 = d;
+    b.i0 = i;
+  } else if (lex_less(d, i, b.d1, b.i1)) {
+    b.d1 = d;
+    b.i1 = i;
   }
 }
 
-__device__ __forceinline__ bool lex_less(unsigned sa, int ja, unsigned sb, int jb) {
-  return sa < sb || (sa == sb && ja < jb);
+// epilogue micro-ops of one drained tile pair (accumulators D0 = tile 2p, D1 = tile 2p+1 of one
+// query tile): 16 slot maxima, then per tile a 7-op max3 tree, the tagged key and its insertion
+// into the lane's top-2 of tile maxima.  38 ops, executed in index order.
+template <int I>
+__device__ __forceinline__ void epi_op(const v16i& D0, const v16i& D1, int (&sl)[16], int& k0, int& k1, int (&T)[8],
+                                       int tag0, int tag1) {
+  if constexpr (I < 16) {
+    sl[I] = imax3(sl[I], D0[I], D1[I]);
+  } else {
+    constexpr int J = (I - 16) % 11;
+    const v16i& D = (I - 16) < 11 ? D0 : D1;
+    const int tag = (I - 16) < 11 ? tag0 : tag1;
+    if constexpr (J == 0) T[0] = imax3(D[0], D[1], D[2]);
+    if constexpr (J == 1) T[1] = imax3(D[3], D[4], D[5]);
+    if constexpr (J == 2) T[2] = imax3(D[6], D[7], D[8]);
+    if constexpr (J == 3) T[3] = imax3(D[9], D[10], D[11]);
+    if constexpr (J == 4) T[4] = imax3(D[12], D[13], D[14]);
+    if constexpr (J == 5) T[5] = imax3(T[0], T[1], T[2]);
+    if constexpr (J == 6) T[6] = imax3(T[3], T[4], D[15]);
+    if constexpr (J == 7) T[7] = max(T[5], T[6]);
+    if constexpr (J == 8) T[7] = (T[7] << TAG_BITS) | tag;
+    if constexpr (J == 9) k1 = imed3(k0, k1, T[7]);
+    if constexpr (J == 10) k0 = max(k0, T[7]);
+  }
+}
+template <int LO, int HI>
+__device__ __forceinline__ void epi_range(const v16i& D0, const v16i& D1, int (&sl)[16], int& k0, int& k1, int (&T)[8],
+                                          int tag0, int tag1) {
+  if constexpr (LO < HI) {
+    epi_op<LO>(D0, D1, sl, k0, k1, T, tag0, tag1);
+    epi_range<LO + 1, HI>(D0, D1, sl, k0, k1, T, tag0, tag1);
+  }
 }
 
-// MODE 0: L2 on centred i8 rows, MODE 1: Hamming on +-1 rows.  SR = train rows per LDS stage.
+// MODE 0: L2 on centred i8 rows, MODE 1: Hamming on +-1 rows.  SR = train rows per LDS stage,
+// NU = query tiles per wave.
 //
-// Workgroup = 4 waves; wave w owns query tiles qtile0+2w, +2w+1 (64 queries, B fragments and the
-// per-query constant accumulator input stay in registers for the whole kernel) and sweeps every
-// train tile of the pair's train image.  Train tiles are staged through LDS (two stage buffers,
-// register-staged copy issued half a stage ahead), 16 accumulator registers = 16 train rows of
-// one query per lane.  "Units" (train tile x query tile) are software-pipelined: the MFMA chain
-// of unit n+1 is issued before the VALU top-2 insertion of unit n.
-template <int KS, int MODE, int SR>
-__global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const ImgDev* __restrict__ imgs,
-                                                          const int2* __restrict__ pairs,
-                                                          const WorkItem* __restrict__ items,
-                                                          const int* __restrict__ nonintegral, int gen,
-                                                          int4* __restrict__ knn, int maxq,
-                                                          int* __restrict__ fix_count,
-                                                          int2* __restrict__ fix_items) {
+// Workgroup = 8 waves = two per SIMD; wave w owns query tiles qtile0 + NU*w .. (B fragments stay in
+// registers for the whole kernel) and sweeps every train tile of the pair's train image.  Train
+// tiles are staged through LDS by LDS-DMA (two stage buffers, one barrier per stage).  The sweep
+// goes by CHAINS: a chain is the MFMAs of one query tile against one train tile PAIR (2*KS
+// MFMAs into two accumulator blocks); between its MFMAs ride the 38 epilogue ops of the
+// previously filled accumulator blocks, so a SIMD's matrix and vector pipes run side by side
+// (4.75 VALU ops per MFMA: scripts/ubench/epi_mix.hip, the gap stays MFMA-paced).
+template <int KS, int MODE, int NU, int SR>
+__global__ __launch_bounds__(512, 2) void knn_kernel(const ImgDev* __restrict__ imgs, const int2* __restrict__ pairs,
+                                                     const WorkItem* __restrict__ items,
+                                                     const int* __restrict__ nonintegral, int gen, int dim,
+                                                     int4* __restrict__ knn, int maxq) {
   constexpr int NC = 2 * KS;
   constexpr int RB = 32 * KS;
-  constexpr int KOFF = RB * 16384;  // >= any ||q||^2 of centred i8 rows
+  constexpr int TILE_BYTES = TILE_ROWS * RB;
   constexpr int STAGE_ROW_BYTES = SR * RB;
   constexpr int STAGE_BYTES = STAGE_ROW_BYTES + SR * 4;
   constexpr int TILES = SR / TILE_ROWS;
-  constexpr int PIECES = STAGE_ROW_BYTES / 4096;  // 16-byte pieces per thread per stage
-  constexpr int HALF = PIECES > 1 ? PIECES / 2 : 1;
+  constexpr int TP = TILES / 2;                       // tile pairs per stage
+  constexpr int PIECES = STAGE_ROW_BYTES / (512 * 16);  // 16-byte pieces per thread per stage
+  constexpr int NG = 2 * KS;                          // MFMAs (= op groups) per chain
+  constexpr int STAGES_PER_EPOCH = EPOCH_TILES / TILES;
+  static_assert(PIECES >= 1 && TP >= 2 && TP % 2 == 0, "stage shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const WorkItem it = items[blockIdx.x];
@@ -238,42 +361,26 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const ImgDev* __restri
   const ImgDev T = imgs[pr.y];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int nqt = (Q.n_rows + TILE_ROWS - 1) / TILE_ROWS;
-  const int qt[2] = {it.qtile0 + 2 * wave, it.qtile0 + 2 * wave + 1};
-
-  // key = base - 2^(IB+1) * dot  (L2)   |   base - 2^(IB-1) * dot  (Hamming).  The query's own
-  // norm is the same for every train row, so it stays out of the keys (added back when the
-  // winners are emitted); base carries +KOFF so that keys stay non-negative without it.
-  // The multiplier is made opaque so that hipcc keeps one v_mad_i32_i24 per element instead of
-  // strength-reducing it into a shift and a subtract.
-  int mul;
-  asm volatile("s_mov_b32 %0, %1" : "=s"(mul) : "i"((MODE == 0) ? -(2 << IB) : -(1 << (IB - 1))));
+  const int nqt = Q.n_pad / TILE_ROWS;
+  int qt[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) qt[u] = it.qtile0 + NU * wave + u;
 
   // query fragments (B operand): lane (r,h) holds bytes [32ks+16h, +16) of query row r
-  v4i bq[2][KS];
+  v4i bq[NU][KS];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < NU; ++u) {
     const int t = qt[u] < nqt ? qt[u] : (nqt > 0 ? nqt - 1 : 0);
-    g_v4i_p src = (g_v4i_p)(Q.tiles + (size_t)t * (TILE_ROWS * RB));
+    g_v4i_p src = (g_v4i_p)(Q.tiles + (size_t)t * TILE_BYTES);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) bq[u][ks] = src[chunk_pos<NC>(r, 2 * ks + h)];
   }
-  const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-  // per-lane LDS byte offsets of the A fragments inside a tile, and of the key bases
+  // per-lane LDS byte offsets of the A fragments inside a tile, and of the C inputs
   int aoff[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) aoff[ks] = chunk_pos<NC>(r, 2 * ks + h) * 16;
-  const int boff = STAGE_ROW_BYTES + h * 16;
-
-  Top2 g[2];
-  unsigned k0[2], k1[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    g[u].s0 = g[u].s1 = KEY_EMPTY;
-    g[u].j0 = g[u].j1 = -1;
-    k0[u] = k1[u] = KEY_EMPTY;
-  }
+  const int coff = STAGE_ROW_BYTES + h * 16;
 
   const int nstages = T.n_pad / SR;
   const int tid = threadIdx.x;
@@ -284,202 +391,252 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const ImgDev* __restri
     const unsigned char* src = (const unsigned char*)T.tiles + (size_t)stage * STAGE_ROW_BYTES;
 #pragma unroll
     for (int i = 0; i < PIECES; ++i)
-      __builtin_amdgcn_global_load_lds((const SFM_GLOBAL void*)(src + (size_t)(i * 256 + tid) * 16),
-                                       (__attribute__((address_space(3))) void*)(dstb + i * 4096 + wave * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const SFM_GLOBAL void*)(src + (size_t)(i * 512 + tid) * 16),
+                                       (__attribute__((address_space(3))) void*)(dstb + i * 8192 + wave * 1024), 16, 0, 0);
     if (wave < SR / 64)
-      __builtin_amdgcn_global_load_lds((const SFM_GLOBAL void*)(T.base + (size_t)stage * SR + tid),
+      __builtin_amdgcn_global_load_lds((const SFM_GLOBAL void*)(T.cin + (size_t)stage * SR + tid),
                                        (__attribute__((address_space(3))) void*)(dstb + STAGE_ROW_BYTES + wave * 256), 4, 0, 0);
   };
-  stage_copy(0, lds);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // one step of the MFMA chain of (fragments fr, query tile u): ks-th K slice
-#define SFM_MFMA(ACC, FR, u, ks) \
-  ACC = __builtin_amdgcn_mfma_i32_32x32x32_i8(FR[ks], bq[u][ks], (ks) == 0 ? zero16 : ACC, 0, 0, 0)
-  // top-2 insertion of accumulator element e of query tile u
-#define SFM_INS(ACC, BS, u, e)                                                             \
-  do {                                                                                     \
-    const unsigned key_ = (unsigned)__mul24(ACC[e], mul) + BS[e];            /* v_mad_i32_i24 */ \
-    const unsigned n1_ = umax_(umin_(k0[u], k1[u]), umin_(umax_(k0[u], k1[u]), key_)); /* v_med3_u32 */ \
-    k0[u] = umin_(k0[u], key_);                                                            \
-    k1[u] = n1_;                                                                           \
-    asm volatile("" : "+v"(k0[u]), "+v"(k1[u])); /* no min/max re-association across elements */ \
-  } while (0)
-  auto ld_afrag = [&](const unsigned char* sb, int tl, int ks) -> v4i {
-    const int4 x = *(const int4*)(sb + tl * (TILE_ROWS * RB) + aoff[ks]);
+  auto ld_afrag = [&](const unsigned char* tb, int ks) -> v4i {  // tb: the tile inside a stage buffer
+    const int4 x = *(const int4*)(tb + aoff[ks]);
     return v4i{x.x, x.y, x.z, x.w};
   };
-  auto ld_bases = [&](const unsigned char* sb, int tl, int gq, unsigned (&bs)[16]) {
-    const uint4 x = *(const uint4*)(sb + boff + (tl * TILE_ROWS + 8 * gq) * 4);
-    bs[4 * gq] = x.x;
-    bs[4 * gq + 1] = x.y;
-    bs[4 * gq + 2] = x.z;
-    bs[4 * gq + 3] = x.w;
+  // C input of the lane's 16 accumulator rows of tile tl: rows 8g + 4h + j
+  auto ld_cin = [&](const unsigned char* sb, int tl, v16i& C) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int4 x = *(const int4*)(sb + coff + (tl * TILE_ROWS + 8 * g) * 4);
+      C[4 * g] = x.x;
+      C[4 * g + 1] = x.y;
+      C[4 * g + 2] = x.z;
+      C[4 * g + 3] = x.w;
+    }
   };
 
-  // MFMA and VALU of a SIMD do not overlap here: the epilogue is VALU-issue-bound (3 ops per
-  // distance: scripts/ubench/valu_rate.hip measures time = VALU issue + 8 cycles per MFMA whatever
-  // the interleave), and a wave that issues a dependent MFMA chain back to back stalls in order
-  // on the matrix pipe.  So per train tile the 2*KS MFMAs of the NEXT tile (both query tiles)
-  // are spread one per group through the 96 insertion ops of the CURRENT tile, the insertions of
-  // the two query tiles alternate (two independent dependency chains per wave), and the LDS
-  // fragment / key-base reads of the tile after ride along.  Groups are pinned by sched_barrier.
-  constexpr int MPG = (KS + 3) / 4;  // MFMAs per group and query tile
-#define SFM_GROUP(g_, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, do_mfma, do_frag)              \
-  do {                                                                                         \
-    if (do_mfma) {                                                                             \
-      _Pragma("unroll") for (int j_ = 0; j_ < MPG; ++j_) {                                     \
-        const int ks_ = ((g_) & 3) * MPG + j_;                                                 \
-        if (ks_ < KS) {                                                                        \
-          if ((g_) < 4) SFM_MFMA(NA0, FN, 0, ks_);                                             \
-          else SFM_MFMA(NA1, FN, 1, ks_);                                                      \
-        }                                                                                      \
-      }                                                                                        \
-      if ((g_) >= 4) ld_bases(SB, (tl) + 1, (g_) - 4, BN);                                     \
-      else if (do_frag) {                                                                      \
-        _Pragma("unroll") for (int j_ = 0; j_ < MPG; ++j_)                                     \
-          if ((g_) * MPG + j_ < KS) FNN[(g_) * MPG + j_] = ld_afrag(SB, (tl) + 2, (g_) * MPG + j_); \
-      }                                                                                        \
-    }                                                                                          \
-    SFM_INS(CA0, BC, 0, 2 * (g_));                                                             \
-    SFM_INS(CA1, BC, 1, 2 * (g_));                                                             \
-    SFM_INS(CA0, BC, 0, 2 * (g_) + 1);                                                         \
-    SFM_INS(CA1, BC, 1, 2 * (g_) + 1);                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-  } while (0)
-#define SFM_BODY(SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_)                        \
-  do {                                                                                         \
-    SFM_GROUP(0, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
-    SFM_GROUP(1, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
-    SFM_GROUP(2, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
-    SFM_GROUP(3, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
-    SFM_GROUP(4, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
-    SFM_GROUP(5, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
-    SFM_GROUP(6, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
-    SFM_GROUP(7, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
-  } while (0)
+  Best2 res[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) res[u].d0 = res[u].d1 = DIST_EMPTY, res[u].i0 = res[u].i1 = 0x7FFFFFFF;
+  const int nodd_t = MODE == 0 ? *(g_i32_p)T.nodd : 0;
+  const int nbits = dim * 8;
 
-  // fragments ping-pong between fa / fb, key bases between ba / bb, accumulators between
-  // (A0, A1) and (B0, B1): tile tl inserts from one pair while tile tl+1 accumulates in the
-  // other.  The pipeline runs across stages: one workgroup barrier per stage, placed before the
-  // stage's last tile body, whose MFMAs already read tile 0 of the next stage.
-  static_assert(TILES == 4 || TILES == 8, "stage = 4 or 8 train tiles");
-  v4i fa[KS], fb[KS];
-  unsigned ba[16], bb[16];
-  v16i A0, A1, B0, B1;
+  for (int ep0 = 0; ep0 < nstages; ep0 += STAGES_PER_EPOCH) {
+    const int ep1 = (ep0 + STAGES_PER_EPOCH < nstages) ? ep0 + STAGES_PER_EPOCH : nstages;
+    const int ep_tile0 = ep0 * TILES;
+    int sl[NU][16], k0[NU], k1[NU];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) fa[ks] = ld_afrag(lds, 0, ks);
+    for (int u = 0; u < NU; ++u) {
+      k0[u] = k1[u] = (int)0x80000000;
 #pragma unroll
-  for (int gq = 0; gq < 4; ++gq) ld_bases(lds, 0, gq, ba);
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) SFM_MFMA(A0, fa, 0, ks);
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) SFM_MFMA(A1, fa, 1, ks);
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) fb[ks] = ld_afrag(lds, 1, ks);
-  __builtin_amdgcn_sched_barrier(0);
-
-  for (int s = 0; s < nstages; ++s) {
-    const unsigned char* sb = lds + (s & 1) * STAGE_BYTES;
-    unsigned char* nb = lds + ((s & 1) ^ 1) * STAGE_BYTES;
-    const bool more = s + 1 < nstages;
-    // the other buffer was last read before the previous stage's barrier: refill it now
-    if (more) stage_copy(s + 1, nb);
-
-    SFM_BODY(sb, 0, A0, A1, B0, B1, fb, fa, ba, bb, true, true);
-    SFM_BODY(sb, 1, B0, B1, A0, A1, fa, fb, bb, ba, true, true);
-    if (TILES == 8) {
-      SFM_BODY(sb, 2, A0, A1, B0, B1, fb, fa, ba, bb, true, true);
-      SFM_BODY(sb, 3, B0, B1, A0, A1, fa, fb, bb, ba, true, true);
-      SFM_BODY(sb, 4, A0, A1, B0, B1, fb, fa, ba, bb, true, true);
-      SFM_BODY(sb, 5, B0, B1, A0, A1, fa, fb, bb, ba, true, true);
+      for (int e = 0; e < 16; ++e) sl[u][e] = HPAD;
     }
-    // tile TILES-2: its MFMAs take the last tile of this stage; nothing of this stage left to prefetch
-    SFM_BODY(sb, TILES - 2, A0, A1, B0, B1, fb, fa, ba, bb, true, false);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the next stage has landed
+    if (ep0 > 0) __syncthreads();  // every wave is done with the stage buffers of the previous epoch
+    stage_copy(ep0, lds + (ep0 & 1) * STAGE_BYTES);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // tile TILES-1: MFMAs on tile 0 of the next stage (fragments fetched now), prefetch of its tile 1
-    if (more) {
+
+    v4i F0[KS], F1[KS];
+    v16i C0, C1, X0, X1, Y0, Y1;
+    int TT[8];
+    {
+      const unsigned char* sb = lds + (ep0 & 1) * STAGE_BYTES;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) fa[ks] = ld_afrag(nb, 0, ks);
+      for (int ks = 0; ks < KS; ++ks) F0[ks] = ld_afrag(sb, ks);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) F1[ks] = ld_afrag(sb + TILE_BYTES, ks);
+      ld_cin(sb, 0, C0);
+      ld_cin(sb, 1, C1);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) X0[e] = X1[e] = Y0[e] = Y1[e] = HPAD;  // draining these changes nothing
     }
-    SFM_BODY(nb, -1, B0, B1, A0, A1, fa, fb, bb, ba, more, more);
-    // tie-break chunk boundary: fold the 8-bit-indexed keys into the running (distance, row)
-    if (((s + 1) * SR) % CHUNK_ROWS == 0) {
-      const int cb = ((s * SR) / CHUNK_ROWS) * CHUNK_ROWS;
+    // tag of the first tile of the pair drained next; the first drain is the dummy one: its blocks hold HPAD,
+    // so whatever (masked) tag it gets, its keys carry the value HPAD and never become candidates
+    int tag = EPOCH_TILES - 1 + 2;
+
+    // One chain: MFMAs of query tile UF against (F0, F1) into (FA, FB); the epilogue of (DA, DB)
+    // (query tile UD, tile tags tag, tag-1) spread between them; with RELOAD, every fragment and C
+    // input is re-fetched for the next tile pair (tiles NT0, NT1 in buffer NSB) right after its last use.
+#define SFM_CHAIN(FA, FB, UF, DA, DB, UD, RELOAD, NSB, NT0, NT1)                                            \
+  do {                                                                                                      \
+    _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_) {                                                     \
+      const int ks_ = g_ % KS;                                                                              \
+      if (g_ < KS) FA = __builtin_amdgcn_mfma_i32_32x32x32_i8(F0[ks_], bq[UF][ks_], ks_ == 0 ? C0 : FA, 0, 0, 0); \
+      else FB = __builtin_amdgcn_mfma_i32_32x32x32_i8(F1[ks_], bq[UF][ks_], ks_ == 0 ? C1 : FB, 0, 0, 0);  \
+      if (RELOAD) {                                                                                         \
+        if (g_ < KS) F0[ks_] = ld_afrag((NSB) + (NT0) * TILE_BYTES, ks_);                                   \
+        else F1[ks_] = ld_afrag((NSB) + (NT1) * TILE_BYTES, ks_);                                           \
+        if (g_ == 0) ld_cin(NSB, NT0, C0);                                                                  \
+        if (g_ == KS) ld_cin(NSB, NT1, C1);                                                                 \
+      }                                                                                                     \
+      switch (g_) {                                                                                         \
+        SFM_EPI_CASES(DA, DB, UD)                                                                           \
+      }                                                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+    }                                                                                                       \
+  } while (0)
+#define SFM_EPI_CASE(G, DA, DB, UD) \
+  case G: epi_range<(G) * 38 / NG, ((G) + 1) * 38 / NG>(DA, DB, sl[UD], k0[UD], k1[UD], TT, tag & TAG_MASK, (tag - 1) & TAG_MASK); break;
+#define SFM_EPI_CASES(DA, DB, UD)                                                                          \
+  SFM_EPI_CASE(0, DA, DB, UD) SFM_EPI_CASE(1, DA, DB, UD) SFM_EPI_CASE(2, DA, DB, UD) SFM_EPI_CASE(3, DA, DB, UD)     \
+  SFM_EPI_CASE(4, DA, DB, UD) SFM_EPI_CASE(5, DA, DB, UD) SFM_EPI_CASE(6, DA, DB, UD) SFM_EPI_CASE(7, DA, DB, UD)     \
+  SFM_EPI_CASE(8, DA, DB, UD) SFM_EPI_CASE(9, DA, DB, UD) SFM_EPI_CASE(10, DA, DB, UD) SFM_EPI_CASE(11, DA, DB, UD)   \
+  SFM_EPI_CASE(12, DA, DB, UD) SFM_EPI_CASE(13, DA, DB, UD) SFM_EPI_CASE(14, DA, DB, UD) SFM_EPI_CASE(15, DA, DB, UD)
+
+    for (int s = ep0; s < ep1; ++s) {
+      const unsigned char* sb = lds + (s & 1) * STAGE_BYTES;
+      unsigned char* nb = lds + ((s & 1) ^ 1) * STAGE_BYTES;
+      const bool more = s + 1 < ep1;
+      // the other buffer was last read before the previous stage's barrier: refill it now
+      if (more) stage_copy(s + 1, nb);
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        chunk_merge(g[u], k0[u], k1[u], cb);
-        k0[u] = k1[u] = KEY_EMPTY;
+      for (int tp = 0; tp < TP; ++tp) {
+        const bool last = tp == TP - 1;
+        if (NU == 2) {
+          SFM_CHAIN(X0, X1, 0, Y0, Y1, 1, false, sb, 0, 0);  // drains the previous pair of query tile 1
+          tag -= 2;
+          if (last) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the next stage has landed
+            __syncthreads();
+          }
+          SFM_CHAIN(Y0, Y1, NU - 1, X0, X1, 0, true, last ? nb : sb, last ? 0 : 2 * tp + 2, last ? 1 : 2 * tp + 3);
+        } else {
+          if (last) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+          }
+          if ((tp & 1) == 0) SFM_CHAIN(X0, X1, 0, Y0, Y1, 0, true, last ? nb : sb, last ? 0 : 2 * tp + 2, last ? 1 : 2 * tp + 3);
+          else SFM_CHAIN(Y0, Y1, 0, X0, X1, 0, true, last ? nb : sb, last ? 0 : 2 * tp + 2, last ? 1 : 2 * tp + 3);
+          tag -= 2;
+        }
       }
+    }
+    // the blocks filled last are still to be drained (Y for both shapes: TP is even)
+    epi_range<0, 38>(Y0, Y1, sl[NU - 1], k0[NU - 1], k1[NU - 1], TT, tag & TAG_MASK, (tag - 1) & TAG_MASK);
+#undef SFM_CHAIN
+#undef SFM_EPI_CASES
+#undef SFM_EPI_CASE
+
+    // ---- resolve the epoch: exact (h, position) of the lane's candidates, then (d, row) per query
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int bv0 = k0[u] >> TAG_BITS, bv1 = k1[u] >> TAG_BITS;  // the two largest tile maxima of the lane
+      const int tl0 = ep_tile0 + (EPOCH_TILES - 1) - (k0[u] & (EPOCH_TILES - 1));
+      const int tl1 = ep_tile0 + (EPOCH_TILES - 1) - (k1[u] & (EPOCH_TILES - 1));
+      const int pb0 = __shfl_xor(bv0, 32), pb1 = __shfl_xor(bv1, 32);
+      // second largest of the four tile maxima of the query's two lanes: four different rows, so a
+      // lower bound of the query's second-best h.  Rows below it are out.
+      const int thr = max(min(bv0, pb0), max(bv1, pb1));
+      unsigned lt = 0;  // bit 15-e: slot e stays below thr
+#pragma unroll
+      for (int e = 0; e < 16; ++e) lt = __builtin_amdgcn_alignbit(lt, (unsigned)(sl[u][e] - thr), 31);
+      const unsigned ge = ~lt & 0xFFFFu;
+      // (a tile maximum of HPAD is a padding tile, the dummy drain or an empty slot: no candidates there)
+      unsigned m0 = (bv0 >= thr && bv0 > HPAD) ? ge : 0u, m1 = (bv1 >= thr && bv1 > HPAD) ? ge : 0u;
+      // lane top-2 by (h descending, position ascending)
+      int h0 = HPAD - 1, p0 = 0x7FFFFFFF, h1 = HPAD - 1, p1 = 0x7FFFFFFF;
+      if (__popc(ge) == 1 && m1 == 0u && m0 != 0u) {
+        // one candidate: the lane's best row, whose value is known (the best row lies in the first
+        // tile that reaches the lane's maximum and in the only slot that reaches thr)
+        const int e = 15 - (31 - __clz((int)ge));
+        h0 = bv0;
+        p0 = tl0 * TILE_ROWS + 8 * (e >> 2) + 4 * h + (e & 3);
+        m0 = 0u;
+      }
+      while (__ballot((m0 | m1) != 0u) != 0ull) {
+        const bool have = (m0 | m1) != 0u;
+        const bool first = m0 != 0u;
+        const unsigned mm = first ? m0 : m1;
+        const int bit = have ? 31 - __clz((int)mm) : 0;
+        const int e = 15 - bit;
+        const int pos = have ? (first ? tl0 : tl1) * TILE_ROWS + 8 * (e >> 2) + 4 * h + (e & 3) : -1;
+        if (first) m0 &= ~(1u << bit);
+        else m1 &= ~(1u << bit);
+        const int ppos = __shfl_xor(pos, 32);
+        // this lane's byte ranges of both rows (its own candidate and its partner's)
+        int dot_me = 0, dot_pa = 0;
+        if (pos >= 0) {
+          g_v4i_p rowp = (g_v4i_p)(T.tiles + (size_t)(pos >> 5) * TILE_BYTES);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const v4i x = rowp[chunk_pos<NC>(pos & 31, 2 * ks + h)];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) dot_me = __builtin_amdgcn_sdot4(x[w], bq[u][ks][w], dot_me, false);
+          }
+          dot_me += ((g_i32_p)T.cin)[pos];
+        }
+        if (ppos >= 0) {
+          g_v4i_p rowp = (g_v4i_p)(T.tiles + (size_t)(ppos >> 5) * TILE_BYTES);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const v4i x = rowp[chunk_pos<NC>(ppos & 31, 2 * ks + h)];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) dot_pa = __builtin_amdgcn_sdot4(x[w], bq[u][ks][w], dot_pa, false);
+          }
+        }
+        const int hv = dot_me + __shfl_xor(dot_pa, 32);
+        if (have) {
+          if (hv > h0 || (hv == h0 && pos < p0)) {
+            h1 = h0;
+            p1 = p0;
+            h0 = hv;
+            p0 = pos;
+          } else if (hv > h1 || (hv == h1 && pos < p1)) {
+            h1 = hv;
+            p1 = pos;
+          }
+        }
+      }
+      // exact squared distance and original row of the lane's two; merge the query's two lanes
+      const int q = qt[u] * TILE_ROWS + r;
+      const int nqq = (MODE == 0 && qt[u] < nqt) ? ((g_i32_p)Q.nq)[q] : 0;
+      int d[2] = {DIST_EMPTY, DIST_EMPTY}, ix[2] = {0x7FFFFFFF, 0x7FFFFFFF};
+      const int hh[2] = {h0, h1}, pp[2] = {p0, p1};
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (hh[k] > HPAD && pp[k] < T.n_pad) {
+          const int row = ((g_i32_p)T.perm)[pp[k]];
+          if (row >= 0) {
+            ix[k] = row;
+            d[k] = MODE == 0 ? nqq - 2 * hh[k] - (pp[k] < nodd_t ? 1 : 0) : (nbits - hh[k]) >> 1;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        best2_insert(res[u], d[k], ix[k]);
+      }
+      const int od0 = __shfl_xor(d[0], 32), oi0 = __shfl_xor(ix[0], 32);
+      const int od1 = __shfl_xor(d[1], 32), oi1 = __shfl_xor(ix[1], 32);
+      best2_insert(res[u], od0, oi0);
+      best2_insert(res[u], od1, oi1);
     }
   }
-#undef SFM_BODY
-#undef SFM_GROUP
-#undef SFM_INS
-#undef SFM_MFMA
 
-  // merge the two half-waves (rows 4h.. of each 8-row group) and emit
+  // emit
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    Top2 p;
-    p.s0 = __shfl_xor(g[u].s0, 32);
-    p.s1 = __shfl_xor(g[u].s1, 32);
-    p.j0 = __shfl_xor(g[u].j0, 32);
-    p.j1 = __shfl_xor(g[u].j1, 32);
-    Top2 m;
-    if (lex_less(p.s0, p.j0, g[u].s0, g[u].j0)) {
-      m.s0 = p.s0;
-      m.j0 = p.j0;
-      if (lex_less(g[u].s0, g[u].j0, p.s1, p.j1)) {
-        m.s1 = g[u].s0;
-        m.j1 = g[u].j0;
-      } else {
-        m.s1 = p.s1;
-        m.j1 = p.j1;
-      }
-    } else {
-      m.s0 = g[u].s0;
-      m.j0 = g[u].j0;
-      if (lex_less(p.s0, p.j0, g[u].s1, g[u].j1)) {
-        m.s1 = p.s0;
-        m.j1 = p.j0;
-      } else {
-        m.s1 = g[u].s1;
-        m.j1 = g[u].j1;
-      }
-    }
+  for (int u = 0; u < NU; ++u) {
     const int q = qt[u] * TILE_ROWS + r;
-    if (h == 0 && qt[u] < nqt && q < Q.n_rows) {
-      int s0i, s1i;
-      if (MODE == 0) {
-        const int adj = ((g_i32_p)Q.nq)[q] - 1 - KOFF;  // key >> IB = ||t||^2 + 1 + KOFF - 2 q.t
-        s0i = (int)m.s0 + adj;
-        s1i = (int)m.s1 + adj;
-      } else {
-        s0i = (int)m.s0;
-        s1i = (int)m.s1;
-      }
-      const bool v0 = m.j0 >= 0 && m.j0 < T.n_rows, v1 = m.j1 >= 0 && m.j1 < T.n_rows;
-      float d0, d1;
-      if (MODE == 0) {
-        d0 = sqrtf((float)s0i);
-        d1 = sqrtf((float)s1i);
-        if (v1 && s1i >= (1 << 22)) {  // sqrtf may merge neighbouring integers: redo exactly
-          const int k = atomicAdd(fix_count, 1);
-          if (k < FIX_CAP) fix_items[k] = make_int2(it.pair, q);
+    if (h == 0 && qt[u] < nqt) {
+      const int qrow = ((g_i32_p)Q.perm)[q];
+      if (qrow >= 0) {
+        const Best2 m = res[u];
+        const bool v0 = m.d0 != DIST_EMPTY, v1 = m.d1 != DIST_EMPTY;
+        float d0, d1;
+        int fix = 0;
+        if (MODE == 0) {
+          d0 = sqrtf((float)m.d0);
+          d1 = sqrtf((float)m.d1);
+          if (v1 && m.d1 >= (1 << 22)) fix = FIX_FLAG;  // sqrtf may merge neighbouring integers: redone exactly
+        } else {
+          d0 = (float)m.d0;
+          d1 = (float)m.d1;
         }
-      } else {
-        d0 = (float)s0i;
-        d1 = (float)s1i;
+        int4 o;
+        o.x = v0 ? m.i0 : -1;
+        o.y = (v1 ? m.i1 : -1) | (v1 ? fix : 0);
+        o.z = __float_as_int(v0 ? d0 : 3.402823466e+38f);
+        o.w = __float_as_int(v1 ? d1 : 3.402823466e+38f);
+        knn[(size_t)it.pair * maxq + qrow] = o;
       }
-      int4 o;
-      o.x = v0 ? m.j0 : -1;
-      o.y = v1 ? m.j1 : -1;
-      o.z = __float_as_int(v0 ? d0 : 3.402823466e+38f);
-      o.w = __float_as_int(v1 ? d1 : 3.402823466e+38f);
-      knn[(size_t)it.pair * maxq + q] = o;
     }
   }
 }
@@ -529,7 +686,7 @@ __device__ __forceinline__ float exact_dist(const void* qrow, const void* trow, 
 }
 
 template <int KIND>
-__device__ void exact_query(const ImgDev& Q, const ImgDev& T, int q, int dim, int4* out) {
+__device__ int4 exact_query(const ImgDev& Q, const ImgDev& T, int q, int dim) {
   const int lane = threadIdx.x & 63;
   const size_t rowb = (size_t)dim * (KIND == KIND_F32_L2 ? 4 : 1);
   const unsigned char* qrow = (const unsigned char*)Q.raw + (size_t)q * rowb;
@@ -587,73 +744,71 @@ __device__ void exact_query(const ImgDev& Q, const ImgDev& T, int q, int dim, in
     j0 = m0;
     j1 = m1;
   }
-  if (lane == 0) {
-    int4 o;
-    o.x = j0;
-    o.y = j1;
-    o.z = __float_as_int(j0 >= 0 ? d0 : 3.402823466e+38f);
-    o.w = __float_as_int(j1 >= 0 ? d1 : 3.402823466e+38f);
-    *out = o;
-  }
+  int4 o;  // the butterfly leaves the same result in every lane
+  o.x = j0;
+  o.y = j1;
+  o.z = __float_as_int(j0 >= 0 ? d0 : 3.402823466e+38f);
+  o.w = __float_as_int(j1 >= 0 ? d1 : 3.402823466e+38f);
+  return o;
 }
 
-// Fixed-size grid.  Phase 1: every pair that touches a non-integer-valued f32 image (or, with
-// force_all, every pair: norms/dims the MFMA kernel is not instantiated for).  Phase 2: the
-// queries the MFMA kernel flagged.
+// Every pair that touches a non-integer-valued f32 image (or, with force_all, every pair:
+// norms/dims the MFMA kernel is not instantiated for).  One wave per query.
 template <int KIND>
 __global__ __launch_bounds__(256) void knn_exact_kernel(const ImgDev* __restrict__ imgs,
                                                         const int2* __restrict__ pairs, int n_pairs,
                                                         const int* __restrict__ nonintegral, int gen,
                                                         int force_all, int dim,
-                                                        int4* __restrict__ knn, int maxq,
-                                                        const int* __restrict__ fix_count,
-                                                        const int2* __restrict__ fix_items) {
-  const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+                                                        int4* __restrict__ knn, int maxq) {
+  const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, lane = threadIdx.x & 63;
   for (int p = blockIdx.x; p < n_pairs; p += gridDim.x) {
     const int2 pr = pairs[p];
     if (!(force_all | (nonintegral[pr.x] == gen) | (nonintegral[pr.y] == gen))) continue;
     const ImgDev Q = imgs[pr.x], T = imgs[pr.y];
-    for (int q = wave; q < Q.n_rows; q += wpb) exact_query<KIND>(Q, T, q, dim, &knn[(size_t)p * maxq + q]);
-  }
-  if (!force_all) {
-    int nfix = *fix_count;
-    nfix = nfix < FIX_CAP ? nfix : FIX_CAP;
-    for (int i = blockIdx.x * wpb + wave; i < nfix; i += gridDim.x * wpb) {
-      const int2 f = fix_items[i];
-      const int2 pr = pairs[f.x];
-      exact_query<KIND>(imgs[pr.x], imgs[pr.y], f.y, dim, &knn[(size_t)f.x * maxq + f.y]);
+    for (int q = wave; q < Q.n_rows; q += wpb) {
+      const int4 o = exact_query<KIND>(Q, T, q, dim);
+      if (lane == 0) knn[(size_t)p * maxq + q] = o;
     }
   }
 }
 
 // ---------------------------------------------------------------- ratio test + compaction
-// reference src/Sfm.cpp:603-607: keep knn[i][0] iff d0 <= ratio*d1 (float), ascending queryIdx
+// reference src/Sfm.cpp:603-607: keep knn[i][0] iff d0 <= ratio*d1 (float), ascending queryIdx.
+// Queries the MFMA kernel flagged (2nd-best squared distance >= 2^22, where sqrtf can merge
+// neighbouring integers and the order by (sqrtf(s), index) can differ from the order by (s, index))
+// are redone here with OpenCV's literal float arithmetic, one wave per flagged query.
+template <int KIND>
 __global__ __launch_bounds__(256) void compact_kernel(const ImgDev* __restrict__ imgs,
                                                       const int2* __restrict__ pairs,
-                                                      const int4* __restrict__ knn, int maxq,
+                                                      int4* __restrict__ knn, int maxq, int dim,
                                                       float ratio, int* __restrict__ counts,
                                                       int* __restrict__ out_q, int* __restrict__ out_t,
-                                                      float* __restrict__ out_d, int* __restrict__ fix_count) {
+                                                      float* __restrict__ out_d) {
   __shared__ int wsum[4];
   __shared__ int running;
   const int p = blockIdx.x;
-  // the fix-up list of this run has been consumed (knn_exact_kernel ran before this kernel): clear
-  // its counter for the plan's next run here instead of with a memset node in front of every run
-  if (blockIdx.x == 0 && threadIdx.x == 0) *fix_count = 0;
   const int2 pr = pairs[p];
-  const int nq = imgs[pr.x].n_rows, nt = imgs[pr.y].n_rows;
+  const ImgDev Q = imgs[pr.x], T = imgs[pr.y];
+  const int nq = Q.n_rows, nt = T.n_rows;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) running = 0;
   __syncthreads();
-  if (nt >= 2) {
+  if (nt >= 1) {
     for (int q0 = 0; q0 < nq; q0 += 256) {
       const int q = q0 + threadIdx.x;
       int4 e = make_int4(-1, -1, 0, 0);
-      bool keep = false;
-      if (q < nq) {
-        e = knn[(size_t)p * maxq + q];
-        keep = e.y >= 0 && __int_as_float(e.z) <= __fmul_rn(ratio, __int_as_float(e.w));
+      if (q < nq) e = knn[(size_t)p * maxq + q];
+      unsigned long long fb = __ballot(q < nq && e.y >= 0 && (e.y & FIX_FLAG) != 0);
+      while (fb) {  // wave-uniform
+        const int l = __ffsll((long long)fb) - 1;
+        fb &= fb - 1;
+        const int4 o = exact_query<KIND>(Q, T, q0 + wave * 64 + l, dim);
+        if (lane == l) {
+          e = o;
+          knn[(size_t)p * maxq + q] = o;
+        }
       }
+      const bool keep = q < nq && nt >= 2 && e.y >= 0 && __int_as_float(e.z) <= __fmul_rn(ratio, __int_as_float(e.w));
       const unsigned long long b = __ballot(keep);
       const int before = __popcll(b & ((1ull << lane) - 1ull));
       if (lane == 0) wsum[wave] = __popcll(b);
@@ -680,14 +835,17 @@ __global__ __launch_bounds__(256) void compact_kernel(const ImgDev* __restrict__
 struct sfmhip_imageset {
   sfmhip_ctx* ctx;
   int n_images, dim, dtype, norm;
-  int kind, ks, sr;  // ks==0: no MFMA instantiation -> exact kernel only
+  int kind, ks, sr, nu;  // ks==0: no MFMA instantiation -> exact kernel only; nu = query tiles per wave
   std::vector<int> n_rows, n_pad;
   std::vector<ImgDev> h_imgs;
   std::vector<void*> owned_raw;
   ImgDev* d_imgs = nullptr;
   int8_t* d_tiles = nullptr;
-  unsigned* d_base = nullptr;
+  int* d_cin = nullptr;
   int* d_nq = nullptr;
+  int* d_perm = nullptr;
+  int* d_par = nullptr;
+  int* d_nodd = nullptr;
   int* d_tile_img = nullptr;
   int* d_tile_first = nullptr;
   int* d_nonintegral = nullptr;  // per image: the number (gen) of the prepare pass that found non-integer f32 values
@@ -710,8 +868,6 @@ struct sfmhip_matchplan {
   int* d_counts = nullptr;
   int *d_out_q = nullptr, *d_out_t = nullptr;
   float* d_out_d = nullptr;
-  int* d_fix_count = nullptr;
-  int2* d_fix_items = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   bool timed = false;
 };
@@ -745,6 +901,7 @@ extern "C" int sfmhip_imageset_create(sfmhip_ctx* ctx, int n_images, const int32
   s->kind = norm == SFMHIP_HAMMING ? KIND_U8_HAMMING : (dtype == SFMHIP_F32 ? KIND_F32_L2 : KIND_U8_L2);
   s->ks = pick_ks(s->kind, dim);
   s->sr = s->ks == 8 ? 128 : 256;
+  s->nu = s->ks == 8 ? 1 : 2;
   const int rb = 32 * (s->ks ? s->ks : 1);
   size_t tot_pad = 0;
   std::vector<int> tile_img, tile_first(n_images + 1, 0);
@@ -754,7 +911,9 @@ extern "C" int sfmhip_imageset_create(sfmhip_ctx* ctx, int n_images, const int32
       return SFMHIP_ERR_ARG;
     }
     s->n_rows.push_back(n_rows[i]);
-    const int pad = ((n_rows[i] + CHUNK_ROWS - 1) / CHUNK_ROWS) * CHUNK_ROWS;
+    // L2 kinds store the rows in parity order, the odd class padded to a tile boundary: up to 31 more positions
+    const int need = n_rows[i] ? n_rows[i] + (s->kind == KIND_U8_HAMMING ? 0 : TILE_ROWS - 1) : 0;
+    const int pad = (need + s->sr - 1) / s->sr * s->sr;
     s->n_pad.push_back(pad);
     s->maxq = std::max(s->maxq, n_rows[i]);
     tile_first[i] = (int)tile_img.size();
@@ -765,7 +924,9 @@ extern "C" int sfmhip_imageset_create(sfmhip_ctx* ctx, int n_images, const int32
   s->total_tiles = (int)tile_img.size();
   int rc = SFMHIP_OK;
   if ((rc = sfm_dev_alloc(&s->d_imgs, (size_t)n_images)) || (rc = sfm_dev_alloc(&s->d_tiles, tot_pad * rb)) ||
-      (rc = sfm_dev_alloc(&s->d_base, tot_pad)) || (rc = sfm_dev_alloc(&s->d_nq, tot_pad)) ||
+      (rc = sfm_dev_alloc(&s->d_cin, tot_pad)) || (rc = sfm_dev_alloc(&s->d_nq, tot_pad)) ||
+      (rc = sfm_dev_alloc(&s->d_perm, tot_pad)) || (rc = sfm_dev_alloc(&s->d_par, tot_pad)) ||
+      (rc = sfm_dev_alloc(&s->d_nodd, (size_t)n_images)) ||
       (rc = sfm_dev_alloc(&s->d_tile_img, tile_img.size())) ||
       (rc = sfm_dev_alloc(&s->d_tile_first, (size_t)n_images + 1)) ||
       (rc = sfm_dev_alloc(&s->d_nonintegral, (size_t)n_images))) {
@@ -782,8 +943,11 @@ extern "C" int sfmhip_imageset_create(sfmhip_ctx* ctx, int n_images, const int32
     ImgDev& I = s->h_imgs[i];
     I.raw = nullptr;
     I.tiles = s->d_tiles + off * rb;
-    I.base = s->d_base + off;
+    I.cin = s->d_cin + off;
     I.nq = s->d_nq + off;
+    I.perm = s->d_perm + off;
+    I.par = s->d_par + off;
+    I.nodd = s->d_nodd + i;
     I.n_rows = s->n_rows[i];
     I.n_pad = s->n_pad[i];
     off += s->n_pad[i];
@@ -821,6 +985,12 @@ template <int KS>
 static void launch_prepare(sfmhip_imageset* s) {
   const dim3 grid(s->total_tiles), block(32 * 2 * KS);
   hipStream_t st = s->ctx->stream;
+  // positions first: parity of the norms (L2 kinds), then one workgroup per image orders the rows
+  if (s->kind == KIND_F32_L2)
+    hipLaunchKernelGGL((parity_kernel<KIND_F32_L2>), grid, dim3(256), 0, st, s->d_imgs, s->d_tile_img, s->d_tile_first, s->dim);
+  else if (s->kind == KIND_U8_L2)
+    hipLaunchKernelGGL((parity_kernel<KIND_U8_L2>), grid, dim3(256), 0, st, s->d_imgs, s->d_tile_img, s->d_tile_first, s->dim);
+  hipLaunchKernelGGL(order_kernel, dim3(s->n_images), dim3(256), 0, st, s->d_imgs, s->kind == KIND_U8_HAMMING ? 0 : 1);
   if (s->kind == KIND_F32_L2)
     hipLaunchKernelGGL((prepare_kernel<KS, KIND_F32_L2>), grid, block, 0, st, s->d_imgs, s->d_tile_img, s->d_tile_first, s->dim, s->d_nonintegral, s->gen);
   else if (s->kind == KIND_U8_L2)
@@ -865,8 +1035,11 @@ extern "C" void sfmhip_imageset_destroy(sfmhip_imageset* s) {
     if (p) hipFree(p);
   hipFree(s->d_imgs);
   hipFree(s->d_tiles);
-  hipFree(s->d_base);
+  hipFree(s->d_cin);
   hipFree(s->d_nq);
+  hipFree(s->d_perm);
+  hipFree(s->d_par);
+  hipFree(s->d_nodd);
   hipFree(s->d_tile_img);
   hipFree(s->d_tile_first);
   hipFree(s->d_nonintegral);
@@ -875,7 +1048,7 @@ extern "C" void sfmhip_imageset_destroy(sfmhip_imageset* s) {
   delete s;
 }
 
-// work list: one workgroup per (pair, block of 8 query tiles).  Ordered so that the blocks a
+// work list: one workgroup per (pair, block of 8*nu query tiles: nu per wave).  Ordered so that the blocks a
 // round-robin dispatcher puts on one XCD (equal index mod 8) walk the same train image
 // together: train images are dealt to the 8 groups, each group sorted by train image.
 static void build_work_items(const sfmhip_imageset* s, const int32_t* pairs, int n_pairs, std::vector<WorkItem>& items) {
@@ -892,8 +1065,10 @@ static void build_work_items(const sfmhip_imageset* s, const int32_t* pairs, int
       cur_t = ti;
       cur_lane = (int)(std::min_element(load, load + 8) - load);
     }
-    const int nqt = (s->n_rows[qi] + TILE_ROWS - 1) / TILE_ROWS;
-    for (int t0 = 0; t0 < nqt; t0 += 8) {
+    // query tiles cover the positions: the rows plus the padding of the odd class (L2 kinds)
+    const int npos = s->n_rows[qi] + (s->kind == KIND_U8_HAMMING ? 0 : TILE_ROWS - 1);
+    const int nqt = std::min((npos + TILE_ROWS - 1) / TILE_ROWS, s->n_pad[qi] / TILE_ROWS);
+    for (int t0 = 0; t0 < nqt; t0 += 8 * s->nu) {
       lanes[cur_lane].push_back(WorkItem{p, t0});
       load[cur_lane] += (size_t)s->n_pad[ti];
     }
@@ -929,21 +1104,19 @@ extern "C" int sfmhip_matchplan_create(sfmhip_imageset* s, const int32_t* pairs,
   build_work_items(s, pairs, n_pairs, items);
   pl->n_items = (int)items.size();
   // room for any pair list of up to cap_pairs pairs (sfmhip_matchplan_set_pairs)
-  pl->cap_items = (size_t)pl->cap_pairs * (size_t)(((pl->maxq + TILE_ROWS - 1) / TILE_ROWS + 7) / 8);
+  pl->cap_items = (size_t)pl->cap_pairs * (size_t)(((pl->maxq + 2 * TILE_ROWS - 2) / TILE_ROWS + 8 * s->nu - 1) / (8 * s->nu));
   int rc = SFMHIP_OK;
   const size_t slots = (size_t)pl->cap_pairs * pl->maxq;
   if ((rc = sfm_dev_alloc(&pl->d_pairs, (size_t)pl->cap_pairs)) || (rc = sfm_dev_alloc(&pl->d_items, pl->cap_items)) ||
       (rc = sfm_dev_alloc(&pl->d_knn, slots)) || (rc = sfm_dev_alloc(&pl->d_counts, (size_t)pl->cap_pairs)) ||
       (rc = sfm_dev_alloc(&pl->d_out_q, slots)) || (rc = sfm_dev_alloc(&pl->d_out_t, slots)) ||
-      (rc = sfm_dev_alloc(&pl->d_out_d, slots)) || (rc = sfm_dev_alloc(&pl->d_fix_count, (size_t)1)) ||
-      (rc = sfm_dev_alloc(&pl->d_fix_items, (size_t)FIX_CAP))) {
+      (rc = sfm_dev_alloc(&pl->d_out_d, slots))) {
     sfmhip_matchplan_destroy(pl);
     return rc;
   }
   if (n_pairs) SFM_HIP_TRY(hipMemcpy(pl->d_pairs, pairs, sizeof(int2) * n_pairs, hipMemcpyHostToDevice));
   if (!items.empty()) SFM_HIP_TRY(hipMemcpy(pl->d_items, items.data(), sizeof(WorkItem) * items.size(), hipMemcpyHostToDevice));
   SFM_HIP_TRY(hipMemset(pl->d_counts, 0, sizeof(int) * pl->cap_pairs));
-  SFM_HIP_TRY(hipMemset(pl->d_fix_count, 0, sizeof(int)));  // (every run leaves it cleared: compact_kernel)
   for (auto& e : pl->ev) SFM_HIP_TRY(hipEventCreate(&e));
   *out = pl;
   return SFMHIP_OK;
@@ -973,17 +1146,14 @@ extern "C" int sfmhip_matchplan_set_pairs(sfmhip_matchplan* pl, const int32_t* p
   return SFMHIP_OK;
 }
 
-template <int KS, int MODE, int SR>
+template <int KS, int MODE, int NU, int SR>
 static int launch_knn(sfmhip_matchplan* pl) {
   sfmhip_imageset* s = pl->set;
   constexpr int LDS = 2 * (SR * 32 * KS + SR * 4);
-  static bool attr_set = false;
-  if (!attr_set) {
-    SFM_HIP_TRY(hipFuncSetAttribute((const void*)knn_mfma_kernel<KS, MODE, SR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((knn_mfma_kernel<KS, MODE, SR>), dim3(pl->n_items), dim3(256), LDS, s->ctx->stream, s->d_imgs,
-                     pl->d_pairs, pl->d_items, s->d_nonintegral, s->gen, pl->d_knn, pl->maxq, pl->d_fix_count, pl->d_fix_items);
+  // (per launch: the attribute belongs to the device's code object, and a context per device may share this process)
+  SFM_HIP_TRY(hipFuncSetAttribute((const void*)knn_kernel<KS, MODE, NU, SR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+  hipLaunchKernelGGL((knn_kernel<KS, MODE, NU, SR>), dim3(pl->n_items), dim3(512), LDS, s->ctx->stream, s->d_imgs,
+                     pl->d_pairs, pl->d_items, s->d_nonintegral, s->gen, s->dim, pl->d_knn, pl->maxq);
   SFM_HIP_TRY(hipGetLastError());
   return SFMHIP_OK;
 }
@@ -999,33 +1169,43 @@ extern "C" int sfmhip_matchplan_run_async(sfmhip_matchplan* pl, float ratio) {
     const bool mfma = s->ks != 0;
     if (mfma && pl->n_items > 0) {
       if (s->kind == KIND_U8_HAMMING) {
-        SFM_TRY((launch_knn<8, 1, 128>(pl)));
+        SFM_TRY((launch_knn<8, 1, 1, 128>(pl)));
       } else {
         switch (s->ks) {
-          case 1: SFM_TRY((launch_knn<1, 0, 256>(pl))); break;
-          case 2: SFM_TRY((launch_knn<2, 0, 256>(pl))); break;
-          case 4: SFM_TRY((launch_knn<4, 0, 256>(pl))); break;
-          case 8: SFM_TRY((launch_knn<8, 0, 128>(pl))); break;
+          case 1: SFM_TRY((launch_knn<1, 0, 2, 256>(pl))); break;
+          case 2: SFM_TRY((launch_knn<2, 0, 2, 256>(pl))); break;
+          case 4: SFM_TRY((launch_knn<4, 0, 2, 256>(pl))); break;
+          case 8: SFM_TRY((launch_knn<8, 0, 1, 128>(pl))); break;
         }
       }
     }
+    // pairs the MFMA kernel leaves alone: a non-integer-valued f32 image, or no MFMA instantiation
     const int force_all = mfma ? 0 : 1;
-    const int grid = std::min(std::max(pl->n_pairs, 256), 2048);
-    if (s->kind == KIND_F32_L2)
-      hipLaunchKernelGGL((knn_exact_kernel<KIND_F32_L2>), dim3(grid), dim3(256), 0, st, s->d_imgs, pl->d_pairs, pl->n_pairs,
-                         s->d_nonintegral, s->gen, force_all, s->dim, pl->d_knn, pl->maxq, pl->d_fix_count, pl->d_fix_items);
-    else if (s->kind == KIND_U8_L2)
-      hipLaunchKernelGGL((knn_exact_kernel<KIND_U8_L2>), dim3(grid), dim3(256), 0, st, s->d_imgs, pl->d_pairs, pl->n_pairs,
-                         s->d_nonintegral, s->gen, force_all, s->dim, pl->d_knn, pl->maxq, pl->d_fix_count, pl->d_fix_items);
-    else
-      hipLaunchKernelGGL((knn_exact_kernel<KIND_U8_HAMMING>), dim3(grid), dim3(256), 0, st, s->d_imgs, pl->d_pairs, pl->n_pairs,
-                         s->d_nonintegral, s->gen, force_all, s->dim, pl->d_knn, pl->maxq, pl->d_fix_count, pl->d_fix_items);
-    SFM_HIP_TRY(hipGetLastError());
+    if (force_all || s->kind == KIND_F32_L2) {
+      const int grid = std::min(std::max(pl->n_pairs, 256), 2048);
+      if (s->kind == KIND_F32_L2)
+        hipLaunchKernelGGL((knn_exact_kernel<KIND_F32_L2>), dim3(grid), dim3(256), 0, st, s->d_imgs, pl->d_pairs, pl->n_pairs,
+                           s->d_nonintegral, s->gen, force_all, s->dim, pl->d_knn, pl->maxq);
+      else if (s->kind == KIND_U8_L2)
+        hipLaunchKernelGGL((knn_exact_kernel<KIND_U8_L2>), dim3(grid), dim3(256), 0, st, s->d_imgs, pl->d_pairs, pl->n_pairs,
+                           s->d_nonintegral, s->gen, force_all, s->dim, pl->d_knn, pl->maxq);
+      else
+        hipLaunchKernelGGL((knn_exact_kernel<KIND_U8_HAMMING>), dim3(grid), dim3(256), 0, st, s->d_imgs, pl->d_pairs, pl->n_pairs,
+                           s->d_nonintegral, s->gen, force_all, s->dim, pl->d_knn, pl->maxq);
+      SFM_HIP_TRY(hipGetLastError());
+    }
   }
   if (timing) SFM_HIP_TRY(hipEventRecord(pl->ev[1], st));
   if (pl->n_pairs > 0) {
-    hipLaunchKernelGGL(compact_kernel, dim3(pl->n_pairs), dim3(256), 0, st, s->d_imgs, pl->d_pairs, pl->d_knn, pl->maxq,
-                       ratio, pl->d_counts, pl->d_out_q, pl->d_out_t, pl->d_out_d, pl->d_fix_count);
+    if (s->kind == KIND_F32_L2)
+      hipLaunchKernelGGL((compact_kernel<KIND_F32_L2>), dim3(pl->n_pairs), dim3(256), 0, st, s->d_imgs, pl->d_pairs, pl->d_knn,
+                         pl->maxq, s->dim, ratio, pl->d_counts, pl->d_out_q, pl->d_out_t, pl->d_out_d);
+    else if (s->kind == KIND_U8_L2)
+      hipLaunchKernelGGL((compact_kernel<KIND_U8_L2>), dim3(pl->n_pairs), dim3(256), 0, st, s->d_imgs, pl->d_pairs, pl->d_knn,
+                         pl->maxq, s->dim, ratio, pl->d_counts, pl->d_out_q, pl->d_out_t, pl->d_out_d);
+    else
+      hipLaunchKernelGGL((compact_kernel<KIND_U8_HAMMING>), dim3(pl->n_pairs), dim3(256), 0, st, s->d_imgs, pl->d_pairs, pl->d_knn,
+                         pl->maxq, s->dim, ratio, pl->d_counts, pl->d_out_q, pl->d_out_t, pl->d_out_d);
     SFM_HIP_TRY(hipGetLastError());
   }
   if (timing) SFM_HIP_TRY(hipEventRecord(pl->ev[2], st));
@@ -1116,8 +1296,6 @@ extern "C" void sfmhip_matchplan_destroy(sfmhip_matchplan* pl) {
   hipFree(pl->d_out_q);
   hipFree(pl->d_out_t);
   hipFree(pl->d_out_d);
-  hipFree(pl->d_fix_count);
-  hipFree(pl->d_fix_items);
   for (auto& e : pl->ev)
     if (e) hipEventDestroy(e);
   delete pl;
