@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "libsfmhip.so")
+# (SFMHIP_SO: a diagnostic build of the same library, e.g. scripts/build_match_variants.py)
+SO = os.environ.get("SFMHIP_SO") or os.path.join(HERE, "libsfmhip.so")
 
 F32, U8 = 0, 1
 L2, HAMMING = 0, 1

@@ -31,6 +31,7 @@
 #include <vector>
 #include <algorithm>
 #include <string.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -46,6 +47,16 @@ constexpr int EPOCH_TILES = 1 << TAG_BITS;  // train tiles per epoch (8192 rows)
 constexpr int TAG_MASK = EPOCH_TILES - 1;
 constexpr int FIX_FLAG = 1 << 30;    // in knn[].y: redo this query exactly (sqrtf merge range)
 constexpr int DIST_EMPTY = 0x7FFFFFFF;
+#ifndef SFM_DBG
+#define SFM_DBG 0  // diagnostic builds (scripts/build_match_variants.py): 1 no candidate loop, 2 no epilogue, 3 no MFMA, 4 stamps
+#endif
+#if SFM_DBG == 4
+// per workgroup (first 4096) and wave: s_memtime at 6 points + candidate-loop trips (sfmhip_dbg_read_stamps)
+__device__ unsigned long long g_stamps[4096 * 8 * 16];
+#define SFM_STAMP(i) do { if (blockIdx.x < 4096 && lane == 0) g_stamps[(blockIdx.x * 8 + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SFM_STAMP(i) do { } while (0)
+#endif
 
 // Pointers read out of the ImgDev records are generic to the compiler (flat_load, which also
 // ties up lgkmcnt next to the LDS reads); these casts tell it they are global memory.
@@ -69,6 +80,7 @@ struct ImgDev {
 struct WorkItem {
   int pair;
   int qtile0;
+  int qimg, timg;  // the pair's images (saves the k-NN kernel one dependent load)
 };
 
 // physical 16-byte chunk of logical chunk c of row r inside a 32-row tile with NC chunks/row:
@@ -275,20 +287,33 @@ __global__ void prepare_kernel(const ImgDev* __restrict__ imgs, const int* __res
   if (KIND == KIND_F32_L2 && !ok) nonintegral[img] = gen;  // (stamped with the prepare pass: no clearing between passes)
 }
 
+// sum over groups of NC consecutive lanes (NC = 2, 4, 8, 16), left in every lane of the group: DPP only
+template <int NC>
+__device__ __forceinline__ int group_sum(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);                   // quad_perm [1,0,3,2]
+  if (NC >= 4) x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
+  if (NC >= 8) x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true);     // row_half_mirror
+  if (NC >= 16) x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true);    // row_mirror
+  return x;
+}
+
 // ---------------------------------------------------------------- MFMA k-NN kernel
-struct Best2 {  // exact (squared distance, original train row) of the best two; DIST_EMPTY = none
-  int d0, i0, d1, i1;
+struct Best2 {  // exact (squared distance, position; original train row) of the best two; DIST_EMPTY = none
+  int d0, i0, x0, d1, i1, x1;
 };
 __device__ __forceinline__ bool lex_less(int da, int ia, int db, int ib) { return da < db || (da == db && ia < ib); }
-__device__ __forceinline__ void best2_insert(Best2& b, int d, int i) {
+__device__ __forceinline__ void best2_insert(Best2& b, int d, int i, int x) {
   if (lex_less(d, i, b.d0, b.i0)) {
     b.d1 = b.d0;
     b.i1 = b.i0;
+    b.x1 = b.x0;
     b.d0 = d;
     b.i0 = i;
+    b.x0 = x;
   } else if (lex_less(d, i, b.d1, b.i1)) {
     b.d1 = d;
     b.i1 = i;
+    b.x1 = x;
   }
 }
 
@@ -296,32 +321,38 @@ __device__ __forceinline__ void best2_insert(Best2& b, int d, int i) {
 // query tile): 16 slot maxima, then per tile a 7-op max3 tree, the tagged key and its insertion
 // into the lane's top-2 of tile maxima.  38 ops, executed in index order.
 template <int I>
-__device__ __forceinline__ void epi_op(const v16i& D0, const v16i& D1, int (&sl)[16], int& k0, int& k1, int (&T)[8],
+__device__ __forceinline__ void epi_op(const v16i& D0, const v16i& D1, int (&sl)[16], int& k0, int& k1, int (&T)[16],
                                        int tag0, int tag1) {
   if constexpr (I < 16) {
     sl[I] = imax3(sl[I], D0[I], D1[I]);
   } else {
     constexpr int J = (I - 16) % 11;
+    constexpr int B = (I - 16) < 11 ? 0 : 8;  // each tree has its own temporaries
     const v16i& D = (I - 16) < 11 ? D0 : D1;
     const int tag = (I - 16) < 11 ? tag0 : tag1;
-    if constexpr (J == 0) T[0] = imax3(D[0], D[1], D[2]);
-    if constexpr (J == 1) T[1] = imax3(D[3], D[4], D[5]);
-    if constexpr (J == 2) T[2] = imax3(D[6], D[7], D[8]);
-    if constexpr (J == 3) T[3] = imax3(D[9], D[10], D[11]);
-    if constexpr (J == 4) T[4] = imax3(D[12], D[13], D[14]);
-    if constexpr (J == 5) T[5] = imax3(T[0], T[1], T[2]);
-    if constexpr (J == 6) T[6] = imax3(T[3], T[4], D[15]);
-    if constexpr (J == 7) T[7] = max(T[5], T[6]);
-    if constexpr (J == 8) T[7] = (T[7] << TAG_BITS) | tag;
-    if constexpr (J == 9) k1 = imed3(k0, k1, T[7]);
-    if constexpr (J == 10) k0 = max(k0, T[7]);
+    if constexpr (J == 0) T[B + 0] = imax3(D[0], D[1], D[2]);
+    if constexpr (J == 1) T[B + 1] = imax3(D[3], D[4], D[5]);
+    if constexpr (J == 2) T[B + 2] = imax3(D[6], D[7], D[8]);
+    if constexpr (J == 3) T[B + 3] = imax3(D[9], D[10], D[11]);
+    if constexpr (J == 4) T[B + 4] = imax3(D[12], D[13], D[14]);
+    if constexpr (J == 5) T[B + 5] = imax3(T[B + 0], T[B + 1], T[B + 2]);
+    if constexpr (J == 6) T[B + 6] = imax3(T[B + 3], T[B + 4], D[15]);
+    if constexpr (J == 7) T[B + 7] = max(T[B + 5], T[B + 6]);
+    if constexpr (J == 8) T[B + 7] = (T[B + 7] << TAG_BITS) | tag;
+    if constexpr (J == 9) k1 = imed3(k0, k1, T[B + 7]);
+    if constexpr (J == 10) k0 = max(k0, T[B + 7]);
   }
 }
+// Issue order of the 38 ops: the tree of D0 first (D0 was finished four MFMAs before D1: nothing waits for
+// the matrix pipe), the dependent tails of both trees spread between the independent slot maxima.
+// ids: 0..15 slot maxima, 16..26 tree/key/insert of D0, 27..37 of D1.
+constexpr int EPI_ORDER[38] = {16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 0, 1,  2,
+                                          32, 33, 3,  4,  5,  34, 6,  7,  8,  9,  35, 10, 11, 12, 13, 36, 37, 14, 15};
 template <int LO, int HI>
-__device__ __forceinline__ void epi_range(const v16i& D0, const v16i& D1, int (&sl)[16], int& k0, int& k1, int (&T)[8],
+__device__ __forceinline__ void epi_range(const v16i& D0, const v16i& D1, int (&sl)[16], int& k0, int& k1, int (&T)[16],
                                           int tag0, int tag1) {
-  if constexpr (LO < HI) {
-    epi_op<LO>(D0, D1, sl, k0, k1, T, tag0, tag1);
+  if constexpr (LO < HI && LO < 38) {
+    epi_op<EPI_ORDER[LO]>(D0, D1, sl, k0, k1, T, tag0, tag1);
     epi_range<LO + 1, HI>(D0, D1, sl, k0, k1, T, tag0, tag1);
   }
 }
@@ -336,42 +367,60 @@ __device__ __forceinline__ void epi_range(const v16i& D0, const v16i& D1, int (&
 // MFMAs into two accumulator blocks); between its MFMAs ride the 38 epilogue ops of the
 // previously filled accumulator blocks, so a SIMD's matrix and vector pipes run side by side
 // (4.75 VALU ops per MFMA: scripts/ubench/epi_mix.hip, the gap stays MFMA-paced).
-template <int KS, int MODE, int NU, int SR>
-__global__ __launch_bounds__(512, 2) void knn_kernel(const ImgDev* __restrict__ imgs, const int2* __restrict__ pairs,
-                                                     const WorkItem* __restrict__ items,
-                                                     const int* __restrict__ nonintegral, int gen, int dim,
-                                                     int4* __restrict__ knn, int maxq) {
+template <int KS, int MODE, int NU, int SR, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restrict__ imgs,
+                                                         const WorkItem* __restrict__ items,
+                                                         const int* __restrict__ nonintegral, int gen, int dim,
+                                                         int4* __restrict__ knn, int maxq, int late_start) {
   constexpr int NC = 2 * KS;
   constexpr int RB = 32 * KS;
   constexpr int TILE_BYTES = TILE_ROWS * RB;
   constexpr int STAGE_ROW_BYTES = SR * RB;
-  constexpr int STAGE_BYTES = STAGE_ROW_BYTES + SR * 4;
+  constexpr int NT = NW * 64;                            // threads
+  constexpr int CIN_COPIES = (SR + NT - 1) / NT;           // every thread copies CIN_COPIES C inputs: no divergent copy code
+  constexpr int STAGE_BYTES = STAGE_ROW_BYTES + CIN_COPIES * NT * 4;
   constexpr int TILES = SR / TILE_ROWS;
   constexpr int TP = TILES / 2;                       // tile pairs per stage
-  constexpr int PIECES = STAGE_ROW_BYTES / (512 * 16);  // 16-byte pieces per thread per stage
+  constexpr int PIECES = STAGE_ROW_BYTES / (NT * 16);   // 16-byte pieces per thread per stage
+  constexpr int BATCH = KS <= 4 ? 4 : 2;                // candidate rows per lane resolved per round
   constexpr int NG = 2 * KS;                          // MFMAs (= op groups) per chain
   constexpr int STAGES_PER_EPOCH = EPOCH_TILES / TILES;
-  static_assert(PIECES >= 1 && TP >= 2 && TP % 2 == 0, "stage shape");
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  static_assert(PIECES >= 1 && TP >= 2 && TP % 2 == 0 && STAGES_PER_EPOCH % 2 == 0, "stage shape");
+  // Two separate LDS objects, not one array cut in two: only then can the compiler tell that the
+  // LDS-DMA filling one buffer does not alias the ds_reads of the other, and leave out the
+  // s_waitcnt vmcnt(0) it otherwise puts in front of every ds_read that follows an LDS-DMA
+  // (which would make the stage copy synchronous).  The stage loop is unrolled by two for it.
+  constexpr int BUF_BYTES = STAGE_BYTES > NW * 3072 ? STAGE_BYTES : NW * 3072;  // (3 KB of resolve scratch per wave)
+  __shared__ __attribute__((aligned(16))) unsigned char ldsA[BUF_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char ldsB[BUF_BYTES];
 
   const WorkItem it = items[blockIdx.x];
-  const int2 pr = pairs[it.pair];
-  if ((nonintegral[pr.x] == gen) | (nonintegral[pr.y] == gen)) return;  // left to the exact kernel
-  const ImgDev Q = imgs[pr.x];
-  const ImgDev T = imgs[pr.y];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((nonintegral[it.qimg] == gen) | (nonintegral[it.timg] == gen)) return;  // left to the exact kernel
+  const ImgDev Q = imgs[it.qimg];
+  const ImgDev T = imgs[it.timg];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: LDS-DMA targets and query tiles stay in SGPRs
   const int r = lane & 31, h = lane >> 5;
   const int nqt = Q.n_pad / TILE_ROWS;
-  int qt[NU];
+  int qt[NU], qtc[NU];  // query tiles of the wave; clamped to the image for the loads
 #pragma unroll
-  for (int u = 0; u < NU; ++u) qt[u] = it.qtile0 + NU * wave + u;
+  for (int u = 0; u < NU; ++u) {
+    qt[u] = it.qtile0 + NU * wave + u;
+    qtc[u] = qt[u] < Q.n_pad / TILE_ROWS ? qt[u] : (Q.n_pad >= TILE_ROWS ? Q.n_pad / TILE_ROWS - 1 : 0);
+  }
+  SFM_STAMP(0);
+  int dbg_trips = 0;
+  // Two workgroups share a CU (NW = 4).  Launched together they would stay in step -- both in the
+  // MFMA-bound sweep, then both in the memory-bound resolve.  The second set of resident workgroups
+  // starts late_start * 8 k cycles late, and every later workgroup inherits the phase of the one it replaces.
+  if (late_start > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+    for (int i = 0; i < late_start; ++i) __builtin_amdgcn_s_sleep(127);
 
   // query fragments (B operand): lane (r,h) holds bytes [32ks+16h, +16) of query row r
   v4i bq[NU][KS];
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    const int t = qt[u] < nqt ? qt[u] : (nqt > 0 ? nqt - 1 : 0);
-    g_v4i_p src = (g_v4i_p)(Q.tiles + (size_t)t * TILE_BYTES);
+    g_v4i_p src = (g_v4i_p)(Q.tiles + (size_t)qtc[u] * TILE_BYTES);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) bq[u][ks] = src[chunk_pos<NC>(r, 2 * ks + h)];
   }
@@ -391,11 +440,13 @@ __global__ __launch_bounds__(512, 2) void knn_kernel(const ImgDev* __restrict__ 
     const unsigned char* src = (const unsigned char*)T.tiles + (size_t)stage * STAGE_ROW_BYTES;
 #pragma unroll
     for (int i = 0; i < PIECES; ++i)
-      __builtin_amdgcn_global_load_lds((const SFM_GLOBAL void*)(src + (size_t)(i * 512 + tid) * 16),
-                                       (__attribute__((address_space(3))) void*)(dstb + i * 8192 + wave * 1024), 16, 0, 0);
-    if (wave < SR / 64)
-      __builtin_amdgcn_global_load_lds((const SFM_GLOBAL void*)(T.cin + (size_t)stage * SR + tid),
-                                       (__attribute__((address_space(3))) void*)(dstb + STAGE_ROW_BYTES + wave * 256), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((const SFM_GLOBAL void*)(src + (size_t)(i * NT + tid) * 16),
+                                       (__attribute__((address_space(3))) void*)(dstb + i * (NT * 16) + wave * 1024), 16, 0, 0);
+    // SR C inputs; threads beyond SR copy those of the next stage (the array is padded by 512)
+#pragma unroll
+    for (int i = 0; i < CIN_COPIES; ++i)
+      __builtin_amdgcn_global_load_lds((const SFM_GLOBAL void*)(T.cin + (size_t)stage * SR + i * NT + tid),
+                                       (__attribute__((address_space(3))) void*)(dstb + STAGE_ROW_BYTES + i * (NT * 4) + wave * 256), 4, 0, 0);
   };
   auto ld_afrag = [&](const unsigned char* tb, int ks) -> v4i {  // tb: the tile inside a stage buffer
     const int4 x = *(const int4*)(tb + aoff[ks]);
@@ -413,9 +464,8 @@ __global__ __launch_bounds__(512, 2) void knn_kernel(const ImgDev* __restrict__ 
     }
   };
 
-  Best2 res[NU];
-#pragma unroll
-  for (int u = 0; u < NU; ++u) res[u].d0 = res[u].d1 = DIST_EMPTY, res[u].i0 = res[u].i1 = 0x7FFFFFFF;
+  // (No per-lane state is kept across the sweep -- it would be spilled: the sweep uses the whole register
+  // budget.  An epoch's result goes to the k-NN buffer; a later epoch merges with what is there.)
   const int nodd_t = MODE == 0 ? *(g_i32_p)T.nodd : 0;
   const int nbits = dim * 8;
 
@@ -430,15 +480,15 @@ __global__ __launch_bounds__(512, 2) void knn_kernel(const ImgDev* __restrict__ 
       for (int e = 0; e < 16; ++e) sl[u][e] = HPAD;
     }
     if (ep0 > 0) __syncthreads();  // every wave is done with the stage buffers of the previous epoch
-    stage_copy(ep0, lds + (ep0 & 1) * STAGE_BYTES);
+    stage_copy(ep0, ldsA);         // (epochs start at even stages: STAGES_PER_EPOCH is even)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     v4i F0[KS], F1[KS];
     v16i C0, C1, X0, X1, Y0, Y1;
-    int TT[8];
+    int TT[16];
     {
-      const unsigned char* sb = lds + (ep0 & 1) * STAGE_BYTES;
+      const unsigned char* sb = ldsA;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) F0[ks] = ld_afrag(sb, ks);
 #pragma unroll
@@ -451,6 +501,7 @@ __global__ __launch_bounds__(512, 2) void knn_kernel(const ImgDev* __restrict__ 
     // tag of the first tile of the pair drained next; the first drain is the dummy one: its blocks hold HPAD,
     // so whatever (masked) tag it gets, its keys carry the value HPAD and never become candidates
     int tag = EPOCH_TILES - 1 + 2;
+    SFM_STAMP(1);
 
     // One chain: MFMAs of query tile UF against (F0, F1) into (FA, FB); the epilogue of (DA, DB)
     // (query tile UD, tile tags tag, tag-1) spread between them; with RELOAD, every fragment and C
@@ -459,7 +510,10 @@ __global__ __launch_bounds__(512, 2) void knn_kernel(const ImgDev* __restrict__ 
   do {                                                                                                      \
     _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_) {                                                     \
       const int ks_ = g_ % KS;                                                                              \
-      if (g_ < KS) FA = __builtin_amdgcn_mfma_i32_32x32x32_i8(F0[ks_], bq[UF][ks_], ks_ == 0 ? C0 : FA, 0, 0, 0); \
+      if (SFM_DBG == 3) {                                                                                   \
+        if (g_ < KS) FA[ks_] += F0[ks_][0] + C0[ks_];                                                       \
+        else FB[ks_] += F1[ks_][0] + C1[ks_];                                                               \
+      } else if (g_ < KS) FA = __builtin_amdgcn_mfma_i32_32x32x32_i8(F0[ks_], bq[UF][ks_], ks_ == 0 ? C0 : FA, 0, 0, 0); \
       else FB = __builtin_amdgcn_mfma_i32_32x32x32_i8(F1[ks_], bq[UF][ks_], ks_ == 0 ? C1 : FB, 0, 0, 0);  \
       if (RELOAD) {                                                                                         \
         if (g_ < KS) F0[ks_] = ld_afrag((NSB) + (NT0) * TILE_BYTES, ks_);                                   \
@@ -467,7 +521,7 @@ __global__ __launch_bounds__(512, 2) void knn_kernel(const ImgDev* __restrict__ 
         if (g_ == 0) ld_cin(NSB, NT0, C0);                                                                  \
         if (g_ == KS) ld_cin(NSB, NT1, C1);                                                                 \
       }                                                                                                     \
-      switch (g_) {                                                                                         \
+      if (SFM_DBG != 2) switch (g_) {                                                                       \
         SFM_EPI_CASES(DA, DB, UD)                                                                           \
       }                                                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                    \
@@ -481,9 +535,7 @@ __global__ __launch_bounds__(512, 2) void knn_kernel(const ImgDev* __restrict__ 
   SFM_EPI_CASE(8, DA, DB, UD) SFM_EPI_CASE(9, DA, DB, UD) SFM_EPI_CASE(10, DA, DB, UD) SFM_EPI_CASE(11, DA, DB, UD)   \
   SFM_EPI_CASE(12, DA, DB, UD) SFM_EPI_CASE(13, DA, DB, UD) SFM_EPI_CASE(14, DA, DB, UD) SFM_EPI_CASE(15, DA, DB, UD)
 
-    for (int s = ep0; s < ep1; ++s) {
-      const unsigned char* sb = lds + (s & 1) * STAGE_BYTES;
-      unsigned char* nb = lds + ((s & 1) ^ 1) * STAGE_BYTES;
+    auto stage = [&](int s, const unsigned char* sb, unsigned char* nb) __attribute__((always_inline)) {
       const bool more = s + 1 < ep1;
       // the other buffer was last read before the previous stage's barrier: refill it now
       if (more) stage_copy(s + 1, nb);
@@ -508,137 +560,285 @@ __global__ __launch_bounds__(512, 2) void knn_kernel(const ImgDev* __restrict__ 
           tag -= 2;
         }
       }
+    
+    };
+    for (int s = ep0; s < ep1; s += 2) {
+      stage(s, ldsA, ldsB);
+      if (s + 1 < ep1) stage(s + 1, ldsB, ldsA);
     }
+    SFM_STAMP(2);
     // the blocks filled last are still to be drained (Y for both shapes: TP is even)
     epi_range<0, 38>(Y0, Y1, sl[NU - 1], k0[NU - 1], k1[NU - 1], TT, tag & TAG_MASK, (tag - 1) & TAG_MASK);
 #undef SFM_CHAIN
 #undef SFM_EPI_CASES
 #undef SFM_EPI_CASE
 
-    // ---- resolve the epoch: exact (h, position) of the lane's candidates, then (d, row) per query
+    // ---- resolve the epoch: exact h of the lane's candidate rows, then (d, row) per query.
+    // Written as phases over the wave's NU query tiles, so that their shuffles, LDS round trips and
+    // global loads are in flight together (this part is latency-bound: two waves per SIMD).
+    // Per-wave scratch in the stage buffers (query tile u in buffer u): past the last stage's barrier
+    // nothing reads them any more (the reloads of the last chain fetch fragments that are never used).
+    int lane_p = lane;
+    asm volatile("" : "+v"(lane_p));  // (what follows is computed after the sweep, not kept in registers or spilled across it)
+    const int r_p = lane_p & 31, h_p = lane_p >> 5;
+    typedef __attribute__((address_space(3))) int* lds_vi_p;
+    // (one wave's LDS operations execute in order; the fences keep the compiler from moving them across a phase boundary)
+#define SFM_WAVE_LDS_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+    lds_vi_p wl[NU], wr[NU], wp[NU];  // packed candidate list, the rows' values, the rows' original indices
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      wl[u] = (lds_vi_p)(__attribute__((address_space(3))) unsigned char*)(u == 0 ? ldsA : ldsB) + wave * 768;
+      wr[u] = wl[u] + 256;
+      wp[u] = wl[u] + 512;
+    }
+    int cpos[NU][4], chv[NU][4], cix[NU][4], slot_[NU][4], count[NU];
+    bool cval[NU][4], cload[NU][4], known[NU];
+    int qrow[NU], nqq[NU];  // original row and norm of the lane's query (in flight during the phases)
+    int ovf[NU];            // the query goes to the exact kernel: too many equal candidates
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int q = qt[u] * TILE_ROWS + r_p;
+      qrow[u] = qt[u] < nqt ? ((g_i32_p)Q.perm)[q] : -1;
+      nqq[u] = (MODE == 0 && qt[u] < nqt) ? ((g_i32_p)Q.nq)[q] : 0;
+      ovf[u] = 0;
+    }
+    // phase A: thresholds, the slots that reach them, the candidate rows
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int bv0 = k0[u] >> TAG_BITS, bv1 = k1[u] >> TAG_BITS;  // the two largest tile maxima of the lane
-      const int tl0 = ep_tile0 + (EPOCH_TILES - 1) - (k0[u] & (EPOCH_TILES - 1));
-      const int tl1 = ep_tile0 + (EPOCH_TILES - 1) - (k1[u] & (EPOCH_TILES - 1));
+      const int tl0 = ep_tile0 + (EPOCH_TILES - 1) - (k0[u] & TAG_MASK);
+      const int tl1 = ep_tile0 + (EPOCH_TILES - 1) - (k1[u] & TAG_MASK);
       const int pb0 = __shfl_xor(bv0, 32), pb1 = __shfl_xor(bv1, 32);
       // second largest of the four tile maxima of the query's two lanes: four different rows, so a
       // lower bound of the query's second-best h.  Rows below it are out.
-      const int thr = max(min(bv0, pb0), max(bv1, pb1));
+      int thr = max(min(bv0, pb0), max(bv1, pb1));
       unsigned lt = 0;  // bit 15-e: slot e stays below thr
 #pragma unroll
       for (int e = 0; e < 16; ++e) lt = __builtin_amdgcn_alignbit(lt, (unsigned)(sl[u][e] - thr), 31);
-      const unsigned ge = ~lt & 0xFFFFu;
-      // (a tile maximum of HPAD is a padding tile, the dummy drain or an empty slot: no candidates there)
-      unsigned m0 = (bv0 >= thr && bv0 > HPAD) ? ge : 0u, m1 = (bv1 >= thr && bv1 > HPAD) ? ge : 0u;
-      // lane top-2 by (h descending, position ascending)
-      int h0 = HPAD - 1, p0 = 0x7FFFFFFF, h1 = HPAD - 1, p1 = 0x7FFFFFFF;
-      if (__popc(ge) == 1 && m1 == 0u && m0 != 0u) {
-        // one candidate: the lane's best row, whose value is known (the best row lies in the first
-        // tile that reaches the lane's maximum and in the only slot that reaches thr)
-        const int e = 15 - (31 - __clz((int)ge));
-        h0 = bv0;
-        p0 = tl0 * TILE_ROWS + 8 * (e >> 2) + 4 * h + (e & 3);
-        m0 = 0u;
+      unsigned ge = ~lt & 0xFFFFu;
+      if (__ballot(__popc(ge) > 2) != 0ull) {
+        // More than two slots reach thr -- typically the best two rows share a tile, which hides the
+        // second from the tile maxima.  The second largest slot maximum is another row's value, so
+        // it bounds the second-best h from below as well: tighten and redo the mask.
+        int a0 = HPAD - 1, a1 = HPAD - 1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          a1 = imed3(a0, a1, sl[u][e]);
+          a0 = max(a0, sl[u][e]);
+        }
+        thr = max(thr, a1);
+        lt = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) lt = __builtin_amdgcn_alignbit(lt, (unsigned)(sl[u][e] - thr), 31);
+        ge = ~lt & 0xFFFFu;
       }
-      while (__ballot((m0 | m1) != 0u) != 0ull) {
-        const bool have = (m0 | m1) != 0u;
-        const bool first = m0 != 0u;
-        const unsigned mm = first ? m0 : m1;
-        const int bit = have ? 31 - __clz((int)mm) : 0;
-        const int e = 15 - bit;
-        const int pos = have ? (first ? tl0 : tl1) * TILE_ROWS + 8 * (e >> 2) + 4 * h + (e & 3) : -1;
-        if (first) m0 &= ~(1u << bit);
-        else m1 &= ~(1u << bit);
-        const int ppos = __shfl_xor(pos, 32);
-        // this lane's byte ranges of both rows (its own candidate and its partner's)
-        int dot_me = 0, dot_pa = 0;
-        if (pos >= 0) {
-          g_v4i_p rowp = (g_v4i_p)(T.tiles + (size_t)(pos >> 5) * TILE_BYTES);
+      // (a tile maximum of HPAD is a padding tile, the dummy drain or an empty slot: no candidates there)
+      const bool t0in = bv0 >= thr && bv0 > HPAD, t1in = bv1 >= thr && bv1 > HPAD;
+      // The rows >= thr of the lane lie in (tiles tl0, tl1) x (slots that reach thr).  Two slots are
+      // resolved; more (only equal values do that now) sends the query to the exact kernel.
+      const int ns = __popc(ge);
+      const int bA = ns ? 31 - __clz((int)ge) : 0;
+      const unsigned ge2 = ge & ~(1u << bA);
+      const int bB = ns >= 2 ? 31 - __clz((int)ge2) : bA;
+      const int eA = 15 - bA, eB = 15 - bB;
+      const int rhoA = 8 * (eA >> 2) + 4 * h_p + (eA & 3), rhoB = 8 * (eB >> 2) + 4 * h_p + (eB & 3);
+      int over = (ns > 2 && (t0in || t1in)) ? 1 : 0;
+      over |= __shfl_xor(over, 32);
+      if (over) ovf[u] = 1;
+      cpos[u][0] = tl0 * TILE_ROWS + rhoA;
+      cpos[u][1] = tl0 * TILE_ROWS + rhoB;
+      cpos[u][2] = tl1 * TILE_ROWS + rhoA;
+      cpos[u][3] = tl1 * TILE_ROWS + rhoB;
+      cval[u][0] = t0in && ns >= 1;
+      cval[u][1] = t0in && ns >= 2;
+      cval[u][2] = t1in && ns >= 1;
+      cval[u][3] = t1in && ns >= 2;
+      // One slot reaches thr: every row >= thr of the lane sits in it, so a tile whose maximum reaches
+      // thr has that maximum in this slot -- row and value are known.  (tl0 is the first tile that
+      // reaches the lane's maximum, tl1 the first other tile that reaches bv1.)
+      known[u] = ns == 1;
+      chv[u][0] = known[u] ? bv0 : HPAD - 1;
+      chv[u][1] = HPAD - 1;
+      chv[u][2] = known[u] ? bv1 : HPAD - 1;
+      chv[u][3] = HPAD - 1;
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            const v4i x = rowp[chunk_pos<NC>(pos & 31, 2 * ks + h)];
+      for (int k = 0; k < 4; ++k) {
+        cval[u][k] = cval[u][k] && cpos[u][k] < T.n_pad && (!known[u] || (k & 1) == 0);
+        cload[u][k] = cval[u][k] && !known[u] && SFM_DBG != 1;
+        cix[u][k] = -1;
+        if (cval[u][k] && known[u]) cix[u][k] = ((g_i32_p)T.perm)[cpos[u][k]];  // (in flight during phase C)
+      }
+    }
+    SFM_STAMP(8);
+    // phase B: pack the rows to recompute into the wave's list
 #pragma unroll
-            for (int w = 0; w < 4; ++w) dot_me = __builtin_amdgcn_sdot4(x[w], bq[u][ks][w], dot_me, false);
+    for (int u = 0; u < NU; ++u) {
+      int base = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned long long bm = __ballot(cload[u][k]);
+        slot_[u][k] = base + __popcll(bm & ((1ull << lane_p) - 1ull));
+        if (cload[u][k]) wl[u][slot_[u][k]] = cpos[u][k] | (r_p << 27);
+        base += __popcll(bm);
+      }
+      count[u] = base;  // wave-uniform
+    }
+    SFM_WAVE_LDS_FENCE();
+    SFM_STAMP(9);
+#if SFM_DBG == 4
+    if (blockIdx.x < 4096 && lane == 0) g_stamps[(blockIdx.x * 8 + wave) * 16 + 13] = count[0];
+#endif
+    // phase C: listed rows are recomputed by the whole wave: NC consecutive lanes take one row per round
+    // (a 16-byte chunk per lane: one cache line per row), dot it with the same chunk of the query's
+    // row, reduce over the NC lanes (DPP) and hand value and original row index back through LDS.
+    {
+      constexpr int RPI = 64 / NC;   // rows per wave-instruction
+      constexpr int UNR = KS <= 4 ? 4 : 2;
+      const int grp = lane_p / NC, c = lane_p % NC;
+      int cmax = count[0];
+#pragma unroll
+      for (int u = 1; u < NU; ++u) cmax = max(cmax, count[u]);
+      for (int j0 = 0; j0 < cmax; j0 += RPI * UNR) {
+        v4i xt[NU][UNR], xq[NU][UNR];
+        int ci[NU][UNR], pi[NU][UNR];
+        unsigned ent[NU][UNR];  // position | query row << 27
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int i = 0; i < UNR; ++i) {
+            const int j = j0 + i * RPI + grp;
+            ent[u][i] = j < count[u] ? (unsigned)wl[u][j] : 0u;
           }
-          dot_me += ((g_i32_p)T.cin)[pos];
-        }
-        if (ppos >= 0) {
-          g_v4i_p rowp = (g_v4i_p)(T.tiles + (size_t)(ppos >> 5) * TILE_BYTES);
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            const v4i x = rowp[chunk_pos<NC>(ppos & 31, 2 * ks + h)];
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
-            for (int w = 0; w < 4; ++w) dot_pa = __builtin_amdgcn_sdot4(x[w], bq[u][ks][w], dot_pa, false);
+          for (int i = 0; i < UNR; ++i) {
+            xt[u][i] = xq[u][i] = v4i{0, 0, 0, 0};
+            ci[u][i] = 0;
+            pi[u][i] = -1;
+            if (j0 + i * RPI + grp < count[u]) {
+              const int ps = (int)(ent[u][i] & ((1u << 27) - 1u)), qr = (int)(ent[u][i] >> 27);
+              xt[u][i] = ((g_v4i_p)(T.tiles + (size_t)(ps >> 5) * TILE_BYTES))[chunk_pos<NC>(ps & 31, c)];
+              xq[u][i] = ((g_v4i_p)(Q.tiles + (size_t)qtc[u] * TILE_BYTES))[chunk_pos<NC>(qr, c)];
+              if (c == 0) {
+                ci[u][i] = ((g_i32_p)T.cin)[ps];
+                pi[u][i] = ((g_i32_p)T.perm)[ps];
+              }
+            }
           }
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int i = 0; i < UNR; ++i) {
+            int dot = ci[u][i];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) dot = __builtin_amdgcn_sdot4(xt[u][i][w], xq[u][i][w], dot, false);
+            dot = group_sum<NC>(dot);
+            const int j = j0 + i * RPI + grp;
+            if (c == 0 && j < count[u]) {
+              wr[u][j] = dot;
+              wp[u][j] = pi[u][i];
+            }
+          }
+      }
+    }
+    SFM_WAVE_LDS_FENCE();
+    SFM_STAMP(10);
+    // phase D: lane top-2 by (h descending, position ascending); phase E: distances, merge of the
+    // query's two lanes by (d, position) -- the same order as (d, original row): equal d means equal
+    // parity class, and positions keep the original order inside a class
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      int h0 = HPAD - 1, p0 = 0x7FFFFFFF, x0 = -1, h1 = HPAD - 1, p1 = 0x7FFFFFFF, x1 = -1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (cload[u][k]) {
+          chv[u][k] = wr[u][slot_[u][k]];
+          cix[u][k] = wp[u][slot_[u][k]];
         }
-        const int hv = dot_me + __shfl_xor(dot_pa, 32);
-        if (have) {
-          if (hv > h0 || (hv == h0 && pos < p0)) {
+        const int hv = chv[u][k], ps = cpos[u][k], ix = cix[u][k];
+        if (cval[u][k] && ix >= 0) {  // (a padding position is no row)
+          if (hv > h0 || (hv == h0 && ps < p0)) {
             h1 = h0;
             p1 = p0;
+            x1 = x0;
             h0 = hv;
-            p0 = pos;
-          } else if (hv > h1 || (hv == h1 && pos < p1)) {
+            p0 = ps;
+            x0 = ix;
+          } else if (hv > h1 || (hv == h1 && ps < p1)) {
             h1 = hv;
-            p1 = pos;
+            p1 = ps;
+            x1 = ix;
           }
         }
       }
-      // exact squared distance and original row of the lane's two; merge the query's two lanes
-      const int q = qt[u] * TILE_ROWS + r;
-      const int nqq = (MODE == 0 && qt[u] < nqt) ? ((g_i32_p)Q.nq)[q] : 0;
-      int d[2] = {DIST_EMPTY, DIST_EMPTY}, ix[2] = {0x7FFFFFFF, 0x7FFFFFFF};
-      const int hh[2] = {h0, h1}, pp[2] = {p0, p1};
+      int d[2];
+      const int hh[2] = {h0, h1}, pp[2] = {p0, p1}, xx[2] = {x0, x1};
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        if (hh[k] > HPAD && pp[k] < T.n_pad) {
-          const int row = ((g_i32_p)T.perm)[pp[k]];
-          if (row >= 0) {
-            ix[k] = row;
-            d[k] = MODE == 0 ? nqq - 2 * hh[k] - (pp[k] < nodd_t ? 1 : 0) : (nbits - hh[k]) >> 1;
-          }
-        }
+        d[k] = DIST_EMPTY;
+        if (hh[k] > HPAD) d[k] = MODE == 0 ? nqq[u] - 2 * hh[k] - (pp[k] < nodd_t ? 1 : 0) : (nbits - hh[k]) >> 1;
       }
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        best2_insert(res[u], d[k], ix[k]);
-      }
-      const int od0 = __shfl_xor(d[0], 32), oi0 = __shfl_xor(ix[0], 32);
-      const int od1 = __shfl_xor(d[1], 32), oi1 = __shfl_xor(ix[1], 32);
-      best2_insert(res[u], od0, oi0);
-      best2_insert(res[u], od1, oi1);
-    }
-  }
-
-  // emit
-#pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    const int q = qt[u] * TILE_ROWS + r;
-    if (h == 0 && qt[u] < nqt) {
-      const int qrow = ((g_i32_p)Q.perm)[q];
-      if (qrow >= 0) {
-        const Best2 m = res[u];
-        const bool v0 = m.d0 != DIST_EMPTY, v1 = m.d1 != DIST_EMPTY;
-        float d0, d1;
-        int fix = 0;
-        if (MODE == 0) {
-          d0 = sqrtf((float)m.d0);
-          d1 = sqrtf((float)m.d1);
-          if (v1 && m.d1 >= (1 << 22)) fix = FIX_FLAG;  // sqrtf may merge neighbouring integers: redone exactly
-        } else {
-          d0 = (float)m.d0;
-          d1 = (float)m.d1;
+      Best2 m;
+      m.d0 = m.d1 = DIST_EMPTY, m.i0 = m.i1 = 0x7FFFFFFF, m.x0 = m.x1 = -1;
+      best2_insert(m, d[0], pp[0], xx[0]);
+      best2_insert(m, d[1], pp[1], xx[1]);
+      const int od0 = __shfl_xor(d[0], 32), op0 = __shfl_xor(pp[0], 32), ox0 = __shfl_xor(xx[0], 32);
+      const int od1 = __shfl_xor(d[1], 32), op1 = __shfl_xor(pp[1], 32), ox1 = __shfl_xor(xx[1], 32);
+      best2_insert(m, od0, op0, ox0);
+      best2_insert(m, od1, op1, ox1);
+      // emit.  Between epochs the entry holds {row0, row1, d0, d1} as integers (an earlier epoch's rows have the
+      // lower indices: on equal d they stay); the last epoch turns it into the final {row0, row1|flag, dist bits}.
+      if (h_p == 0 && qrow[u] >= 0) {
+        int4* dst = &knn[(size_t)it.pair * maxq + qrow[u]];
+        if (ep0 > 0) {
+          const int4 pv = *dst;
+          Best2 a;
+          a.d0 = pv.z, a.x0 = pv.x, a.i0 = -2, a.d1 = pv.w, a.x1 = pv.y, a.i1 = -1;  // (positions below any of this epoch)
+          if (pv.y == FIX_FLAG) ovf[u] = 1;
+          if (m.d0 != DIST_EMPTY) best2_insert(a, m.d0, m.i0, m.x0);
+          if (m.d1 != DIST_EMPTY) best2_insert(a, m.d1, m.i1, m.x1);
+          m = a;
         }
         int4 o;
-        o.x = v0 ? m.i0 : -1;
-        o.y = (v1 ? m.i1 : -1) | (v1 ? fix : 0);
-        o.z = __float_as_int(v0 ? d0 : 3.402823466e+38f);
-        o.w = __float_as_int(v1 ? d1 : 3.402823466e+38f);
-        knn[(size_t)it.pair * maxq + qrow] = o;
+        if (ep1 < nstages) {
+          o.x = m.x0;
+          o.y = ovf[u] ? FIX_FLAG : m.x1;
+          o.z = m.d0;
+          o.w = m.d1;
+        } else {
+          const bool v0 = m.d0 != DIST_EMPTY, v1 = m.d1 != DIST_EMPTY;
+          float d0, d1;
+          int fix = 0;
+          if (MODE == 0) {
+            d0 = sqrtf((float)m.d0);
+            d1 = sqrtf((float)m.d1);
+            if (v1 && m.d1 >= (1 << 22)) fix = FIX_FLAG;  // sqrtf may merge neighbouring integers: redone exactly
+          } else {
+            d0 = (float)m.d0;
+            d1 = (float)m.d1;
+          }
+          o.x = v0 ? m.x0 : -1;
+          o.y = v1 ? (m.x1 | fix) : -1;
+          if (ovf[u]) o.y = FIX_FLAG;  // (any non-negative flagged value: the compaction kernel recomputes the query)
+          o.z = __float_as_int(v0 ? d0 : 3.402823466e+38f);
+          o.w = __float_as_int(v1 ? d1 : 3.402823466e+38f);
+        }
+        *dst = o;
       }
     }
+    SFM_STAMP(3);
+    SFM_STAMP(4);
   }
+
+  SFM_STAMP(5);
+#if SFM_DBG == 4
+  if (blockIdx.x < 4096 && lane == 0) {
+    g_stamps[(blockIdx.x * 8 + wave) * 16 + 14] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
+    g_stamps[(blockIdx.x * 8 + wave) * 16 + 15] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+  }
+  if (blockIdx.x < 4096 && lane == 0) g_stamps[(blockIdx.x * 8 + wave) * 16 + 6] = dbg_trips;
+#endif
 }
 
 // ---------------------------------------------------------------- exact (VALU) k-NN
@@ -836,6 +1036,8 @@ struct sfmhip_imageset {
   sfmhip_ctx* ctx;
   int n_images, dim, dtype, norm;
   int kind, ks, sr, nu;  // ks==0: no MFMA instantiation -> exact kernel only; nu = query tiles per wave
+  int nw = 4;            // waves per k-NN workgroup: 4 (two workgroups per CU, which drift half a sweep apart) or 8
+  int late_start = 0;    // nw == 4: start delay of the second set of resident workgroups, in 8 k cycles
   std::vector<int> n_rows, n_pad;
   std::vector<ImgDev> h_imgs;
   std::vector<void*> owned_raw;
@@ -902,6 +1104,8 @@ extern "C" int sfmhip_imageset_create(sfmhip_ctx* ctx, int n_images, const int32
   s->ks = pick_ks(s->kind, dim);
   s->sr = s->ks == 8 ? 128 : 256;
   s->nu = s->ks == 8 ? 1 : 2;
+  if (const char* e = getenv("SFMHIP_KNN_NW")) s->nw = atoi(e) == 8 ? 8 : 4;          // (tuning knobs, not API)
+  if (const char* e = getenv("SFMHIP_KNN_LATE")) s->late_start = std::max(0, atoi(e));
   const int rb = 32 * (s->ks ? s->ks : 1);
   size_t tot_pad = 0;
   std::vector<int> tile_img, tile_first(n_images + 1, 0);
@@ -924,7 +1128,7 @@ extern "C" int sfmhip_imageset_create(sfmhip_ctx* ctx, int n_images, const int32
   s->total_tiles = (int)tile_img.size();
   int rc = SFMHIP_OK;
   if ((rc = sfm_dev_alloc(&s->d_imgs, (size_t)n_images)) || (rc = sfm_dev_alloc(&s->d_tiles, tot_pad * rb)) ||
-      (rc = sfm_dev_alloc(&s->d_cin, tot_pad)) || (rc = sfm_dev_alloc(&s->d_nq, tot_pad)) ||
+      (rc = sfm_dev_alloc(&s->d_cin, tot_pad + 512)) || (rc = sfm_dev_alloc(&s->d_nq, tot_pad)) ||
       (rc = sfm_dev_alloc(&s->d_perm, tot_pad)) || (rc = sfm_dev_alloc(&s->d_par, tot_pad)) ||
       (rc = sfm_dev_alloc(&s->d_nodd, (size_t)n_images)) ||
       (rc = sfm_dev_alloc(&s->d_tile_img, tile_img.size())) ||
@@ -1048,7 +1252,7 @@ extern "C" void sfmhip_imageset_destroy(sfmhip_imageset* s) {
   delete s;
 }
 
-// work list: one workgroup per (pair, block of 8*nu query tiles: nu per wave).  Ordered so that the blocks a
+// work list: one workgroup per (pair, block of nw*nu query tiles: nu per wave).  Ordered so that the blocks a
 // round-robin dispatcher puts on one XCD (equal index mod 8) walk the same train image
 // together: train images are dealt to the 8 groups, each group sorted by train image.
 static void build_work_items(const sfmhip_imageset* s, const int32_t* pairs, int n_pairs, std::vector<WorkItem>& items) {
@@ -1068,8 +1272,8 @@ static void build_work_items(const sfmhip_imageset* s, const int32_t* pairs, int
     // query tiles cover the positions: the rows plus the padding of the odd class (L2 kinds)
     const int npos = s->n_rows[qi] + (s->kind == KIND_U8_HAMMING ? 0 : TILE_ROWS - 1);
     const int nqt = std::min((npos + TILE_ROWS - 1) / TILE_ROWS, s->n_pad[qi] / TILE_ROWS);
-    for (int t0 = 0; t0 < nqt; t0 += 8 * s->nu) {
-      lanes[cur_lane].push_back(WorkItem{p, t0});
+    for (int t0 = 0; t0 < nqt; t0 += s->nw * s->nu) {
+      lanes[cur_lane].push_back(WorkItem{p, t0, qi, ti});
       load[cur_lane] += (size_t)s->n_pad[ti];
     }
   }
@@ -1104,7 +1308,7 @@ extern "C" int sfmhip_matchplan_create(sfmhip_imageset* s, const int32_t* pairs,
   build_work_items(s, pairs, n_pairs, items);
   pl->n_items = (int)items.size();
   // room for any pair list of up to cap_pairs pairs (sfmhip_matchplan_set_pairs)
-  pl->cap_items = (size_t)pl->cap_pairs * (size_t)(((pl->maxq + 2 * TILE_ROWS - 2) / TILE_ROWS + 8 * s->nu - 1) / (8 * s->nu));
+  pl->cap_items = (size_t)pl->cap_pairs * (size_t)(((pl->maxq + 2 * TILE_ROWS - 2) / TILE_ROWS + s->nw * s->nu - 1) / (s->nw * s->nu));
   int rc = SFMHIP_OK;
   const size_t slots = (size_t)pl->cap_pairs * pl->maxq;
   if ((rc = sfm_dev_alloc(&pl->d_pairs, (size_t)pl->cap_pairs)) || (rc = sfm_dev_alloc(&pl->d_items, pl->cap_items)) ||
@@ -1149,11 +1353,12 @@ extern "C" int sfmhip_matchplan_set_pairs(sfmhip_matchplan* pl, const int32_t* p
 template <int KS, int MODE, int NU, int SR>
 static int launch_knn(sfmhip_matchplan* pl) {
   sfmhip_imageset* s = pl->set;
-  constexpr int LDS = 2 * (SR * 32 * KS + SR * 4);
-  // (per launch: the attribute belongs to the device's code object, and a context per device may share this process)
-  SFM_HIP_TRY(hipFuncSetAttribute((const void*)knn_kernel<KS, MODE, NU, SR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-  hipLaunchKernelGGL((knn_kernel<KS, MODE, NU, SR>), dim3(pl->n_items), dim3(512), LDS, s->ctx->stream, s->d_imgs,
-                     pl->d_pairs, pl->d_items, s->d_nonintegral, s->gen, s->dim, pl->d_knn, pl->maxq);
+  if (s->nw == 4)
+    hipLaunchKernelGGL((knn_kernel<KS, MODE, NU, SR, 4>), dim3(pl->n_items), dim3(256), 0, s->ctx->stream, s->d_imgs,
+                       pl->d_items, s->d_nonintegral, s->gen, s->dim, pl->d_knn, pl->maxq, s->late_start);
+  else
+    hipLaunchKernelGGL((knn_kernel<KS, MODE, NU, SR, 8>), dim3(pl->n_items), dim3(512), 0, s->ctx->stream, s->d_imgs,
+                       pl->d_items, s->d_nonintegral, s->gen, s->dim, pl->d_knn, pl->maxq, 0);
   SFM_HIP_TRY(hipGetLastError());
   return SFMHIP_OK;
 }
@@ -1326,3 +1531,9 @@ extern "C" int sfmhip_match_knn2(sfmhip_ctx* ctx, const void* q, int nq, const v
   sfmhip_imageset_destroy(s);
   return rc;
 }
+
+#if SFM_DBG == 4
+extern "C" int sfmhip_dbg_read_stamps(void* out, size_t bytes) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), bytes) == hipSuccess ? 0 : -1;
+}
+#endif
