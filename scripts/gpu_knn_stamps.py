@@ -27,6 +27,7 @@ print("workgroup span median", np.median(wg))
 # phases of the resolve (both query tiles together)
 print("drain+thr+mask+candidates (2->8)", np.median(st[:, :, 8] - st[:, :, 2]), " list pack (8->9)", np.median(st[:, :, 9] - st[:, :, 8]),
       " rows+dots (9->10)", np.median(st[:, :, 10] - st[:, :, 9]), " read back + merge (10->3)", np.median(st[:, :, 3] - st[:, :, 10]),
+      " [rows: issue (9->11)", np.median(st[:, :, 11] - st[:, :, 9]), "wait (11->12)", np.median(st[:, :, 12] - st[:, :, 11]), "dots (12->10)", np.median(st[:, :, 10] - st[:, :, 12]), "]",
       " rows in the list of tile 0: median", np.median(st[:, :, 13]), "max", st[:, :, 13].max())
 
 # co-residency: workgroups by CU (HW_ID: wave_id[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]; XCC_ID[3:0])

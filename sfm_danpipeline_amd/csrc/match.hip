@@ -290,7 +290,7 @@ __global__ void prepare_kernel(const ImgDev* __restrict__ imgs, const int* __res
 // sum over groups of NC consecutive lanes (NC = 2, 4, 8, 16), left in every lane of the group: DPP only
 template <int NC>
 __device__ __forceinline__ int group_sum(int x) {
-  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);                   // quad_perm [1,0,3,2]
+  if (NC >= 2) x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
   if (NC >= 4) x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
   if (NC >= 8) x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true);     // row_half_mirror
   if (NC >= 16) x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true);    // row_mirror
@@ -390,9 +390,12 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
   // LDS-DMA filling one buffer does not alias the ds_reads of the other, and leave out the
   // s_waitcnt vmcnt(0) it otherwise puts in front of every ds_read that follows an LDS-DMA
   // (which would make the stage copy synchronous).  The stage loop is unrolled by two for it.
-  constexpr int BUF_BYTES = STAGE_BYTES > NW * 3072 ? STAGE_BYTES : NW * 3072;  // (3 KB of resolve scratch per wave)
-  __shared__ __attribute__((aligned(16))) unsigned char ldsA[BUF_BYTES];
-  __shared__ __attribute__((aligned(16))) unsigned char ldsB[BUF_BYTES];
+  // (resolve scratch per wave and query tile: 2 KB of lists + a copy of the query tile; tile u of a wave in buffer u)
+  constexpr int SCRATCH_W = 2048 + TILE_ROWS * RB;
+  constexpr int BUFA_BYTES = STAGE_BYTES > NW * SCRATCH_W ? STAGE_BYTES : NW * SCRATCH_W;
+  constexpr int BUFB_BYTES = (NU < 2 || STAGE_BYTES > NW * SCRATCH_W) ? STAGE_BYTES : NW * SCRATCH_W;
+  __shared__ __attribute__((aligned(16))) unsigned char ldsA[BUFA_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char ldsB[BUFB_BYTES];
 
   const WorkItem it = items[blockIdx.x];
   if ((nonintegral[it.qimg] == gen) | (nonintegral[it.timg] == gen)) return;  // left to the exact kernel
@@ -574,8 +577,9 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
 #undef SFM_EPI_CASE
 
     // ---- resolve the epoch: exact h of the lane's candidate rows, then (d, row) per query.
-    // Written as phases over the wave's NU query tiles, so that their shuffles, LDS round trips and
-    // global loads are in flight together (this part is latency-bound: two waves per SIMD).
+    // Written as phases over the wave's NU query tiles, branch-free where it can be, so that their
+    // shuffles, LDS round trips and global loads are in flight together: this part runs once per
+    // sweep on two waves per SIMD and is bound by instruction count and latency, not by throughput.
     // Per-wave scratch in the stage buffers (query tile u in buffer u): past the last stage's barrier
     // nothing reads them any more (the reloads of the last chain fetch fragments that are never used).
     int lane_p = lane;
@@ -584,23 +588,32 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
     typedef __attribute__((address_space(3))) int* lds_vi_p;
     // (one wave's LDS operations execute in order; the fences keep the compiler from moving them across a phase boundary)
 #define SFM_WAVE_LDS_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-    lds_vi_p wl[NU], wr[NU], wp[NU];  // packed candidate list, the rows' values, the rows' original indices
+    lds_vi_p wl[NU], wr[NU];  // packed list of the rows to recompute (256 entries), their values
+    __attribute__((address_space(3))) unsigned char* wq[NU];  // the wave's query tile, in the tile image's layout
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      wl[u] = (lds_vi_p)(__attribute__((address_space(3))) unsigned char*)(u == 0 ? ldsA : ldsB) + wave * 768;
+      __attribute__((address_space(3))) unsigned char* ws =
+          (__attribute__((address_space(3))) unsigned char*)(u == 0 ? ldsA : ldsB) + wave * SCRATCH_W;
+      wl[u] = (lds_vi_p)ws;
       wr[u] = wl[u] + 256;
-      wp[u] = wl[u] + 512;
+      wq[u] = ws + 2048;
+      // (the query rows are in registers, half a row per lane: through LDS every lane can reach any of them,
+      // and the recompute below reads half as many bytes from the vector cache)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        *(__attribute__((address_space(3))) v4i*)(wq[u] + chunk_pos<NC>(r_p, 2 * ks + h_p) * 16) = bq[u][ks];
     }
-    int cpos[NU][4], chv[NU][4], cix[NU][4], slot_[NU][4], count[NU];
-    bool cval[NU][4], cload[NU][4], known[NU];
+    constexpr int SH = (NC == 16) ? 0 : (NC == 8) ? 1 : (NC == 4) ? 2 : 3;  // (the swizzle of chunk_pos)
+    int cpos[NU][4], chv[NU][4], slot_[NU][4], count[NU];
+    bool cval[NU][4], cload[NU][4];
     int qrow[NU], nqq[NU];  // original row and norm of the lane's query (in flight during the phases)
     int ovf[NU];            // the query goes to the exact kernel: too many equal candidates
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      const int q = qt[u] * TILE_ROWS + r_p;
-      qrow[u] = qt[u] < nqt ? ((g_i32_p)Q.perm)[q] : -1;
-      nqq[u] = (MODE == 0 && qt[u] < nqt) ? ((g_i32_p)Q.nq)[q] : 0;
-      ovf[u] = 0;
+      const int q = qtc[u] * TILE_ROWS + r_p;
+      qrow[u] = ((g_i32_p)Q.perm)[q];
+      nqq[u] = ((g_i32_p)Q.nq)[q];
+      if (qt[u] >= nqt) qrow[u] = -1;  // (a query tile beyond the image: the wave swept a copy of the last one)
     }
     // phase A: thresholds, the slots that reach them, the candidate rows
 #pragma unroll
@@ -612,10 +625,13 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
       // second largest of the four tile maxima of the query's two lanes: four different rows, so a
       // lower bound of the query's second-best h.  Rows below it are out.
       int thr = max(min(bv0, pb0), max(bv1, pb1));
-      unsigned lt = 0;  // bit 15-e: slot e stays below thr
+      unsigned lta = 0, ltb = 0;  // bit 7-e / 7-(e-8): slot e stays below thr (two chains: shorter dependency)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) lt = __builtin_amdgcn_alignbit(lt, (unsigned)(sl[u][e] - thr), 31);
-      unsigned ge = ~lt & 0xFFFFu;
+      for (int e = 0; e < 8; ++e) {
+        lta = __builtin_amdgcn_alignbit(lta, (unsigned)(sl[u][e] - thr), 31);
+        ltb = __builtin_amdgcn_alignbit(ltb, (unsigned)(sl[u][e + 8] - thr), 31);
+      }
+      unsigned ge = ~((lta << 8) | ltb) & 0xFFFFu;  // bit 15-e: slot e reaches thr
       if (__ballot(__popc(ge) > 2) != 0ull) {
         // More than two slots reach thr -- typically the best two rows share a tile, which hides the
         // second from the tile maxima.  The second largest slot maximum is another row's value, so
@@ -627,24 +643,31 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
           a0 = max(a0, sl[u][e]);
         }
         thr = max(thr, a1);
-        lt = 0;
+        lta = ltb = 0;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) lt = __builtin_amdgcn_alignbit(lt, (unsigned)(sl[u][e] - thr), 31);
-        ge = ~lt & 0xFFFFu;
+        for (int e = 0; e < 8; ++e) {
+          lta = __builtin_amdgcn_alignbit(lta, (unsigned)(sl[u][e] - thr), 31);
+          ltb = __builtin_amdgcn_alignbit(ltb, (unsigned)(sl[u][e + 8] - thr), 31);
+        }
+        ge = ~((lta << 8) | ltb) & 0xFFFFu;
       }
       // (a tile maximum of HPAD is a padding tile, the dummy drain or an empty slot: no candidates there)
       const bool t0in = bv0 >= thr && bv0 > HPAD, t1in = bv1 >= thr && bv1 > HPAD;
       // The rows >= thr of the lane lie in (tiles tl0, tl1) x (slots that reach thr).  Two slots are
       // resolved; more (only equal values do that now) sends the query to the exact kernel.
       const int ns = __popc(ge);
-      const int bA = ns ? 31 - __clz((int)ge) : 0;
+      const int bA = 31 - __clz((int)(ge | 1u));
       const unsigned ge2 = ge & ~(1u << bA);
       const int bB = ns >= 2 ? 31 - __clz((int)ge2) : bA;
       const int eA = 15 - bA, eB = 15 - bB;
       const int rhoA = 8 * (eA >> 2) + 4 * h_p + (eA & 3), rhoB = 8 * (eB >> 2) + 4 * h_p + (eB & 3);
       int over = (ns > 2 && (t0in || t1in)) ? 1 : 0;
       over |= __shfl_xor(over, 32);
-      if (over) ovf[u] = 1;
+      ovf[u] = over;
+      // One slot reaches thr: every row >= thr of the lane sits in it, so a tile whose maximum reaches
+      // thr has that maximum in this slot -- row and value are known.  (tl0 is the first tile that
+      // reaches the lane's maximum, tl1 the first other tile that reaches bv1.)
+      const bool known = ns == 1;
       cpos[u][0] = tl0 * TILE_ROWS + rhoA;
       cpos[u][1] = tl0 * TILE_ROWS + rhoB;
       cpos[u][2] = tl1 * TILE_ROWS + rhoA;
@@ -653,20 +676,14 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
       cval[u][1] = t0in && ns >= 2;
       cval[u][2] = t1in && ns >= 1;
       cval[u][3] = t1in && ns >= 2;
-      // One slot reaches thr: every row >= thr of the lane sits in it, so a tile whose maximum reaches
-      // thr has that maximum in this slot -- row and value are known.  (tl0 is the first tile that
-      // reaches the lane's maximum, tl1 the first other tile that reaches bv1.)
-      known[u] = ns == 1;
-      chv[u][0] = known[u] ? bv0 : HPAD - 1;
+      chv[u][0] = known ? bv0 : HPAD - 1;
       chv[u][1] = HPAD - 1;
-      chv[u][2] = known[u] ? bv1 : HPAD - 1;
+      chv[u][2] = known ? bv1 : HPAD - 1;
       chv[u][3] = HPAD - 1;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        cval[u][k] = cval[u][k] && cpos[u][k] < T.n_pad && (!known[u] || (k & 1) == 0);
-        cload[u][k] = cval[u][k] && !known[u] && SFM_DBG != 1;
-        cix[u][k] = -1;
-        if (cval[u][k] && known[u]) cix[u][k] = ((g_i32_p)T.perm)[cpos[u][k]];  // (in flight during phase C)
+        cval[u][k] = cval[u][k] && cpos[u][k] < T.n_pad;
+        cload[u][k] = cval[u][k] && !known && SFM_DBG != 1;
       }
     }
     SFM_STAMP(8);
@@ -688,105 +705,104 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
 #if SFM_DBG == 4
     if (blockIdx.x < 4096 && lane == 0) g_stamps[(blockIdx.x * 8 + wave) * 16 + 13] = count[0];
 #endif
-    // phase C: listed rows are recomputed by the whole wave: NC consecutive lanes take one row per round
-    // (a 16-byte chunk per lane: one cache line per row), dot it with the same chunk of the query's
-    // row, reduce over the NC lanes (DPP) and hand value and original row index back through LDS.
+    // phase C: the listed rows are recomputed LPR lanes to a row, two 16-byte chunks per lane (a row's lanes
+    // read one cache line together: the texture addresser, not the arithmetic, bounds this phase).  Train
+    // row chunk p (physical order) holds logical chunk p ^ key(train row), which the query's row keeps
+    // at physical chunk p ^ key(train) ^ key(query).
     {
-      constexpr int RPI = 64 / NC;   // rows per wave-instruction
-      constexpr int UNR = KS <= 4 ? 4 : 2;
-      const int grp = lane_p / NC, c = lane_p % NC;
+      constexpr int LPR = NC >= 2 ? NC / 2 : 1;  // lanes per row
+      constexpr int CPL = NC / LPR;              // chunks per lane
+      constexpr int RPS = 64 / LPR;              // rows per step
+      constexpr int STEPS = 64 / RPS;            // steps that cover 64 rows
+      const int grp = lane_p / LPR, c = lane_p % LPR;
       int cmax = count[0];
 #pragma unroll
       for (int u = 1; u < NU; ++u) cmax = max(cmax, count[u]);
-      for (int j0 = 0; j0 < cmax; j0 += RPI * UNR) {
-        v4i xt[NU][UNR], xq[NU][UNR];
-        int ci[NU][UNR], pi[NU][UNR];
-        unsigned ent[NU][UNR];  // position | query row << 27
+      for (int j0 = 0; j0 < cmax; j0 += 64) {
+        v4i xt[NU][STEPS][CPL], xq[NU][STEPS][CPL];
+        int ci[NU][STEPS];
 #pragma unroll
         for (int u = 0; u < NU; ++u)
 #pragma unroll
-          for (int i = 0; i < UNR; ++i) {
-            const int j = j0 + i * RPI + grp;
-            ent[u][i] = j < count[u] ? (unsigned)wl[u][j] : 0u;
-          }
+          for (int st = 0; st < STEPS; ++st) {
+            const int j = j0 + st * RPS + grp;
+            unsigned ent = (unsigned)wl[u][j & 255];  // position | query row << 27
+            if (j >= count[u]) ent = 0u;              // (row 0 of the image: fetched, not used)
+            const unsigned ps = ent & ((1u << 27) - 1u), qr = ent >> 27;
+            const unsigned x = ((ps >> SH) ^ (qr >> SH)) & (unsigned)(NC - 1);
+            const unsigned char* trow = (const unsigned char*)T.tiles + ps * (unsigned)RB;
+            const __attribute__((address_space(3))) unsigned char* qrw = wq[u] + qr * (unsigned)RB;
 #pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-          for (int i = 0; i < UNR; ++i) {
-            xt[u][i] = xq[u][i] = v4i{0, 0, 0, 0};
-            ci[u][i] = 0;
-            pi[u][i] = -1;
-            if (j0 + i * RPI + grp < count[u]) {
-              const int ps = (int)(ent[u][i] & ((1u << 27) - 1u)), qr = (int)(ent[u][i] >> 27);
-              xt[u][i] = ((g_v4i_p)(T.tiles + (size_t)(ps >> 5) * TILE_BYTES))[chunk_pos<NC>(ps & 31, c)];
-              xq[u][i] = ((g_v4i_p)(Q.tiles + (size_t)qtc[u] * TILE_BYTES))[chunk_pos<NC>(qr, c)];
-              if (c == 0) {
-                ci[u][i] = ((g_i32_p)T.cin)[ps];
-                pi[u][i] = ((g_i32_p)T.perm)[ps];
-              }
+            for (int i = 0; i < CPL; ++i) {
+              const unsigned p_ = (unsigned)(c + i * LPR);
+              xt[u][st][i] = *(g_v4i_p)(trow + p_ * 16);
+              xq[u][st][i] = *(const __attribute__((address_space(3))) v4i*)(qrw + ((p_ ^ x) << 4));
             }
+            ci[u][st] = ((g_i32_p)T.cin)[ps];
           }
+        SFM_STAMP(11);
+#if SFM_DBG == 4
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SFM_STAMP(12);
+#endif
 #pragma unroll
         for (int u = 0; u < NU; ++u)
 #pragma unroll
-          for (int i = 0; i < UNR; ++i) {
-            int dot = ci[u][i];
+          for (int st = 0; st < STEPS; ++st) {
+            int dot = 0;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) dot = __builtin_amdgcn_sdot4(xt[u][i][w], xq[u][i][w], dot, false);
-            dot = group_sum<NC>(dot);
-            const int j = j0 + i * RPI + grp;
-            if (c == 0 && j < count[u]) {
-              wr[u][j] = dot;
-              wp[u][j] = pi[u][i];
-            }
+            for (int i = 0; i < CPL; ++i)
+#pragma unroll
+              for (int w = 0; w < 4; ++w) dot = __builtin_amdgcn_sdot4(xt[u][st][i][w], xq[u][st][i][w], dot, false);
+            dot = group_sum<LPR>(dot) + ci[u][st];
+            wr[u][(j0 + st * RPS + grp) & 255] = dot;  // (every lane of the group writes the same value)
           }
       }
     }
     SFM_WAVE_LDS_FENCE();
     SFM_STAMP(10);
-    // phase D: lane top-2 by (h descending, position ascending); phase E: distances, merge of the
-    // query's two lanes by (d, position) -- the same order as (d, original row): equal d means equal
-    // parity class, and positions keep the original order inside a class
+    // phase D: lane top-2 by (h descending, position ascending) as 64-bit keys; phase E: distances, merge of
+    // the query's two lanes by (d, position) -- the same order as (d, original row): equal d means equal
+    // parity class, and positions keep the original order inside a class -- then the rows' original indices
+    long long best[NU][2];  // query level: (d << 32 | position), ascending; 0x7FFF...: none
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      int h0 = HPAD - 1, p0 = 0x7FFFFFFF, x0 = -1, h1 = HPAD - 1, p1 = 0x7FFFFFFF, x1 = -1;
+      long long key[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (cload[u][k]) {
-          chv[u][k] = wr[u][slot_[u][k]];
-          cix[u][k] = wp[u][slot_[u][k]];
-        }
-        const int hv = chv[u][k], ps = cpos[u][k], ix = cix[u][k];
-        if (cval[u][k] && ix >= 0) {  // (a padding position is no row)
-          if (hv > h0 || (hv == h0 && ps < p0)) {
-            h1 = h0;
-            p1 = p0;
-            x1 = x0;
-            h0 = hv;
-            p0 = ps;
-            x0 = ix;
-          } else if (hv > h1 || (hv == h1 && ps < p1)) {
-            h1 = hv;
-            p1 = ps;
-            x1 = ix;
-          }
-        }
+        if (cload[u][k]) chv[u][k] = wr[u][slot_[u][k]];
+        const int hv = cval[u][k] ? chv[u][k] : HPAD - 1;
+        key[k] = ((long long)hv << 32) | (unsigned)(0x7FFFFFFF - cpos[u][k]);  // larger = better
       }
-      int d[2];
-      const int hh[2] = {h0, h1}, pp[2] = {p0, p1}, xx[2] = {x0, x1};
+      const long long a = max(key[0], key[1]), b = min(key[0], key[1]);
+      const long long c = max(key[2], key[3]), dd = min(key[2], key[3]);
+      const long long l0 = max(a, c), l1 = max(min(a, c), max(b, dd));
+      long long dk[2];
+      const long long lk[2] = {l0, l1};
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        d[k] = DIST_EMPTY;
-        if (hh[k] > HPAD) d[k] = MODE == 0 ? nqq[u] - 2 * hh[k] - (pp[k] < nodd_t ? 1 : 0) : (nbits - hh[k]) >> 1;
+        const int hv = (int)(lk[k] >> 32), ps = 0x7FFFFFFF - (int)(unsigned)lk[k];
+        const int d = MODE == 0 ? nqq[u] - 2 * hv - (ps < nodd_t ? 1 : 0) : (nbits - hv) >> 1;
+        dk[k] = hv > HPAD ? (((long long)d << 32) | (unsigned)ps) : 0x7FFFFFFFFFFFFFFFll;  // smaller = better
       }
+      const long long o0 = __shfl_xor(dk[0], 32), o1 = __shfl_xor(dk[1], 32);
+      best[u][0] = min(dk[0], o0);
+      best[u][1] = min(max(dk[0], o0), min(dk[1], o1));
+    }
+    int x0[NU], x1[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const unsigned p0 = (unsigned)best[u][0], p1 = (unsigned)best[u][1];
+      x0[u] = ((g_i32_p)T.perm)[p0 < (unsigned)T.n_pad ? p0 : 0u];
+      x1[u] = ((g_i32_p)T.perm)[p1 < (unsigned)T.n_pad ? p1 : 0u];
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
       Best2 m;
-      m.d0 = m.d1 = DIST_EMPTY, m.i0 = m.i1 = 0x7FFFFFFF, m.x0 = m.x1 = -1;
-      best2_insert(m, d[0], pp[0], xx[0]);
-      best2_insert(m, d[1], pp[1], xx[1]);
-      const int od0 = __shfl_xor(d[0], 32), op0 = __shfl_xor(pp[0], 32), ox0 = __shfl_xor(xx[0], 32);
-      const int od1 = __shfl_xor(d[1], 32), op1 = __shfl_xor(pp[1], 32), ox1 = __shfl_xor(xx[1], 32);
-      best2_insert(m, od0, op0, ox0);
-      best2_insert(m, od1, op1, ox1);
+      m.d0 = (int)(best[u][0] >> 32), m.i0 = (int)(unsigned)best[u][0], m.x0 = x0[u];
+      m.d1 = (int)(best[u][1] >> 32), m.i1 = (int)(unsigned)best[u][1], m.x1 = x1[u];
+      if (best[u][0] == 0x7FFFFFFFFFFFFFFFll || m.x0 < 0) m.d0 = DIST_EMPTY, m.i0 = 0x7FFFFFFF, m.x0 = -1;  // (a padding position is no row)
+      if (best[u][1] == 0x7FFFFFFFFFFFFFFFll || m.x1 < 0) m.d1 = DIST_EMPTY, m.i1 = 0x7FFFFFFF, m.x1 = -1;
       // emit.  Between epochs the entry holds {row0, row1, d0, d1} as integers (an earlier epoch's rows have the
       // lower indices: on equal d they stay); the last epoch turns it into the final {row0, row1|flag, dist bits}.
       if (h_p == 0 && qrow[u] >= 0) {
