@@ -15,6 +15,7 @@ L = _lib.lib()
 L.sfmhip_dbg_read_stamps.argtypes = [C.c_void_p, C.c_size_t]
 assert L.sfmhip_dbg_read_stamps(buf.ctypes.data, buf.nbytes) == 0
 nwav = int(os.environ.get("SFMHIP_KNN_NW", "8"))
+print('queries redone exactly by the compaction kernel (3 sweeps):', int(buf[-1]), ' of them overflow-flagged:', int(buf[-2]))
 st = buf.reshape(4096, 8, 16).astype(np.int64)[:, :nwav, :]
 d = np.diff(st[:, :, :6], axis=2)
 names = ["prologue(bq, first stage)", "main loop", "drain+resolve u0", "resolve u1", "emit"]

@@ -46,9 +46,13 @@ constexpr int TAG_BITS = 8;          // tile tag in the low bits of a tile-maxim
 constexpr int EPOCH_TILES = 1 << TAG_BITS;  // train tiles per epoch (8192 rows): structures are resolved per epoch
 constexpr int TAG_MASK = EPOCH_TILES - 1;
 constexpr int FIX_FLAG = 1 << 30;    // in knn[].y: redo this query exactly (sqrtf merge range)
+constexpr int FIX_GRID = 1024;       // workgroups of knn_fixup_kernel
+constexpr int FIX_CAP = 1 << 20;     // flagged queries that are also LISTED, for a one-wave-per-query fix-up kernel;
+                                     // beyond it they stay flagged in-band and the compaction kernel redoes them
 constexpr int DIST_EMPTY = 0x7FFFFFFF;
+constexpr int HCHUNK = 128;  // Hamming kernel: rows per tie-break chunk (7 index bits in the key)
 #ifndef SFM_DBG
-#define SFM_DBG 0  // diagnostic builds (scripts/build_match_variants.py): 1 no candidate loop, 2 no epilogue, 3 no MFMA, 4 stamps
+#define SFM_DBG 0  // diagnostic builds (scripts/build_match_variants.py): 1 no candidate loop, 2 no epilogue, 3 no MFMA, 4 stamps, 5 no exact redo
 #endif
 #if SFM_DBG == 4
 // per workgroup (first 4096) and wave: s_memtime at 6 points + candidate-loop trips (sfmhip_dbg_read_stamps)
@@ -217,7 +221,7 @@ __global__ void prepare_kernel(const ImgDev* __restrict__ imgs, const int* __res
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int k = c * 16 + e;
-      v[e] = (valid && k < nbits) ? (((bits >> e) & 1u) ? 1 : -1) : 0;
+      v[e] = (valid && k < nbits) ? (((bits >> e) & 1u) ? 8 : -8) : 0;  // (+-8: the products of the keyed kernel are +-64)
     }
   } else {
     // the lane's 16 elements: four 16-byte loads (f32) / one (u8) when the chunk lies inside the
@@ -279,7 +283,8 @@ __global__ void prepare_kernel(const ImgDev* __restrict__ imgs, const int* __res
   *dst = out;
   if (c == 0) {
     int ci;
-    if (KIND == KIND_U8_HAMMING) ci = valid ? 0 : HPAD;     // h = q.t = nbits - 2 hamming
+    if (KIND == KIND_U8_HAMMING)  // key base of knn_keyed_kernel: key = base - 64 q.t = 128 hamming + (row mod 128)
+      ci = ((valid ? dim * 8 * 64 : (dim * 8 + 1) * 128)) | (pos & (HCHUNK - 1));
     else ci = valid ? -((n2 + 1) >> 1) : HPAD;              // h = q.t - ceil(||t||^2 / 2)
     I.cin[pos] = ci;
     I.nq[pos] = valid ? n2 : 0;
@@ -371,7 +376,8 @@ template <int KS, int MODE, int NU, int SR, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restrict__ imgs,
                                                          const WorkItem* __restrict__ items,
                                                          const int* __restrict__ nonintegral, int gen, int dim,
-                                                         int4* __restrict__ knn, int maxq, int late_start) {
+                                                         int4* __restrict__ knn, int maxq, int late_start,
+                                                         int* __restrict__ fix_count, int2* __restrict__ fix_items) {
   constexpr int NC = 2 * KS;
   constexpr int RB = 32 * KS;
   constexpr int TILE_BYTES = TILE_ROWS * RB;
@@ -839,6 +845,10 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
           if (ovf[u]) o.y = FIX_FLAG;  // (any non-negative flagged value: the compaction kernel recomputes the query)
           o.z = __float_as_int(v0 ? d0 : 3.402823466e+38f);
           o.w = __float_as_int(v1 ? d1 : 3.402823466e+38f);
+          if (o.y >= 0 && (o.y & FIX_FLAG)) {
+            const int k = atomicAdd(fix_count, 1);
+            if (k < FIX_CAP) fix_items[k] = make_int2(it.pair, qrow[u]);
+          }
         }
         *dst = o;
       }
@@ -856,6 +866,307 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
   if (blockIdx.x < 4096 && lane == 0) g_stamps[(blockIdx.x * 8 + wave) * 16 + 6] = dbg_trips;
 #endif
 }
+
+// ---------------------------------------------------------------- MFMA k-NN kernel, Hamming
+// Binary rows are stored as +-8 bytes.  With the query fragments negated the i8 MFMA yields
+// C - 64 q.t, and with C = 64 nbits + (row mod 128) that IS the key (128 hamming + row-in-chunk):
+// minima of unsigned keys order by (distance, lower train index) = cv::batchDistance's insertion
+// rule, at two VALU ops per distance (v_med3_u32 + v_min_u32) and nothing to build.  Integer
+// distances tie all the time, so the value-only structures of the L2 kernel are no use here.
+constexpr int HIB = 7;
+constexpr unsigned KEY_EMPTY = 0xFFFFFFFFu;
+__device__ __forceinline__ unsigned umin_(unsigned a, unsigned b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
+struct Top2 {
+  unsigned s0, s1;  // key >> HIB of best / 2nd best (0xFFFFFFFF = empty)
+  int j0, j1;       // their train rows
+};
+
+__device__ __forceinline__ void chunk_merge(Top2& g, unsigned k0, unsigned k1, int cb) {
+  // candidates of a later chunk: on equal distance the earlier (already held) row wins
+  const unsigned ns0 = k0 >> HIB, ns1 = k1 >> HIB;
+  const int nj0 = cb + (int)(k0 & (HCHUNK - 1)), nj1 = cb + (int)(k1 & (HCHUNK - 1));
+  const bool e0 = (k0 == KEY_EMPTY), e1 = (k1 == KEY_EMPTY);
+  const unsigned a0 = e0 ? KEY_EMPTY : ns0, a1 = e1 ? KEY_EMPTY : ns1;
+  if (a0 < g.s0) {
+    if (a1 < g.s0) {
+      g.s1 = a1;
+      g.j1 = nj1;
+    } else {
+      g.s1 = g.s0;
+      g.j1 = g.j0;
+    }
+    g.s0 = a0;
+    g.j0 = nj0;
+  } else if (a0 < g.s1) {
+    g.s1 = a0;
+    g.j1 = nj0;
+  }
+}
+
+__device__ __forceinline__ bool lex_less_u(unsigned sa, int ja, unsigned sb, int jb) {
+  return sa < sb || (sa == sb && ja < jb);
+}
+
+// Workgroup = 4 waves; wave w owns query tiles qtile0+2w, +2w+1 (64 queries, B fragments stay in
+// registers for the whole kernel) and sweeps every train tile of the pair's train image.  Train
+// tiles are staged through LDS (two stage buffers: two LDS objects, so that the LDS-DMA of one does
+// not make the compiler wait before the ds_reads of the other), 16 accumulator registers = 16
+// train rows of one query per lane.  "Units" (train tile x query tile) are software-pipelined: the
+// MFMA chain of unit n+1 is issued between the top-2 insertions of unit n.
+template <int KS, int SR>
+__global__ __launch_bounds__(256, 2) void knn_keyed_kernel(const ImgDev* __restrict__ imgs,
+                                                           const WorkItem* __restrict__ items, int dim,
+                                                           int4* __restrict__ knn, int maxq) {
+  constexpr int MODE = 1;
+  constexpr int NC = 2 * KS;
+  constexpr int RB = 32 * KS;
+  constexpr int STAGE_ROW_BYTES = SR * RB;
+  constexpr int STAGE_BYTES = STAGE_ROW_BYTES + SR * 4;
+  constexpr int TILES = SR / TILE_ROWS;
+  constexpr int PIECES = STAGE_ROW_BYTES / 4096;  // 16-byte pieces per thread per stage
+  constexpr int HALF = PIECES > 1 ? PIECES / 2 : 1;
+  __shared__ __attribute__((aligned(16))) unsigned char ldsA[STAGE_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char ldsB[STAGE_BYTES];
+
+  const WorkItem it = items[blockIdx.x];
+  const ImgDev Q = imgs[it.qimg];
+  const ImgDev T = imgs[it.timg];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int nqt = (Q.n_rows + TILE_ROWS - 1) / TILE_ROWS;
+  const int qt[2] = {it.qtile0 + 2 * wave, it.qtile0 + 2 * wave + 1};
+
+  // query fragments (B operand): lane (r,h) holds bytes [32ks+16h, +16) of query row r
+  v4i bq[2][KS];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int t = qt[u] < nqt ? qt[u] : (nqt > 0 ? nqt - 1 : 0);
+    g_v4i_p src = (g_v4i_p)(Q.tiles + (size_t)t * (TILE_ROWS * RB));
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      v4i x = src[chunk_pos<NC>(r, 2 * ks + h)];
+      // bytes are +8, -8 or 0 (padding): negate them in place (0x08 * 30 = 0xF0 flips 0x08 <-> 0xF8)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) x[w] ^= (int)(((unsigned)x[w] & 0x08080808u) * 30u);
+      bq[u][ks] = x;
+    }
+  }
+
+  // per-lane LDS byte offsets of the A fragments inside a tile, and of the key bases
+  int aoff[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) aoff[ks] = chunk_pos<NC>(r, 2 * ks + h) * 16;
+  const int boff = STAGE_ROW_BYTES + h * 16;
+
+  Top2 g[2];
+  unsigned k0[2], k1[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    g[u].s0 = g[u].s1 = KEY_EMPTY;
+    g[u].j0 = g[u].j1 = -1;
+    k0[u] = k1[u] = KEY_EMPTY;
+  }
+
+  const int nstages = T.n_pad / SR;
+  const int tid = threadIdx.x;
+
+  // Stage copy: the tile image is already in LDS order, so a stage is a linear copy; LDS-DMA
+  // (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs, no ds_write) moves it.
+  auto stage_copy = [&](int stage, unsigned char* dstb) {
+    const unsigned char* src = (const unsigned char*)T.tiles + (size_t)stage * STAGE_ROW_BYTES;
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i)
+      __builtin_amdgcn_global_load_lds((const SFM_GLOBAL void*)(src + (size_t)(i * 256 + tid) * 16),
+                                       (__attribute__((address_space(3))) void*)(dstb + i * 4096 + wave * 1024), 16, 0, 0);
+    if (wave < SR / 64)
+      __builtin_amdgcn_global_load_lds((const SFM_GLOBAL void*)(T.cin + (size_t)stage * SR + tid),
+                                       (__attribute__((address_space(3))) void*)(dstb + STAGE_ROW_BYTES + wave * 256), 4, 0, 0);
+  };
+  stage_copy(0, ldsA);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // one step of the MFMA chain of (fragments fr, query tile u): ks-th K slice
+#define SFM_MFMA(ACC, FR, u, ks, BS) \
+  ACC = __builtin_amdgcn_mfma_i32_32x32x32_i8(FR[ks], bq[u][ks], (ks) == 0 ? BS : ACC, 0, 0, 0)
+  // top-2 insertion of accumulator element e of query tile u
+#define SFM_INS(ACC, u, e)                                                             \
+  do {                                                                                     \
+    const unsigned key_ = (unsigned)ACC[e];                 /* the accumulator is the key */ \
+    const unsigned n1_ = umax_(umin_(k0[u], k1[u]), umin_(umax_(k0[u], k1[u]), key_)); /* v_med3_u32 */ \
+    k0[u] = umin_(k0[u], key_);                                                            \
+    k1[u] = n1_;                                                                           \
+    asm volatile("" : "+v"(k0[u]), "+v"(k1[u])); /* no min/max re-association across elements */ \
+  } while (0)
+  auto ld_afrag = [&](const unsigned char* sb, int tl, int ks) -> v4i {
+    const int4 x = *(const int4*)(sb + tl * (TILE_ROWS * RB) + aoff[ks]);
+    return v4i{x.x, x.y, x.z, x.w};
+  };
+  auto ld_bases = [&](const unsigned char* sb, int tl, int gq, v16i& bs) {
+    const int4 x = *(const int4*)(sb + boff + (tl * TILE_ROWS + 8 * gq) * 4);
+    bs[4 * gq] = x.x;
+    bs[4 * gq + 1] = x.y;
+    bs[4 * gq + 2] = x.z;
+    bs[4 * gq + 3] = x.w;
+  };
+
+  // MFMA and VALU of a SIMD do not overlap here: the epilogue is VALU-issue-bound (3 ops per
+  // distance: scripts/ubench/valu_rate.hip measures time = VALU issue + 8 cycles per MFMA whatever
+  // the interleave), and a wave that issues a dependent MFMA chain back to back stalls in order
+  // on the matrix pipe.  So per train tile the 2*KS MFMAs of the NEXT tile (both query tiles)
+  // are spread one per group through the 96 insertion ops of the CURRENT tile, the insertions of
+  // the two query tiles alternate (two independent dependency chains per wave), and the LDS
+  // fragment / key-base reads of the tile after ride along.  Groups are pinned by sched_barrier.
+  constexpr int MPG = (KS + 3) / 4;  // MFMAs per group and query tile
+#define SFM_GROUP(g_, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, do_mfma, do_frag)              \
+  do {                                                                                         \
+    if (do_mfma) {                                                                             \
+      _Pragma("unroll") for (int j_ = 0; j_ < MPG; ++j_) {                                     \
+        const int ks_ = ((g_) & 3) * MPG + j_;                                                 \
+        if (ks_ < KS) {                                                                        \
+          if ((g_) < 4) SFM_MFMA(NA0, FN, 0, ks_, BN);                                         \
+          else SFM_MFMA(NA1, FN, 1, ks_, BN);                                                  \
+        }                                                                                      \
+      }                                                                                        \
+      if ((g_) >= 4) {                                                                         \
+        if (do_frag) ld_bases(SB, (tl) + 2, (g_) - 4, BC); /* C inputs of the chain after next */ \
+      }                                                                                        \
+      else if (do_frag) {                                                                      \
+        _Pragma("unroll") for (int j_ = 0; j_ < MPG; ++j_)                                     \
+          if ((g_) * MPG + j_ < KS) FNN[(g_) * MPG + j_] = ld_afrag(SB, (tl) + 2, (g_) * MPG + j_); \
+      }                                                                                        \
+    }                                                                                          \
+    SFM_INS(CA0, 0, 2 * (g_));                                                                 \
+    SFM_INS(CA1, 1, 2 * (g_));                                                                 \
+    SFM_INS(CA0, 0, 2 * (g_) + 1);                                                             \
+    SFM_INS(CA1, 1, 2 * (g_) + 1);                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+  } while (0)
+#define SFM_BODY(SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_)                        \
+  do {                                                                                         \
+    SFM_GROUP(0, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
+    SFM_GROUP(1, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
+    SFM_GROUP(2, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
+    SFM_GROUP(3, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
+    SFM_GROUP(4, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
+    SFM_GROUP(5, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
+    SFM_GROUP(6, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
+    SFM_GROUP(7, SB, tl, CA0, CA1, NA0, NA1, FN, FNN, BC, BN, mf_, fr_);                       \
+  } while (0)
+
+  // fragments ping-pong between fa / fb, key bases between ba / bb, accumulators between
+  // (A0, A1) and (B0, B1): tile tl inserts from one pair while tile tl+1 accumulates in the
+  // other.  The pipeline runs across stages: one workgroup barrier per stage, placed before the
+  // stage's last tile body, whose MFMAs already read tile 0 of the next stage.
+  static_assert(TILES == 4 || TILES == 8, "stage = 4 or 8 train tiles");
+  v4i fa[KS], fb[KS];
+  v16i ba, bb;  // key bases = C inputs of the chains (ba: the tile being inserted was started from it; bb: the next)
+  v16i A0, A1, B0, B1;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) fa[ks] = ld_afrag(ldsA, 0, ks);
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) ld_bases(ldsA, 0, gq, ba);
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) ld_bases(ldsA, 1, gq, bb);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) SFM_MFMA(A0, fa, 0, ks, ba);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) SFM_MFMA(A1, fa, 1, ks, ba);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) fb[ks] = ld_afrag(ldsA, 1, ks);
+  __builtin_amdgcn_sched_barrier(0);
+
+  auto stage = [&](int s, const unsigned char* sb, unsigned char* nb) __attribute__((always_inline)) {
+    const bool more = s + 1 < nstages;
+    // the other buffer was last read before the previous stage's barrier: refill it now
+    if (more) stage_copy(s + 1, nb);
+
+    SFM_BODY(sb, 0, A0, A1, B0, B1, fb, fa, ba, bb, true, true);
+    SFM_BODY(sb, 1, B0, B1, A0, A1, fa, fb, bb, ba, true, true);
+    if (TILES == 8) {
+      SFM_BODY(sb, 2, A0, A1, B0, B1, fb, fa, ba, bb, true, true);
+      SFM_BODY(sb, 3, B0, B1, A0, A1, fa, fb, bb, ba, true, true);
+      SFM_BODY(sb, 4, A0, A1, B0, B1, fb, fa, ba, bb, true, true);
+      SFM_BODY(sb, 5, B0, B1, A0, A1, fa, fb, bb, ba, true, true);
+    }
+    // tile TILES-2: its MFMAs take the last tile of this stage; nothing of this stage left to prefetch
+    SFM_BODY(sb, TILES - 2, A0, A1, B0, B1, fb, fa, ba, bb, true, false);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the next stage has landed
+    __syncthreads();
+    // tile TILES-1: MFMAs on tile 0 of the next stage (fragments fetched now), prefetch of its tile 1
+    if (more) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) fa[ks] = ld_afrag(nb, 0, ks);
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) ld_bases(nb, 0, gq, ba);  // C inputs of the next stage's first chain
+    }
+    SFM_BODY(nb, -1, B0, B1, A0, A1, fa, fb, bb, ba, more, more);
+    // tie-break chunk boundary: fold the 8-bit-indexed keys into the running (distance, row)
+    if (((s + 1) * SR) % HCHUNK == 0) {
+      const int cb = ((s * SR) / HCHUNK) * HCHUNK;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        chunk_merge(g[u], k0[u], k1[u], cb);
+        k0[u] = k1[u] = KEY_EMPTY;
+      }
+    }
+  };
+  for (int s = 0; s < nstages; s += 2) {
+    stage(s, ldsA, ldsB);
+    if (s + 1 < nstages) stage(s + 1, ldsB, ldsA);
+  }
+#undef SFM_BODY
+#undef SFM_GROUP
+#undef SFM_INS
+#undef SFM_MFMA
+
+  // merge the two half-waves (rows 4h.. of each 8-row group) and emit
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    Top2 p;
+    p.s0 = __shfl_xor(g[u].s0, 32);
+    p.s1 = __shfl_xor(g[u].s1, 32);
+    p.j0 = __shfl_xor(g[u].j0, 32);
+    p.j1 = __shfl_xor(g[u].j1, 32);
+    Top2 m;
+    if (lex_less_u(p.s0, p.j0, g[u].s0, g[u].j0)) {
+      m.s0 = p.s0;
+      m.j0 = p.j0;
+      if (lex_less_u(g[u].s0, g[u].j0, p.s1, p.j1)) {
+        m.s1 = g[u].s0;
+        m.j1 = g[u].j0;
+      } else {
+        m.s1 = p.s1;
+        m.j1 = p.j1;
+      }
+    } else {
+      m.s0 = g[u].s0;
+      m.j0 = g[u].j0;
+      if (lex_less_u(p.s0, p.j0, g[u].s1, g[u].j1)) {
+        m.s1 = p.s0;
+        m.j1 = p.j0;
+      } else {
+        m.s1 = g[u].s1;
+        m.j1 = g[u].j1;
+      }
+    }
+    const int q = qt[u] * TILE_ROWS + r;
+    if (h == 0 && qt[u] < nqt && q < Q.n_rows) {
+      const int s0i = (int)m.s0, s1i = (int)m.s1;  // hamming distances
+      const bool v0 = m.j0 >= 0 && m.j0 < T.n_rows, v1 = m.j1 >= 0 && m.j1 < T.n_rows;
+      const float d0 = (float)s0i, d1 = (float)s1i;
+      int4 o;
+      o.x = v0 ? m.j0 : -1;
+      o.y = v1 ? m.j1 : -1;
+      o.z = __float_as_int(v0 ? d0 : 3.402823466e+38f);
+      o.w = __float_as_int(v1 ? d1 : 3.402823466e+38f);
+      knn[(size_t)it.pair * maxq + q] = o;
+    }
+  }
+}
+
 
 // ---------------------------------------------------------------- exact (VALU) k-NN
 // One wave per query.  Distances and their ordering restate cv::batchDistance literally:
@@ -989,6 +1300,195 @@ __global__ __launch_bounds__(256) void knn_exact_kernel(const ImgDev* __restrict
 }
 
 // ---------------------------------------------------------------- ratio test + compaction
+// One query by a whole 256-thread block, for the L2 kinds: eight lanes share a train row -- lane l takes
+// the elements k = l (mod 8), in ascending k: exactly the eight interleaved partial sums of exact_dist, then
+// combined in its fixed order -- so a wave does eight rows per round from coalesced 32-byte segments, and the
+// four waves split the rows.  Same arithmetic, same bits as exact_query; ~8x less time per query.
+template <int KIND>
+__device__ int4 exact_query_block(const ImgDev& Q, const ImgDev& T, int q, int dim, int row0, int row1, int4* sh /* [4] */) {
+  static_assert(KIND == KIND_F32_L2 || KIND == KIND_U8_L2, "L2 kinds");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l = lane & 7, grp = lane >> 3;
+  const size_t rowb = (size_t)dim * (KIND == KIND_F32_L2 ? 4 : 1);
+  const unsigned char* qrow = (const unsigned char*)Q.raw + (size_t)q * rowb;
+  float d0 = 3.402823466e+38f, d1 = 3.402823466e+38f;
+  int j0 = -1, j1 = -1;
+  constexpr int RU = 4;  // rows per group and round: four independent chains, their loads in flight together
+  for (int jb = row0 + wave * 8 * RU; jb < row1; jb += 32 * RU) {
+    int jr[RU];
+    const unsigned char* trow[RU];
+#pragma unroll
+    for (int a = 0; a < RU; ++a) {
+      jr[a] = jb + a * 8 + grp;  // (ascending within the group: round by round, a by a)
+      trow[a] = (const unsigned char*)T.raw + (size_t)(jr[a] < row1 ? jr[a] : 0) * rowb;
+    }
+    float d[RU];
+    if (KIND == KIND_F32_L2) {
+      float acc[RU];
+#pragma unroll
+      for (int a = 0; a < RU; ++a) acc[a] = 0.f;
+      for (int k = l; k < dim; k += 8) {
+        const float qv = ((const float*)qrow)[k];
+#pragma unroll
+        for (int a = 0; a < RU; ++a) {
+          const float x = __fsub_rn(qv, ((const float*)trow[a])[k]);
+          acc[a] = __fadd_rn(acc[a], __fmul_rn(x, x));
+        }
+      }
+      // ((a0+a4)+(a2+a6)) + ((a1+a5)+(a3+a7)): float addition commutes, so both lanes of a pair get the same bits
+#pragma unroll
+      for (int a = 0; a < RU; ++a) {
+        acc[a] = __fadd_rn(acc[a], __shfl_xor(acc[a], 4));
+        acc[a] = __fadd_rn(acc[a], __shfl_xor(acc[a], 2));
+        acc[a] = __fadd_rn(acc[a], __shfl_xor(acc[a], 1));
+        d[a] = sqrtf(acc[a]);
+      }
+    } else {
+      int si[RU];
+#pragma unroll
+      for (int a = 0; a < RU; ++a) si[a] = 0;
+      for (int k = l; k < dim; k += 8) {
+        const int qv = (int)qrow[k];
+#pragma unroll
+        for (int a = 0; a < RU; ++a) {
+          const int x = qv - (int)trow[a][k];
+          si[a] += x * x;
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < RU; ++a) {
+        si[a] += __shfl_xor(si[a], 4);
+        si[a] += __shfl_xor(si[a], 2);
+        si[a] += __shfl_xor(si[a], 1);
+        d[a] = sqrtf((float)si[a]);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < RU; ++a) {
+      if (jr[a] < row1 && (d[a] < d1 || j1 < 0)) {  // (a group meets its rows in ascending order)
+        if (d[a] < d0 || j0 < 0) {
+          d1 = d0;
+          j1 = j0;
+          d0 = d[a];
+          j0 = jr[a];
+        } else {
+          d1 = d[a];
+          j1 = jr[a];
+        }
+      }
+    }
+  }
+  auto less = [](float da, int ja, float db, int jb) {
+    if (ja < 0) return false;
+    if (jb < 0) return true;
+    return da < db || (da == db && ja < jb);
+  };
+  auto merge = [&](float e0, int i0, float e1, int i1) {
+    float n0, n1;
+    int m0, m1;
+    if (less(e0, i0, d0, j0)) {
+      n0 = e0;
+      m0 = i0;
+      if (less(d0, j0, e1, i1)) {
+        n1 = d0;
+        m1 = j0;
+      } else {
+        n1 = e1;
+        m1 = i1;
+      }
+    } else {
+      n0 = d0;
+      m0 = j0;
+      if (less(e0, i0, d1, j1)) {
+        n1 = e0;
+        m1 = i0;
+      } else {
+        n1 = d1;
+        m1 = j1;
+      }
+    }
+    d0 = n0;
+    d1 = n1;
+    j0 = m0;
+    j1 = m1;
+  };
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) merge(__shfl_xor(d0, o), __shfl_xor(j0, o), __shfl_xor(d1, o), __shfl_xor(j1, o));
+  __syncthreads();  // (sh may still be read from the previous query)
+  if (lane == 0) sh[wave] = make_int4(j0, j1, __float_as_int(d0), __float_as_int(d1));
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+    if (w != wave) merge(__int_as_float(sh[w].z), sh[w].x, __int_as_float(sh[w].w), sh[w].y);
+  int4 o;
+  o.x = j0;
+  o.y = j1;
+  o.z = __float_as_int(j0 >= 0 ? d0 : 3.402823466e+38f);
+  o.w = __float_as_int(j1 >= 0 ? d1 : 3.402823466e+38f);
+  return o;
+}
+
+// The listed flagged queries.  With few of them (the usual case) up to eight workgroups share a query --
+// slices of the train rows, partial results in `part`, the workgroup that arrives last merges -- so that a
+// handful of flagged queries does not leave the chip waiting for a handful of workgroups.
+template <int KIND>
+__global__ __launch_bounds__(256) void knn_fixup_kernel(const ImgDev* __restrict__ imgs, const int2* __restrict__ pairs,
+                                                        int dim, int4* __restrict__ knn, int maxq,
+                                                        const int* __restrict__ fix_count,
+                                                        const int2* __restrict__ fix_items, int4* __restrict__ part,
+                                                        int* __restrict__ arrived) {
+  __shared__ int4 sh[4];
+  __shared__ int last_s;
+  int nfix = *fix_count;
+  nfix = nfix < FIX_CAP ? nfix : FIX_CAP;
+  if (nfix == 0) return;
+  int S = (int)gridDim.x / nfix;  // workgroups per query (nfix * S <= gridDim.x: the size of part / arrived)
+  S = S < 1 ? 1 : (S > 8 ? 8 : S);
+  for (int unit = blockIdx.x; unit < nfix * S; unit += gridDim.x) {
+    const int i = unit / S, c = unit % S;
+    const int2 f = fix_items[i];
+    const int2 pr = pairs[f.x];
+    const ImgDev T = imgs[pr.y];
+    const int chunk = ((T.n_rows + S - 1) / S + 127) / 128 * 128;
+    const int row0 = c * chunk, row1 = (c + 1) * chunk < T.n_rows ? (c + 1) * chunk : T.n_rows;
+    int4 o = exact_query_block<KIND>(imgs[pr.x], T, f.y, dim, row0, row1, sh);
+    if (S > 1) {
+      if (threadIdx.x == 0) {
+        part[i * S + c] = o;
+        __threadfence();
+        last_s = atomicAdd(&arrived[i], 1) == S - 1;
+      }
+      __syncthreads();
+      if (!last_s) continue;
+      if (threadIdx.x == 0) {
+        __threadfence();
+        arrived[i] = 0;  // (for the next run)
+        float d0 = 3.402823466e+38f, d1 = 3.402823466e+38f;
+        int j0 = -1, j1 = -1;
+        for (int cc = 0; cc < S; ++cc) {  // slices in row order: on equal distance the earlier row stays in front
+          const int4 e = part[i * S + cc];  // (behind the acquire side of the fence above)
+          const int js[2] = {e.x, e.y};
+          const float ds[2] = {__int_as_float(e.z), __int_as_float(e.w)};
+          for (int k = 0; k < 2; ++k) {
+            if (js[k] < 0) continue;
+            if (j0 < 0 || ds[k] < d0) {
+              d1 = d0;
+              j1 = j0;
+              d0 = ds[k];
+              j0 = js[k];
+            } else if (j1 < 0 || ds[k] < d1) {
+              d1 = ds[k];
+              j1 = js[k];
+            }
+          }
+        }
+        o = make_int4(j0, j1, __float_as_int(j0 >= 0 ? d0 : 3.402823466e+38f), __float_as_int(j1 >= 0 ? d1 : 3.402823466e+38f));
+      }
+    }
+    if (threadIdx.x == 0) knn[(size_t)f.x * maxq + f.y] = o;
+  }
+}
+
 // reference src/Sfm.cpp:603-607: keep knn[i][0] iff d0 <= ratio*d1 (float), ascending queryIdx.
 // Queries the MFMA kernel flagged (2nd-best squared distance >= 2^22, where sqrtf can merge
 // neighbouring integers and the order by (sqrtf(s), index) can differ from the order by (s, index))
@@ -999,10 +1499,13 @@ __global__ __launch_bounds__(256) void compact_kernel(const ImgDev* __restrict__
                                                       int4* __restrict__ knn, int maxq, int dim,
                                                       float ratio, int* __restrict__ counts,
                                                       int* __restrict__ out_q, int* __restrict__ out_t,
-                                                      float* __restrict__ out_d) {
+                                                      float* __restrict__ out_d, int* __restrict__ fix_count) {
   __shared__ int wsum[4];
   __shared__ int running;
   const int p = blockIdx.x;
+  // the fix-up list of this run has been consumed (knn_fixup_kernel ran before this kernel): clear its
+  // counter for the plan's next run here instead of with a memset node in front of every run
+  if (blockIdx.x == 0 && threadIdx.x == 0) *fix_count = 0;
   const int2 pr = pairs[p];
   const ImgDev Q = imgs[pr.x], T = imgs[pr.y];
   const int nq = Q.n_rows, nt = T.n_rows;
@@ -1015,7 +1518,11 @@ __global__ __launch_bounds__(256) void compact_kernel(const ImgDev* __restrict__
       int4 e = make_int4(-1, -1, 0, 0);
       if (q < nq) e = knn[(size_t)p * maxq + q];
       unsigned long long fb = __ballot(q < nq && e.y >= 0 && (e.y & FIX_FLAG) != 0);
-      while (fb) {  // wave-uniform
+#if SFM_DBG == 4
+      if (lane == 0 && fb) atomicAdd(&g_stamps[4096 * 8 * 16 - 1], (unsigned long long)__popcll(fb));
+      if (lane == 0) atomicAdd(&g_stamps[4096 * 8 * 16 - 2], (unsigned long long)__popcll(__ballot(q < nq && e.y == FIX_FLAG)));
+#endif
+      while (fb && SFM_DBG != 5) {  // wave-uniform
         const int l = __ffsll((long long)fb) - 1;
         fb &= fb - 1;
         const int4 o = exact_query<KIND>(Q, T, q0 + wave * 64 + l, dim);
@@ -1086,6 +1593,10 @@ struct sfmhip_matchplan {
   int* d_counts = nullptr;
   int *d_out_q = nullptr, *d_out_t = nullptr;
   float* d_out_d = nullptr;
+  int* d_fix_count = nullptr;
+  int2* d_fix_items = nullptr;
+  int4* d_fix_part = nullptr;   // knn_fixup_kernel: partial results of the workgroups sharing a query
+  int* d_fix_arrived = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   bool timed = false;
 };
@@ -1120,8 +1631,10 @@ extern "C" int sfmhip_imageset_create(sfmhip_ctx* ctx, int n_images, const int32
   s->ks = pick_ks(s->kind, dim);
   s->sr = s->ks == 8 ? 128 : 256;
   s->nu = s->ks == 8 ? 1 : 2;
+  if (s->kind == KIND_U8_HAMMING) s->nu = 2;  // (knn_keyed_kernel: 4 waves x 2 query tiles)
   if (const char* e = getenv("SFMHIP_KNN_NW")) s->nw = atoi(e) == 8 ? 8 : 4;          // (tuning knobs, not API)
   if (const char* e = getenv("SFMHIP_KNN_LATE")) s->late_start = std::max(0, atoi(e));
+  if (s->kind == KIND_U8_HAMMING) s->nw = 4;
   const int rb = 32 * (s->ks ? s->ks : 1);
   size_t tot_pad = 0;
   std::vector<int> tile_img, tile_first(n_images + 1, 0);
@@ -1330,13 +1843,17 @@ extern "C" int sfmhip_matchplan_create(sfmhip_imageset* s, const int32_t* pairs,
   if ((rc = sfm_dev_alloc(&pl->d_pairs, (size_t)pl->cap_pairs)) || (rc = sfm_dev_alloc(&pl->d_items, pl->cap_items)) ||
       (rc = sfm_dev_alloc(&pl->d_knn, slots)) || (rc = sfm_dev_alloc(&pl->d_counts, (size_t)pl->cap_pairs)) ||
       (rc = sfm_dev_alloc(&pl->d_out_q, slots)) || (rc = sfm_dev_alloc(&pl->d_out_t, slots)) ||
-      (rc = sfm_dev_alloc(&pl->d_out_d, slots))) {
+      (rc = sfm_dev_alloc(&pl->d_out_d, slots)) || (rc = sfm_dev_alloc(&pl->d_fix_count, (size_t)1)) ||
+      (rc = sfm_dev_alloc(&pl->d_fix_items, (size_t)FIX_CAP)) || (rc = sfm_dev_alloc(&pl->d_fix_part, (size_t)FIX_GRID)) ||
+      (rc = sfm_dev_alloc(&pl->d_fix_arrived, (size_t)FIX_GRID))) {
     sfmhip_matchplan_destroy(pl);
     return rc;
   }
   if (n_pairs) SFM_HIP_TRY(hipMemcpy(pl->d_pairs, pairs, sizeof(int2) * n_pairs, hipMemcpyHostToDevice));
   if (!items.empty()) SFM_HIP_TRY(hipMemcpy(pl->d_items, items.data(), sizeof(WorkItem) * items.size(), hipMemcpyHostToDevice));
   SFM_HIP_TRY(hipMemset(pl->d_counts, 0, sizeof(int) * pl->cap_pairs));
+  SFM_HIP_TRY(hipMemset(pl->d_fix_count, 0, sizeof(int)));  // (every run leaves it cleared: compact_kernel)
+  SFM_HIP_TRY(hipMemset(pl->d_fix_arrived, 0, sizeof(int) * FIX_GRID));  // (and these: the merging workgroup)
   for (auto& e : pl->ev) SFM_HIP_TRY(hipEventCreate(&e));
   *out = pl;
   return SFMHIP_OK;
@@ -1371,10 +1888,11 @@ static int launch_knn(sfmhip_matchplan* pl) {
   sfmhip_imageset* s = pl->set;
   if (s->nw == 4)
     hipLaunchKernelGGL((knn_kernel<KS, MODE, NU, SR, 4>), dim3(pl->n_items), dim3(256), 0, s->ctx->stream, s->d_imgs,
-                       pl->d_items, s->d_nonintegral, s->gen, s->dim, pl->d_knn, pl->maxq, s->late_start);
+                       pl->d_items, s->d_nonintegral, s->gen, s->dim, pl->d_knn, pl->maxq, s->late_start, pl->d_fix_count,
+                       pl->d_fix_items);
   else
     hipLaunchKernelGGL((knn_kernel<KS, MODE, NU, SR, 8>), dim3(pl->n_items), dim3(512), 0, s->ctx->stream, s->d_imgs,
-                       pl->d_items, s->d_nonintegral, s->gen, s->dim, pl->d_knn, pl->maxq, 0);
+                       pl->d_items, s->d_nonintegral, s->gen, s->dim, pl->d_knn, pl->maxq, 0, pl->d_fix_count, pl->d_fix_items);
   SFM_HIP_TRY(hipGetLastError());
   return SFMHIP_OK;
 }
@@ -1390,7 +1908,9 @@ extern "C" int sfmhip_matchplan_run_async(sfmhip_matchplan* pl, float ratio) {
     const bool mfma = s->ks != 0;
     if (mfma && pl->n_items > 0) {
       if (s->kind == KIND_U8_HAMMING) {
-        SFM_TRY((launch_knn<8, 1, 1, 128>(pl)));
+        hipLaunchKernelGGL((knn_keyed_kernel<8, 128>), dim3(pl->n_items), dim3(256), 0, st, s->d_imgs, pl->d_items, s->dim,
+                           pl->d_knn, pl->maxq);
+        SFM_HIP_TRY(hipGetLastError());
       } else {
         switch (s->ks) {
           case 1: SFM_TRY((launch_knn<1, 0, 2, 256>(pl))); break;
@@ -1415,18 +1935,27 @@ extern "C" int sfmhip_matchplan_run_async(sfmhip_matchplan* pl, float ratio) {
                            s->d_nonintegral, s->gen, force_all, s->dim, pl->d_knn, pl->maxq);
       SFM_HIP_TRY(hipGetLastError());
     }
+    if (mfma && pl->n_items > 0 && s->kind != KIND_U8_HAMMING) {  // the listed sqrtf-merge candidates, one wave each
+      if (s->kind == KIND_F32_L2)
+        hipLaunchKernelGGL((knn_fixup_kernel<KIND_F32_L2>), dim3(FIX_GRID), dim3(256), 0, st, s->d_imgs, pl->d_pairs, s->dim, pl->d_knn,
+                           pl->maxq, pl->d_fix_count, pl->d_fix_items, pl->d_fix_part, pl->d_fix_arrived);
+      else
+        hipLaunchKernelGGL((knn_fixup_kernel<KIND_U8_L2>), dim3(FIX_GRID), dim3(256), 0, st, s->d_imgs, pl->d_pairs, s->dim, pl->d_knn,
+                           pl->maxq, pl->d_fix_count, pl->d_fix_items, pl->d_fix_part, pl->d_fix_arrived);
+      SFM_HIP_TRY(hipGetLastError());
+    }
   }
   if (timing) SFM_HIP_TRY(hipEventRecord(pl->ev[1], st));
   if (pl->n_pairs > 0) {
     if (s->kind == KIND_F32_L2)
       hipLaunchKernelGGL((compact_kernel<KIND_F32_L2>), dim3(pl->n_pairs), dim3(256), 0, st, s->d_imgs, pl->d_pairs, pl->d_knn,
-                         pl->maxq, s->dim, ratio, pl->d_counts, pl->d_out_q, pl->d_out_t, pl->d_out_d);
+                         pl->maxq, s->dim, ratio, pl->d_counts, pl->d_out_q, pl->d_out_t, pl->d_out_d, pl->d_fix_count);
     else if (s->kind == KIND_U8_L2)
       hipLaunchKernelGGL((compact_kernel<KIND_U8_L2>), dim3(pl->n_pairs), dim3(256), 0, st, s->d_imgs, pl->d_pairs, pl->d_knn,
-                         pl->maxq, s->dim, ratio, pl->d_counts, pl->d_out_q, pl->d_out_t, pl->d_out_d);
+                         pl->maxq, s->dim, ratio, pl->d_counts, pl->d_out_q, pl->d_out_t, pl->d_out_d, pl->d_fix_count);
     else
       hipLaunchKernelGGL((compact_kernel<KIND_U8_HAMMING>), dim3(pl->n_pairs), dim3(256), 0, st, s->d_imgs, pl->d_pairs, pl->d_knn,
-                         pl->maxq, s->dim, ratio, pl->d_counts, pl->d_out_q, pl->d_out_t, pl->d_out_d);
+                         pl->maxq, s->dim, ratio, pl->d_counts, pl->d_out_q, pl->d_out_t, pl->d_out_d, pl->d_fix_count);
     SFM_HIP_TRY(hipGetLastError());
   }
   if (timing) SFM_HIP_TRY(hipEventRecord(pl->ev[2], st));
@@ -1517,6 +2046,10 @@ extern "C" void sfmhip_matchplan_destroy(sfmhip_matchplan* pl) {
   hipFree(pl->d_out_q);
   hipFree(pl->d_out_t);
   hipFree(pl->d_out_d);
+  hipFree(pl->d_fix_count);
+  hipFree(pl->d_fix_items);
+  hipFree(pl->d_fix_part);
+  hipFree(pl->d_fix_arrived);
   for (auto& e : pl->ev)
     if (e) hipEventDestroy(e);
   delete pl;
