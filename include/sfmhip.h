@@ -106,6 +106,9 @@ int sfmhip_matchplan_fetch_knn(sfmhip_matchplan* plan, int pair, int32_t* idx, f
 /* seconds of device time of the last run's kernels, by stage (hipEvents on the ctx stream):
  * [0]=prepare (last prepare_async) [1]=knn kernels [2]=compaction; and the knn-kernel count */
 int sfmhip_matchplan_last_timing(sfmhip_matchplan* plan, double seconds[3]);
+/* seconds of the last run's k-NN kernel alone -- the one launch the MFMA roofline is priced on (stage [1]
+ * above also holds the exact / fix-up kernels that follow it) */
+int sfmhip_matchplan_last_knn_kernel_time(sfmhip_matchplan* plan, double* seconds);
 void sfmhip_matchplan_destroy(sfmhip_matchplan* plan);
 
 /* ---- triangulateViews numerics (reference src/Sfm.cpp:812-860) ----

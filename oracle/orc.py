@@ -74,6 +74,8 @@ def lib():
         L.orc_match_knn2.restype = C.c_int
         L.orc_match_many.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp]
         L.orc_match_many.restype = C.c_int
+        L.orc_match_many_checksum.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp]
+        L.orc_match_many_checksum.restype = C.c_int
         L.orc_triangulate.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, vp, vp, vp]
         L.orc_triangulate.restype = C.c_int
         L.orc_ba_residual.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp, vp]
@@ -144,6 +146,48 @@ def match_many(imgs, pairs, norm=NORM_L2, ratio=0.8, threads=1):
     if rc:
         raise RuntimeError(f"orc_match_many rc={rc}")
     return counts[:len(pairs)]
+
+
+def match_many_checksum(imgs, pairs, norm=NORM_L2, ratio=0.8, threads=1):
+    """match_many plus (n_pairs, 2) uint64 checksums: [sum, xor] over each pair's matches of
+    match_mix(queryIdx, trainIdx, distance bits)."""
+    imgs = [np.ascontiguousarray(a) for a in imgs]
+    dtype = DTYPE_F32 if imgs[0].dtype == np.float32 else DTYPE_U8
+    ptrs = (C.c_void_p * len(imgs))(*[a.ctypes.data for a in imgs])
+    n_rows = np.array([a.shape[0] for a in imgs], np.int32)
+    pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    counts = np.zeros(max(len(pairs), 1), np.int32)
+    cs = np.zeros((max(len(pairs), 1), 2), np.uint64)
+    rc = lib().orc_match_many_checksum(ptrs, _p(n_rows), imgs[0].shape[1], dtype, norm, _p(pairs), len(pairs), ratio,
+                                       threads, _p(counts), _p(cs))
+    if rc:
+        raise RuntimeError(f"orc_match_many_checksum rc={rc}")
+    return counts[:len(pairs)], cs[:len(pairs)]
+
+
+def match_mix(q, t, dist):
+    """The per-match value of the pair checksums, vectorised (numpy arrays in, uint64 out)."""
+    with np.errstate(over="ignore"):
+        x = q.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) + t.astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F) + \
+            np.ascontiguousarray(dist, np.float32).view(np.uint32).astype(np.uint64) * np.uint64(0x165667B19E3779F9)
+        x ^= x >> np.uint64(29)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(32)
+    return x
+
+
+def pair_checksums(counts, oq, ot, od):
+    """(n_pairs, 2) uint64 [sum, xor] of match_mix over each pair's slice of concatenated match lists."""
+    x = match_mix(np.asarray(oq), np.asarray(ot), np.asarray(od))
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    cs = np.zeros((len(counts), 2), np.uint64)
+    with np.errstate(over="ignore"):
+        for p in range(len(counts)):
+            seg = x[off[p]:off[p + 1]]
+            if len(seg):
+                cs[p, 0] = np.sum(seg, dtype=np.uint64)
+                cs[p, 1] = np.bitwise_xor.reduce(seg)
+    return cs
 
 
 def triangulate(P1, P2, K, dist, xy1, xy2, max_err=6.0):

@@ -43,6 +43,13 @@ int orc_match_many(const void* const* imgs, const int32_t* n_rows, int dim, int 
  * projectPoints in both views, float 6 px filter.  xy1/xy2 are the already-gathered pixel
  * coordinates (AlignedPoints, src/Sfm.cpp:694-711).  X: 3*m doubles, err: 2*m floats (may be
  * NULL), keep: m bytes. */
+/* orc_match_many plus a checksum per pair: checksums[2p] = sum, [2p+1] = xor of orc_match_mix over the
+ * pair's matches (queryIdx, trainIdx, bit pattern of the float distance). */
+int orc_match_many_checksum(const void* const* imgs, const int32_t* n_rows, int dim, int dtype, int norm,
+                            const int32_t* pairs, int n_pairs, float ratio, int threads, int32_t* counts,
+                            uint64_t* checksums);
+uint64_t orc_match_mix(uint32_t q, uint32_t t, uint32_t dist_bits);
+
 int orc_triangulate(const double P1[12], const double P2[12], const double K[9],
                     const double dist[5], const double* xy1, const double* xy2, int m,
                     float max_err, double* X, float* err, uint8_t* keep);

@@ -139,8 +139,36 @@ int orc_match_knn2(const void* q, int nq, const void* t, int nt, int dim, int dt
 
 /* Many pairs in one call, parallel over (pair, query row) so that every host core has work:
  * the CPU-baseline leg of bench.py.  counts[p] = matches of pair p (ratio-filtered). */
+static int match_many_impl(const void* const* imgs, const int32_t* n_rows, int dim, int dtype, int norm,
+                           const int32_t* pairs, int n_pairs, float ratio, int threads, int32_t* counts,
+                           uint64_t* checksums);
+
 int orc_match_many(const void* const* imgs, const int32_t* n_rows, int dim, int dtype, int norm,
                    const int32_t* pairs, int n_pairs, float ratio, int threads, int32_t* counts) {
+  return match_many_impl(imgs, n_rows, dim, dtype, norm, pairs, n_pairs, ratio, threads, counts, NULL);
+}
+
+/* The same with a checksum of every pair's match list: checksums[2p] = sum, [2p+1] = xor over the
+ * pair's matches of orc_match_mix(queryIdx, trainIdx, distance bits) -- what full-size parity
+ * tests and bench.py compare with the GPU lists (all 1225 pairs of cfg2, not a sample). */
+int orc_match_many_checksum(const void* const* imgs, const int32_t* n_rows, int dim, int dtype, int norm,
+                            const int32_t* pairs, int n_pairs, float ratio, int threads, int32_t* counts,
+                            uint64_t* checksums) {
+  return match_many_impl(imgs, n_rows, dim, dtype, norm, pairs, n_pairs, ratio, threads, counts, checksums);
+}
+
+uint64_t orc_match_mix(uint32_t q, uint32_t t, uint32_t dist_bits) {
+  uint64_t x = (uint64_t)q * 0x9E3779B97F4A7C15ull + (uint64_t)t * 0xC2B2AE3D27D4EB4Full +
+               (uint64_t)dist_bits * 0x165667B19E3779F9ull;
+  x ^= x >> 29;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 32;
+  return x;
+}
+
+static int match_many_impl(const void* const* imgs, const int32_t* n_rows, int dim, int dtype, int norm,
+                           const int32_t* pairs, int n_pairs, float ratio, int threads, int32_t* counts,
+                           uint64_t* checksums) {
   if (n_pairs < 0 || dim <= 0) return -1;
   if (threads < 1) threads = 1;
   int64_t* off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_pairs + 1));
@@ -149,6 +177,7 @@ int orc_match_many(const void* const* imgs, const int32_t* n_rows, int dim, int 
   for (int p = 0; p < n_pairs; ++p) off[p + 1] = off[p] + n_rows[pairs[2 * p]];
   const int64_t total = off[n_pairs];
   for (int p = 0; p < n_pairs; ++p) counts[p] = 0;
+  if (checksums) memset(checksums, 0, sizeof(uint64_t) * 2 * (size_t)n_pairs);
   const size_t esz = dtype == ORC_DTYPE_F32 ? 4 : 1;
 #pragma omp parallel for schedule(dynamic, 64) num_threads(threads)
   for (int64_t w = 0; w < total; ++w) {
@@ -163,6 +192,7 @@ int orc_match_many(const void* const* imgs, const int32_t* n_rows, int dim, int 
     const unsigned char* t = (const unsigned char*)imgs[ti];
     int32_t i0 = -1, i1 = -1;
     int pass = 0;
+    float dist0 = 0.f;
     if (norm == ORC_NORM_HAMMING) {
       int d0 = INT_MAX, d1 = INT_MAX;
       for (int j = 0; j < nt; ++j) {
@@ -170,6 +200,7 @@ int orc_match_many(const void* const* imgs, const int32_t* n_rows, int dim, int 
         KNN2_INSERT(d, j, d0, i0, d1, i1);
       }
       pass = i1 >= 0 && (float)d0 <= ratio * (float)d1;
+      dist0 = (float)d0;
     } else {
       float d0 = FLT_MAX, d1 = FLT_MAX;
       for (int j = 0; j < nt; ++j) {
@@ -178,10 +209,20 @@ int orc_match_many(const void* const* imgs, const int32_t* n_rows, int dim, int 
         KNN2_INSERT(d, j, d0, i0, d1, i1);
       }
       pass = i1 >= 0 && d0 <= ratio * d1;
+      dist0 = d0;
     }
     if (pass) {
 #pragma omp atomic
       counts[p]++;
+      if (checksums) {
+        uint32_t bits;
+        memcpy(&bits, &dist0, 4);
+        const uint64_t x = orc_match_mix((uint32_t)i, (uint32_t)i0, bits);
+#pragma omp atomic
+        checksums[2 * p] += x;
+#pragma omp atomic
+        checksums[2 * p + 1] ^= x;
+      }
     }
   }
   free(off);

@@ -42,7 +42,8 @@ SYMBOLS = [
     "sfmhip_last_hip_error", "sfmhip_version", "sfmhip_match_knn2", "sfmhip_imageset_create",
     "sfmhip_imageset_upload", "sfmhip_imageset_adopt_device", "sfmhip_imageset_prepare_async",
     "sfmhip_imageset_destroy", "sfmhip_matchplan_create", "sfmhip_matchplan_set_pairs", "sfmhip_matchplan_run_async", "sfmhip_matchplan_fetch",
-    "sfmhip_matchplan_fetch_knn", "sfmhip_matchplan_last_timing", "sfmhip_matchplan_destroy",
+    "sfmhip_matchplan_fetch_knn", "sfmhip_matchplan_last_timing", "sfmhip_matchplan_last_knn_kernel_time",
+    "sfmhip_matchplan_destroy",
     "sfmhip_triangulate", "sfmhip_find_2d3d", "sfmhip_merge_new_points", "sfmhip_ba_default_opts", "sfmhip_ba_solve", "sfmhip_ba_create",
     "sfmhip_ba_set_allreduce", "sfmhip_ba_set_params", "sfmhip_ba_get_params", "sfmhip_ba_run",
     "sfmhip_ba_iterate", "sfmhip_ba_reduced_system", "sfmhip_ba_last_timing", "sfmhip_ba_destroy",
@@ -84,6 +85,7 @@ def lib():
     L.sfmhip_matchplan_fetch.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.sfmhip_matchplan_fetch_knn.argtypes = [vp, cint, vp, vp]
     L.sfmhip_matchplan_last_timing.argtypes = [vp, vp]
+    L.sfmhip_matchplan_last_knn_kernel_time.argtypes = [vp, C.POINTER(C.c_double)]
     L.sfmhip_matchplan_destroy.argtypes = [vp]
     L.sfmhip_matchplan_destroy.restype = None
     if hasattr(L, "sfmhip_triangulate"):

@@ -1552,6 +1552,55 @@ __global__ __launch_bounds__(256) void compact_kernel(const ImgDev* __restrict__
   if (threadIdx.x == 0) counts[p] = running;
 }
 
+// ---------------------------------------------------------------- packing for the host
+// exclusive scan of the pair counts (one workgroup) ...
+__global__ __launch_bounds__(1024) void pack_offsets_kernel(const int* __restrict__ counts, int n_pairs,
+                                                            long long* __restrict__ offsets) {
+  __shared__ long long wsum[16];
+  __shared__ long long running;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) running = 0;
+  __syncthreads();
+  for (int p0 = 0; p0 < n_pairs; p0 += 1024) {
+    const int p = p0 + threadIdx.x;
+    const long long c = p < n_pairs ? counts[p] : 0;
+    long long x = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const long long y = __shfl_up(x, o);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    long long before = running;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (p < n_pairs) offsets[p] = before + x - c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      long long t = 0;
+      for (int w = 0; w < 16; ++w) t += wsum[w];
+      running += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) offsets[n_pairs] = running;
+}
+// ... and the pairs' lists, gathered into one array of {queryIdx, trainIdx, distance bits} records
+__global__ __launch_bounds__(256) void pack_lists_kernel(const int* __restrict__ counts, const long long* __restrict__ offsets,
+                                                         int maxq, const int* __restrict__ out_q, const int* __restrict__ out_t,
+                                                         const float* __restrict__ out_d, int* __restrict__ packed) {
+  const int p = blockIdx.x;
+  const int n = counts[p];
+  const long long o = offsets[p];
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const size_t src = (size_t)p * maxq + i;
+    int* dst = packed + 3 * (o + i);
+    dst[0] = out_q[src];
+    dst[1] = out_t[src];
+    dst[2] = __float_as_int(out_d[src]);
+  }
+}
+
 }  // namespace
 
 // ================================================================= host side
@@ -1595,9 +1644,12 @@ struct sfmhip_matchplan {
   float* d_out_d = nullptr;
   int* d_fix_count = nullptr;
   int2* d_fix_items = nullptr;
+  long long* d_offsets = nullptr;  // fetch: exclusive scan of the counts, packed {q, t, dist} records
+  int* d_packed = nullptr;
   int4* d_fix_part = nullptr;   // knn_fixup_kernel: partial results of the workgroups sharing a query
   int* d_fix_arrived = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_k = nullptr;  // end of the k-NN kernel proper (ev[0] .. ev_k = that one launch)
   bool timed = false;
 };
 
@@ -1855,6 +1907,7 @@ extern "C" int sfmhip_matchplan_create(sfmhip_imageset* s, const int32_t* pairs,
   SFM_HIP_TRY(hipMemset(pl->d_fix_count, 0, sizeof(int)));  // (every run leaves it cleared: compact_kernel)
   SFM_HIP_TRY(hipMemset(pl->d_fix_arrived, 0, sizeof(int) * FIX_GRID));  // (and these: the merging workgroup)
   for (auto& e : pl->ev) SFM_HIP_TRY(hipEventCreate(&e));
+  SFM_HIP_TRY(hipEventCreate(&pl->ev_k));
   *out = pl;
   return SFMHIP_OK;
 }
@@ -1920,6 +1973,7 @@ extern "C" int sfmhip_matchplan_run_async(sfmhip_matchplan* pl, float ratio) {
         }
       }
     }
+    if (timing) SFM_HIP_TRY(hipEventRecord(pl->ev_k, st));
     // pairs the MFMA kernel leaves alone: a non-integer-valued f32 image, or no MFMA instantiation
     const int force_all = mfma ? 0 : 1;
     if (force_all || s->kind == KIND_F32_L2) {
@@ -1969,24 +2023,37 @@ extern "C" int sfmhip_matchplan_fetch(sfmhip_matchplan* pl, int32_t* counts, int
   sfmhip_imageset* s = pl->set;
   SFM_HIP_TRY(hipSetDevice(s->ctx->device));
   hipStream_t st = s->ctx->stream;
-  if (pl->n_pairs) SFM_HIP_TRY(hipMemcpyAsync(counts, pl->d_counts, sizeof(int) * pl->n_pairs, hipMemcpyDeviceToHost, st));
+  const bool lists = out_q || out_t || out_dist;
+  if (total) *total = 0;
+  if (pl->n_pairs == 0) return SFMHIP_OK;
+  // The lists leave the device packed: a scan of the counts and a gather into {q, t, dist} records on the
+  // device, then two copies (counts + offsets, records) instead of three per pair.
+  if (lists) {
+    if (!pl->d_offsets) SFM_TRY(sfm_dev_alloc(&pl->d_offsets, (size_t)pl->cap_pairs + 1));
+    if (!pl->d_packed) SFM_TRY(sfm_dev_alloc(&pl->d_packed, 3 * (size_t)pl->cap_pairs * pl->maxq));
+    hipLaunchKernelGGL(pack_offsets_kernel, dim3(1), dim3(1024), 0, st, pl->d_counts, pl->n_pairs, pl->d_offsets);
+    hipLaunchKernelGGL(pack_lists_kernel, dim3(pl->n_pairs), dim3(256), 0, st, pl->d_counts, pl->d_offsets, pl->maxq,
+                       pl->d_out_q, pl->d_out_t, pl->d_out_d, pl->d_packed);
+    SFM_HIP_TRY(hipGetLastError());
+  }
+  SFM_HIP_TRY(hipMemcpyAsync(counts, pl->d_counts, sizeof(int) * pl->n_pairs, hipMemcpyDeviceToHost, st));
   SFM_HIP_TRY(hipStreamSynchronize(st));
   int64_t tot = 0;
   for (int p = 0; p < pl->n_pairs; ++p) tot += counts[p];
   if (total) *total = tot;
-  if (!out_q && !out_t && !out_dist) return SFMHIP_OK;
+  if (!lists) return SFMHIP_OK;
   if (tot > capacity) return SFMHIP_ERR_ARG;
-  int64_t off = 0;
-  for (int p = 0; p < pl->n_pairs; ++p) {
-    const size_t n = (size_t)counts[p], src = (size_t)p * pl->maxq;
-    if (n) {
-      if (out_q) SFM_HIP_TRY(hipMemcpyAsync(out_q + off, pl->d_out_q + src, n * 4, hipMemcpyDeviceToHost, st));
-      if (out_t) SFM_HIP_TRY(hipMemcpyAsync(out_t + off, pl->d_out_t + src, n * 4, hipMemcpyDeviceToHost, st));
-      if (out_dist) SFM_HIP_TRY(hipMemcpyAsync(out_dist + off, pl->d_out_d + src, n * 4, hipMemcpyDeviceToHost, st));
-    }
-    off += (int64_t)n;
-  }
+  if (tot == 0) return SFMHIP_OK;
+  void* stage = nullptr;
+  SFM_TRY(sfm_ctx_pinned(s->ctx, (size_t)tot * 12, &stage));
+  SFM_HIP_TRY(hipMemcpyAsync(stage, pl->d_packed, (size_t)tot * 12, hipMemcpyDeviceToHost, st));
   SFM_HIP_TRY(hipStreamSynchronize(st));
+  const int32_t* rec = (const int32_t*)stage;
+  for (int64_t i = 0; i < tot; ++i) {
+    if (out_q) out_q[i] = rec[3 * i];
+    if (out_t) out_t[i] = rec[3 * i + 1];
+    if (out_dist) memcpy(&out_dist[i], &rec[3 * i + 2], 4);
+  }
   return SFMHIP_OK;
 }
 
@@ -2036,6 +2103,18 @@ extern "C" int sfmhip_matchplan_last_timing(sfmhip_matchplan* pl, double seconds
   return SFMHIP_OK;
 }
 
+extern "C" int sfmhip_matchplan_last_knn_kernel_time(sfmhip_matchplan* pl, double* seconds) {
+  if (!pl || !seconds) return SFMHIP_ERR_ARG;
+  *seconds = 0;
+  if (pl->timed && pl->n_pairs > 0) {
+    float ms = 0;
+    SFM_HIP_TRY(hipEventSynchronize(pl->ev_k));
+    SFM_HIP_TRY(hipEventElapsedTime(&ms, pl->ev[0], pl->ev_k));
+    *seconds = ms * 1e-3;
+  }
+  return SFMHIP_OK;
+}
+
 extern "C" void sfmhip_matchplan_destroy(sfmhip_matchplan* pl) {
   if (!pl) return;
   hipSetDevice(pl->set->ctx->device);
@@ -2050,8 +2129,11 @@ extern "C" void sfmhip_matchplan_destroy(sfmhip_matchplan* pl) {
   hipFree(pl->d_fix_items);
   hipFree(pl->d_fix_part);
   hipFree(pl->d_fix_arrived);
+  hipFree(pl->d_offsets);
+  hipFree(pl->d_packed);
   for (auto& e : pl->ev)
     if (e) hipEventDestroy(e);
+  if (pl->ev_k) hipEventDestroy(pl->ev_k);
   delete pl;
 }
 

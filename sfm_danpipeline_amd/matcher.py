@@ -144,7 +144,9 @@ class MatchPlan:
     def last_timing(self):
         t = np.zeros(3, np.float64)
         check(lib().sfmhip_matchplan_last_timing(self.h, t.ctypes.data), "sfmhip_matchplan_last_timing")
-        return dict(prepare_s=t[0], knn_s=t[1], compact_s=t[2])
+        k = C.c_double(0)
+        check(lib().sfmhip_matchplan_last_knn_kernel_time(self.h, C.byref(k)), "sfmhip_matchplan_last_knn_kernel_time")
+        return dict(prepare_s=t[0], knn_s=t[1], compact_s=t[2], knn_kernel_s=k.value)
 
     def close(self):
         if self.h:

@@ -70,6 +70,32 @@ def test_extreme_values_take_the_exact_fixup_path(ctx, orc):
     _assert_pair(orc, pl, 0, q, t, _lib.L2)
 
 
+def test_more_flagged_queries_than_the_fixup_list_holds(ctx, orc):
+    """Every query lands in the sqrtf-merge range (2nd-best squared distance >= 2^22): 600 pairs x 2000
+    queries = 1.2 M flagged, more than the 2^20 entries of the fix-up list.  Nothing may be dropped:
+    what does not fit the list stays flagged in-band and is redone by the compaction kernel."""
+    import os
+    rng = np.random.default_rng(77)
+    qs = [(rng.random((2000, 128)) < 0.1).astype(np.float32) * 255 for _ in range(30)]     # mostly 0
+    ts = [(rng.random((256, 128)) < 0.9).astype(np.float32) * 255 for _ in range(20)]      # mostly 255
+    imgs = qs + ts
+    pairs = np.array([[a, 30 + b] for a in range(30) for b in range(20)], np.int32)
+    s, pl = _plan(ctx, imgs, pairs)
+    cnt, oq, ot, od = pl.fetch()
+    for p in (0, 313, 599):
+        ki, kd = pl.fetch_knn(p)
+        assert np.all(kd[:, 1] >= 2048.0)                  # all of them in the merge range
+        _assert_pair(orc, pl, p, imgs[pairs[p, 0]], imgs[pairs[p, 1]], _lib.L2)
+    ocnt, ocs = orc.match_many_checksum(imgs, pairs, threads=os.cpu_count() or 8)
+    assert np.array_equal(cnt, ocnt)
+    assert np.array_equal(orc.pair_checksums(cnt, oq, ot, od), ocs)
+    # a k-NN checksum too (the ratio test passes few of these): every pair's raw lists on sampled pairs
+    for p in range(7, 600, 37):
+        ki, kd = pl.fetch_knn(p)
+        r = orc.match_knn2(imgs[pairs[p, 0]], imgs[pairs[p, 1]], want_knn=True, threads=8)
+        assert np.array_equal(ki, r[3]) and np.array_equal(kd.view(np.uint32), r[4].view(np.uint32))
+
+
 def test_non_integer_rows_use_the_exact_kernel(ctx, orc):
     imgs = synth.sift_image_set(3, 200, 128, bank=300, seed=5)
     mixed = [imgs[0] + 0.25, imgs[1], imgs[2]]        # one non-integer image poisons only its pairs
@@ -132,6 +158,11 @@ def test_cfg2_full_size_properties(ctx, orc):
     assert od.max() < 400                                  # true matches sit at ~sigma*sqrt(2*128)
     for p in (0, 611, 1224):
         _assert_pair(orc, pl, p, imgs[pairs[p, 0]], imgs[pairs[p, 1]], _lib.L2)
+    # ALL 1225 pairs against the oracle: counts and a per-pair checksum of (queryIdx, trainIdx, distance bits)
+    import os
+    ocnt, ocs = orc.match_many_checksum(imgs, pairs, threads=os.cpu_count() or 8)
+    assert np.array_equal(cnt, ocnt)
+    assert np.array_equal(orc.pair_checksums(cnt, oq, ot, od), ocs)
 
 
 def test_train_permutation_property(ctx):
@@ -170,6 +201,12 @@ def test_cfg5_orb_shard_properties(ctx, orc):
     assert 150 < cnt.mean() < 350 and od.max() < 110 and np.all(od == np.round(od))
     for p in (0, len(mine) // 2, len(mine) - 1):
         _assert_pair(orc, pl, p, imgs[mine[p, 0]], imgs[mine[p, 1]], _lib.HAMMING)
+    # 32 sampled pairs of the shard against the oracle by per-pair checksum (counts + every match)
+    import os
+    sample = np.random.default_rng(11).choice(len(mine), 32, replace=False)
+    ocnt, ocs = orc.match_many_checksum(imgs, mine[sample], norm=orc.NORM_HAMMING, threads=os.cpu_count() or 8)
+    gcs = orc.pair_checksums(cnt, oq, ot, od)
+    assert np.array_equal(cnt[sample], ocnt) and np.array_equal(gcs[sample], ocs)
     print(f"[cfg5 shard] {len(mine)} pairs incl. upload + first run: {dt:.2f} s")
 
 
