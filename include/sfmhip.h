@@ -202,6 +202,12 @@ int sfmhip_ba_iterate(sfmhip_ba* ba, int iters, sfmhip_ba_summary* summary);
 /* One linearisation at the current parameters: reduced system of this rank's points,
  * dim = 6*n_cam+1, S row-major full symmetric, before any all-reduce.  Test hook. */
 int sfmhip_ba_reduced_system(sfmhip_ba* ba, double radius, double* S, double* g, double* cost);
+/* Residual and Jacobian of n single observations as the solver linearises them (SimpleReprojectionError,
+ * reference src/BundleAdjustment.cpp:10-35; analytic derivative of the theta^2 branch autodiff takes).
+ * cams6: n x 6, pts3: n x 3, obs_xy: n x 2; r: n x 2, Jc: n x (2x6 row-major), Jp: n x (2x3), Jf: n x 2.
+ * Test hook. */
+int sfmhip_ba_linearize_obs(sfmhip_ctx* ctx, int n, const double* cams6, const double* pts3, double focal,
+                            const double* obs_xy, double* r, double* Jc, double* Jp, double* Jf);
 /* device seconds of the last run/iterate by kernel group:
  * [0]=linearise+eliminate [1]=allreduce [2]=reduced solve [3]=back-substitute+cost */
 int sfmhip_ba_last_timing(sfmhip_ba* ba, double seconds[4], int* launches);

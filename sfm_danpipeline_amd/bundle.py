@@ -93,6 +93,23 @@ def default_opts(**kw):
 
 
 # ----------------------------------------------------------------------------- device problem
+def linearize_obs(cams6, pts3, focal, obs_xy, ctx=None):
+    """Test hook: residual r (n,2) and Jacobian blocks Jc (n,2,6), Jp (n,2,3), Jf (n,2) of n single
+    observations, computed by the solver's own device linearisation (sfmhip_ba_linearize_obs)."""
+    from ._lib import default_context
+    ctx = ctx or default_context()
+    cams = np.ascontiguousarray(cams6, np.float64).reshape(-1, 6)
+    pts = np.ascontiguousarray(pts3, np.float64).reshape(-1, 3)
+    xy = np.ascontiguousarray(obs_xy, np.float64).reshape(-1, 2)
+    n = cams.shape[0]
+    assert pts.shape[0] == n and xy.shape[0] == n
+    r, Jc, Jp, Jf = np.empty((n, 2)), np.empty((n, 2, 6)), np.empty((n, 2, 3)), np.empty((n, 2))
+    check(lib().sfmhip_ba_linearize_obs(ctx.h, n, cams.ctypes.data, pts.ctypes.data, float(focal), xy.ctypes.data,
+                                        r.ctypes.data, Jc.ctypes.data, Jp.ctypes.data, Jf.ctypes.data),
+          "sfmhip_ba_linearize_obs")
+    return r, Jc, Jp, Jf
+
+
 class BaProblem:
     """sfmhip_ba object: this rank's points + observations, all cameras and the shared focal."""
 

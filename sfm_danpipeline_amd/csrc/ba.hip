@@ -2623,6 +2623,66 @@ extern "C" int sfmhip_ba_iterate(sfmhip_ba* b, int iters, sfmhip_ba_summary* sum
   return SFMHIP_OK;
 }
 
+// Test hook: residual and Jacobian of n observations exactly as the solver's kernels linearise them
+// (cam_table + obs_linearize: the analytic derivative of the branch of AngleAxisRotatePoint that autodiff
+// takes, reference src/BundleAdjustment.cpp:10-35), one thread per observation.
+namespace {
+__global__ void ba_linearize_obs_kernel(const double* __restrict__ cams6, const double* __restrict__ pts3, double focal,
+                                        const double* __restrict__ obs_xy, int n, double* __restrict__ r,
+                                        double* __restrict__ Jc, double* __restrict__ Jp, double* __restrict__ Jf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double cd[CAMD];
+  cam_table(cams6 + 6 * (size_t)i, cd, true);
+  const double X[3] = {pts3[3 * (size_t)i], pts3[3 * (size_t)i + 1], pts3[3 * (size_t)i + 2]};
+  ObsLin o;
+  obs_linearize((const double*)cd, X, focal, obs_xy[2 * (size_t)i], obs_xy[2 * (size_t)i + 1], nullptr, nullptr, 1.0, o);
+  r[2 * (size_t)i] = o.r0;
+  r[2 * (size_t)i + 1] = o.r1;
+  for (int k = 0; k < 12; ++k) Jc[12 * (size_t)i + k] = o.Jc[k];
+  for (int k = 0; k < 6; ++k) Jp[6 * (size_t)i + k] = o.Jp[k];
+  Jf[2 * (size_t)i] = o.Jf[0];
+  Jf[2 * (size_t)i + 1] = o.Jf[1];
+}
+}  // namespace
+
+extern "C" int sfmhip_ba_linearize_obs(sfmhip_ctx* ctx, int n, const double* cams6, const double* pts3, double focal,
+                                       const double* obs_xy, double* r, double* Jc, double* Jp, double* Jf) {
+  if (!ctx || n < 0 || (n && (!cams6 || !pts3 || !obs_xy || !r || !Jc || !Jp || !Jf))) return SFMHIP_ERR_ARG;
+  if (n == 0) return SFMHIP_OK;
+  SFM_HIP_TRY(hipSetDevice(ctx->device));
+  double *d_in = nullptr, *d_out = nullptr;
+  const size_t nin = (size_t)n * 11, nout = (size_t)n * 22;
+  int rc = sfm_dev_alloc(&d_in, nin);
+  if (rc == SFMHIP_OK) rc = sfm_dev_alloc(&d_out, nout);
+  if (rc != SFMHIP_OK) {
+    hipFree(d_in);
+    hipFree(d_out);
+    return rc;
+  }
+  hipStream_t st = ctx->stream;
+  hipError_t e = hipMemcpyAsync(d_in, cams6, sizeof(double) * 6 * n, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_in + 6 * (size_t)n, pts3, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_in + 9 * (size_t)n, obs_xy, sizeof(double) * 2 * n, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(ba_linearize_obs_kernel, dim3((n + 127) / 128), dim3(128), 0, st, d_in, d_in + 6 * (size_t)n, focal,
+                       d_in + 9 * (size_t)n, n, d_out, d_out + 2 * (size_t)n, d_out + 14 * (size_t)n, d_out + 20 * (size_t)n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(r, d_out, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(Jc, d_out + 2 * (size_t)n, sizeof(double) * 12 * n, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(Jp, d_out + 14 * (size_t)n, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(Jf, d_out + 20 * (size_t)n, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  hipFree(d_in);
+  hipFree(d_out);
+  if (e != hipSuccess) {
+    g_sfmhip_last_hip_error = (int)e;
+    return SFMHIP_ERR_HIP;
+  }
+  return SFMHIP_OK;
+}
+
 extern "C" int sfmhip_ba_reduced_system(sfmhip_ba* b, double radius, double* S, double* g, double* cost) {
   if (!b || !(radius > 0)) return SFMHIP_ERR_ARG;
   SFM_HIP_TRY(hipSetDevice(b->ctx->device));

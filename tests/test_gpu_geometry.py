@@ -206,6 +206,48 @@ def test_allreduce_hook_with_a_mirrored_rank(ctx):
     assert abs(f1 - f2) <= 1e-9 * f1
 
 
+def test_residual_and_jacobian_per_observation(ctx, orc, golden):
+    """The device linearisation of single observations (a-4, src/BundleAdjustment.cpp:10-35) against the
+    complex-step golden Jacobians in BOTH theta^2 branches -- the first-order branch is the one the base
+    camera P_left = I always takes (src/Sfm.cpp:432,772) -- and against the oracle on random observations."""
+    g = golden["ba"]
+    n = len(g["jac_cams"])
+    r, Jc, Jp, Jf = bundle.linearize_obs(g["jac_cams"], np.tile(g["jac_X"], (n, 1)), 1500.0, np.tile(g["jac_obs"], (n, 1)), ctx=ctx)
+    for i in range(n):
+        J = g["jac_J"][i]
+        assert np.allclose(r[i], g["jac_r"][i], atol=1e-12)
+        assert np.allclose(Jc[i], J[:, :6], rtol=1e-11, atol=1e-11)
+        assert np.allclose(Jp[i], J[:, 6:9], rtol=1e-11, atol=1e-11)
+        assert np.allclose(Jf[i], J[:, 9], rtol=1e-13, atol=1e-13)
+    rng = np.random.default_rng(4)
+    m = 500
+    cams = np.concatenate([rng.normal(0, 0.4, (m, 3)), rng.normal(0, 0.3, (m, 2)), rng.uniform(4, 8, (m, 1))], axis=1)
+    cams[::5, :3] = 0.0                                   # exactly the identity rotation: theta^2 == 0
+    cams[1::5, :3] *= 1e-9                                # theta^2 below DBL_EPSILON: still the first-order branch
+    X = rng.uniform(-1, 1, (m, 3))
+    xy = rng.normal(0, 50, (m, 2))
+    r, Jc, Jp, Jf = bundle.linearize_obs(cams, X, 1520.0, xy, ctx=ctx)
+    for i in range(m):
+        ro, Jco, Jpo, Jfo = orc.ba_residual(cams[i], X[i], 1520.0, xy[i])
+        assert np.allclose(r[i], ro, rtol=1e-12, atol=1e-10)
+        assert np.allclose(Jc[i], Jco, rtol=1e-10, atol=1e-9) and np.allclose(Jp[i], Jpo, rtol=1e-10, atol=1e-9)
+        assert np.allclose(Jf[i], Jfo, rtol=1e-12, atol=1e-12)
+
+
+def test_cfg4_full_size_three_iterations_vs_oracle(ctx, orc):
+    """BASELINE cfg4 at full size (200 cams / 100k points / 1M obs): the first three LM iterations,
+    device solver against the oracle -- termination, iteration and accepted-step counts, costs, parameters."""
+    pb = synth.ba_problem(200, 100000, 10, seed=777)
+    kw = dict(max_iterations=3, max_time_s=0.0)
+    c, p, f, s = bundle.ba_solve(*_ba_args(pb), ctx=ctx, opts=bundle.default_opts(**kw))
+    co, po, fo, so = orc.ba_solve(*_ba_args(pb), opts=orc.default_opts(**kw))
+    assert (s.termination, s.iterations, s.successful_steps) == (so.termination, so.iterations, so.successful_steps)
+    assert abs(s.initial_cost - so.initial_cost) <= 1e-12 * so.initial_cost
+    assert abs(s.final_cost - so.final_cost) <= 1e-9 * so.final_cost
+    assert np.allclose(c, co, rtol=1e-6, atol=1e-9) and np.allclose(p, po, rtol=1e-6, atol=1e-9)
+    assert abs(f - fo) <= 1e-6 * fo
+
+
 def test_cfg4_iterations_decrease_cost(ctx):
     """BASELINE cfg4 shape (200 cams / 100k points / 1M obs): LM iterations run and descend."""
     pb = synth.ba_problem(200, 100000, 10, seed=777)
