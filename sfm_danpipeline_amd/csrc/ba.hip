@@ -1751,6 +1751,8 @@ struct sfmhip_ba {
   std::vector<unsigned char> h_cam_used;
   unsigned char* d_cam_used = nullptr;
   bool cam_used_known = false;
+  double* d_flag = nullptr;  // one double: rank-consistent decisions (ba_agree_flag)
+  bool chol_attr_set = false;
   // plan
   Chunk* d_chunks = nullptr;
   int* d_chunk_ids[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -2090,6 +2092,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
     d.xinv = d.red2 + 16;
   }
   BA_A(b->d_cam_used, n_cam);
+  BA_A(b->d_flag, 2);
   BA_A(b->d_chunks, chunks.size());
   for (int c = 0; c < 8; ++c) BA_A(b->d_chunk_ids[c], ids[c].size());
   BA_A(b->d_sig_cams, sig_cams.size());
@@ -2211,6 +2214,19 @@ static int ba_allreduce(sfmhip_ba* b, double* buf, size_t count) {
   return rc == 0 ? SFMHIP_OK : SFMHIP_ERR_COMM;
 }
 
+// sum of a 0/1 flag over the ranks (host value in, host value out): a rank-consistent decision
+static int ba_agree_flag(sfmhip_ba* b, int* flag) {
+  hipStream_t st = b->ctx->stream;
+  double* slot = b->d_flag;
+  double v = *flag ? 1.0 : 0.0;
+  SFM_HIP_TRY(hipMemcpyAsync(slot, &v, sizeof(double), hipMemcpyHostToDevice, st));
+  SFM_TRY(ba_allreduce(b, slot, 1));
+  SFM_HIP_TRY(hipMemcpyAsync(&v, slot, sizeof(double), hipMemcpyDeviceToHost, st));
+  SFM_HIP_TRY(hipStreamSynchronize(st));
+  *flag = v > 0.5 ? 1 : 0;
+  return SFMHIP_OK;
+}
+
 static int ba_prepare_scale(sfmhip_ba* b, int jacobi) {
   hipStream_t st = b->ctx->stream;
   BaDev& d = b->d;
@@ -2319,10 +2335,11 @@ static int ba_reduced_solve(sfmhip_ba* b) {
   const int nt = b->ld / CB;
   int nchol = 0;
   {
-    static bool c2_attr = false;
-    if (!c2_attr) {
+    // (once per problem object, not once per process: the attribute belongs to the device's code object,
+    // and contexts on several devices may share a process)
+    if (!b->chol_attr_set) {
       SFM_HIP_TRY(hipFuncSetAttribute((const void*)chol_step2, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS_BYTES));
-      c2_attr = true;
+      b->chol_attr_set = true;
     }
     for (int k2 = 0; 2 * k2 < nt; ++k2, ++nchol) {
       const int m2 = nt - 2 * k2 - 2;
@@ -2583,7 +2600,14 @@ extern "C" int sfmhip_ba_run(sfmhip_ba* b, const sfmhip_ba_opts* opts, sfmhip_ba
   } else {
     for (;;) {
       if (s.iter >= opts->max_iterations) break;                            // NO_CONVERGENCE
-      if (opts->max_time_s > 0 && elapsed() >= opts->max_time_s) break;     // NO_CONVERGENCE
+      if (opts->max_time_s > 0) {                                           // NO_CONVERGENCE
+        // Every other stop rule reads all-reduced scalars; a wall clock is per rank.  With world > 1 the
+        // ranks agree on it first (one 1-double sum: anybody's limit reached stops everybody), or one
+        // would leave the loop while the others wait for it in the next all-reduce.
+        int up = elapsed() >= opts->max_time_s ? 1 : 0;
+        if (b->world > 1) SFM_TRY(ba_agree_flag(b, &up));
+        if (up) break;
+      }
       if (s.radius < opts->min_radius) {
         term = SFMHIP_BA_CONVERGENCE;
         break;

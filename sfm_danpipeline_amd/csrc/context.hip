@@ -25,7 +25,12 @@ static int init_common(int device, hipStream_t stream, bool own, sfmhip_ctx** ou
   c->device = device;
   c->n_cu = prop.multiProcessorCount;
   if (own) {
-    SFM_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      g_sfmhip_last_hip_error = (int)e;
+      delete c;
+      return SFMHIP_ERR_HIP;
+    }
     c->own_stream = true;
   } else {
     c->stream = stream;

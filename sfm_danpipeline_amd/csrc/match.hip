@@ -1718,9 +1718,22 @@ extern "C" int sfmhip_imageset_create(sfmhip_ctx* ctx, int n_images, const int32
     sfmhip_imageset_destroy(s);
     return rc;
   }
-  SFM_HIP_TRY(hipMemcpy(s->d_tile_img, tile_img.data(), tile_img.size() * sizeof(int), hipMemcpyHostToDevice));
-  SFM_HIP_TRY(hipMemcpy(s->d_tile_first, tile_first.data(), tile_first.size() * sizeof(int), hipMemcpyHostToDevice));
-  SFM_HIP_TRY(hipMemset(s->d_nonintegral, 0xFF, n_images * sizeof(int)));  // -1: set by no prepare pass
+  // (from here on a HIP failure must not leak the object: destroy, then report)
+#define SFM_HIP_TRY_OR_DESTROY(expr, obj, destroy)                                        \
+  do {                                                                                    \
+    hipError_t e__ = (expr);                                                              \
+    if (e__ != hipSuccess) {                                                              \
+      g_sfmhip_last_hip_error = (int)e__;                                                 \
+      fprintf(stderr, "[sfmhip] %s:%d %s -> %s\n", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+      destroy(obj);                                                                       \
+      return SFMHIP_ERR_HIP;                                                              \
+    }                                                                                     \
+  } while (0)
+  SFM_HIP_TRY_OR_DESTROY(hipMemcpy(s->d_tile_img, tile_img.data(), tile_img.size() * sizeof(int), hipMemcpyHostToDevice), s,
+                         sfmhip_imageset_destroy);
+  SFM_HIP_TRY_OR_DESTROY(hipMemcpy(s->d_tile_first, tile_first.data(), tile_first.size() * sizeof(int), hipMemcpyHostToDevice), s,
+                         sfmhip_imageset_destroy);
+  SFM_HIP_TRY_OR_DESTROY(hipMemset(s->d_nonintegral, 0xFF, n_images * sizeof(int)), s, sfmhip_imageset_destroy);  // -1: set by no prepare pass
   s->h_imgs.resize(n_images);
   s->owned_raw.assign(n_images, nullptr);
   size_t off = 0;
@@ -1737,8 +1750,8 @@ extern "C" int sfmhip_imageset_create(sfmhip_ctx* ctx, int n_images, const int32
     I.n_pad = s->n_pad[i];
     off += s->n_pad[i];
   }
-  SFM_HIP_TRY(hipEventCreate(&s->ev_prep0));
-  SFM_HIP_TRY(hipEventCreate(&s->ev_prep1));
+  SFM_HIP_TRY_OR_DESTROY(hipEventCreate(&s->ev_prep0), s, sfmhip_imageset_destroy);
+  SFM_HIP_TRY_OR_DESTROY(hipEventCreate(&s->ev_prep1), s, sfmhip_imageset_destroy);
   *out = s;
   return SFMHIP_OK;
 }
@@ -1901,13 +1914,15 @@ extern "C" int sfmhip_matchplan_create(sfmhip_imageset* s, const int32_t* pairs,
     sfmhip_matchplan_destroy(pl);
     return rc;
   }
-  if (n_pairs) SFM_HIP_TRY(hipMemcpy(pl->d_pairs, pairs, sizeof(int2) * n_pairs, hipMemcpyHostToDevice));
-  if (!items.empty()) SFM_HIP_TRY(hipMemcpy(pl->d_items, items.data(), sizeof(WorkItem) * items.size(), hipMemcpyHostToDevice));
-  SFM_HIP_TRY(hipMemset(pl->d_counts, 0, sizeof(int) * pl->cap_pairs));
-  SFM_HIP_TRY(hipMemset(pl->d_fix_count, 0, sizeof(int)));  // (every run leaves it cleared: compact_kernel)
-  SFM_HIP_TRY(hipMemset(pl->d_fix_arrived, 0, sizeof(int) * FIX_GRID));  // (and these: the merging workgroup)
-  for (auto& e : pl->ev) SFM_HIP_TRY(hipEventCreate(&e));
-  SFM_HIP_TRY(hipEventCreate(&pl->ev_k));
+  if (n_pairs) SFM_HIP_TRY_OR_DESTROY(hipMemcpy(pl->d_pairs, pairs, sizeof(int2) * n_pairs, hipMemcpyHostToDevice), pl, sfmhip_matchplan_destroy);
+  if (!items.empty())
+    SFM_HIP_TRY_OR_DESTROY(hipMemcpy(pl->d_items, items.data(), sizeof(WorkItem) * items.size(), hipMemcpyHostToDevice), pl,
+                           sfmhip_matchplan_destroy);
+  SFM_HIP_TRY_OR_DESTROY(hipMemset(pl->d_counts, 0, sizeof(int) * pl->cap_pairs), pl, sfmhip_matchplan_destroy);
+  SFM_HIP_TRY_OR_DESTROY(hipMemset(pl->d_fix_count, 0, sizeof(int)), pl, sfmhip_matchplan_destroy);  // (every run leaves it cleared: compact_kernel)
+  SFM_HIP_TRY_OR_DESTROY(hipMemset(pl->d_fix_arrived, 0, sizeof(int) * FIX_GRID), pl, sfmhip_matchplan_destroy);  // (and these: the merging workgroup)
+  for (auto& e : pl->ev) SFM_HIP_TRY_OR_DESTROY(hipEventCreate(&e), pl, sfmhip_matchplan_destroy);
+  SFM_HIP_TRY_OR_DESTROY(hipEventCreate(&pl->ev_k), pl, sfmhip_matchplan_destroy);
   *out = pl;
   return SFMHIP_OK;
 }

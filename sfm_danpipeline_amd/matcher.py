@@ -56,6 +56,10 @@ class ImageSet:
             n_rows = [d.shape[0] for d in descriptors]
             dim = descriptors[0].shape[1]
             dtype = _dtype_code(descriptors[0])
+            for i, d in enumerate(descriptors):   # the upload copies n_rows * dim * elemsize bytes of EVERY matrix
+                if d.ndim != 2 or d.shape[1] != dim or d.dtype != descriptors[0].dtype:
+                    raise ValueError(f"descriptor matrix {i}: shape {d.shape} / {d.dtype}, expected (*, {dim}) "
+                                     f"{descriptors[0].dtype} like matrix 0")
         self.n_rows = np.ascontiguousarray(n_rows, np.int32)
         self.n_images = len(self.n_rows)
         self.dim, self.dtype, self.norm = int(dim), int(dtype), int(norm)
