@@ -58,6 +58,9 @@ int sfmhip_init(int device, sfmhip_ctx** out);
 int sfmhip_init_on_stream(int device, void* hip_stream, sfmhip_ctx** out);
 void sfmhip_shutdown(sfmhip_ctx* ctx);
 int sfmhip_synchronize(sfmhip_ctx* ctx);
+/* the context's HIP device and hipStream_t (for code that enqueues next to it: RCCL, see sfmhip_rccl.h) */
+int sfmhip_device(sfmhip_ctx* ctx);
+void* sfmhip_stream(sfmhip_ctx* ctx);
 /* Stage timing (sfmhip_matchplan_last_timing, sfmhip_ba_last_timing) is opt-in: the hipEvents it
  * records between the stages of a run cost ~5-10 us of stream bubble each (3-4 % of a cfg2 sweep
  * or a cfg4 LM iteration).  Off by default; while off the *_last_timing calls report zeros. */

@@ -38,7 +38,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
 
 # every symbol include/sfmhip.h declares (tests check the built library exports all of them)
 SYMBOLS = [
-    "sfmhip_init", "sfmhip_init_on_stream", "sfmhip_shutdown", "sfmhip_synchronize", "sfmhip_set_timing", "sfmhip_error_string",
+    "sfmhip_init", "sfmhip_init_on_stream", "sfmhip_shutdown", "sfmhip_synchronize", "sfmhip_device", "sfmhip_stream", "sfmhip_set_timing", "sfmhip_error_string",
     "sfmhip_last_hip_error", "sfmhip_version", "sfmhip_match_knn2", "sfmhip_imageset_create",
     "sfmhip_imageset_upload", "sfmhip_imageset_adopt_device", "sfmhip_imageset_prepare_async",
     "sfmhip_imageset_destroy", "sfmhip_matchplan_create", "sfmhip_matchplan_set_pairs", "sfmhip_matchplan_run_async", "sfmhip_matchplan_fetch",

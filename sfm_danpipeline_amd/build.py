@@ -77,5 +77,23 @@ def build_host_demo(force=False):
     return exe
 
 
+def build_rccl(force=False):
+    """libsfmhip_rccl.so: the native RCCL binding of the sharded BA (include/sfmhip_rccl.h)."""
+    src = os.path.join(CSRC, "rccl", "sfmhip_rccl.cpp")
+    so = os.path.join(HERE, "libsfmhip_rccl.so")
+    if not force and os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(src), os.path.getmtime(SO)):
+        return so
+    build()
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [_hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(rocm, "include"),
+           "-o", so, src, "-L", HERE, "-lsfmhip", "-L", os.path.join(rocm, "lib"), "-lrccl", "-lamdhip64",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    subprocess.check_call(cmd)
+    exe = os.path.join(HERE, "sfm_rccl_selftest")
+    subprocess.check_call(["g++", "-O2", "-std=c++14", "-o", exe, os.path.join(CSRC, "rccl", "rccl_selftest.cpp"), "-L", HERE,
+                           "-lsfmhip_rccl", "-lsfmhip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")])
+    return so
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

@@ -79,6 +79,9 @@ int sfm_ctx_pinned(sfmhip_ctx* ctx, size_t bytes, void** out) {
   return SFMHIP_OK;
 }
 
+extern "C" int sfmhip_device(sfmhip_ctx* ctx) { return ctx ? ctx->device : -1; }
+extern "C" void* sfmhip_stream(sfmhip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
 extern "C" const char* sfmhip_error_string(int status) {
   switch (status) {
     case SFMHIP_OK: return "ok";

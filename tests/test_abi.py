@@ -62,3 +62,20 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "from oracle" not in text and "import oracle" not in text and "sfm_oracle" not in text, f
+
+
+def test_rccl_library_exports_what_its_header_declares():
+    """libsfmhip_rccl.so (native RCCL binding of the sharded BA) builds, exports every symbol of
+    include/sfmhip_rccl.h and really calls into RCCL (no compute: symbol tables only)."""
+    import subprocess
+    so = build.build_rccl()
+    hdr = open(os.path.join(ROOT, "include", "sfmhip_rccl.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(sfmhip_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared
+    syms = subprocess.run(["nm", "-D", so], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (sfmhip_[a-z0-9_]+)", syms))
+    assert not [s for s in declared if s not in exported]
+    assert re.search(r" U ncclAllReduce", syms) and re.search(r" U ncclCommInitRank", syms)
+    needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True, check=True).stdout
+    assert "librccl.so" in needed and "libsfmhip.so" in needed
