@@ -134,3 +134,14 @@ def test_sharded_reduced_systems_sum_to_the_unsharded_one(orc):
         assert np.abs(S - offdiag).max() <= 1e-12 * np.abs(full[0]).max()
         assert np.abs(g - full[1]).max() <= 1e-12 * np.abs(full[1]).max()
         assert abs(cost - full[2]) <= 1e-12 * full[2]
+
+
+def test_cfg1_temple_plumbing_is_recorded_as_not_runnable_yet():
+    """BASELINE.json configs[0]: data/temple (10 x 640x480 PNG) through OpenCV BFMatcher + Ceres on the CPU.
+    Explicit record instead of silence: nothing in this repository reads an image yet (SURVEY.md section 8f-3,
+    the descriptor front end, is not built), OpenCV/Ceres are not installed, and /root/reference -- where the
+    PNGs live -- does not travel to the GPU box.  The call order of the plumbing (getMatching ->
+    triangulateViews -> adjustCurrentBundle on reference-shaped containers) IS exercised, on synthetic
+    features, by tests/test_gpu_host_cpp.py and tests/test_sanitizers_cpu.py."""
+    import pytest
+    pytest.skip("cfg1 (data/temple plumbing): needs the f-3 descriptor front end (not built) or OpenCV (absent)")

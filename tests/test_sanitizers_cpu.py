@@ -1,0 +1,36 @@
+"""CPU: AddressSanitizer + UBSan runs (`make -C oracle asan`) of the oracle's entry points and of the C++ host
+mirror of the reference's call surface (csrc/host/*.cpp + selftest.cpp).  The host mirror runs against
+tests/stub/sfmhip_stub.c, a stand-in for the C ABI answered by the oracle: sanitizers are not available on the
+GPU pool, so this is where the host-side container handling gets its memory-safety check."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+
+
+def _build():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "asan"], stdout=subprocess.DEVNULL)
+
+
+def _clean(r):
+    bad = [m for m in ("ERROR: AddressSanitizer", "ERROR: LeakSanitizer", "runtime error:") if m in r.stderr]
+    assert r.returncode == 0 and not bad, r.stderr[-3000:]
+
+
+def test_oracle_entry_points_under_asan_ubsan():
+    _build()
+    r = subprocess.run([os.path.join(ROOT, "oracle", "_asan", "oracle_asan_driver")], capture_output=True, text=True,
+                       timeout=600, env=ENV)
+    _clean(r)
+    assert "oracle asan driver ok" in r.stdout
+
+
+def test_cpp_host_mirror_under_asan_ubsan(tmp_path, orc):
+    from tests import hostcpp_io
+    _build()
+    w = hostcpp_io.write_input(tmp_path)
+    r = subprocess.run([os.path.join(ROOT, "oracle", "_asan", "host_selftest_asan"), str(tmp_path / "in.bin"),
+                        str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=600, env=ENV)
+    _clean(r)
+    hostcpp_io.check_output(tmp_path, orc, w)     # and the containers it filled are the oracle's results
