@@ -94,3 +94,17 @@ class TorchAllReduce:
 
     def __call__(self, ptr, count):
         self.dist.all_reduce(self._view(ptr, count), op=self.dist.ReduceOp.SUM, group=self.group)
+
+
+class StagedAllReduce(TorchAllReduce):
+    """The same sum through a HOST staging copy and whatever backend the process group has (gloo):
+    for functional runs of the N>1 path where RCCL cannot be used -- two ranks sharing one device
+    (a single-GPU box).  Synchronous; not a performance path."""
+
+    def __call__(self, ptr, count):
+        v = self._view(ptr, count)
+        self.torch.cuda.synchronize()
+        h = v.cpu()
+        self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+        v.copy_(h)
+        self.torch.cuda.synchronize()

@@ -283,3 +283,54 @@ def test_degenerate_problems_do_not_crash(ctx, orc):
     co, po, fo, so = orc.ba_solve(*one, opts=orc.default_opts(max_time_s=0.0, max_iterations=20))
     assert s.termination == so.termination and np.isfinite(s.final_cost)
     assert abs(s.final_cost - so.final_cost) <= 1e-6 * max(so.final_cost, 1e-12) + 1e-12
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from sfm_danpipeline_amd import _lib as L, bundle as B, sharding, synth as S
+    ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    pb = S.ba_problem(16, 6000, 6, seed=44)
+    loc = sharding.local_ba_problem(pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], pb["pts0"], rank, world)
+    prob = B.BaProblem(16, len(loc["pts"]), loc["obs_cam"], loc["obs_pt"], loc["obs_xy"], ctx=ctx)
+    prob.set_allreduce(sharding.StagedAllReduce(device="cuda:0"), rank, world)
+    prob.set_params(pb["cams0"], loc["pts"], pb["focal0"])
+    s = prob.iterate(6)
+    c, p, f = prob.get_params()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), c=c, p=p, f=f, lo=loc["lo"], hi=loc["hi"], cost=s.final_cost,
+             steps=s.successful_steps)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_share_the_device_and_run_the_sharded_solver(ctx, tmp_path):
+    """The N>1 data path with the device kernels as the per-rank engine: two processes (gloo, the all-reduce
+    staged through the host because RCCL refuses two ranks on one device) each hold half the points; pack,
+    exchange, unpack, redundant reduced solve and per-rank back-substitution must walk the iterates of one
+    process holding everything, and the replicated cameras must agree between the ranks."""
+    import socket
+    import torch.multiprocessing as mp
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    pb = synth.ba_problem(16, 6000, 6, seed=44)
+    one = bundle.BaProblem(16, 6000, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
+    one.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+    s1 = one.iterate(6)
+    c1, p1, f1 = one.get_params()
+    assert int(r0["steps"]) == int(r1["steps"]) == s1.successful_steps
+    assert abs(float(r0["cost"]) - s1.final_cost) <= 1e-9 * s1.final_cost and float(r0["cost"]) == float(r1["cost"])
+    assert np.allclose(r0["c"], c1, rtol=1e-9, atol=1e-12) and abs(float(r0["f"]) - f1) <= 1e-9 * f1
+    assert np.allclose(r0["c"], r1["c"], rtol=1e-12, atol=1e-14)          # replicas stay together
+    # (points: absolute tolerance -- coordinates near zero carry the f64 summation-order noise of the exchange)
+    assert np.allclose(np.concatenate([r0["p"], r1["p"]]), p1, rtol=1e-8, atol=1e-9)
