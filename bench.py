@@ -14,10 +14,18 @@ device synchronisation; `value` is the matching throughput (pairs/s over all ran
 `ba_iterations_per_s` the BA rate, `ms_per_step` their sum per step.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL):
-  * matching is weak-scaled: independent units -- every rank matches the 1225 pairs of its own
-    50-image set, no collective on the data path;
+  * the headline stays N=1-compatible and weak-scaled: independent units -- every rank matches the 1225 pairs
+    of its own 50-image set, no collective on the data path;
+  * `cfg5_strong` (every N, 1 included): BASELINE cfg5 -- the 124 750 pairs of 500 ORB-256 images, Hamming --
+    dealt over the ranks by sharding.shard_pairs, fixed total work, per-pair checksums merged on rank 0:
+    the strong-scaling figure of the matcher, and its checksum does not depend on N;
   * BA is the one cfg4 problem, points block-partitioned over the ranks, the reduced camera
-    system summed by one all-reduce per LM iteration (strong scaling; reported separately).
+    system summed by one all-reduce per LM iteration (strong scaling; `ba_amdahl` splits the iteration
+    into what shards, what is replicated and the exchange).
+
+Extra fields: `sustained` (the same step looped for >= 2 s: past DVFS settling), `value_host_visible`
+(every sweep followed by the packed device-to-host fetch of counts + match lists), the dominant kernel's own
+duration behind `roofline` (`launch_ms`, HIP events on the library's stream around that one launch).
 """
 import argparse
 import json
@@ -44,11 +52,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=96, help="pairs of cfg2 timed on the host cores")
     ap.add_argument("--cpu-ba-iters", type=int, default=8)
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the cfg5 strong-scaling leg")
+    ap.add_argument("--lean", action="store_true",
+                    help="timed regions and per-kernel samples only (no sustained / host-visible loops, no cfg5, no CPU "
+                         "baseline): the command to run under rocprofv3, whose traces grow with every dispatch")
+    ap.add_argument("--sustain-s", type=float, default=2.0, help="seconds of the sustained loops")
     ap.add_argument("--match-streams", type=int, default=1, choices=(1, 2),
                     help="2: consecutive batches alternate between two resident buffers on two HIP streams "
                          "(+5 %% pairs/s; per-kernel durations of overlapping launches are then not comparable "
                          "with the single-launch figure the roofline uses, hence not the default)")
     args = ap.parse_args()
+    if args.lean:
+        args.no_cfg5 = args.no_cpu_baseline = True
 
     import torch
     import torch.distributed as dist
@@ -145,10 +160,32 @@ def main():
         for _ in range(min(args.steps, 5)):
             match_step(one_stream=True)
         tm = plan.last_timing()          # synchronises on the recorded events
-        samples.append((tm["prepare_s"], tm["knn_s"], tm["compact_s"]))
+        samples.append((tm["prepare_s"], tm["knn_kernel_s"], tm["compact_s"], tm["knn_s"]))
     ctx.set_timing(False)
-    prep_s, knn_s, comp_s = [float(np.mean([s[i] for s in samples])) for i in range(3)]
+    prep_s, knn_s, comp_s, knn_stage_s = [float(np.mean([s[i] for s in samples])) for i in range(4)]
     counts = plan.counts()
+
+    # ------------------------------------------------------------------ sustained (>= 2 s) and host-visible rates
+    def loop_for(seconds, fn, unit):
+        barrier()
+        n, t0 = 0, time.perf_counter()
+        while True:
+            for _ in range(unit):
+                fn()
+            n += unit
+            torch.cuda.synchronize(dev)
+            if time.perf_counter() - t0 >= seconds:
+                break
+        barrier()
+        return n, time.perf_counter() - t0
+    n_sus, t_sus = (0, 1.0) if args.lean else loop_for(args.sustain_s, match_step, 50)
+    sustained_pairs_s = n_sus * len(pairs) / t_sus
+
+    def match_and_fetch():
+        match_step(one_stream=True)
+        plan.fetch()                      # counts + packed {q, t, dist} lists on the host: what getMatching's caller sees
+    n_hv, t_hv = (0, 1.0) if args.lean else loop_for(1.0, match_and_fetch, 5)
+    host_visible_pairs_s = n_hv * len(pairs) / t_hv
 
     # ------------------------------------------------------------------ timed: BA, K iterations
     barrier()
@@ -164,6 +201,59 @@ def main():
     ba_t = {k: v - ba_t0[k] for k, v in ba.last_timing().items()}
     ctx.set_timing(False)
     barrier()
+    t0 = time.perf_counter()
+    n_ba_sus = 0
+    while not args.lean and time.perf_counter() - t0 < args.sustain_s:
+        ba.iterate(100)
+        n_ba_sus += 100
+    barrier()
+    sustained_ba_its = n_ba_sus / (time.perf_counter() - t0)
+
+    # ------------------------------------------------------------------ cfg5, strong scaling over the ranks
+    cfg5 = None
+    if not args.no_cfg5:
+        from oracle import orc as _orc_ck      # (the checker's numpy checksum helper only: nothing of it is timed)
+        o_imgs = synth.orb_image_set()         # 500 x 5000 x 32 B, seeded: the same set on every rank
+        o_pairs = synth.all_pairs(len(o_imgs))
+        shards = sharding.shard_pairs(o_pairs, [len(a) for a in o_imgs], world)
+        mine = o_pairs[shards[rank]]
+        o_dev = [torch.from_numpy(a).to(dev) for a in o_imgs]
+        o_set = matcher.ImageSet(n_rows=[len(a) for a in o_imgs], dim=32, dtype=_lib.U8, norm=_lib.HAMMING, ctx=ctx)
+        for i, t in enumerate(o_dev):
+            o_set.adopt_device(i, t.data_ptr(), keepalive=t)
+        o_plan = matcher.MatchPlan(o_set, mine)
+        o_set.prepare_async()
+        o_plan.run_async(0.8)                  # warm-up
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            o_set.prepare_async()
+            o_plan.run_async(0.8)
+        barrier()
+        t_cfg5 = (time.perf_counter() - t0) / 2
+        o_cnt, o_q, o_t, o_d = o_plan.fetch()
+        cs = _orc_ck.pair_checksums(o_cnt, o_q, o_t, o_d)
+        with np.errstate(over="ignore"):
+            part = np.array([np.sum(cs[:, 0], dtype=np.uint64), np.bitwise_xor.reduce(cs[:, 1]) if len(cs) else np.uint64(0),
+                             np.uint64(int(o_cnt.sum()))], np.uint64)
+        if world > 1:
+            tt = torch.tensor([t_cfg5], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_cfg5 = float(tt[0])
+            gathered = [None] * world
+            dist.all_gather_object(gathered, part)       # result merge only: no collective on the data path
+            with np.errstate(over="ignore"):
+                part = np.array([np.sum([g[0] for g in gathered], dtype=np.uint64),
+                                 np.bitwise_xor.reduce(np.array([g[1] for g in gathered], np.uint64)),
+                                 np.sum([g[2] for g in gathered], dtype=np.uint64)], np.uint64)
+        cfg5 = {"workload": "cfg5: 500 img x 5000 ORB-256, all 124750 pairs, Hamming; pairs dealt over the ranks "
+                            "(sharding.shard_pairs), descriptors resident on every rank",
+                "pairs": int(len(o_pairs)), "pairs_this_rank": int(len(mine)), "seconds_per_sweep": round(t_cfg5, 5),
+                "pairs_per_s": round(len(o_pairs) / t_cfg5, 1), "scaling": "strong", "matches": int(part[2]),
+                "checksum": [int(part[0]), int(part[1])]}
+        o_plan.close()
+        o_set.close()
+        del o_dev
 
     # max over ranks
     if world > 1:
@@ -198,20 +288,23 @@ def main():
 
     ops_per_pair = 2.0 * n_feat * n_feat * dim                     # 1.024 GOP per cfg2 pair
     knn_tops = ops_per_pair * len(pairs) / knn_s / 1e12
-    # secondary limiter: the fused top-2 epilogue, 3 VALU lane-ops per distance
-    # (v_mad_i32_i24 + v_med3_u32 + v_min_u32) against 256 CU x 128 lanes x 2.4 GHz
-    valu_tlops = 3.0 * n_feat * n_feat * len(pairs) / knn_s / 1e12
-    roofline = {"kernel": "knn_mfma_kernel<KS=4,L2> (i8 MFMA 32x32x32 + fused top-2)", "bound": "mfma",
+    # secondary limiter: the epilogue, 19 VALU lane-ops per 16 distances
+    # (v_max3_i32 slot maxima over tile pairs + a max3 tree per tile) against 256 CU x 128 lanes x 2.4 GHz
+    valu_tlops = (19.0 / 16.0) * n_feat * n_feat * len(pairs) / knn_s / 1e12
+    roofline = {"kernel": "knn_kernel<KS=4,L2,NU=2,SR=256,NW=4> (i8 MFMA 32x32x32, train norm through the C operand, "
+                          "value-only slot / tile-maximum epilogue, exact resolve of the candidates)", "bound": "mfma",
                 "achieved": round(knn_tops, 2), "peak": I8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
-                "frac": round(knn_tops / I8_DENSE_PEAK_TOPS, 4), "traffic": hbm_bytes("knn_mfma_kernel"),
+                "frac": round(knn_tops / I8_DENSE_PEAK_TOPS, 4), "traffic": hbm_bytes("knn_kernel"),
                 "f32_equivalent_frac": round(knn_tops / F32_MFMA_PEAK_TFLOPS, 3),
                 "valu_epilogue": {"achieved": round(valu_tlops, 2), "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
                                   "frac": round(valu_tlops / VALU_PEAK_TLANEOPS, 4),
-                                  "note": "min/max/med3/mad24 issue at 4 cycles per wave64 op on gfx950 "
-                                          "(scripts/ubench/op_rate.hip): the epilogue, not the MFMA pipe, "
-                                          "bounds this kernel"},
-                "launch_ms": round(knn_s * 1e3, 4), "prepare_ms": round(prep_s * 1e3, 4),
-                "compact_ms": round(comp_s * 1e3, 4)}
+                                  "note": "19 VALU ops per 32x32 tile = 1.19 per distance (v_max3_i32 / v_med3_i32 issue "
+                                          "at ~4 cycles per wave64 op on gfx950: scripts/ubench/epi_mix.hip); the MFMA "
+                                          "pipe bounds the sweep, the per-sweep resolve the rest (DESIGN.md K1)"},
+                "launch_ms": round(knn_s * 1e3, 4), "knn_stage_ms": round(knn_stage_s * 1e3, 4),
+                "prepare_ms": round(prep_s * 1e3, 4), "compact_ms": round(comp_s * 1e3, 4),
+                "note": "launch_ms = that one kernel (hipEvents on the library's stream around its launch, mean of the last "
+                        "step of 4 rounds of back-to-back steps); knn_stage_ms adds the exact / fix-up kernels behind it"}
     n_obs_l, n_pt_l, n_cam = len(loc["obs_cam"]), len(loc["pts"]), 200
     red_dim = 6 * n_cam + 1
     ba_bytes = 3 * n_obs_l * 24 + 2 * n_pt_l * 24 + 2 * red_dim * red_dim * 8 + n_cam * 48   # section 8d
@@ -235,29 +328,51 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import orc   # the checker, timed as the reported host-CPU baseline ("port")
         orc.build()
+        native = orc.use_native()               # -O3 -march=native, compiled on this host
         cores = os.cpu_count() or 1
-        # bounded sample: grow the pair count until the matcher leg is ~10 s of wall time
-        npairs, cpu_match_s, cpu_counts = min(args.cpu_pairs, len(pairs)), 0.0, None
+        # matcher, all cores: a bounded sample grown until the leg is ~5 s of wall time; the per-pair checksums of
+        # (queryIdx, trainIdx, distance bits) -- not just the counts -- must equal those of the GPU lists
+        g_cnt, g_q, g_t, g_d = plan.fetch()
+        g_cs = orc.pair_checksums(g_cnt, g_q, g_t, g_d)
+        npairs, cpu_match_s = min(args.cpu_pairs, len(pairs)), 0.0
         while True:
             t0 = time.perf_counter()
-            cpu_counts = orc.match_many(imgs, pairs[:npairs], threads=cores)
+            cpu_counts, cpu_cs = orc.match_many_checksum(imgs, pairs[:npairs], threads=cores)
             cpu_match_s = time.perf_counter() - t0
             if cpu_match_s >= 5.0 or npairs == len(pairs):
                 break
-            npairs = min(len(pairs), max(npairs * 2, int(npairs * 10.0 / max(cpu_match_s, 1e-3))))
-        assert np.array_equal(cpu_counts, counts[:npairs]), "CPU baseline and GPU match counts differ"
-        cpu_ba_s, _ = orc.ba_time_iterations(pb["cams0"], pb["pts0"], pb["focal0"], pb["obs_cam"], pb["obs_pt"],
-                                             pb["obs_xy"], args.cpu_ba_iters)
+            npairs = min(len(pairs), max(npairs * 2, int(npairs * 8.0 / max(cpu_match_s, 1e-3))))
+        assert np.array_equal(cpu_counts, g_cnt[:npairs]), "CPU baseline and GPU match counts differ"
+        assert np.array_equal(cpu_cs, g_cs[:npairs]), "CPU baseline and GPU match lists differ (per-pair checksums)"
+        # matcher, one thread: a few pairs (~1 s each)
+        n1 = 2
+        t0 = time.perf_counter()
+        c1, cs1 = orc.match_many_checksum(imgs, pairs[:n1], threads=1)
+        cpu_match1_s = time.perf_counter() - t0
+        assert np.array_equal(cs1, g_cs[:n1])
+        # BA: one thread (Ceres' default num_threads, nothing at src/BundleAdjustment.cpp:115-121 overrides it) and all cores
+        ba_args = (pb["cams0"], pb["pts0"], pb["focal0"], pb["obs_cam"], pb["obs_pt"], pb["obs_xy"])
+        cpu_ba_s, _ = orc.ba_time_iterations(*ba_args, args.cpu_ba_iters)
+        ba_threads = min(cores, 16)            # (more only adds private copies of the 11.5 MB reduced system to sum up)
+        orc.ba_set_threads(ba_threads)
+        cpu_ba_all_s, _ = orc.ba_time_iterations(*ba_args, args.cpu_ba_iters)
+        orc.ba_set_threads(1)
         cpu_pairs_s = npairs / cpu_match_s
         cpu_ba_its = args.cpu_ba_iters / cpu_ba_s
         cpu_step_ms = 1e3 * (len(pairs) / cpu_pairs_s + 1.0 / cpu_ba_its)
         cpu_baseline = {"value": round(cpu_pairs_s, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
                         "sample": f"first {npairs} of the 1225 cfg2 pairs, oracle matcher parallel over pairs x rows on "
-                                  f"{cores} threads ({cpu_match_s:.1f} s); {args.cpu_ba_iters} LM iterations of cfg4 "
-                                  f"on 1 thread like Ceres' default ({cpu_ba_s:.1f} s)",
+                                  f"{cores} threads ({cpu_match_s:.1f} s), lists checksum-equal to the GPU's; "
+                                  f"{args.cpu_ba_iters} LM iterations of cfg4 on 1 thread like Ceres' default ({cpu_ba_s:.1f} s)",
+                        "march_native": bool(native),
+                        "matcher_1_thread_pairs_per_s": round(n1 / cpu_match1_s, 4),
                         "ba_iterations_per_s": round(cpu_ba_its, 4), "ba_cores": 1,
+                        "ba_threaded_iterations_per_s": round(args.cpu_ba_iters / cpu_ba_all_s, 4), "ba_threads": ba_threads,
                         "ms_per_step_extrapolated": round(cpu_step_ms, 1),
-                        "gpu_over_cpu_step": round(cpu_step_ms / (ms_match + ms_ba), 1)}
+                        "gpu_over_cpu_step": round(cpu_step_ms / (ms_match + ms_ba), 1),
+                        "note": "a reported baseline, not the target: the oracle restates OpenCV's / Ceres' arithmetic "
+                                "row by row (no blocking, no SIMD kernels of a tuned BLAS); the roofline fractions say "
+                                "what the GPU kernels are worth"}
 
     if rank == 0:
         out = {
@@ -277,6 +392,18 @@ def main():
                        "match_streams": N_STREAMS,
                        "parallelism": f"pairs x{world} (weak" + (f"; consecutive batches alternate between {N_STREAMS} HIP "
                                       "streams per GPU" if N_STREAMS > 1 else "") + f"), BA points/{world} + all-reduce"},
+            "sustained": {"seconds": args.sustain_s, "pairs_per_s": round(sustained_pairs_s, 1),
+                          "ba_iterations_per_s": round(sustained_ba_its, 2)},
+            "value_host_visible": {"pairs_per_s": round(host_visible_pairs_s, 1),
+                                   "note": "every sweep followed by sfmhip_matchplan_fetch: counts + one packed "
+                                           "{queryIdx, trainIdx, distance} array to host memory"},
+            "cfg5_strong": cfg5,
+            "ba_amdahl": {"sharded_ms": round(1e3 * (ba_t["eliminate_s"] + ba_t["backsub_s"]) / args.steps, 4),
+                          "replicated_ms": round(1e3 * ba_t["solve_s"] / args.steps, 4),
+                          "allreduce_ms": round(1e3 * ba_t["allreduce_s"] / args.steps, 4),
+                          "note": "linearise + eliminate + back-substitute shard with the points; the reduced solve "
+                                  "runs on every rank; the exchange is added: BA iterations/s do not scale with N "
+                                  "(DESIGN.md section 5)"},
             "roofline": roofline, "roofline_ba": roofline_ba, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))

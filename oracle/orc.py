@@ -60,6 +60,21 @@ class BaSummary(C.Structure):
 
 
 _lib = None
+_native = False
+
+
+def use_native():
+    """Switch this process to the oracle compiled -march=native on THIS host (bench.py's cpu_baseline leg);
+    returns True if that build is in use (False: the compile failed, the portable build stays)."""
+    global _lib, _native, _SO
+    so = os.path.join(_HERE, "libsfm_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libsfm_oracle_native.so"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+    except (subprocess.CalledProcessError, OSError):
+        return False
+    _SO, _lib, _native = so, None, True
+    return True
 
 
 def lib():
@@ -265,6 +280,14 @@ def ba_reduced_system(cams6, pts3, focal, obs_cam, obs_pt, obs_xy, radius=1e4, s
     if rc:
         raise RuntimeError(f"orc_ba_reduced_system rc={rc}")
     return S, g, float(cost[0]), sc_out
+
+
+def ba_set_threads(n):
+    """Threads of the BA oracle's per-point passes (1 = Ceres' default and the parity order)."""
+    L = lib()
+    L.orc_ba_set_threads.argtypes = [C.c_int]
+    L.orc_ba_set_threads.restype = None
+    L.orc_ba_set_threads(int(n))
 
 
 def ba_time_iterations(cams6, pts3, focal, obs_cam, obs_pt, obs_xy, iters):

@@ -95,6 +95,8 @@ typedef struct {
 } orc_ba_summary;
 
 void orc_ba_default_opts(orc_ba_opts* o);
+/* threads of the per-point passes (what Ceres' num_threads does); 1 = the serial reference order (default) */
+void orc_ba_set_threads(int n);
 
 /* ceres::Solve(DENSE_SCHUR, LM) as configured at src/BundleAdjustment.cpp:115-123.
  * Parameters are updated in place with the best accepted iterate whatever the termination

@@ -14,10 +14,18 @@
 #include "sfm_oracle.h"
 #include <float.h>
 #include <math.h>
+#include <omp.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+
+/* Threads of the evaluation / elimination / back-substitution passes (OpenMP over points), for the "all cores"
+ * leg of the CPU baseline: what Ceres does with num_threads > 1.  The dense Cholesky stays on one thread (Eigen
+ * LLT in Ceres 1.13).  1 (the default, Ceres' default: src/BundleAdjustment.cpp:115-121 sets no thread count)
+ * runs the loops serially in their written order: the parity tests use that. */
+static int g_threads = 1;
+void orc_ba_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 
 static double now_s(void) {
   struct timespec ts;
@@ -297,6 +305,7 @@ static void ba_free(ba_t* b) {
 /* cost only, at (cams, pts, focal) */
 static double ba_cost(const ba_t* b, const double* cams, const double* pts, double focal) {
   double cost = 0;
+#pragma omp parallel for if (g_threads > 1) num_threads(g_threads) reduction(+ : cost) schedule(static)
   for (int p = 0; p < b->np; ++p)
     for (int k = b->pt_ptr[p]; k < b->pt_ptr[p + 1]; ++k) {
       double r[2];
@@ -312,7 +321,8 @@ static double ba_linearize(ba_t* b, int first, int jacobi_scaling) {
   double cost = 0;
   memset(b->grad_c, 0, sizeof(double) * 6 * (size_t)b->nc);
   memset(b->grad_p, 0, sizeof(double) * 3 * (size_t)b->np);
-  b->grad_f = 0;
+  double grad_f = 0;
+#pragma omp parallel for if (g_threads > 1) num_threads(g_threads) reduction(+ : cost, grad_f) schedule(static)
   for (int p = 0; p < b->np; ++p)
     for (int k = b->pt_ptr[p]; k < b->pt_ptr[p + 1]; ++k) {
       const int c = b->o_cam[k];
@@ -320,10 +330,15 @@ static double ba_linearize(ba_t* b, int first, int jacobi_scaling) {
       double *Jc = b->Jc + 12 * k, *Jp = b->Jp + 6 * k, *Jf = b->Jf + 2 * k;
       orc_ba_residual(b->cams + 6 * c, b->pts + 3 * p, b->focal, b->o_xy + 2 * k, r, Jc, Jp, Jf);
       cost += r[0] * r[0] + r[1] * r[1];
-      for (int j = 0; j < 6; ++j) b->grad_c[6 * c + j] += Jc[j] * r[0] + Jc[6 + j] * r[1];
+      for (int j = 0; j < 6; ++j) {
+        const double v = Jc[j] * r[0] + Jc[6 + j] * r[1];
+#pragma omp atomic
+        b->grad_c[6 * c + j] += v;
+      }
       for (int j = 0; j < 3; ++j) b->grad_p[3 * p + j] += Jp[j] * r[0] + Jp[3 + j] * r[1];
-      b->grad_f += Jf[0] * r[0] + Jf[1] * r[1];
+      grad_f += Jf[0] * r[0] + Jf[1] * r[1];
     }
+  b->grad_f = grad_f;
   if (first && jacobi_scaling) {
     double* nc2 = (double*)xcalloc((size_t)6 * b->nc, sizeof(double));
     double* np2 = (double*)xcalloc((size_t)3 * b->np, sizeof(double));
@@ -343,6 +358,7 @@ static double ba_linearize(ba_t* b, int first, int jacobi_scaling) {
     free(np2);
   }
   /* scale columns */
+#pragma omp parallel for if (g_threads > 1) num_threads(g_threads) schedule(static)
   for (int p = 0; p < b->np; ++p)
     for (int k = b->pt_ptr[p]; k < b->pt_ptr[p + 1]; ++k) {
       const int c = b->o_cam[k];
@@ -418,15 +434,26 @@ static int ba_eliminate(ba_t* b, double radius, double* S, double* g) {
   for (int i = 0; i < fo; ++i) S[(size_t)i * dim + i] = b->diag_c[i] / radius;
   S[(size_t)fo * dim + fo] = b->diag_f / radius;
   enum { MAXN = 4096 };
+  int rc = 0;
+  /* one thread: straight into S, g.  More: every thread sums its points into a private copy, added up below */
+  const int T = g_threads > 1 ? (g_threads < 32 ? g_threads : 32) : 1;
+  double* Sall = T > 1 ? (double*)xcalloc((size_t)T * ((size_t)dim * dim + dim), sizeof(double)) : NULL;
+  double* const S_out = S;
+  double* const g_out = g;
+#pragma omp parallel num_threads(T) if (T > 1)
+  {
+  const int tid = T > 1 ? omp_get_thread_num() : 0;
+  double* S = T > 1 ? Sall + (size_t)tid * ((size_t)dim * dim + dim) : S_out;
+  double* g = T > 1 ? S + (size_t)dim * dim : g_out;
   double* W = (double*)xcalloc((size_t)MAXN * 18, sizeof(double));  /* Jc^T Jp per obs */
   double* WC = (double*)xcalloc((size_t)MAXN * 18, sizeof(double)); /* W * Cinv */
-  int rc = 0;
+#pragma omp for schedule(static)
   for (int p = 0; p < b->np; ++p) {
     const int k0 = b->pt_ptr[p], n = b->pt_ptr[p + 1] - k0;
-    if (n == 0) continue;
+    if (n == 0 || rc) continue;
     if (n > MAXN) {
       rc = -4;
-      break;
+      continue;
     }
     double C[9] = {0}, gp[3] = {0}, wf[3] = {0};
     for (int j = 0; j < 3; ++j) C[4 * j] = b->diag_p[3 * p + j] / radius;
@@ -456,7 +483,7 @@ static int ba_eliminate(ba_t* b, double radius, double* S, double* g) {
     double Ci[9];
     if (inv3_spd(C, Ci)) {
       rc = -5;
-      break;
+      continue;
     }
     double Cg[3], Cwf[3];
     for (int a = 0; a < 3; ++a) {
@@ -511,6 +538,18 @@ static int ba_eliminate(ba_t* b, double radius, double* S, double* g) {
   }
   free(W);
   free(WC);
+  }
+  if (T > 1) {
+    for (int t = 0; t < T; ++t) {
+      const double* St = Sall + (size_t)t * ((size_t)dim * dim + dim);
+#pragma omp parallel for num_threads(T) schedule(static)
+      for (int i = 0; i < dim; ++i) {
+        for (int j = i; j < dim; ++j) S[(size_t)i * dim + j] += St[(size_t)i * dim + j];
+        g[i] += St[(size_t)dim * dim + i];
+      }
+    }
+    free(Sall);
+  }
   if (rc) return rc;
   for (int i = 0; i < dim; ++i) /* mirror to a full symmetric matrix */
     for (int j = i + 1; j < dim; ++j) S[(size_t)j * dim + i] = S[(size_t)i * dim + j];
@@ -560,6 +599,8 @@ static int ba_backsub(ba_t* b, double radius, const double* z) {
   const int fo = 6 * b->nc;
   for (int i = 0; i < fo; ++i) b->step_c[i] = -z[i];
   b->step_f = -z[fo];
+  int bad = 0;
+#pragma omp parallel for if (g_threads > 1) num_threads(g_threads) schedule(static)
   for (int p = 0; p < b->np; ++p) {
     const int k0 = b->pt_ptr[p], n = b->pt_ptr[p + 1] - k0;
     if (n == 0) {
@@ -582,16 +623,20 @@ static int ba_backsub(ba_t* b, double radius, const double* z) {
       }
     }
     double Ci[9];
-    if (inv3_spd(C, Ci)) return -5;
+    if (inv3_spd(C, Ci)) {
+      bad = 1;
+      continue;
+    }
     for (int a = 0; a < 3; ++a)
       b->step_p[3 * p + a] = -(Ci[3 * a] * e[0] + Ci[3 * a + 1] * e[1] + Ci[3 * a + 2] * e[2]);
   }
-  return 0;
+  return bad ? -5 : 0;
 }
 
 /* model_cost_change = -(J d).(r + J d / 2) with the scaled J and scaled step */
 static double ba_model_cost_change(const ba_t* b) {
   double acc = 0;
+#pragma omp parallel for if (g_threads > 1) num_threads(g_threads) reduction(+ : acc) schedule(static)
   for (int p = 0; p < b->np; ++p)
     for (int k = b->pt_ptr[p]; k < b->pt_ptr[p + 1]; ++k) {
       const int c = b->o_cam[k];
