@@ -445,17 +445,35 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
 
   // Stage copy: the tile image is already in LDS order, so a stage is a linear copy; LDS-DMA
   // (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs, no ds_write) moves it.
+  // (buffer_load ... lds, not global_load_lds: the compiler books the latter as a FLAT access that may touch
+  // LDS, and while one is pending it turns every counted LDS wait into s_waitcnt lgkmcnt(0) -- each MFMA
+  // that needs a fragment would then wait for the youngest ds_read in flight, not for its own)
+  const __amdgpu_buffer_rsrc_t rs_tiles = __builtin_amdgcn_make_buffer_rsrc((void*)T.tiles, 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_cin = __builtin_amdgcn_make_buffer_rsrc((void*)T.cin, 0, 0x7FFFFFFF, 0x00020000);
   auto stage_copy = [&](int stage, unsigned char* dstb) {
+    const int off = stage * STAGE_ROW_BYTES;  // (a tile image stays below 2 GB: n_pad * RB)
+#if SFM_DBG == 6
     const unsigned char* src = (const unsigned char*)T.tiles + (size_t)stage * STAGE_ROW_BYTES;
 #pragma unroll
     for (int i = 0; i < PIECES; ++i)
       __builtin_amdgcn_global_load_lds((const SFM_GLOBAL void*)(src + (size_t)(i * NT + tid) * 16),
                                        (__attribute__((address_space(3))) void*)(dstb + i * (NT * 16) + wave * 1024), 16, 0, 0);
-    // SR C inputs; threads beyond SR copy those of the next stage (the array is padded by 512)
 #pragma unroll
     for (int i = 0; i < CIN_COPIES; ++i)
       __builtin_amdgcn_global_load_lds((const SFM_GLOBAL void*)(T.cin + (size_t)stage * SR + i * NT + tid),
                                        (__attribute__((address_space(3))) void*)(dstb + STAGE_ROW_BYTES + i * (NT * 4) + wave * 256), 4, 0, 0);
+    (void)off;
+#else
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_tiles, (__attribute__((address_space(3))) void*)(dstb + i * (NT * 16) + wave * 1024),
+                                               16, (i * NT + tid) * 16, off, 0, 0);
+    // SR C inputs; threads beyond SR copy those of the next stage (the array is padded by 512)
+#pragma unroll
+    for (int i = 0; i < CIN_COPIES; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_cin, (__attribute__((address_space(3))) void*)(dstb + STAGE_ROW_BYTES + i * (NT * 4) + wave * 256),
+                                               4, (i * NT + tid) * 4, stage * SR * 4, 0, 0);
+#endif
   };
   auto ld_afrag = [&](const unsigned char* tb, int ks) -> v4i {  // tb: the tile inside a stage buffer
     const int4 x = *(const int4*)(tb + aoff[ks]);
@@ -500,10 +518,7 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
       const unsigned char* sb = ldsA;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) F0[ks] = ld_afrag(sb, ks);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) F1[ks] = ld_afrag(sb + TILE_BYTES, ks);
-      ld_cin(sb, 0, C0);
-      ld_cin(sb, 1, C1);
+      ld_cin(sb, 0, C0);  // (F1 / C1 of a pair are fetched by the pair's first chain)
 #pragma unroll
       for (int e = 0; e < 16; ++e) X0[e] = X1[e] = Y0[e] = Y1[e] = HPAD;  // draining these changes nothing
     }
@@ -513,9 +528,13 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
     SFM_STAMP(1);
 
     // One chain: MFMAs of query tile UF against (F0, F1) into (FA, FB); the epilogue of (DA, DB)
-    // (query tile UD, tile tags tag, tag-1) spread between them; with RELOAD, every fragment and C
-    // input is re-fetched for the next tile pair (tiles NT0, NT1 in buffer NSB) right after its last use.
-#define SFM_CHAIN(FA, FB, UF, DA, DB, UD, RELOAD, NSB, NT0, NT1)                                            \
+    // (query tile UD, tile tags tag, tag-1) spread between them.  The LDS reads come in two batches, each
+    // KS MFMAs ahead of its first use (the compiler waits for ALL outstanding LDS reads before an MFMA that
+    // needs any of them, so a read issued just before such a wait would cost its whole latency):
+    //   LD1: at the chain's first group, F1 / C1 of THIS pair (tile T1 of buffer SB1), used from group KS on;
+    //   LD0: in groups 0..KS-1, each F0 fragment right after its last use (and C0 after the first MFMA), of the
+    //        NEXT pair (tile T0 of SB0): used by the next chain, KS groups later at the earliest.
+#define SFM_CHAIN(FA, FB, UF, DA, DB, UD, LD1, SB1, T1, LD0, SB0, T0)                                       \
   do {                                                                                                      \
     _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_) {                                                     \
       const int ks_ = g_ % KS;                                                                              \
@@ -524,11 +543,13 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
         else FB[ks_] += F1[ks_][0] + C1[ks_];                                                               \
       } else if (g_ < KS) FA = __builtin_amdgcn_mfma_i32_32x32x32_i8(F0[ks_], bq[UF][ks_], ks_ == 0 ? C0 : FA, 0, 0, 0); \
       else FB = __builtin_amdgcn_mfma_i32_32x32x32_i8(F1[ks_], bq[UF][ks_], ks_ == 0 ? C1 : FB, 0, 0, 0);  \
-      if (RELOAD) {                                                                                         \
-        if (g_ < KS) F0[ks_] = ld_afrag((NSB) + (NT0) * TILE_BYTES, ks_);                                   \
-        else F1[ks_] = ld_afrag((NSB) + (NT1) * TILE_BYTES, ks_);                                           \
-        if (g_ == 0) ld_cin(NSB, NT0, C0);                                                                  \
-        if (g_ == KS) ld_cin(NSB, NT1, C1);                                                                 \
+      if ((LD1) && g_ == 0) {                                                                               \
+        _Pragma("unroll") for (int k2_ = 0; k2_ < KS; ++k2_) F1[k2_] = ld_afrag((SB1) + (T1) * TILE_BYTES, k2_); \
+        ld_cin(SB1, T1, C1);                                                                                \
+      }                                                                                                     \
+      if ((LD0) && g_ < KS) {                                                                               \
+        F0[ks_] = ld_afrag((SB0) + (T0) * TILE_BYTES, ks_);                                                 \
+        if (g_ == 0) ld_cin(SB0, T0, C0);                                                                   \
       }                                                                                                     \
       if (SFM_DBG != 2) switch (g_) {                                                                       \
         SFM_EPI_CASES(DA, DB, UD)                                                                           \
@@ -552,20 +573,26 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
       for (int tp = 0; tp < TP; ++tp) {
         const bool last = tp == TP - 1;
         if (NU == 2) {
-          SFM_CHAIN(X0, X1, 0, Y0, Y1, 1, false, sb, 0, 0);  // drains the previous pair of query tile 1
+          // query tile 0 against the pair (drains the previous pair of query tile 1); fetches the pair's second tile
+          SFM_CHAIN(X0, X1, 0, Y0, Y1, 1, true, sb, 2 * tp + 1, false, sb, 0);
           tag -= 2;
           if (last) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the next stage has landed
             __syncthreads();
           }
-          SFM_CHAIN(Y0, Y1, NU - 1, X0, X1, 0, true, last ? nb : sb, last ? 0 : 2 * tp + 2, last ? 1 : 2 * tp + 3);
+          // query tile 1 against the pair (drains query tile 0 of it); fetches the next pair's first tile
+          SFM_CHAIN(Y0, Y1, NU - 1, X0, X1, 0, false, sb, 0, true, last ? nb : sb, last ? 0 : 2 * tp + 2);
         } else {
           if (last) {
+            // (the pair's second tile before the barrier: past it nothing may read this stage's buffer)
+#pragma unroll
+            for (int k2 = 0; k2 < KS; ++k2) F1[k2] = ld_afrag(sb + (2 * tp + 1) * TILE_BYTES, k2);
+            ld_cin(sb, 2 * tp + 1, C1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
           }
-          if ((tp & 1) == 0) SFM_CHAIN(X0, X1, 0, Y0, Y1, 0, true, last ? nb : sb, last ? 0 : 2 * tp + 2, last ? 1 : 2 * tp + 3);
-          else SFM_CHAIN(Y0, Y1, 0, X0, X1, 0, true, last ? nb : sb, last ? 0 : 2 * tp + 2, last ? 1 : 2 * tp + 3);
+          if ((tp & 1) == 0) SFM_CHAIN(X0, X1, 0, Y0, Y1, 0, !last, sb, 2 * tp + 1, true, last ? nb : sb, last ? 0 : 2 * tp + 2);
+          else SFM_CHAIN(Y0, Y1, 0, X0, X1, 0, !last, sb, 2 * tp + 1, true, last ? nb : sb, last ? 0 : 2 * tp + 2);
           tag -= 2;
         }
       }
@@ -974,16 +1001,20 @@ __global__ __launch_bounds__(256, 2) void knn_keyed_kernel(const ImgDev* __restr
 
   // Stage copy: the tile image is already in LDS order, so a stage is a linear copy; LDS-DMA
   // (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs, no ds_write) moves it.
+  // (buffer_load ... lds: see knn_kernel)
+  const __amdgpu_buffer_rsrc_t rs_tiles = __builtin_amdgcn_make_buffer_rsrc((void*)T.tiles, 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_cin = __builtin_amdgcn_make_buffer_rsrc((void*)T.cin, 0, 0x7FFFFFFF, 0x00020000);
   auto stage_copy = [&](int stage, unsigned char* dstb) {
-    const unsigned char* src = (const unsigned char*)T.tiles + (size_t)stage * STAGE_ROW_BYTES;
+    const int off = stage * STAGE_ROW_BYTES;
 #pragma unroll
     for (int i = 0; i < PIECES; ++i)
-      __builtin_amdgcn_global_load_lds((const SFM_GLOBAL void*)(src + (size_t)(i * 256 + tid) * 16),
-                                       (__attribute__((address_space(3))) void*)(dstb + i * 4096 + wave * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_tiles, (__attribute__((address_space(3))) void*)(dstb + i * 4096 + wave * 1024), 16,
+                                               (i * 256 + tid) * 16, off, 0, 0);
     if (wave < SR / 64)
-      __builtin_amdgcn_global_load_lds((const SFM_GLOBAL void*)(T.cin + (size_t)stage * SR + tid),
-                                       (__attribute__((address_space(3))) void*)(dstb + STAGE_ROW_BYTES + wave * 256), 4, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_cin, (__attribute__((address_space(3))) void*)(dstb + STAGE_ROW_BYTES + wave * 256), 4,
+                                               tid * 4, stage * SR * 4, 0, 0);
   };
+
   stage_copy(0, ldsA);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
