@@ -65,10 +65,20 @@ def build_host_demo(force=False):
     """C++ host mirror (Sfm.h / BundleAdjustment.h call surface) + its self-test executable."""
     host = os.path.join(CSRC, "host")
     exe = os.path.join(HERE, "sfm_host_selftest")
-    srcs = [os.path.join(host, f) for f in ("Sfm.cpp", "BundleAdjustment.cpp", "selftest.cpp")]
-    if not all(os.path.exists(s) for s in srcs):
-        return None
-    if not force and os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(s) for s in srcs):
+    return _build_host_exe(exe, ("Sfm.cpp", "SfmIO.cpp", "BundleAdjustment.cpp", "selftest.cpp"), force)
+
+
+def build_io_demo(force=False):
+    """The I/O self-test of the host mirror (imagesLOAD / getCameraMatrix / PMVS2).
+    Runs without a GPU: the host classes open the device only when a matching / BA call needs it."""
+    return _build_host_exe(os.path.join(HERE, "sfm_io_selftest"), ("Sfm.cpp", "SfmIO.cpp", "BundleAdjustment.cpp", "io_selftest.cpp"), force)
+
+
+def _build_host_exe(exe, files, force):
+    host = os.path.join(CSRC, "host")
+    srcs = [os.path.join(host, f) for f in files]
+    deps = srcs + [os.path.join(host, f) for f in os.listdir(host) if f.endswith(".h")]
+    if not force and os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(s) for s in deps):
         return exe
     build()
     cmd = ["g++", "-O2", "-std=c++14", "-I", os.path.join(HERE, "..", "include"), "-I", host, "-o", exe] + srcs + \

@@ -20,6 +20,12 @@ class StructFromMotion {
   int detector;
   std::set<int> nDoneViews;  // reference include/Sfm.h:24-25
   std::set<int> nGoodViews;
+  // image I/O state, reference include/Sfm.h:18-23
+  std::vector<cv::Mat> mColorImages;
+  std::vector<cv::Mat> mGrayImages;
+  std::vector<cv::Mat> nImages;
+  std::vector<std::string> nImagesPath;
+  std::string pathImages;
   // pair-match cache: getMatching is a pure function of two descriptor
   // matrices and the reference calls it ~1.5 N^2 times for N(N-1)/2 distinct pairs
   std::map<std::pair<int, int>, Matching> pairCache;
@@ -61,6 +67,29 @@ class StructFromMotion {
   // reference src/Sfm.cpp:883-888 is a stub whose call names a member that no longer exists;
   // wired here with imagesPts2D, the member of the required type
   void adjustCurrentBundle();
+
+  // ---- I/O and interchange formats (csrc/host/SfmIO.cpp)
+  // reference include/Sfm.h:77, src/Sfm.cpp:118-198: scan a directory for .jpg/.png, sort, decode to BGR,
+  // x0.6 bilinear iff rows > 480 and cols > 640, colour + gray copies.  PNG is decoded here (no OpenCV, no
+  // libpng); a .jpg in the directory is reported and fails the load (no JPEG decoder in this build).
+  bool imagesLOAD(const std::string& directoryPath);
+  // reference include/Sfm.h:99, src/Sfm.cpp:203-252: the OpenCV FileStorage XML with Camera_Matrix and
+  // Distortion_Coefficients.  Values are read as the numbers the file holds (the reference reads a `dt f`
+  // matrix through at<double>); coefficient slots kept in file order.
+  bool getCameraMatrix(const std::string str);
+  // reference include/Sfm.h:179, src/Sfm.cpp:1246-1303: denseCloud/{visualize,txt,models}, options.txt,
+  // visualize/%04d.jpg = a byte copy of the input file (what the reference's `cp -f` does; its imwrite
+  // targets the command string and writes nothing), txt/%04d.txt = "CONTOUR" + K*P.  Does NOT run pmvs2.
+  void PMVS2();
+  // reference src/Sfm.cpp:69-81 (step 8 of map3D): denseCloud/models/options.txt.ply -> MAP3D.pcd.  The reference
+  // does this with pcl::PLYReader + pcl::io::savePCDFile (ASCII, PointXYZRGB); here a PLY reader (ascii and
+  // binary_little_endian; x y z [nx ny nz] [diffuse_]red green blue) and a PCD v0.7 ASCII writer in the layout PCL
+  // 1.8 documents (FIELDS x y z rgb, rgb = the packed 0x00RRGGBB word printed as a float).  Returns the point count
+  // (0 = "ply file is empty", the reference's failure case).  Not pinned against PCL: it is absent from the image.
+  static size_t convertPLYtoPCD(const std::string& plyPath, const std::string& pcdPath);
+  const std::vector<cv::Mat>& colorImages() const { return mColorImages; }
+  const std::vector<cv::Mat>& grayImages() const { return mGrayImages; }
+  const std::vector<std::string>& imagePaths() const { return nImagesPath; }
 
   // ---- stand-ins for the out-of-scope front end: hand the pipeline state in directly
   void setDescriptors(const std::vector<cv::Mat>& d) {

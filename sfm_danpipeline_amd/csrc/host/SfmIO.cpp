@@ -1,0 +1,624 @@
+// SfmIO.cpp -- image loading, calibration XML and PMVS2 export of the reference's StructFromMotion
+// (src/Sfm.cpp:118-252, 1246-1303), without OpenCV / Boost / libpng: a PNG decoder
+// (zlib inflate + unfiltering), cv::resize(INTER_LINEAR) and cv::cvtColor(BGR2GRAY) for 8-bit images restated
+// from OpenCV 3.4.1's fixed-point arithmetic, a reader for the two opencv-matrix nodes of the calibration file.
+// Host code only: this row has no performance content.
+#include <dirent.h>
+#include <sys/stat.h>
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include "Sfm.h"
+
+namespace {
+
+// ---------------------------------------------------------------- zlib inflate (RFC 1950/1951)
+struct BitReader {
+  const uint8_t* p;
+  size_t n, pos;
+  uint32_t bits;
+  int nbits;
+  bool ok;
+  BitReader(const uint8_t* d, size_t len) : p(d), n(len), pos(0), bits(0), nbits(0), ok(true) {}
+  uint32_t get(int k) {
+    while (nbits < k) {
+      if (pos >= n) {
+        ok = false;
+        return 0;
+      }
+      bits |= (uint32_t)p[pos++] << nbits;
+      nbits += 8;
+    }
+    const uint32_t v = bits & ((1u << k) - 1u);
+    bits >>= k;
+    nbits -= k;
+    return k ? v : 0;
+  }
+};
+struct Huffman {
+  uint16_t count[16], symbol[288];
+  void build(const uint8_t* len, int n) {
+    for (int i = 0; i < 16; ++i) count[i] = 0;
+    for (int i = 0; i < n; ++i) count[len[i]]++;
+    count[0] = 0;
+    uint16_t offs[16];
+    offs[1] = 0;
+    for (int i = 1; i < 15; ++i) offs[i + 1] = offs[i] + count[i];
+    for (int i = 0; i < n; ++i)
+      if (len[i]) symbol[offs[len[i]]++] = (uint16_t)i;
+  }
+  int decode(BitReader& br) const {
+    int code = 0, first = 0, index = 0;
+    for (int l = 1; l <= 15; ++l) {
+      code |= (int)br.get(1);
+      if (!br.ok) return -1;
+      const int c = count[l];
+      if (code - c < first) return symbol[index + (code - first)];
+      index += c;
+      first += c;
+      first <<= 1;
+      code <<= 1;
+    }
+    return -1;
+  }
+};
+bool inflate_zlib(const std::vector<uint8_t>& in, std::vector<uint8_t>& out) {
+  if (in.size() < 6 || (in[0] & 0x0F) != 8 || ((in[0] << 8) | in[1]) % 31 != 0 || (in[1] & 0x20)) return false;
+  BitReader br(in.data() + 2, in.size() - 2);
+  static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+  static const uint16_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+  static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+  static const uint16_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+  int last = 0;
+  while (!last) {
+    last = (int)br.get(1);
+    const int type = (int)br.get(2);
+    if (!br.ok) return false;
+    if (type == 0) {
+      br.bits = 0;
+      br.nbits = 0;
+      if (br.pos + 4 > br.n) return false;
+      const unsigned len = br.p[br.pos] | (br.p[br.pos + 1] << 8), nlen = br.p[br.pos + 2] | (br.p[br.pos + 3] << 8);
+      br.pos += 4;
+      if ((len ^ 0xFFFFu) != nlen || br.pos + len > br.n) return false;
+      out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
+      br.pos += len;
+      continue;
+    }
+    if (type == 3) return false;
+    Huffman hl, hd;
+    uint8_t lens[320];
+    if (type == 1) {
+      int i = 0;
+      for (; i < 144; ++i) lens[i] = 8;
+      for (; i < 256; ++i) lens[i] = 9;
+      for (; i < 280; ++i) lens[i] = 7;
+      for (; i < 288; ++i) lens[i] = 8;
+      hl.build(lens, 288);
+      for (i = 0; i < 30; ++i) lens[i] = 5;
+      hd.build(lens, 30);
+    } else {
+      const int nlen = (int)br.get(5) + 257, ndist = (int)br.get(5) + 1, ncode = (int)br.get(4) + 4;
+      static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+      uint8_t cl[19] = {0};
+      for (int i = 0; i < ncode; ++i) cl[order[i]] = (uint8_t)br.get(3);
+      if (!br.ok || nlen > 286 || ndist > 30) return false;
+      Huffman hc;
+      hc.build(cl, 19);
+      int idx = 0;
+      while (idx < nlen + ndist) {
+        const int sym = hc.decode(br);
+        if (sym < 0) return false;
+        if (sym < 16) lens[idx++] = (uint8_t)sym;
+        else {
+          int rep = 0, val = 0;
+          if (sym == 16) {
+            if (idx == 0) return false;
+            val = lens[idx - 1];
+            rep = 3 + (int)br.get(2);
+          } else if (sym == 17) rep = 3 + (int)br.get(3);
+          else rep = 11 + (int)br.get(7);
+          if (idx + rep > nlen + ndist) return false;
+          while (rep--) lens[idx++] = (uint8_t)val;
+        }
+      }
+      hl.build(lens, nlen);
+      hd.build(lens + nlen, ndist);
+    }
+    for (;;) {
+      const int sym = hl.decode(br);
+      if (sym < 0 || !br.ok) return false;
+      if (sym < 256) out.push_back((uint8_t)sym);
+      else if (sym == 256) break;
+      else {
+        const int s = sym - 257;
+        if (s >= 29) return false;
+        const int len = lbase[s] + (int)br.get(lext[s]);
+        const int ds = hd.decode(br);
+        if (ds < 0 || ds >= 30) return false;
+        const size_t dist = dbase[ds] + br.get(dext[ds]);
+        if (!br.ok || dist > out.size()) return false;
+        const size_t from = out.size() - dist;
+        for (int i = 0; i < len; ++i) out.push_back(out[from + i]);
+      }
+    }
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------- PNG -> BGR (what cv::imread(path) returns)
+uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; }
+int paeth(int a, int b, int c) {
+  const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+  return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+bool decode_png(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) {
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  if (f.size() < 8 || memcmp(f.data(), sig, 8) != 0) {
+    why = "not a PNG file";
+    return false;
+  }
+  uint32_t w = 0, h = 0;
+  int depth = 0, ctype = 0, interlace = 0;
+  std::vector<uint8_t> idat, plte;
+  size_t pos = 8;
+  while (pos + 12 <= f.size()) {
+    const uint32_t len = be32(&f[pos]);
+    const char* tag = (const char*)&f[pos + 4];
+    if (pos + 12 + len > f.size()) break;
+    const uint8_t* d = &f[pos + 8];
+    if (!memcmp(tag, "IHDR", 4) && len >= 13) {
+      w = be32(d);
+      h = be32(d + 4);
+      depth = d[8];
+      ctype = d[9];
+      interlace = d[12];
+    } else if (!memcmp(tag, "PLTE", 4)) plte.assign(d, d + len);
+    else if (!memcmp(tag, "IDAT", 4)) idat.insert(idat.end(), d, d + len);
+    else if (!memcmp(tag, "IEND", 4)) break;
+    pos += 12 + len;
+  }
+  if (!w || !h || interlace) {
+    why = interlace ? "interlaced PNG (not supported)" : "no IHDR";
+    return false;
+  }
+  const int nch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+  if (!nch || (depth != 8 && depth != 16 && !((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) {
+    why = "unsupported colour type / bit depth";
+    return false;
+  }
+  std::vector<uint8_t> raw;
+  if (!inflate_zlib(idat, raw)) {
+    why = "corrupt zlib stream";
+    return false;
+  }
+  const size_t bpp_bits = (size_t)nch * depth, stride = (w * bpp_bits + 7) / 8, bpp = std::max<size_t>(1, bpp_bits / 8);
+  if (raw.size() < (stride + 1) * h) {
+    why = "truncated image data";
+    return false;
+  }
+  std::vector<uint8_t> img(stride * h), zero(stride, 0);
+  for (uint32_t y = 0; y < h; ++y) {
+    const uint8_t* in = &raw[(stride + 1) * y];
+    uint8_t* cur = &img[stride * y];
+    const uint8_t* up = y ? &img[stride * (y - 1)] : zero.data();
+    const int ft = in[0];
+    for (size_t x = 0; x < stride; ++x) {
+      const int a = x >= bpp ? cur[x - bpp] : 0, b = up[x], c = x >= bpp ? up[x - bpp] : 0;
+      int v = in[1 + x];
+      if (ft == 1) v += a;
+      else if (ft == 2) v += b;
+      else if (ft == 3) v += (a + b) >> 1;
+      else if (ft == 4) v += paeth(a, b, c);
+      else if (ft != 0) {
+        why = "bad filter type";
+        return false;
+      }
+      cur[x] = (uint8_t)v;
+    }
+  }
+  bgr = cv::Mat((int)h, (int)w, CV_8UC3);
+  for (uint32_t y = 0; y < h; ++y) {
+    const uint8_t* r = &img[stride * y];
+    uint8_t* o = bgr.ptr() + (size_t)y * w * 3;
+    for (uint32_t x = 0; x < w; ++x) {
+      uint8_t R, G, B;
+      auto sample = [&](size_t idx) -> int {  // idx-th sample of the row, scaled to 8 bit as libpng's strip/expand does
+        if (depth == 8) return r[idx];
+        if (depth == 16) return r[2 * idx];   // png_set_strip_16: the high byte
+        const int per = 8 / depth, sh = (per - 1 - (int)(idx % per)) * depth;
+        const int v = (r[idx / per] >> sh) & ((1 << depth) - 1);
+        return ctype == 3 ? v : v * 255 / ((1 << depth) - 1);  // gray: expand to 8 bit
+      };
+      if (ctype == 3) {
+        const size_t pi = (size_t)sample(x);
+        if (3 * pi + 2 >= plte.size()) {
+          why = "palette index out of range";
+          return false;
+        }
+        R = plte[3 * pi], G = plte[3 * pi + 1], B = plte[3 * pi + 2];
+      } else if (nch <= 2) {
+        R = G = B = (uint8_t)sample((size_t)x * nch);
+      } else {
+        R = (uint8_t)sample((size_t)x * nch), G = (uint8_t)sample((size_t)x * nch + 1), B = (uint8_t)sample((size_t)x * nch + 2);
+      }
+      o[3 * x] = B, o[3 * x + 1] = G, o[3 * x + 2] = R;  // alpha is dropped (IMREAD_COLOR)
+    }
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------- cv::resize(src, dst, Size(), fx, fy, INTER_LINEAR), 8-bit
+// OpenCV 3.4.1 imgproc/resize.cpp: dsize = (cvRound(cols*fx), cvRound(rows*fy)); source coordinate of dst x:
+// (x + 0.5)/fx - 0.5; 11-bit fixed-point weights (INTER_RESIZE_COEF_SCALE = 2048); horizontal pass in int, vertical
+// pass ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2) >> 2.
+int cv_round(double v) { return (int)std::lrint(v); }
+cv::Mat resize_linear_8u(const cv::Mat& src, double fx, double fy) {
+  const int cn = src.channels(), sw = src.cols, sh = src.rows;
+  const int dw = cv_round(sw * fx), dh = cv_round(sh * fy);
+  cv::Mat dst(dh, dw, src.type());
+  const double scale_x = 1.0 / fx, scale_y = 1.0 / fy;
+  std::vector<int> xofs(dw), yofs(dh);
+  std::vector<short> alpha(2 * (size_t)dw), beta(2 * (size_t)dh);
+  for (int dx = 0; dx < dw; ++dx) {
+    float f = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = (int)std::floor(f);
+    f -= sx;
+    if (sx < 0) f = 0, sx = 0;
+    if (sx >= sw - 1) f = 0, sx = sw - 1;
+    xofs[dx] = sx;
+    const float c0 = 1.f - f, c1 = f;
+    alpha[2 * dx] = (short)cv_round(c0 * 2048.f);
+    alpha[2 * dx + 1] = (short)cv_round(c1 * 2048.f);
+  }
+  for (int dy = 0; dy < dh; ++dy) {
+    float f = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = (int)std::floor(f);
+    f -= sy;
+    yofs[dy] = sy;
+    beta[2 * dy] = (short)cv_round((1.f - f) * 2048.f);
+    beta[2 * dy + 1] = (short)cv_round(f * 2048.f);
+  }
+  std::vector<int> row0((size_t)dw * cn), row1((size_t)dw * cn);
+  auto hrow = [&](int sy, std::vector<int>& out) {
+    sy = std::min(std::max(sy, 0), sh - 1);  // rows beyond the image: border replicate
+    const unsigned char* s = src.ptr() + (size_t)sy * sw * cn;
+    for (int dx = 0; dx < dw; ++dx) {
+      const int sx = xofs[dx], sx1 = std::min(sx + 1, sw - 1);
+      for (int c = 0; c < cn; ++c) out[(size_t)dx * cn + c] = s[sx * cn + c] * alpha[2 * dx] + s[sx1 * cn + c] * alpha[2 * dx + 1];
+    }
+  };
+  for (int dy = 0; dy < dh; ++dy) {
+    hrow(yofs[dy], row0);
+    hrow(yofs[dy] + 1, row1);
+    const int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+    unsigned char* d = dst.ptr() + (size_t)dy * dw * cn;
+    for (size_t i = 0; i < (size_t)dw * cn; ++i)
+      d[i] = (unsigned char)((((b0 * (row0[i] >> 4)) >> 16) + ((b1 * (row1[i] >> 4)) >> 16) + 2) >> 2);
+  }
+  return dst;
+}
+// cv::cvtColor(BGR2GRAY), 8-bit: (B*1868 + G*9617 + R*4899 + (1 << 13)) >> 14  (color.cpp: yuv_shift = 14)
+cv::Mat bgr_to_gray(const cv::Mat& bgr) {
+  cv::Mat g(bgr.rows, bgr.cols, CV_8UC1);
+  const unsigned char* s = bgr.ptr();
+  unsigned char* d = g.ptr();
+  for (size_t i = 0, n = (size_t)bgr.rows * bgr.cols; i < n; ++i)
+    d[i] = (unsigned char)((s[3 * i] * 1868 + s[3 * i + 1] * 9617 + s[3 * i + 2] * 4899 + (1 << 13)) >> 14);
+  return g;
+}
+
+bool read_file(const std::string& path, std::vector<uint8_t>& out) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  const long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out.resize(n > 0 ? (size_t)n : 0);
+  const bool ok = n >= 0 && fread(out.data(), 1, out.size(), f) == out.size();
+  fclose(f);
+  return ok;
+}
+std::string lower_ext(const std::string& p) {
+  const size_t dot = p.find_last_of('.'), slash = p.find_last_of('/');
+  if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) return "";
+  std::string e = p.substr(dot);
+  for (char& c : e) c = (char)std::tolower((unsigned char)c);
+  return e;
+}
+
+// one <Name type_id="opencv-matrix"> node: rows, cols, data (numbers as text)
+bool xml_matrix(const std::string& xml, const std::string& name, cv::Mat_<double>& out) {
+  const size_t a = xml.find("<" + name);
+  if (a == std::string::npos) return false;
+  const size_t b = xml.find("</" + name + ">", a);
+  if (b == std::string::npos) return false;
+  const std::string node = xml.substr(a, b - a);
+  auto field = [&](const char* tag, std::string& v) {
+    const std::string open = std::string("<") + tag + ">", close = std::string("</") + tag + ">";
+    const size_t i = node.find(open), j = node.find(close);
+    if (i == std::string::npos || j == std::string::npos || j < i) return false;
+    v = node.substr(i + open.size(), j - i - open.size());
+    return true;
+  };
+  std::string r, c, d;
+  if (!field("rows", r) || !field("cols", c) || !field("data", d)) return false;
+  const int rows = atoi(r.c_str()), cols = atoi(c.c_str());
+  if (rows <= 0 || cols <= 0) return false;
+  out = cv::Mat_<double>(rows, cols);
+  std::istringstream is(d);
+  for (int i = 0; i < rows * cols; ++i)
+    if (!(is >> out.data[i])) return false;
+  return true;
+}
+void mkdirs(const std::string& p) {
+  for (size_t i = 1; i <= p.size(); ++i)
+    if (i == p.size() || p[i] == '/') mkdir(p.substr(0, i).c_str(), 0777);
+}
+
+}  // namespace
+
+// reference src/Sfm.cpp:118-198
+bool StructFromMotion::imagesLOAD(const std::string& directoryPath) {
+  std::cout << "Getting images..." << std::flush;
+  pathImages = directoryPath;
+  nImagesPath.clear();
+  nImages.clear();
+  mColorImages.clear();
+  mGrayImages.clear();
+  DIR* dir = opendir(directoryPath.c_str());
+  if (!dir) {
+    std::cerr << "Cannot open directory: " << directoryPath << std::endl;
+    return false;
+  }
+  const std::string base = directoryPath + (directoryPath.empty() || directoryPath.back() == '/' ? "" : "/");
+  while (dirent* e = readdir(dir)) {
+    const std::string ext = lower_ext(e->d_name);
+    if (ext == ".jpg" || ext == ".png") nImagesPath.push_back(base + e->d_name);  // :129-135
+  }
+  closedir(dir);
+  std::sort(nImagesPath.begin(), nImagesPath.end());  // :138
+  if (nImagesPath.empty()) {
+    std::cerr << "Unable to find valid files in images directory (\"" << directoryPath << "\")." << std::endl;
+    return false;
+  }
+  std::cout << "Found " << nImagesPath.size() << " image files in directory." << std::endl;
+  for (const std::string& imageFilename : nImagesPath) {
+    std::vector<uint8_t> bytes;
+    cv::Mat image;
+    std::string why = "cannot read the file";
+    bool ok = read_file(imageFilename, bytes);
+    if (ok && lower_ext(imageFilename) == ".jpg") {
+      ok = false;
+      why = "JPEG decoding is not part of this build";
+    } else if (ok) {
+      ok = decode_png(bytes, image, why);
+    }
+    if (!ok) {  // cv::imread returns an empty Mat; the reference then reports and fails (:158-161)
+      std::cerr << "[x]" << "\n" << "Unable to read image from file: " << imageFilename << " (" << why << ")" << std::endl;
+      return false;
+    }
+    if (image.rows > 480 && image.cols > 640) nImages.push_back(resize_linear_8u(image, 0.60, 0.60));  // :153-155
+    else nImages.push_back(image);
+  }
+  if (nImages.size() < 2) {
+    std::cerr << "Sorry. is not enough images, 6 minimum" << std::endl;  // :172-175
+    return false;
+  }
+  for (size_t i = 0; i < nImages.size(); ++i) {  // :177-195: decoded images are CV_8UC3 here, so the copy branch
+    mColorImages.push_back(nImages[i]);
+    mGrayImages.push_back(bgr_to_gray(mColorImages[i]));
+  }
+  return true;
+}
+
+// reference src/Sfm.cpp:203-252
+bool StructFromMotion::getCameraMatrix(const std::string str) {
+  std::cout << "Getting camera matrix..." << std::endl;
+  std::vector<uint8_t> bytes;
+  cv::Mat_<double> intrinsics, cameraDistCoeffs;
+  if (read_file(str, bytes)) {
+    const std::string xml(bytes.begin(), bytes.end());
+    xml_matrix(xml, "Camera_Matrix", intrinsics);
+    xml_matrix(xml, "Distortion_Coefficients", cameraDistCoeffs);
+  }
+  if (intrinsics.rows != 3 || intrinsics.cols != 3 || intrinsics(2, 0) != 0) {  // :216
+    std::cerr << "Error: no found or invalid camera calibration file.xml" << std::endl;
+    return false;
+  }
+  cv::Mat_<double> cam_matrix(3, 3);
+  cam_matrix(0, 0) = intrinsics(0, 0);
+  cam_matrix(1, 1) = intrinsics(1, 1);
+  cam_matrix(0, 2) = intrinsics(0, 2);
+  cam_matrix(1, 2) = intrinsics(1, 2);
+  cam_matrix(2, 2) = 1;
+  cv::Mat_<double> distortionC(1, 5);
+  for (int i = 0; i < 5; ++i)  // slots in file order (the reference labels them k1,k2,k3,p1,p2: :230-236)
+    distortionC(0, i) = (cameraDistCoeffs.rows * cameraDistCoeffs.cols > i) ? cameraDistCoeffs.data[i] : 0.0;
+  cameraMatrix.K = cam_matrix;
+  cameraMatrix.distCoef = distortionC;
+  std::cout << "Camera matrix:" << "\n";
+  for (int r = 0; r < 3; ++r) std::cout << cam_matrix(r, 0) << " " << cam_matrix(r, 1) << " " << cam_matrix(r, 2) << "\n";
+  return true;
+}
+
+// reference src/Sfm.cpp:1246-1303
+void StructFromMotion::PMVS2() {
+  std::cout << "Creating folders for PMVS2..." << std::endl;
+  mkdirs("denseCloud/visualize");
+  mkdirs("denseCloud/txt");
+  mkdirs("denseCloud/models");
+  {
+    std::ofstream option("denseCloud/options.txt");
+    option << "minImageNum 5" << std::endl;
+    option << "CPU 4" << std::endl;
+    option << "timages  -1 " << 0 << " " << (nImages.size() - 1) << std::endl;
+    option << "oimages 0" << std::endl;
+    option << "level 1" << std::endl;
+  }
+  for (size_t i = 0; i < nCameraPoses.size(); ++i) {
+    char str[256];
+    if (i < nImagesPath.size()) {  // `cp -f <input> denseCloud/visualize/%04d.jpg`: a byte copy whatever the format
+      std::vector<uint8_t> bytes;
+      std::snprintf(str, sizeof str, "denseCloud/visualize/%04d.jpg", (int)i);
+      if (read_file(nImagesPath[i], bytes)) {
+        FILE* o = fopen(str, "wb");
+        if (o) {
+          fwrite(bytes.data(), 1, bytes.size(), o);
+          fclose(o);
+        }
+      }
+    }
+    std::snprintf(str, sizeof str, "denseCloud/txt/%04d.txt", (int)i);
+    std::ofstream ofs(str);
+    const cv::Matx34d& P = nCameraPoses[i];
+    cv::Matx34d pose;  // K*P
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c) {
+        double v = 0;
+        for (int k = 0; k < 3; ++k) v += cameraMatrix.K(r, k) * P(k, c);
+        pose(r, c) = v;
+      }
+    ofs << "CONTOUR" << std::endl;
+    ofs << pose(0, 0) << " " << pose(0, 1) << " " << pose(0, 2) << " " << pose(0, 3) << "\n"
+        << pose(1, 0) << " " << pose(1, 1) << " " << pose(1, 2) << " " << pose(1, 3) << "\n"
+        << pose(2, 0) << " " << pose(2, 1) << " " << pose(2, 2) << " " << pose(2, 3) << std::endl;
+    ofs << std::endl;
+  }
+  std::cout << "Camera poses saved." << "\n" << "Camera images saved." << std::endl;
+}
+
+// reference src/Sfm.cpp:69-81
+size_t StructFromMotion::convertPLYtoPCD(const std::string& plyPath, const std::string& pcdPath) {
+  std::vector<uint8_t> f;
+  if (!read_file(plyPath, f)) return 0;
+  // header: lines up to "end_header"
+  size_t pos = 0;
+  auto line = [&](std::string& out) {
+    if (pos >= f.size()) return false;
+    size_t e = pos;
+    while (e < f.size() && f[e] != '\n') ++e;
+    out.assign((const char*)&f[pos], e - pos);
+    if (!out.empty() && out.back() == '\r') out.pop_back();
+    pos = e + 1;
+    return true;
+  };
+  std::string l;
+  if (!line(l) || l != "ply") return 0;
+  struct Prop {
+    std::string type, name;
+  };
+  std::vector<Prop> props;
+  size_t nvert = 0;
+  bool binary = false, in_vertex = false, done = false;
+  while (line(l)) {
+    std::istringstream is(l);
+    std::string w;
+    is >> w;
+    if (w == "format") {
+      is >> w;
+      if (w == "binary_little_endian") binary = true;
+      else if (w != "ascii") return 0;
+    } else if (w == "element") {
+      std::string nm;
+      size_t cnt = 0;
+      is >> nm >> cnt;
+      in_vertex = nm == "vertex";
+      if (in_vertex) nvert = cnt;
+    } else if (w == "property" && in_vertex) {
+      Prop p;
+      is >> p.type >> p.name;
+      if (p.type == "list") return 0;
+      props.push_back(p);
+    } else if (w == "end_header") {
+      done = true;
+      break;
+    }
+  }
+  if (!done || !nvert || props.empty()) return 0;
+  auto size_of = [](const std::string& t) {
+    if (t == "char" || t == "uchar" || t == "int8" || t == "uint8") return 1;
+    if (t == "short" || t == "ushort" || t == "int16" || t == "uint16") return 2;
+    if (t == "double" || t == "float64") return 8;
+    return 4;
+  };
+  int ix = -1, iy = -1, iz = -1, ir = -1, ig = -1, ib = -1;
+  for (size_t i = 0; i < props.size(); ++i) {
+    const std::string& n = props[i].name;
+    if (n == "x") ix = (int)i;
+    else if (n == "y") iy = (int)i;
+    else if (n == "z") iz = (int)i;
+    else if (n == "red" || n == "diffuse_red") ir = (int)i;
+    else if (n == "green" || n == "diffuse_green") ig = (int)i;
+    else if (n == "blue" || n == "diffuse_blue") ib = (int)i;
+  }
+  if (ix < 0 || iy < 0 || iz < 0) return 0;
+  std::vector<float> xyz;
+  std::vector<uint32_t> rgb;
+  xyz.reserve(3 * nvert);
+  rgb.reserve(nvert);
+  std::vector<double> v(props.size());
+  std::istringstream body;
+  if (!binary) body.str(std::string((const char*)f.data() + std::min(pos, f.size()), f.size() - std::min(pos, f.size())));
+  for (size_t k = 0; k < nvert; ++k) {
+    for (size_t i = 0; i < props.size(); ++i) {
+      if (!binary) {
+        if (!(body >> v[i])) return 0;
+        continue;
+      }
+      const int sz = size_of(props[i].type);
+      if (pos + sz > f.size()) return 0;
+      const uint8_t* p = &f[pos];
+      const std::string& t = props[i].type;
+      if (t == "float" || t == "float32") {
+        float x;
+        memcpy(&x, p, 4);
+        v[i] = x;
+      } else if (sz == 8) memcpy(&v[i], p, 8);
+      else if (sz == 1) v[i] = (t == "char" || t == "int8") ? (double)(int8_t)p[0] : (double)p[0];
+      else if (sz == 2) {
+        uint16_t x;
+        memcpy(&x, p, 2);
+        v[i] = (t == "short" || t == "int16") ? (double)(int16_t)x : (double)x;
+      } else {
+        uint32_t x;
+        memcpy(&x, p, 4);
+        v[i] = (t == "int" || t == "int32") ? (double)(int32_t)x : (double)x;
+      }
+      pos += sz;
+    }
+    xyz.push_back((float)v[ix]);
+    xyz.push_back((float)v[iy]);
+    xyz.push_back((float)v[iz]);
+    const uint32_t r = ir >= 0 ? (uint32_t)v[ir] & 255u : 0, g = ig >= 0 ? (uint32_t)v[ig] & 255u : 0, b = ib >= 0 ? (uint32_t)v[ib] & 255u : 0;
+    rgb.push_back((r << 16) | (g << 8) | b);
+  }
+  std::ofstream o(pcdPath);
+  if (!o) return 0;
+  o << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgb\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n"
+    << "WIDTH " << nvert << "\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << nvert << "\nDATA ascii\n";
+  o.precision(8);
+  auto put = [&](float x) {
+    if (std::isfinite(x)) o << x;
+    else o << "nan";
+  };
+  for (size_t k = 0; k < nvert; ++k) {
+    float packed;
+    memcpy(&packed, &rgb[k], 4);
+    put(xyz[3 * k]);
+    o << " ";
+    put(xyz[3 * k + 1]);
+    o << " ";
+    put(xyz[3 * k + 2]);
+    o << " ";
+    put(packed);
+    o << "\n";
+  }
+  return nvert;
+}

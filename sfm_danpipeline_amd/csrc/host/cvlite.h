@@ -10,6 +10,8 @@
 
 #define CV_8U 0
 #define CV_32F 5
+#define CV_8UC1 0
+#define CV_8UC3 16  /* CV_MAKETYPE(CV_8U, 3) */
 
 namespace cv {
 
@@ -61,18 +63,22 @@ struct Mat_ {
   const T& operator()(int r, int c) const { return data[(size_t)r * cols + c]; }
 };
 
-// descriptor matrix: rows = features, row-major contiguous, CV_32F (SIFT) or CV_8U (ORB/AKAZE)
+// descriptor matrix: rows = features, row-major contiguous, CV_32F (SIFT) or CV_8U (ORB/AKAZE);
+// also the 8-bit images of the loader (CV_8UC1 gray, CV_8UC3 BGR: interleaved channels)
 struct Mat {
-  int rows, cols, depth;
+  int rows, cols, depth, ch;
   std::vector<unsigned char> bytes;
-  Mat() : rows(0), cols(0), depth(CV_32F) {}
-  Mat(int r, int c, int type, const void* src = nullptr) : rows(r), cols(c), depth(type) {
+  Mat() : rows(0), cols(0), depth(CV_32F), ch(1) {}
+  Mat(int r, int c, int type, const void* src = nullptr) : rows(r), cols(c), depth(type & 7), ch((type >> 3) + 1) {
     bytes.resize((size_t)r * c * elemSize());
     if (src && !bytes.empty()) std::memcpy(bytes.data(), src, bytes.size());
   }
-  size_t elemSize() const { return depth == CV_32F ? 4 : 1; }
-  int type() const { return depth; }
+  size_t elemSize() const { return (depth == CV_32F ? 4 : 1) * (size_t)ch; }
+  int type() const { return depth | ((ch - 1) << 3); }
+  int channels() const { return ch; }
+  bool empty() const { return bytes.empty(); }
   const unsigned char* ptr() const { return bytes.data(); }
+  unsigned char* ptr() { return bytes.data(); }
 };
 
 }  // namespace cv

@@ -1,0 +1,330 @@
+"""CPU: I/O and interchange formats of the C++ host mirror -- imagesLOAD
+(reference src/Sfm.cpp:118-198), getCameraMatrix (:203-252), PMVS2 export (:1246-1303) -- through the
+`sfm_io_selftest` executable.  Decoded pixels are compared with PIL's decoder; resize / gray with the
+fixed-point arithmetic of OpenCV 3.4.1 restated in numpy here (no cv2 in the image) and with a float
+bilinear / float luma as a tolerance cross-check; the PMVS files with text built from the reference's
+own format statements."""
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from sfm_danpipeline_amd import build
+
+PIL = pytest.importorskip("PIL.Image")
+REF_DATA = "/root/reference/data"
+
+
+# ---------------------------------------------------------------- helpers
+def _png_bytes(arr, ctype, depth=8, palette=None, filters=(0, 1, 2, 3, 4), level=6, stored=False):
+    """A PNG writer that exercises every row filter (PIL's writer picks few)."""
+    h, w = arr.shape[:2]
+    rows = arr.reshape(h, -1).astype(np.uint8)
+    bpp = max(1, rows.shape[1] // w) if depth >= 8 else 1
+    out = bytearray()
+    prev = np.zeros(rows.shape[1], np.int32)
+    for y in range(h):
+        cur = rows[y].astype(np.int32)
+        left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+        ul = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+        ft = filters[y % len(filters)]
+        if ft == 0:
+            enc = cur
+        elif ft == 1:
+            enc = cur - left
+        elif ft == 2:
+            enc = cur - prev
+        elif ft == 3:
+            enc = cur - ((left + prev) >> 1)
+        else:
+            p = left + prev - ul
+            pa, pb, pc = abs(p - left), abs(p - prev), abs(p - ul)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+            enc = cur - pred
+        out.append(ft)
+        out += (enc & 255).astype(np.uint8).tobytes()
+        prev = cur
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data))
+    comp = zlib.compress(bytes(out), 0 if stored else level)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+    if palette is not None:
+        png += chunk(b"PLTE", palette.astype(np.uint8).tobytes())
+    half = len(comp) // 2      # two IDAT chunks: the stream continues across chunk boundaries
+    return png + chunk(b"IDAT", comp[:half]) + chunk(b"IDAT", comp[half:]) + chunk(b"IEND", b"")
+
+
+def _pil_bgr(path):
+    return np.asarray(PIL.open(path).convert("RGB"))[:, :, ::-1].copy()
+
+
+def _cv_round(x):
+    return np.rint(x).astype(np.int64)      # lrint: round half to even
+
+
+def _cv_resize_linear_u8(src, fx, fy):
+    """cv::resize(INTER_LINEAR) for CV_8U as OpenCV 3.4.1 computes it (11-bit coefficients, two passes)."""
+    sh, sw, cn = src.shape
+    dw, dh = int(_cv_round(sw * fx)), int(_cv_round(sh * fy))
+
+    def taps(d, s, f_scale):
+        x = ((np.arange(d) + 0.5) * (1.0 / f_scale) - 0.5).astype(np.float32)
+        i = np.floor(x).astype(np.int64)
+        f = (x - i.astype(np.float32)).astype(np.float32)
+        return i, f
+    ix, fx_ = taps(dw, sw, fx)
+    lo = ix < 0
+    fx_[lo], ix[lo] = 0, 0
+    hi = ix >= sw - 1
+    fx_[hi], ix[hi] = 0, sw - 1
+    a0 = _cv_round((np.float32(1) - fx_) * np.float32(2048)).astype(np.int64)
+    a1 = _cv_round(fx_ * np.float32(2048)).astype(np.int64)
+    iy, fy_ = taps(dh, sh, fy)
+    b0 = _cv_round((np.float32(1) - fy_) * np.float32(2048)).astype(np.int64)
+    b1 = _cv_round(fy_ * np.float32(2048)).astype(np.int64)
+    s = src.astype(np.int64)
+    ix1 = np.minimum(ix + 1, sw - 1)
+    hz = s[:, ix, :] * a0[None, :, None] + s[:, ix1, :] * a1[None, :, None]
+    r0 = hz[np.clip(iy, 0, sh - 1)]
+    r1 = hz[np.clip(iy + 1, 0, sh - 1)]
+    out = (((b0[:, None, None] * (r0 >> 4)) >> 16) + ((b1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8)
+
+
+def _float_bilinear(src, fx, fy):
+    sh, sw, _ = src.shape
+    dw, dh = int(_cv_round(sw * fx)), int(_cv_round(sh * fy))
+    x = np.clip((np.arange(dw) + 0.5) / fx - 0.5, 0, sw - 1)
+    y = np.clip((np.arange(dh) + 0.5) / fy - 0.5, 0, sh - 1)
+    x0, y0 = np.floor(x).astype(int), np.floor(y).astype(int)
+    x1, y1 = np.minimum(x0 + 1, sw - 1), np.minimum(y0 + 1, sh - 1)
+    wx, wy = (x - x0)[None, :, None], (y - y0)[:, None, None]
+    s = src.astype(np.float64)
+    top = s[y0][:, x0] * (1 - wx) + s[y0][:, x1] * wx
+    bot = s[y1][:, x0] * (1 - wx) + s[y1][:, x1] * wx
+    return top * (1 - wy) + bot * wy
+
+
+def _cv_gray(bgr):
+    b, g, r = (bgr[..., i].astype(np.int64) for i in range(3))
+    return ((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+
+
+def _run(tmp_path, img_dir, xml):
+    exe = build.build_io_demo()
+    out = tmp_path / "io_out.bin"
+    r = subprocess.run([exe, str(img_dir), str(xml), str(out)], capture_output=True, text=True, timeout=300, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    raw = open(out, "rb").read()
+    ok_img, ok_cal, n = struct.unpack("<iii", raw[:12])
+    off, imgs = 12, []
+    for _ in range(n):
+        rows, cols = struct.unpack("<ii", raw[off:off + 8])
+        off += 8
+        bgr = np.frombuffer(raw[off:off + rows * cols * 3], np.uint8).reshape(rows, cols, 3)
+        off += rows * cols * 3
+        gray = np.frombuffer(raw[off:off + rows * cols], np.uint8).reshape(rows, cols)
+        off += rows * cols
+        imgs.append((bgr, gray))
+    K = dist = None
+    if ok_cal:
+        K = np.frombuffer(raw[off:off + 72], "<f8").reshape(3, 3)
+        dist = np.frombuffer(raw[off + 72:off + 112], "<f8")
+    return ok_img, ok_cal, imgs, K, dist, r
+
+
+XML = """<?xml version="1.0"?>
+<opencv_storage>
+<Camera_Matrix type_id="opencv-matrix">
+  <rows>3</rows>
+  <cols>3</cols>
+  <dt>f</dt>
+  <data>
+    1520.40 0. 302.32 0. 1525.90
+    246.87 0. 0. 1.</data></Camera_Matrix>
+<Distortion_Coefficients type_id="opencv-matrix">
+  <rows>5</rows>
+  <cols>1</cols>
+  <dt>f</dt>
+  <data>
+    -0.125 0.25 1e-3 -2.5e-4 0.0625</data></Distortion_Coefficients>
+</opencv_storage>
+"""
+
+
+def _make_dir(tmp_path, rng):
+    d = tmp_path / "imgs"
+    d.mkdir()
+    ramp = lambda h, w, c: ((np.add.outer(np.arange(h) * 3, np.arange(w) * 5)[..., None] + np.arange(c) * 40
+                             + rng.integers(0, 30, (h, w, c))) % 256).astype(np.uint8)
+    rgb = ramp(53, 71, 3)
+    (d / "b_rgb.PNG").write_bytes(_png_bytes(rgb, 2))                       # upper-case extension (:132 lowercases)
+    gray = ramp(40, 33, 1)
+    (d / "a_gray.png").write_bytes(_png_bytes(gray, 0, filters=(4, 3)))
+    rgba = ramp(37, 41, 4)
+    (d / "c_rgba.png").write_bytes(_png_bytes(rgba, 6, filters=(1, 4, 2), level=9))
+    pal = rng.integers(0, 256, (17, 3)).astype(np.uint8)
+    idx = rng.integers(0, 17, (29, 31, 1)).astype(np.uint8)
+    (d / "d_pal.png").write_bytes(_png_bytes(idx, 3, palette=pal, stored=True))
+    big = ramp(485, 700, 3)                                                 # rows > 480 and cols > 640 -> x0.6
+    (d / "e_big.png").write_bytes(_png_bytes(big, 2, filters=(4,)))
+    edge = ramp(481, 640, 3)                                                # cols == 640: NOT resized (strict >)
+    PIL.fromarray(edge).save(d / "f_edge.png")                              # PIL's own writer
+    (d / "notes.txt").write_text("not an image")
+    ga = ramp(21, 19, 2)
+    (d / "g_ga.png").write_bytes(_png_bytes(ga, 4, filters=(3, 0)))
+    return d, dict(big=big, edge=edge)
+
+
+def test_images_load_matches_pil_and_the_opencv_arithmetic(tmp_path):
+    rng = np.random.default_rng(5)
+    d, src = _make_dir(tmp_path, rng)
+    (tmp_path / "cam.xml").write_text(XML)
+    ok_img, ok_cal, imgs, K, dist, _ = _run(tmp_path, d, tmp_path / "cam.xml")
+    assert ok_img == 1 and ok_cal == 1
+    names = sorted(f for f in os.listdir(d) if f.lower().endswith((".png", ".jpg")))   # :138 std::sort, byte order
+    assert names == ["a_gray.png", "b_rgb.PNG", "c_rgba.png", "d_pal.png", "e_big.png", "f_edge.png", "g_ga.png"]
+    assert len(imgs) == len(names)
+    for name, (bgr, gray) in zip(names, imgs):
+        want = _pil_bgr(d / name)
+        if name == "e_big.png":
+            assert bgr.shape == (291, 420, 3)
+            assert np.array_equal(bgr, _cv_resize_linear_u8(want, 0.6, 0.6))
+            assert np.abs(bgr.astype(np.float64) - _float_bilinear(want, 0.6, 0.6)).max() <= 1.0
+        else:
+            assert np.array_equal(bgr, want), name
+        assert np.array_equal(gray, _cv_gray(bgr)), name
+        luma = 0.114 * bgr[..., 0] + 0.587 * bgr[..., 1] + 0.299 * bgr[..., 2]
+        assert np.abs(gray - luma).max() <= 0.51
+    assert imgs[5][0].shape == (481, 640, 3)
+    # calibration: the numbers the file holds, zero skew / 1 at (2,2), coefficient slots in file order (:230-236)
+    assert np.array_equal(K, np.array([[1520.40, 0, 302.32], [0, 1525.90, 246.87], [0, 0, 1]]))
+    assert np.array_equal(dist, np.array([-0.125, 0.25, 1e-3, -2.5e-4, 0.0625]))
+
+
+def _fmt(v):
+    return "%g" % v          # operator<<(double) with default precision 6
+
+
+def test_pmvs2_export_files(tmp_path):
+    rng = np.random.default_rng(6)
+    d, _ = _make_dir(tmp_path, rng)
+    (tmp_path / "cam.xml").write_text(XML)
+    ok_img, ok_cal, imgs, K, _, _ = _run(tmp_path, d, tmp_path / "cam.xml")
+    assert ok_img and ok_cal
+    n = len(imgs)
+    dense = tmp_path / "denseCloud"
+    assert sorted(os.listdir(dense)) == ["models", "options.txt", "txt", "visualize"]
+    assert (dense / "options.txt").read_text() == "minImageNum 5\nCPU 4\ntimages  -1 0 %d\noimages 0\nlevel 1\n" % (n - 1)
+    names = sorted(f for f in os.listdir(d) if f.lower().endswith((".png", ".jpg")))
+    assert sorted(os.listdir(dense / "visualize")) == ["%04d.jpg" % i for i in range(n)]
+    assert sorted(os.listdir(dense / "txt")) == ["%04d.txt" % i for i in range(n)]
+    for i in range(n):
+        assert (dense / "visualize" / ("%04d.jpg" % i)).read_bytes() == (d / names[i]).read_bytes()   # `cp -f`
+        P = np.hstack([np.eye(3), np.array([[0.25 * i], [-0.5], [1.0 / 3.0 * i]])])    # io_selftest.cpp's poses
+        KP = K @ P
+        want = "CONTOUR\n" + "\n".join(" ".join(_fmt(v) for v in row) for row in KP) + "\n\n"
+        assert (dense / "txt" / ("%04d.txt" % i)).read_text() == want
+
+
+def test_load_failures_follow_the_reference(tmp_path):
+    (tmp_path / "cam.xml").write_text(XML)
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    ok_img, ok_cal, imgs, *_ = _run(tmp_path, empty, tmp_path / "cam.xml")      # :141-145 no valid files
+    assert ok_img == 0 and ok_cal == 1
+    one = tmp_path / "one"
+    one.mkdir()
+    PIL.fromarray(np.zeros((8, 8, 3), np.uint8)).save(one / "x.png")
+    assert _run(tmp_path, one, tmp_path / "cam.xml")[0] == 0                    # :172-175 fewer than two images
+    bad = tmp_path / "bad"
+    bad.mkdir()
+    PIL.fromarray(np.zeros((8, 8, 3), np.uint8)).save(bad / "x.png")
+    (bad / "y.png").write_bytes(b"\x89PNG\r\n\x1a\n" + b"garbage" * 10)
+    assert _run(tmp_path, bad, tmp_path / "cam.xml")[0] == 0                    # :158-161 unreadable image
+    trunc = tmp_path / "trunc"
+    trunc.mkdir()
+    good = _png_bytes(np.zeros((16, 16, 3), np.uint8) + 7, 2)
+    (trunc / "x.png").write_bytes(good)
+    (trunc / "y.png").write_bytes(good[:len(good) - 40])
+    assert _run(tmp_path, trunc, tmp_path / "cam.xml")[0] == 0
+    assert _run(tmp_path, tmp_path / "missing_dir", tmp_path / "cam.xml")[0] == 0
+    # calibration: missing file, missing node, non-zero K(2,0) (:216)
+    two = tmp_path / "two"
+    two.mkdir()
+    for nme in ("a.png", "b.png"):
+        PIL.fromarray(np.full((8, 8, 3), 9, np.uint8)).save(two / nme)
+    assert _run(tmp_path, two, tmp_path / "nope.xml")[:2] == (1, 0)
+    (tmp_path / "skew.xml").write_text(XML.replace("246.87 0. 0. 1.", "246.87 0.5 0. 1."))
+    assert _run(tmp_path, two, tmp_path / "skew.xml")[1] == 0
+    (tmp_path / "nok.xml").write_text(XML.replace("Camera_Matrix", "Kamera"))
+    assert _run(tmp_path, two, tmp_path / "nok.xml")[1] == 0
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF_DATA, "temple")), reason="the reference's dataset is not on this machine")
+def test_the_references_own_dataset_and_calibration_file(tmp_path):
+    """data/temple (640x480 PNGs: no resize) and its camera_calibration_template.xml, read in place."""
+    ok_img, ok_cal, imgs, K, dist, _ = _run(tmp_path, os.path.join(REF_DATA, "temple"),
+                                           os.path.join(REF_DATA, "temple", "camera_calibration_template.xml"))
+    assert ok_img == 1 and ok_cal == 1
+    names = sorted(f for f in os.listdir(os.path.join(REF_DATA, "temple")) if f.lower().endswith((".png", ".jpg")))
+    assert len(imgs) == len(names) >= 2
+    for name, (bgr, gray) in zip(names, imgs):
+        assert np.array_equal(bgr, _pil_bgr(os.path.join(REF_DATA, "temple", name))), name
+        assert np.array_equal(gray, _cv_gray(bgr))
+    assert np.array_equal(K, np.array([[1520.0, 0, 302.2], [0, 1520.0, 246.87], [0, 0, 1.0]]))
+    assert np.array_equal(dist, np.zeros(5))
+
+
+def _ply_text(xyz, nrm, rgb):
+    """The vertex layout PMVS2 writes to models/options.txt.ply."""
+    head = ("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+            "property float nx\nproperty float ny\nproperty float nz\nproperty uchar diffuse_red\n"
+            "property uchar diffuse_green\nproperty uchar diffuse_blue\nend_header\n" % len(xyz))
+    return head + "".join("%g %g %g %g %g %g %d %d %d\n" % (*p, *n, *c) for p, n, c in zip(xyz, nrm, rgb))
+
+
+def _read_pcd(path):
+    lines = open(path).read().split("\n")
+    k = lines.index("DATA ascii")
+    vals = np.array([[np.float32(t) for t in l.split()] for l in lines[k + 1:] if l], np.float32)
+    return lines[:k + 1], vals
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_ply_to_pcd_conversion(tmp_path, binary):
+    """map3D step 8 (src/Sfm.cpp:69-81): the dense cloud PMVS2 leaves as PLY, saved as MAP3D.pcd (PCL ASCII)."""
+    rng = np.random.default_rng(12)
+    n = 257
+    xyz = rng.normal(size=(n, 3)).astype(np.float32)
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    rgb = rng.integers(0, 256, (n, 3)).astype(np.uint8)
+    if binary:
+        head = _ply_text([], [], []).replace("format ascii 1.0", "format binary_little_endian 1.0").replace("vertex 0", "vertex %d" % n)
+        rec = np.zeros(n, np.dtype([("p", "<f4", 3), ("n", "<f4", 3), ("c", "u1", 3)]))
+        rec["p"], rec["n"], rec["c"] = xyz, nrm, rgb
+        (tmp_path / "m.ply").write_bytes(head.encode() + rec.tobytes())
+    else:
+        (tmp_path / "m.ply").write_text(_ply_text(xyz.astype(np.float64), nrm.astype(np.float64), rgb))
+        xyz = np.array([[np.float32("%g" % v) for v in p] for p in xyz], np.float32)    # what the text holds
+    exe = build.build_io_demo()
+    r = subprocess.run([exe, "--ply2pcd", str(tmp_path / "m.ply"), str(tmp_path / "MAP3D.pcd")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and int(r.stdout) == n
+    head, vals = _read_pcd(tmp_path / "MAP3D.pcd")
+    assert head == ["# .PCD v0.7 - Point Cloud Data file format", "VERSION 0.7", "FIELDS x y z rgb", "SIZE 4 4 4 4", "TYPE F F F F",
+                    "COUNT 1 1 1 1", "WIDTH %d" % n, "HEIGHT 1", "VIEWPOINT 0 0 0 1 0 0 0", "POINTS %d" % n, "DATA ascii"]
+    p8 = lambda a: np.array([np.float32("%.8g" % v) for v in a.ravel()], np.float32).reshape(a.shape)   # precision(8)
+    assert np.array_equal(vals[:, :3], p8(xyz))
+    packed = (rgb[:, 0].astype(np.uint32) << 16) | (rgb[:, 1].astype(np.uint32) << 8) | rgb[:, 2]
+    want = packed.view(np.float32)
+    assert np.array_equal(vals[:, 3], p8(want))              # the rgb word goes through the same 8 digits, as in PCL's files
+    # empty / missing input: 0 points, the reference's "ply file is empty" failure
+    (tmp_path / "e.ply").write_text(_ply_text([], [], []))
+    r = subprocess.run([exe, "--ply2pcd", str(tmp_path / "e.ply"), str(tmp_path / "e.pcd")], capture_output=True, text=True, timeout=60)
+    assert int(r.stdout) == 0
+    r = subprocess.run([exe, "--ply2pcd", str(tmp_path / "none.ply"), str(tmp_path / "e.pcd")], capture_output=True, text=True, timeout=60)
+    assert int(r.stdout) == 0

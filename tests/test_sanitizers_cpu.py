@@ -34,3 +34,34 @@ def test_cpp_host_mirror_under_asan_ubsan(tmp_path, orc):
                         str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=600, env=ENV)
     _clean(r)
     hostcpp_io.check_output(tmp_path, orc, w)     # and the containers it filled are the oracle's results
+
+
+def test_host_io_under_asan_ubsan(tmp_path):
+    """imagesLOAD / getCameraMatrix / PMVS2 (csrc/host/SfmIO.cpp: PNG inflate + unfilter, XML, file export) on
+    good, truncated and corrupt inputs."""
+    import numpy as np
+    from tests import test_host_io as hio
+    _build()
+    exe = os.path.join(ROOT, "oracle", "_asan", "io_selftest_asan")
+    d, _ = hio._make_dir(tmp_path, np.random.default_rng(8))
+    (tmp_path / "cam.xml").write_text(hio.XML)
+    r = subprocess.run([exe, str(d), str(tmp_path / "cam.xml"), str(tmp_path / "o.bin")], capture_output=True, text=True,
+                       timeout=600, env=ENV, cwd=tmp_path)
+    _clean(r)
+    assert os.path.exists(tmp_path / "denseCloud" / "txt" / "0000.txt")
+    good = (d / "b_rgb.PNG").read_bytes()
+    rng = np.random.default_rng(9)
+    for k in range(24):                      # corrupt / truncated streams must fail cleanly, never read out of bounds
+        bad = tmp_path / ("bad%d" % k)
+        bad.mkdir()
+        (bad / "a.png").write_bytes(good)
+        b = bytearray(good)
+        if k % 3 == 0:
+            b = b[:int(rng.integers(9, len(b)))]
+        else:
+            for _ in range(1 + k % 5):
+                b[int(rng.integers(8, len(b)))] ^= int(rng.integers(1, 256))
+        (bad / "b.png").write_bytes(bytes(b))
+        r = subprocess.run([exe, str(bad), str(tmp_path / "cam.xml"), str(tmp_path / "o.bin")], capture_output=True, text=True,
+                           timeout=600, env=ENV, cwd=tmp_path)
+        _clean(r)
