@@ -6,7 +6,8 @@ import numpy as np
 from sfm_danpipeline_amd import synth, bundle, _lib
 
 ctx = _lib.default_context()
-for (nc, npt, k) in ((7, 400, 5), (50, 20000, 10), (200, 100000, 10)):
+sizes = ((200, 100000, 10),) if "cfg4" in sys.argv[1:] else ((7, 400, 5), (50, 20000, 10), (200, 100000, 10))
+for (nc, npt, k) in sizes:
     pb = synth.ba_problem(nc, npt, k, seed=777)
     prob = bundle.BaProblem(nc, npt, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
     for rep in range(3):

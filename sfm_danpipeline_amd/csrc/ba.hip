@@ -283,8 +283,8 @@ __device__ __forceinline__ bool chol3_inv(const double C[6] /*00 10 11 20 21 22*
 
 // ---------------------------------------------------------------- Jacobi scaling (iteration 0)
 // one thread per point: unscaled squared column norms of the point's three columns (complete
-// locally) and ||x||^2 of the points.  The camera and focal columns come from ba_cam_blocks in
-// its norms-only mode (into red_dc, summed across ranks before ba_make_scale).
+// locally) and ||x||^2 of the points.  The camera and focal columns come from the linearisation
+// kernels in their norms-only mode (into red_dc, summed across ranks before ba_make_scale).
 __global__ __launch_bounds__(256) void ba_point_norms(BaDev d, int jacobi) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   double xn2 = 0;
@@ -336,26 +336,51 @@ __global__ void ba_make_scale(BaDev d, int jacobi) {
 //                     Gram matrix sum_p M_p^T M_p, a (6n+2)^2 <= 64^2 dense block that every
 //                     wave accumulates on v_mfma_f64_16x16x4_f64 (4 points = 12 rows = 3 k-steps
 //                     per iteration, upper tiles only) and the workgroup scatters into S once.
+#ifdef SFM_ELIM_STAMPS
+// diagnostic build only (scripts/elim_stamps.py): s_memtime at the phase boundaries of workgroup 0 / wave 0
+__device__ unsigned long long g_elim_stamps[32];
+__device__ unsigned long long g_elim_dump[32];
+#define EL_STAMP(slot, cond)                                                         \
+  do {                                                                               \
+    unsigned long long t_;                                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+    ((blockIdx.x == 0 && wave == 0 && (cond)) ? g_elim_stamps : g_elim_dump)[slot] = t_; \
+  } while (0)
+#define EL_STAMPW(slot)                                                        \
+  do {                                                                         \
+    unsigned long long t_;                                                     \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    ((blockIdx.x == 0) ? g_elim_stamps : g_elim_dump)[slot] = t_;              \
+  } while (0)
+#else
+#define EL_STAMP(slot, cond)
+#define EL_STAMPW(slot)
+#endif
 constexpr int MP = 80;  // LDS row pitch (doubles) of a wave's M panel: the 4 k-rows of one
                         // fragment read sit 160 dwords apart -> disjoint banks
 
+typedef __attribute__((address_space(3))) double lds_double;
 struct CamLds {  // camera table transposed in LDS: element e of camera slot o at [e*16 + o]
-  const double* base;
-  __device__ __forceinline__ double operator[](int e) const { return base[e * 16]; }
+  const lds_double* base;   // R, t (12 entries): loop-invariant per lane, the compiler keeps them in registers
+  const lds_double* dbase;  // dR/dw (27 entries): re-read every iteration through a pinned pointer (54 VGPRs
+                            // that the F^T F accumulators need more)
+  __device__ __forceinline__ double operator[](int e) const { return e < 12 ? base[e * 16] : dbase[e * 16]; }
 };
 
 template <int NB>
-__global__ __launch_bounds__(256, 2) void ba_eliminate_mfma(BaDev d, const Chunk* __restrict__ chunks,
+__global__ __launch_bounds__(512) void ba_eliminate_mfma(BaDev d, const Chunk* __restrict__ chunks,
                                                          const int* __restrict__ chunk_ids,
                                                          const int* __restrict__ sig_cams, double inv_radius,
-                                                         double lm_lo, double lm_hi, int rank) {
+                                                         double lm_lo, double lm_hi, int rank,
+                                                         int norms /* 1: unscaled squared column norms of the cameras and the focal into dc, nothing else */) {
   constexpr int NT = NB * (NB + 1) / 2;
   __shared__ __attribute__((aligned(16))) double s_cam[CAMD * 16];
   extern __shared__ __attribute__((aligned(16))) double s_M[];  // nw x 12 x MP panels; also the cross-wave reduction buffer
   __shared__ int s_gidx[64];  // local Gram index -> row/column of S; -2: the rhs column u; -1: padding
   const int nw = blockDim.x >> 6;  // 4 waves for long runs, 1 for runs of a few points (unstructured visibility)
-  const Chunk ch = chunks[chunk_ids[blockIdx.x]];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  EL_STAMP(0, true);
+  const Chunk ch = chunks[chunk_ids[blockIdx.x]];
   const int n = ch.n;
   const int* cams = sig_cams + ch.sig_off;
   const int sld = d.ld, fo = 6 * d.nc;
@@ -363,7 +388,11 @@ __global__ __launch_bounds__(256, 2) void ba_eliminate_mfma(BaDev d, const Chunk
     const int o = idx / CAMD, e = idx - o * CAMD;
     s_cam[e * 16 + o] = d.camd[(size_t)CAMD * cams[o] + e];
   }
-  for (int idx = tid; idx < nw * 12 * MP; idx += (int)blockDim.x) s_M[idx] = 0.0;
+  // dynamic LDS: the F^T F accumulators [wave][e][slot] (nw x 36 x 16) + [3][16] | the waves' panels, later the
+  // cross-wave reduction and the staged Gram block
+  const int ff_sz = nw * 576 + 48;
+  double* s_P = s_M + ff_sz;
+  for (int idx = tid; idx < ff_sz + nw * 12 * MP; idx += (int)blockDim.x) s_M[idx] = 0.0;
   if (tid < 64) {
     int gi = -1;
     if (tid < 6 * n) gi = 6 * cams[tid / 6] + tid % 6;
@@ -378,34 +407,93 @@ __global__ __launch_bounds__(256, 2) void ba_eliminate_mfma(BaDev d, const Chunk
   {
     const int cam = cams[oc];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) sc[j] = d.scale_c[6 * cam + j];
+    for (int j = 0; j < 6; ++j) sc[j] = norms ? 1.0 : d.scale_c[6 * cam + j];
   }
-  const double sf = *d.scale_f, focal = *d.focal;
+  const double sf = norms ? 1.0 : *d.scale_f, focal = *d.focal;
   const int kobs0 = d.optr[ch.p0];
   __syncthreads();
+  EL_STAMP(1, true);
 
   v4d acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
   double gmax = 0.0;
   int nfail = 0;
-  double* Mw = s_M + wave * (12 * MP);
-  const CamLds cd{s_cam + oc};
+  double* Mw = s_P + wave * (12 * MP);
+  const lds_double* cam_lds = (const lds_double*)s_cam + oc;
   const int frow = lane >> 4, fcol = lane & 15;
+  // F^T F part of a camera slot (the 6x6 block (upper, 21), the focal border (6), F^T b (6), Jf^2, Jf r, r^2 --
+  // what ba_cam_blocks formed from a second linearisation) is accumulated in LDS, ds_add_f64 by the slot's four point
+  // lanes: as registers the 36 sums cost the 72 VGPRs that keep the loop from spilling and from prefetching
+  lds_double* ffw = (lds_double*)s_M + wave * 576 + oc;
+  // point data of the next iteration is loaded one iteration ahead (a lone wave per SIMD otherwise waits a global
+  // round trip per iteration)
+  double nX[3], nsp[3] = {1.0, 1.0, 1.0};
+  double2 nxy;
+  auto fetch = [&](int quad_) {
+    const int pi_ = 4 * quad_ + q;
+    const int pl_ = pi_ < ch.cnt ? pi_ : ch.cnt - 1;
+    const int p_ = ch.p0 + pl_;
+    nX[0] = d.pts[3 * p_];
+    nX[1] = d.pts[3 * p_ + 1];
+    nX[2] = d.pts[3 * p_ + 2];
+    if (!norms) {
+      nsp[0] = d.scale_p[3 * p_];
+      nsp[1] = d.scale_p[3 * p_ + 1];
+      nsp[2] = d.scale_p[3 * p_ + 2];
+    }
+    nxy = d.oxy[kobs0 + pl_ * n + oc];
+  };
+  fetch(wave);
+  EL_STAMP(2, true);
+  EL_STAMPW(24 + (wave & 3));
 
   for (int quad = wave; 4 * quad < ch.cnt; quad += nw) {
+    EL_STAMP(8, quad == wave + 2 * nw);
+    const lds_double* cam_d = cam_lds;
+    asm volatile("" : "+v"(cam_d));
+    const CamLds cd{cam_lds, cam_d};
     const int pi = 4 * quad + q;
     const bool pv = pi < ch.cnt;
-    const int pl = pv ? pi : ch.cnt - 1;
-    const int p = ch.p0 + pl;
-    const double X[3] = {d.pts[3 * p], d.pts[3 * p + 1], d.pts[3 * p + 2]};
-    const double sp[3] = {d.scale_p[3 * p], d.scale_p[3 * p + 1], d.scale_p[3 * p + 2]};
+    const double X[3] = {nX[0], nX[1], nX[2]};
+    const double sp[3] = {nsp[0], nsp[1], nsp[2]};
+    const double2 xy = nxy;
+    if (4 * (quad + nw) < ch.cnt) fetch(quad + nw);
     ObsLin ol;
-    {
-      const double2 xy = d.oxy[kobs0 + pl * n + oc];
-      obs_linearize(cd, X, focal, xy.x, xy.y, sc, sp, sf, ol);
-    }
+    obs_linearize(cd, X, focal, xy.x, xy.y, sc, sp, sf, ol);
+    EL_STAMP(9, quad == wave + 2 * nw);
     const double live = (pv && valid_o) ? 1.0 : 0.0;
+    if (pv && valid_o) {
+      // (Jc[4] = Jc[9] = 0: row 0 has no t_y column, row 1 no t_x column; entry (3,4) is identically zero)
+      auto ff_add = [&](int e, double v) {
+        __hip_atomic_fetch_add(ffw + e * 16, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      };
+      int e = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = i; j < 6; ++j, ++e) {
+          const bool a0 = i != 4 && j != 4, a1 = i != 3 && j != 3;
+          if (a0 && a1) ff_add(e, fma(ol.Jc[i], ol.Jc[j], ol.Jc[6 + i] * ol.Jc[6 + j]));
+          else if (a0) ff_add(e, ol.Jc[i] * ol.Jc[j]);
+          else if (a1) ff_add(e, ol.Jc[6 + i] * ol.Jc[6 + j]);
+        }
+        if (i == 4) {
+          ff_add(21 + i, ol.Jc[6 + i] * ol.Jf[1]);
+          ff_add(27 + i, ol.Jc[6 + i] * ol.r1);
+        } else if (i == 3) {
+          ff_add(21 + i, ol.Jc[i] * ol.Jf[0]);
+          ff_add(27 + i, ol.Jc[i] * ol.r0);
+        } else {
+          ff_add(21 + i, fma(ol.Jc[i], ol.Jf[0], ol.Jc[6 + i] * ol.Jf[1]));
+          ff_add(27 + i, fma(ol.Jc[i], ol.r0, ol.Jc[6 + i] * ol.r1));
+        }
+      }
+      ff_add(33, fma(ol.Jf[0], ol.Jf[0], ol.Jf[1] * ol.Jf[1]));
+      ff_add(34, fma(ol.Jf[0], ol.r0, ol.Jf[1] * ol.r1));
+      ff_add(35, fma(ol.r0, ol.r0, ol.r1 * ol.r1));
+    }
+    EL_STAMP(10, quad == wave + 2 * nw);
     // point block C = sum Jp^T Jp (lower: 00 10 11 20 21 22), gp = Jp^T r, wf = Jp^T Jf
     double red[12];
     red[0] = live * (ol.Jp[0] * ol.Jp[0] + ol.Jp[3] * ol.Jp[3]);
@@ -426,6 +514,7 @@ __global__ __launch_bounds__(256, 2) void ba_eliminate_mfma(BaDev d, const Chunk
     C[0] += fmin(fmax(C[0], lm_lo), lm_hi) * inv_radius;
     C[2] += fmin(fmax(C[2], lm_lo), lm_hi) * inv_radius;
     C[5] += fmin(fmax(C[5], lm_lo), lm_hi) * inv_radius;
+    EL_STAMP(11, quad == wave + 2 * nw);
     double Li[6];
     const bool pd = chol3_inv(C, Li);
     if (!pd) {
@@ -435,6 +524,7 @@ __global__ __launch_bounds__(256, 2) void ba_eliminate_mfma(BaDev d, const Chunk
     const double pvf = pv ? 1.0 : 0.0;
     // gradient of the point (unscaled) for the gradient tolerance
     gmax = fmax(gmax, pvf * fmax(fabs(red[6] * rcp_f64(sp[0])), fmax(fabs(red[7] * rcp_f64(sp[1])), fabs(red[8] * rcp_f64(sp[2])))));
+    EL_STAMP(12, quad == wave + 2 * nw);
     if (valid_o) {
       // W = Jc^T Jp (6x3); T = W Li^T : T[i][k] = sum_{a<=k} W[i][a] Li[k][a]; row k of the panel
       double* row0 = Mw + (3 * q) * MP + 6 * o;
@@ -458,6 +548,7 @@ __global__ __launch_bounds__(256, 2) void ba_eliminate_mfma(BaDev d, const Chunk
       b0[MP + 1] = pvf * (Li[1] * red[6] + Li[2] * red[7]);
       b0[2 * MP + 1] = pvf * (Li[3] * red[6] + Li[4] * red[7] + Li[5] * red[8]);
     }
+    EL_STAMP(13, quad == wave + 2 * nw);
     // Gram update: the same fragment serves as A (M^T tile) and B (M tile) operand
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
@@ -471,57 +562,133 @@ __global__ __launch_bounds__(256, 2) void ba_eliminate_mfma(BaDev d, const Chunk
         for (int tj = ti; tj < NB; ++tj, ++t)
           acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[ti], fr[tj], acc[t], 0, 0, 0);
     }
+    EL_STAMP(14, quad == wave + 2 * nw);
   }
+  EL_STAMP(3, true);
+  EL_STAMPW(20 + (wave & 7));
 
-  // ---- cross-wave sum of the Gram tiles (s_M is free now), then one scatter into S per chunk
-  __syncthreads();
-#pragma unroll 1
-  for (int w = 1; w < nw; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) s_M[(t * 4 + g) * 64 + lane] = acc[t][g];
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[t][g] += s_M[(t * 4 + g) * 64 + lane];
-    }
-    __syncthreads();
-  }
-  double* scv = red_sc(d);
+  // ---- epilogue.  Only LDS traffic between the barriers (a barrier waits for the wave's outstanding global
+  // atomics: ~2 us each), every global atomic in the last phase:
+  //   A  all loops done; wave 0 stores its Gram tiles to s_G (MFMA layout [tile][register][lane], over the panels)
+  //   B  the other waves add theirs (ds_add_f64); the F^T F sums over the waves are folded in (S += F^T F - Gram)
+  //   C  the three scalar sums over the slots
+  //   D  one atomic per entry of the block and workgroup, issued by all waves, every workgroup starting at a
+  //      different entry: the workgroups of a round end together and neighbouring signatures share most of their
+  //      destinations -- same-address atomics serialise in L2
+  lds_double* s_G = (lds_double*)s_P;  // NT x 256
+  lds_double* s_F = (lds_double*)s_M;  // [wave][e][slot] nw x 36 x 16 (the accumulators) | [3][16] the scalars per slot
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     gmax = fmax(gmax, __shfl_down(gmax, off));
     nfail += __shfl_down(nfail, off);
   }
-  if (lane == 0) {
+  __syncthreads();
+  EL_STAMP(15, true);
+  if (wave == 0 && !norms) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) s_G[(t * 4 + g) * 64 + lane] = acc[t][g];
+  }
+  __syncthreads();
+  EL_STAMP(16, true);
+  if (wave != 0 && !norms) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        __hip_atomic_fetch_add(s_G + (t * 4 + g) * 64 + lane, acc[t][g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  // local (row, column) of the Gram block -> its slot in s_G (row <= column)
+  auto g_slot = [&](int lr, int lc) {
+    const int ti = lr >> 4, tj = lc >> 4;
+    const int t = ti * NB - ti * (ti - 1) / 2 + (tj - ti);
+    return (t * 4 + ((lr & 15) >> 2)) * 64 + (lr & 3) * 16 + (lc & 15);
+  };
+  auto g_sub = [&](int lr, int lc, double v) {
+    __hip_atomic_fetch_add(s_G + g_slot(lr, lc), -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  for (int idx = tid; idx < 36 * 16; idx += (int)blockDim.x) {
+    const int e = idx >> 4, slot = idx & 15;
+    if (slot >= n) continue;
+    double v = 0.0;
+    for (int w = 0; w < nw; ++w) v += s_F[(w * 36 + e) * 16 + slot];
+    s_F[e * 16 + slot] = v;  // (the sum over the waves, for phases C and D)
+    if (norms || e >= 33) continue;
+    if (e < 21) {
+      int i = 0, rem = e;
+      while (rem >= 6 - i) {
+        rem -= 6 - i;
+        ++i;
+      }
+      g_sub(6 * slot + i, 6 * slot + i + rem, v);
+    } else if (e < 27) {
+      g_sub(6 * slot + e - 21, 6 * n, v);      // the focal column
+    } else {
+      g_sub(6 * slot + e - 27, 6 * n + 1, v);  // the rhs column
+    }
+  }
+  __syncthreads();
+  EL_STAMP(4, true);
+  if (tid < 3) {
+    double v = 0.0;
+    for (int slot = 0; slot < n; ++slot) v += s_F[(33 + tid) * 16 + slot];
+    s_F[(nw * 36 + tid) * 16] = v;
+    if (!norms && tid < 2) g_sub(6 * n, 6 * n + tid, v);
+  }
+  __syncthreads();
+  EL_STAMP(5, true);
+  double* scv = red_sc(d);
+  if (lane == 0 && !norms) {
     if (nfail) atomic_add_f64(scv + 2, (double)nfail);
     atomic_max_pos_f64(scv + SC + rank, gmax);
   }
-  if (wave == 0) {
+  for (int idx = tid; idx < 33 * 16; idx += (int)blockDim.x) {  // F^T F diagonal -> dc, F^T b -> gF
+    const int e = idx >> 4, slot = idx & 15;
+    if (slot >= n) continue;
+    const int r0 = 6 * cams[slot];
+    if (e < 21) {
+      int i = 0, rem = e;
+      while (rem >= 6 - i) {
+        rem -= 6 - i;
+        ++i;
+      }
+      if (rem == 0) atomic_add_f64(red_dc(d) + r0 + i, s_F[e * 16 + slot]);
+    } else if (e >= 27 && !norms) {
+      atomic_add_f64(red_gF(d) + r0 + e - 27, s_F[e * 16 + slot]);
+    }
+  }
+  if (tid < 3) {
+    const double v = s_F[(nw * 36 + tid) * 16];
+    if (tid == 0) atomic_add_f64(red_dc(d) + fo, v);
+    else if (norms) {
+    } else if (tid == 1) atomic_add_f64(red_gF(d) + fo, v);
+    else atomic_add_f64(scv + 0, v);
+  }
+  if (norms) return;
+  {
     double* S = red_S(d);
     double* g = red_g(d);
-    int t = 0;
-#pragma unroll
-    for (int ti = 0; ti < NB; ++ti)
-#pragma unroll
-      for (int tj = ti; tj < NB; ++tj, ++t) {
-        const int lc = 16 * tj + fcol;
-        const int gc = s_gidx[lc];
-#pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-          const int lr = 16 * ti + frow + 4 * gg;
-          const int gr = s_gidx[lr];
-          if (gr < 0 || lr > lc) continue;
-          if (gc >= 0) atomic_add_f64(S + (size_t)gr * sld + gc, -acc[t][gg]);
-          else if (gc == -2) atomic_add_f64(g + gr, -acc[t][gg]);
-        }
+    constexpr int TOT = NT * 256;
+    const int rot = (int)((blockIdx.x * 7u) % (unsigned)NT) * 256 + (int)((blockIdx.x * 3u) & 3u) * 64;
+    for (int k = tid; k < TOT; k += (int)blockDim.x) {
+      int idx = k + rot;
+      if (idx >= TOT) idx -= TOT;
+      int t = idx >> 8, ti = 0;
+      while (t >= NB - ti) {
+        t -= NB - ti;
+        ++ti;
       }
+      const int tj = ti + t, gg = (idx >> 6) & 3, ln = idx & 63;
+      const int lr = 16 * ti + (ln >> 4) + 4 * gg, lc = 16 * tj + (ln & 15);
+      const int gr = s_gidx[lr], gc = s_gidx[lc];
+      if (gr < 0 || lr > lc || gc == -1) continue;
+      const double v = -s_G[idx];
+      if (gc >= 0) atomic_add_f64(S + (size_t)gr * sld + gc, v);
+      else atomic_add_f64(g + gr, v);
+    }
   }
+  EL_STAMP(6, true);
 }
 
 // F^T F part of the reduced system from the camera-major observation list: thread per
@@ -1764,6 +1931,7 @@ struct sfmhip_ba {
   int cam_split = 1;
   int* d_fb_points = nullptr;
   int n_fb = 0;
+  int elim_waves = 4;  // waves per workgroup of the long-run class of ba_eliminate_mfma (8, 4 or 2)
   // device storage owned
   std::vector<void*> allocs;
   size_t red_count = 0;
@@ -1821,6 +1989,11 @@ static int ba_alloc(sfmhip_ba* b, T** p, size_t n) {
   return SFMHIP_OK;
 }
 
+#ifdef SFM_ELIM_STAMPS
+extern "C" int sfmhip_debug_elim_stamps(unsigned long long* out32) {
+  return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_elim_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -2;
+}
+#endif
 #ifdef SFM_CHOL_STAMPS
 extern "C" int sfmhip_debug_chol_stamps(unsigned long long* out16) {
   return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_chol_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -2;
@@ -1974,9 +2147,13 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   std::vector<Chunk> chunks;
   std::vector<int> ids[8], sig_cams, fb;
   constexpr int SHORT_RUN = 12;  // runs of at most this many points go to one-wave workgroups
-  // points per workgroup: 2 workgroups of 4 waves are resident per CU (register-bound), so the
-  // launch runs in rounds of 512 workgroups; pick the run length that minimises
-  // rounds x (run length + fixed per-workgroup cost, ~40 points' worth of prologue + scatter)
+  // points per workgroup: 2 workgroups of 4 waves are resident per CU (register-bound), so the launch runs in
+  // rounds of 512 workgroups; a wave takes 4 points per iteration (~3.7 us at n = 10) and a fixed ~7 iterations'
+  // worth of prologue, reductions and scatter (s_memtime stamps, scripts/elim_stamps.py).  Pick the run length
+  // that minimises rounds x (iterations per wave + fixed).  Measured at cfg4 (scripts/gpu_ba_elim_ab.py, stage
+  // time per LM iteration): 400 workgroups of 4 waves 100 us; 800 of 2 waves 106 us; 200 of 8 waves 150 us -- the
+  // two waves a SIMD gets from ONE workgroup run in lockstep (both want the vector ALU, then both the MFMA pipe,
+  // and the younger one loses), the waves of two workgroups drift apart and overlap; 800 of 4 waves (2 rounds) 136 us.
   int target = 64;
   const std::vector<int>& gstart = run_start;  // first sorted point of every run, + np
   {
@@ -1984,13 +2161,20 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
     for (size_t gi = 0; gi + 1 < gstart.size(); ++gi)
       if (gstart[gi + 1] - gstart[gi] > SHORT_RUN) gsz.push_back(gstart[gi + 1] - gstart[gi]);
     double best = 1e300;
-    for (int t = 32; t <= 512; t += 4) {
+    for (int t = 32; t <= 1024; t += 4) {
       long long w = 0;
       for (int g : gsz) w += (g + t - 1) / t;
-      const double cost = (double)((w + 511) / 512) * (t + 40);
+      const double cost = (double)((w + 511) / 512) * ((double)((t + 15) / 16) + 7.0);
       if (cost < best) {
         best = cost;
         target = t;
+      }
+    }
+    if (const char* e = getenv("SFMHIP_BA_ELIM")) {  // "waves,target" (measurement)
+      int w_ = 0, t_ = 0;
+      if (sscanf(e, "%d,%d", &w_, &t_) == 2 && (w_ == 2 || w_ == 4 || w_ == 8) && t_ >= 8) {
+        b->elim_waves = w_;
+        target = t_;
       }
     }
   }
@@ -2019,37 +2203,26 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
     }
   }
   lap_("chunks");
-  // ---- camera-major copy of the observations (sorted point index, xy) for ba_cam_blocks
-  std::vector<int> cptr(n_cam + 1, 0), cpt(b->no);
-  std::vector<double> cxy(2 * (size_t)b->no);
+  // ---- camera-major copy of the GENERIC path's observations (sorted point index, xy) for ba_cam_blocks: the
+  //      MFMA path forms the F^T F part of its points itself, so this is empty for structured visibility
+  std::vector<int> cptr(n_cam + 1, 0), cpt;
+  std::vector<double> cxy;
   {
-    // stable counting sort by camera, the sorted points split over the host threads: per-thread
-    // counts, offsets by (camera, thread), then every thread scatters into its own ranges
-    const int nth = host_threads(b->np);
-    std::vector<int> tcnt((size_t)nth * n_cam, 0);
-    host_parallel_for_t(b->np, nth, [&](int t, int lo, int hi) {
-      int* c = tcnt.data() + (size_t)t * n_cam;
-      for (int k = optr[lo]; k < optr[hi]; ++k) c[ocam[k]]++;
-    });
-    for (int c = 0; c < n_cam; ++c) {
-      int run = cptr[c];
-      for (int t = 0; t < nth; ++t) {
-        const int v = tcnt[(size_t)t * n_cam + c];
-        tcnt[(size_t)t * n_cam + c] = run;
-        run += v;
+    size_t nfo = 0;
+    for (int sp : fb) nfo += (size_t)(optr[sp + 1] - optr[sp]);
+    cpt.resize(nfo);
+    cxy.resize(2 * nfo);
+    for (int sp : fb)
+      for (int k = optr[sp]; k < optr[sp + 1]; ++k) cptr[ocam[k] + 1]++;
+    for (int c = 0; c < n_cam; ++c) cptr[c + 1] += cptr[c];
+    std::vector<int> fill(cptr.begin(), cptr.end() - 1);
+    for (int sp : fb)  // ascending sorted point index: the order inside a camera is the stable one
+      for (int k = optr[sp]; k < optr[sp + 1]; ++k) {
+        const int dst = fill[ocam[k]]++;
+        cpt[dst] = sp;
+        cxy[2 * (size_t)dst] = oxy[2 * (size_t)k];
+        cxy[2 * (size_t)dst + 1] = oxy[2 * (size_t)k + 1];
       }
-      cptr[c + 1] = run;
-    }
-    host_parallel_for_t(b->np, nth, [&](int t, int lo, int hi) {
-      int* fillc = tcnt.data() + (size_t)t * n_cam;
-      for (int sp = lo; sp < hi; ++sp)
-        for (int k = optr[sp]; k < optr[sp + 1]; ++k) {
-          const int dst = fillc[ocam[k]]++;
-          cpt[dst] = sp;
-          cxy[2 * (size_t)dst] = oxy[2 * (size_t)k];
-          cxy[2 * (size_t)dst + 1] = oxy[2 * (size_t)k + 1];
-        }
-    });
     b->cam_split = std::max(1, std::min(64, 1024 / std::max(n_cam, 1)));
   }
   lap_("camera-major copy");
@@ -2227,6 +2400,30 @@ static int ba_agree_flag(sfmhip_ba* b, int* flag) {
   return SFMHIP_OK;
 }
 
+// the MFMA linearisation / elimination launches (one per Gram width and run class); norms = 1: the norms-only mode
+static int ba_launch_eliminate(sfmhip_ba* b, double inv_radius, double lm_lo, double lm_hi, int norms) {
+  hipStream_t st = b->ctx->stream;
+  int nl = 0;
+#define BA_ELIM(NB)                                                                                                   \
+  for (int cls = 0; cls < 2; ++cls) {                                                                                 \
+    const int li = 4 * cls + NB - 1, nthreads = cls ? 64 : 64 * b->elim_waves;                                        \
+    if (!b->n_chunk_ids[li]) continue;                                                                                \
+    /* wave panels | the cross-wave Gram reduction (NT x 4 x 64) | the F^T F reduction */                             \
+    const size_t nw_ = nthreads / 64, gram_ = (size_t)(NB * (NB + 1) / 2) * 256;                                      \
+    const size_t lds = sizeof(double) * (nw_ * 576 + 48 + std::max(nw_ * 12 * MP, gram_));                            \
+    hipLaunchKernelGGL((ba_eliminate_mfma<NB>), dim3(b->n_chunk_ids[li]), dim3(nthreads), lds, st, b->d,              \
+                       b->d_chunks, b->d_chunk_ids[li],                                                               \
+                       b->d_sig_cams, inv_radius, lm_lo, lm_hi, b->rank, norms);                                      \
+    ++nl;                                                                                                             \
+  }
+  BA_ELIM(1)
+  BA_ELIM(2)
+  BA_ELIM(3)
+  BA_ELIM(4)
+#undef BA_ELIM
+  return nl;
+}
+
 static int ba_prepare_scale(sfmhip_ba* b, int jacobi) {
   hipStream_t st = b->ctx->stream;
   BaDev& d = b->d;
@@ -2235,9 +2432,12 @@ static int ba_prepare_scale(sfmhip_ba* b, int jacobi) {
   hipLaunchKernelGGL(ba_cam_prep, dim3((b->nc + 63) / 64), dim3(64), 0, st, d.cams, d.camd, b->nc, 1);
   b->camd_valid = true;
   if (b->np) hipLaunchKernelGGL(ba_point_norms, dim3((b->np + 255) / 256), dim3(256), 0, st, d, jacobi);
-  if (b->no && jacobi)
-    hipLaunchKernelGGL(ba_cam_blocks, dim3(b->nc * b->cam_split), dim3(256), 0, st, d, b->d_cptr, b->d_cpt, b->d_cxy,
-                       b->cam_split, 1);
+  if (b->no && jacobi) {
+    ba_launch_eliminate(b, 1.0, 1e-6, 1e32, 1);
+    if (b->n_fb)
+      hipLaunchKernelGGL(ba_cam_blocks, dim3(b->nc * b->cam_split), dim3(256), 0, st, d, b->d_cptr, b->d_cpt, b->d_cxy,
+                         b->cam_split, 1);
+  }
   SFM_HIP_TRY(hipGetLastError());
   SFM_TRY(ba_allreduce(b, d.red + tail, (size_t)b->ld + SC));
   hipLaunchKernelGGL(ba_make_scale, dim3((b->dim + 255) / 256), dim3(256), 0, st, d, jacobi);
@@ -2278,25 +2478,12 @@ static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_o
   }
   const double inv_radius = 1.0 / radius;
   int nl = 0;
-  if (b->no) {
+  if (b->n_fb) {  // F^T F of the generic path's points (the MFMA path forms its own)
     hipLaunchKernelGGL(ba_cam_blocks, dim3(b->nc * b->cam_split), dim3(256), 0, st, d, b->d_cptr, b->d_cpt, b->d_cxy,
                        b->cam_split, 0);
     ++nl;
   }
-#define BA_ELIM(NB)                                                                                                   \
-  for (int cls = 0; cls < 2; ++cls) {                                                                                 \
-    const int li = 4 * cls + NB - 1, nthreads = cls ? 64 : 256;                                                       \
-    if (!b->n_chunk_ids[li]) continue;                                                                                \
-    hipLaunchKernelGGL((ba_eliminate_mfma<NB>), dim3(b->n_chunk_ids[li]), dim3(nthreads),                             \
-                       sizeof(double) * (nthreads / 64) * 12 * MP, st, d, b->d_chunks, b->d_chunk_ids[li],            \
-                       b->d_sig_cams, inv_radius, o->min_lm_diagonal, o->max_lm_diagonal, b->rank);                   \
-    ++nl;                                                                                                             \
-  }
-  BA_ELIM(1)
-  BA_ELIM(2)
-  BA_ELIM(3)
-  BA_ELIM(4)
-#undef BA_ELIM
+  nl += ba_launch_eliminate(b, inv_radius, o->min_lm_diagonal, o->max_lm_diagonal, 0);
   if (b->n_fb)
     hipLaunchKernelGGL(ba_eliminate_generic, dim3(b->n_fb), dim3(64), 0, st, d, b->d_fb_points, radius,
                        o->min_lm_diagonal, o->max_lm_diagonal, b->rank);
