@@ -211,6 +211,18 @@ int sfmhip_ba_reduced_system(sfmhip_ba* ba, double radius, double* S, double* g,
  * Test hook. */
 int sfmhip_ba_linearize_obs(sfmhip_ctx* ctx, int n, const double* cams6, const double* pts3, double focal,
                             const double* obs_xy, double* r, double* Jc, double* Jp, double* Jf);
+/* Test hook: the solution z of the damped reduced system (S + D/radius) z = g at the current parameters, as the
+ * solver's own factorisation (dense or dissected, see sfmhip_ba_reduced_layout) computes it; z: 6*n_cam + 1
+ * doubles in the solver's scaled coordinates (the system sfmhip_ba_reduced_system returns); *chol_failed != 0 when
+ * a pivot was not positive.  Single rank only. */
+int sfmhip_ba_reduced_step(sfmhip_ba* ba, double radius, double* z, int* chol_failed);
+/* How the reduced camera system of this problem is factored (decided at the first run / iterate; zeros before):
+ * layout[0] = independent interior chains of the dissected camera graph (0: one dense factorisation),
+ * layout[1] = 32-column tiles of the longest chain, layout[2] = tiles of the separator (with the focal),
+ * layout[3] = tiles of the dense matrix.  The factorisation's dependency chain is layout[1] + layout[2] tiles
+ * instead of layout[3].  Replaces nothing in the reference (Eigen's dense LLT, src/BundleAdjustment.cpp:116,
+ * has no such choice); SFMHIP_BA_ND=0 in the environment keeps the dense factorisation. */
+int sfmhip_ba_reduced_layout(sfmhip_ba* ba, int32_t layout[4]);
 /* device seconds of the last run/iterate by kernel group:
  * [0]=linearise+eliminate [1]=allreduce [2]=reduced solve [3]=back-substitute+cost */
 int sfmhip_ba_last_timing(sfmhip_ba* ba, double seconds[4], int* launches);

@@ -176,6 +176,21 @@ class BaProblem:
         check(lib().sfmhip_ba_last_timing(self.h, t.ctypes.data, C.addressof(n)), "sfmhip_ba_last_timing")
         return dict(eliminate_s=t[0], allreduce_s=t[1], solve_s=t[2], backsub_s=t[3], launches=n.value)
 
+    def reduced_step(self, radius):
+        """z with (S + D/radius) z = g from the solver's own factorisation (sfmhip_ba_reduced_step); returns
+        (z, chol_failed)."""
+        z = np.zeros(6 * self.n_cam + 1)
+        info = C.c_int(0)
+        check(lib().sfmhip_ba_reduced_step(self.h, float(radius), z.ctypes.data, C.addressof(info)), "sfmhip_ba_reduced_step")
+        return z, info.value
+
+    def reduced_layout(self):
+        """How the reduced camera system is factored (sfmhip_ba_reduced_layout): chains = 0 is the dense
+        factorisation; valid after the first run / iterate."""
+        a = np.zeros(4, np.int32)
+        check(lib().sfmhip_ba_reduced_layout(self.h, a.ctypes.data), "sfmhip_ba_reduced_layout")
+        return dict(chains=int(a[0]), chain_tiles=int(a[1]), separator_tiles=int(a[2]), dense_tiles=int(a[3]))
+
     def close(self):
         if self.h:
             lib().sfmhip_ba_destroy(self.h)

@@ -37,6 +37,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <thread>
 #include <vector>
@@ -1607,24 +1608,24 @@ __device__ __forceinline__ void chol2_panel(double* __restrict__ A, double* __re
   }
 }
 
-__global__ __launch_bounds__(C2_WAVES * 64) void chol_step2(double* __restrict__ A, double* __restrict__ y,
-                                                            double* __restrict__ X, int ld, int nt, int k2,
-                                                            int tiles_per_wg, int* __restrict__ info) {
-  extern __shared__ __attribute__((aligned(16))) double sAll[];  // C2_LDS_BYTES, see C2_OFF_*
+// (bid: the workgroup's index within its matrix -- blockIdx.x when a launch factors one matrix)
+__device__ __forceinline__ void chol_step2_body(double* __restrict__ A, double* __restrict__ y, double* __restrict__ X,
+                                                int ld, int nt, int k2, int tiles_per_wg, int* __restrict__ info,
+                                                const int bid, double* sAll) {
   const int m2 = nt - 2 * k2 - 2;  // tile rows below the two panels (the rhs row comes on top)
   const int npanel = m2 + 2;       // owner, m2 tile rows, rhs
   const int nx = 2 * k2 + 2;       // rows 0..b of the identity block X (see below) take part as tile rows
-  if ((int)blockIdx.x < npanel + nx) {
-    if ((int)blockIdx.x >= npanel) {
+  if (bid < npanel + nx) {
+    if (bid >= npanel) {
       // X starts as the identity and rides along as nt more tile rows: X <- X L^-T, i.e. L^-T when the
       // factorisation ends, and the backward substitution becomes the product z = X y.  (Row block
       // r' is all zero left of column block r' and untouched until its own panel: rows 0..b here.)
-      chol2_panel<false>(A, y, X, ld, k2, info, false, ((int)blockIdx.x - npanel) * CB, sAll);
+      chol2_panel<false>(A, y, X, ld, k2, info, false, (bid - npanel) * CB, sAll);
       return;
     }
-    const bool owner = blockIdx.x == 0;
-    const int r0 = (2 * k2 + 1 + (int)blockIdx.x) * CB;
-    if ((int)blockIdx.x == npanel - 1)
+    const bool owner = bid == 0;
+    const int r0 = (2 * k2 + 1 + bid) * CB;
+    if (bid == npanel - 1)
       chol2_panel<true>(A, y, A, ld, k2, info, false, r0, sAll);
     else
       chol2_panel<false>(A, y, A, ld, k2, info, owner, r0, sAll);
@@ -1637,7 +1638,7 @@ __global__ __launch_bounds__(C2_WAVES * 64) void chol_step2(double* __restrict__
   // (four tiles per workgroup -- one wave per SIMD: a tile is 64 MFMAs -- while that fits one round of
   // workgroups on the device; every workgroup of this kernel holds a CU's LDS)
   if (wave >= tiles_per_wg) return;
-  int t = ((int)blockIdx.x - npanel - nx) * tiles_per_wg + wave;
+  int t = (bid - npanel - nx) * tiles_per_wg + wave;
   const int ntrail = m2 * (m2 + 1) / 2 + m2;
   if (t >= ntrail + 2 * k2 * m2) return;
   int ti_rel = 0;
@@ -1724,6 +1725,42 @@ __global__ __launch_bounds__(C2_WAVES * 64) void chol_step2(double* __restrict__
       }
     }
 }
+
+__global__ __launch_bounds__(C2_WAVES * 64) void chol_step2(double* __restrict__ A, double* __restrict__ y,
+                                                            double* __restrict__ X, int ld, int nt, int k2,
+                                                            int tiles_per_wg, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double sAll[];  // C2_LDS_BYTES, see C2_OFF_*
+  chol_step2_body(A, y, X, ld, nt, k2, tiles_per_wg, info, (int)blockIdx.x, sAll);
+}
+
+// Several independent matrices ("chains": the interiors of a dissected camera graph, see NdPlan) at the same
+// panel pair k2 in ONE launch.  ALL panel workgroups come first in the grid, the trailing workgroups after them:
+// the panel workgroups of a matrix read its diagonal tiles D_aa, D_ba, D_bb from global memory and the owner
+// stores L_aa, L_ba, L_bb over them ~25 k cycles later, so every panel workgroup has to be resident from the
+// start of the launch (one workgroup per CU: the host keeps their number within the device's CUs).
+constexpr int ND_MAX = 8;
+struct ChainSet {
+  int n;
+  double* A[ND_MAX];
+  double* y[ND_MAX];
+  double* X[ND_MAX];
+  int ld[ND_MAX], nt[ND_MAX], tpw[ND_MAX];
+  int pan0[ND_MAX + 1];  // first panel workgroup of chain c (pan0[n]: all panel workgroups)
+  int trl0[ND_MAX + 1];  // first trailing workgroup of chain c, counted from pan0[n]
+};
+__global__ __launch_bounds__(C2_WAVES * 64) void chol_step2_chains(ChainSet cs, int k2, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double sAll[];
+  int c = 0, bid;
+  if ((int)blockIdx.x < cs.pan0[cs.n]) {
+    while (c + 1 < cs.n && (int)blockIdx.x >= cs.pan0[c + 1]) ++c;
+    bid = (int)blockIdx.x - cs.pan0[c];
+  } else {
+    const int t = (int)blockIdx.x - cs.pan0[cs.n];
+    while (c + 1 < cs.n && t >= cs.trl0[c + 1]) ++c;
+    bid = cs.pan0[c + 1] - cs.pan0[c] + (t - cs.trl0[c]);
+  }
+  chol_step2_body(cs.A[c], cs.y[c], cs.X[c], cs.ld[c], cs.nt[c], k2, cs.tpw[c], info, bid, sAll);
+}
 #undef CHOL_MFMA
 
 // z = L^-T y = X y.  X (column-major like A: X(i, j) = X[j*ld + i]) is upper triangular by 32x32
@@ -1748,6 +1785,217 @@ __global__ __launch_bounds__(256) void chol_apply_inverse(const double* __restri
     for (int k = 0; k < 8; ++k) v += s_part[k][i];
     atomic_add_f64(z + tr * CB + i, v);
   }
+}
+
+// ---------------------------------------------------------------- dissected reduced system
+// S is dense by storage only: its block pattern is the camera co-visibility graph.  When that graph has small
+// vertex separators (an ordered capture: cfg4's ring, banded plus a cyclic corner), the cameras are ordered
+// [interior 1 | interior 2 | ... | separator + focal] with no edge between two interiors (NdPlan, host), and
+//   [ D_1          C_1^T ]        L_ii = chol(D_i),  L_Si = C_i L_ii^-T   (P independent "chains", one launch
+//   [      D_2     C_2^T ]                                                 of chol_step2_chains per panel pair)
+//   [ C_1  C_2 ... D_S   ]        D_S' = D_S - sum_i L_Si L_Si^T,  L_SS = chol(D_S')
+// The dependency chain is max_i |interior i| + |separator| columns instead of all of them.  Every chain is a
+// dense square matrix of its own, M_i = [D_i, . ; C_i, 0] (interior tiles, then the separator's), on which the
+// dense kernel runs its first |interior i| / 64 launches: what is then in the lower right block is chain i's
+// part of the Schur complement (but for the last launch's pending panels, nd_combine adds both), its rhs row
+// holds y_i = L_ii^-1 g_i and -L_Si y_i, its X holds L_ii^-T.  Solution: z_S = L_SS^-T y_S,
+// z_i = L_ii^-T (y_i - L_Si^T z_S).
+struct NdChain {
+  double* M;       // (32 N)^2 column-major lower
+  double* y;       // 32 N
+  double* X;       // (32 N)^2
+  const int* inv;  // 32 N: chain index -> index in S (the parameter's column), -1 = padding
+  int ld, ni, N;   // 32 N; interior tiles (the separator: all of them); tiles
+};
+struct NdSet {
+  int n;  // chains; c[n] is the separator
+  NdChain c[ND_MAX + 1];
+};
+
+// fills the chains from S (after ba_finalize: the LM diagonal is on it), g and the identity.
+// job = (chain, tile row, tile column, kind): kind 0 a 32x32 tile of M, kind 1 tile row of y and of X's diagonal
+__global__ __launch_bounds__(256) void nd_gather(NdSet ns, const int4* __restrict__ jobs, const double* __restrict__ S,
+                                                 const double* __restrict__ g, int ldS) {
+  const int4 job = jobs[blockIdx.x];
+  const NdChain ch = ns.c[job.x];
+  const int tr = job.y, tc = job.z;
+  if (job.w == 1) {
+    if (threadIdx.x < 32) {
+      const int idx = tr * 32 + threadIdx.x;
+      const int l = ch.inv[idx];
+      ch.y[idx] = (tr < ch.ni && l >= 0) ? g[l] : 0.0;
+      ch.X[(size_t)idx * ch.ld + idx] = 1.0;
+    }
+    return;
+  }
+  __shared__ double sh[32][33];
+  const int r = threadIdx.x & 31, cg = threadIdx.x >> 5;
+  // S holds its upper triangle row-major: element (a, b), a <= b, at S[a*ldS + b].  Read with the lanes along
+  // the contiguous index, transpose through LDS where the tile lies on the other side.
+  const int lr_lane = ch.inv[tr * 32 + r], lc_lane = ch.inv[tc * 32 + r];
+  for (int j = cg; j < 32; j += 8) {
+    // lanes along the tile's rows: value (row r, column j)
+    const int lc = ch.inv[tc * 32 + j];
+    double v = 0.0;
+    if (lr_lane >= 0 && lc >= 0) {
+      if (lr_lane >= lc) v = S[(size_t)lc * ldS + lr_lane];
+    } else if (lr_lane < 0 && lc < 0 && tr == tc && r == j) v = 1.0;
+    sh[j][r] = v;
+  }
+  __syncthreads();
+  for (int j = cg; j < 32; j += 8) {
+    // lanes along the tile's columns: value (row j, column r), for the pairs stored the other way round
+    const int lr = ch.inv[tr * 32 + j];
+    if (lr >= 0 && lc_lane >= 0 && lr < lc_lane) sh[r][j] = S[(size_t)lr * ldS + lc_lane];
+  }
+  __syncthreads();
+  for (int j = cg; j < 32; j += 8) ch.M[(size_t)(tc * 32 + j) * ch.ld + tr * 32 + r] = sh[j][r];
+}
+
+// D_S' and its rhs: what the chains accumulated in their lower right blocks, and the rank-64 update of each
+// chain's last launch that nothing has folded in yet.  One workgroup per tile (tr, tc) of the separator's lower
+// triangle (tr == NS: the rhs), one wave per chain: the tile and the pending panels' rows go straight from global
+// memory into the MFMA operand layout (as in chol_step2's trailing tiles), the waves' tiles are summed through LDS.
+__global__ __launch_bounds__(256) void nd_combine(NdSet ns) {
+  const NdChain sp = ns.c[ns.n];
+  int tr = 0, t = blockIdx.x;  // -> (tr, tc): rows 0..NS-1 of the lower triangle, then the NS rhs jobs
+  while (tr < sp.N && t > tr) {
+    t -= tr + 1;
+    ++tr;
+  }
+  const int tc = t;
+  __shared__ double s_red[4][16][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j16 = lane & 15, q = lane >> 4;
+  if (tr == sp.N) {
+    // the rhs row: y_S[c] += y_i[o + c] - sum_k y_i[k0 + k] L_i(o + c, k0 + k); lane = (c, half of the 64 k)
+    double acc = 0.0;
+    const int c = lane & 31, kh = lane >> 5;
+    for (int ci = wave; ci < ns.n; ci += 4) {
+      const NdChain ch = ns.c[ci];
+      const int o = ch.ni * 32, k0 = o - 64 + 32 * kh;
+      double lv[32], yv[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        lv[k] = ch.M[(size_t)(k0 + k) * ch.ld + o + tc * 32 + c];
+        yv[k] = ch.y[k0 + k];
+      }
+      if (kh == 0) acc += ch.y[o + tc * 32 + c];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) acc -= yv[k] * lv[k];
+    }
+    acc += __shfl_down(acc, 32);
+    if (lane < 32) s_red[wave][0][lane] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32) sp.y[tc * 32 + c] += s_red[0][0][c] + s_red[1][0][c] + s_red[2][0][c] + s_red[3][0][c];
+    return;
+  }
+  v4d acc[4];  // [2 * ci + ri]: 16x16 sub-tiles, lane = row j16 of the sub-tile, registers = columns q + 4g
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = v4d{0.0, 0.0, 0.0, 0.0};
+  for (int ci = wave; ci < ns.n; ci += 4) {
+    const NdChain ch = ns.c[ci];
+    const int o = ch.ni * 32, p0 = o - 64, rb = o + tr * 32, cb = o + tc * 32;
+    const size_t st = 4 * (size_t)ch.ld;
+    double a[2][16], bb[2][16];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      ld_strided<16>(a[h], ch.M + (size_t)(p0 + q) * ch.ld + cb + 16 * h + j16, st);
+      ld_strided<16>(bb[h], ch.M + (size_t)(p0 + q) * ch.ld + rb + 16 * h + j16, st);
+    }
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+      for (int ri = 0; ri < 2; ++ri) {
+        double t4[4];
+        ld_strided<4>(t4, ch.M + (size_t)(cb + 16 * c2 + q) * ch.ld + rb + 16 * ri + j16, st);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[2 * c2 + ri][g] += t4[g];
+      }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[0][ks], bb[0][ks], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[0][ks], bb[1][ks], acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[1][ks], bb[0][ks], acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[1][ks], bb[1][ks], acc[3], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) s_red[wave][4 * i + g][lane] = acc[i][g];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+      for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int e = 4 * (2 * c2 + ri) + g;
+          double* pt = sp.M + (size_t)(tc * 32 + 16 * c2 + q + 4 * g) * sp.ld + tr * 32 + 16 * ri + j16;
+          *pt += s_red[0][e][lane] + s_red[1][e][lane] + s_red[2][e][lane] + s_red[3][e][lane];
+        }
+  }
+}
+
+// The three-step solve z_S = L_SS^-T y_S; w_i = y_i - L_Si^T z_S; z_i = L_ii^-T w_i as three small launches, each
+// one global round trip deep (a fused kernel had to recompute z_S and most of w in every workgroup: 35 MB of
+// reads, 23 us; these three: 10 us).
+// nd_xy: out = X y over the interior tiles of chains [c_lo, c_lo + gridDim.y): workgroup = 32 rows, thread =
+// (row, one of 32 column slices); X(i, j) = X[j*ld + i] upper triangular.  The result goes to z where the
+// parameter lives in S's index space and, for the separator, to its zs in chain order.
+__global__ __launch_bounds__(1024) void nd_xy(NdSet ns, int c_lo, double* __restrict__ z) {
+  __shared__ double s_red[32][33];
+  const NdChain ch = ns.c[c_lo + blockIdx.y];
+  const int tr = blockIdx.x;
+  if (tr >= ch.ni) return;
+  const int n = ch.ni * 32, r = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  double a = 0.0;
+  for (int jb = tr * 32; jb < n; jb += 256) {
+    double x[8], yv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = jb + sl + 32 * u, jj = j < n ? j : n - 1;
+      x[u] = ch.X[(size_t)jj * ch.ld + tr * 32 + r];
+      yv[u] = ch.y[jj] * (j < n ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += x[u] * yv[u];
+  }
+  s_red[sl][r] = a;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v += s_red[k][threadIdx.x];
+    const int l = ch.inv[tr * 32 + threadIdx.x];
+    if (l >= 0) z[l] = v;
+    if (c_lo == ns.n) ch.M[tr * 32 + threadIdx.x] = v;  // z_S in chain order: column 0 of L_SS is no longer needed
+  }
+}
+// nd_w: y_i[c] -= sum_s L_i(o + s, c) z_S[s]; a wave per interior column (flat index over the chains)
+struct NdCols {
+  int col0[ND_MAX + 1];
+};
+__global__ __launch_bounds__(256) void nd_w(NdSet ns, NdCols cols) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int col = blockIdx.x * 4 + wave;
+  if (col >= cols.col0[ns.n]) return;
+  int c = 0;
+  while (col >= cols.col0[c + 1]) ++c;
+  const NdChain ch = ns.c[c], sp = ns.c[ns.n];
+  const int k = col - cols.col0[c], nS = sp.N * 32;
+  const double* Lc = ch.M + (size_t)k * ch.ld + ch.ni * 32;
+  const double yk = ch.y[k];
+  double acc = 0.0;
+  for (int s0 = 4 * lane; s0 < nS; s0 += 256) {
+    const double4 l4 = *(const double4*)(Lc + s0), z4 = *(const double4*)(sp.M + s0);
+    acc += l4.x * z4.x + l4.y * z4.y + l4.z * z4.z + l4.w * z4.w;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if (lane == 0) ch.y[k] = yk - acc;
 }
 
 // ---------------------------------------------------------------- step application
@@ -1932,6 +2180,18 @@ struct sfmhip_ba {
   int* d_fb_points = nullptr;
   int n_fb = 0;
   int elim_waves = 4;  // waves per workgroup of the long-run class of ba_eliminate_mfma (8, 4 or 2)
+  // dissected reduced system (NdPlan below): built at the first solve (with world > 1 the camera graph is the
+  // union over the ranks, which needs the all-reduce)
+  std::vector<unsigned long long> h_adj;  // camera co-visibility, nc x ceil(nc/64) bit rows (this rank's points)
+  bool nd_ready = false, nd_on = false;
+  NdSet nd{};
+  NdCols nd_cols{};
+  int nd_max_ni = 0;
+  double* nd_buf = nullptr;  // all chain matrices, vectors and X blocks: zeroed at every solve
+  size_t nd_buf_count = 0;
+  int4* nd_gather_jobs = nullptr;
+  int nd_n_gather = 0;
+  bool chol_chains_attr_set = false;
   // device storage owned
   std::vector<void*> allocs;
   size_t red_count = 0;
@@ -2203,6 +2463,23 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
     }
   }
   lap_("chunks");
+  // ---- camera co-visibility (one bit row per camera) for the dissection of the reduced system
+  if (n_cam >= 64 && n_cam <= 4096) {
+    const int wpr = (n_cam + 63) / 64;
+    b->h_adj.assign((size_t)n_cam * wpr, 0ull);
+    auto add_clique = [&](const int* cs, int n) {
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) b->h_adj[(size_t)cs[i] * wpr + (cs[j] >> 6)] |= 1ull << (cs[j] & 63);
+    };
+    std::vector<char> is_fb(b->np, 0);
+    for (int q : fb) is_fb[q] = 1;
+    for (size_t gi = 0; gi + 1 < gstart.size(); ++gi) {
+      const int sp = gstart[gi];
+      if (!is_fb[sp]) add_clique(&ocam[optr[sp]], optr[sp + 1] - optr[sp]);  // one signature per run
+    }
+    for (int q : fb) add_clique(&ocam[optr[q]], optr[q + 1] - optr[q]);
+    lap_("camera graph");
+  }
   // ---- camera-major copy of the GENERIC path's observations (sorted point index, xy) for ba_cam_blocks: the
   //      MFMA path forms the F^T F part of its points itself, so this is empty for structured visibility
   std::vector<int> cptr(n_cam + 1, 0), cpt;
@@ -2470,7 +2747,8 @@ static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_o
     SFM_HIP_TRY(hipEventRecord(b->ev[0], st));
     b->ev_on[0] = true;
   }
-  SFM_HIP_TRY(hipMemsetAsync(d.red, 0, sizeof(double) * b->red_count, st));
+  // (X, the last ld*ld doubles, belongs to the dense factorisation only)
+  SFM_HIP_TRY(hipMemsetAsync(d.red, 0, sizeof(double) * (b->nd_on ? b->red_count - b->ssz : b->red_count), st));
   if (!b->camd_valid) {
     hipLaunchKernelGGL(ba_cam_prep, dim3((b->nc + 63) / 64), dim3(64), 0, st, d.cams, d.camd, b->nc, 1);
     b->camd_valid = true;
@@ -2514,7 +2792,355 @@ static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_o
   return SFMHIP_OK;
 }
 
+// ---------------------------------------------------------------- NdPlan: dissection of the camera graph
+// Order: reverse Cuthill-McKee positions pi; a cut at position p puts every camera at or behind p that sees a
+// camera before p into the separator; what is left falls into connected components that do not see each
+// other (interiors).  Cuts are chosen from a grid of positions (1..3 cuts) to minimise the number of
+// two-panel launches on the dependency chain, max_i tiles_i / 2 + tiles_S / 2 + a constant for the gather /
+// combine / three-step solve; the dense factorisation stays when that does not win by 20 %.
+static int ba_nd_build(sfmhip_ba* b) {
+  b->nd_ready = true;
+  b->nd_on = false;
+  const int nc = b->nc;
+  const char* env = getenv("SFMHIP_BA_ND");  // "0": dense always; "1": dissect whenever a cut exists (tests)
+  if (b->h_adj.empty() || (env && env[0] == '0')) return SFMHIP_OK;
+  const bool force = env && env[0] == '1';
+  const int wpr = (nc + 63) / 64;
+  std::vector<unsigned long long> adj = b->h_adj;
+  if (b->world > 1) {
+    // union over the ranks: bits as doubles through the caller's sum all-reduce (set-up, once)
+    std::vector<double> h((size_t)nc * nc);
+    for (int i = 0; i < nc; ++i)
+      for (int j = 0; j < nc; ++j) h[(size_t)i * nc + j] = (adj[(size_t)i * wpr + (j >> 6)] >> (j & 63)) & 1ull ? 1.0 : 0.0;
+    double* dbuf = nullptr;
+    SFM_TRY(ba_alloc(b, &dbuf, h.size()));
+    SFM_HIP_TRY(hipMemcpy(dbuf, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    SFM_TRY(ba_allreduce(b, dbuf, h.size()));
+    SFM_HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    SFM_HIP_TRY(hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < nc; ++i)
+      for (int j = 0; j < nc; ++j)
+        if (h[(size_t)i * nc + j] > 0.5) adj[(size_t)i * wpr + (j >> 6)] |= 1ull << (j & 63);
+  }
+  std::vector<std::vector<int>> nb(nc);
+  for (int i = 0; i < nc; ++i)
+    for (int j = 0; j < nc; ++j)
+      if (j != i && ((adj[(size_t)i * wpr + (j >> 6)] >> (j & 63)) & 1ull)) nb[i].push_back(j);
+  // ---- RCM positions (every connected component from a pseudo-peripheral start)
+  std::vector<int> order, pos(nc, -1), lvl(nc);
+  order.reserve(nc);
+  auto bfs = [&](int start, std::vector<int>& out) {
+    out.clear();
+    std::fill(lvl.begin(), lvl.end(), -1);
+    out.push_back(start);
+    lvl[start] = 0;
+    for (size_t h = 0; h < out.size(); ++h) {
+      const int u = out[h];
+      std::vector<int> nx;
+      for (int v : nb[u])
+        if (lvl[v] < 0 && pos[v] < 0) {
+          lvl[v] = lvl[u] + 1;
+          nx.push_back(v);
+        }
+      std::sort(nx.begin(), nx.end(), [&](int a, int c) { return nb[a].size() != nb[c].size() ? nb[a].size() < nb[c].size() : a < c; });
+      for (int v : nx) out.push_back(v);
+    }
+  };
+  std::vector<int> comp;
+  for (int s0 = 0; s0 < nc; ++s0) {
+    if (pos[s0] >= 0) continue;
+    int start = s0;
+    for (int rep = 0; rep < 2; ++rep) {  // farthest vertex of the farthest vertex
+      bfs(start, comp);
+      start = comp.back();
+    }
+    bfs(start, comp);
+    for (int v : comp) {
+      pos[v] = (int)order.size();
+      order.push_back(v);
+    }
+  }
+  std::vector<int> minpos(nc);
+  for (int v = 0; v < nc; ++v) {
+    int m = pos[v];
+    for (int u : nb[v]) m = std::min(m, pos[u]);
+    minpos[v] = m;
+  }
+  // ---- evaluate a set of cuts: separator, components (chains by LPT when more than ND_MAX), launches
+  struct Eval {
+    double cost = 1e300;
+    std::vector<int> sep;                  // cameras
+    std::vector<std::vector<int>> chains;  // cameras of every chain, ascending
+  };
+  const int dense_tiles = b->ld / CB, n_cu_ = b->ctx->n_cu;
+  auto evaluate = [&](const std::vector<int>& cuts, Eval& e) {
+    std::vector<char> in_sep(nc, 0);
+    for (int v = 0; v < nc; ++v)
+      for (int p : cuts)
+        if (pos[v] >= p && minpos[v] < p) in_sep[v] = 1;
+    std::vector<int> root(nc);
+    for (int v = 0; v < nc; ++v) root[v] = v;
+    std::function<int(int)> find = [&](int x) {
+      while (root[x] != x) x = root[x] = root[root[x]];
+      return x;
+    };
+    for (int v = 0; v < nc; ++v)
+      if (!in_sep[v])
+        for (int u : nb[v])
+          if (!in_sep[u]) root[find(u)] = find(v);
+    std::map<int, std::vector<int>> comps;
+    e.sep.clear();
+    for (int v = 0; v < nc; ++v) {
+      if (in_sep[v]) e.sep.push_back(v);
+      else comps[find(v)].push_back(v);
+    }
+    if (comps.size() < 2) return;
+    std::vector<std::vector<int>> cl;
+    for (auto& kv : comps) cl.push_back(kv.second);
+    std::sort(cl.begin(), cl.end(), [](const std::vector<int>& a, const std::vector<int>& c) {
+      return a.size() != c.size() ? a.size() > c.size() : a[0] < c[0];
+    });
+    const int nch = (int)std::min<size_t>(cl.size(), ND_MAX);
+    e.chains.assign(nch, {});
+    for (auto& c : cl) {
+      int best = 0;
+      for (int k = 1; k < nch; ++k)
+        if (e.chains[k].size() < e.chains[best].size()) best = k;
+      e.chains[best].insert(e.chains[best].end(), c.begin(), c.end());
+    }
+    int max_t = 0;
+    for (auto& c : e.chains) {
+      std::sort(c.begin(), c.end());
+      max_t = std::max(max_t, (int)((6 * c.size() + 63) / 64) * 2);
+    }
+    const int sep_t = (int)((6 * e.sep.size() + 1 + 63) / 64) * 2;
+    e.cost = 0.5 * max_t + 0.5 * sep_t + 2.5;
+    // every panel workgroup of a launch has to be resident (chol_step2_chains): launch 0 has N_i + 2 per chain
+    int pan = 0;
+    for (auto& c : e.chains) pan += (int)((6 * c.size() + 63) / 64) * 2 + sep_t + 2;
+    if (pan > n_cu_) e.cost = 1e300;
+  };
+  Eval best;
+  {
+    const int G = nc > 1024 ? 12 : 24;
+    std::vector<int> grid;
+    for (int k = 1; k < G; ++k) grid.push_back((int)((long long)nc * k / G));
+    Eval e;
+    const char* ce = getenv("SFMHIP_BA_ND_CUTS");  // at most this many cuts (experiments)
+    const int max_cuts = ce ? atoi(ce) : 3;
+    for (size_t i = 0; i < grid.size(); ++i) {
+      evaluate({grid[i]}, e);
+      if (e.cost < best.cost) best = e;
+      for (size_t j = i + 1; j < grid.size() && max_cuts >= 2; ++j) {
+        evaluate({grid[i], grid[j]}, e);
+        if (e.cost < best.cost) best = e;
+        if (nc <= 1024 && max_cuts >= 3)
+          for (size_t k = j + 1; k < grid.size(); k += 2) {
+            evaluate({grid[i], grid[j], grid[k]}, e);
+            if (e.cost < best.cost) best = e;
+          }
+      }
+    }
+  }
+  if (best.chains.empty() || best.cost >= 1e299 || !(force || best.cost <= 0.8 * (0.5 * dense_tiles))) return SFMHIP_OK;
+  {  // what nd_backsolve holds in LDS
+    size_t max_c = 0;
+    for (auto& c : best.chains) max_c = std::max(max_c, c.size());
+    (void)max_c;
+  }
+  // ---- chains: index maps, buffers, job lists
+  const int P = (int)best.chains.size();
+  if (getenv("SFMHIP_BA_ND_VERBOSE")) {  // the plan's invariants: a partition of the cameras, no edge between two chains
+    std::vector<int> owner(nc, -2);
+    int bad = 0;
+    for (int c : best.sep) owner[c] = -1;
+    for (int i = 0; i < P; ++i)
+      for (int c : best.chains[i]) {
+        if (owner[c] != -2) ++bad;
+        owner[c] = i;
+      }
+    for (int c = 0; c < nc; ++c) {
+      if (owner[c] == -2) ++bad;
+      for (int u : nb[c])
+        if (owner[c] >= 0 && owner[u] >= 0 && owner[u] != owner[c]) ++bad;
+    }
+    fprintf(stderr, "[sfmhip] dissection check: %d violations\n", bad);
+  }
+  const int NS = (int)((6 * best.sep.size() + 1 + 63) / 64) * 2;
+  std::vector<int> invS((size_t)NS * 32, -1);
+  {
+    int k = 0;
+    for (int c : best.sep)
+      for (int j = 0; j < 6; ++j) invS[k++] = 6 * c + j;
+    invS[k++] = 6 * nc;  // the focal
+  }
+  NdSet& ns = b->nd;
+  ns.n = P;
+  std::vector<std::vector<int>> inv(P);
+  size_t total = 0;
+  std::vector<size_t> offM(P + 1), offy(P + 1), offX(P + 1);
+  b->nd_max_ni = 0;
+  for (int i = 0; i <= P; ++i) {
+    const int ni = i < P ? (int)((6 * best.chains[i].size() + 63) / 64) * 2 : NS;
+    const int N = i < P ? ni + NS : NS;
+    if (i < P) {
+      inv[i].assign((size_t)N * 32, -1);
+      int k = 0;
+      for (int c : best.chains[i])
+        for (int j = 0; j < 6; ++j) inv[i][k++] = 6 * c + j;
+      for (int k2 = 0; k2 < NS * 32; ++k2) inv[i][(size_t)ni * 32 + k2] = invS[k2];
+      b->nd_max_ni = std::max(b->nd_max_ni, ni);
+    }
+    ns.c[i].ld = N * 32;
+    ns.c[i].ni = ni;
+    ns.c[i].N = N;
+    offM[i] = total;
+    total += (size_t)N * 32 * N * 32;
+    offX[i] = total;
+    total += (size_t)N * 32 * N * 32;
+    offy[i] = total;
+    total += (size_t)N * 32;
+  }
+  SFM_TRY(ba_alloc(b, &b->nd_buf, total));
+  b->nd_buf_count = total;
+  std::vector<int4> gj;
+  b->nd_cols.col0[0] = 0;
+  for (int i = 0; i <= P; ++i) {
+    NdChain& c = ns.c[i];
+    c.M = b->nd_buf + offM[i];
+    c.X = b->nd_buf + offX[i];
+    c.y = b->nd_buf + offy[i];
+    int* dinv = nullptr;
+    const std::vector<int>& hv = i < P ? inv[i] : invS;
+    SFM_TRY(ba_alloc(b, &dinv, hv.size()));
+    SFM_HIP_TRY(hipMemcpy(dinv, hv.data(), hv.size() * 4, hipMemcpyHostToDevice));
+    c.inv = dinv;
+    if (i < P) b->nd_cols.col0[i + 1] = b->nd_cols.col0[i] + c.ni * 32;
+    for (int tr = 0; tr < c.N; ++tr) {
+      for (int tc = 0; tc <= std::min(tr, c.ni - 1); ++tc) gj.push_back(make_int4(i, tr, tc, 0));
+      gj.push_back(make_int4(i, tr, 0, 1));
+    }
+  }
+  SFM_TRY(ba_alloc(b, &b->nd_gather_jobs, gj.size()));
+  SFM_HIP_TRY(hipMemcpy(b->nd_gather_jobs, gj.data(), gj.size() * sizeof(int4), hipMemcpyHostToDevice));
+  b->nd_n_gather = (int)gj.size();
+  b->nd_on = true;
+  if (getenv("SFMHIP_BA_ND_VERBOSE")) {
+    fprintf(stderr, "[sfmhip] reduced system dissected: %d chains (", P);
+    for (int i = 0; i < P; ++i) fprintf(stderr, "%s%d", i ? "," : "", ns.c[i].ni);
+    fprintf(stderr, " tiles) + separator %d tiles (%zu cameras); dense %d tiles\n", NS, best.sep.size(), dense_tiles);
+  }
+  return SFMHIP_OK;
+}
+
+// trailing tiles per workgroup of a chol_step2 launch: the fewest that keep the launch to one round of workgroups
+static void chol_launch_shape(int nt, int k2, int budget, int* npan, int* ntrail) {
+  const int m2 = nt - 2 * k2 - 2;
+  *ntrail = k2 == 0 ? 0 : m2 * (m2 + 1) / 2 + m2 + 2 * k2 * m2;
+  *npan = m2 + 2 + 2 * k2 + 2;
+  (void)budget;
+}
+
+// diagnostic (SFMHIP_BA_ND_DEBUG): NaN / magnitude census of every chain's buffers after a stage
+static void nd_census(sfmhip_ba* b, const char* stage) {
+  hipStreamSynchronize(b->ctx->stream);
+  for (int i = 0; i <= b->nd.n; ++i) {
+    const NdChain& c = b->nd.c[i];
+    const size_t n = (size_t)c.ld;
+    std::vector<double> M(n * n), X(n * n), y(n);
+    hipMemcpy(M.data(), c.M, n * n * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(X.data(), c.X, n * n * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(y.data(), c.y, n * 8, hipMemcpyDeviceToHost);
+    size_t nanL = 0, nanW = 0, nanX = 0, nany = 0;
+    double maxL = 0, maxW = 0;
+    const size_t o = (size_t)c.ni * 32;
+    long first_nan_col = -1, first_nan_row = -1;
+    for (size_t col = 0; col < n; ++col)
+      for (size_t r = col; r < n; ++r) {
+        const double v = M[col * n + r];
+        const bool w = col >= o && i < b->nd.n;
+        if (v != v) {
+          (w ? nanW : nanL)++;
+          if (first_nan_col < 0) first_nan_col = (long)col, first_nan_row = (long)r;
+        } else (w ? maxW : maxL) = std::max(w ? maxW : maxL, std::fabs(v));
+      }
+    for (double v : X) nanX += v != v;
+    for (double v : y) nany += v != v;
+    fprintf(stderr, "[nd %s] chain %d (ni %d N %d): NaN L %zu W %zu X %zu y %zu  first (r %ld, c %ld)  max|L| %.3e max|W| %.3e\n", stage, i,
+            c.ni, c.N, nanL, nanW, nanX, nany, first_nan_row, first_nan_col, maxL, maxW);
+  }
+}
+
+static int ba_reduced_solve_nd(sfmhip_ba* b) {
+  const bool dbg = getenv("SFMHIP_BA_ND_DEBUG") != nullptr;
+  hipStream_t st = b->ctx->stream;
+  BaDev& d = b->d;
+  const NdSet& ns = b->nd;
+  const int P = ns.n;
+  const NdChain& sp = ns.c[P];
+  if (!b->chol_chains_attr_set) {
+    SFM_HIP_TRY(hipFuncSetAttribute((const void*)chol_step2_chains, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS_BYTES));
+    SFM_HIP_TRY(hipFuncSetAttribute((const void*)chol_step2, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS_BYTES));
+    b->chol_chains_attr_set = true;
+  }
+  SFM_HIP_TRY(hipMemsetAsync(b->nd_buf, 0, sizeof(double) * b->nd_buf_count, st));
+  hipLaunchKernelGGL(nd_gather, dim3(b->nd_n_gather), dim3(256), 0, st, ns, b->nd_gather_jobs, d.red, d.red + b->ssz, d.ld);
+  int nl = 2;
+  if (dbg) nd_census(b, "gather");
+  for (int k2 = 0; 2 * k2 < b->nd_max_ni; ++k2, ++nl) {
+    ChainSet cs{};
+    int tpw = 4, total = 0;
+    for (;; ++tpw) {
+      cs.n = 0;
+      int pan = 0, trl = 0;
+      for (int i = 0; i < P; ++i) {
+        if (2 * k2 >= ns.c[i].ni) continue;
+        int npan, ntrail;
+        chol_launch_shape(ns.c[i].N, k2, 0, &npan, &ntrail);
+        const int j = cs.n++;
+        cs.A[j] = ns.c[i].M;
+        cs.y[j] = ns.c[i].y;
+        cs.X[j] = ns.c[i].X;
+        cs.ld[j] = ns.c[i].ld;
+        cs.nt[j] = ns.c[i].N;
+        cs.tpw[j] = tpw;
+        cs.pan0[j] = pan;
+        cs.trl0[j] = trl;
+        pan += npan;
+        trl += (ntrail + tpw - 1) / tpw;
+      }
+      cs.pan0[cs.n] = pan;
+      cs.trl0[cs.n] = trl;
+      total = pan + trl;
+      if (total <= b->ctx->n_cu || tpw >= C2_WAVES) break;
+    }
+    hipLaunchKernelGGL(chol_step2_chains, dim3(total), dim3(C2_WAVES * 64), C2_LDS_BYTES, st, cs, k2, d.info);
+    if (dbg) {
+      char nm[32];
+      snprintf(nm, sizeof nm, "chains k2=%d wg=%d tpw=%d", k2, total, tpw);
+      nd_census(b, nm);
+    }
+  }
+  hipLaunchKernelGGL(nd_combine, dim3(sp.N * (sp.N + 1) / 2 + sp.N), dim3(256), 0, st, ns);
+  ++nl;
+  for (int k2 = 0; 2 * k2 < sp.N; ++k2, ++nl) {
+    int npan, ntrail, tpw = 4;
+    chol_launch_shape(sp.N, k2, 0, &npan, &ntrail);
+    while (tpw < C2_WAVES && npan + (ntrail + tpw - 1) / tpw > b->ctx->n_cu) ++tpw;
+    hipLaunchKernelGGL(chol_step2, dim3(npan + (ntrail + tpw - 1) / tpw), dim3(C2_WAVES * 64), C2_LDS_BYTES, st, sp.M, sp.y,
+                       sp.X, sp.ld, sp.N, k2, tpw, d.info);
+  }
+  // z_S = L_SS^-T y_S;  w_i = y_i - L_Si^T z_S;  z_i = L_ii^-T w_i
+  hipLaunchKernelGGL(nd_xy, dim3(sp.N, 1), dim3(1024), 0, st, ns, P, d.z);
+  hipLaunchKernelGGL(nd_w, dim3((b->nd_cols.col0[P] + 3) / 4), dim3(256), 0, st, ns, b->nd_cols);
+  hipLaunchKernelGGL(nd_xy, dim3(b->nd_max_ni, P), dim3(1024), 0, st, ns, 0, d.z);
+  SFM_HIP_TRY(hipGetLastError());
+  b->launches += nl + 3;
+  return SFMHIP_OK;
+}
+
 static int ba_reduced_solve(sfmhip_ba* b) {
+  if (b->nd_on) return ba_reduced_solve_nd(b);
   hipStream_t st = b->ctx->stream;
   BaDev& d = b->d;
   double* A = d.red;
@@ -2533,6 +3159,9 @@ static int ba_reduced_solve(sfmhip_ba* b) {
       // launch 0 has no pending update; later launches: the tiles right of the panels, and those of X
       const int ntrail = k2 == 0 ? 0 : m2 * (m2 + 1) / 2 + m2 + 2 * k2 * m2;
       const int npan = m2 + 2 + 2 * k2 + 2;
+      // (every panel workgroup has to be resident when the launch starts: the owner overwrites the diagonal
+      // tiles the others read; one workgroup per CU)
+      if (npan > b->ctx->n_cu) return SFMHIP_ERR_UNSUPPORTED;
       int tpw = 4;  // trailing tiles per workgroup: the fewest that keep the launch to one round of workgroups
       while (tpw < C2_WAVES && npan + (ntrail + tpw - 1) / tpw > b->ctx->n_cu) ++tpw;
       hipLaunchKernelGGL(chol_step2, dim3(npan + (ntrail + tpw - 1) / tpw), dim3(C2_WAVES * 64), C2_LDS_BYTES, st, A, y,
@@ -2643,6 +3272,7 @@ static int ba_begin(sfmhip_ba* b, const sfmhip_ba_opts* o) {
   SFM_HIP_TRY(hipSetDevice(b->ctx->device));
   for (double& t : b->t_acc) t = 0;
   b->launches = 0;
+  if (!b->nd_ready) SFM_TRY(ba_nd_build(b));
   SFM_TRY(ba_prepare_scale(b, o->jacobi_scaling));
   LmState& s = b->lm;
   s = LmState();
@@ -2921,6 +3551,34 @@ extern "C" int sfmhip_ba_reduced_system(sfmhip_ba* b, double radius, double* S, 
     for (int i = 0; i < n; ++i)
       for (int j = i + 1; j < n; ++j) S[(size_t)j * n + i] = S[(size_t)i * n + j];
   if (cost) *cost = 0.5 * sc0;
+  return SFMHIP_OK;
+}
+
+extern "C" int sfmhip_ba_reduced_step(sfmhip_ba* b, double radius, double* z, int* chol_failed) {
+  if (!b || !z || !(radius > 0)) return SFMHIP_ERR_ARG;
+  if (b->world != 1) return SFMHIP_ERR_UNSUPPORTED;
+  SFM_HIP_TRY(hipSetDevice(b->ctx->device));
+  sfmhip_ba_opts o;
+  sfmhip_ba_default_opts(&o);
+  if (!b->nd_ready) SFM_TRY(ba_nd_build(b));
+  if (!b->scale_ready) SFM_TRY(ba_prepare_scale(b, o.jacobi_scaling));
+  SFM_TRY(ba_linearize_eliminate(b, radius, &o, true));
+  SFM_TRY(ba_reduced_solve(b));
+  hipStream_t st = b->ctx->stream;
+  int info = 0;
+  SFM_HIP_TRY(hipMemcpyAsync(z, b->d.z, sizeof(double) * b->dim, hipMemcpyDeviceToHost, st));
+  SFM_HIP_TRY(hipMemcpyAsync(&info, b->d.info, sizeof(int), hipMemcpyDeviceToHost, st));
+  SFM_HIP_TRY(hipStreamSynchronize(st));
+  if (chol_failed) *chol_failed = info;
+  return SFMHIP_OK;
+}
+
+extern "C" int sfmhip_ba_reduced_layout(sfmhip_ba* b, int32_t layout[4]) {
+  if (!b || !layout) return SFMHIP_ERR_ARG;
+  layout[0] = b->nd_on ? b->nd.n : 0;
+  layout[1] = b->nd_on ? b->nd_max_ni : 0;
+  layout[2] = b->nd_on ? b->nd.c[b->nd.n].N : 0;
+  layout[3] = b->nd_ready ? b->ld / CB : 0;
   return SFMHIP_OK;
 }
 

@@ -139,6 +139,77 @@ def test_cfg4_sized_reduced_system_matches_oracle_iterates(ctx, orc):
     assert abs(f - fo) <= BA_PARAM_RTOL * fo
 
 
+def test_dissected_reduced_system_walks_the_dense_iterates(ctx, orc, monkeypatch):
+    """The reduced camera system factored as independent chains + separator (ring capture: the camera graph has
+    small separators) against the dense factorisation of the same system, iterate by iterate, and both against
+    the oracle; the layout query says which one ran."""
+    pb = synth.ba_problem(96, 12000, 6, seed=5)
+    opts = dict(max_time_s=0.0, max_iterations=6)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SFMHIP_BA_ND", mode)      # read when the problem plans its first solve
+        prob = bundle.BaProblem(96, 12000, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
+        prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+        s = prob.run(bundle.default_opts(**opts))
+        out[mode] = (s, prob.get_params(), prob.reduced_layout())
+        prob.close()
+    (s0, (c0, p0, f0), l0), (s1, (c1, p1, f1), l1) = out["0"], out["1"]
+    assert l0["chains"] == 0 and l0["dense_tiles"] == 20
+    assert l1["chains"] >= 2 and l1["chain_tiles"] + l1["separator_tiles"] < l1["dense_tiles"]
+    assert (s0.termination, s0.iterations, s0.successful_steps) == (s1.termination, s1.iterations, s1.successful_steps)
+    assert abs(s0.final_cost - s1.final_cost) <= 1e-11 * s0.final_cost
+    assert np.allclose(c0, c1, rtol=1e-9, atol=1e-12) and np.allclose(p0, p1, rtol=1e-8, atol=1e-10) and abs(f0 - f1) <= 1e-10 * f0
+    co, po, fo, so = orc.ba_solve(*_ba_args(pb), opts=orc.default_opts(**opts))
+    assert (s1.termination, s1.iterations, s1.successful_steps) == (so.termination, so.iterations, so.successful_steps)
+    assert abs(s1.final_cost - so.final_cost) <= BA_COST_RTOL * so.final_cost
+    assert np.allclose(c1, co, rtol=BA_PARAM_RTOL, atol=1e-9) and np.allclose(p1, po, rtol=BA_PARAM_RTOL, atol=1e-9)
+
+
+@pytest.mark.parametrize("shape,nd", [((96, 6000, 6), "0"), ((96, 6000, 6), "1"), ((180, 8000, 8), "0"), ((560, 8000, 8), "1")])
+def test_reduced_step_solves_the_reduced_system(ctx, monkeypatch, shape, nd):
+    """(S + D/r) z = g, z from the solver's own factorisation (dense; dissected: chains + separator), against
+    numpy on the system the solver hands out.  560 cameras: six chains whose launches exceed one round of
+    workgroups (every panel workgroup must be resident before the owner overwrites the diagonal tiles)."""
+    monkeypatch.setenv("SFMHIP_BA_ND", nd)
+    nc, npt, k = shape
+    pb = synth.ba_problem(nc, npt, k, seed=5)
+    prob = bundle.BaProblem(nc, npt, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
+    prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+    z, failed = prob.reduced_step(1e4)
+    S, g, _ = prob.reduced_system(1e4)
+    lay = prob.reduced_layout()
+    assert failed == 0 and (lay["chains"] >= 2) == (nd == "1")
+    assert np.linalg.norm(S @ z - g) <= 1e-12 * np.linalg.norm(g)
+    zr = np.linalg.solve(S, g)
+    assert np.abs(z - zr).max() <= 1e-9 * np.abs(zr).max()
+    prob.close()
+
+
+def test_reduced_layout_follows_the_camera_graph(ctx, monkeypatch):
+    """cfg4's co-visibility (a ring, every point seen by 10 consecutive cameras) is dissected by default; cameras
+    that all see each other (random visibility) leave no separator and keep the dense factorisation; small
+    systems are not worth it."""
+    monkeypatch.delenv("SFMHIP_BA_ND", raising=False)
+    pb = synth.ba_problem(200, 20000, 10, seed=3)
+    ring = bundle.BaProblem(200, 20000, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
+    ring.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+    assert ring.reduced_layout()["dense_tiles"] == 0          # not planned yet
+    ring.iterate(1)
+    lay = ring.reduced_layout()
+    assert lay["chains"] == 4 and lay["dense_tiles"] == 38 and lay["chain_tiles"] + lay["separator_tiles"] <= 16
+    rng = np.random.default_rng(0)
+    oc = np.concatenate([np.sort(rng.choice(200, 10, replace=False)) for _ in range(20000)]).astype(np.int32)
+    rnd = bundle.BaProblem(200, 20000, oc, pb["obs_pt"], pb["obs_xy"], ctx=ctx)
+    rnd.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+    rnd.iterate(1)
+    assert rnd.reduced_layout()["chains"] == 0
+    small = synth.ba_problem(50, 5000, 10, seed=4)
+    sm = bundle.BaProblem(50, 5000, small["obs_cam"], small["obs_pt"], small["obs_xy"], ctx=ctx)
+    sm.set_params(small["cams0"], small["pts0"], small["focal0"])
+    sm.iterate(1)
+    assert sm.reduced_layout()["chains"] == 0
+
+
 def test_noise_free_scene_converges_to_zero_cost(ctx):
     pb = synth.ba_problem(8, 300, 5, seed=3, noise_px=0.0)
     c, p, f, s = bundle.ba_solve(*_ba_args(pb), ctx=ctx, opts=bundle.default_opts(
@@ -285,7 +356,7 @@ def test_degenerate_problems_do_not_crash(ctx, orc):
     assert abs(s.final_cost - so.final_cost) <= 1e-6 * max(so.final_cost, 1e-12) + 1e-12
 
 
-def _two_rank_worker(rank, world, port, out_dir):
+def _two_rank_worker(rank, world, port, out_dir, shape=(16, 6000, 6, 44)):
     import os
     import sys
     import torch
@@ -297,21 +368,23 @@ def _two_rank_worker(rank, world, port, out_dir):
     torch.cuda.set_device(0)
     from sfm_danpipeline_amd import _lib as L, bundle as B, sharding, synth as S
     ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
-    pb = S.ba_problem(16, 6000, 6, seed=44)
+    pb = S.ba_problem(shape[0], shape[1], shape[2], seed=shape[3])
     loc = sharding.local_ba_problem(pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], pb["pts0"], rank, world)
-    prob = B.BaProblem(16, len(loc["pts"]), loc["obs_cam"], loc["obs_pt"], loc["obs_xy"], ctx=ctx)
+    prob = B.BaProblem(shape[0], len(loc["pts"]), loc["obs_cam"], loc["obs_pt"], loc["obs_xy"], ctx=ctx)
     prob.set_allreduce(sharding.StagedAllReduce(device="cuda:0"), rank, world)
     prob.set_params(pb["cams0"], loc["pts"], pb["focal0"])
     s = prob.iterate(6)
     c, p, f = prob.get_params()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), c=c, p=p, f=f, lo=loc["lo"], hi=loc["hi"], cost=s.final_cost,
-             steps=s.successful_steps)
+             steps=s.successful_steps, chains=prob.reduced_layout()["chains"])
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_share_the_device_and_run_the_sharded_solver(ctx, tmp_path):
-    """The N>1 data path with the device kernels as the per-rank engine: two processes (gloo, the all-reduce
+@pytest.mark.parametrize("shape,nd", [((16, 6000, 6, 44), None), ((96, 9000, 5, 45), "1")])
+def test_two_ranks_share_the_device_and_run_the_sharded_solver(ctx, tmp_path, monkeypatch, shape, nd):
+    """(second case: the dissected reduced system, whose camera graph is the union over the ranks)
+    The N>1 data path with the device kernels as the per-rank engine: two processes (gloo, the all-reduce
     staged through the host because RCCL refuses two ranks on one device) each hold half the points; pack,
     exchange, unpack, redundant reduced solve and per-rank back-substitution must walk the iterates of one
     process holding everything, and the replicated cameras must agree between the ranks."""
@@ -321,10 +394,15 @@ def test_two_ranks_share_the_device_and_run_the_sharded_solver(ctx, tmp_path):
     s_.bind(("127.0.0.1", 0))
     port = s_.getsockname()[1]
     s_.close()
-    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    if nd is None:
+        monkeypatch.delenv("SFMHIP_BA_ND", raising=False)
+    else:
+        monkeypatch.setenv("SFMHIP_BA_ND", nd)
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), shape), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    pb = synth.ba_problem(16, 6000, 6, seed=44)
-    one = bundle.BaProblem(16, 6000, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
+    assert (int(r0["chains"]) >= 2) == (nd == "1") and int(r0["chains"]) == int(r1["chains"])
+    pb = synth.ba_problem(shape[0], shape[1], shape[2], seed=shape[3])
+    one = bundle.BaProblem(shape[0], shape[1], pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
     one.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
     s1 = one.iterate(6)
     c1, p1, f1 = one.get_params()
