@@ -199,6 +199,7 @@ def main():
     ba_t0 = ba.last_timing()
     ba.iterate(args.steps)
     ba_t = {k: v - ba_t0[k] for k, v in ba.last_timing().items()}
+    ba_layout = ba.reduced_layout()
     ctx.set_timing(False)
     barrier()
     t0 = time.perf_counter()
@@ -310,8 +311,9 @@ def main():
     ba_bytes = 3 * n_obs_l * 24 + 2 * n_pt_l * 24 + 2 * red_dim * red_dim * 8 + n_cam * 48   # section 8d
     ba_stream_s = (ba_t["eliminate_s"] + ba_t["backsub_s"]) / max(args.steps, 1)
     ba_gbs = ba_bytes / ba_stream_s / 1e9
-    tr_ba = [hbm_bytes(k) for k in ("ba_cam_blocks", "ba_eliminate_mfma", "ba_backsub")]
-    roofline_ba = {"kernels": "ba_cam_blocks + ba_eliminate_mfma + ba_backsub (per LM iteration, this rank's shard)",
+    tr_ba = [hbm_bytes(k) for k in ("ba_eliminate_mfma", "ba_backsub")]
+    roofline_ba = {"kernels": "ba_eliminate_mfma (one linearisation: F^T F + Schur correction) + ba_backsub (per LM iteration, "
+                              "this rank's shard)",
                    "bound": "hbm", "achieved": round(ba_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": round(ba_gbs / HBM_PEAK_GBS, 4),
                    "traffic": sum(tr_ba) if all(t is not None for t in tr_ba) else None,
@@ -320,8 +322,11 @@ def main():
                    "reduced_solve_ms": round(1e3 * ba_t["solve_s"] / args.steps, 4),
                    "backsub_cost_ms": round(1e3 * ba_t["backsub_s"] / args.steps, 4),
                    "launches_per_iter": round(ba_t["launches"] / max(args.steps, 1), 1),
-                   "note": "latency-bound: the 1216-column dependency chain of the reduced system's Cholesky (19 "
-                           "two-panel launches) dominates the iteration (DESIGN.md section 3)"}
+                   "reduced_layout": ba_layout,
+                   "note": "instruction-issue / latency-bound in the per-point linearisation; the reduced system is factored "
+                           "as independent chains of the dissected camera graph + separator (reduced_layout: tiles of 32 "
+                           "columns; the dependency chain is chain_tiles + separator_tiles instead of dense_tiles; "
+                           "DESIGN.md section 3)"}
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only)
     cpu_baseline = None

@@ -12,7 +12,7 @@ cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 rm -rf $O/kt
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
 P2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
-P3="FETCH_SIZE TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"
+P3="FETCH_SIZE"  # (alone: with the TCC hit/miss counters the request "exceeds the capabilities of the hardware to collect")
 P4="WRITE_SIZE SQ_WAVES SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"
 i=0
 FILES=""
