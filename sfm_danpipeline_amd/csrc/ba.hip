@@ -47,7 +47,7 @@ namespace {
 
 constexpr int CAMD = 40;     // doubles per camera table: R[9] t[3] dR/dw[27] pad
 constexpr int SC = 16;       // scalar slots at the tail of the all-reduce buffer (+ world)
-constexpr int FB_MAXN = 64;  // fallback kernel: max observations per point
+constexpr int FB_MAXN = 256;  // generic kernel: max observations per point (its T rows live in LDS: 37 KB)
 
 struct Chunk {
   int sig_off;  // offset into sig_cams
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(256) void ba_cam_blocks(BaDev d, const int* __restr
   }
 }
 
-// Generic path of the Schur correction: one wave per point; any observation count up to FB_MAXN,
+// Generic path of the Schur correction: one wave per point (observations in blocks of 64); any observation count up to FB_MAXN,
 // cameras in any order, repeated cameras allowed.  Per-point atomics (no accumulation across
 // points).  The F^T F part of these points comes from ba_cam_blocks like everyone else's.
 __global__ __launch_bounds__(64) void ba_eliminate_generic(BaDev d, const int* __restrict__ plist, double radius,
@@ -799,30 +799,30 @@ __global__ __launch_bounds__(64) void ba_eliminate_generic(BaDev d, const int* _
   const int lane = threadIdx.x;
   const int k0 = d.optr[p], n = d.optr[p + 1] - k0;
   const int dim = d.ld /* row stride of S */, fo = 6 * d.nc;
-  const bool is_obs = lane < n;
-  const int k = k0 + (is_obs ? lane : 0);
-  const int mycam = d.ocam[k];
-  if (is_obs) s_cam[lane] = mycam;
   const double X[3] = {d.pts[3 * p], d.pts[3 * p + 1], d.pts[3 * p + 2]};
   const double sp[3] = {d.scale_p[3 * p], d.scale_p[3 * p + 1], d.scale_p[3 * p + 2]};
   const double sf = *d.scale_f, focal = *d.focal;
-  ObsLin o;
-  {
-    const double2 xy = d.oxy[k];
-    obs_linearize(d.camd + (size_t)CAMD * mycam, X, focal, xy.x, xy.y, d.scale_c + 6 * mycam, sp, sf, o);
-  }
-  const double live = is_obs ? 1.0 : 0.0;
+  // pass 1: the point block and its right-hand sides, observations in blocks of 64 (lane = observation)
   double red[12];
-  red[0] = live * (o.Jp[0] * o.Jp[0] + o.Jp[3] * o.Jp[3]);
-  red[1] = live * (o.Jp[1] * o.Jp[0] + o.Jp[4] * o.Jp[3]);
-  red[2] = live * (o.Jp[1] * o.Jp[1] + o.Jp[4] * o.Jp[4]);
-  red[3] = live * (o.Jp[2] * o.Jp[0] + o.Jp[5] * o.Jp[3]);
-  red[4] = live * (o.Jp[2] * o.Jp[1] + o.Jp[5] * o.Jp[4]);
-  red[5] = live * (o.Jp[2] * o.Jp[2] + o.Jp[5] * o.Jp[5]);
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    red[6 + a] = live * (o.Jp[a] * o.r0 + o.Jp[3 + a] * o.r1);
-    red[9 + a] = live * (o.Jp[a] * o.Jf[0] + o.Jp[3 + a] * o.Jf[1]);
+  for (int e = 0; e < 12; ++e) red[e] = 0.0;
+  for (int ob = lane; ob < n; ob += 64) {
+    const int cam = d.ocam[k0 + ob];
+    s_cam[ob] = cam;
+    const double2 xy = d.oxy[k0 + ob];
+    ObsLin o;
+    obs_linearize(d.camd + (size_t)CAMD * cam, X, focal, xy.x, xy.y, d.scale_c + 6 * cam, sp, sf, o);
+    red[0] += o.Jp[0] * o.Jp[0] + o.Jp[3] * o.Jp[3];
+    red[1] += o.Jp[1] * o.Jp[0] + o.Jp[4] * o.Jp[3];
+    red[2] += o.Jp[1] * o.Jp[1] + o.Jp[4] * o.Jp[4];
+    red[3] += o.Jp[2] * o.Jp[0] + o.Jp[5] * o.Jp[3];
+    red[4] += o.Jp[2] * o.Jp[1] + o.Jp[5] * o.Jp[4];
+    red[5] += o.Jp[2] * o.Jp[2] + o.Jp[5] * o.Jp[5];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      red[6 + a] += o.Jp[a] * o.r0 + o.Jp[3 + a] * o.r1;
+      red[9 + a] += o.Jp[a] * o.Jf[0] + o.Jp[3 + a] * o.Jf[1];
+    }
   }
 #pragma unroll
   for (int e = 0; e < 12; ++e) {
@@ -839,15 +839,20 @@ __global__ __launch_bounds__(64) void ba_eliminate_generic(BaDev d, const int* _
   double* S = red_S(d);
   double* g = red_g(d);
   double* scv = red_sc(d);
-  if (is_obs) {
+  // pass 2: T_o = (Jc_o^T Jp_o) C^-1/2 of every observation (linearised again: cheaper than keeping 18 doubles each)
+  for (int ob = lane; ob < n; ob += 64) {
+    const int cam = s_cam[ob];
+    const double2 xy = d.oxy[k0 + ob];
+    ObsLin o;
+    obs_linearize(d.camd + (size_t)CAMD * cam, X, focal, xy.x, xy.y, d.scale_c + 6 * cam, sp, sf, o);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const double w0 = o.Jc[i] * o.Jp[0] + o.Jc[6 + i] * o.Jp[3];
       const double w1 = o.Jc[i] * o.Jp[1] + o.Jc[6 + i] * o.Jp[4];
       const double w2 = o.Jc[i] * o.Jp[2] + o.Jc[6 + i] * o.Jp[5];
-      s_T[lane * 18 + 3 * i + 0] = w0 * Li[0];
-      s_T[lane * 18 + 3 * i + 1] = w0 * Li[1] + w1 * Li[2];
-      s_T[lane * 18 + 3 * i + 2] = w0 * Li[3] + w1 * Li[4] + w2 * Li[5];
+      s_T[ob * 18 + 3 * i + 0] = w0 * Li[0];
+      s_T[ob * 18 + 3 * i + 1] = w0 * Li[1] + w1 * Li[2];
+      s_T[ob * 18 + 3 * i + 2] = w0 * Li[3] + w1 * Li[4] + w2 * Li[5];
     }
   }
   double tf[3], u[3];
@@ -865,11 +870,11 @@ __global__ __launch_bounds__(64) void ba_eliminate_generic(BaDev d, const int* _
     atomic_max_pos_f64(scv + SC + rank, gm);
   }
   __syncthreads();
-  if (is_obs) {  // border: S[cam][focal] -= T t_f ; g[cam] -= T u
-    const int r0 = 6 * mycam;
+  for (int ob = lane; ob < n; ob += 64) {  // border: S[cam][focal] -= T t_f ; g[cam] -= T u
+    const int r0 = 6 * s_cam[ob];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const double* T = s_T + lane * 18 + 3 * i;
+      const double* T = s_T + ob * 18 + 3 * i;
       atomic_add_f64(S + (size_t)(r0 + i) * dim + fo, -(T[0] * tf[0] + T[1] * tf[1] + T[2] * tf[2]));
       atomic_add_f64(g + r0 + i, -(T[0] * u[0] + T[1] * u[1] + T[2] * u[2]));
     }
