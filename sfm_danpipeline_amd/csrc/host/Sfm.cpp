@@ -130,6 +130,50 @@ void StructFromMotion::adjustCurrentBundle() {
   BundleAdjustment::adjustBundle(nReconstructionCloud, nCameraPoses, cameraMatrix, imagesPts2D);
 }
 
+// reference src/Sfm.cpp:499-585
+std::map<float, std::pair<int, int>> StructFromMotion::findBestPair() {
+  std::cout << "Getting best two views for baseline..." << std::endl;
+  std::map<float, std::pair<int, int>> numInliers;
+  const int numImg = (int)imagesDescriptors.size();
+  if (!pairCacheOn) matchAllPairs();
+  std::vector<std::pair<int, int>> ids;
+  std::vector<size_t> nmatch;
+  std::vector<int32_t> offsets(1, 0);
+  std::vector<double> left, right;
+  for (int queryImage = 0; queryImage < numImg - 1; queryImage++)
+    for (int trainImage = queryImage + 1; trainImage < numImg; trainImage++) {
+      Matching correspondences;
+      getMatching(queryImage, trainImage, &correspondences);
+      if (correspondences.size() < 120) continue;  // :533
+      Points2d alignedLeft, alignedRight;
+      AlignedPointsFromMatch(imagesPts2D.at(queryImage), imagesPts2D.at(trainImage), correspondences, alignedLeft, alignedRight);
+      for (size_t i = 0; i < alignedLeft.size(); ++i) {
+        left.push_back(alignedLeft[i].x);
+        left.push_back(alignedLeft[i].y);
+        right.push_back(alignedRight[i].x);
+        right.push_back(alignedRight[i].y);
+      }
+      offsets.push_back((int32_t)(left.size() / 2));
+      ids.push_back(std::make_pair(queryImage, trainImage));
+      nmatch.push_back(correspondences.size());
+    }
+  std::vector<int32_t> inliers(ids.size() + 1, 0);
+  const cv::Mat_<double>& Km = cameraMatrix.K;
+  const int rc = sfmhip_score_essential(sfm_hip_context(), (int)ids.size(), offsets.data(), left.data(), right.data(), Km(0, 0),
+                                        Km(1, 1), Km(0, 2), Km(1, 2), 0.999, 1.0, inliers.data(), nullptr, nullptr);  // :542-543
+  if (rc != SFMHIP_OK) {
+    std::cerr << "findBestPair: " << sfmhip_error_string(rc) << std::endl;
+    return numInliers;
+  }
+  for (size_t p = 0; p < ids.size(); ++p) {
+    const float poseInliersRatio = (float)inliers[p] / (float)nmatch[p];  // :563
+    std::cout << "pair:" << "[" << ids[p].first << "," << ids[p].second << "]" << " has:" << nmatch[p] << " matches and "
+              << poseInliersRatio << " pose inliers ratio." << std::endl;
+    numInliers[poseInliersRatio] = ids[p];  // :569
+  }
+  return numInliers;
+}
+
 void StructFromMotion::matchAllPairs() {
   const int n = (int)imagesDescriptors.size();
   pairCache.clear();

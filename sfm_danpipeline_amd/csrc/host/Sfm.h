@@ -64,6 +64,12 @@ class StructFromMotion {
   // The all-pairs loop of findBestPair (src/Sfm.cpp:511-515) as ONE batched device launch; fills
   // the pair cache that getMatching then serves from (identical results, pair order q<t).
   void matchAllPairs();
+  // reference include/Sfm.h:83, src/Sfm.cpp:499-585: the all-pairs matching (matchAllPairs: one batched launch),
+  // then for every pair with >= 120 matches the pose-inlier ratio of cv::findEssentialMat(RANSAC, 0.999, 1.0)
+  // (sfmhip_score_essential, all pairs in one call), collected in the map keyed by that float: ascending, equal keys
+  // overwrite.  Not mirrored: the drawMatches / imshow / waitKey(100) per pair and the homography inlier count,
+  // which the reference only prints (:545,567).
+  std::map<float, std::pair<int, int>> findBestPair();
   // reference src/Sfm.cpp:883-888 is a stub whose call names a member that no longer exists;
   // wired here with imagesPts2D, the member of the required type
   void adjustCurrentBundle();

@@ -11,6 +11,7 @@
 //              n x (f64 xyz[3], f64 xy[2])
 //        mergeNewPoints(cloud shifted by (0,0,0.004) ++ cloud shifted by (5,0,0) ++ the same again):
 //              i32 cloud size before, i32 after, then (after-before) x f64 xyz[3] of the appended points
+//        findBestPair() (SURVEY 8f-1 scoring half): i32 n, n x (f32 poseInliersRatio, i32 q, i32 t) in map order
 //        after adjustCurrentBundle: f64 K[9], n_cam x f64 pose[12], n_pt x f64 xyz[3]
 #include <cstdio>
 #include <cstdlib>
@@ -129,6 +130,17 @@ int main(int argc, char** argv) {
     fwrite(&before, 4, 1, o);
     fwrite(&after, 4, 1, o);
     for (int i = before; i < after; ++i) fwrite(&sfm.nReconstructionCloud[i].pt.x, 8, 3, o);
+  }
+  // ---- findBestPair: the pair cache, then the E-matrix RANSAC score of every pair with >= 120 matches
+  {
+    const std::map<float, std::pair<int, int>> best_pairs = sfm.findBestPair();
+    n = (int)best_pairs.size();
+    fwrite(&n, 4, 1, o);
+    for (const auto& kv : best_pairs) {
+      fwrite(&kv.first, 4, 1, o);
+      fwrite(&kv.second.first, 4, 1, o);
+      fwrite(&kv.second.second, 4, 1, o);
+    }
   }
   // ---- adjustCurrentBundle on the BA block
   const int n_cam = rd<int>(f);

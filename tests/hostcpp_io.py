@@ -52,7 +52,7 @@ def write_input(tmp_path):
     return dict(d0=d0, d1=d1, perm=perm, xy0=xy0, xy1=xy1, sc=sc, cloud=cloud, poses=poses, K=K, feats=feats)
 
 
-def check_output(tmp_path, orc, w):
+def check_output(tmp_path, orc, w, scored_by_stub=False):
     d0, d1, perm, xy0, xy1, sc = w["d0"], w["d1"], w["perm"], w["xy0"], w["xy1"], w["sc"]
     cloud, poses, K, feats = w["cloud"], w["poses"], w["K"], w["feats"]
     raw = open(tmp_path / "out.bin", "rb").read()
@@ -88,6 +88,16 @@ def check_output(tmp_path, orc, w):
     acc, nacc = orc.merge_new_points(c["X"], fresh)
     assert before == n2 and after - before == nacc and np.array_equal(added, fresh[acc])
     assert not acc[:n2].any() and not acc[2 * n2:].any()         # too close / duplicates of appended points
+    # findBestPair: one pair (two images), >= 120 matches, keyed by the pose-inlier ratio of the E-matrix RANSAC
+    nbp = struct.unpack_from("<i", raw, pos)[0]; pos += 4
+    bp = np.frombuffer(raw, dtype=np.dtype([("ratio", "<f4"), ("q", "<i4"), ("t", "<i4")]), count=nbp, offset=pos); pos += 12 * nbp
+    assert nbp == 1 and (int(bp["q"][0]), int(bp["t"][0])) == (0, 1)
+    if scored_by_stub:
+        assert bp["ratio"][0] == np.float32(1.0)              # (the C-ABI stand-in of the sanitizer run counts every match)
+    else:
+        from oracle import sfm_oracle_score as score
+        cnt = score.find_essential_mat_ransac(xy0[rq], xy1[rt], sc["K"])[0]
+        assert bp["ratio"][0] == np.float32(np.float32(cnt) / np.float32(n)) and cnt > 0.8 * n
     Kout = np.frombuffer(raw, "<f8", 9, pos).reshape(3, 3); pos += 72
     poses_out = np.frombuffer(raw, "<f8", 12 * len(poses), pos).reshape(-1, 3, 4); pos += 96 * len(poses)
     pts_out = np.frombuffer(raw, "<f8", 3 * len(cloud), pos).reshape(-1, 3)

@@ -145,6 +145,21 @@ int sfmhip_triangulate(sfmhip_ctx* ctx, const double P1[12], const double P2[12]
   if (!err) free(e);
   return rc ? SFMHIP_ERR_ARG : SFMHIP_OK;
 }
+/* the scoring half of findBestPair: the stand-in counts every match as an inlier (the RANSAC itself is device code and
+ * its checker is numpy; what the sanitizer run exercises is the host mirror's container handling around the call) */
+int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_t* offsets, const double* left_xy, const double* right_xy,
+                           double fx, double fy, double cx, double cy, double prob, double threshold, int32_t* inliers,
+                           uint8_t* mask, int32_t* iterations) {
+  (void)ctx; (void)left_xy; (void)right_xy; (void)fx; (void)fy; (void)cx; (void)cy; (void)prob; (void)threshold;
+  for (int p = 0; p < n_pairs; ++p) {
+    inliers[p] = offsets[p + 1] - offsets[p];
+    if (iterations) iterations[p] = 1;
+    if (mask)
+      for (int i = offsets[p]; i < offsets[p + 1]; ++i) mask[i] = 1;
+  }
+  return SFMHIP_OK;
+}
+
 int sfmhip_find_2d3d(sfmhip_ctx* ctx, const int32_t* trk_ptr, const int32_t* trk_view, const int32_t* trk_feat, int n_cloud,
                      int done_view, int new_view, const int32_t* match_q, const int32_t* match_t, int n_match, int32_t* out_cloud,
                      int32_t* out_feat, int32_t* n_out) {
