@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=96, help="pairs of cfg2 timed on the host cores")
     ap.add_argument("--cpu-ba-iters", type=int, default=8)
     ap.add_argument("--no-cfg5", action="store_true", help="skip the cfg5 strong-scaling leg")
+    ap.add_argument("--no-score", action="store_true", help="skip the findBestPair scoring leg (E-matrix RANSAC of 1225 pairs)")
     ap.add_argument("--lean", action="store_true",
                     help="timed regions and per-kernel samples only (no sustained / host-visible loops, no cfg5, no CPU "
                          "baseline): the command to run under rocprofv3, whose traces grow with every dispatch")
@@ -63,7 +64,7 @@ def main():
                          "with the single-launch figure the roofline uses, hence not the default)")
     args = ap.parse_args()
     if args.lean:
-        args.no_cfg5 = args.no_cpu_baseline = True
+        args.no_cfg5 = args.no_cpu_baseline = args.no_score = True
 
     import torch
     import torch.distributed as dist
@@ -256,6 +257,33 @@ def main():
         o_set.close()
         del o_dev
 
+    # ------------------------------------------------------------------ findBestPair's scoring half (rank 0)
+    score_leg = None
+    if rank == 0 and not args.no_score:
+        from sfm_danpipeline_amd import scoring
+        from oracle import sfm_oracle_score as _score_ck     # the checker (numpy), timed on a sample as the CPU figure
+        Kc = np.array([[1520.0, 0, 302.2], [0, 1520.0, 246.87], [0, 0, 1]])
+        srng = np.random.default_rng(4321)
+        sp = []
+        for p_ in range(len(pairs)):                          # one two-view scene per pair of the cfg2 sweep
+            sc_ = synth.two_view_scene(m=int(srng.integers(150, 900)), seed=5000 + p_, K=Kc, noise_px=0.4,
+                                       outlier_frac=float(srng.uniform(0.1, 0.5)))
+            sp.append((sc_["xy1"], sc_["xy2"]))
+        scoring.score_essential(sp[:8], Kc, ctx=ctx)          # warm-up
+        t0 = time.perf_counter()
+        s_inl, _, s_its = scoring.score_essential(sp, Kc, ctx=ctx)
+        t_score = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ck = [_score_ck.find_essential_mat_ransac(a_, b_, Kc) for a_, b_ in sp[:12]]
+        t_ck = (time.perf_counter() - t0) / 12
+        assert all((int(s_inl[i]), int(s_its[i])) == (ck[i][0], ck[i][3]) for i in range(12)), "scoring differs from its restatement"
+        score_leg = {"workload": "E-matrix RANSAC score (cv::findEssentialMat(RANSAC, 0.999, 1.0) inlier count) of 1225 pairs, "
+                                 "150-900 matches each, 10-50 % wrong matches; host buffers in, counts out (whole call)",
+                     "pairs": len(sp), "matches": int(sum(len(a_) for a_, _ in sp)), "seconds": round(t_score, 5),
+                     "pairs_per_s": round(len(sp) / t_score, 1), "ransac_iterations_mean": round(float(s_its.mean()), 1),
+                     "cpu_restatement_pairs_per_s": round(1.0 / t_ck, 2), "cpu_sample": "12 pairs, numpy, 1 thread; counts and "
+                     "iteration numbers of the sample equal the device's", "parity": "unpinned (no OpenCV in the image)"}
+
     # max over ranks
     if world > 1:
         tt = torch.tensor([t_match, t_ba], device=dev, dtype=torch.float64)
@@ -402,7 +430,7 @@ def main():
             "value_host_visible": {"pairs_per_s": round(host_visible_pairs_s, 1),
                                    "note": "every sweep followed by sfmhip_matchplan_fetch: counts + one packed "
                                            "{queryIdx, trainIdx, distance} array to host memory"},
-            "cfg5_strong": cfg5,
+            "cfg5_strong": cfg5, "find_best_pair_scoring": score_leg,
             "ba_amdahl": {"sharded_ms": round(1e3 * (ba_t["eliminate_s"] + ba_t["backsub_s"]) / args.steps, 4),
                           "replicated_ms": round(1e3 * ba_t["solve_s"] / args.steps, 4),
                           "allreduce_ms": round(1e3 * ba_t["allreduce_s"] / args.steps, 4),
