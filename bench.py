@@ -137,9 +137,18 @@ def main():
         plans[j].run_async(0.8)
 
     # ------------------------------------------------------------------ warmup
+    # BA first, the matching sweeps last: the timed matching region then starts from the load it measures.  (With
+    # the LM iterations between the warm-up sweeps and the timed sweeps, the first sweeps after the switch from the
+    # latency-bound BA kernels to the MFMA-bound sweep ran slow: a 20-step region measured 0.73 ms per sweep where
+    # a 100-step one measured 0.686, scripts/gpu_sync_test.py: 0.667 either way without the switch.)
+    ba.iterate(max(args.warmup, 1))
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.1:      # (and the device out of its idle power state)
+        for _ in range(10):
+            match_step()
+        torch.cuda.synchronize(dev)
     for _ in range(max(args.warmup, 1)):
         match_step()
-    ba.iterate(max(args.warmup, 1))
     barrier()
 
     # ------------------------------------------------------------------ timed: matching, K steps
@@ -189,6 +198,8 @@ def main():
     host_visible_pairs_s = n_hv * len(pairs) / t_hv
 
     # ------------------------------------------------------------------ timed: BA, K iterations
+    # (the same switch in the other direction: W iterations of BA right before the timed ones)
+    ba.iterate(max(args.warmup, 1) + 20)
     barrier()
     t0 = time.perf_counter()
     ba_sum = ba.iterate(args.steps)
