@@ -1829,8 +1829,13 @@ __global__ __launch_bounds__(256) void nd_gather(NdSet ns, const int4* __restric
       const int idx = tr * 32 + threadIdx.x;
       const int l = ch.inv[idx];
       ch.y[idx] = (tr < ch.ni && l >= 0) ? g[l] : 0.0;
-      ch.X[(size_t)idx * ch.ld + idx] = 1.0;
     }
+    return;
+  }
+  if (job.w >= 2) {  // 2: a zero tile of M (the chain's part of the Schur complement starts at 0); 3: a tile of X = I
+    double* dst = (job.w == 2 ? ch.M : ch.X) + (size_t)(tc * 32) * ch.ld + tr * 32;
+    const int r_ = threadIdx.x & 31;
+    for (int j = threadIdx.x >> 5; j < 32; j += 8) dst[(size_t)j * ch.ld + r_] = (job.w == 3 && tr == tc && j == r_) ? 1.0 : 0.0;
     return;
   }
   __shared__ double sh[32][33];
@@ -2192,7 +2197,7 @@ struct sfmhip_ba {
   NdSet nd{};
   NdCols nd_cols{};
   int nd_max_ni = 0;
-  double* nd_buf = nullptr;  // all chain matrices, vectors and X blocks: zeroed at every solve
+  double* nd_buf = nullptr;  // all chain matrices, vectors and X blocks (nd_gather writes what the factorisation reads)
   size_t nd_buf_count = 0;
   int4* nd_gather_jobs = nullptr;
   int nd_n_gather = 0;
@@ -3024,6 +3029,11 @@ static int ba_nd_build(sfmhip_ba* b) {
     for (int tr = 0; tr < c.N; ++tr) {
       for (int tc = 0; tc <= std::min(tr, c.ni - 1); ++tc) gj.push_back(make_int4(i, tr, tc, 0));
       gj.push_back(make_int4(i, tr, 0, 1));
+      // what the factorisation reads before it writes: the lower right block of M (zero), the interior rows of X
+      // (the identity; its tiles left of the diagonal are read too) -- no memset of the chain buffers
+      for (int tc = c.ni; tc <= tr; ++tc) gj.push_back(make_int4(i, tr, tc, 2));
+      if (tr < c.ni)
+        for (int tc = 0; tc < c.N; ++tc) gj.push_back(make_int4(i, tr, tc, 3));
     }
   }
   SFM_TRY(ba_alloc(b, &b->nd_gather_jobs, gj.size()));
@@ -3088,9 +3098,8 @@ static int ba_reduced_solve_nd(sfmhip_ba* b) {
     SFM_HIP_TRY(hipFuncSetAttribute((const void*)chol_step2, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS_BYTES));
     b->chol_chains_attr_set = true;
   }
-  SFM_HIP_TRY(hipMemsetAsync(b->nd_buf, 0, sizeof(double) * b->nd_buf_count, st));
   hipLaunchKernelGGL(nd_gather, dim3(b->nd_n_gather), dim3(256), 0, st, ns, b->nd_gather_jobs, d.red, d.red + b->ssz, d.ld);
-  int nl = 2;
+  int nl = 1;
   if (dbg) nd_census(b, "gather");
   for (int k2 = 0; 2 * k2 < b->nd_max_ni; ++k2, ++nl) {
     ChainSet cs{};
