@@ -158,6 +158,18 @@ int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_t* offsets,
                            const double* right_xy, double fx, double fy, double cx, double cy, double prob,
                            double threshold, int32_t* inliers, uint8_t* mask, int32_t* iterations);
 
+/* The homography side of the same loop: findHomographyInliers (reference src/Sfm.cpp:667-689) =
+ *   cv::countNonZero(mask) of cv::findHomography(query_points, train_points, CV_RANSAC, 0.004 * maxVal, mask)
+ * as OpenCV 3.4.1 (calib3d/fundam.cpp) runs it: points converted to float, 4-point samples (drawn again when
+ * checkSubset rejects them: a collinear triple, or the orientation of a triple not preserved), normalised DLT
+ * (smallest eigenvector of L^T L, H[2][2] = 1), the reprojection error and the threshold test in float arithmetic,
+ * confidence / max_iters as given (findHomography's defaults: 0.995, 2000); the mask is the RANSAC mask.
+ * thresholds: one per pair (the reference: 0.004 * the largest coordinate among the pair's query points; <= 0: 3).
+ * Pairs with fewer than 4 matches score 0.  Parity unpinned, like sfmhip_score_essential. */
+int sfmhip_score_homography(sfmhip_ctx* ctx, int n_pairs, const int32_t* offsets, const double* left_xy,
+                            const double* right_xy, const double* thresholds, double confidence, int max_iters,
+                            int32_t* inliers, uint8_t* mask, int32_t* iterations);
+
 /* ---- adjustBundle solver core (reference src/BundleAdjustment.cpp:46-175) ---- */
 typedef struct {
   int max_iterations;           /* 500   src/BundleAdjustment.cpp:118 */

@@ -130,6 +130,36 @@ void StructFromMotion::adjustCurrentBundle() {
   BundleAdjustment::adjustBundle(nReconstructionCloud, nCameraPoses, cameraMatrix, imagesPts2D);
 }
 
+// cv::minMaxIdx over a vector<Point2d>: the largest of all x and y (the array is taken as single-channel)
+static double max_coordinate(const Points2d& pts) {
+  double m = -1.7976931348623157e308;
+  for (const cv::Point2d& p : pts) m = std::max(m, std::max(p.x, p.y));
+  return m;
+}
+
+// reference src/Sfm.cpp:667-689
+int StructFromMotion::findHomographyInliers(const int& idx_query, const int& idx_train, const Matching& matches) {
+  Points2d query_points, train_points;
+  AlignedPointsFromMatch(imagesPts2D.at(idx_query), imagesPts2D.at(idx_train), matches, query_points, train_points);
+  if (matches.size() < 4) return 0;
+  const int32_t offsets[2] = {0, (int32_t)query_points.size()};
+  std::vector<double> l, r;
+  for (size_t i = 0; i < query_points.size(); ++i) {
+    l.push_back(query_points[i].x);
+    l.push_back(query_points[i].y);
+    r.push_back(train_points[i].x);
+    r.push_back(train_points[i].y);
+  }
+  const double thr = 0.004 * max_coordinate(query_points);
+  int32_t inl = 0;
+  const int rc = sfmhip_score_homography(sfm_hip_context(), 1, offsets, l.data(), r.data(), &thr, 0.995, 2000, &inl, nullptr, nullptr);
+  if (rc != SFMHIP_OK) {
+    std::cerr << "findHomographyInliers: " << sfmhip_error_string(rc) << std::endl;
+    return 0;
+  }
+  return inl;
+}
+
 // reference src/Sfm.cpp:499-585
 std::map<float, std::pair<int, int>> StructFromMotion::findBestPair() {
   std::cout << "Getting best two views for baseline..." << std::endl;
@@ -139,7 +169,7 @@ std::map<float, std::pair<int, int>> StructFromMotion::findBestPair() {
   std::vector<std::pair<int, int>> ids;
   std::vector<size_t> nmatch;
   std::vector<int32_t> offsets(1, 0);
-  std::vector<double> left, right;
+  std::vector<double> left, right, hthr;
   for (int queryImage = 0; queryImage < numImg - 1; queryImage++)
     for (int trainImage = queryImage + 1; trainImage < numImg; trainImage++) {
       Matching correspondences;
@@ -154,6 +184,7 @@ std::map<float, std::pair<int, int>> StructFromMotion::findBestPair() {
         right.push_back(alignedRight[i].y);
       }
       offsets.push_back((int32_t)(left.size() / 2));
+      hthr.push_back(0.004 * max_coordinate(alignedLeft));  // :674,681
       ids.push_back(std::make_pair(queryImage, trainImage));
       nmatch.push_back(correspondences.size());
     }
@@ -161,14 +192,19 @@ std::map<float, std::pair<int, int>> StructFromMotion::findBestPair() {
   const cv::Mat_<double>& Km = cameraMatrix.K;
   const int rc = sfmhip_score_essential(sfm_hip_context(), (int)ids.size(), offsets.data(), left.data(), right.data(), Km(0, 0),
                                         Km(1, 1), Km(0, 2), Km(1, 2), 0.999, 1.0, inliers.data(), nullptr, nullptr);  // :542-543
-  if (rc != SFMHIP_OK) {
-    std::cerr << "findBestPair: " << sfmhip_error_string(rc) << std::endl;
+  std::vector<int32_t> hom(ids.size() + 1, 0);
+  int rc2 = rc;
+  if (rc == SFMHIP_OK)
+    rc2 = sfmhip_score_homography(sfm_hip_context(), (int)ids.size(), offsets.data(), left.data(), right.data(), hthr.data(), 0.995,
+                                  2000, hom.data(), nullptr, nullptr);  // :545
+  if (rc != SFMHIP_OK || rc2 != SFMHIP_OK) {
+    std::cerr << "findBestPair: " << sfmhip_error_string(rc != SFMHIP_OK ? rc : rc2) << std::endl;
     return numInliers;
   }
   for (size_t p = 0; p < ids.size(); ++p) {
     const float poseInliersRatio = (float)inliers[p] / (float)nmatch[p];  // :563
-    std::cout << "pair:" << "[" << ids[p].first << "," << ids[p].second << "]" << " has:" << nmatch[p] << " matches and "
-              << poseInliersRatio << " pose inliers ratio." << std::endl;
+    std::cout << "pair:" << "[" << ids[p].first << "," << ids[p].second << "]" << " has:" << nmatch[p] << " matches " << hom[p]
+              << " inliers and " << poseInliersRatio << " pose inliers ratio." << std::endl;  // :567
     numInliers[poseInliersRatio] = ids[p];  // :569
   }
   return numInliers;

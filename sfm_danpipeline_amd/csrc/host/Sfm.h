@@ -67,9 +67,11 @@ class StructFromMotion {
   // reference include/Sfm.h:83, src/Sfm.cpp:499-585: the all-pairs matching (matchAllPairs: one batched launch),
   // then for every pair with >= 120 matches the pose-inlier ratio of cv::findEssentialMat(RANSAC, 0.999, 1.0)
   // (sfmhip_score_essential, all pairs in one call), collected in the map keyed by that float: ascending, equal keys
-  // overwrite.  Not mirrored: the drawMatches / imshow / waitKey(100) per pair and the homography inlier count,
-  // which the reference only prints (:545,567).
+  // overwrite; the homography inlier count the reference prints next to it (:545,567) comes from
+  // sfmhip_score_homography, all pairs in one call.  Not mirrored: the drawMatches / imshow / waitKey(100) per pair.
   std::map<float, std::pair<int, int>> findBestPair();
+  // reference include/Sfm.h:137, src/Sfm.cpp:667-689: cv::findHomography(RANSAC, 0.004 * maxVal) inlier count of one pair
+  int findHomographyInliers(const int& idx_query, const int& idx_train, const Matching& matches);
   // reference src/Sfm.cpp:883-888 is a stub whose call names a member that no longer exists;
   // wired here with imagesPts2D, the member of the required type
   void adjustCurrentBundle();

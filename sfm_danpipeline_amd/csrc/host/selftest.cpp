@@ -11,7 +11,8 @@
 //              n x (f64 xyz[3], f64 xy[2])
 //        mergeNewPoints(cloud shifted by (0,0,0.004) ++ cloud shifted by (5,0,0) ++ the same again):
 //              i32 cloud size before, i32 after, then (after-before) x f64 xyz[3] of the appended points
-//        findBestPair() (SURVEY 8f-1 scoring half): i32 n, n x (f32 poseInliersRatio, i32 q, i32 t) in map order
+//        findBestPair() (SURVEY 8f-1 scoring half): i32 n, n x (f32 poseInliersRatio, i32 q, i32 t) in map order,
+//              then i32 findHomographyInliers(0, 1, matches)
 //        after adjustCurrentBundle: f64 K[9], n_cam x f64 pose[12], n_pt x f64 xyz[3]
 #include <cstdio>
 #include <cstdlib>
@@ -141,6 +142,8 @@ int main(int argc, char** argv) {
       fwrite(&kv.second.first, 4, 1, o);
       fwrite(&kv.second.second, 4, 1, o);
     }
+    const int hom = sfm.findHomographyInliers(0, 1, cached);
+    fwrite(&hom, 4, 1, o);
   }
   // ---- adjustCurrentBundle on the BA block
   const int n_cam = rd<int>(f);

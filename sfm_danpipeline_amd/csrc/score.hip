@@ -416,6 +416,232 @@ int ransac_update_num_iters(double p, double ep, int model_points, int max_iters
   return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)std::nearbyint(num / denom);  // cvRound
 }
 
+
+// ================================================================ homography (findHomographyInliers, src/Sfm.cpp:667-689)
+// cv::findHomography(query, train, RANSAC, threshold, mask) as OpenCV 3.4.1 (calib3d/fundam.cpp) runs it: FLOAT
+// points; 4-point samples, a sample drawn again when checkSubset rejects it (host, below); model = normalised DLT,
+// the eigenvector of the smallest eigenvalue of L^T L (here: cyclic Jacobi) scaled to H[2][2] = 1; the error and the
+// threshold test in float arithmetic; the mask is the RANSAC mask (the refit + LM refinement change H only).
+__device__ int homography_kernel(const float (*M)[2], const float (*m)[2], double* H) {
+  const int count = 4;
+  double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
+  for (int i = 0; i < count; ++i) {
+    cmx += m[i][0]; cmy += m[i][1];
+    cMx += M[i][0]; cMy += M[i][1];
+  }
+  cmx /= count; cmy /= count; cMx /= count; cMy /= count;
+  for (int i = 0; i < count; ++i) {
+    smx += fabs(m[i][0] - cmx); smy += fabs(m[i][1] - cmy);
+    sMx += fabs(M[i][0] - cMx); sMy += fabs(M[i][1] - cMy);
+  }
+  if (fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON) return 0;
+  smx = count / smx; smy = count / smy; sMx = count / sMx; sMy = count / sMy;
+  double A[9][9], V[9][9];
+  for (int j = 0; j < 9; ++j)
+    for (int k = 0; k < 9; ++k) A[j][k] = 0.0, V[j][k] = j == k ? 1.0 : 0.0;
+  for (int i = 0; i < count; ++i) {
+    const double x = (m[i][0] - cmx) * smx, y = (m[i][1] - cmy) * smy;
+    const double X = (M[i][0] - cMx) * sMx, Y = (M[i][1] - cMy) * sMy;
+    const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+    const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+    for (int j = 0; j < 9; ++j)
+      for (int k = j; k < 9; ++k) A[j][k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+  }
+  for (int j = 0; j < 9; ++j)
+    for (int k = 0; k < j; ++k) A[j][k] = A[k][j];
+  // cyclic Jacobi: A <- J^T A J, V <- V J
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int j = 0; j < 9; ++j) {
+      diag += A[j][j] * A[j][j];
+      for (int k = j + 1; k < 9; ++k) off += A[j][k] * A[j][k];
+    }
+    if (off <= 1e-32 * diag) break;
+    for (int p = 0; p < 8; ++p)
+      for (int q = p + 1; q < 9; ++q) {
+        const double apq = A[p][q];
+        if (apq == 0.0) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+        const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
+        for (int k = 0; k < 9; ++k) {
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - sn * akq;
+          A[k][q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < 9; ++k) {
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - sn * aqk;
+          A[q][k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < 9; ++k) {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - sn * vkq;
+          V[k][q] = sn * vkp + c * vkq;
+        }
+      }
+  }
+  int best = 0;
+  for (int j = 1; j < 9; ++j)
+    if (A[j][j] < A[best][best]) best = j;
+  double h0[9];
+  for (int k = 0; k < 9; ++k) h0[k] = V[k][best];
+  // H = invHnorm * H0 * Hnorm2, then / H[2][2]
+  const double inv[9] = {1.0 / smx, 0, cmx, 0, 1.0 / smy, cmy, 0, 0, 1};
+  const double hn2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
+  double t[9], r[9];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) t[3 * a + b] = inv[3 * a] * h0[b] + inv[3 * a + 1] * h0[3 + b] + inv[3 * a + 2] * h0[6 + b];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) r[3 * a + b] = t[3 * a] * hn2[b] + t[3 * a + 1] * hn2[3 + b] + t[3 * a + 2] * hn2[6 + b];
+  const double s = 1.0 / r[8];
+  for (int k = 0; k < 9; ++k) H[k] = r[k] * s;
+  return 1;
+}
+
+struct HJob {
+  int off, count, samp;
+  float t;  // (float)(threshold * threshold) of the pair
+};
+
+__global__ __launch_bounds__(64) void homog_solve(const HJob* __restrict__ jobs, int n_jobs, int chunk,
+                                                  const int* __restrict__ samples, const float* __restrict__ p1,
+                                                  const float* __restrict__ p2, double* __restrict__ models,
+                                                  int* __restrict__ n_models) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_jobs * chunk) return;
+  const int j = t / chunk, it = t - j * chunk;
+  const HJob jb = jobs[j];
+  const int* s = samples + ((size_t)jb.samp + it) * 4;
+  float M[4][2], m[4][2];
+  bool ok = true;
+  for (int k = 0; k < 4; ++k) {
+    if (s[k] < 0) {  // (no acceptable sample was found for this iteration: RANSAC has ended there)
+      ok = false;
+      break;
+    }
+    const size_t i = (size_t)jb.off + s[k];
+    M[k][0] = p1[2 * i]; M[k][1] = p1[2 * i + 1];
+    m[k][0] = p2[2 * i]; m[k][1] = p2[2 * i + 1];
+  }
+  double H[9];
+  const int n = ok ? homography_kernel(M, m, H) : 0;
+  n_models[t] = n;
+  if (n)
+    for (int e = 0; e < 9; ++e) models[(size_t)t * 9 + e] = H[e];
+}
+
+// HomographyEstimatorCallback::computeError + findInliers, float arithmetic
+__device__ __forceinline__ bool homog_inlier(const float* Hf, float Mx, float My, float mx, float my, float t) {
+  const float ww = 1.f / (Hf[6] * Mx + Hf[7] * My + 1.f);
+  const float dx = (Hf[0] * Mx + Hf[1] * My + Hf[2]) * ww - mx;
+  const float dy = (Hf[3] * Mx + Hf[4] * My + Hf[5]) * ww - my;
+  return dx * dx + dy * dy <= t;
+}
+
+__global__ __launch_bounds__(256) void homog_count(const HJob* __restrict__ jobs, int chunk, const float* __restrict__ p1,
+                                                   const float* __restrict__ p2, const double* __restrict__ models,
+                                                   const int* __restrict__ n_models, int* __restrict__ counts) {
+  __shared__ float sH[8];
+  __shared__ int s_cnt;
+  const int slot = blockIdx.x;
+  const HJob jb = jobs[slot / chunk];
+  const int nm = n_models[slot];
+  if (threadIdx.x == 0) s_cnt = 0;
+  if (threadIdx.x < 8 && nm) sH[threadIdx.x] = (float)models[(size_t)slot * 9 + threadIdx.x];
+  __syncthreads();
+  if (nm) {
+    int cnt = 0;
+    for (int i = threadIdx.x; i < jb.count; i += 256) {
+      const size_t k = (size_t)jb.off + i;
+      cnt += homog_inlier(sH, p1[2 * k], p1[2 * k + 1], p2[2 * k], p2[2 * k + 1], jb.t) ? 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_cnt, cnt);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) counts[slot] = nm ? s_cnt : 0;
+}
+
+__global__ __launch_bounds__(256) void homog_mask(const int* __restrict__ offsets, const float* __restrict__ p1,
+                                                  const float* __restrict__ p2, const double* __restrict__ best_H,
+                                                  const unsigned char* __restrict__ has, const float* __restrict__ tt,
+                                                  unsigned char* __restrict__ mask) {
+  const int pr = blockIdx.x;
+  const int o = offsets[pr], n = offsets[pr + 1] - o;
+  __shared__ float sH[8];
+  if (threadIdx.x < 8) sH[threadIdx.x] = (float)best_H[(size_t)pr * 9 + threadIdx.x];
+  __syncthreads();
+  const int h = has[pr];
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const size_t k = (size_t)o + i;
+    mask[k] = h == 2 ? 1 : h == 1 ? (homog_inlier(sH, p1[2 * k], p1[2 * k + 1], p2[2 * k], p2[2 * k + 1], tt[pr]) ? 1 : 0) : 0;
+  }
+}
+
+// ---- host: HomographyEstimatorCallback::checkSubset and the per-pair sample stream
+static bool have_collinear(const float (*p)[2], int count) {
+  const int i = count - 1;
+  for (int j = 0; j < i; ++j) {
+    const double dx1 = p[j][0] - p[i][0], dy1 = p[j][1] - p[i][1];
+    for (int k = 0; k < j; ++k) {
+      const double dx2 = p[k][0] - p[i][0], dy2 = p[k][1] - p[i][1];
+      if (std::fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (std::fabs(dx1) + std::fabs(dy1) + std::fabs(dx2) + std::fabs(dy2))) return true;
+    }
+  }
+  return false;
+}
+static double det3(const double* m) {
+  return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+static bool homography_check_subset(const float (*s1)[2], const float (*s2)[2]) {
+  if (have_collinear(s1, 4) || have_collinear(s2, 4)) return false;
+  static const int tt[4][3] = {{0, 1, 2}, {1, 2, 3}, {0, 2, 3}, {0, 1, 3}};
+  int negative = 0;
+  for (int i = 0; i < 4; ++i) {
+    const int* t = tt[i];
+    const double A[9] = {s1[t[0]][0], s1[t[0]][1], 1., s1[t[1]][0], s1[t[1]][1], 1., s1[t[2]][0], s1[t[2]][1], 1.};
+    const double B[9] = {s2[t[0]][0], s2[t[0]][1], 1., s2[t[1]][0], s2[t[1]][1], 1., s2[t[2]][0], s2[t[2]][1], 1.};
+    negative += det3(A) * det3(B) < 0;
+  }
+  return negative == 0 || negative == 4;
+}
+struct HSampleStream {  // per pair: the accepted 4-point samples in order (-1: getSubset gave up after 10000 attempts)
+  CvRng rng;
+  std::vector<int> idx;
+  bool dead = false;
+  void extend(const float* m1, const float* m2, int count, int n_iters) {
+    while ((int)idx.size() < 4 * n_iters) {
+      int s[4] = {-1, -1, -1, -1};
+      bool found = false;
+      for (int attempt = 0; attempt < 10000 && !dead; ++attempt) {
+        for (int i = 0; i < 4;) {
+          const int v = rng.uniform(0, count);
+          int j = 0;
+          for (; j < i; ++j)
+            if (s[j] == v) break;
+          if (j < i) continue;
+          s[i++] = v;
+        }
+        float a[4][2], b[4][2];
+        for (int k = 0; k < 4; ++k) {
+          a[k][0] = m1[2 * s[k]]; a[k][1] = m1[2 * s[k] + 1];
+          b[k][0] = m2[2 * s[k]]; b[k][1] = m2[2 * s[k] + 1];
+        }
+        if (homography_check_subset(a, b)) {
+          found = true;
+          break;
+        }
+      }
+      if (!found) {
+        dead = true;
+        s[0] = s[1] = s[2] = s[3] = -1;
+      }
+      idx.insert(idx.end(), s, s + 4);
+    }
+  }
+};
+
 }  // namespace
 
 extern "C" int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_t* offsets, const double* left_xy,
@@ -579,6 +805,177 @@ extern "C" int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_
     SFM_HIP_TRY(hipMemcpyAsync(d_bestE, best_E.data(), sizeof(double) * 9 * n_pairs, hipMemcpyHostToDevice, st));
     SFM_HIP_TRY(hipMemcpyAsync(d_has, has.data(), n_pairs, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(score_mask, dim3(n_pairs), dim3(256), 0, st, d_off, d_p1, d_p2, d_bestE, d_has, t, d_mask);
+    SFM_HIP_TRY(hipGetLastError());
+    SFM_HIP_TRY(hipMemcpyAsync(mask, d_mask, (size_t)total, hipMemcpyDeviceToHost, st));
+  }
+  SFM_HIP_TRY(hipStreamSynchronize(st));
+  return SFMHIP_OK;
+}
+
+extern "C" int sfmhip_score_homography(sfmhip_ctx* ctx, int n_pairs, const int32_t* offsets, const double* left_xy,
+                                       const double* right_xy, const double* thresholds, double confidence, int max_iters,
+                                       int32_t* inliers, uint8_t* mask, int32_t* iterations) {
+  if (!ctx || n_pairs < 0 || !offsets || !inliers || !thresholds || !(confidence > 0 && confidence < 1)) return SFMHIP_ERR_ARG;
+  if (n_pairs == 0) return SFMHIP_OK;
+  const long long total = offsets[n_pairs];
+  if (total < 0 || (total > 0 && (!left_xy || !right_xy))) return SFMHIP_ERR_ARG;
+  for (int p = 0; p < n_pairs; ++p)
+    if (offsets[p + 1] < offsets[p]) return SFMHIP_ERR_ARG;
+  SFM_HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  constexpr int MODEL_POINTS = 4;
+  const int MAX_ITERS = std::max(max_iters, 1);
+  struct Bufs {
+    std::vector<void*> v;
+    ~Bufs() {
+      for (void* p : v) hipFree(p);
+    }
+  } bufs;
+  auto dalloc = [&](void** p, size_t bytes) -> int {
+    if (hipMalloc(p, bytes ? bytes : 8) != hipSuccess) return SFMHIP_ERR_ALLOC;
+    bufs.v.push_back(*p);
+    return SFMHIP_OK;
+  };
+  // the points as float (findHomography converts them to CV_32F before anything else)
+  std::vector<float> h1(2 * (size_t)std::max<long long>(total, 1)), h2(h1.size());
+  for (long long i = 0; i < 2 * total; ++i) {
+    h1[i] = (float)left_xy[i];
+    h2[i] = (float)right_xy[i];
+  }
+  float *d_p1 = nullptr, *d_p2 = nullptr;
+  SFM_TRY(dalloc((void**)&d_p1, sizeof(float) * h1.size()));
+  SFM_TRY(dalloc((void**)&d_p2, sizeof(float) * h2.size()));
+  SFM_HIP_TRY(hipMemcpyAsync(d_p1, h1.data(), sizeof(float) * h1.size(), hipMemcpyHostToDevice, st));
+  SFM_HIP_TRY(hipMemcpyAsync(d_p2, h2.data(), sizeof(float) * h2.size(), hipMemcpyHostToDevice, st));
+  struct PairState {
+    int count, niters, iter, best;
+    float t;
+    bool done;
+  };
+  std::vector<PairState> ps(n_pairs);
+  std::vector<HSampleStream> streams(n_pairs);
+  std::vector<double> best_H((size_t)n_pairs * 9, 0.0);
+  std::vector<unsigned char> has(n_pairs, 0);
+  std::vector<float> tts(n_pairs);
+  for (int p = 0; p < n_pairs; ++p) {
+    PairState& s = ps[p];
+    s.count = offsets[p + 1] - offsets[p];
+    double thr = thresholds[p];
+    if (thr <= 0) thr = 3;  // defaultRANSACReprojThreshold
+    s.t = tts[p] = (float)(thr * thr);
+    s.niters = MAX_ITERS;
+    s.iter = s.best = 0;
+    s.done = s.count < MODEL_POINTS;
+  }
+  int chunk = 32;
+  std::vector<HJob> jobs;
+  std::vector<int> job_pair, h_samples, h_nm, h_counts;
+  std::vector<double> h_models;
+  HJob* d_jobs = nullptr;
+  int *d_samples = nullptr, *d_nm = nullptr, *d_counts = nullptr;
+  double* d_models = nullptr;
+  size_t cap_jobs = 0, cap_slots = 0, cap_samples = 0;
+  for (;;) {
+    jobs.clear();
+    job_pair.clear();
+    h_samples.clear();
+    for (int p = 0; p < n_pairs; ++p) {
+      PairState& s = ps[p];
+      if (s.done) continue;
+      HJob jb;
+      jb.off = offsets[p];
+      jb.count = s.count;
+      jb.t = s.t;
+      jb.samp = (int)(h_samples.size() / 4);
+      if (s.count == MODEL_POINTS) {  // method == 0 || npoints == 4: runKernel on the four, the mask all ones
+        for (int it = 0; it < chunk; ++it)
+          for (int k = 0; k < 4; ++k) h_samples.push_back(k);
+      } else {
+        HSampleStream& ss = streams[p];
+        ss.extend(h1.data() + 2 * (size_t)offsets[p], h2.data() + 2 * (size_t)offsets[p], s.count, s.iter + chunk);
+        h_samples.insert(h_samples.end(), ss.idx.begin() + 4 * (size_t)s.iter, ss.idx.begin() + 4 * (size_t)(s.iter + chunk));
+      }
+      jobs.push_back(jb);
+      job_pair.push_back(p);
+    }
+    if (jobs.empty()) break;
+    const size_t nj = jobs.size(), slots = nj * (size_t)chunk;
+    if (nj > cap_jobs) {
+      SFM_TRY(dalloc((void**)&d_jobs, sizeof(HJob) * nj));
+      cap_jobs = nj;
+    }
+    if (slots > cap_slots) {
+      SFM_TRY(dalloc((void**)&d_nm, sizeof(int) * slots));
+      SFM_TRY(dalloc((void**)&d_counts, sizeof(int) * slots));
+      SFM_TRY(dalloc((void**)&d_models, sizeof(double) * slots * 9));
+      cap_slots = slots;
+    }
+    if (h_samples.size() > cap_samples) {
+      SFM_TRY(dalloc((void**)&d_samples, sizeof(int) * h_samples.size()));
+      cap_samples = h_samples.size();
+    }
+    SFM_HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(HJob) * nj, hipMemcpyHostToDevice, st));
+    SFM_HIP_TRY(hipMemcpyAsync(d_samples, h_samples.data(), sizeof(int) * h_samples.size(), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(homog_solve, dim3((unsigned)((slots + 63) / 64)), dim3(64), 0, st, d_jobs, (int)nj, chunk, d_samples, d_p1,
+                       d_p2, d_models, d_nm);
+    hipLaunchKernelGGL(homog_count, dim3((unsigned)slots), dim3(256), 0, st, d_jobs, chunk, d_p1, d_p2, d_models, d_nm, d_counts);
+    SFM_HIP_TRY(hipGetLastError());
+    h_nm.resize(slots);
+    h_counts.resize(slots);
+    h_models.resize(slots * 9);
+    SFM_HIP_TRY(hipMemcpyAsync(h_nm.data(), d_nm, sizeof(int) * slots, hipMemcpyDeviceToHost, st));
+    SFM_HIP_TRY(hipMemcpyAsync(h_counts.data(), d_counts, sizeof(int) * slots, hipMemcpyDeviceToHost, st));
+    SFM_HIP_TRY(hipMemcpyAsync(h_models.data(), d_models, sizeof(double) * slots * 9, hipMemcpyDeviceToHost, st));
+    SFM_HIP_TRY(hipStreamSynchronize(st));
+    for (size_t j = 0; j < nj; ++j) {
+      const int p = job_pair[j];
+      PairState& s = ps[p];
+      if (s.count == MODEL_POINTS) {
+        if (h_nm[j * chunk] > 0) {
+          s.best = MODEL_POINTS;
+          has[p] = 2;
+        }
+        s.done = true;
+        continue;
+      }
+      for (int it = 0; it < chunk && s.iter < s.niters; ++it, ++s.iter) {
+        const size_t slot = j * chunk + it;
+        if (streams[p].idx[4 * (size_t)s.iter] < 0) {  // getSubset failed: run() leaves the loop (iter 0: no model at all)
+          s.niters = s.iter;
+          break;
+        }
+        if (h_nm[slot] <= 0) continue;
+        const int good = h_counts[slot];
+        if (good > std::max(s.best, MODEL_POINTS - 1)) {
+          s.best = good;
+          has[p] = 1;
+          for (int e = 0; e < 9; ++e) best_H[(size_t)p * 9 + e] = h_models[slot * 9 + e];
+          s.niters = ransac_update_num_iters(confidence, (double)(s.count - good) / s.count, MODEL_POINTS, s.niters);
+        }
+      }
+      if (s.iter >= s.niters) s.done = true;
+    }
+    chunk = std::min(2 * chunk, 256);
+  }
+  for (int p = 0; p < n_pairs; ++p) {
+    inliers[p] = ps[p].best;
+    if (iterations) iterations[p] = ps[p].iter;
+  }
+  if (mask && total > 0) {
+    int* d_off = nullptr;
+    double* d_bestH = nullptr;
+    float* d_tt = nullptr;
+    unsigned char *d_has = nullptr, *d_mask = nullptr;
+    SFM_TRY(dalloc((void**)&d_off, sizeof(int) * (n_pairs + 1)));
+    SFM_TRY(dalloc((void**)&d_bestH, sizeof(double) * 9 * n_pairs));
+    SFM_TRY(dalloc((void**)&d_tt, sizeof(float) * n_pairs));
+    SFM_TRY(dalloc((void**)&d_has, n_pairs));
+    SFM_TRY(dalloc((void**)&d_mask, (size_t)total));
+    SFM_HIP_TRY(hipMemcpyAsync(d_off, offsets, sizeof(int) * (n_pairs + 1), hipMemcpyHostToDevice, st));
+    SFM_HIP_TRY(hipMemcpyAsync(d_bestH, best_H.data(), sizeof(double) * 9 * n_pairs, hipMemcpyHostToDevice, st));
+    SFM_HIP_TRY(hipMemcpyAsync(d_tt, tts.data(), sizeof(float) * n_pairs, hipMemcpyHostToDevice, st));
+    SFM_HIP_TRY(hipMemcpyAsync(d_has, has.data(), n_pairs, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(homog_mask, dim3(n_pairs), dim3(256), 0, st, d_off, d_p1, d_p2, d_bestH, d_has, d_tt, d_mask);
     SFM_HIP_TRY(hipGetLastError());
     SFM_HIP_TRY(hipMemcpyAsync(mask, d_mask, (size_t)total, hipMemcpyDeviceToHost, st));
   }

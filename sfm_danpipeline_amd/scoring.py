@@ -30,6 +30,29 @@ def score_essential(pairs_points, K, prob=0.999, threshold=1.0, want_mask=False,
     return inl[:n], masks, its[:n]
 
 
+def score_homography(pairs_points, thresholds=None, confidence=0.995, max_iters=2000, want_mask=False, ctx=None):
+    """findHomographyInliers (src/Sfm.cpp:667-689) for a batch: the RANSAC inlier count of cv::findHomography(left,
+    right, RANSAC, threshold).  thresholds None: the reference's 0.004 * (largest coordinate of the pair's left points)."""
+    ctx = ctx or default_context()
+    n = len(pairs_points)
+    counts = np.array([len(a) for a, _ in pairs_points], np.int32)
+    offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    cat = lambda k: (np.ascontiguousarray(np.concatenate([np.asarray(p[k], np.float64).reshape(-1, 2) for p in pairs_points]))
+                     if n and offsets[-1] else np.zeros((0, 2)))
+    left, right = cat(0), cat(1)
+    if thresholds is None:
+        thresholds = [0.004 * float(np.max(a)) if len(a) else 0.0 for a, _ in pairs_points]   # cv::minMaxIdx over x and y
+    thr = np.ascontiguousarray(np.asarray(thresholds, np.float64).reshape(-1)) if n else np.zeros(1)
+    inl = np.zeros(max(n, 1), np.int32)
+    its = np.zeros(max(n, 1), np.int32)
+    mask = np.zeros(max(int(offsets[-1]), 1), np.uint8) if want_mask else None
+    check(lib().sfmhip_score_homography(ctx.h, n, offsets.ctypes.data, left.ctypes.data, right.ctypes.data, thr.ctypes.data,
+                                        float(confidence), int(max_iters), inl.ctypes.data,
+                                        mask.ctypes.data if want_mask else None, its.ctypes.data), "sfmhip_score_homography")
+    masks = [mask[offsets[i]:offsets[i + 1]].copy() for i in range(n)] if want_mask else None
+    return inl[:n], masks, its[:n]
+
+
 def find_best_pair(pair_ids, pairs_points, K, min_matches=120, ctx=None):
     """src/Sfm.cpp:511-569 after the matching: pair_ids in the loop's order; pairs with fewer than `min_matches`
     matches are skipped (:533).  Returns [(float32 ratio, (q, t))] ascending -- the iteration order of the map."""

@@ -160,6 +160,19 @@ int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_t* offsets,
   return SFMHIP_OK;
 }
 
+int sfmhip_score_homography(sfmhip_ctx* ctx, int n_pairs, const int32_t* offsets, const double* left_xy, const double* right_xy,
+                            const double* thresholds, double confidence, int max_iters, int32_t* inliers, uint8_t* mask,
+                            int32_t* iterations) {
+  (void)ctx; (void)left_xy; (void)right_xy; (void)thresholds; (void)confidence; (void)max_iters;
+  for (int p = 0; p < n_pairs; ++p) {
+    inliers[p] = offsets[p + 1] - offsets[p];
+    if (iterations) iterations[p] = 1;
+    if (mask)
+      for (int i = offsets[p]; i < offsets[p + 1]; ++i) mask[i] = 1;
+  }
+  return SFMHIP_OK;
+}
+
 int sfmhip_find_2d3d(sfmhip_ctx* ctx, const int32_t* trk_ptr, const int32_t* trk_view, const int32_t* trk_feat, int n_cloud,
                      int done_view, int new_view, const int32_t* match_q, const int32_t* match_t, int n_match, int32_t* out_cloud,
                      int32_t* out_feat, int32_t* n_out) {

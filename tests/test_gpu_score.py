@@ -62,3 +62,40 @@ def test_sample_models_agree_with_the_action_matrix_solver(ctx):
         cnt, mask, E, it = S.find_essential_mat_ransac(a, b, K)
         inl, _, its = scoring.score_essential([(a, b)], K, ctx=ctx)
         assert int(inl[0]) == cnt == 400 and int(its[0]) == it      # noise-free: the first sample explains everything
+
+
+def _planar(n, seed, outliers, noise=0.4):
+    rng = np.random.default_rng(seed)
+    Ht = np.array([[1.02, 0.05, 12.0], [-0.03, 0.98, -7.0], [1e-5, -2e-5, 1.0]])
+    p = rng.uniform(0, 640, (n, 2))
+    ph = np.concatenate([p, np.ones((n, 1))], 1) @ Ht.T
+    q = ph[:, :2] / ph[:, 2:] + rng.normal(0, noise, (n, 2))
+    out = rng.random(n) < outliers
+    q[out] = rng.uniform(0, 640, (int(out.sum()), 2))
+    return p, q
+
+
+def test_homography_inliers_match_the_restatement(ctx):
+    """findHomographyInliers (src/Sfm.cpp:667-689): counts, iteration numbers and masks against the numpy
+    restatement of cv::findHomography(RANSAC) -- float points, checkSubset, float error arithmetic."""
+    a, b = _scene(400, 31, outliers=0.2)                      # a general scene: few points agree with any homography
+    pairs = [_planar(600, 0, 0.3), _planar(150, 1, 0.6), _planar(2000, 2, 0.1), (a, b), _planar(40, 3, 0.0), _planar(300, 4, 0.85)]
+    inl, masks, its = scoring.score_homography(pairs, want_mask=True, ctx=ctx)
+    for i, (p, q) in enumerate(pairs):
+        cnt, mask, it = S.find_homography_ransac(p, q, 0.004 * float(np.max(p)))
+        assert (int(inl[i]), int(its[i])) == (cnt, it), i
+        assert np.array_equal(masks[i], mask), i
+        assert S.find_homography_inliers(p, q) == cnt
+    assert inl[0] > 0.6 * 600 and inl[3] < 0.5 * 400
+
+
+def test_homography_degenerate_inputs(ctx):
+    p, q = _planar(50, 9, 0.0)
+    line = np.stack([np.arange(30.0), 2 * np.arange(30.0)], 1)      # every sample is collinear: getSubset gives up
+    pairs = [(p[:0], q[:0]), (p[:3], q[:3]), (p[:4], q[:4]), (p[:5], q[:5]), (line, line + 1.0)]
+    inl, masks, its = scoring.score_homography(pairs, want_mask=True, ctx=ctx)
+    assert inl[0] == 0 and inl[1] == 0
+    assert inl[2] == 4 and masks[2].all()                     # npoints == 4: runKernel on all of them, the mask all ones
+    cnt, mask, it = S.find_homography_ransac(p[:5], q[:5], 0.004 * float(np.max(p[:5])))
+    assert (int(inl[3]), int(its[3])) == (cnt, it)
+    assert inl[4] == 0 and its[4] == 0                        # run() returns false at iteration 0
