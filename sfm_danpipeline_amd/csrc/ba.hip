@@ -1614,8 +1614,10 @@ __device__ __forceinline__ void chol2_panel(double* __restrict__ A, double* __re
 }
 
 // (bid: the workgroup's index within its matrix -- blockIdx.x when a launch factors one matrix)
+// (nxc: the tile columns of X that are wanted -- nt for a whole matrix, the interior tiles for a chain, whose X is
+// only used up to there: the trailing tiles of X right of that are not formed)
 __device__ __forceinline__ void chol_step2_body(double* __restrict__ A, double* __restrict__ y, double* __restrict__ X,
-                                                int ld, int nt, int k2, int tiles_per_wg, int* __restrict__ info,
+                                                int ld, int nt, int nxc, int k2, int tiles_per_wg, int* __restrict__ info,
                                                 const int bid, double* sAll) {
   const int m2 = nt - 2 * k2 - 2;  // tile rows below the two panels (the rhs row comes on top)
   const int npanel = m2 + 2;       // owner, m2 tile rows, rhs
@@ -1645,15 +1647,16 @@ __device__ __forceinline__ void chol_step2_body(double* __restrict__ A, double* 
   if (wave >= tiles_per_wg) return;
   int t = (bid - npanel - nx) * tiles_per_wg + wave;
   const int ntrail = m2 * (m2 + 1) / 2 + m2;
-  if (t >= ntrail + 2 * k2 * m2) return;
+  const int mx = max(0, nxc - 2 * k2 - 2);  // column blocks of X right of the panels
+  if (t >= ntrail + 2 * k2 * mx) return;
   int ti_rel = 0;
   const double* Rrow = A;  // the tile's row space
   double* Wrow = A;
   int rb_x = -1;
   if (t >= ntrail) {
     t -= ntrail;
-    rb_x = (t / m2) * CB;
-    t %= m2;
+    rb_x = (t / mx) * CB;
+    t %= mx;
     Rrow = X;
     Wrow = X;
   } else {
@@ -1735,7 +1738,7 @@ __global__ __launch_bounds__(C2_WAVES * 64) void chol_step2(double* __restrict__
                                                             double* __restrict__ X, int ld, int nt, int k2,
                                                             int tiles_per_wg, int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double sAll[];  // C2_LDS_BYTES, see C2_OFF_*
-  chol_step2_body(A, y, X, ld, nt, k2, tiles_per_wg, info, (int)blockIdx.x, sAll);
+  chol_step2_body(A, y, X, ld, nt, nt, k2, tiles_per_wg, info, (int)blockIdx.x, sAll);
 }
 
 // Several independent matrices ("chains": the interiors of a dissected camera graph, see NdPlan) at the same
@@ -1749,7 +1752,7 @@ struct ChainSet {
   double* A[ND_MAX];
   double* y[ND_MAX];
   double* X[ND_MAX];
-  int ld[ND_MAX], nt[ND_MAX], tpw[ND_MAX];
+  int ld[ND_MAX], nt[ND_MAX], nxc[ND_MAX], tpw[ND_MAX];
   int pan0[ND_MAX + 1];  // first panel workgroup of chain c (pan0[n]: all panel workgroups)
   int trl0[ND_MAX + 1];  // first trailing workgroup of chain c, counted from pan0[n]
 };
@@ -1764,7 +1767,7 @@ __global__ __launch_bounds__(C2_WAVES * 64) void chol_step2_chains(ChainSet cs, 
     while (c + 1 < cs.n && t >= cs.trl0[c + 1]) ++c;
     bid = cs.pan0[c + 1] - cs.pan0[c] + (t - cs.trl0[c]);
   }
-  chol_step2_body(cs.A[c], cs.y[c], cs.X[c], cs.ld[c], cs.nt[c], k2, cs.tpw[c], info, bid, sAll);
+  chol_step2_body(cs.A[c], cs.y[c], cs.X[c], cs.ld[c], cs.nt[c], cs.nxc[c], k2, cs.tpw[c], info, bid, sAll);
 }
 #undef CHOL_MFMA
 
@@ -3049,11 +3052,10 @@ static int ba_nd_build(sfmhip_ba* b) {
 }
 
 // trailing tiles per workgroup of a chol_step2 launch: the fewest that keep the launch to one round of workgroups
-static void chol_launch_shape(int nt, int k2, int budget, int* npan, int* ntrail) {
-  const int m2 = nt - 2 * k2 - 2;
-  *ntrail = k2 == 0 ? 0 : m2 * (m2 + 1) / 2 + m2 + 2 * k2 * m2;
+static void chol_launch_shape(int nt, int nxc, int k2, int* npan, int* ntrail) {
+  const int m2 = nt - 2 * k2 - 2, mx = std::max(0, nxc - 2 * k2 - 2);
+  *ntrail = k2 == 0 ? 0 : m2 * (m2 + 1) / 2 + m2 + 2 * k2 * mx;
   *npan = m2 + 2 + 2 * k2 + 2;
-  (void)budget;
 }
 
 // diagnostic (SFMHIP_BA_ND_DEBUG): NaN / magnitude census of every chain's buffers after a stage
@@ -3110,13 +3112,14 @@ static int ba_reduced_solve_nd(sfmhip_ba* b) {
       for (int i = 0; i < P; ++i) {
         if (2 * k2 >= ns.c[i].ni) continue;
         int npan, ntrail;
-        chol_launch_shape(ns.c[i].N, k2, 0, &npan, &ntrail);
+        chol_launch_shape(ns.c[i].N, ns.c[i].ni, k2, &npan, &ntrail);
         const int j = cs.n++;
         cs.A[j] = ns.c[i].M;
         cs.y[j] = ns.c[i].y;
         cs.X[j] = ns.c[i].X;
         cs.ld[j] = ns.c[i].ld;
         cs.nt[j] = ns.c[i].N;
+        cs.nxc[j] = ns.c[i].ni;
         cs.tpw[j] = tpw;
         cs.pan0[j] = pan;
         cs.trl0[j] = trl;
@@ -3139,7 +3142,7 @@ static int ba_reduced_solve_nd(sfmhip_ba* b) {
   ++nl;
   for (int k2 = 0; 2 * k2 < sp.N; ++k2, ++nl) {
     int npan, ntrail, tpw = 4;
-    chol_launch_shape(sp.N, k2, 0, &npan, &ntrail);
+    chol_launch_shape(sp.N, sp.N, k2, &npan, &ntrail);
     while (tpw < C2_WAVES && npan + (ntrail + tpw - 1) / tpw > b->ctx->n_cu) ++tpw;
     hipLaunchKernelGGL(chol_step2, dim3(npan + (ntrail + tpw - 1) / tpw), dim3(C2_WAVES * 64), C2_LDS_BYTES, st, sp.M, sp.y,
                        sp.X, sp.ld, sp.N, k2, tpw, d.info);
