@@ -142,6 +142,20 @@ int sfmhip_merge_new_points(sfmhip_ctx* ctx, const double* cloud_xyz, int n_clou
                             const double* new_xyz, int n_new, float min_dist, uint8_t* accept,
                             int32_t* n_accepted);
 
+/* ---- the detector / descriptor front end of getFeature (reference src/Sfm.cpp:300-330) ----
+ * cv::xfeatures2d::SIFT::create(nfeatures = 0, nOctaveLayers, contrastThreshold, edgeThreshold, sigma)
+ *     ->detectAndCompute(gray, noArray(), keypoints, descriptors)
+ * as OpenCV 3.4.1's float pipeline computes it (doubled base image, Gaussian / DoG pyramids, refined extrema,
+ * orientation peaks, removeDuplicatedSorted, 4x4x8 descriptors x512 saturated to 8 bit and stored as float).
+ * gray: rows x cols 8-bit, host memory.  keypoints: 6 floats each -- pt.x, pt.y, size, angle, response, and the
+ * int32 `octave` field bit-copied into the sixth float -- in OpenCV's sorted order; descriptors: 128 floats each
+ * (integer values 0..255: the input layout of the matcher).  capacity: keypoints the output arrays hold; 0 with null
+ * arrays = count only.  *n_keypoints receives the count; more than `capacity` returns SFMHIP_ERR_ARG.
+ * Parity unpinned (OpenCV is not available here): see DESIGN.md section 1, row f-3. */
+int sfmhip_sift_detect_and_compute(sfmhip_ctx* ctx, const uint8_t* gray, int rows, int cols, int n_octave_layers,
+                                   double contrast_threshold, double edge_threshold, double sigma, int capacity,
+                                   float* keypoints, float* descriptors, int32_t* n_keypoints);
+
 /* ---- the scoring half of findBestPair (reference src/Sfm.cpp:536-563) ----
  * For every pair of a batch the inlier count of
  *   cv::findEssentialMat(alignedLeft, alignedRight, K, CV_RANSAC, prob, threshold, mask)       (src/Sfm.cpp:542-543)

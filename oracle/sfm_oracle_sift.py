@@ -100,8 +100,7 @@ def resize_nearest_half(img):
 
 def build_pyramids(gray_u8, n_layers=3, sigma=1.6):
     base = gray_u8.astype(np.float32)
-    sig_diff = np.sqrt(max(sigma * sigma - SIFT_INIT_SIGMA * SIFT_INIT_SIGMA * 4, 0.01))
-    sig_diff = float(np.float32(sig_diff))                                          # sqrtf(...)
+    sig_diff = float(np.sqrt(max(F(F(F(sigma) * F(sigma)) - F(SIFT_INIT_SIGMA * SIFT_INIT_SIGMA * 4)), F(0.01))))   # sqrtf, float
     base = gaussian_blur(resize_linear_x2(base), sig_diff)
     n_oct = cv_round(np.log(float(min(base.shape))) / np.log(2.0) - 2) + 1          # - firstOctave (= -1)
     sig = [sigma]
