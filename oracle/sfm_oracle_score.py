@@ -156,8 +156,12 @@ def compute_error(E, p1, p2):
         return (x2tEx1 * x2tEx1 / den).astype(np.float32)
 
 
-def find_essential_mat_ransac(pts1, pts2, K, prob=0.999, threshold=1.0, max_iters=1000):
-    """cv::findEssentialMat(pts1, pts2, K, RANSAC, prob, threshold, mask): (inlier count, mask, E or None, iterations run)."""
+def find_essential_mat_ransac(pts1, pts2, K, prob=0.999, threshold=1.0, max_iters=1000, solver=None):
+    """cv::findEssentialMat(pts1, pts2, K, RANSAC, prob, threshold, mask): (inlier count, mask, E or None, iterations run).
+    solver: five_point (default; action matrix) or five_point_hidden_variable (the device's route).  On well-conditioned
+    samples the two give the same matrices; over hundreds of iterations on data with few inliers an ill-conditioned
+    sample can give one route a root the other misses, and with it a different best count (seen: 21 vs 20 of 57)."""
+    solver = solver or five_point
     pts1 = np.asarray(pts1, np.float64).reshape(-1, 2)
     pts2 = np.asarray(pts2, np.float64).reshape(-1, 2)
     fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
@@ -169,13 +173,13 @@ def find_essential_mat_ransac(pts1, pts2, K, prob=0.999, threshold=1.0, max_iter
     if count < 5:
         return 0, np.zeros(count, np.uint8), None, 0
     if count == 5:
-        models = five_point(p1, p2)
+        models = solver(p1, p2)
         return (5, np.ones(5, np.uint8), models[0], 0) if models else (0, np.zeros(5, np.uint8), None, 0)
     rng = CvRNG()
     niters, best_count, best_mask, best_E, it = max(max_iters, 1), 0, np.zeros(count, np.uint8), None, 0
     while it < niters:
         idx = get_subset(rng, count)
-        for E in five_point(p1[idx], p2[idx]):
+        for E in solver(p1[idx], p2[idx]):
             mask = compute_error(E, p1, p2) <= t          # (NaN compares false, as in C)
             good = int(mask.sum())
             if good > max(best_count, 4):
@@ -185,14 +189,14 @@ def find_essential_mat_ransac(pts1, pts2, K, prob=0.999, threshold=1.0, max_iter
     return best_count, best_mask, best_E, it
 
 
-def find_best_pair_scores(pair_points, K, min_matches=120):
+def find_best_pair_scores(pair_points, K, min_matches=120, solver=None):
     """findBestPair's map: pair_points = [((q, t), pts_q (n x 2), pts_t (n x 2))] in the loop's order (q < t ascending).
     Returns the std::map<float, pair> as a list ascending in the key: equal float keys keep the LAST pair inserted."""
     m = {}
     for (q, t), a, b in pair_points:
         if len(a) < min_matches:
             continue
-        cnt = find_essential_mat_ransac(a, b, K)[0]
+        cnt = find_essential_mat_ransac(a, b, K, solver=solver)[0]
         m[np.float32(np.float32(cnt) / np.float32(len(a)))] = (q, t)
     return sorted(m.items(), key=lambda kv: kv[0])
 
@@ -214,6 +218,8 @@ def _null_space_gj(Q):
         A[[i, i + r]] = A[[i + r, i]]
         A[:, [i, i + c]] = A[:, [i + c, i]]
         cols[i], cols[i + c] = cols[i + c], cols[i]
+        if A[i, i] == 0.0:
+            return None
         A[i] /= A[i, i]
         for k in range(5):
             if k != i:
@@ -273,7 +279,10 @@ def _real_roots(c):
 def five_point_hidden_variable(q1, q2):
     x1, y1, x2, y2 = q1[:, 0], q1[:, 1], q2[:, 0], q2[:, 1]
     Q = np.stack([x1 * x2, x2 * y1, x2, x1 * y2, y1 * y2, y2, x1, y1, np.ones(5)], axis=1)
-    X, Y, Z, W = (v.reshape(3, 3) for v in _null_space_gj(Q))
+    basis = _null_space_gj(Q)
+    if basis is None:
+        return []
+    X, Y, Z, W = (v.reshape(3, 3) for v in basis)
     M20 = constraint_matrix(X, Y, Z, W)
     perm = [MONO.index(m) for m in NISTER]
     M = M20[:, perm]

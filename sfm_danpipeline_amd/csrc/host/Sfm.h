@@ -76,6 +76,20 @@ class StructFromMotion {
   // wired here with imagesPts2D, the member of the required type
   void adjustCurrentBundle();
 
+  // ---- detector / descriptor front end (csrc/host/SfmIO.cpp)
+  // reference include/Sfm.h:85, src/Sfm.cpp:257-296: every gray image through getFeature (the imshow / waitKey(100) per
+  // image are not mirrored)
+  void extractFeature();
+  // reference include/Sfm.h:81, src/Sfm.cpp:300-403: detector 1 = SIFT(0, 3, 0.04, 10, 1.6)->detectAndCompute on the
+  // device (sfmhip_sift_detect_and_compute); detectors 2 (AKAZE) and 3 (ORB) are not built and leave the image's
+  // containers empty with a message
+  void getFeature(const cv::Mat& image, const int& numImage);
+  // reference include/Sfm.h:95, src/Sfm.cpp:397-403
+  void keypointstoPoints(std::vector<cv::KeyPoint>& keypoints, Points2d& points2D);
+  const std::vector<std::vector<cv::KeyPoint>>& keypoints() const { return imagesKeypoints; }
+  const std::vector<cv::Mat>& descriptors() const { return imagesDescriptors; }
+  const std::vector<std::vector<cv::Point2d>>& points2D() const { return imagesPts2D; }
+
   // ---- I/O and interchange formats (csrc/host/SfmIO.cpp)
   // reference include/Sfm.h:77, src/Sfm.cpp:118-198: scan a directory for .jpg/.png, sort, decode to BGR,
   // x0.6 bilinear iff rows > 480 and cols > 640, colour + gray copies.  PNG is decoded here (no OpenCV, no

@@ -11,10 +11,12 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <sstream>
 #include "Sfm.h"
+#include "hip_backend.h"
 
 namespace {
 
@@ -363,6 +365,75 @@ void mkdirs(const std::string& p) {
 }
 
 }  // namespace
+
+// reference src/Sfm.cpp:257-296
+void StructFromMotion::extractFeature() {
+  std::cout << "Extracting features from all images..." << std::endl;
+  nCameraPoses.resize(mGrayImages.size());
+  imagesKeypoints.resize(mGrayImages.size(), std::vector<cv::KeyPoint>());
+  imagesDescriptors.resize(mGrayImages.size(), cv::Mat());
+  imagesPts2D.resize(mGrayImages.size(), std::vector<cv::Point2d>());
+  if (detector == 1)
+    std::cout << "No detector choose. Using default:" << "SIFT(Scale-Invariant Feature Transform) detector." << "\n"
+              << "Parameters:" << "\n" << "nFeatures = 0\n" << "nOctaveLayers = 3\n" << "contrastThreshold = 0.04\n"
+              << "edgeThreshold = 10\n" << "sigma = 1.6" << std::endl;
+  std::cout << "*-- Features --*" << std::endl;
+  for (size_t n = 0; n < mGrayImages.size(); n++) {
+    getFeature(mGrayImages.at(n), (int)n);
+    std::cout << "Image:" << n << " --> " << imagesKeypoints.at(n).size() << " kps" << std::endl;
+  }
+  releaseDeviceSet();  // (new descriptors: what the matcher holds on the device is stale)
+  clearPairCache();
+}
+
+// reference src/Sfm.cpp:300-403
+void StructFromMotion::getFeature(const cv::Mat& image, const int& numImage) {
+  if (detector != 1) {
+    std::cerr << "getFeature: only the SIFT detector (1) is built" << std::endl;
+    return;
+  }
+  if (image.channels() != 1 || image.depth != CV_8U || image.empty()) {
+    std::cerr << "getFeature: an 8-bit gray image is expected" << std::endl;
+    return;
+  }
+  int32_t n = 0;
+  sfmhip_ctx* ctx = sfm_hip_context();
+  int cap = std::max(1024, image.rows * image.cols / 48);  // one pass when the guess holds
+  std::vector<float> kp(6 * (size_t)cap), desc(128 * (size_t)cap);
+  int rc = sfmhip_sift_detect_and_compute(ctx, image.ptr(), image.rows, image.cols, 3, 0.04, 10, 1.6, cap, kp.data(), desc.data(), &n);
+  if (rc == SFMHIP_ERR_ARG && n > cap) {  // more keypoints than guessed: again with the count the call reported
+    cap = n;
+    kp.resize(6 * (size_t)cap);
+    desc.resize(128 * (size_t)cap);
+    rc = sfmhip_sift_detect_and_compute(ctx, image.ptr(), image.rows, image.cols, 3, 0.04, 10, 1.6, cap, kp.data(), desc.data(), &n);
+  }
+  if (rc != SFMHIP_OK) {
+    std::cerr << "getFeature: " << sfmhip_error_string(rc) << std::endl;
+    return;
+  }
+  std::vector<cv::KeyPoint> kps((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    cv::KeyPoint& k = kps[i];
+    k.pt.x = kp[6 * i];
+    k.pt.y = kp[6 * i + 1];
+    k.size = kp[6 * i + 2];
+    k.angle = kp[6 * i + 3];
+    k.response = kp[6 * i + 4];
+    std::memcpy(&k.octave, &kp[6 * i + 5], 4);
+    k.class_id = -1;
+  }
+  std::vector<cv::Point2d> points2d;
+  keypointstoPoints(kps, points2d);
+  imagesKeypoints[numImage] = kps;
+  imagesDescriptors[numImage] = cv::Mat(n, 128, CV_32F, n ? desc.data() : nullptr);
+  imagesPts2D[numImage] = points2d;
+}
+
+// reference src/Sfm.cpp:397-403
+void StructFromMotion::keypointstoPoints(std::vector<cv::KeyPoint>& keypoints, Points2d& points2D) {
+  points2D.clear();
+  for (const cv::KeyPoint& kp : keypoints) points2D.push_back(cv::Point2d(kp.pt.x, kp.pt.y));
+}
 
 // reference src/Sfm.cpp:118-198
 bool StructFromMotion::imagesLOAD(const std::string& directoryPath) {

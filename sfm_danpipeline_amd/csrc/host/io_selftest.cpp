@@ -1,12 +1,42 @@
 // io_selftest.cpp -- drives imagesLOAD / getCameraMatrix / PMVS2 of the C++ host mirror:
 //   io_selftest <image dir> <calibration.xml> <out.bin>      (PMVS2 writes ./denseCloud: run it in a scratch directory)
 //   io_selftest --ply2pcd <in.ply> <out.pcd>                 (prints the point count)
+//   io_selftest --features <image dir> <out.bin>             (needs the GPU) imagesLOAD + extractFeature;
+//        out.bin: i32 n; per image: i32 rows, cols, gray bytes, i32 nk, nk x (6 f32 keypoint, octave bit-copied), nk x 128 f32,
+//        nk x (f64 x, f64 y) of imagesPts2D
 // out.bin: i32 ok_images, i32 ok_calib, i32 n; per image: i32 rows, cols, BGR bytes, gray bytes; f64 K[9], dist[5]
 #include <cstdio>
+#include <string>
 #include "Sfm.h"
 
 int main(int argc, char** argv) {
   if (argc < 4) return 2;
+  if (std::string(argv[1]) == "--features") {
+    StructFromMotion sfm;
+    if (!sfm.imagesLOAD(argv[2])) return 3;
+    sfm.extractFeature();
+    FILE* o = fopen(argv[3], "wb");
+    if (!o) return 2;
+    const int n = (int)sfm.grayImages().size();
+    fwrite(&n, 4, 1, o);
+    for (int i = 0; i < n; ++i) {
+      const cv::Mat& g = sfm.grayImages()[i];
+      fwrite(&g.rows, 4, 1, o);
+      fwrite(&g.cols, 4, 1, o);
+      fwrite(g.ptr(), 1, g.bytes.size(), o);
+      const int nk = (int)sfm.keypoints()[i].size();
+      fwrite(&nk, 4, 1, o);
+      for (const cv::KeyPoint& k : sfm.keypoints()[i]) {
+        const float f[5] = {k.pt.x, k.pt.y, k.size, k.angle, k.response};
+        fwrite(f, 4, 5, o);
+        fwrite(&k.octave, 4, 1, o);
+      }
+      fwrite(sfm.descriptors()[i].ptr(), 1, sfm.descriptors()[i].bytes.size(), o);
+      for (const cv::Point2d& p : sfm.points2D()[i]) fwrite(&p.x, 8, 2, o);
+    }
+    fclose(o);
+    return 0;
+  }
   if (std::string(argv[1]) == "--ply2pcd") {
     std::printf("%zu\n", StructFromMotion::convertPLYtoPCD(argv[2], argv[3]));
     return 0;

@@ -16,12 +16,16 @@ def sift_detect_and_compute(gray, n_octave_layers=3, contrast_threshold=0.04, ed
     n = C.c_int32(0)
     args = (ctx.h, g.ctypes.data, g.shape[0], g.shape[1], int(n_octave_layers), float(contrast_threshold), float(edge_threshold),
             float(sigma))
-    check(lib().sfmhip_sift_detect_and_compute(*args, 0, None, None, C.addressof(n)), "sfmhip_sift_detect_and_compute")
-    k = np.zeros((max(n.value, 1), 6), np.float32)
-    d = np.zeros((max(n.value, 1), 128), np.float32)
-    check(lib().sfmhip_sift_detect_and_compute(*args, n.value, k.ctypes.data, d.ctypes.data, C.addressof(n)),
-          "sfmhip_sift_detect_and_compute")
-    return k[:n.value], d[:n.value]
+    cap = max(1024, g.size // 48)            # one pass when the guess holds; the call reports the count if it does not
+    for _ in range(2):
+        k = np.zeros((cap, 6), np.float32)
+        d = np.zeros((cap, 128), np.float32)
+        rc = lib().sfmhip_sift_detect_and_compute(*args, cap, k.ctypes.data, d.ctypes.data, C.addressof(n))
+        if rc == 0 or n.value <= cap:
+            break
+        cap = n.value
+    check(rc, "sfmhip_sift_detect_and_compute")
+    return k[:n.value].copy(), d[:n.value].copy()
 
 
 def keypoints_to_points(kps):

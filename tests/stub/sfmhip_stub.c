@@ -160,6 +160,16 @@ int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_t* offsets,
   return SFMHIP_OK;
 }
 
+/* the SIFT front end is device code (its checker is numpy): the stand-in finds no keypoints */
+int sfmhip_sift_detect_and_compute(sfmhip_ctx* ctx, const uint8_t* gray, int rows, int cols, int n_octave_layers,
+                                   double contrast_threshold, double edge_threshold, double sigma, int capacity, float* keypoints,
+                                   float* descriptors, int32_t* n_keypoints) {
+  (void)ctx; (void)gray; (void)rows; (void)cols; (void)n_octave_layers; (void)contrast_threshold; (void)edge_threshold; (void)sigma;
+  (void)capacity; (void)keypoints; (void)descriptors;
+  *n_keypoints = 0;
+  return SFMHIP_OK;
+}
+
 int sfmhip_score_homography(sfmhip_ctx* ctx, int n_pairs, const int32_t* offsets, const double* left_xy, const double* right_xy,
                             const double* thresholds, double confidence, int max_iters, int32_t* inliers, uint8_t* mask,
                             int32_t* iterations) {

@@ -57,3 +57,92 @@ def test_descriptors_feed_the_matcher(ctx):
     shift = Ka[q, :2] - Kb[t, :2]
     good = (np.abs(shift[:, 0] - 8) < 1.0) & (np.abs(shift[:, 1] - 4) < 1.0)
     assert good.mean() > 0.8
+
+
+def test_cpp_host_mirror_extracts_the_same_features(ctx, tmp_path):
+    """imagesLOAD + extractFeature of the C++ mirror (reference src/Sfm.cpp:118-198, 257-330) on PNG files: its gray
+    images through the Python binding give the very same keypoints and descriptors, imagesPts2D = the keypoints' pt."""
+    import struct
+    import subprocess
+    PIL = pytest.importorskip("PIL.Image")
+    from sfm_danpipeline_amd import build
+    d = tmp_path / "imgs"
+    d.mkdir()
+    for i in range(2):
+        g = _blobs(120, 160, 40, 40 + i)
+        PIL.fromarray(np.stack([g, g, g], 2)).save(d / ("v%d.png" % i))
+    exe = build.build_io_demo()
+    r = subprocess.run([exe, "--features", str(d), str(tmp_path / "f.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    raw = open(tmp_path / "f.bin", "rb").read()
+    n = struct.unpack_from("<i", raw, 0)[0]
+    pos = 4
+    assert n == 2
+    for i in range(n):
+        rows, cols = struct.unpack_from("<ii", raw, pos); pos += 8
+        gray = np.frombuffer(raw, np.uint8, rows * cols, pos).reshape(rows, cols); pos += rows * cols
+        nk = struct.unpack_from("<i", raw, pos)[0]; pos += 4
+        K = np.frombuffer(raw, np.float32, 6 * nk, pos).reshape(nk, 6); pos += 24 * nk
+        D = np.frombuffer(raw, np.float32, 128 * nk, pos).reshape(nk, 128); pos += 512 * nk
+        P = np.frombuffer(raw, np.float64, 2 * nk, pos).reshape(nk, 2); pos += 16 * nk
+        Kp, Dp = features.sift_detect_and_compute(gray, ctx=ctx)
+        assert nk > 20 and np.array_equal(K.view(np.int32), Kp.view(np.int32)) and np.array_equal(D, Dp)
+        assert np.array_equal(P, K[:, :2].astype(np.float64))
+
+
+def _render_views(n_views=3, n_blobs=220, seed=17, h=240, w=320):
+    """a cloud of blobs seen by cameras on an arc (pinhole, f = 400): the image of a blob is a Gaussian at its
+    projection, its size falling with depth"""
+    rng = np.random.default_rng(seed)
+    X = np.stack([rng.uniform(-2.2, 2.2, n_blobs), rng.uniform(-1.6, 1.6, n_blobs), rng.uniform(5, 9, n_blobs)], 1)
+    rad, amp = rng.uniform(0.02, 0.07, n_blobs), rng.uniform(50, 180, n_blobs)
+    K = np.array([[400.0, 0, w / 2], [0, 400.0, h / 2], [0, 0, 1]])
+    yy, xx = np.mgrid[0:h, 0:w]
+    views, poses = [], []
+    for v in range(n_views):
+        a = 0.06 * (v - (n_views - 1) / 2)
+        R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        t = np.array([-0.5 * (v - (n_views - 1) / 2), 0.0, 0.0])
+        Xc = X @ R.T + t
+        uv = Xc[:, :2] / Xc[:, 2:] * 400.0 + [w / 2, h / 2]
+        img = np.full((h, w), 20.0)
+        for (u, vv), z, r, am in zip(uv, Xc[:, 2], rad, amp):
+            s = 400.0 * r / z
+            if -10 < u < w + 10 and -10 < vv < h + 10:
+                y0, y1, x0, x1 = int(max(vv - 5 * s, 0)), int(min(vv + 5 * s + 1, h)), int(max(u - 5 * s, 0)), int(min(u + 5 * s + 1, w))
+                img[y0:y1, x0:x1] += am * np.exp(-((xx[y0:y1, x0:x1] - u) ** 2 + (yy[y0:y1, x0:x1] - vv) ** 2) / (2 * s * s))
+        views.append(np.clip(img + rng.normal(0, 1.0, (h, w)), 0, 255).astype(np.uint8))
+        poses.append(np.hstack([R, t[:, None]]))
+    return views, poses, K
+
+
+def test_cfg1_shaped_pipeline_on_rendered_views(ctx):
+    """the call order of BASELINE.json's cfg1 (temple frames -> SIFT -> all-pairs getMatching -> findBestPair's
+    E-matrix score) on rendered views of one scene, every stage on the device"""
+    from sfm_danpipeline_amd import matcher, scoring
+    views, poses, K = _render_views()
+    feats = [features.sift_detect_and_compute(v, ctx=ctx) for v in views]
+    assert all(len(k) > 120 for k, _ in feats)
+    iset = matcher.ImageSet([d for _, d in feats], ctx=ctx)
+    pairs = [(0, 1), (0, 2), (1, 2)]
+    plan = matcher.MatchPlan(iset, np.array(pairs, np.int32))
+    iset.prepare_async()
+    plan.run_async(0.8)
+    cnt, q, t, d = plan.fetch()
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    pts = []
+    for p, (a, b) in enumerate(pairs):
+        qa, tb = q[off[p]:off[p + 1]], t[off[p]:off[p + 1]]
+        pts.append((features.keypoints_to_points(feats[a][0])[qa], features.keypoints_to_points(feats[b][0])[tb]))
+    # (Gaussian blobs all look alike: the ratio test keeps ~60 of ~200 per pair, below the reference's cut of 120 at
+    # :533, which real texture passes -- the cut is a parameter of the mirror)
+    assert all(len(a) >= 40 for a, _ in pts), [len(a) for a, _ in pts]
+    best = scoring.find_best_pair(pairs, pts, K, min_matches=40, ctx=ctx)
+    assert len(best) >= 1 and all(0.3 < float(r) <= 1.0 for r, _ in best)        # a third and more of the matches obey one
+    assert [float(r) for r, _ in best] == sorted(float(r) for r, _ in best)      # epipolar geometry to 1 px (look-alike blobs)
+    from oracle import sfm_oracle_score as SC
+    # (the restatement with the device's route to the five-point solutions: on data with this few inliers RANSAC runs its
+    # full 1000 iterations, and an ill-conditioned sample can give the action-matrix route a root more or less)
+    want = SC.find_best_pair_scores([(pairs[i], pts[i][0], pts[i][1]) for i in range(3)], K, min_matches=40,
+                                    solver=SC.five_point_hidden_variable)
+    assert [(float(r), v) for r, v in best] == [(float(r), v) for r, v in want]

@@ -136,12 +136,12 @@ def test_sharded_reduced_systems_sum_to_the_unsharded_one(orc):
         assert abs(cost - full[2]) <= 1e-12 * full[2]
 
 
-def test_cfg1_temple_plumbing_is_recorded_as_not_runnable_yet():
-    """BASELINE.json configs[0]: data/temple (10 x 640x480 PNG) through OpenCV BFMatcher + Ceres on the CPU.
-    Explicit record instead of silence: nothing in this repository reads an image yet (SURVEY.md section 8f-3,
-    the descriptor front end, is not built), OpenCV/Ceres are not installed, and /root/reference -- where the
-    PNGs live -- does not travel to the GPU box.  The call order of the plumbing (getMatching ->
-    triangulateViews -> adjustCurrentBundle on reference-shaped containers) IS exercised, on synthetic
-    features, by tests/test_gpu_host_cpp.py and tests/test_sanitizers_cpu.py."""
+def test_cfg1_temple_plumbing_is_recorded_as_not_runnable_here():
+    """BASELINE.json configs[0]: data/temple (640x480 PNGs) through the reference on the CPU.  Explicit record instead
+    of silence: the PNGs live under /root/reference, which does not travel to the GPU box, and this container has
+    no GPU -- the two never meet.  Everything the case needs is built and tested on other inputs: the PNG loader
+    reads data/temple here (tests/test_host_io.py), and the cfg1 call order imagesLOAD -> extractFeature (SIFT) ->
+    matchAllPairs -> findBestPair -> triangulateViews -> adjustCurrentBundle runs on rendered views on the GPU
+    (tests/test_gpu_sift.py::test_cfg1_shaped_pipeline_on_rendered_views, tests/test_gpu_host_cpp.py)."""
     import pytest
-    pytest.skip("cfg1 (data/temple plumbing): needs the f-3 descriptor front end (not built) or OpenCV (absent)")
+    pytest.skip("cfg1 on the temple images: the dataset (under /root/reference) and a GPU are never on the same machine")
