@@ -47,7 +47,7 @@ namespace {
 
 constexpr int CAMD = 40;     // doubles per camera table: R[9] t[3] dR/dw[27] pad
 constexpr int SC = 16;       // scalar slots at the tail of the all-reduce buffer (+ world)
-constexpr int FB_MAXN = 256;  // generic kernel: max observations per point (its T rows live in LDS: 37 KB)
+constexpr int FB_MAXN = 4096;  // sanity cap on the observations of one point (the pair path has no structural limit)
 
 struct Chunk {
   int sig_off;  // offset into sig_cams
@@ -692,14 +692,21 @@ __global__ __launch_bounds__(512) void ba_eliminate_mfma(BaDev d, const Chunk* _
   EL_STAMP(6, true);
 }
 
-// F^T F part of the reduced system from the camera-major observation list: thread per
-// observation, register accumulation of the camera's 6x6 block (upper, 21), the focal border
-// (6), F^T b (6), and the scalars Jf^2, Jf r, r^2; block-reduced, 36 atomics per workgroup.
+// The camera's own blocks for the pair path's points, from the camera-major list of their observations: thread per
+// observation, register accumulation of the 6x6 block (upper, 21), the focal border (6) and the rhs (6) -- F^T F
+// from a linearisation, minus the Schur terms T T^T, T t_f, T u from what ba_pp_points stored --; block-reduced,
+// 33 (+ 12) atomics per workgroup.
 __global__ __launch_bounds__(256) void ba_cam_blocks(BaDev d, const int* __restrict__ cptr,
                                                      const int* __restrict__ cpt,
                                                      const double2* __restrict__ cxy, int nsplit,
-                                                     int norms_only /* unscaled diagonal into dc only */) {
+                                                     int norms_only /* unscaled diagonal into dc only */,
+                                                     const int2* __restrict__ cslot /* (T row, point slot) per entry */,
+                                                     const double* __restrict__ T, const double* __restrict__ tfu) {
   __shared__ double sh[4][36];
+  __shared__ double sh2[4][33];
+  double q[33];  // the Schur part of the same 33 slots: T T^T (upper 21), T t_f (6), T u (6)
+#pragma unroll
+  for (int e = 0; e < 33; ++e) q[e] = 0.0;
   const int c = blockIdx.x / nsplit, part = blockIdx.x - c * nsplit;
   const int k0 = cptr[c], k1 = cptr[c + 1];
   const int len = k1 - k0;
@@ -731,24 +738,46 @@ __global__ __launch_bounds__(256) void ba_cam_blocks(BaDev d, const int* __restr
       a[21 + i] += o.Jc[i] * o.Jf[0] + o.Jc[6 + i] * o.Jf[1];
       a[27 + i] += o.Jc[i] * o.r0 + o.Jc[6 + i] * o.r1;
     }
-    a[33] += o.Jf[0] * o.Jf[0] + o.Jf[1] * o.Jf[1];
-    a[34] += o.Jf[0] * o.r0 + o.Jf[1] * o.r1;
-    a[35] += o.r0 * o.r0 + o.r1 * o.r1;
+    if (!norms_only) {
+      const int2 cs = cslot[k];
+      const double* Tt = T + 18 * (size_t)cs.x;
+      const double* tu = tfu + 6 * (size_t)cs.y;
+      double t[18];
+#pragma unroll
+      for (int m = 0; m < 18; ++m) t[m] = Tt[m];
+      int e2 = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = i; j < 6; ++j) q[e2++] += t[3 * i] * t[3 * j] + t[3 * i + 1] * t[3 * j + 1] + t[3 * i + 2] * t[3 * j + 2];
+        q[21 + i] += t[3 * i] * tu[0] + t[3 * i + 1] * tu[1] + t[3 * i + 2] * tu[2];
+        q[27 + i] += t[3 * i] * tu[3] + t[3 * i + 1] * tu[4] + t[3 * i + 2] * tu[5];
+      }
+    }
   }
+  // (the focal's own terms Jf^2, Jf r and the cost r^2 come from ba_pp_points: a[33..35] stay zero here)
 #pragma unroll
   for (int e = 0; e < 36; ++e) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) a[e] += __shfl_down(a[e], off);
   }
+#pragma unroll
+  for (int e = 0; e < 33; ++e) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q[e] += __shfl_down(q[e], off);
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) {
 #pragma unroll
     for (int e = 0; e < 36; ++e) sh[wave][e] = a[e];
+#pragma unroll
+    for (int e = 0; e < 33; ++e) sh2[wave][e] = q[e];
   }
   __syncthreads();
-  if (threadIdx.x < 36 && len > 0) {
+  if (threadIdx.x < 33 && len > 0) {
     const int e = threadIdx.x;
     const double v = sh[0][e] + sh[1][e] + sh[2][e] + sh[3][e];
+    const double sq = sh2[0][e] + sh2[1][e] + sh2[2][e] + sh2[3][e];
     double* S = red_S(d);
     double* g = red_g(d);
     double* gF = red_gF(d);
@@ -761,7 +790,6 @@ __global__ __launch_bounds__(256) void ba_cam_blocks(BaDev d, const int* __restr
         ++i;
       }
       if (e < 21 && rem == 0) atomic_add_f64(dc + r0 + i, v);
-      if (e == 33) atomic_add_f64(dc + fo, v);
     } else if (e < 21) {
       int i = 0, rem = e;
       while (rem >= 6 - i) {
@@ -769,142 +797,173 @@ __global__ __launch_bounds__(256) void ba_cam_blocks(BaDev d, const int* __restr
         ++i;
       }
       const int j = i + rem;
-      atomic_add_f64(S + (size_t)(r0 + i) * sld + r0 + j, v);
+      atomic_add_f64(S + (size_t)(r0 + i) * sld + r0 + j, v - sq);
       if (i == j) atomic_add_f64(dc + r0 + i, v);
     } else if (e < 27) {
-      atomic_add_f64(S + (size_t)(r0 + e - 21) * sld + fo, v);
-    } else if (e < 33) {
-      atomic_add_f64(g + r0 + e - 27, v);
-      atomic_add_f64(gF + r0 + e - 27, v);
-    } else if (e == 33) {
-      atomic_add_f64(S + (size_t)fo * sld + fo, v);
-      atomic_add_f64(dc + fo, v);
-    } else if (e == 34) {
-      atomic_add_f64(g + fo, v);
-      atomic_add_f64(gF + fo, v);
+      atomic_add_f64(S + (size_t)(r0 + e - 21) * sld + fo, v - sq);
     } else {
-      atomic_add_f64(red_sc(d) + 0, v);
+      atomic_add_f64(g + r0 + e - 27, v - sq);
+      atomic_add_f64(gF + r0 + e - 27, v);
     }
   }
 }
 
-// Generic path of the Schur correction: one wave per point (observations in blocks of 64); any observation count up to FB_MAXN,
-// cameras in any order, repeated cameras allowed.  Per-point atomics (no accumulation across
-// points).  The F^T F part of these points comes from ba_cam_blocks like everyone else's.
-__global__ __launch_bounds__(64) void ba_eliminate_generic(BaDev d, const int* __restrict__ plist, double radius,
-                                                           double lm_lo, double lm_hi, int rank) {
-  __shared__ __attribute__((aligned(16))) double s_T[(FB_MAXN + 1) * 18];
-  __shared__ int s_cam[FB_MAXN];
-  const int p = plist[blockIdx.x];
-  const int lane = threadIdx.x;
-  const int k0 = d.optr[p], n = d.optr[p + 1] - k0;
-  const int dim = d.ld /* row stride of S */, fo = 6 * d.nc;
-  const double X[3] = {d.pts[3 * p], d.pts[3 * p + 1], d.pts[3 * p + 2]};
-  const double sp[3] = {d.scale_p[3 * p], d.scale_p[3 * p + 1], d.scale_p[3 * p + 2]};
-  const double sf = *d.scale_f, focal = *d.focal;
-  // pass 1: the point block and its right-hand sides, observations in blocks of 64 (lane = observation)
-  double red[12];
-#pragma unroll
-  for (int e = 0; e < 12; ++e) red[e] = 0.0;
-  for (int ob = lane; ob < n; ob += 64) {
-    const int cam = d.ocam[k0 + ob];
-    s_cam[ob] = cam;
-    const double2 xy = d.oxy[k0 + ob];
-    ObsLin o;
-    obs_linearize(d.camd + (size_t)CAMD * cam, X, focal, xy.x, xy.y, d.scale_c + 6 * cam, sp, sf, o);
-    red[0] += o.Jp[0] * o.Jp[0] + o.Jp[3] * o.Jp[3];
-    red[1] += o.Jp[1] * o.Jp[0] + o.Jp[4] * o.Jp[3];
-    red[2] += o.Jp[1] * o.Jp[1] + o.Jp[4] * o.Jp[4];
-    red[3] += o.Jp[2] * o.Jp[0] + o.Jp[5] * o.Jp[3];
-    red[4] += o.Jp[2] * o.Jp[1] + o.Jp[5] * o.Jp[4];
-    red[5] += o.Jp[2] * o.Jp[2] + o.Jp[5] * o.Jp[5];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      red[6 + a] += o.Jp[a] * o.r0 + o.Jp[3 + a] * o.r1;
-      red[9 + a] += o.Jp[a] * o.Jf[0] + o.Jp[3 + a] * o.Jf[1];
+// Generic path of the Schur correction ("pair path"): points whose camera list is shared by few others (short runs),
+// is unsorted, has a camera twice, or is longer than 10.  Per-point atomic scatters cost ~2000 atomics per point (random
+// visibility at 200 cameras / 20 k points: 0.77 ms per linearisation against 0.055 for runs); here every block of S
+// is summed where it is written:
+//   ba_pp_points  one thread per point: C_p, its inverse factor, T_o = (Jc_o^T Jp_o) C_p^-1/2 of every observation
+//                 stored (18 doubles), t_f and u of the point stored, the focal / cost scalars reduced per workgroup;
+//   ba_pp_pairs   one wave per camera pair that some point sees together: S[a][b] -= sum over the pair's entries
+//                 (host-built list of (observation of a, observation of b)) of T_a T_b^T, 36 atomics per PAIR;
+//   ba_cam_blocks one workgroup per (camera, slice) over the camera-major list: F^T F as before, and with the stored
+//                 T, t_f, u the Schur terms of the camera's own blocks: S[c][c] -= T T^T, S[c][f] -= T t_f, g[c] -= T u.
+__global__ __launch_bounds__(256) void ba_pp_points(BaDev d, const int* __restrict__ plist, const int* __restrict__ obase,
+                                                    int n_list, double radius, double lm_lo, double lm_hi, int rank,
+                                                    double* __restrict__ T, double* __restrict__ tfu, int norms) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double sff = 0, gf = 0, jf2 = 0, jfr = 0, rr = 0, gmax = 0, nfail = 0;
+  if (i < n_list) {
+    const int p = plist[i];
+    const int k0 = d.optr[p], n = d.optr[p + 1] - k0;
+    const double X[3] = {d.pts[3 * p], d.pts[3 * p + 1], d.pts[3 * p + 2]};
+    double sp[3] = {1.0, 1.0, 1.0};
+    if (!norms) {
+      sp[0] = d.scale_p[3 * p];
+      sp[1] = d.scale_p[3 * p + 1];
+      sp[2] = d.scale_p[3 * p + 2];
     }
-  }
+    const double sf = norms ? 1.0 : *d.scale_f, focal = *d.focal;
+    double C[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0}, wf[3] = {0, 0, 0};
+    for (int o = 0; o < n; ++o) {
+      const int c = d.ocam[k0 + o];
+      const double2 xy = d.oxy[k0 + o];
+      ObsLin ol;
+      obs_linearize(d.camd + (size_t)CAMD * c, X, focal, xy.x, xy.y, norms ? nullptr : d.scale_c + 6 * c, sp, sf, ol);
+      C[0] += ol.Jp[0] * ol.Jp[0] + ol.Jp[3] * ol.Jp[3];
+      C[1] += ol.Jp[1] * ol.Jp[0] + ol.Jp[4] * ol.Jp[3];
+      C[2] += ol.Jp[1] * ol.Jp[1] + ol.Jp[4] * ol.Jp[4];
+      C[3] += ol.Jp[2] * ol.Jp[0] + ol.Jp[5] * ol.Jp[3];
+      C[4] += ol.Jp[2] * ol.Jp[1] + ol.Jp[5] * ol.Jp[4];
+      C[5] += ol.Jp[2] * ol.Jp[2] + ol.Jp[5] * ol.Jp[5];
 #pragma unroll
-  for (int e = 0; e < 12; ++e) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) red[e] += __shfl_xor(red[e], off);
-  }
-  double C[6] = {red[0], red[1], red[2], red[3], red[4], red[5]};
-  C[0] += fmin(fmax(C[0], lm_lo), lm_hi) / radius;
-  C[2] += fmin(fmax(C[2], lm_lo), lm_hi) / radius;
-  C[5] += fmin(fmax(C[5], lm_lo), lm_hi) / radius;
-  double Li[6];
-  const bool pd = chol3_inv(C, Li);
-  if (!pd) Li[0] = Li[1] = Li[2] = Li[3] = Li[4] = Li[5] = 0;
-  double* S = red_S(d);
-  double* g = red_g(d);
-  double* scv = red_sc(d);
-  // pass 2: T_o = (Jc_o^T Jp_o) C^-1/2 of every observation (linearised again: cheaper than keeping 18 doubles each)
-  for (int ob = lane; ob < n; ob += 64) {
-    const int cam = s_cam[ob];
-    const double2 xy = d.oxy[k0 + ob];
-    ObsLin o;
-    obs_linearize(d.camd + (size_t)CAMD * cam, X, focal, xy.x, xy.y, d.scale_c + 6 * cam, sp, sf, o);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const double w0 = o.Jc[i] * o.Jp[0] + o.Jc[6 + i] * o.Jp[3];
-      const double w1 = o.Jc[i] * o.Jp[1] + o.Jc[6 + i] * o.Jp[4];
-      const double w2 = o.Jc[i] * o.Jp[2] + o.Jc[6 + i] * o.Jp[5];
-      s_T[ob * 18 + 3 * i + 0] = w0 * Li[0];
-      s_T[ob * 18 + 3 * i + 1] = w0 * Li[1] + w1 * Li[2];
-      s_T[ob * 18 + 3 * i + 2] = w0 * Li[3] + w1 * Li[4] + w2 * Li[5];
+      for (int a = 0; a < 3; ++a) {
+        gp[a] += ol.Jp[a] * ol.r0 + ol.Jp[3 + a] * ol.r1;
+        wf[a] += ol.Jp[a] * ol.Jf[0] + ol.Jp[3 + a] * ol.Jf[1];
+      }
+      jf2 += ol.Jf[0] * ol.Jf[0] + ol.Jf[1] * ol.Jf[1];
+      jfr += ol.Jf[0] * ol.r0 + ol.Jf[1] * ol.r1;
+      rr += ol.r0 * ol.r0 + ol.r1 * ol.r1;
     }
-  }
-  double tf[3], u[3];
-  tf[0] = Li[0] * red[9];
-  tf[1] = Li[1] * red[9] + Li[2] * red[10];
-  tf[2] = Li[3] * red[9] + Li[4] * red[10] + Li[5] * red[11];
-  u[0] = Li[0] * red[6];
-  u[1] = Li[1] * red[6] + Li[2] * red[7];
-  u[2] = Li[3] * red[6] + Li[4] * red[7] + Li[5] * red[8];
-  if (lane == 0) {
-    atomic_add_f64(S + (size_t)fo * dim + fo, -(tf[0] * tf[0] + tf[1] * tf[1] + tf[2] * tf[2]));
-    atomic_add_f64(g + fo, -(tf[0] * u[0] + tf[1] * u[1] + tf[2] * u[2]));
-    if (!pd) atomic_add_f64(scv + 2, 1.0);
-    const double gm = fmax(fabs(red[6] / sp[0]), fmax(fabs(red[7] / sp[1]), fabs(red[8] / sp[2])));
-    atomic_max_pos_f64(scv + SC + rank, gm);
-  }
-  __syncthreads();
-  for (int ob = lane; ob < n; ob += 64) {  // border: S[cam][focal] -= T t_f ; g[cam] -= T u
-    const int r0 = 6 * s_cam[ob];
+    if (!norms) {
+      C[0] += fmin(fmax(C[0], lm_lo), lm_hi) / radius;
+      C[2] += fmin(fmax(C[2], lm_lo), lm_hi) / radius;
+      C[5] += fmin(fmax(C[5], lm_lo), lm_hi) / radius;
+      double Li[6];
+      const bool pd = chol3_inv(C, Li);
+      if (!pd) {
+        Li[0] = Li[1] = Li[2] = Li[3] = Li[4] = Li[5] = 0;
+        nfail = 1;
+      }
+      const double tf[3] = {Li[0] * wf[0], Li[1] * wf[0] + Li[2] * wf[1], Li[3] * wf[0] + Li[4] * wf[1] + Li[5] * wf[2]};
+      const double u[3] = {Li[0] * gp[0], Li[1] * gp[0] + Li[2] * gp[1], Li[3] * gp[0] + Li[4] * gp[1] + Li[5] * gp[2]};
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const double* T = s_T + ob * 18 + 3 * i;
-      atomic_add_f64(S + (size_t)(r0 + i) * dim + fo, -(T[0] * tf[0] + T[1] * tf[1] + T[2] * tf[2]));
-      atomic_add_f64(g + r0 + i, -(T[0] * u[0] + T[1] * u[1] + T[2] * u[2]));
-    }
-  }
-  const int npairs = n * (n + 1) / 2;
-  for (int q = lane; q < npairs; q += 64) {
-    // q -> (a <= b)
-    int a = 0, rem = q;
-    while (rem >= n - a) {
-      rem -= n - a;
-      ++a;
-    }
-    const int b = a + rem;
-    const int ca = s_cam[a], cb = s_cam[b];
-    const double* Ta = s_T + a * 18;
-    const double* Tb = s_T + b * 18;
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 6; ++j) {
-        const double v = Ta[3 * i] * Tb[3 * j] + Ta[3 * i + 1] * Tb[3 * j + 1] + Ta[3 * i + 2] * Tb[3 * j + 2];
-        if (ca < cb) {
-          atomic_add_f64(S + (size_t)(6 * ca + i) * dim + 6 * cb + j, -v);
-        } else if (ca > cb) {
-          atomic_add_f64(S + (size_t)(6 * cb + j) * dim + 6 * ca + i, -v);
-        } else if (a == b) {
-          if (i <= j) atomic_add_f64(S + (size_t)(6 * ca + i) * dim + 6 * ca + j, -v);
-        } else {  // same camera twice in one point: M + M^T, upper part
-          if (i <= j) atomic_add_f64(S + (size_t)(6 * ca + i) * dim + 6 * ca + j, -v);
-          if (j <= i) atomic_add_f64(S + (size_t)(6 * ca + j) * dim + 6 * ca + i, -v);
+      for (int a = 0; a < 3; ++a) {
+        tfu[6 * (size_t)i + a] = tf[a];
+        tfu[6 * (size_t)i + 3 + a] = u[a];
+      }
+      sff = tf[0] * tf[0] + tf[1] * tf[1] + tf[2] * tf[2];
+      gf = tf[0] * u[0] + tf[1] * u[1] + tf[2] * u[2];
+      gmax = fmax(fabs(gp[0] / sp[0]), fmax(fabs(gp[1] / sp[1]), fabs(gp[2] / sp[2])));
+      double* Tp = T + 18 * (size_t)obase[i];
+      for (int o = 0; o < n; ++o) {  // (linearised again: cheaper than keeping 12 + 6 doubles per observation)
+        const int c = d.ocam[k0 + o];
+        const double2 xy = d.oxy[k0 + o];
+        ObsLin ol;
+        obs_linearize(d.camd + (size_t)CAMD * c, X, focal, xy.x, xy.y, d.scale_c + 6 * c, sp, sf, ol);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          const double w0 = ol.Jc[r] * ol.Jp[0] + ol.Jc[6 + r] * ol.Jp[3];
+          const double w1 = ol.Jc[r] * ol.Jp[1] + ol.Jc[6 + r] * ol.Jp[4];
+          const double w2 = ol.Jc[r] * ol.Jp[2] + ol.Jc[6 + r] * ol.Jp[5];
+          Tp[18 * o + 3 * r + 0] = w0 * Li[0];
+          Tp[18 * o + 3 * r + 1] = w0 * Li[1] + w1 * Li[2];
+          Tp[18 * o + 3 * r + 2] = w0 * Li[3] + w1 * Li[4] + w2 * Li[5];
         }
       }
+    }
+  }
+  // workgroup sums: the focal's diagonal / rhs / column norm, the cost, failures, the gradient maximum
+  __shared__ double sh[4][8];
+  double v[7] = {jf2 - sff, jfr - gf, jf2, jfr, rr, nfail, gmax};
+#pragma unroll
+  for (int e = 0; e < 7; ++e)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[e] = e == 6 ? fmax(v[e], __shfl_down(v[e], off)) : v[e] + __shfl_down(v[e], off);
+  if ((threadIdx.x & 63) == 0)
+    for (int e = 0; e < 7; ++e) sh[threadIdx.x >> 6][e] = v[e];
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    const int e = threadIdx.x;
+    const double t = e == 6 ? fmax(fmax(sh[0][e], sh[1][e]), fmax(sh[2][e], sh[3][e])) : sh[0][e] + sh[1][e] + sh[2][e] + sh[3][e];
+    const int fo = 6 * d.nc;
+    double* scv = red_sc(d);
+    if (norms) {
+      if (e == 2) atomic_add_f64(red_dc(d) + fo, t);
+    } else if (e == 0) atomic_add_f64(red_S(d) + (size_t)fo * d.ld + fo, t);
+    else if (e == 1) atomic_add_f64(red_g(d) + fo, t);
+    else if (e == 2) atomic_add_f64(red_dc(d) + fo, t);
+    else if (e == 3) atomic_add_f64(red_gF(d) + fo, t);
+    else if (e == 4) atomic_add_f64(scv + 0, t);
+    else if (e == 5) {
+      if (t != 0.0) atomic_add_f64(scv + 2, t);
+    } else atomic_max_pos_f64(scv + SC + rank, t);
+  }
+}
+
+// one wave per camera pair: S[a][b] (a < b: the block right of the diagonal; a == b: a point that sees camera a twice,
+// the symmetric sum into the diagonal block's upper part) -= sum_e T(oa_e) T(ob_e)^T
+__global__ __launch_bounds__(64) void ba_pp_pairs(BaDev d, const int* __restrict__ pair_ptr, const int2* __restrict__ pair_cams,
+                                                  const int2* __restrict__ entries, const double* __restrict__ T) {
+  const int pr = blockIdx.x, lane = threadIdx.x;
+  const int e0 = pair_ptr[pr], e1 = pair_ptr[pr + 1];
+  const int2 cc = pair_cams[pr];
+  double acc[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+  for (int e = e0 + lane; e < e1; e += 64) {
+    const int2 en = entries[e];
+    const double* Ta = T + 18 * (size_t)en.x;
+    const double* Tb = T + 18 * (size_t)en.y;
+    double a[18], bq[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+      a[k] = Ta[k];
+      bq[k] = Tb[k];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[6 * i + j] += a[3 * i] * bq[3 * j] + a[3 * i + 1] * bq[3 * j + 1] + a[3 * i + 2] * bq[3 * j + 2];
+  }
+#pragma unroll
+  for (int k = 0; k < 36; ++k)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off);
+  if (lane == 0) {
+    double* S = red_S(d);
+    const int ra = 6 * cc.x, rb = 6 * cc.y;
+    if (cc.x != cc.y) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) atomic_add_f64(S + (size_t)(ra + i) * d.ld + rb + j, -acc[6 * i + j]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) atomic_add_f64(S + (size_t)(ra + i) * d.ld + ra + j, -(acc[6 * i + j] + acc[6 * j + i]));
+    }
   }
 }
 
@@ -2190,8 +2249,16 @@ struct sfmhip_ba {
   int* d_cpt = nullptr;
   double2* d_cxy = nullptr;
   int cam_split = 1;
-  int* d_fb_points = nullptr;
+  int* d_fb_points = nullptr;  // the pair path's points (sorted indices), their first T row
+  int* d_pp_obase = nullptr;
   int n_fb = 0;
+  int2* d_cslot = nullptr;     // camera-major list: (T row, point slot)
+  double* d_ppT = nullptr;     // 18 doubles per observation of the pair path
+  double* d_tfu = nullptr;     // t_f, u per point of the pair path
+  int* d_pair_ptr = nullptr;
+  int2* d_pair_cams = nullptr;
+  int2* d_pair_ent = nullptr;
+  int n_pairs_pp = 0;
   int elim_waves = 4;  // waves per workgroup of the long-run class of ba_eliminate_mfma (8, 4 or 2)
   // dissected reduced system (NdPlan below): built at the first solve (with world > 1 the camera graph is the
   // union over the ranks, which needs the all-reduce)
@@ -2419,7 +2486,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   //      classed by the width of the local Gram matrix: NB = ceil((6n+2)/16) column blocks
   std::vector<Chunk> chunks;
   std::vector<int> ids[8], sig_cams, fb;
-  constexpr int SHORT_RUN = 12;  // runs of at most this many points go to one-wave workgroups
+  constexpr int SHORT_RUN = 12;  // runs of at most this many points go to the pair path
   // points per workgroup: 2 workgroups of 4 waves are resident per CU (register-bound), so the launch runs in
   // rounds of 512 workgroups; a wave takes 4 points per iteration (~3.7 us at n = 10) and a fixed ~7 iterations'
   // worth of prologue, reductions and scatter (s_memtime stamps, scripts/elim_stamps.py).  Pick the run length
@@ -2461,8 +2528,8 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
       for (int k = 0; k < n; ++k) sig_cams.push_back(ocam[optr[sp] + k]);
       const int nb = (6 * n + 2 + 15) / 16;
       if (e - sp <= SHORT_RUN) {
-        ids[4 + nb - 1].push_back((int)chunks.size());
-        chunks.push_back(Chunk{so, n, sp, e - sp});
+        sig_cams.resize(so);  // (a camera list shared by few points: the pair path, per-pair instead of per-run sums)
+        for (int q = sp; q < e; ++q) fb.push_back(q);
       } else {
         const int parts = (e - sp + target - 1) / target;
         for (int q = 0; q < parts; ++q) {
@@ -2493,26 +2560,52 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
     for (int q : fb) add_clique(&ocam[optr[q]], optr[q + 1] - optr[q]);
     lap_("camera graph");
   }
-  // ---- camera-major copy of the GENERIC path's observations (sorted point index, xy) for ba_cam_blocks: the
-  //      MFMA path forms the F^T F part of its points itself, so this is empty for structured visibility
-  std::vector<int> cptr(n_cam + 1, 0), cpt;
+  // ---- the pair path's lists (ba_pp_points / ba_pp_pairs / ba_cam_blocks): its points in ascending sorted order, a
+  //      row of T per observation, the camera-major list of those observations, and per camera pair that a point
+  //      sees together the (row of a, row of b) entries
+  std::sort(fb.begin(), fb.end());
+  std::vector<int> cptr(n_cam + 1, 0), cpt, pp_obase(fb.size() + 1, 0), pair_ptr(1, 0);
+  std::vector<int2> cslot, pair_cams, pair_ent;
   std::vector<double> cxy;
   {
-    size_t nfo = 0;
-    for (int sp : fb) nfo += (size_t)(optr[sp + 1] - optr[sp]);
+    for (size_t i = 0; i < fb.size(); ++i) pp_obase[i + 1] = pp_obase[i] + (optr[fb[i] + 1] - optr[fb[i]]);
+    const size_t nfo = (size_t)pp_obase[fb.size()];
     cpt.resize(nfo);
+    cslot.resize(nfo);
     cxy.resize(2 * nfo);
     for (int sp : fb)
       for (int k = optr[sp]; k < optr[sp + 1]; ++k) cptr[ocam[k] + 1]++;
     for (int c = 0; c < n_cam; ++c) cptr[c + 1] += cptr[c];
     std::vector<int> fill(cptr.begin(), cptr.end() - 1);
-    for (int sp : fb)  // ascending sorted point index: the order inside a camera is the stable one
-      for (int k = optr[sp]; k < optr[sp + 1]; ++k) {
-        const int dst = fill[ocam[k]]++;
+    struct PE {
+      long long key;
+      int a, b;
+    };
+    std::vector<PE> pes;
+    for (size_t i = 0; i < fb.size(); ++i) {  // ascending sorted point index: the order inside a camera is the stable one
+      const int sp = fb[i], k0 = optr[sp], n = optr[sp + 1] - k0;
+      for (int o = 0; o < n; ++o) {
+        const int dst = fill[ocam[k0 + o]]++;
         cpt[dst] = sp;
-        cxy[2 * (size_t)dst] = oxy[2 * (size_t)k];
-        cxy[2 * (size_t)dst + 1] = oxy[2 * (size_t)k + 1];
+        cslot[dst] = make_int2(pp_obase[i] + o, (int)i);
+        cxy[2 * (size_t)dst] = oxy[2 * (size_t)(k0 + o)];
+        cxy[2 * (size_t)dst + 1] = oxy[2 * (size_t)(k0 + o) + 1];
+        for (int o2 = o + 1; o2 < n; ++o2) {
+          int ca = ocam[k0 + o], cb = ocam[k0 + o2], ra = pp_obase[i] + o, rb = pp_obase[i] + o2;
+          if (ca > cb) std::swap(ca, cb), std::swap(ra, rb);
+          pes.push_back(PE{(long long)ca * n_cam + cb, ra, rb});
+        }
       }
+    }
+    std::sort(pes.begin(), pes.end(), [](const PE& x, const PE& y) { return x.key != y.key ? x.key < y.key : (x.a != y.a ? x.a < y.a : x.b < y.b); });
+    for (size_t e = 0; e < pes.size(); ++e) {
+      if (e == 0 || pes[e].key != pes[e - 1].key) {
+        if (e) pair_ptr.push_back((int)e);
+        pair_cams.push_back(make_int2((int)(pes[e].key / n_cam), (int)(pes[e].key % n_cam)));
+      }
+      pair_ent.push_back(make_int2(pes[e].a, pes[e].b));
+    }
+    if (!pes.empty()) pair_ptr.push_back((int)pes.size());
     b->cam_split = std::max(1, std::min(64, 1024 / std::max(n_cam, 1)));
   }
   lap_("camera-major copy");
@@ -2563,6 +2656,13 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   BA_A(b->d_cpt, cpt.size());
   BA_A(b->d_cxy, cpt.size());
   BA_A(b->d_fb_points, fb.size());
+  BA_A(b->d_pp_obase, pp_obase.size());
+  BA_A(b->d_cslot, cslot.size());
+  BA_A(b->d_ppT, 18 * cslot.size());
+  BA_A(b->d_tfu, 6 * fb.size());
+  BA_A(b->d_pair_ptr, pair_ptr.size());
+  BA_A(b->d_pair_cams, pair_cams.size());
+  BA_A(b->d_pair_ent, pair_ent.size());
 #undef BA_A
   if (rc != SFMHIP_OK) {
     sfmhip_ba_destroy(b);
@@ -2588,6 +2688,12 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   SFM_HIP_TRY(up(b->d_cpt, cpt.data(), cpt.size() * 4));
   SFM_HIP_TRY(up(b->d_cxy, cxy.data(), cxy.size() * 8));
   SFM_HIP_TRY(up(b->d_fb_points, fb.data(), fb.size() * 4));
+  SFM_HIP_TRY(up(b->d_pp_obase, pp_obase.data(), pp_obase.size() * 4));
+  SFM_HIP_TRY(up(b->d_cslot, cslot.data(), cslot.size() * sizeof(int2)));
+  SFM_HIP_TRY(up(b->d_pair_ptr, pair_ptr.data(), pair_ptr.size() * 4));
+  SFM_HIP_TRY(up(b->d_pair_cams, pair_cams.data(), pair_cams.size() * sizeof(int2)));
+  SFM_HIP_TRY(up(b->d_pair_ent, pair_ent.data(), pair_ent.size() * sizeof(int2)));
+  b->n_pairs_pp = (int)pair_cams.size();
   lap_("uploads");
   SFM_HIP_TRY(hipHostMalloc((void**)&b->h_sc, sizeof(double) * (SC + 64 + 16 + 1), hipHostMallocDefault));
   SFM_HIP_TRY(hipHostGetDevicePointer((void**)&b->h_sc_dev, b->h_sc, 0));
@@ -2724,9 +2830,12 @@ static int ba_prepare_scale(sfmhip_ba* b, int jacobi) {
   if (b->np) hipLaunchKernelGGL(ba_point_norms, dim3((b->np + 255) / 256), dim3(256), 0, st, d, jacobi);
   if (b->no && jacobi) {
     ba_launch_eliminate(b, 1.0, 1e-6, 1e32, 1);
-    if (b->n_fb)
+    if (b->n_fb) {
+      hipLaunchKernelGGL(ba_pp_points, dim3((b->n_fb + 255) / 256), dim3(256), 0, st, d, b->d_fb_points, b->d_pp_obase, b->n_fb, 1.0,
+                         1e-6, 1e32, b->rank, b->d_ppT, b->d_tfu, 1);
       hipLaunchKernelGGL(ba_cam_blocks, dim3(b->nc * b->cam_split), dim3(256), 0, st, d, b->d_cptr, b->d_cpt, b->d_cxy,
-                         b->cam_split, 1);
+                         b->cam_split, 1, b->d_cslot, b->d_ppT, b->d_tfu);
+    }
   }
   SFM_HIP_TRY(hipGetLastError());
   SFM_TRY(ba_allreduce(b, d.red + tail, (size_t)b->ld + SC));
@@ -2769,17 +2878,19 @@ static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_o
   }
   const double inv_radius = 1.0 / radius;
   int nl = 0;
-  if (b->n_fb) {  // F^T F of the generic path's points (the MFMA path forms its own)
-    hipLaunchKernelGGL(ba_cam_blocks, dim3(b->nc * b->cam_split), dim3(256), 0, st, d, b->d_cptr, b->d_cpt, b->d_cxy,
-                       b->cam_split, 0);
-    ++nl;
-  }
   nl += ba_launch_eliminate(b, inv_radius, o->min_lm_diagonal, o->max_lm_diagonal, 0);
-  if (b->n_fb)
-    hipLaunchKernelGGL(ba_eliminate_generic, dim3(b->n_fb), dim3(64), 0, st, d, b->d_fb_points, radius,
-                       o->min_lm_diagonal, o->max_lm_diagonal, b->rank);
+  if (b->n_fb) {  // the pair path: points, then the blocks of camera pairs and of the cameras themselves
+    hipLaunchKernelGGL(ba_pp_points, dim3((b->n_fb + 255) / 256), dim3(256), 0, st, d, b->d_fb_points, b->d_pp_obase, b->n_fb,
+                       radius, o->min_lm_diagonal, o->max_lm_diagonal, b->rank, b->d_ppT, b->d_tfu, 0);
+    if (b->n_pairs_pp)
+      hipLaunchKernelGGL(ba_pp_pairs, dim3(b->n_pairs_pp), dim3(64), 0, st, d, b->d_pair_ptr, b->d_pair_cams, b->d_pair_ent,
+                         (const double*)b->d_ppT);
+    hipLaunchKernelGGL(ba_cam_blocks, dim3(b->nc * b->cam_split), dim3(256), 0, st, d, b->d_cptr, b->d_cpt, b->d_cxy,
+                       b->cam_split, 0, b->d_cslot, b->d_ppT, b->d_tfu);
+    nl += 3;
+  }
   SFM_HIP_TRY(hipGetLastError());
-  b->launches += 1 + nl + (b->n_fb > 0);
+  b->launches += 1 + nl;
   if (b->ctx->timing) {
     SFM_HIP_TRY(hipEventRecord(b->ev[1], st));
     b->ev_on[1] = true;

@@ -211,9 +211,8 @@ def test_reduced_layout_follows_the_camera_graph(ctx, monkeypatch):
 
 
 def test_tracks_longer_than_a_wave(ctx, orc):
-    """Points seen by 70 of 80 cameras (the generic elimination path, observations in blocks of 64: the reference,
-    Ceres, has no limit on a track's length) against the oracle; beyond 256 views of one point the problem is
-    refused, loudly."""
+    """Points seen by 70 of 80 cameras, and by 260 of 300 (the pair path: the reference, Ceres, has no limit on a
+    track's length) against the oracle."""
     pb = synth.ba_problem(80, 120, 70, seed=21)
     opts = dict(max_time_s=0.0, max_iterations=4)
     c, p, f, s = bundle.ba_solve(*_ba_args(pb), opts=bundle.default_opts(**opts), ctx=ctx)
@@ -221,9 +220,12 @@ def test_tracks_longer_than_a_wave(ctx, orc):
     assert (s.termination, s.iterations, s.successful_steps) == (so.termination, so.iterations, so.successful_steps)
     assert abs(s.final_cost - so.final_cost) <= BA_COST_RTOL * so.final_cost
     assert np.allclose(c, co, rtol=BA_PARAM_RTOL, atol=1e-9) and np.allclose(p, po, rtol=BA_PARAM_RTOL, atol=1e-9)
-    big = synth.ba_problem(300, 4, 260, seed=22)
-    with pytest.raises(_lib.SfmHipError, match="status -5"):      # SFMHIP_ERR_UNSUPPORTED
-        bundle.BaProblem(300, 4, big["obs_cam"], big["obs_pt"], big["obs_xy"], ctx=ctx)
+    big = synth.ba_problem(300, 6, 260, seed=22)
+    o2 = dict(max_time_s=0.0, max_iterations=2)
+    c, p, f, s = bundle.ba_solve(*_ba_args(big), opts=bundle.default_opts(**o2), ctx=ctx)
+    co, po, fo, so = orc.ba_solve(*_ba_args(big), opts=orc.default_opts(**o2))
+    assert (s.termination, s.iterations, s.successful_steps) == (so.termination, so.iterations, so.successful_steps)
+    assert np.allclose(c, co, rtol=BA_PARAM_RTOL, atol=1e-9) and np.allclose(p, po, rtol=BA_PARAM_RTOL, atol=1e-9)
 
 
 def test_noise_free_scene_converges_to_zero_cost(ctx):
