@@ -13,18 +13,19 @@
 // upper triangle is formed (= a column-major lower triangle for the Cholesky kernels).
 //
 // Kernels per LM iteration:
-//   ba_cam_blocks     F^T F part of the reduced system (camera 6x6 blocks, focal border, F^T b,
-//                     cost) from a camera-major copy of the observations.
-//   ba_eliminate_mfma<NB>  Schur correction.  A workgroup owns a run of points of one signature;
-//                     16 lanes linearise the (<=10) observations of a point (4 points per wave
-//                     and iteration), DPP-reduce the 3x3 point block, publish
-//                     T_o = (Jc^T Jp) C^-1/2 as 3 rows of a 12 x 64 LDS panel, and the wave adds
-//                     the panel's Gram matrix on v_mfma_f64_16x16x4_f64; one f64 atomic scatter
-//                     into S per workgroup.
+//   ba_eliminate_mfma<NB>  ONE linearisation forms all of S for the points in long runs.  A workgroup owns a run of
+//                     points of one signature; 16 lanes linearise the (<=10) observations of a point (4 points per
+//                     wave and iteration), DPP-reduce the 3x3 point block, publish T_o = (Jc^T Jp) C^-1/2 as 3 rows
+//                     of a 12 x 64 LDS panel, and the wave adds the panel's Gram matrix on v_mfma_f64_16x16x4_f64;
+//                     F^T F accumulates in LDS next to it; one f64 atomic per entry of the block and workgroup.
+//   ba_pp_points / ba_pp_pairs / ba_cam_blocks   the pair path for every other point (short runs, unsorted or
+//                     repeated cameras, long tracks): T rows stored per observation, S blocks summed per camera
+//                     pair and per camera.
 //   ba_finalize       LM diagonal (clamped squared column norms / radius) onto S, gradient max.
-//   chol_step2        dense blocked Cholesky of S (two 32-column panels per launch) with the rhs
-//                     carried as an extra row (y = L^-1 g) and the identity as nt extra tile rows
-//                     (X = L^-T); chol_apply_inverse then forms z = X y.
+//   chol_step2 / chol_step2_chains   blocked Cholesky of S (two 32-column panels per launch) with the rhs carried
+//                     as an extra row (y = L^-1 g) and the identity as extra tile rows (X = L^-T): dense, or on
+//                     the independent chains + separator of a dissected camera graph (nd_gather, nd_combine,
+//                     nd_xy, nd_w).
 //   ba_cand_cams      candidate cameras / focal and their rotation tables.
 //   ba_backsub        per point: back-substitution, model cost change, candidate point,
 //                     candidate cost.
