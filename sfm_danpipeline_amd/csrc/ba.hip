@@ -1071,8 +1071,10 @@ __device__ __forceinline__ int lds_wait_ge(const int* flag, int need) {
 //   the pending panels' rows of block rows a, b and r are staged in LDS once (C2_OFF_PAB/PRW) and
 //   every other fold (D_ba = tile(b,a), T_a = tile(r,a), D_bb, T_b = tile(r,b)) takes its operands
 //   from there; POTRF(D_aa) | Y = D_ba L_aa^-T (= L_ba) and X_a = T_a L_aa^-T trailing it | U2 |
-//   POTRF(D_bb) | X_b = T_b L_bb^-T trailing it.  The owner has no tile row of its own; it stores L_aa,
-//   L_ba, L_bb.  The row blocks 0..b of X (see chol_step2) are further tile rows like any other.
+//   POTRF(D_bb) | X_b = T_b L_bb^-T trailing it.  The owner has no tile row of its own and stores nothing:
+//   the diagonal tiles stay as they were read (no later launch reads them, and the workgroups of this launch may
+//   start at any time -- a launch that shares the device with another stream or process does not start as one
+//   round); it reports a failed pivot.  The row blocks 0..b of X (see chol_step2) are further tile rows like any other.
 // f64 MFMA throughput (16 FMA/clock/SIMD on gfx950, no more than the vector ALU) is what the
 // first half of a launch is short of: the folds are ordered per SIMD by hand (priorities do not
 // order the MFMAs of co-resident waves) and the right column halves of D_bb and T_b, which the
@@ -1530,8 +1532,7 @@ __device__ __forceinline__ void chol2_panel(double* __restrict__ A, double* __re
     bool bad = false;
     const int c0 = pass ? b0 : a0;
     chol2_potrf_blocks(acc, sAll + opaque(pass * 3 * T), sdi_all + opaque(pass * CB), s_flag + opaque(F_PROG_A + pass),
-                       bad, lane, owner ? A + (size_t)c0 * ld + c0 : nullptr, ld,
-                       pass ? &s_flag[F_DBB_HI] : nullptr);
+                       bad, lane, nullptr, ld, pass ? &s_flag[F_DBB_HI] : nullptr);
     C2_STAMP(pass ? 4 : 2);
     if (owner && bad && lane == 0) atomicExch(info, c0 + 1);  // the host discards the step
     if (!pass) {
@@ -1658,7 +1659,7 @@ __device__ __forceinline__ void chol2_panel(double* __restrict__ A, double* __re
     size_t stride;
     bool on = lane < CB;
     if (wave == 2) {
-      out = A + (size_t)a0 * ld + b0 + i, stride = ld, on = on && owner;
+      out = A + (size_t)a0 * ld + b0 + i, stride = ld, on = false;  // (Y stays in LDS, see chol_step2)
     } else if (RHS) {
       out = y + c0, stride = 1, on = lane == 0;
     } else {
@@ -1802,10 +1803,9 @@ __global__ __launch_bounds__(C2_WAVES * 64) void chol_step2(double* __restrict__
 }
 
 // Several independent matrices ("chains": the interiors of a dissected camera graph, see NdPlan) at the same
-// panel pair k2 in ONE launch.  ALL panel workgroups come first in the grid, the trailing workgroups after them:
-// the panel workgroups of a matrix read its diagonal tiles D_aa, D_ba, D_bb from global memory and the owner
-// stores L_aa, L_ba, L_bb over them ~25 k cycles later, so every panel workgroup has to be resident from the
-// start of the launch (one workgroup per CU: the host keeps their number within the device's CUs).
+// panel pair k2 in ONE launch.  ALL panel workgroups come first in the grid, the trailing workgroups after them
+// (the panel workgroups are the long ones: they start in the first round; the host keeps their number within the
+// device's CUs).
 constexpr int ND_MAX = 8;
 struct ChainSet {
   int n;
@@ -2356,7 +2356,7 @@ extern "C" void sfmhip_ba_default_opts(sfmhip_ba_opts* o) {
   o->max_lm_diagonal = 1e32;
   o->jacobi_scaling = 1;
   o->max_consecutive_invalid = 5;
-  o->verbose = 0;
+  o->verbose = getenv("SFMHIP_BA_VERBOSE") ? 1 : 0;  // (diagnosis: the LM log on stderr)
 }
 
 extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const int32_t* obs_cam,
@@ -2607,7 +2607,9 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
       pair_ent.push_back(make_int2(pes[e].a, pes[e].b));
     }
     if (!pes.empty()) pair_ptr.push_back((int)pes.size());
-    b->cam_split = std::max(1, std::min(64, 1024 / std::max(n_cam, 1)));
+    // (a workgroup per (camera, slice): ~1024 entries each, so that the 69-value block reduction is paid once per four
+    // entries of a thread: 57 -> 25 us at 200 cameras x 1000 observations)
+    b->cam_split = (int)std::max<size_t>(1, std::min<size_t>(64, nfo / (size_t)std::max(n_cam, 1) / 1024));
   }
   lap_("camera-major copy");
   // ---- device storage
@@ -3040,7 +3042,8 @@ static int ba_nd_build(sfmhip_ba* b) {
     }
     const int sep_t = (int)((6 * e.sep.size() + 1 + 63) / 64) * 2;
     e.cost = 0.5 * max_t + 0.5 * sep_t + 2.5;
-    // every panel workgroup of a launch has to be resident (chol_step2_chains): launch 0 has N_i + 2 per chain
+    // the panel workgroups of a launch in one round of workgroups (a second round doubles the launch): launch 0
+    // has N_i + 2 per chain
     int pan = 0;
     for (auto& c : e.chains) pan += (int)((6 * c.size() + 63) / 64) * 2 + sep_t + 2;
     if (pan > n_cu_) e.cost = 1e300;
@@ -3288,9 +3291,6 @@ static int ba_reduced_solve(sfmhip_ba* b) {
       // launch 0 has no pending update; later launches: the tiles right of the panels, and those of X
       const int ntrail = k2 == 0 ? 0 : m2 * (m2 + 1) / 2 + m2 + 2 * k2 * m2;
       const int npan = m2 + 2 + 2 * k2 + 2;
-      // (every panel workgroup has to be resident when the launch starts: the owner overwrites the diagonal
-      // tiles the others read; one workgroup per CU)
-      if (npan > b->ctx->n_cu) return SFMHIP_ERR_UNSUPPORTED;
       int tpw = 4;  // trailing tiles per workgroup: the fewest that keep the launch to one round of workgroups
       while (tpw < C2_WAVES && npan + (ntrail + tpw - 1) / tpw > b->ctx->n_cu) ++tpw;
       hipLaunchKernelGGL(chol_step2, dim3(npan + (ntrail + tpw - 1) / tpw), dim3(C2_WAVES * 64), C2_LDS_BYTES, st, A, y,
@@ -3461,7 +3461,9 @@ static int ba_one_iteration(sfmhip_ba* b, const sfmhip_ba_opts* o, bool timing_o
     }
     s.radius /= s.decrease_factor;
     s.decrease_factor *= 2.0;
-    if (o->verbose) fprintf(stderr, "[sfmhip-ba] it %d invalid step (info %d), radius %.3e\n", s.iter, sc.info, s.radius);
+    if (o->verbose)
+      fprintf(stderr, "[sfmhip-ba] it %d invalid step (info %d, point blocks not PD %.0f, model cost change %.6e, candidate cost %.6e, |step|^2 %.6e), radius %.3e\n",
+              s.iter, sc.info, sc.nfail, sc.mcc, sc.cost_c, sc.step_n2, s.radius);
     return SFMHIP_OK;
   }
   s.invalid = 0;

@@ -1,5 +1,6 @@
 // common.h -- context object and error plumbing shared by the HIP translation units.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -45,6 +46,10 @@ static inline int sfm_dev_alloc(T** p, size_t n) {
     g_sfmhip_last_hip_error = (int)e;
     return SFMHIP_ERR_ALLOC;
   }
+  // SFMHIP_POISON=1 (tests): fresh device memory holds 0xFF bytes (NaN as float / double, -1 as int) instead of
+  // whatever the driver hands out -- a kernel that reads before it writes shows up as NaN, not as a rare flake
+  static const bool poison = getenv("SFMHIP_POISON") != nullptr;
+  if (poison) hipMemset(v, 0xFF, (n ? n : 1) * sizeof(T));
   *p = (T*)v;
   return SFMHIP_OK;
 }
