@@ -48,6 +48,11 @@ namespace {
 
 constexpr int CAMD = 40;     // doubles per camera table: R[9] t[3] dR/dw[27] pad
 constexpr int SC = 16;       // scalar slots at the tail of the all-reduce buffer (+ world)
+// ba_backsub's four sums land in RED2_SLOTS x 4 slots (workgroup mod RED2_SLOTS) that the host adds up: atomics of
+// many workgroups on ONE address drain at ~44 ns each on this device (1563 workgroups on 4 addresses: 69 us).
+// Layout of red2: [0..8) sums | RED2_SLOTS x 4 slots | RED2_TMP | RED2_INFO (an int) | pad; [0, RED2_SUM_N) is all-reduced.
+constexpr int RED2_SLOTS = 32, RED2_SUM_N = 8 + 4 * RED2_SLOTS, RED2_TMP = RED2_SUM_N, RED2_INFO = RED2_SUM_N + 1,
+              RED2_N = RED2_SUM_N + 8;
 constexpr int FB_MAXN = 4096;  // sanity cap on the observations of one point (the pair path has no structural limit)
 
 struct Chunk {
@@ -82,7 +87,7 @@ struct BaDev {
   double* red;
   double* z;     // dim solution
   double* xinv;  // ld x ld, column-major like S's triangle: the identity on entry to the factorisation, L^-T after it
-  double* red2;  // 16 scalars of the step evaluation
+  double* red2;  // 16 scalars of the step evaluation + RED2_SLOTS x 4 partial sums of ba_backsub
   int* info;     // cholesky failure flag
 };
 
@@ -226,9 +231,9 @@ __device__ __forceinline__ void obs_residual(CP cd, const double X[3], double fo
 }
 
 // unscaled Jacobian; sc/sp/sf (may be null -> 1) scale the columns
-template <typename CP>
-__device__ __forceinline__ void obs_linearize(CP cd, const double X[3], double focal, double ox, double oy,
-                                              const double* sc, const double* sp, double sf, ObsLin& o) {
+template <typename CP, typename SP>
+__device__ __forceinline__ void obs_linearize_g(CP cd, const double X[3], double focal, double ox, double oy,
+                                                SP sc, const double* sp, double sf, ObsLin& o) {
   const double px = cd[0] * X[0] + cd[1] * X[1] + cd[2] * X[2] + cd[9];
   const double py = cd[3] * X[0] + cd[4] * X[1] + cd[5] * X[2] + cd[10];
   const double pz = cd[6] * X[0] + cd[7] * X[1] + cd[8] * X[2] + cd[11];
@@ -263,6 +268,20 @@ __device__ __forceinline__ void obs_linearize(CP cd, const double X[3], double f
   }
   o.Jf[0] = xp * sf;
   o.Jf[1] = yp * sf;
+}
+
+template <typename CP>
+__device__ __forceinline__ void obs_linearize(CP cd, const double X[3], double focal, double ox, double oy,
+                                              const double* sc, const double* sp, double sf, ObsLin& o) {
+  obs_linearize_g<CP, const double*>(cd, X, focal, ox, oy, sc, sp, sf, o);
+}
+// A pointer the whole wave shares, in the constant address space: loads through it are scalar loads (one request per
+// wave into SGPRs) instead of 64 lanes fetching the same address through the vector memory pipe.
+typedef __attribute__((address_space(4))) const double cst_double;
+__device__ __forceinline__ cst_double* wave_uniform_ptr(const double* p) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return (cst_double*)(((unsigned long long)hi << 32) | lo);
 }
 
 // 3x3 SPD: inverse of the Cholesky factor (Li lower, C^-1 = Li^T Li); returns false if not PD.
@@ -2103,9 +2122,24 @@ __global__ void ba_cand_cams(BaDev d, const unsigned char* __restrict__ cam_used
   }
 }
 
-// per point: back-substitute, model cost change, candidate point + candidate cost
+// per point: back-substitute, model cost change, candidate point + candidate cost.
+// LPP lanes per point (a quad or a pair of lanes, or one): the point's observations are dealt over them and the
+// sums meet by DPP inside the quad, every lane of which then holds the same totals bit for bit.  One linearisation
+// per observation: with a_o = -Jc_o z_c - Jf_o z_f (known before the point's step) and m_o = a_o + Jp_o s the model
+// cost change  sum_o m_o.(r_o + m_o/2)  is
+//   sum a.r + s.(sum Jp^T r) + (sum |a|^2)/2 + s.(sum Jp^T a) + s^T (sum Jp^T Jp) s / 2,
+// all of them sums the first pass forms next to C_p and e = sum Jp^T (r + a); the second pass only evaluates the
+// candidate's residuals.
+template <int LPP>
+__device__ __forceinline__ double lpp_sum(double v) {
+  if (LPP >= 2) v += dpp_f64<0xB1>(v);  // quad_perm [1,0,3,2]
+  if (LPP >= 4) v += dpp_f64<0x4E>(v);  // quad_perm [2,3,0,1]
+  return v;
+}
+template <int LPP>
 __global__ __launch_bounds__(256) void ba_backsub(BaDev d, double radius, double lm_lo, double lm_hi) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = t / LPP, sub = t % LPP;
   double mcc = 0, cost_c = 0, sn2 = 0, cn2 = 0;
   if (p < d.np) {
     const double X[3] = {d.pts[3 * p], d.pts[3 * p + 1], d.pts[3 * p + 2]};
@@ -2113,18 +2147,35 @@ __global__ __launch_bounds__(256) void ba_backsub(BaDev d, double radius, double
     const double sf = *d.scale_f, focal = *d.focal, focal_c = *d.focal_c;
     const double zf = d.z[6 * d.nc];
     const int k0 = d.optr[p], k1 = d.optr[p + 1];
-    double C[6] = {0, 0, 0, 0, 0, 0}, e[3] = {0, 0, 0};
-    for (int k = k0; k < k1; ++k) {
+    double C[6] = {0, 0, 0, 0, 0, 0}, pr[3] = {0, 0, 0}, pa[3] = {0, 0, 0}, ar = 0, aa = 0;
+    for (int k = k0 + sub; k < k1; k += LPP) {
       const int c = d.ocam[k];
       const double2 xy = d.oxy[k];
       ObsLin o;
-      obs_linearize(d.camd + (size_t)CAMD * c, X, focal, xy.x, xy.y, d.scale_c + 6 * c, sp, sf, o);
-      double s0 = o.r0 - o.Jf[0] * zf, s1 = o.r1 - o.Jf[1] * zf;
+      double a0, a1;
+      // (the points of a run see the same cameras: the wave's lanes then want the same table, which goes through
+      // the scalar cache -- with 51 doubles per observation the kernel is otherwise bound by the number of vector
+      // memory instructions, 16 cycles each whatever the lanes ask for)
+      if (__builtin_amdgcn_ballot_w64(c != __builtin_amdgcn_readfirstlane(c)) == 0) {
+        cst_double* const zc = wave_uniform_ptr(d.z + 6 * c);
+        obs_linearize_g(wave_uniform_ptr(d.camd + (size_t)CAMD * c), X, focal, xy.x, xy.y,
+                        wave_uniform_ptr(d.scale_c + 6 * c), sp, sf, o);
+        a0 = -o.Jf[0] * zf, a1 = -o.Jf[1] * zf;
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const double zj = d.z[6 * c + j];
-        s0 -= o.Jc[j] * zj;
-        s1 -= o.Jc[6 + j] * zj;
+        for (int j = 0; j < 6; ++j) {
+          const double zj = zc[j];
+          a0 -= o.Jc[j] * zj;
+          a1 -= o.Jc[6 + j] * zj;
+        }
+      } else {
+        obs_linearize(d.camd + (size_t)CAMD * c, X, focal, xy.x, xy.y, d.scale_c + 6 * c, sp, sf, o);
+        a0 = -o.Jf[0] * zf, a1 = -o.Jf[1] * zf;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const double zj = d.z[6 * c + j];
+          a0 -= o.Jc[j] * zj;
+          a1 -= o.Jc[6 + j] * zj;
+        }
       }
       C[0] += o.Jp[0] * o.Jp[0] + o.Jp[3] * o.Jp[3];
       C[1] += o.Jp[1] * o.Jp[0] + o.Jp[4] * o.Jp[3];
@@ -2133,8 +2184,21 @@ __global__ __launch_bounds__(256) void ba_backsub(BaDev d, double radius, double
       C[4] += o.Jp[2] * o.Jp[1] + o.Jp[5] * o.Jp[4];
       C[5] += o.Jp[2] * o.Jp[2] + o.Jp[5] * o.Jp[5];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) e[a] += o.Jp[a] * s0 + o.Jp[3 + a] * s1;
+      for (int a = 0; a < 3; ++a) {
+        pr[a] += o.Jp[a] * o.r0 + o.Jp[3 + a] * o.r1;
+        pa[a] += o.Jp[a] * a0 + o.Jp[3 + a] * a1;
+      }
+      ar += a0 * o.r0 + a1 * o.r1;
+      aa += a0 * a0 + a1 * a1;
     }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) C[j] = lpp_sum<LPP>(C[j]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) pr[j] = lpp_sum<LPP>(pr[j]), pa[j] = lpp_sum<LPP>(pa[j]);
+    ar = lpp_sum<LPP>(ar);
+    aa = lpp_sum<LPP>(aa);
+    const double C0[6] = {C[0], C[1], C[2], C[3], C[4], C[5]};
+    const double e[3] = {pr[0] + pa[0], pr[1] + pa[1], pr[2] + pa[2]};
     C[0] += fmin(fmax(C[0], lm_lo), lm_hi) / radius;
     C[2] += fmin(fmax(C[2], lm_lo), lm_hi) / radius;
     C[5] += fmin(fmax(C[5], lm_lo), lm_hi) / radius;
@@ -2148,30 +2212,27 @@ __global__ __launch_bounds__(256) void ba_backsub(BaDev d, double radius, double
     for (int j = 0; j < 3; ++j) {
       const double dl = stp[j] * sp[j];
       Xc[j] = X[j] + dl;
-      d.pts_c[3 * p + j] = Xc[j];
-      sn2 += dl * dl;
-      cn2 += Xc[j] * Xc[j];
+      if (sub == 0) {
+        d.pts_c[3 * p + j] = Xc[j];
+        sn2 += dl * dl;
+        cn2 += Xc[j] * Xc[j];
+      }
     }
-    for (int k = k0; k < k1; ++k) {
+    if (sub == 0) {
+      // s^T C0 s (C0 lower triangle: 00, 10, 11, 20, 21, 22)
+      const double q = stp[0] * (C0[0] * stp[0] + 2.0 * (C0[1] * stp[1] + C0[3] * stp[2])) +
+                       stp[1] * (C0[2] * stp[1] + 2.0 * C0[4] * stp[2]) + stp[2] * C0[5] * stp[2];
+      mcc = ar + (stp[0] * pr[0] + stp[1] * pr[1] + stp[2] * pr[2]) +
+            0.5 * aa + (stp[0] * pa[0] + stp[1] * pa[1] + stp[2] * pa[2]) + 0.5 * q;
+    }
+    for (int k = k0 + sub; k < k1; k += LPP) {
       const int c = d.ocam[k];
       const double2 xy = d.oxy[k];
-      ObsLin o;
-      obs_linearize(d.camd + (size_t)CAMD * c, X, focal, xy.x, xy.y, d.scale_c + 6 * c, sp, sf, o);
-      double m0 = -o.Jf[0] * zf, m1 = -o.Jf[1] * zf;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const double zj = d.z[6 * c + j];
-        m0 -= o.Jc[j] * zj;
-        m1 -= o.Jc[6 + j] * zj;
-      }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        m0 += o.Jp[j] * stp[j];
-        m1 += o.Jp[3 + j] * stp[j];
-      }
-      mcc += m0 * (o.r0 + m0 / 2.0) + m1 * (o.r1 + m1 / 2.0);
       double r0, r1;
-      obs_residual(d.camd_c + (size_t)CAMD * c, Xc, focal_c, xy.x, xy.y, r0, r1);
+      if (__builtin_amdgcn_ballot_w64(c != __builtin_amdgcn_readfirstlane(c)) == 0)
+        obs_residual(wave_uniform_ptr(d.camd_c + (size_t)CAMD * c), Xc, focal_c, xy.x, xy.y, r0, r1);
+      else
+        obs_residual(d.camd_c + (size_t)CAMD * c, Xc, focal_c, xy.x, xy.y, r0, r1);
       cost_c += r0 * r0 + r1 * r1;
     }
   }
@@ -2192,10 +2253,11 @@ __global__ __launch_bounds__(256) void ba_backsub(BaDev d, double radius, double
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomic_add_f64(d.red2 + 0, sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
-    atomic_add_f64(d.red2 + 1, sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
-    atomic_add_f64(d.red2 + 2, sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3]);
-    atomic_add_f64(d.red2 + 3, sh[3][0] + sh[3][1] + sh[3][2] + sh[3][3]);
+    double* slot = d.red2 + 8 + 4 * (blockIdx.x % RED2_SLOTS);
+    atomic_add_f64(slot + 0, sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+    atomic_add_f64(slot + 1, sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
+    atomic_add_f64(slot + 2, sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3]);
+    atomic_add_f64(slot + 3, sh[3][0] + sh[3][1] + sh[3][2] + sh[3][3]);
   }
 }
 
@@ -2625,7 +2687,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   // [S | g | F^T b | diag | SC scalars + one slot per rank (<= 64) | the step evaluation's 8 sums, a
   // scratch double, the factorisation's status]: the tail past the all-reduced part is zeroed with
   // the rest at every linearisation and comes back to the host in the same copy as the scalars
-  b->red_count = b->ssz + 3 * (size_t)b->ld + SC + 64 + 16 + b->ssz;  // ... | X (chol_step2), zeroed with the rest
+  b->red_count = b->ssz + 3 * (size_t)b->ld + SC + 64 + RED2_N + b->ssz;  // ... | X (chol_step2), zeroed with the rest
 #define BA_A(ptr, n)                         \
   if (rc == SFMHIP_OK) rc = ba_alloc(b, &(ptr), (size_t)(n))
   BA_A(d_optr, b->np + 1);
@@ -2647,8 +2709,8 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   BA_A(d.z, b->ld);
   if (rc == SFMHIP_OK) {
     d.red2 = d.red + b->ssz + 3 * (size_t)b->ld + SC + 64;
-    d.info = (int*)(d.red2 + 9);
-    d.xinv = d.red2 + 16;
+    d.info = (int*)(d.red2 + RED2_INFO);
+    d.xinv = d.red2 + RED2_N;
   }
   BA_A(b->d_cam_used, n_cam);
   BA_A(b->d_flag, 2);
@@ -2698,9 +2760,9 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   SFM_HIP_TRY(up(b->d_pair_ent, pair_ent.data(), pair_ent.size() * sizeof(int2)));
   b->n_pairs_pp = (int)pair_cams.size();
   lap_("uploads");
-  SFM_HIP_TRY(hipHostMalloc((void**)&b->h_sc, sizeof(double) * (SC + 64 + 16 + 1), hipHostMallocDefault));
+  SFM_HIP_TRY(hipHostMalloc((void**)&b->h_sc, sizeof(double) * (SC + 64 + RED2_N + 1), hipHostMallocDefault));
   SFM_HIP_TRY(hipHostGetDevicePointer((void**)&b->h_sc_dev, b->h_sc, 0));
-  b->h_sc[SC + 64 + 16] = 0.0;
+  b->h_sc[SC + 64 + RED2_N] = 0.0;
   for (auto& e : b->ev) SFM_HIP_TRY(hipEventCreate(&e));
   b->h_pts_in.assign(3 * (size_t)n_pt, 0.0);
   lap_("pinned + events");
@@ -2854,7 +2916,7 @@ static int ba_prepare_scale(sfmhip_ba* b, int jacobi) {
     SFM_HIP_TRY(hipMemcpyAsync(b->d_cam_used, b->h_cam_used.data(), b->nc, hipMemcpyHostToDevice, st));
   }
   const double pts_n2 = dc[b->ld + 1];
-  double* tmp = d.red2 + 8;
+  double* tmp = d.red2 + RED2_TMP;
   hipLaunchKernelGGL(ba_cam_norm, dim3(1), dim3(256), 0, st, d, b->d_cam_used, tmp);
   double cam_n2 = 0;
   SFM_HIP_TRY(hipMemcpyAsync(&cam_n2, tmp, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -3310,11 +3372,22 @@ static int ba_step_eval(sfmhip_ba* b, double radius, const sfmhip_ba_opts* o) {
   BaDev& d = b->d;
   hipLaunchKernelGGL(ba_cand_cams, dim3((b->nc + 1 + 63) / 64), dim3(64), 0, st, d, b->d_cam_used, b->rank);
   if (b->np)
-    hipLaunchKernelGGL(ba_backsub, dim3((b->np + 255) / 256), dim3(256), 0, st, d, radius, o->min_lm_diagonal,
-                       o->max_lm_diagonal);
+  {
+    static const int lpp_env = getenv("SFMHIP_BA_BACKSUB_LPP") ? atoi(getenv("SFMHIP_BA_BACKSUB_LPP")) : 1;  // (measurement)
+    const size_t np = (size_t)b->np;
+    if (lpp_env == 1)
+      hipLaunchKernelGGL(ba_backsub<1>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, d, radius,
+                         o->min_lm_diagonal, o->max_lm_diagonal);
+    else if (lpp_env == 2)
+      hipLaunchKernelGGL(ba_backsub<2>, dim3((unsigned)((2 * np + 255) / 256)), dim3(256), 0, st, d, radius,
+                         o->min_lm_diagonal, o->max_lm_diagonal);
+    else
+      hipLaunchKernelGGL(ba_backsub<4>, dim3((unsigned)((4 * np + 255) / 256)), dim3(256), 0, st, d, radius,
+                         o->min_lm_diagonal, o->max_lm_diagonal);
+  }
   SFM_HIP_TRY(hipGetLastError());
   b->launches += 2;
-  SFM_TRY(ba_allreduce(b, d.red2, 8));
+  SFM_TRY(ba_allreduce(b, d.red2, RED2_SUM_N));
   return SFMHIP_OK;
 }
 
@@ -3335,8 +3408,9 @@ struct IterScalars {
 // go to the host in one piece: a one-workgroup kernel writes them into the pinned buffer and then a
 // sequence number behind them; the host spins on the sequence number.  (A blit + hipStreamSynchronize
 // costs ~15 us more per iteration: copy-kernel launch, completion interrupt, wake-up.)
-constexpr int H_SC_N = SC + 64 + 16;
-__global__ __launch_bounds__(128) void ba_publish(const double* __restrict__ src, double* __restrict__ host, double seq) {
+constexpr int H_SC_N = SC + 64 + RED2_N;
+static_assert(H_SC_N <= 256, "ba_publish copies one double per thread");
+__global__ __launch_bounds__(256) void ba_publish(const double* __restrict__ src, double* __restrict__ host, double seq) {
   const int i = threadIdx.x;
   if (i < H_SC_N) host[i] = src[i];
   __threadfence_system();
@@ -3352,7 +3426,7 @@ static int ba_read_scalars(sfmhip_ba* b, IterScalars* s, bool with_step) {
   BaDev& d = b->d;
   const size_t sc_off = b->ssz + 3 * (size_t)b->ld;
   b->h_seq += 1.0;
-  hipLaunchKernelGGL(ba_publish, dim3(1), dim3(128), 0, st, d.red + sc_off, b->h_sc_dev, b->h_seq);
+  hipLaunchKernelGGL(ba_publish, dim3(1), dim3(256), 0, st, d.red + sc_off, b->h_sc_dev, b->h_seq);
   SFM_HIP_TRY(hipGetLastError());
   {
     volatile double* flag = b->h_sc + H_SC_N;
@@ -3375,11 +3449,13 @@ static int ba_read_scalars(sfmhip_ba* b, IterScalars* s, bool with_step) {
   s->gmax = b->h_sc[3];
   if (with_step) {
     const double* step = b->h_sc + SC + 64;
-    s->cost_c = 0.5 * step[0];
-    s->mcc = -step[1];
-    s->step_n2 = step[2];
-    s->cand_n2 = step[3];
-    memcpy(&s->info, step + 9, sizeof(int));
+    double sum[4] = {step[0], step[1], step[2], step[3]};
+    for (int k = 0; k < 4 * RED2_SLOTS; ++k) sum[k & 3] += step[8 + k];
+    s->cost_c = 0.5 * sum[0];
+    s->mcc = -sum[1];
+    s->step_n2 = sum[2];
+    s->cand_n2 = sum[3];
+    memcpy(&s->info, step + RED2_INFO, sizeof(int));
   }
   return SFMHIP_OK;
 }
