@@ -34,9 +34,15 @@ struct sfmhip_ctx {
   // reusable pinned + device scratch for the one-shot host-pointer entry points
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
+  // two grow-only device blocks for entry points that would otherwise hipMalloc / hipFree per call (sift.hip)
+  void* dev_scratch[2] = {nullptr, nullptr};
+  size_t dev_scratch_bytes[2] = {0, 0};
 };
 
 int sfm_ctx_pinned(sfmhip_ctx* ctx, size_t bytes, void** out);
+// block `which` (0 or 1) of at least `bytes` bytes; its contents do not survive a growing call.  The caller's work on
+// it is ordered by the context's stream (the entry points that use it end with a stream synchronisation).
+int sfm_ctx_dev_scratch(sfmhip_ctx* ctx, int which, size_t bytes, void** out);
 
 template <typename T>
 static inline int sfm_dev_alloc(T** p, size_t n) {

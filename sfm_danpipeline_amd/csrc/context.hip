@@ -50,6 +50,8 @@ extern "C" void sfmhip_shutdown(sfmhip_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   if (ctx->pinned) hipHostFree(ctx->pinned);
+  for (void* p : ctx->dev_scratch)
+    if (p) hipFree(p);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -76,6 +78,20 @@ int sfm_ctx_pinned(sfmhip_ctx* ctx, size_t bytes, void** out) {
     ctx->pinned_bytes = bytes;
   }
   *out = ctx->pinned;
+  return SFMHIP_OK;
+}
+
+int sfm_ctx_dev_scratch(sfmhip_ctx* ctx, int which, size_t bytes, void** out) {
+  if (which < 0 || which > 1) return SFMHIP_ERR_ARG;
+  if (ctx->dev_scratch_bytes[which] < bytes) {
+    if (ctx->dev_scratch[which]) hipFree(ctx->dev_scratch[which]);
+    ctx->dev_scratch[which] = nullptr;
+    ctx->dev_scratch_bytes[which] = 0;
+    const size_t want = bytes + bytes / 4;  // (headroom: the next image of a set is about the same size)
+    if (hipMalloc(&ctx->dev_scratch[which], want) != hipSuccess) return SFMHIP_ERR_ALLOC;
+    ctx->dev_scratch_bytes[which] = want;
+  }
+  *out = ctx->dev_scratch[which];
   return SFMHIP_OK;
 }
 

@@ -5,8 +5,8 @@
 // Gaussian images per octave (separable blur, INTER_NEAREST halving); difference of Gaussians; 26-neighbour extrema
 // above the contrast floor; adjustLocalExtrema (Newton steps with Cramer's rule in float, contrast and edge tests);
 // orientation histogram and peaks; KeyPointsFilter::removeDuplicatedSorted and the rescale of the doubled octave (host);
-// the 4 x 4 x 8 descriptor.  The pyramid kernels are HBM-bound streaming kernels; the keypoint stages are one thread
-// per candidate / keypoint with the reference's sequential accumulation order, so that the numbers are those of the
+// the 4 x 4 x 8 descriptor.  The pyramid kernels are HBM-bound streaming kernels; the keypoint stages are one wave
+// per candidate / keypoint with the reference's sequential accumulation order (per histogram bin), so that the numbers are those of the
 // numpy restatement the tests hold (test infrastructure).  Parity with OpenCV itself is unpinned: it is not in the
 // image; where its float results depend on SIMD paths or its own exp / atan2 approximations, one order of operations
 // is fixed here (exp / cos / sin / pow: evaluated in double, rounded to float).
@@ -165,11 +165,16 @@ __device__ bool solve3(const float a[3][3], const float b[3], float x[3]) {
   return true;
 }
 
-// adjustLocalExtrema + calcOrientationHist + the peaks: one thread per candidate
-__global__ __launch_bounds__(64) void sift_refine(Pyr P, const float* __restrict__ G, const float* __restrict__ D,
-                                                  const Cand* __restrict__ cand, int n_cand, float contrast_thr, float edge_thr,
-                                                  float sigma, KeyPt* __restrict__ out, int* __restrict__ n_out, int cap) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// adjustLocalExtrema + calcOrientationHist + the peaks: one WAVE per candidate.  The Newton steps run on every lane
+// alike (uniform data, a few dozen loads); the orientation window -- OpenCV fills arrays for all its samples and
+// then adds them to the histogram in sample order -- is computed 64 samples at a time, a lane each, and added by
+// bin: lane b looks at the 64 (bin, value) pairs in lane order (v_readlane) and adds those of its bin, so every
+// bin sees its samples in the reference's order and the sums are the sequential ones bit for bit.
+__global__ __launch_bounds__(256) void sift_refine(Pyr P, const float* __restrict__ G, const float* __restrict__ D,
+                                                   const Cand* __restrict__ cand, int n_cand, float contrast_thr, float edge_thr,
+                                                   float sigma, KeyPt* __restrict__ out, int* __restrict__ n_out, int cap) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (t >= n_cand) return;
   const Cand cd = cand[t];
   const int o = cd.o, nl = P.n_layers, h = P.h[o], w = P.w[o];
@@ -233,32 +238,49 @@ __global__ __launch_bounds__(64) void sift_refine(Pyr P, const float* __restrict
   const float sg = 1.5f * scl_octv;
   const float expf_scale = -1.f / (2.f * (sg * sg));
   const float* gimg = G + P.goff[o] + (size_t)layer * isz;
-  float tmp[ORI_BINS];
-  for (int b = 0; b < ORI_BINS; ++b) tmp[b] = 0.f;
-  for (int ii = -radius; ii <= radius; ++ii) {
-    const int y = r + ii;
-    if (y <= 0 || y >= h - 1) continue;
-    for (int jj = -radius; jj <= radius; ++jj) {
-      const int x = c + jj;
-      if (x <= 0 || x >= w - 1) continue;
-      const size_t q = (size_t)y * w + x;
-      const float dx = gimg[q + 1] - gimg[q - 1], dy = gimg[q - w] - gimg[q + w];
-      const float wgt = (float)exp((double)((float)(ii * ii + jj * jj) * expf_scale));
-      const float ori = fast_atan2_deg(dy, dx);
-      const float mag = sqrtf(dx * dx + dy * dy);
-      int b = cv_round((float)(ORI_BINS / 360.0) * ori);
-      if (b >= ORI_BINS) b -= ORI_BINS;
-      if (b < 0) b += ORI_BINS;
-      tmp[b] = tmp[b] + wgt * mag;
+  float acc = 0.f;  // lane b < ORI_BINS: bin b of the raw histogram
+  {
+    const int W = 2 * radius + 1, total = W * W;
+    for (int base = 0; base < total; base += 64) {
+      const int k = base + lane;
+      int bin = -1;
+      float val = 0.f;
+      if (k < total) {
+        const int ii = k / W - radius, jj = k % W - radius;
+        const int y = r + ii, x = c + jj;
+        if (!(y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1)) {
+          const size_t q = (size_t)y * w + x;
+          const float dx = gimg[q + 1] - gimg[q - 1], dy = gimg[q - w] - gimg[q + w];
+          const float wgt = (float)exp((double)((float)(ii * ii + jj * jj) * expf_scale));
+          const float ori = fast_atan2_deg(dy, dx);
+          const float mag = sqrtf(dx * dx + dy * dy);
+          bin = cv_round((float)(ORI_BINS / 360.0) * ori);
+          if (bin >= ORI_BINS) bin -= ORI_BINS;
+          if (bin < 0) bin += ORI_BINS;
+          val = wgt * mag;
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(bin >= 0) == 0) continue;
+#pragma unroll 8
+      for (int sidx = 0; sidx < 64; ++sidx) {
+        const int bs = __builtin_amdgcn_readlane(bin, sidx);
+        const float vs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), sidx));
+        acc = bs == lane ? acc + vs : acc;
+      }
     }
   }
+  auto T = [&](int k) {  // raw bin k (mod ORI_BINS), on every lane
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), (k + ORI_BINS) % ORI_BINS));
+  };
   float hist[ORI_BINS], omax = 0.f;
+#pragma unroll
   for (int b = 0; b < ORI_BINS; ++b) {
-    auto T = [&](int k) { return tmp[(k + ORI_BINS) % ORI_BINS]; };
     hist[b] = (T(b - 2) + T(b + 2)) * (1.f / 16.f) + (T(b - 1) + T(b + 1)) * (4.f / 16.f) + T(b) * (6.f / 16.f);
     omax = b == 0 ? hist[0] : fmaxf(omax, hist[b]);
   }
   const float mag_thr = omax * 0.8f;
+  if (lane != 0) return;
+#pragma unroll
   for (int j = 0; j < ORI_BINS; ++j) {
     const int l = j > 0 ? j - 1 : ORI_BINS - 1, r2 = j < ORI_BINS - 1 ? j + 1 : 0;
     if (hist[j] > hist[l] && hist[j] > hist[r2] && hist[j] >= mag_thr) {
@@ -272,11 +294,25 @@ __global__ __launch_bounds__(64) void sift_refine(Pyr P, const float* __restrict
   }
 }
 
-// calcSIFTDescriptor: one thread per keypoint, the reference's accumulation order
-__global__ __launch_bounds__(64) void sift_describe(Pyr P, const float* __restrict__ G, const KeyPt* __restrict__ kps, int n,
-                                                    float* __restrict__ desc) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
+// calcSIFTDescriptor: one WAVE per keypoint.  OpenCV fills arrays for the window's samples (those that fall into the
+// 4 x 4 grid and the image), then adds each sample's eight trilinear shares to the histogram in sample order.  Here 64
+// window positions at a time are evaluated a lane each, the valid ones compacted in raster order (ballot + prefix
+// count) into LDS with their eight shares, and lanes 0..7 -- one per share -- add them sample by sample: the eight
+// bins of a sample are distinct and LDS operations of a wave execute in order, so every bin receives its shares in
+// the reference's order.  The norms are sequential sums over the 128 values in order (v_readlane).
+constexpr int HIST_N = (DW + 2) * (DW + 2) * (DB + 2);
+constexpr int DESC_WAVES = 4;
+__global__ __launch_bounds__(64 * DESC_WAVES) void sift_describe(Pyr P, const float* __restrict__ G, const KeyPt* __restrict__ kps,
+                                                                 int n, float* __restrict__ desc) {
+  __shared__ float s_hist_all[DESC_WAVES][HIST_N];
+  __shared__ float s_val_all[DESC_WAVES][64 * 8];
+  __shared__ int s_idx_all[DESC_WAVES][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = blockIdx.x * DESC_WAVES + wave;
+  if (t >= n) return;  // (no workgroup barrier below: the waves are independent)
+  float* const s_hist = s_hist_all[wave];
+  float* const s_val = s_val_all[wave];
+  int* const s_idx = s_idx_all[wave];
   const KeyPt kp = kps[t];  // (already rescaled by 0.5 and with the first octave folded in, as OpenCV hands it over)
   int octave = kp.octave & 255;
   const int layer = (kp.octave >> 8) & 255;
@@ -298,14 +334,23 @@ __global__ __launch_bounds__(64) void sift_describe(Pyr P, const float* __restri
   radius = min(radius, (int)sqrt((double)cols * cols + (double)rows * rows));
   cos_t /= hist_width;
   sin_t /= hist_width;
-  float hist[(DW + 2) * (DW + 2) * (DB + 2)];
-  for (int k = 0; k < (DW + 2) * (DW + 2) * (DB + 2); ++k) hist[k] = 0.f;
-  for (int i = -radius; i <= radius; ++i)
-    for (int j = -radius; j <= radius; ++j) {
+  for (int k = lane; k < HIST_N; k += 64) s_hist[k] = 0.f;
+  const int W = 2 * radius + 1;
+  const long long total = (long long)W * W;
+  // the share of lane kk = 4 r + 2 c + o goes to bin idx + koff
+  const int koff = (lane & 1) + ((lane >> 1) & 1) * (DB + 2) + ((lane >> 2) & 1) * (DW + 2) * (DB + 2);
+  for (long long base = 0; base < total; base += 64) {
+    const long long k = base + lane;
+    bool valid = false;
+    int idx = 0;
+    float v[8];
+    if (k < total) {
+      const int i = (int)(k / W) - radius, j = (int)(k % W) - radius;
       const float c_rot = (float)j * cos_t - (float)i * sin_t, r_rot = (float)j * sin_t + (float)i * cos_t;
       const float rbin = r_rot + (float)(DW / 2) - 0.5f, cbin = c_rot + (float)(DW / 2) - 0.5f;
       const int r = py + i, c = px + j;
       if (rbin > -1 && rbin < DW && cbin > -1 && cbin < DW && r > 0 && r < rows - 1 && c > 0 && c < cols - 1) {
+        valid = true;
         const size_t q = (size_t)r * cols + c;
         const float dx = img[q + 1] - img[q - 1], dy = img[q - cols] - img[q + cols];
         const float wgt = (float)exp((double)((c_rot * c_rot + r_rot * r_rot) * exp_scale));
@@ -320,40 +365,59 @@ __global__ __launch_bounds__(64) void sift_describe(Pyr P, const float* __restri
         if (o0 >= DB) o0 -= DB;
         const float v_r1 = mg * rb, v_r0 = mg - v_r1;
         const float v_rc11 = v_r1 * cb, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cb, v_rc00 = v_r0 - v_rc01;
-        const float v111 = v_rc11 * ob, v110 = v_rc11 - v111, v101 = v_rc10 * ob, v100 = v_rc10 - v101;
-        const float v011 = v_rc01 * ob, v010 = v_rc01 - v011, v001 = v_rc00 * ob, v000 = v_rc00 - v001;
-        const int idx = ((r0 + 1) * (DW + 2) + c0 + 1) * (DB + 2) + o0;
-        hist[idx] += v000;
-        hist[idx + 1] += v001;
-        hist[idx + (DB + 2)] += v010;
-        hist[idx + (DB + 3)] += v011;
-        hist[idx + (DW + 2) * (DB + 2)] += v100;
-        hist[idx + (DW + 2) * (DB + 2) + 1] += v101;
-        hist[idx + (DW + 3) * (DB + 2)] += v110;
-        hist[idx + (DW + 3) * (DB + 2) + 1] += v111;
+        v[7] = v_rc11 * ob, v[6] = v_rc11 - v[7], v[5] = v_rc10 * ob, v[4] = v_rc10 - v[5];
+        v[3] = v_rc01 * ob, v[2] = v_rc01 - v[3], v[1] = v_rc00 * ob, v[0] = v_rc00 - v[1];
+        idx = ((r0 + 1) * (DW + 2) + c0 + 1) * (DB + 2) + o0;
       }
     }
-  float dst[DW * DW * DB];
-  for (int i = 0; i < DW; ++i)
-    for (int j = 0; j < DW; ++j) {
-      const int idx = ((i + 1) * (DW + 2) + (j + 1)) * (DB + 2);
-      hist[idx] += hist[idx + DB];
-      hist[idx + 1] += hist[idx + DB + 1];
-      for (int k = 0; k < DB; ++k) dst[(i * DW + j) * DB + k] = hist[idx + k];
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(valid);
+    if (m == 0) continue;
+    if (valid) {
+      const int pos = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+      s_idx[pos] = idx;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s_val[8 * pos + e] = v[e];
     }
-  float nrm2 = 0.f;
-  for (int k = 0; k < DW * DW * DB; ++k) nrm2 = nrm2 + dst[k] * dst[k];
-  const float thr = sqrtf(nrm2) * 0.2f;
-  nrm2 = 0.f;
-  for (int k = 0; k < DW * DW * DB; ++k) {
-    const float v = fminf(dst[k], thr);
-    dst[k] = v;
-    nrm2 = nrm2 + v * v;
+    __builtin_amdgcn_wave_barrier();
+    const int nv = __builtin_popcountll(m);
+    if (lane < 8) {
+      for (int sidx = 0; sidx < nv; ++sidx) {
+        const int bi = s_idx[sidx] + koff;
+        s_hist[bi] = s_hist[bi] + s_val[8 * sidx + lane];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
+  // the circular orientation bins, then the 128 values (two per lane: k = lane, 64 + lane)
+  if (lane < DW * DW) {
+    const int idx = ((lane / DW + 1) * (DW + 2) + (lane % DW + 1)) * (DB + 2);
+    s_hist[idx] = s_hist[idx] + s_hist[idx + DB];
+    s_hist[idx + 1] = s_hist[idx + 1] + s_hist[idx + DB + 1];
+  }
+  __builtin_amdgcn_wave_barrier();
+  float d2[2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int k = 64 * hh + lane, cell = k / DB, kb = k % DB;
+    d2[hh] = s_hist[((cell / DW + 1) * (DW + 2) + (cell % DW + 1)) * (DB + 2) + kb];
+  }
+  auto ordered_sum_sq = [&](float a, float b) {  // sum_k x_k * x_k, k = 0..127 in order
+    const float qa = a * a, qb = b * b;
+    float sum = 0.f;
+    for (int k = 0; k < 64; ++k) sum = sum + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qa), k));
+    for (int k = 0; k < 64; ++k) sum = sum + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qb), k));
+    return sum;
+  };
+  float nrm2 = ordered_sum_sq(d2[0], d2[1]);
+  const float thr = sqrtf(nrm2) * 0.2f;
+  d2[0] = fminf(d2[0], thr);
+  d2[1] = fminf(d2[1], thr);
+  nrm2 = ordered_sum_sq(d2[0], d2[1]);
   nrm2 = 512.f / fmaxf(sqrtf(nrm2), FLT_EPSILON);
-  for (int k = 0; k < DW * DW * DB; ++k) {
-    const int v = cv_round(dst[k] * nrm2);  // saturate_cast<uchar>
-    desc[(size_t)t * 128 + k] = (float)min(max(v, 0), 255);
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int vv = cv_round(d2[hh] * nrm2);  // saturate_cast<uchar>
+    desc[(size_t)t * 128 + 64 * hh + lane] = (float)min(max(vv, 0), 255);
   }
 }
 
@@ -384,16 +448,12 @@ extern "C" int sfmhip_sift_detect_and_compute(sfmhip_ctx* ctx, const uint8_t* gr
   SFM_HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int nl = n_octave_layers;
-  struct Bufs {
-    std::vector<void*> v;
-    ~Bufs() {
-      for (void* p : v) hipFree(p);
-    }
-  } bufs;
-  auto dalloc = [&](void** p, size_t bytes) -> int {
-    if (hipMalloc(p, bytes ? bytes : 8) != hipSuccess) return SFMHIP_ERR_ALLOC;
-    bufs.v.push_back(*p);
-    return SFMHIP_OK;
+  // device memory: two blocks the context keeps between calls (an image set is extracted image by image), carved
+  // here -- block 0 for what the image size fixes, block 1 for what the number of candidates fixes
+  auto carve = [](size_t& off, size_t bytes) {
+    const size_t at = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return at;
   };
   // ---- geometry of the pyramid (base = doubled image; nOctaves = cvRound(log2(min side) - 2) + 1)
   Pyr P{};
@@ -417,10 +477,6 @@ extern "C" int sfmhip_sift_detect_and_compute(sfmhip_ctx* ctx, const uint8_t* gr
   }
   unsigned char* d_gray = nullptr;
   float *G = nullptr, *D = nullptr, *tmp = nullptr, *d_kern = nullptr;
-  SFM_TRY(dalloc((void**)&d_gray, (size_t)rows * cols));
-  SFM_TRY(dalloc((void**)&G, sizeof(float) * gtot));
-  SFM_TRY(dalloc((void**)&D, sizeof(float) * dtot));
-  SFM_TRY(dalloc((void**)&tmp, sizeof(float) * (size_t)bh * bw));
   // the kernels: base blur, then sig[1 .. nl + 2]
   std::vector<std::vector<float>> kerns;
   {
@@ -439,7 +495,25 @@ extern "C" int sfmhip_sift_detect_and_compute(sfmhip_ctx* ctx, const uint8_t* gr
     koff.push_back(koff_total);
     koff_total += kk.size();
   }
-  SFM_TRY(dalloc((void**)&d_kern, sizeof(float) * koff_total));
+  const int cand_cap = (int)std::min<size_t>((size_t)bh * bw / 4 + 1024, (size_t)1 << 24);
+  Cand* d_cand = nullptr;
+  int* d_cnt = nullptr;
+  {
+    size_t off = 0;
+    const size_t o_gray = carve(off, (size_t)rows * cols), o_G = carve(off, sizeof(float) * gtot),
+                 o_D = carve(off, sizeof(float) * dtot), o_tmp = carve(off, sizeof(float) * (size_t)bh * bw),
+                 o_kern = carve(off, sizeof(float) * koff_total), o_cand = carve(off, sizeof(Cand) * cand_cap),
+                 o_cnt = carve(off, sizeof(int) * 2);
+    char* base = nullptr;
+    SFM_TRY(sfm_ctx_dev_scratch(ctx, 0, off, (void**)&base));
+    d_gray = (unsigned char*)(base + o_gray);
+    G = (float*)(base + o_G);
+    D = (float*)(base + o_D);
+    tmp = (float*)(base + o_tmp);
+    d_kern = (float*)(base + o_kern);
+    d_cand = (Cand*)(base + o_cand);
+    d_cnt = (int*)(base + o_cnt);
+  }
   for (size_t i = 0; i < kerns.size(); ++i)
     SFM_HIP_TRY(hipMemcpyAsync(d_kern + koff[i], kerns[i].data(), sizeof(float) * kerns[i].size(), hipMemcpyHostToDevice, st));
   SFM_HIP_TRY(hipMemcpyAsync(d_gray, gray, (size_t)rows * cols, hipMemcpyHostToDevice, st));
@@ -469,11 +543,6 @@ extern "C" int sfmhip_sift_detect_and_compute(sfmhip_ctx* ctx, const uint8_t* gr
                        (const float*)(G + P.goff[o]), D + P.doff[o], n);
   }
   // ---- extrema -> candidates -> keypoints
-  const int cand_cap = (int)std::min<size_t>((size_t)bh * bw / 4 + 1024, (size_t)1 << 24);
-  Cand* d_cand = nullptr;
-  int* d_cnt = nullptr;
-  SFM_TRY(dalloc((void**)&d_cand, sizeof(Cand) * cand_cap));
-  SFM_TRY(dalloc((void**)&d_cnt, sizeof(int) * 2));
   SFM_HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int) * 2, st));
   const float thr = (float)(int)std::floor(0.5 * contrast_threshold / nl * 255);
   for (int o = 0; o < n_oct; ++o) {
@@ -493,9 +562,9 @@ extern "C" int sfmhip_sift_detect_and_compute(sfmhip_ctx* ctx, const uint8_t* gr
   const int n_cand = h_cnt[0];
   const int kp_cap = 4 * n_cand + 16;
   KeyPt* d_kp = nullptr;
-  SFM_TRY(dalloc((void**)&d_kp, sizeof(KeyPt) * kp_cap));
+  SFM_TRY(sfm_ctx_dev_scratch(ctx, 1, sizeof(KeyPt) * kp_cap, (void**)&d_kp));
   if (n_cand > 0)
-    hipLaunchKernelGGL(sift_refine, dim3((n_cand + 63) / 64), dim3(64), 0, st, P, (const float*)G, (const float*)D,
+    hipLaunchKernelGGL(sift_refine, dim3((n_cand + 3) / 4), dim3(256), 0, st, P, (const float*)G, (const float*)D,
                        (const Cand*)d_cand, n_cand, (float)contrast_threshold, (float)edge_threshold, (float)sigma, d_kp,
                        d_cnt + 1, kp_cap);
   SFM_HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
@@ -529,9 +598,18 @@ extern "C" int sfmhip_sift_detect_and_compute(sfmhip_ctx* ctx, const uint8_t* gr
   if (nk > capacity) return capacity == 0 ? SFMHIP_OK : SFMHIP_ERR_ARG;  // (capacity 0: a count-only call)
   if (nk == 0) return SFMHIP_OK;
   float* d_desc = nullptr;
-  SFM_TRY(dalloc((void**)&d_desc, sizeof(float) * 128 * (size_t)nk));
+  {
+    // (block 1 again, now that the number of keypoints is known: the device copy of the unsorted keypoints is done
+    // with -- the stream is idle -- and a growing call may move the block)
+    size_t off = 0;
+    const size_t o_kp = carve(off, sizeof(KeyPt) * nk), o_desc = carve(off, sizeof(float) * 128 * (size_t)nk);
+    char* base = nullptr;
+    SFM_TRY(sfm_ctx_dev_scratch(ctx, 1, off, (void**)&base));
+    d_kp = (KeyPt*)(base + o_kp);
+    d_desc = (float*)(base + o_desc);
+  }
   SFM_HIP_TRY(hipMemcpyAsync(d_kp, kps.data(), sizeof(KeyPt) * nk, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(sift_describe, dim3((nk + 63) / 64), dim3(64), 0, st, P, (const float*)G, (const KeyPt*)d_kp, nk, d_desc);
+  hipLaunchKernelGGL(sift_describe, dim3((nk + DESC_WAVES - 1) / DESC_WAVES), dim3(64 * DESC_WAVES), 0, st, P, (const float*)G, (const KeyPt*)d_kp, nk, d_desc);
   SFM_HIP_TRY(hipGetLastError());
   SFM_HIP_TRY(hipMemcpyAsync(descriptors, d_desc, sizeof(float) * 128 * (size_t)nk, hipMemcpyDeviceToHost, st));
   SFM_HIP_TRY(hipStreamSynchronize(st));
