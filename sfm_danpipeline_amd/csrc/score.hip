@@ -642,6 +642,16 @@ struct HSampleStream {  // per pair: the accepted 4-point samples in order (-1: 
   }
 };
 
+// The model of a RANSAC iteration that raised a pair's best count stays on the device: (index of the model in the
+// chunk's model array, pair) -> best[pair].  (Downloading every model of every iteration for the host to pick from
+// moved 720 bytes per iteration: 0.9 GB for 1225 pairs x 1000 iterations.)
+__global__ void score_keep_best(const int2* __restrict__ upd, int n, const double* __restrict__ models, double* __restrict__ best) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 9 * n) return;
+  const int2 u = upd[i / 9];
+  best[(size_t)u.y * 9 + i % 9] = models[(size_t)u.x * 9 + i % 9];
+}
+
 }  // namespace
 
 extern "C" int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_t* offsets, const double* left_xy,
@@ -688,9 +698,14 @@ extern "C" int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_
     bool done;
   };
   std::vector<PairState> ps(n_pairs);
-  std::vector<double> best_E((size_t)n_pairs * 9, 0.0);
   std::vector<unsigned char> has(n_pairs, 0);
   std::map<int, SampleStream> streams;
+  double* d_bestE = nullptr;
+  int2* d_upd = nullptr;
+  std::vector<int2> upd;
+  SFM_TRY(dalloc((void**)&d_bestE, sizeof(double) * 9 * n_pairs));
+  SFM_TRY(dalloc((void**)&d_upd, sizeof(int2) * n_pairs));
+  SFM_HIP_TRY(hipMemsetAsync(d_bestE, 0, sizeof(double) * 9 * n_pairs, st));
   for (int p = 0; p < n_pairs; ++p) {
     PairState& s = ps[p];
     s.count = offsets[p + 1] - offsets[p];
@@ -703,7 +718,6 @@ extern "C" int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_
   int chunk = 32;
   std::vector<ScoreJob> jobs;
   std::vector<int> job_pair, h_samples, h_nm, h_counts;
-  std::vector<double> h_models;
   ScoreJob* d_jobs = nullptr;
   int *d_samples = nullptr, *d_nm = nullptr, *d_counts = nullptr;
   double* d_models = nullptr;
@@ -755,11 +769,10 @@ extern "C" int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_
     SFM_HIP_TRY(hipGetLastError());
     h_nm.resize(slots);
     h_counts.resize(slots * MAX_MODELS);
-    h_models.resize(slots * MAX_MODELS * 9);
     SFM_HIP_TRY(hipMemcpyAsync(h_nm.data(), d_nm, sizeof(int) * slots, hipMemcpyDeviceToHost, st));
     SFM_HIP_TRY(hipMemcpyAsync(h_counts.data(), d_counts, sizeof(int) * slots * MAX_MODELS, hipMemcpyDeviceToHost, st));
-    SFM_HIP_TRY(hipMemcpyAsync(h_models.data(), d_models, sizeof(double) * slots * MAX_MODELS * 9, hipMemcpyDeviceToHost, st));
     SFM_HIP_TRY(hipStreamSynchronize(st));
+    upd.clear();
     // ---- ptsetreg.cpp run(): the models of a sample in order, the iteration limit from the best count so far
     for (size_t j = 0; j < nj; ++j) {
       PairState& s = ps[job_pair[j]];
@@ -768,11 +781,12 @@ extern "C" int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_
         if (h_nm[slot] > 0) {
           s.best = MODEL_POINTS;
           has[job_pair[j]] = 2;
-          for (int e = 0; e < 9; ++e) best_E[(size_t)job_pair[j] * 9 + e] = h_models[slot * MAX_MODELS * 9 + e];
+          upd.push_back(int2{(int)(slot * MAX_MODELS), job_pair[j]});
         }
         s.done = true;
         continue;
       }
+      long long keep = -1;  // the last model of this chunk that raised the best count
       for (int it = 0; it < chunk && s.iter < s.niters; ++it, ++s.iter) {
         const size_t slot = j * chunk + it;
         for (int m = 0; m < h_nm[slot]; ++m) {
@@ -780,12 +794,18 @@ extern "C" int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_
           if (good > std::max(s.best, MODEL_POINTS - 1)) {
             s.best = good;
             has[job_pair[j]] = 1;
-            for (int e = 0; e < 9; ++e) best_E[(size_t)job_pair[j] * 9 + e] = h_models[(slot * MAX_MODELS + m) * 9 + e];
+            keep = (long long)(slot * MAX_MODELS + m);
             s.niters = ransac_update_num_iters(prob, (double)(s.count - good) / s.count, MODEL_POINTS, s.niters);
           }
         }
       }
+      if (keep >= 0) upd.push_back(int2{(int)keep, job_pair[j]});
       if (s.iter >= s.niters) s.done = true;
+    }
+    if (!upd.empty()) {  // (before the next chunk's solve overwrites the models; same stream)
+      SFM_HIP_TRY(hipMemcpyAsync(d_upd, upd.data(), sizeof(int2) * upd.size(), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(score_keep_best, dim3((unsigned)((9 * upd.size() + 255) / 256)), dim3(256), 0, st, (const int2*)d_upd,
+                         (int)upd.size(), (const double*)d_models, d_bestE);
     }
     chunk = std::min(2 * chunk, 256);
   }
@@ -795,14 +815,11 @@ extern "C" int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_
   }
   if (mask && total > 0) {
     int* d_off = nullptr;
-    double* d_bestE = nullptr;
     unsigned char *d_has = nullptr, *d_mask = nullptr;
     SFM_TRY(dalloc((void**)&d_off, sizeof(int) * (n_pairs + 1)));
-    SFM_TRY(dalloc((void**)&d_bestE, sizeof(double) * 9 * n_pairs));
     SFM_TRY(dalloc((void**)&d_has, n_pairs));
     SFM_TRY(dalloc((void**)&d_mask, (size_t)total));
     SFM_HIP_TRY(hipMemcpyAsync(d_off, offsets, sizeof(int) * (n_pairs + 1), hipMemcpyHostToDevice, st));
-    SFM_HIP_TRY(hipMemcpyAsync(d_bestE, best_E.data(), sizeof(double) * 9 * n_pairs, hipMemcpyHostToDevice, st));
     SFM_HIP_TRY(hipMemcpyAsync(d_has, has.data(), n_pairs, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(score_mask, dim3(n_pairs), dim3(256), 0, st, d_off, d_p1, d_p2, d_bestE, d_has, t, d_mask);
     SFM_HIP_TRY(hipGetLastError());
@@ -854,9 +871,14 @@ extern "C" int sfmhip_score_homography(sfmhip_ctx* ctx, int n_pairs, const int32
   };
   std::vector<PairState> ps(n_pairs);
   std::vector<HSampleStream> streams(n_pairs);
-  std::vector<double> best_H((size_t)n_pairs * 9, 0.0);
   std::vector<unsigned char> has(n_pairs, 0);
   std::vector<float> tts(n_pairs);
+  double* d_bestH = nullptr;
+  int2* d_upd = nullptr;
+  std::vector<int2> upd;
+  SFM_TRY(dalloc((void**)&d_bestH, sizeof(double) * 9 * n_pairs));
+  SFM_TRY(dalloc((void**)&d_upd, sizeof(int2) * n_pairs));
+  SFM_HIP_TRY(hipMemsetAsync(d_bestH, 0, sizeof(double) * 9 * n_pairs, st));
   for (int p = 0; p < n_pairs; ++p) {
     PairState& s = ps[p];
     s.count = offsets[p + 1] - offsets[p];
@@ -870,7 +892,6 @@ extern "C" int sfmhip_score_homography(sfmhip_ctx* ctx, int n_pairs, const int32
   int chunk = 32;
   std::vector<HJob> jobs;
   std::vector<int> job_pair, h_samples, h_nm, h_counts;
-  std::vector<double> h_models;
   HJob* d_jobs = nullptr;
   int *d_samples = nullptr, *d_nm = nullptr, *d_counts = nullptr;
   double* d_models = nullptr;
@@ -922,11 +943,10 @@ extern "C" int sfmhip_score_homography(sfmhip_ctx* ctx, int n_pairs, const int32
     SFM_HIP_TRY(hipGetLastError());
     h_nm.resize(slots);
     h_counts.resize(slots);
-    h_models.resize(slots * 9);
     SFM_HIP_TRY(hipMemcpyAsync(h_nm.data(), d_nm, sizeof(int) * slots, hipMemcpyDeviceToHost, st));
     SFM_HIP_TRY(hipMemcpyAsync(h_counts.data(), d_counts, sizeof(int) * slots, hipMemcpyDeviceToHost, st));
-    SFM_HIP_TRY(hipMemcpyAsync(h_models.data(), d_models, sizeof(double) * slots * 9, hipMemcpyDeviceToHost, st));
     SFM_HIP_TRY(hipStreamSynchronize(st));
+    upd.clear();
     for (size_t j = 0; j < nj; ++j) {
       const int p = job_pair[j];
       PairState& s = ps[p];
@@ -938,6 +958,7 @@ extern "C" int sfmhip_score_homography(sfmhip_ctx* ctx, int n_pairs, const int32
         s.done = true;
         continue;
       }
+      long long keep = -1;
       for (int it = 0; it < chunk && s.iter < s.niters; ++it, ++s.iter) {
         const size_t slot = j * chunk + it;
         if (streams[p].idx[4 * (size_t)s.iter] < 0) {  // getSubset failed: run() leaves the loop (iter 0: no model at all)
@@ -949,11 +970,17 @@ extern "C" int sfmhip_score_homography(sfmhip_ctx* ctx, int n_pairs, const int32
         if (good > std::max(s.best, MODEL_POINTS - 1)) {
           s.best = good;
           has[p] = 1;
-          for (int e = 0; e < 9; ++e) best_H[(size_t)p * 9 + e] = h_models[slot * 9 + e];
+          keep = (long long)slot;
           s.niters = ransac_update_num_iters(confidence, (double)(s.count - good) / s.count, MODEL_POINTS, s.niters);
         }
       }
+      if (keep >= 0) upd.push_back(int2{(int)keep, p});
       if (s.iter >= s.niters) s.done = true;
+    }
+    if (!upd.empty()) {
+      SFM_HIP_TRY(hipMemcpyAsync(d_upd, upd.data(), sizeof(int2) * upd.size(), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(score_keep_best, dim3((unsigned)((9 * upd.size() + 255) / 256)), dim3(256), 0, st, (const int2*)d_upd,
+                         (int)upd.size(), (const double*)d_models, d_bestH);
     }
     chunk = std::min(2 * chunk, 256);
   }
@@ -963,16 +990,13 @@ extern "C" int sfmhip_score_homography(sfmhip_ctx* ctx, int n_pairs, const int32
   }
   if (mask && total > 0) {
     int* d_off = nullptr;
-    double* d_bestH = nullptr;
     float* d_tt = nullptr;
     unsigned char *d_has = nullptr, *d_mask = nullptr;
     SFM_TRY(dalloc((void**)&d_off, sizeof(int) * (n_pairs + 1)));
-    SFM_TRY(dalloc((void**)&d_bestH, sizeof(double) * 9 * n_pairs));
     SFM_TRY(dalloc((void**)&d_tt, sizeof(float) * n_pairs));
     SFM_TRY(dalloc((void**)&d_has, n_pairs));
     SFM_TRY(dalloc((void**)&d_mask, (size_t)total));
     SFM_HIP_TRY(hipMemcpyAsync(d_off, offsets, sizeof(int) * (n_pairs + 1), hipMemcpyHostToDevice, st));
-    SFM_HIP_TRY(hipMemcpyAsync(d_bestH, best_H.data(), sizeof(double) * 9 * n_pairs, hipMemcpyHostToDevice, st));
     SFM_HIP_TRY(hipMemcpyAsync(d_tt, tts.data(), sizeof(float) * n_pairs, hipMemcpyHostToDevice, st));
     SFM_HIP_TRY(hipMemcpyAsync(d_has, has.data(), n_pairs, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(homog_mask, dim3(n_pairs), dim3(256), 0, st, d_off, d_p1, d_p2, d_bestH, d_has, d_tt, d_mask);
