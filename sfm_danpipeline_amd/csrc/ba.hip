@@ -147,6 +147,37 @@ __device__ __forceinline__ double row16_sum(double v) {
   return v;
 }
 
+
+// Reduce-scatter of P per-lane values over the wave: at every step (partner = lane ^ OFF, OFF = 32 .. 1) a lane keeps
+// one half of its list and adds the partner's copy of that half (zero-padded when the length is odd), so that after
+// six steps the lane holds the wave's sums of the entries [base, base + n) of the original list (n <= ceil(P / 64)):
+// about P exchanges in all instead of 6 P for a butterfly that leaves every sum on lane 0, and whatever follows
+// (atomics, LDS stores) is one instruction of many lanes instead of many instructions of one lane.
+template <int P, int OFF, int NOUT>
+__device__ __forceinline__ void wave_reduce_scatter(const double (&cur)[P], int lane, int& base, int& n, double (&out)[NOUT]) {
+  if constexpr (OFF == 0) {
+    static_assert(P <= NOUT, "out holds ceil(P0 / 64) entries");
+#pragma unroll
+    for (int k = 0; k < P; ++k) out[k] = cur[k];
+  } else {
+    constexpr int H = (P + 1) / 2;
+    const bool bit = (lane & OFF) != 0;
+    double nxt[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+      const double lo = cur[k], hi = H + k < P ? cur[H + k] : 0.0;
+      nxt[k] = (bit ? hi : lo) + __shfl_xor(bit ? lo : hi, OFF);
+    }
+    if (bit) {
+      base += H;
+      n = n > H ? n - H : 0;
+    } else {
+      n = n < H ? n : H;
+    }
+    wave_reduce_scatter<H, OFF / 2, NOUT>(nxt, lane, base, n, out);
+  }
+}
+
 // ---------------------------------------------------------------- camera tables
 // R = dp/dX and dR/dw_j of ceres::AngleAxisRotatePoint, same theta^2 > eps branch as the
 // expression autodiff differentiates (src/BundleAdjustment.cpp:16).
@@ -721,7 +752,8 @@ __global__ __launch_bounds__(256) void ba_cam_blocks(BaDev d, const int* __restr
                                                      const double2* __restrict__ cxy, int nsplit,
                                                      int norms_only /* unscaled diagonal into dc only */,
                                                      const int2* __restrict__ cslot /* (T row, point slot) per entry */,
-                                                     const double* __restrict__ T, const double* __restrict__ tfu) {
+                                                     const double* __restrict__ T, const double* __restrict__ tfu,
+                                                     const double* __restrict__ pp_part, int n_part, int rank) {
   __shared__ double sh[4][36];
   __shared__ double sh2[4][33];
   double q[33];  // the Schur part of the same 33 slots: T T^T (upper 21), T t_f (6), T u (6)
@@ -776,22 +808,15 @@ __global__ __launch_bounds__(256) void ba_cam_blocks(BaDev d, const int* __restr
     }
   }
   // (the focal's own terms Jf^2, Jf r and the cost r^2 come from ba_pp_points: a[33..35] stay zero here)
-#pragma unroll
-  for (int e = 0; e < 36; ++e) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) a[e] += __shfl_down(a[e], off);
-  }
-#pragma unroll
-  for (int e = 0; e < 33; ++e) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) q[e] += __shfl_down(q[e], off);
-  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) {
-#pragma unroll
-    for (int e = 0; e < 36; ++e) sh[wave][e] = a[e];
-#pragma unroll
-    for (int e = 0; e < 33; ++e) sh2[wave][e] = q[e];
+  {
+    double o1[1];
+    int base = 0, n = 36;
+    wave_reduce_scatter<36, 32, 1>(a, lane, base, n, o1);
+    if (n > 0) sh[wave][base] = o1[0];
+    base = 0, n = 33;
+    wave_reduce_scatter<33, 32, 1>(q, lane, base, n, o1);
+    if (n > 0) sh2[wave][base] = o1[0];
   }
   __syncthreads();
   if (threadIdx.x < 33 && len > 0) {
@@ -826,22 +851,65 @@ __global__ __launch_bounds__(256) void ba_cam_blocks(BaDev d, const int* __restr
       atomic_add_f64(gF + r0 + e - 27, v);
     }
   }
+  // ---- workgroup 0: the scalars of ba_pp_points (its workgroups' partial sums: the focal's diagonal / rhs / column
+  // norm, the cost, failures, the gradient maximum)
+  if (blockIdx.x != 0 || n_part <= 0) return;
+  __syncthreads();
+  double v[7];
+#pragma unroll
+  for (int e = 0; e < 7; ++e) v[e] = 0.0;
+  for (int w = threadIdx.x; w < n_part; w += 256)
+#pragma unroll
+    for (int e = 0; e < 7; ++e) v[e] = e == 6 ? fmax(v[e], pp_part[8 * (size_t)w + e]) : v[e] + pp_part[8 * (size_t)w + e];
+#pragma unroll
+  for (int e = 0; e < 7; ++e)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[e] = e == 6 ? fmax(v[e], __shfl_down(v[e], off)) : v[e] + __shfl_down(v[e], off);
+  if (lane == 0)
+    for (int e = 0; e < 7; ++e) sh[wave][e] = v[e];
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    const int e = threadIdx.x;
+    const double t = e == 6 ? fmax(fmax(sh[0][e], sh[1][e]), fmax(sh[2][e], sh[3][e])) : sh[0][e] + sh[1][e] + sh[2][e] + sh[3][e];
+    const int fo = 6 * d.nc;
+    double* scv = red_sc(d);
+    if (norms_only) {
+      if (e == 2) atomic_add_f64(red_dc(d) + fo, t);
+    } else if (e == 0) atomic_add_f64(red_S(d) + (size_t)fo * d.ld + fo, t);
+    else if (e == 1) atomic_add_f64(red_g(d) + fo, t);
+    else if (e == 2) atomic_add_f64(red_dc(d) + fo, t);
+    else if (e == 3) atomic_add_f64(red_gF(d) + fo, t);
+    else if (e == 4) atomic_add_f64(scv + 0, t);
+    else if (e == 5) {
+      if (t != 0.0) atomic_add_f64(scv + 2, t);
+    } else atomic_max_pos_f64(scv + SC + rank, t);
+  }
 }
 
 // Generic path of the Schur correction ("pair path"): points whose camera list is shared by few others (short runs),
 // is unsorted, has a camera twice, or is longer than 10.  Per-point atomic scatters cost ~2000 atomics per point (random
 // visibility at 200 cameras / 20 k points: 0.77 ms per linearisation against 0.055 for runs); here every block of S
 // is summed where it is written:
-//   ba_pp_points  one thread per point: C_p, its inverse factor, T_o = (Jc_o^T Jp_o) C_p^-1/2 of every observation
+//   ba_pp_points  PP_LANES lanes per point (the observations dealt over them, the sums met by DPP): C_p, its inverse factor, T_o = (Jc_o^T Jp_o) C_p^-1/2 of every observation
 //                 stored (18 doubles), t_f and u of the point stored, the focal / cost scalars reduced per workgroup;
 //   ba_pp_pairs   one wave per camera pair that some point sees together: S[a][b] -= sum over the pair's entries
 //                 (host-built list of (observation of a, observation of b)) of T_a T_b^T, 36 atomics per PAIR;
 //   ba_cam_blocks one workgroup per (camera, slice) over the camera-major list: F^T F as before, and with the stored
 //                 T, t_f, u the Schur terms of the camera's own blocks: S[c][c] -= T T^T, S[c][f] -= T t_f, g[c] -= T u.
+// (one thread per point left 20 k points on 313 waves, each walking its observations twice: 39 us of pure latency)
+constexpr int PP_LANES = 8;
+__device__ __forceinline__ double pp_group_sum(double v) {  // over the 8 lanes of a point, every lane gets the total
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);  // row_half_mirror
+  return v;
+}
 __global__ __launch_bounds__(256) void ba_pp_points(BaDev d, const int* __restrict__ plist, const int* __restrict__ obase,
                                                     int n_list, double radius, double lm_lo, double lm_hi, int rank,
-                                                    double* __restrict__ T, double* __restrict__ tfu, int norms) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+                                                    double* __restrict__ T, double* __restrict__ tfu, int norms,
+                                                    double* __restrict__ part /* 8 per workgroup */) {
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gt / PP_LANES, sub = gt % PP_LANES;
   double sff = 0, gf = 0, jf2 = 0, jfr = 0, rr = 0, gmax = 0, nfail = 0;
   if (i < n_list) {
     const int p = plist[i];
@@ -855,7 +923,7 @@ __global__ __launch_bounds__(256) void ba_pp_points(BaDev d, const int* __restri
     }
     const double sf = norms ? 1.0 : *d.scale_f, focal = *d.focal;
     double C[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0}, wf[3] = {0, 0, 0};
-    for (int o = 0; o < n; ++o) {
+    for (int o = sub; o < n; o += PP_LANES) {
       const int c = d.ocam[k0 + o];
       const double2 xy = d.oxy[k0 + o];
       ObsLin ol;
@@ -875,6 +943,11 @@ __global__ __launch_bounds__(256) void ba_pp_points(BaDev d, const int* __restri
       jfr += ol.Jf[0] * ol.r0 + ol.Jf[1] * ol.r1;
       rr += ol.r0 * ol.r0 + ol.r1 * ol.r1;
     }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) C[a] = pp_group_sum(C[a]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) gp[a] = pp_group_sum(gp[a]), wf[a] = pp_group_sum(wf[a]);
+    // (jf2, jfr, rr stay per lane: the workgroup sums below add them up)
     if (!norms) {
       C[0] += fmin(fmax(C[0], lm_lo), lm_hi) / radius;
       C[2] += fmin(fmax(C[2], lm_lo), lm_hi) / radius;
@@ -883,20 +956,22 @@ __global__ __launch_bounds__(256) void ba_pp_points(BaDev d, const int* __restri
       const bool pd = chol3_inv(C, Li);
       if (!pd) {
         Li[0] = Li[1] = Li[2] = Li[3] = Li[4] = Li[5] = 0;
-        nfail = 1;
+        if (sub == 0) nfail = 1;
       }
       const double tf[3] = {Li[0] * wf[0], Li[1] * wf[0] + Li[2] * wf[1], Li[3] * wf[0] + Li[4] * wf[1] + Li[5] * wf[2]};
       const double u[3] = {Li[0] * gp[0], Li[1] * gp[0] + Li[2] * gp[1], Li[3] * gp[0] + Li[4] * gp[1] + Li[5] * gp[2]};
+      if (sub == 0) {
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        tfu[6 * (size_t)i + a] = tf[a];
-        tfu[6 * (size_t)i + 3 + a] = u[a];
+        for (int a = 0; a < 3; ++a) {
+          tfu[6 * (size_t)i + a] = tf[a];
+          tfu[6 * (size_t)i + 3 + a] = u[a];
+        }
+        sff = tf[0] * tf[0] + tf[1] * tf[1] + tf[2] * tf[2];
+        gf = tf[0] * u[0] + tf[1] * u[1] + tf[2] * u[2];
+        gmax = fmax(fabs(gp[0] / sp[0]), fmax(fabs(gp[1] / sp[1]), fabs(gp[2] / sp[2])));
       }
-      sff = tf[0] * tf[0] + tf[1] * tf[1] + tf[2] * tf[2];
-      gf = tf[0] * u[0] + tf[1] * u[1] + tf[2] * u[2];
-      gmax = fmax(fabs(gp[0] / sp[0]), fmax(fabs(gp[1] / sp[1]), fabs(gp[2] / sp[2])));
       double* Tp = T + 18 * (size_t)obase[i];
-      for (int o = 0; o < n; ++o) {  // (linearised again: cheaper than keeping 12 + 6 doubles per observation)
+      for (int o = sub; o < n; o += PP_LANES) {  // (linearised again: cheaper than keeping 12 + 6 doubles per observation)
         const int c = d.ocam[k0 + o];
         const double2 xy = d.oxy[k0 + o];
         ObsLin ol;
@@ -923,21 +998,12 @@ __global__ __launch_bounds__(256) void ba_pp_points(BaDev d, const int* __restri
   if ((threadIdx.x & 63) == 0)
     for (int e = 0; e < 7; ++e) sh[threadIdx.x >> 6][e] = v[e];
   __syncthreads();
+  // (no atomics here: a few hundred workgroups adding to the same seven addresses drain at ~44 ns each, 27 us for
+  // 625 workgroups; ba_cam_blocks, which always follows, adds the partial sums up and issues the seven atomics once)
   if (threadIdx.x < 7) {
     const int e = threadIdx.x;
-    const double t = e == 6 ? fmax(fmax(sh[0][e], sh[1][e]), fmax(sh[2][e], sh[3][e])) : sh[0][e] + sh[1][e] + sh[2][e] + sh[3][e];
-    const int fo = 6 * d.nc;
-    double* scv = red_sc(d);
-    if (norms) {
-      if (e == 2) atomic_add_f64(red_dc(d) + fo, t);
-    } else if (e == 0) atomic_add_f64(red_S(d) + (size_t)fo * d.ld + fo, t);
-    else if (e == 1) atomic_add_f64(red_g(d) + fo, t);
-    else if (e == 2) atomic_add_f64(red_dc(d) + fo, t);
-    else if (e == 3) atomic_add_f64(red_gF(d) + fo, t);
-    else if (e == 4) atomic_add_f64(scv + 0, t);
-    else if (e == 5) {
-      if (t != 0.0) atomic_add_f64(scv + 2, t);
-    } else atomic_max_pos_f64(scv + SC + rank, t);
+    part[8 * (size_t)blockIdx.x + e] =
+        e == 6 ? fmax(fmax(sh[0][e], sh[1][e]), fmax(sh[2][e], sh[3][e])) : sh[0][e] + sh[1][e] + sh[2][e] + sh[3][e];
   }
 }
 
@@ -966,23 +1032,20 @@ __global__ __launch_bounds__(64) void ba_pp_pairs(BaDev d, const int* __restrict
 #pragma unroll
       for (int j = 0; j < 6; ++j) acc[6 * i + j] += a[3 * i] * bq[3 * j] + a[3 * i + 1] * bq[3 * j + 1] + a[3 * i + 2] * bq[3 * j + 2];
   }
-#pragma unroll
-  for (int k = 0; k < 36; ++k)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off);
-  if (lane == 0) {
+  // (the wave's sums by reduce-scatter: every one of 36 lanes ends up with one entry and issues its own atomic)
+  double tot1[1];
+  int k = 0, nk = 36;
+  wave_reduce_scatter<36, 32, 1>(acc, lane, k, nk, tot1);
+  const double tot = tot1[0];
+  if (nk > 0) {
     double* S = red_S(d);
-    const int ra = 6 * cc.x, rb = 6 * cc.y;
+    const int ra = 6 * cc.x, rb = 6 * cc.y, i = k / 6, j = k % 6;
     if (cc.x != cc.y) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) atomic_add_f64(S + (size_t)(ra + i) * d.ld + rb + j, -acc[6 * i + j]);
+      atomic_add_f64(S + (size_t)(ra + i) * d.ld + rb + j, -tot);
     } else {
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = i; j < 6; ++j) atomic_add_f64(S + (size_t)(ra + i) * d.ld + ra + j, -(acc[6 * i + j] + acc[6 * j + i]));
+      // (a point that sees camera a twice: the symmetric sum into the diagonal block's upper part)
+      if (i == j) atomic_add_f64(S + (size_t)(ra + i) * d.ld + ra + i, -2.0 * tot);
+      else atomic_add_f64(S + (size_t)(ra + (i < j ? i : j)) * d.ld + ra + (i < j ? j : i), -tot);
     }
   }
 }
@@ -2318,6 +2381,8 @@ struct sfmhip_ba {
   int2* d_cslot = nullptr;     // camera-major list: (T row, point slot)
   double* d_ppT = nullptr;     // 18 doubles per observation of the pair path
   double* d_tfu = nullptr;     // t_f, u per point of the pair path
+  double* d_pp_part = nullptr;  // 8 partial sums per workgroup of ba_pp_points
+  int n_pp_part = 0;
   int* d_pair_ptr = nullptr;
   int2* d_pair_cams = nullptr;
   int2* d_pair_ent = nullptr;
@@ -2725,6 +2790,8 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   BA_A(b->d_cslot, cslot.size());
   BA_A(b->d_ppT, 18 * cslot.size());
   BA_A(b->d_tfu, 6 * fb.size());
+  b->n_pp_part = (int)((fb.size() * PP_LANES + 255) / 256);
+  BA_A(b->d_pp_part, 8 * (size_t)b->n_pp_part);
   BA_A(b->d_pair_ptr, pair_ptr.size());
   BA_A(b->d_pair_cams, pair_cams.size());
   BA_A(b->d_pair_ent, pair_ent.size());
@@ -2896,10 +2963,10 @@ static int ba_prepare_scale(sfmhip_ba* b, int jacobi) {
   if (b->no && jacobi) {
     ba_launch_eliminate(b, 1.0, 1e-6, 1e32, 1);
     if (b->n_fb) {
-      hipLaunchKernelGGL(ba_pp_points, dim3((b->n_fb + 255) / 256), dim3(256), 0, st, d, b->d_fb_points, b->d_pp_obase, b->n_fb, 1.0,
-                         1e-6, 1e32, b->rank, b->d_ppT, b->d_tfu, 1);
+      hipLaunchKernelGGL(ba_pp_points, dim3((unsigned)(((size_t)b->n_fb * PP_LANES + 255) / 256)), dim3(256), 0, st, d, b->d_fb_points, b->d_pp_obase, b->n_fb, 1.0,
+                         1e-6, 1e32, b->rank, b->d_ppT, b->d_tfu, 1, b->d_pp_part);
       hipLaunchKernelGGL(ba_cam_blocks, dim3(b->nc * b->cam_split), dim3(256), 0, st, d, b->d_cptr, b->d_cpt, b->d_cxy,
-                         b->cam_split, 1, b->d_cslot, b->d_ppT, b->d_tfu);
+                         b->cam_split, 1, b->d_cslot, b->d_ppT, b->d_tfu, b->d_pp_part, b->n_pp_part, b->rank);
     }
   }
   SFM_HIP_TRY(hipGetLastError());
@@ -2945,13 +3012,13 @@ static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_o
   int nl = 0;
   nl += ba_launch_eliminate(b, inv_radius, o->min_lm_diagonal, o->max_lm_diagonal, 0);
   if (b->n_fb) {  // the pair path: points, then the blocks of camera pairs and of the cameras themselves
-    hipLaunchKernelGGL(ba_pp_points, dim3((b->n_fb + 255) / 256), dim3(256), 0, st, d, b->d_fb_points, b->d_pp_obase, b->n_fb,
-                       radius, o->min_lm_diagonal, o->max_lm_diagonal, b->rank, b->d_ppT, b->d_tfu, 0);
+    hipLaunchKernelGGL(ba_pp_points, dim3((unsigned)(((size_t)b->n_fb * PP_LANES + 255) / 256)), dim3(256), 0, st, d, b->d_fb_points, b->d_pp_obase, b->n_fb,
+                       radius, o->min_lm_diagonal, o->max_lm_diagonal, b->rank, b->d_ppT, b->d_tfu, 0, b->d_pp_part);
     if (b->n_pairs_pp)
       hipLaunchKernelGGL(ba_pp_pairs, dim3(b->n_pairs_pp), dim3(64), 0, st, d, b->d_pair_ptr, b->d_pair_cams, b->d_pair_ent,
                          (const double*)b->d_ppT);
     hipLaunchKernelGGL(ba_cam_blocks, dim3(b->nc * b->cam_split), dim3(256), 0, st, d, b->d_cptr, b->d_cpt, b->d_cxy,
-                       b->cam_split, 0, b->d_cslot, b->d_ppT, b->d_tfu);
+                       b->cam_split, 0, b->d_cslot, b->d_ppT, b->d_tfu, b->d_pp_part, b->n_pp_part, b->rank);
     nl += 3;
   }
   SFM_HIP_TRY(hipGetLastError());
