@@ -2186,32 +2186,38 @@ __global__ void ba_cand_cams(BaDev d, const unsigned char* __restrict__ cam_used
 }
 
 // per point: back-substitute, model cost change, candidate point + candidate cost.
-// LPP lanes per point (a quad or a pair of lanes, or one): the point's observations are dealt over them and the
-// sums meet by DPP inside the quad, every lane of which then holds the same totals bit for bit.  One linearisation
-// per observation: with a_o = -Jc_o z_c - Jf_o z_f (known before the point's step) and m_o = a_o + Jp_o s the model
-// cost change  sum_o m_o.(r_o + m_o/2)  is
+// One linearisation per observation: with a_o = -Jc_o z_c - Jf_o z_f (known before the point's step) and
+// m_o = a_o + Jp_o s the model cost change  sum_o m_o.(r_o + m_o/2)  is
 //   sum a.r + s.(sum Jp^T r) + (sum |a|^2)/2 + s.(sum Jp^T a) + s^T (sum Jp^T Jp) s / 2,
 // all of them sums the first pass forms next to C_p and e = sum Jp^T (r + a); the second pass only evaluates the
 // candidate's residuals.
-template <int LPP>
-__device__ __forceinline__ double lpp_sum(double v) {
-  if (LPP >= 2) v += dpp_f64<0xB1>(v);  // quad_perm [1,0,3,2]
-  if (LPP >= 4) v += dpp_f64<0x4E>(v);  // quad_perm [2,3,0,1]
-  return v;
-}
-template <int LPP>
+// WPP waves per block of 64 points: a lane is a point, wave `sub` of the block takes the observations sub, sub + WPP,
+// ... -- the lanes of a wave still look at the same observation index, so inside a run they agree on the camera and
+// its table comes through scalar loads (below) -- and the 14 sums meet through LDS, added in wave order by every
+// wave alike.  A thread walks a chain of dependent loads per observation; with one wave per block a SIMD has 1.5
+// waves and nothing to overlap them with.
+constexpr int BS_SUMS = 14;
+template <int WPP>
 __global__ __launch_bounds__(256) void ba_backsub(BaDev d, double radius, double lm_lo, double lm_hi) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int p = t / LPP, sub = t % LPP;
+  constexpr int BLOCKS = 4 / WPP;  // blocks of 64 points per workgroup
+  __shared__ double s_part[WPP > 1 ? 4 * BS_SUMS * 64 : 1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wb = wave / WPP, sub = wave % WPP;
+  const int p = (blockIdx.x * BLOCKS + wb) * 64 + lane;
+  const bool active = p < d.np;
   double mcc = 0, cost_c = 0, sn2 = 0, cn2 = 0;
-  if (p < d.np) {
-    const double X[3] = {d.pts[3 * p], d.pts[3 * p + 1], d.pts[3 * p + 2]};
-    const double sp[3] = {d.scale_p[3 * p], d.scale_p[3 * p + 1], d.scale_p[3 * p + 2]};
-    const double sf = *d.scale_f, focal = *d.focal, focal_c = *d.focal_c;
-    const double zf = d.z[6 * d.nc];
-    const int k0 = d.optr[p], k1 = d.optr[p + 1];
-    double C[6] = {0, 0, 0, 0, 0, 0}, pr[3] = {0, 0, 0}, pa[3] = {0, 0, 0}, ar = 0, aa = 0;
-    for (int k = k0 + sub; k < k1; k += LPP) {
+  double X[3] = {0, 0, 0}, sp[3] = {1, 1, 1};
+  double sm[BS_SUMS];  // C (6: 00 10 11 20 21 22), Jp^T r (3), Jp^T a (3), a.r, |a|^2
+#pragma unroll
+  for (int e = 0; e < BS_SUMS; ++e) sm[e] = 0.0;
+  int k0 = 0, k1 = 0;
+  const double sf = *d.scale_f, focal = *d.focal, focal_c = *d.focal_c;
+  const double zf = d.z[6 * d.nc];
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) X[j] = d.pts[3 * p + j], sp[j] = d.scale_p[3 * p + j];
+    k0 = d.optr[p], k1 = d.optr[p + 1];
+    for (int k = k0 + sub; k < k1; k += WPP) {
       const int c = d.ocam[k];
       const double2 xy = d.oxy[k];
       ObsLin o;
@@ -2240,27 +2246,38 @@ __global__ __launch_bounds__(256) void ba_backsub(BaDev d, double radius, double
           a1 -= o.Jc[6 + j] * zj;
         }
       }
-      C[0] += o.Jp[0] * o.Jp[0] + o.Jp[3] * o.Jp[3];
-      C[1] += o.Jp[1] * o.Jp[0] + o.Jp[4] * o.Jp[3];
-      C[2] += o.Jp[1] * o.Jp[1] + o.Jp[4] * o.Jp[4];
-      C[3] += o.Jp[2] * o.Jp[0] + o.Jp[5] * o.Jp[3];
-      C[4] += o.Jp[2] * o.Jp[1] + o.Jp[5] * o.Jp[4];
-      C[5] += o.Jp[2] * o.Jp[2] + o.Jp[5] * o.Jp[5];
+      sm[0] += o.Jp[0] * o.Jp[0] + o.Jp[3] * o.Jp[3];
+      sm[1] += o.Jp[1] * o.Jp[0] + o.Jp[4] * o.Jp[3];
+      sm[2] += o.Jp[1] * o.Jp[1] + o.Jp[4] * o.Jp[4];
+      sm[3] += o.Jp[2] * o.Jp[0] + o.Jp[5] * o.Jp[3];
+      sm[4] += o.Jp[2] * o.Jp[1] + o.Jp[5] * o.Jp[4];
+      sm[5] += o.Jp[2] * o.Jp[2] + o.Jp[5] * o.Jp[5];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        pr[a] += o.Jp[a] * o.r0 + o.Jp[3 + a] * o.r1;
-        pa[a] += o.Jp[a] * a0 + o.Jp[3 + a] * a1;
+        sm[6 + a] += o.Jp[a] * o.r0 + o.Jp[3 + a] * o.r1;
+        sm[9 + a] += o.Jp[a] * a0 + o.Jp[3 + a] * a1;
       }
-      ar += a0 * o.r0 + a1 * o.r1;
-      aa += a0 * a0 + a1 * a1;
+      sm[12] += a0 * o.r0 + a1 * o.r1;
+      sm[13] += a0 * a0 + a1 * a1;
     }
+  }
+  if (WPP > 1) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) C[j] = lpp_sum<LPP>(C[j]);
+    for (int e = 0; e < BS_SUMS; ++e) s_part[(wave * BS_SUMS + e) * 64 + lane] = sm[e];
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 3; ++j) pr[j] = lpp_sum<LPP>(pr[j]), pa[j] = lpp_sum<LPP>(pa[j]);
-    ar = lpp_sum<LPP>(ar);
-    aa = lpp_sum<LPP>(aa);
-    const double C0[6] = {C[0], C[1], C[2], C[3], C[4], C[5]};
+    for (int e = 0; e < BS_SUMS; ++e) {
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < WPP; ++w) v += s_part[((wb * WPP + w) * BS_SUMS + e) * 64 + lane];
+      sm[e] = v;
+    }
+  }
+  if (active) {
+    double C[6] = {sm[0], sm[1], sm[2], sm[3], sm[4], sm[5]};
+    const double* pr = sm + 6;
+    const double* pa = sm + 9;
+    const double ar = sm[12], aa = sm[13];
     const double e[3] = {pr[0] + pa[0], pr[1] + pa[1], pr[2] + pa[2]};
     C[0] += fmin(fmax(C[0], lm_lo), lm_hi) / radius;
     C[2] += fmin(fmax(C[2], lm_lo), lm_hi) / radius;
@@ -2282,13 +2299,13 @@ __global__ __launch_bounds__(256) void ba_backsub(BaDev d, double radius, double
       }
     }
     if (sub == 0) {
-      // s^T C0 s (C0 lower triangle: 00, 10, 11, 20, 21, 22)
-      const double q = stp[0] * (C0[0] * stp[0] + 2.0 * (C0[1] * stp[1] + C0[3] * stp[2])) +
-                       stp[1] * (C0[2] * stp[1] + 2.0 * C0[4] * stp[2]) + stp[2] * C0[5] * stp[2];
+      // s^T C0 s (C0 = the undamped sums, lower triangle: 00, 10, 11, 20, 21, 22)
+      const double q = stp[0] * (sm[0] * stp[0] + 2.0 * (sm[1] * stp[1] + sm[3] * stp[2])) +
+                       stp[1] * (sm[2] * stp[1] + 2.0 * sm[4] * stp[2]) + stp[2] * sm[5] * stp[2];
       mcc = ar + (stp[0] * pr[0] + stp[1] * pr[1] + stp[2] * pr[2]) +
             0.5 * aa + (stp[0] * pa[0] + stp[1] * pa[1] + stp[2] * pa[2]) + 0.5 * q;
     }
-    for (int k = k0 + sub; k < k1; k += LPP) {
+    for (int k = k0 + sub; k < k1; k += WPP) {
       const int c = d.ocam[k];
       const double2 xy = d.oxy[k];
       double r0, r1;
@@ -2307,12 +2324,11 @@ __global__ __launch_bounds__(256) void ba_backsub(BaDev d, double radius, double
     sn2 += __shfl_down(sn2, o);
     cn2 += __shfl_down(cn2, o);
   }
-  if ((threadIdx.x & 63) == 0) {
-    const int w = threadIdx.x >> 6;
-    sh[0][w] = mcc;
-    sh[1][w] = cost_c;
-    sh[2][w] = sn2;
-    sh[3][w] = cn2;
+  if (lane == 0) {
+    sh[0][wave] = mcc;
+    sh[1][wave] = cost_c;
+    sh[2][wave] = sn2;
+    sh[3][wave] = cn2;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -3440,17 +3456,17 @@ static int ba_step_eval(sfmhip_ba* b, double radius, const sfmhip_ba_opts* o) {
   hipLaunchKernelGGL(ba_cand_cams, dim3((b->nc + 1 + 63) / 64), dim3(64), 0, st, d, b->d_cam_used, b->rank);
   if (b->np)
   {
-    static const int lpp_env = getenv("SFMHIP_BA_BACKSUB_LPP") ? atoi(getenv("SFMHIP_BA_BACKSUB_LPP")) : 1;  // (measurement)
-    const size_t np = (size_t)b->np;
-    if (lpp_env == 1)
-      hipLaunchKernelGGL(ba_backsub<1>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, d, radius,
-                         o->min_lm_diagonal, o->max_lm_diagonal);
-    else if (lpp_env == 2)
-      hipLaunchKernelGGL(ba_backsub<2>, dim3((unsigned)((2 * np + 255) / 256)), dim3(256), 0, st, d, radius,
-                         o->min_lm_diagonal, o->max_lm_diagonal);
+    static const int wpp_env = getenv("SFMHIP_BA_BACKSUB_WPP") ? atoi(getenv("SFMHIP_BA_BACKSUB_WPP")) : 2;  // (measurement)
+    const size_t nblk = ((size_t)b->np + 63) / 64;  // blocks of 64 points
+    if (wpp_env == 1)
+      hipLaunchKernelGGL(ba_backsub<1>, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, st, d, radius, o->min_lm_diagonal,
+                         o->max_lm_diagonal);
+    else if (wpp_env == 2)
+      hipLaunchKernelGGL(ba_backsub<2>, dim3((unsigned)((nblk + 1) / 2)), dim3(256), 0, st, d, radius, o->min_lm_diagonal,
+                         o->max_lm_diagonal);
     else
-      hipLaunchKernelGGL(ba_backsub<4>, dim3((unsigned)((4 * np + 255) / 256)), dim3(256), 0, st, d, radius,
-                         o->min_lm_diagonal, o->max_lm_diagonal);
+      hipLaunchKernelGGL(ba_backsub<4>, dim3((unsigned)nblk), dim3(256), 0, st, d, radius, o->min_lm_diagonal,
+                         o->max_lm_diagonal);
   }
   SFM_HIP_TRY(hipGetLastError());
   b->launches += 2;
