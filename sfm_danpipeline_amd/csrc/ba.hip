@@ -1106,9 +1106,13 @@ constexpr int CBP = 34;  // LDS row pitch in doubles: 16-byte aligned rows, conf
 #define CHOL_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0)
 
 // Bounded LDS spin, until *flag >= need: one opaque asm block (a C loop splits the unrolled block
-// steps that call it into basic blocks, and the register allocator spills).
+// steps that call it into basic blocks, and the register allocator spills).  The counters of a workgroup are one
+// 64-byte block of LDS; a spin that runs out of budget (a bug, not a data condition) leaves a mark in the block's
+// last word (F_TIMEOUT), which every wave looks at when it is done (chol2_report_timeout): the launch then reports
+// a failed factorisation and the host discards the step instead of taking a wrong one.
 __device__ __forceinline__ int lds_wait_ge(const int* flag, int need) {
   const unsigned addr = (unsigned)(size_t)(const __attribute__((address_space(3))) int*)flag;
+  const unsigned mark = (addr & ~63u) | 60u;
   int seen_, budget_ = 1 << 20;
   asm volatile(
       "1:\n\t"
@@ -1118,12 +1122,14 @@ __device__ __forceinline__ int lds_wait_ge(const int* flag, int need) {
       "s_cbranch_vccz 2f\n\t"
       "s_sub_u32 %1, %1, 1\n\t"
       "s_cmp_eq_u32 %1, 0\n\t"
-      "s_cbranch_scc1 2f\n\t"
+      "s_cbranch_scc1 3f\n\t"
       "s_sleep 1\n\t"
       "s_branch 1b\n\t"
+      "3:\n\t"
+      "ds_write_b32 %4, %3\n\t"  // (need >= 1: any non-zero value marks the timeout)
       "2:\n\t"
       : "=&v"(seen_), "+s"(budget_)
-      : "v"(addr), "v"(need)
+      : "v"(addr), "v"(need), "v"(mark)
       : "vcc", "scc", "memory");
   return seen_;  // (what the counter read: callers catching up on several steps need not poll again)
 }
@@ -1167,7 +1173,7 @@ __device__ __forceinline__ int lds_wait_ge(const int* flag, int need) {
 // Trailing workgroups (one wave per tile, four tiles each) fold the pending panels into the tiles
 // right of the block column.
 constexpr int C2_WAVES = 11;
-enum { F_PROG_A = 0, F_PROG_B, F_CNT_DAA, F_CNT_TA, F_CNT_DBA, F_YPROG, F_XPROG, F_STAGED, F_DBB_HI, F_TB_HI, F_DBA_S3, F_COUNT };
+enum { F_PROG_A = 0, F_PROG_B, F_CNT_DAA, F_CNT_TA, F_CNT_DBA, F_YPROG, F_XPROG, F_STAGED, F_DBB_HI, F_TB_HI, F_DBA_S3, F_COUNT, F_TIMEOUT = 15 };
 // dynamic LDS of chol_step2 (doubles): five tiles | 1/diag of both panels | the pending panels' rows
 // of the block rows a and b (64 rows x 64 columns, [column][row], pitch PAB) and of the own tile row
 // (32 x 64, pitch PRW) | the counters.  The pitches put the four k-slices of an MFMA operand read
@@ -1175,7 +1181,8 @@ enum { F_PROG_A = 0, F_PROG_B, F_CNT_DAA, F_CNT_TA, F_CNT_DBA, F_YPROG, F_XPROG,
 constexpr int C2_PAB = 80, C2_PRW = 48;
 constexpr int C2_OFF_SDI = 5 * CB * CBP, C2_OFF_PAB = C2_OFF_SDI + 2 * CB, C2_OFF_PRW = C2_OFF_PAB + 64 * C2_PAB,
               C2_OFF_FLAG = C2_OFF_PRW + 64 * C2_PRW, C2_LDS_BYTES = (C2_OFF_FLAG + 8) * 8;
-static_assert(F_COUNT <= 16, "the counters have 8 doubles of LDS");
+static_assert(F_COUNT <= F_TIMEOUT, "the counters have 8 doubles of LDS, the last word is the timeout mark");
+static_assert((C2_OFF_FLAG * 8) % 64 == 0, "lds_wait_ge finds the timeout mark in the counters' 64-byte block");
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 // (explicitly LDS-typed: through a generic pointer these become flat, system-scope operations)
@@ -1436,7 +1443,7 @@ __device__ __forceinline__ void chol2_panel(double* __restrict__ A, double* __re
   auto own_tile = [&](int cb, int s) -> v4d {  // sub-tile s of the own tile row at columns cb..
     return RHS ? chol2_tile_rhs(y, cb, s, lane) : chol2_tile(Arow, ld, r0, cb, s, lane);
   };
-  if (threadIdx.x < F_COUNT) s_flag[threadIdx.x] = 0;
+  if (threadIdx.x <= F_TIMEOUT) s_flag[threadIdx.x] = 0;
   __syncthreads();
   if (wave == 0) C2_STAMP(0);
   const double* const opab = sPab + q * C2_PAB + j16;  // the lane's element of k-slice 0, row 0
@@ -1537,7 +1544,9 @@ __device__ __forceinline__ void chol2_panel(double* __restrict__ A, double* __re
       if (pend) chol2_fold(t0, opab + 16 * (dba_s & 1), C2_PAB, opab + 32 + 16 * (dba_s >> 1), C2_PAB);
       chol2_put(sYb, dba_s, lane, t0);
       lds_flag_add(&s_flag[F_CNT_DBA], lane);
+#ifndef SFM_CHOL_BREAK_HANDOFF  // (diagnostic build: the hand-off never arrives, the waiting wave must report it)
       if (dba_s == 3) lds_flag_add(&s_flag[F_DBA_S3], lane);
+#endif
       C2_STAMP(16 + dba_s);
     }
     if (ta_s >= 0) {
@@ -1756,6 +1765,11 @@ __device__ __forceinline__ void chol2_panel(double* __restrict__ A, double* __re
   }
 }
 
+__device__ __forceinline__ void chol2_report_timeout(double* sAll, int* __restrict__ info) {
+  const int* s_flag = (const int*)(sAll + C2_OFF_FLAG);
+  if (*(volatile const lds_int*)(s_flag + F_TIMEOUT) != 0 && (threadIdx.x & 63) == 0) atomicExch(info, -1);
+}
+
 // (bid: the workgroup's index within its matrix -- blockIdx.x when a launch factors one matrix)
 // (nxc: the tile columns of X that are wanted -- nt for a whole matrix, the interior tiles for a chain, whose X is
 // only used up to there: the trailing tiles of X right of that are not formed)
@@ -1771,6 +1785,7 @@ __device__ __forceinline__ void chol_step2_body(double* __restrict__ A, double* 
       // factorisation ends, and the backward substitution becomes the product z = X y.  (Row block
       // r' is all zero left of column block r' and untouched until its own panel: rows 0..b here.)
       chol2_panel<false>(A, y, X, ld, k2, info, false, (bid - npanel) * CB, sAll);
+      chol2_report_timeout(sAll, info);
       return;
     }
     const bool owner = bid == 0;
@@ -1779,6 +1794,7 @@ __device__ __forceinline__ void chol_step2_body(double* __restrict__ A, double* 
       chol2_panel<true>(A, y, A, ld, k2, info, false, r0, sAll);
     else
       chol2_panel<false>(A, y, A, ld, k2, info, owner, r0, sAll);
+    chol2_report_timeout(sAll, info);
     return;
   }
   // ---- trailing tiles (k2 >= 1), one wave each (its four sub-tiles share the operands): tile row
