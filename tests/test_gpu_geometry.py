@@ -165,11 +165,13 @@ def test_dissected_reduced_system_walks_the_dense_iterates(ctx, orc, monkeypatch
     assert np.allclose(c1, co, rtol=BA_PARAM_RTOL, atol=1e-9) and np.allclose(p1, po, rtol=BA_PARAM_RTOL, atol=1e-9)
 
 
-@pytest.mark.parametrize("shape,nd", [((96, 6000, 6), "0"), ((96, 6000, 6), "1"), ((180, 8000, 8), "0"), ((560, 8000, 8), "1")])
+@pytest.mark.parametrize("shape,nd", [((96, 6000, 6), "0"), ((96, 6000, 6), "1"), ((180, 8000, 8), "0"), ((560, 8000, 8), "1"),
+                                      ((1400, 9000, 8), "0")])
 def test_reduced_step_solves_the_reduced_system(ctx, monkeypatch, shape, nd):
     """(S + D/r) z = g, z from the solver's own factorisation (dense; dissected: chains + separator), against
     numpy on the system the solver hands out.  560 cameras: six chains whose launches exceed one round of
-    workgroups (every panel workgroup must be resident before the owner overwrites the diagonal tiles)."""
+    workgroups; 1400 cameras dense: 266 panel workgroups on 256 CUs (no workgroup of a launch may depend on another
+    one's being resident: until round 2 the owner overwrote the diagonal tiles the others read)."""
     monkeypatch.setenv("SFMHIP_BA_ND", nd)
     nc, npt, k = shape
     pb = synth.ba_problem(nc, npt, k, seed=5)
