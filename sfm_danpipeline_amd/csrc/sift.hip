@@ -88,18 +88,48 @@ __global__ void sift_half_nearest(const float* __restrict__ src, int h, int w, f
   const int sx = min((int)floor((double)x * ((double)w / (double)dw)), w - 1);
   dst[(size_t)y * dw + x] = src[(size_t)sy * w + sx];
 }
-__global__ void sift_sub(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ c, size_t n) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) c[i] = a[i] - b[i];
+struct Pyr {  // per octave: image size and the offsets of its Gaussian / DoG images in the two arenas
+  int h[16], w[16];
+  size_t goff[16], doff[16];
+  int n_oct, n_layers;
+};
+// (the small octaves are a few thousand pixels: one launch for all octaves, a table of first blocks per octave)
+struct OctBlocks {
+  int first[17];  // first block of octave o; first[n_oct] = all blocks
+};
+__device__ __forceinline__ int oct_of_block(const OctBlocks& t, int n_oct, int b) {
+  int o = 0;
+  while (o + 1 < n_oct && b >= t.first[o + 1]) ++o;
+  return o;
+}
+
+// DoG: D[o][i] = G[o][i + 1] - G[o][i], i < nl + 2, all octaves
+__global__ __launch_bounds__(256) void sift_sub_all(Pyr P, OctBlocks t, const float* __restrict__ G, float* __restrict__ D) {
+  const int o = oct_of_block(t, P.n_oct, blockIdx.x);
+  const size_t isz = (size_t)P.h[o] * P.w[o], n = (size_t)(P.n_layers + 2) * isz;
+  const size_t i = (size_t)(blockIdx.x - t.first[o]) * 256 + threadIdx.x;
+  if (i < n) D[P.doff[o] + i] = G[P.goff[o] + isz + i] - G[P.goff[o] + i];
 }
 
 struct Cand {
   int o, layer, r, c;
 };
 // 26-neighbour extrema of DoG layer `layer` of one octave (prev, cur, next), |val| > thr
-__global__ void sift_extrema(const float* __restrict__ prv, const float* __restrict__ cur, const float* __restrict__ nxt, int h,
-                             int w, int o, int layer, float thr, Cand* __restrict__ out, int* __restrict__ n_out, int cap) {
-  const int c = IMG_BORDER + blockIdx.x * blockDim.x + threadIdx.x, r = IMG_BORDER + blockIdx.y;
+// (all octaves and layers in one launch: block -> octave (table), then layer, row, 64-column block)
+__global__ __launch_bounds__(64) void sift_extrema(Pyr P, OctBlocks t, const float* __restrict__ D, float thr,
+                                                   Cand* __restrict__ out, int* __restrict__ n_out, int cap) {
+  const int o = oct_of_block(t, P.n_oct, blockIdx.x);
+  const int h = P.h[o], w = P.w[o];
+  if (h <= 2 * IMG_BORDER || w <= 2 * IMG_BORDER) return;
+  const int bx = (w - 2 * IMG_BORDER + 63) / 64, by = h - 2 * IMG_BORDER;
+  int rem = blockIdx.x - t.first[o];
+  const int layer = 1 + rem / (bx * by);
+  rem -= (layer - 1) * (bx * by);
+  const int yb = rem / bx, xb = rem - yb * bx;
+  const size_t isz = (size_t)h * w;
+  const float* cur = D + P.doff[o] + (size_t)layer * isz;
+  const float *prv = cur - isz, *nxt = cur + isz;
+  const int c = IMG_BORDER + xb * 64 + threadIdx.x, r = IMG_BORDER + yb;
   if (c >= w - IMG_BORDER || r >= h - IMG_BORDER) return;
   const float val = cur[(size_t)r * w + c];
   if (!(fabsf(val) > thr)) return;
@@ -137,11 +167,6 @@ __device__ float fast_atan2_deg(float y, float x) {
   return a;
 }
 
-struct Pyr {  // per octave: image size and the offsets of its Gaussian / DoG images in the two arenas
-  int h[16], w[16];
-  size_t goff[16], doff[16];
-  int n_oct, n_layers;
-};
 struct KeyPt {
   float x, y, size, angle, response;
   int octave;
@@ -537,23 +562,29 @@ extern "C" int sfmhip_sift_detect_and_compute(sfmhip_ctx* ctx, const uint8_t* gr
     }
     for (int i = 1; i < nl + 3; ++i) blur(G + P.goff[o] + (size_t)(i - 1) * isz, G + P.goff[o] + (size_t)i * isz, h, w, i);
   }
-  for (int o = 0; o < n_oct; ++o) {
-    const size_t isz = (size_t)P.h[o] * P.w[o], n = (size_t)(nl + 2) * isz;
-    hipLaunchKernelGGL(sift_sub, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)(G + P.goff[o] + isz),
-                       (const float*)(G + P.goff[o]), D + P.doff[o], n);
+  {
+    OctBlocks t{};
+    int nb = 0;
+    for (int o = 0; o < n_oct; ++o) {
+      t.first[o] = nb;
+      nb += (int)(((size_t)(nl + 2) * P.h[o] * P.w[o] + 255) / 256);
+    }
+    t.first[n_oct] = nb;
+    hipLaunchKernelGGL(sift_sub_all, dim3(nb), dim3(256), 0, st, P, t, (const float*)G, D);
   }
   // ---- extrema -> candidates -> keypoints
   SFM_HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int) * 2, st));
   const float thr = (float)(int)std::floor(0.5 * contrast_threshold / nl * 255);
-  for (int o = 0; o < n_oct; ++o) {
-    const int h = P.h[o], w = P.w[o];
-    if (h <= 2 * IMG_BORDER || w <= 2 * IMG_BORDER) continue;
-    const size_t isz = (size_t)h * w;
-    for (int i = 1; i <= nl; ++i) {
-      const float* cur = D + P.doff[o] + (size_t)i * isz;
-      hipLaunchKernelGGL(sift_extrema, dim3((w - 2 * IMG_BORDER + 63) / 64, h - 2 * IMG_BORDER), dim3(64), 0, st, cur - isz, cur,
-                         cur + isz, h, w, o, i, thr, d_cand, d_cnt, cand_cap);
+  {
+    OctBlocks t{};
+    int nb = 0;
+    for (int o = 0; o < n_oct; ++o) {
+      t.first[o] = nb;
+      const int h = P.h[o], w = P.w[o];
+      if (h > 2 * IMG_BORDER && w > 2 * IMG_BORDER) nb += nl * ((w - 2 * IMG_BORDER + 63) / 64) * (h - 2 * IMG_BORDER);
     }
+    t.first[n_oct] = nb;
+    if (nb) hipLaunchKernelGGL(sift_extrema, dim3(nb), dim3(64), 0, st, P, t, (const float*)D, thr, d_cand, d_cnt, cand_cap);
   }
   int h_cnt[2] = {0, 0};
   SFM_HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
