@@ -1980,9 +1980,37 @@ struct NdSet {
 
 // fills the chains from S (after ba_finalize: the LM diagonal is on it), g and the identity.
 // job = (chain, tile row, tile column, kind): kind 0 a 32x32 tile of M, kind 1 tile row of y and of X's diagonal
+// fin != 0: ba_finalize's work rides along (one launch less per LM iteration) -- the LM diagonal is added to the
+// diagonal elements as the tiles are copied (S itself stays undamped), and one more workgroup (job kind 4) leaves the
+// clamped column norms, the gradient maximum and a zeroed z.
 __global__ __launch_bounds__(256) void nd_gather(NdSet ns, const int4* __restrict__ jobs, const double* __restrict__ S,
-                                                 const double* __restrict__ g, int ldS) {
+                                                 const double* __restrict__ g, int ldS, BaDev d, int fin, double radius,
+                                                 double lm_lo, double lm_hi, int world) {
   const int4 job = jobs[blockIdx.x];
+  if (job.w == 4) {
+    if (!fin) return;
+    __shared__ double shm[4];
+    const double* gF = red_gF(d);
+    const double* dc = red_dc(d);
+    double* scv = red_sc(d);
+    double gm = 0;
+    for (int i = threadIdx.x; i < d.dim; i += 256) {
+      d.diag[i] = fmin(fmax(dc[i], lm_lo), lm_hi);
+      const double sc = i < 6 * d.nc ? d.scale_c[i] : *d.scale_f;
+      gm = fmax(gm, fabs(gF[i] / sc));
+    }
+    for (int i = threadIdx.x; i < d.ld; i += 256) d.z[i] = 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_down(gm, o));
+    if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = gm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      gm = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3]));
+      for (int r = 0; r < world; ++r) gm = fmax(gm, scv[SC + r]);
+      scv[3] = gm;  // gradient max norm (unscaled), all parameter blocks, all ranks
+    }
+    return;
+  }
   const NdChain ch = ns.c[job.x];
   const int tr = job.y, tc = job.z;
   if (job.w == 1) {
@@ -2010,6 +2038,7 @@ __global__ __launch_bounds__(256) void nd_gather(NdSet ns, const int4* __restric
     double v = 0.0;
     if (lr_lane >= 0 && lc >= 0) {
       if (lr_lane >= lc) v = S[(size_t)lc * ldS + lr_lane];
+      if (fin && lr_lane == lc) v += fmin(fmax(red_dc(d)[lc], lm_lo), lm_hi) / radius;
     } else if (lr_lane < 0 && lc < 0 && tr == tc && r == j) v = 1.0;
     sh[j][r] = v;
   }
@@ -2195,7 +2224,14 @@ __global__ void ba_cand_cams(BaDev d, const unsigned char* __restrict__ cam_used
     sn2 += dl * dl;
     cn2 += f * f;
   }
-  if (rank == 0 && (sn2 != 0 || cn2 != 0)) {
+  // (one atomic pair per wave: 201 threads adding to the same two addresses drain at ~44 ns each, which was the
+  // kernel's whole 8.8 us)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sn2 += __shfl_down(sn2, o);
+    cn2 += __shfl_down(cn2, o);
+  }
+  if (rank == 0 && (threadIdx.x & 63) == 0 && (sn2 != 0 || cn2 != 0)) {
     atomic_add_f64(d.red2 + 2, sn2);
     atomic_add_f64(d.red2 + 3, cn2);
   }
@@ -2432,6 +2468,9 @@ struct sfmhip_ba {
   int4* nd_gather_jobs = nullptr;
   int nd_n_gather = 0;
   bool chol_chains_attr_set = false;
+  // ba_finalize deferred to the next nd_gather (the LM loop's linearisations, when the dissected solve follows)
+  bool fin_pending = false, defer_fin = false;
+  double fin_radius = 0, fin_lo = 0, fin_hi = 0;
   // device storage owned
   std::vector<void*> allocs;
   size_t red_count = 0;
@@ -3073,8 +3112,24 @@ static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_o
     SFM_HIP_TRY(hipEventRecord(b->ev[2], st));
     b->ev_on[2] = true;
   }
+  if (b->defer_fin && b->nd_on && add_diag) {
+    b->fin_pending = true;
+    b->fin_radius = radius, b->fin_lo = o->min_lm_diagonal, b->fin_hi = o->max_lm_diagonal;
+    return SFMHIP_OK;
+  }
+  b->fin_pending = false;  // (this linearisation replaces one whose finalisation may still have been pending)
   hipLaunchKernelGGL(ba_finalize, dim3(1), dim3(1024), 0, st, d, radius, o->min_lm_diagonal, o->max_lm_diagonal,
                      b->world, add_diag ? 1 : 0);
+  SFM_HIP_TRY(hipGetLastError());
+  b->launches += 1;
+  return SFMHIP_OK;
+}
+
+// (a linearisation whose finalisation was left to a gather that will not come: before anyone reads its scalars)
+static int ba_finish_pending(sfmhip_ba* b) {
+  if (!b->fin_pending) return SFMHIP_OK;
+  b->fin_pending = false;
+  hipLaunchKernelGGL(ba_finalize, dim3(1), dim3(1024), 0, b->ctx->stream, b->d, b->fin_radius, b->fin_lo, b->fin_hi, b->world, 1);
   SFM_HIP_TRY(hipGetLastError());
   b->launches += 1;
   return SFMHIP_OK;
@@ -3315,6 +3370,7 @@ static int ba_nd_build(sfmhip_ba* b) {
         for (int tc = 0; tc < c.N; ++tc) gj.push_back(make_int4(i, tr, tc, 3));
     }
   }
+  gj.push_back(make_int4(0, 0, 0, 4));  // (ba_finalize's part, when it is deferred to the gather)
   SFM_TRY(ba_alloc(b, &b->nd_gather_jobs, gj.size()));
   SFM_HIP_TRY(hipMemcpy(b->nd_gather_jobs, gj.data(), gj.size() * sizeof(int4), hipMemcpyHostToDevice));
   b->nd_n_gather = (int)gj.size();
@@ -3376,7 +3432,9 @@ static int ba_reduced_solve_nd(sfmhip_ba* b) {
     SFM_HIP_TRY(hipFuncSetAttribute((const void*)chol_step2, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS_BYTES));
     b->chol_chains_attr_set = true;
   }
-  hipLaunchKernelGGL(nd_gather, dim3(b->nd_n_gather), dim3(256), 0, st, ns, b->nd_gather_jobs, d.red, d.red + b->ssz, d.ld);
+  hipLaunchKernelGGL(nd_gather, dim3(b->nd_n_gather), dim3(256), 0, st, ns, b->nd_gather_jobs, d.red, d.red + b->ssz, d.ld, d,
+                     b->fin_pending ? 1 : 0, b->fin_radius, b->fin_lo, b->fin_hi, b->world);
+  b->fin_pending = false;
   int nl = 1;
   if (dbg) nd_census(b, "gather");
   for (int k2 = 0; 2 * k2 < b->nd_max_ni; ++k2, ++nl) {
@@ -3600,7 +3658,9 @@ static int ba_one_iteration(sfmhip_ba* b, const sfmhip_ba_opts* o, bool timing_o
   IterScalars sc{};
   *stop = -1;
   ++s.iter;
+  b->defer_fin = true;  // (the dissected solve follows: its gather does ba_finalize's part)
   if (!s.have_lin) SFM_TRY(ba_linearize_eliminate(b, s.radius, o, true));
+  b->defer_fin = false;
   s.have_lin = false;
   SFM_TRY(ba_reduced_solve(b));
   if (b->ctx->timing) {
@@ -3667,7 +3727,9 @@ static int ba_one_iteration(sfmhip_ba* b, const sfmhip_ba_opts* o, bool timing_o
     s.decrease_factor = 2.0;
     // re-linearise at the new x; with the new radius this is also the next reduced system.
     // Enqueued only: its cost / gradient come back with the next iteration's scalars.
+    b->defer_fin = true;  // (finished by the next iteration's gather, or by ba_flush_lin)
     SFM_TRY(ba_linearize_eliminate(b, s.radius, o, true));
+    b->defer_fin = false;
     s.cost = sc.cost_c;  // provisional (same residuals, other summation order)
     s.have_lin = true;
     s.lin_unread = true;
@@ -3683,6 +3745,7 @@ static int ba_flush_lin(sfmhip_ba* b) {
   LmState& s = b->lm;
   if (!s.lin_unread) return SFMHIP_OK;
   IterScalars sc{};
+  SFM_TRY(ba_finish_pending(b));
   SFM_TRY(ba_read_scalars(b, &sc, false));
   s.cost = sc.cost;
   s.gmax = sc.gmax;
