@@ -1616,19 +1616,20 @@ __global__ __launch_bounds__(1024) void pack_offsets_kernel(const int* __restric
   }
   if (threadIdx.x == 0) offsets[n_pairs] = running;
 }
-// ... and the pairs' lists, gathered into one array of {queryIdx, trainIdx, distance bits} records
+// ... and the pairs' lists, gathered into three arrays back to back: queryIdx | trainIdx | distance bits, each of
+// offsets[n_pairs] entries (the host copies them out with three memcpy, not record by record)
 __global__ __launch_bounds__(256) void pack_lists_kernel(const int* __restrict__ counts, const long long* __restrict__ offsets,
-                                                         int maxq, const int* __restrict__ out_q, const int* __restrict__ out_t,
-                                                         const float* __restrict__ out_d, int* __restrict__ packed) {
+                                                         int n_pairs, int maxq, const int* __restrict__ out_q,
+                                                         const int* __restrict__ out_t, const float* __restrict__ out_d,
+                                                         int* __restrict__ packed) {
   const int p = blockIdx.x;
   const int n = counts[p];
-  const long long o = offsets[p];
+  const long long o = offsets[p], tot = offsets[n_pairs];
   for (int i = threadIdx.x; i < n; i += 256) {
     const size_t src = (size_t)p * maxq + i;
-    int* dst = packed + 3 * (o + i);
-    dst[0] = out_q[src];
-    dst[1] = out_t[src];
-    dst[2] = __float_as_int(out_d[src]);
+    packed[o + i] = out_q[src];
+    packed[tot + o + i] = out_t[src];
+    packed[2 * tot + o + i] = __float_as_int(out_d[src]);
   }
 }
 
@@ -2078,8 +2079,8 @@ extern "C" int sfmhip_matchplan_fetch(sfmhip_matchplan* pl, int32_t* counts, int
     if (!pl->d_offsets) SFM_TRY(sfm_dev_alloc(&pl->d_offsets, (size_t)pl->cap_pairs + 1));
     if (!pl->d_packed) SFM_TRY(sfm_dev_alloc(&pl->d_packed, 3 * (size_t)pl->cap_pairs * pl->maxq));
     hipLaunchKernelGGL(pack_offsets_kernel, dim3(1), dim3(1024), 0, st, pl->d_counts, pl->n_pairs, pl->d_offsets);
-    hipLaunchKernelGGL(pack_lists_kernel, dim3(pl->n_pairs), dim3(256), 0, st, pl->d_counts, pl->d_offsets, pl->maxq,
-                       pl->d_out_q, pl->d_out_t, pl->d_out_d, pl->d_packed);
+    hipLaunchKernelGGL(pack_lists_kernel, dim3(pl->n_pairs), dim3(256), 0, st, pl->d_counts, pl->d_offsets, pl->n_pairs,
+                       pl->maxq, pl->d_out_q, pl->d_out_t, pl->d_out_d, pl->d_packed);
     SFM_HIP_TRY(hipGetLastError());
   }
   SFM_HIP_TRY(hipMemcpyAsync(counts, pl->d_counts, sizeof(int) * pl->n_pairs, hipMemcpyDeviceToHost, st));
@@ -2095,11 +2096,9 @@ extern "C" int sfmhip_matchplan_fetch(sfmhip_matchplan* pl, int32_t* counts, int
   SFM_HIP_TRY(hipMemcpyAsync(stage, pl->d_packed, (size_t)tot * 12, hipMemcpyDeviceToHost, st));
   SFM_HIP_TRY(hipStreamSynchronize(st));
   const int32_t* rec = (const int32_t*)stage;
-  for (int64_t i = 0; i < tot; ++i) {
-    if (out_q) out_q[i] = rec[3 * i];
-    if (out_t) out_t[i] = rec[3 * i + 1];
-    if (out_dist) memcpy(&out_dist[i], &rec[3 * i + 2], 4);
-  }
+  if (out_q) memcpy(out_q, rec, (size_t)tot * 4);
+  if (out_t) memcpy(out_t, rec + tot, (size_t)tot * 4);
+  if (out_dist) memcpy(out_dist, rec + 2 * tot, (size_t)tot * 4);
   return SFMHIP_OK;
 }
 
