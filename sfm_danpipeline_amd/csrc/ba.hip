@@ -2690,9 +2690,9 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   // rounds of 512 workgroups; a wave takes 4 points per iteration (~3.7 us at n = 10) and a fixed ~7 iterations'
   // worth of prologue, reductions and scatter (s_memtime stamps, scripts/elim_stamps.py).  Pick the run length
   // that minimises rounds x (iterations per wave + fixed).  Measured at cfg4 (scripts/gpu_ba_elim_ab.py, stage
-  // time per LM iteration): 400 workgroups of 4 waves 100 us; 800 of 2 waves 106 us; 200 of 8 waves 150 us -- the
-  // two waves a SIMD gets from ONE workgroup run in lockstep (both want the vector ALU, then both the MFMA pipe,
-  // and the younger one loses), the waves of two workgroups drift apart and overlap; 800 of 4 waves (2 rounds) 136 us.
+  // time per LM iteration): 400 workgroups of 4 waves 100 us; 800 of 2 waves 106 us; 200 of 8 waves 150 us (not a
+  // matter of the two waves of a SIMD running in step: starting waves 4..7 up to 8 k cycles late changes nothing,
+  // 148-151 us); 800 of 4 waves (2 rounds) 136 us.
   int target = 64;
   const std::vector<int>& gstart = run_start;  // first sorted point of every run, + np
   {
