@@ -2475,6 +2475,8 @@ struct sfmhip_ba {
   std::vector<void*> allocs;
   size_t red_count = 0;
   double* d_red_pack = nullptr;  // world > 1: the all-reduce payload (packed upper triangle of S + tail)
+  int2* d_xblocks = nullptr;     // world > 1, sparse camera graph: the co-visible camera pairs (a <= b) that are exchanged
+  int n_xblocks = 0;             // 0: the dense exchange
   double* h_sc = nullptr;  // pinned: scalars read back per iteration (+ the sequence number of ba_publish)
   double* h_sc_dev = nullptr;  // the same buffer as the device sees it
   double h_seq = 0.0;
@@ -2980,6 +2982,39 @@ __global__ __launch_bounds__(256) void ba_pack_red(const double* __restrict__ re
   }
 }
 
+// The same exchange for a camera graph with few edges (the union over the ranks, known since the set-up): only the
+// 6 x 6 blocks of co-visible camera pairs (a <= b), the focal column and the tail cross xGMI --
+// [n_blocks x 36 | S[0..dim)[focal] | g | F^T b | diag | scalars + rank slots]; cfg4: 0.65 MB instead of 6.0 MB,
+// a latency-bound instead of a bandwidth-bound all-reduce on point-to-point links.
+__global__ __launch_bounds__(64) void ba_pack_sparse(const double* __restrict__ red, double* __restrict__ packed, int ld, int dim,
+                                                     const int2* __restrict__ blocks, int n_blocks, int tail_n, int unpack) {
+  const size_t ssz = (size_t)ld * ld;
+  double* redw = const_cast<double*>(red);
+  const int bi = blockIdx.x;
+  if (bi < n_blocks) {
+    const int2 ab = blocks[bi];
+    const int e = threadIdx.x;
+    if (e < 36) {
+      const size_t at = (size_t)(6 * ab.x + e / 6) * ld + 6 * ab.y + e % 6;
+      if (unpack) redw[at] = packed[(size_t)bi * 36 + e];
+      else packed[(size_t)bi * 36 + e] = red[at];
+    }
+    return;
+  }
+  const size_t base = (size_t)n_blocks * 36;
+  // the focal column (rows 0..dim-1, column dim-1), then the tail
+  for (int i = threadIdx.x + 64 * (bi - n_blocks); i < dim + tail_n; i += 64 * (int)(gridDim.x - n_blocks)) {
+    if (i < dim) {
+      const size_t at = (size_t)i * ld + dim - 1;
+      if (unpack) redw[at] = packed[base + i];
+      else packed[base + i] = red[at];
+    } else {
+      if (unpack) redw[ssz + i - dim] = packed[base + i];
+      else packed[base + i] = red[ssz + i - dim];
+    }
+  }
+}
+
 static int ba_allreduce(sfmhip_ba* b, double* buf, size_t count) {
   if (b->world <= 1) return SFMHIP_OK;
   const int rc = b->allreduce(buf, count, b->allreduce_user);
@@ -3101,11 +3136,22 @@ static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_o
   if (b->world > 1) {
     const int tail_n = 3 * b->ld + SC + b->world;
     const size_t tri = (size_t)b->ld * (b->ld + 1) / 2;
-    hipLaunchKernelGGL(ba_pack_red, dim3(b->ld + 1), dim3(256), 0, st, d.red, b->d_red_pack, b->ld, tail_n, 0);
-    SFM_HIP_TRY(hipGetLastError());
-    SFM_TRY(ba_allreduce(b, b->d_red_pack, tri + tail_n));
-    hipLaunchKernelGGL(ba_pack_red, dim3(b->ld + 1), dim3(256), 0, st, d.red, b->d_red_pack, b->ld, tail_n, 1);
-    SFM_HIP_TRY(hipGetLastError());
+    if (b->n_xblocks > 0) {
+      const int extra = (b->dim + tail_n + 63) / 64 < 64 ? (b->dim + tail_n + 63) / 64 : 64;
+      hipLaunchKernelGGL(ba_pack_sparse, dim3(b->n_xblocks + extra), dim3(64), 0, st, d.red, b->d_red_pack, b->ld, b->dim,
+                         (const int2*)b->d_xblocks, b->n_xblocks, tail_n, 0);
+      SFM_HIP_TRY(hipGetLastError());
+      SFM_TRY(ba_allreduce(b, b->d_red_pack, (size_t)b->n_xblocks * 36 + b->dim + tail_n));
+      hipLaunchKernelGGL(ba_pack_sparse, dim3(b->n_xblocks + extra), dim3(64), 0, st, d.red, b->d_red_pack, b->ld, b->dim,
+                         (const int2*)b->d_xblocks, b->n_xblocks, tail_n, 1);
+      SFM_HIP_TRY(hipGetLastError());
+    } else {
+      hipLaunchKernelGGL(ba_pack_red, dim3(b->ld + 1), dim3(256), 0, st, d.red, b->d_red_pack, b->ld, tail_n, 0);
+      SFM_HIP_TRY(hipGetLastError());
+      SFM_TRY(ba_allreduce(b, b->d_red_pack, tri + tail_n));
+      hipLaunchKernelGGL(ba_pack_red, dim3(b->ld + 1), dim3(256), 0, st, d.red, b->d_red_pack, b->ld, tail_n, 1);
+      SFM_HIP_TRY(hipGetLastError());
+    }
     b->launches += 2;
   }
   if (b->ctx->timing) {
@@ -3146,7 +3192,7 @@ static int ba_nd_build(sfmhip_ba* b) {
   b->nd_on = false;
   const int nc = b->nc;
   const char* env = getenv("SFMHIP_BA_ND");  // "0": dense always; "1": dissect whenever a cut exists (tests)
-  if (b->h_adj.empty() || (env && env[0] == '0')) return SFMHIP_OK;
+  if (b->h_adj.empty()) return SFMHIP_OK;
   const bool force = env && env[0] == '1';
   const int wpr = (nc + 63) / 64;
   std::vector<unsigned long long> adj = b->h_adj;
@@ -3164,7 +3210,22 @@ static int ba_nd_build(sfmhip_ba* b) {
     for (int i = 0; i < nc; ++i)
       for (int j = 0; j < nc; ++j)
         if (h[(size_t)i * nc + j] > 0.5) adj[(size_t)i * wpr + (j >> 6)] |= 1ull << (j & 63);
+    // ---- the exchange of a linearisation: only the blocks of camera pairs that some rank's points see together,
+    // when that is less than half of the packed triangle (SFMHIP_BA_XSPARSE=0: the dense exchange always)
+    std::vector<int2> xb;
+    for (int a = 0; a < nc; ++a)
+      for (int c = a; c < nc; ++c)
+        if (c == a || ((adj[(size_t)a * wpr + (c >> 6)] >> (c & 63)) & 1ull) || ((adj[(size_t)c * wpr + (a >> 6)] >> (a & 63)) & 1ull))
+          xb.push_back(make_int2(a, c));
+    const size_t tri = (size_t)b->ld * (b->ld + 1) / 2;
+    const char* xs = getenv("SFMHIP_BA_XSPARSE");
+    if (!(xs && xs[0] == '0') && xb.size() * 36 + b->dim < tri / 2) {
+      SFM_TRY(ba_alloc(b, &b->d_xblocks, xb.size()));
+      SFM_HIP_TRY(hipMemcpy(b->d_xblocks, xb.data(), xb.size() * sizeof(int2), hipMemcpyHostToDevice));
+      b->n_xblocks = (int)xb.size();
+    }
   }
+  if (env && env[0] == '0') return SFMHIP_OK;
   std::vector<std::vector<int>> nb(nc);
   for (int i = 0; i < nc; ++i)
     for (int j = 0; j < nc; ++j)

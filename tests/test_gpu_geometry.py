@@ -392,12 +392,13 @@ def _two_rank_worker(rank, world, port, out_dir, shape=(16, 6000, 6, 44)):
     pb = S.ba_problem(shape[0], shape[1], shape[2], seed=shape[3])
     loc = sharding.local_ba_problem(pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], pb["pts0"], rank, world)
     prob = B.BaProblem(shape[0], len(loc["pts"]), loc["obs_cam"], loc["obs_pt"], loc["obs_xy"], ctx=ctx)
-    prob.set_allreduce(sharding.StagedAllReduce(device="cuda:0"), rank, world)
+    ar = sharding.StagedAllReduce(device="cuda:0")
+    prob.set_allreduce(ar, rank, world)
     prob.set_params(pb["cams0"], loc["pts"], pb["focal0"])
     s = prob.iterate(6)
     c, p, f = prob.get_params()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), c=c, p=p, f=f, lo=loc["lo"], hi=loc["hi"], cost=s.final_cost,
-             steps=s.successful_steps, chains=prob.reduced_layout()["chains"])
+             steps=s.successful_steps, chains=prob.reduced_layout()["chains"], counts=np.array(ar.counts))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -422,7 +423,18 @@ def test_two_ranks_share_the_device_and_run_the_sharded_solver(ctx, tmp_path, mo
     mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), shape), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     assert (int(r0["chains"]) >= 2) == (nd == "1") and int(r0["chains"]) == int(r1["chains"])
+    # the linearisations' exchange: the blocks of co-visible camera pairs + focal column + tail, not the packed
+    # triangle (cameras that see each other across at most `views` positions of the ring: a sparse graph)
+    ld = (6 * shape[0] + 1 + 63) // 64 * 64
+    dense = ld * (ld + 1) // 2 + 3 * ld + 16 + 2
     pb = synth.ba_problem(shape[0], shape[1], shape[2], seed=shape[3])
+    seen = {(a, a) for a in range(shape[0])}
+    for cams in {tuple(sorted(set(c))) for c in pb["obs_cam"].reshape(-1, shape[2]).tolist()}:
+        seen.update((a, b) for i, a in enumerate(cams) for b in cams[i:])
+    sparse = 36 * len(seen) + (6 * shape[0] + 1) + 3 * ld + 16 + 2
+    want, other = (sparse, dense) if shape[0] >= 64 else (dense, sparse)   # (below 64 cameras the triangle is small anyway)
+    assert want in r0["counts"] and other not in r0["counts"] and np.array_equal(r0["counts"], r1["counts"]), \
+        (sparse, dense, sorted(set(r0["counts"].tolist())))
     one = bundle.BaProblem(shape[0], shape[1], pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
     one.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
     s1 = one.iterate(6)
