@@ -6,7 +6,8 @@
  * its own block of points (sfmhip_ba_create on the rank's shard), and the per-iteration sum of the
  * reduced camera system -- the exchange step behind ceres::Solve(DENSE_SCHUR), reference
  * src/BundleAdjustment.cpp:116,123 -- is ONE ncclAllReduce(sum, ncclDouble) over xGMI on the context's
- * stream, plus the 8-double step evaluation.  Kept in a library of its own so that libsfmhip.so carries
+ * stream (the packed upper triangle, or only the 6 x 6 blocks of co-visible camera pairs when the camera graph is
+ * sparse), plus the 136-double step evaluation.  Kept in a library of its own so that libsfmhip.so carries
  * no RCCL dependency (a process that already hosts another RCCL, e.g. torch's, keeps using the
  * callback form sfmhip_ba_set_allreduce).
  */
