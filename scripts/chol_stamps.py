@@ -12,7 +12,7 @@ SO = os.path.join(PKG, "libsfmhip_diag.so")
 
 
 def build():
-    srcs = ["context.hip", "match.hip", "triangulate.hip", "incremental.hip", "ba.hip"]
+    srcs = ["context.hip", "match.hip", "triangulate.hip", "incremental.hip", "score.hip", "sift.hip", "ba.hip"]
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
            "-Wno-unused-value", "-ffp-contract=fast", "-DSFM_CHOL_STAMPS", f"-I{ROOT}/include", "-o", SO] + \
           [os.path.join(PKG, "csrc", s) for s in srcs]
