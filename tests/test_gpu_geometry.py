@@ -445,3 +445,39 @@ def test_two_ranks_share_the_device_and_run_the_sharded_solver(ctx, tmp_path, mo
     assert np.allclose(r0["c"], r1["c"], rtol=1e-12, atol=1e-14)          # replicas stay together
     # (points: absolute tolerance -- coordinates near zero carry the f64 summation-order noise of the exchange)
     assert np.allclose(np.concatenate([r0["p"], r1["p"]]), p1, rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_solver_on_a_busy_device_walks_the_same_iterates(ctx):
+    """The reduced solve with the CUs contended: a second stream keeps the device full of k-NN sweeps while the LM
+    iterations run, so the factorisation's workgroups do not start together.  (Until late in round 2 the owner
+    workgroup of a chol_step2 launch overwrote the diagonal tiles the other panel workgroups read at their start: a
+    panel workgroup that started late read L for D and the step came out wrong or NaN -- two processes on one GPU,
+    or a second stream, were enough.)"""
+    import torch
+    from sfm_danpipeline_amd import matcher
+    dev = torch.device("cuda:0")
+    side = torch.cuda.Stream(dev)
+    ctx2 = _lib.Context(0, stream=side.cuda_stream)
+    imgs = synth.sift_image_set(24, 2000, 128, seed=99)
+    iset = matcher.ImageSet(imgs, ctx=ctx2)
+    plan = matcher.MatchPlan(iset, synth.all_pairs(24))
+    for shape in ((120, 12000, 8), (16, 6000, 6)):
+        pb = synth.ba_problem(shape[0], shape[1], shape[2], seed=31)
+        prob = bundle.BaProblem(shape[0], shape[1], pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
+        prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+        quiet = prob.iterate(8)
+        cq, pq, fq = prob.get_params()
+        for rep in range(3):
+            prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+            iset.prepare_async()
+            for _ in range(12):                       # ~8 ms of sweeps queued on the other stream
+                plan.run_async(0.8)
+            busy = prob.iterate(8)
+            cb, pb_, fb = prob.get_params()
+            ctx2.synchronize()
+            assert (busy.successful_steps, busy.iterations) == (quiet.successful_steps, quiet.iterations)
+            assert abs(busy.final_cost - quiet.final_cost) <= 1e-9 * quiet.final_cost
+            assert np.allclose(cb, cq, rtol=1e-9, atol=1e-12) and abs(fb - fq) <= 1e-9 * abs(fq)
+        prob.close()
+    ctx2.close() if hasattr(ctx2, "close") else None
