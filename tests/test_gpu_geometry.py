@@ -480,4 +480,6 @@ def test_solver_on_a_busy_device_walks_the_same_iterates(ctx):
             assert abs(busy.final_cost - quiet.final_cost) <= 1e-9 * quiet.final_cost
             assert np.allclose(cb, cq, rtol=1e-9, atol=1e-12) and abs(fb - fq) <= 1e-9 * abs(fq)
         prob.close()
-    ctx2.close() if hasattr(ctx2, "close") else None
+    plan.close()
+    iset.close()
+    ctx2.close()                                      # (after everything that lives on it)
