@@ -2093,6 +2093,17 @@ __global__ __launch_bounds__(256) void nd_combine(NdSet ns) {
   v4d acc[4];  // [2 * ci + ri]: 16x16 sub-tiles, lane = row j16 of the sub-tile, registers = columns q + 4g
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = v4d{0.0, 0.0, 0.0, 0.0};
+  // (wave 0 adds the sums to the separator's tile at the end: its values are asked for now, not after the reduction)
+  double spv[16];
+  if (wave == 0) {
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+      for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          spv[4 * (2 * c2 + ri) + g] = sp.M[(size_t)(tc * 32 + 16 * c2 + q + 4 * g) * sp.ld + tr * 32 + 16 * ri + j16];
+  }
   for (int ci = wave; ci < ns.n; ci += 4) {
     const NdChain ch = ns.c[ci];
     const int o = ch.ni * 32, p0 = o - 64, rb = o + tr * 32, cb = o + tc * 32;
@@ -2134,7 +2145,7 @@ __global__ __launch_bounds__(256) void nd_combine(NdSet ns) {
         for (int g = 0; g < 4; ++g) {
           const int e = 4 * (2 * c2 + ri) + g;
           double* pt = sp.M + (size_t)(tc * 32 + 16 * c2 + q + 4 * g) * sp.ld + tr * 32 + 16 * ri + j16;
-          *pt += s_red[0][e][lane] + s_red[1][e][lane] + s_red[2][e][lane] + s_red[3][e][lane];
+          *pt = spv[e] + (s_red[0][e][lane] + s_red[1][e][lane] + s_red[2][e][lane] + s_red[3][e][lane]);
         }
   }
 }
@@ -3427,8 +3438,9 @@ static int ba_nd_build(sfmhip_ba* b) {
       // what the factorisation reads before it writes: the lower right block of M (zero), the interior rows of X
       // (the identity; its tiles left of the diagonal are read too) -- no memset of the chain buffers
       for (int tc = c.ni; tc <= tr; ++tc) gj.push_back(make_int4(i, tr, tc, 2));
+      // (a chain's X is only formed up to its interior columns: nxc in chol_step2_chains)
       if (tr < c.ni)
-        for (int tc = 0; tc < c.N; ++tc) gj.push_back(make_int4(i, tr, tc, 3));
+        for (int tc = 0; tc < (i < P ? c.ni : c.N); ++tc) gj.push_back(make_int4(i, tr, tc, 3));
     }
   }
   gj.push_back(make_int4(0, 0, 0, 4));  // (ba_finalize's part, when it is deferred to the gather)
