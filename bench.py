@@ -140,7 +140,7 @@ def main():
     # BA first, the matching sweeps last: the timed matching region then starts from the load it measures.  (With
     # the LM iterations between the warm-up sweeps and the timed sweeps, the first sweeps after the switch from the
     # latency-bound BA kernels to the MFMA-bound sweep ran slow: a 20-step region measured 0.73 ms per sweep where
-    # a 100-step one measured 0.686, scripts/gpu_sync_test.py: 0.667 either way without the switch.)
+    # a 100-step one measured 0.686, scripts/gpu_sync_check.py: 0.667 either way without the switch.)
     ba.iterate(max(args.warmup, 1))
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < 0.1:      # (and the device out of its idle power state)

@@ -159,18 +159,25 @@ int sfmhip_sift_detect_and_compute(sfmhip_ctx* ctx, const uint8_t* gray, int row
 /* ---- the scoring half of findBestPair (reference src/Sfm.cpp:536-563) ----
  * For every pair of a batch the inlier count of
  *   cv::findEssentialMat(alignedLeft, alignedRight, K, CV_RANSAC, prob, threshold, mask)       (src/Sfm.cpp:542-543)
- * as OpenCV 3.4.1 computes it: points normalised by (p - c) / f, threshold / ((fx + fy) / 2), cv::RNG restarted at
- * (uint64)-1, five distinct sample indices, the models of a sample in turn, goodCount > max(best, 4) updates the
- * best and the iteration limit (RANSACUpdateNumIters, at most 1000), error = squared epipolar residual over the four
- * squared line coefficients as a float <= (float)(t*t).  The five-point solver is this library's own (OpenCV is not
- * available to pin it against): the count does not depend on the order of a sample's models, the mask of two
- * equally good models can.
+ * as OpenCV 3.4.1 computes it: points normalised as p * (1 / f) + (-c / f), threshold / ((fx + fy) / 2), cv::RNG
+ * restarted at (uint64)-1, five distinct sample indices, the models of a sample in turn, goodCount > max(best, 4)
+ * updates the best and the iteration limit (RANSACUpdateNumIters, at most 1000), error = squared epipolar residual
+ * over the four squared line coefficients as a float <= (float)(t*t).  The five-point solver follows the library's
+ * runKernel step by step (Jacobi-SVD null space, 10 x 20 elimination, tenth-degree polynomial, solvePoly's
+ * Durand-Kerner iteration, real iff |imag| <= 1e-10, SVD::solveZ, models in root order); OpenCV is not available to
+ * pin it against.
  * offsets: n_pairs + 1 prefix sums of the match counts; left_xy / right_xy: 2 doubles per match (pixels), pair after
  * pair (host memory); inliers: n_pairs; mask (optional): one byte per match; iterations (optional): RANSAC iterations
  * run per pair.  Pairs with fewer than 5 matches score 0 (findEssentialMat returns an empty matrix). */
 int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_t* offsets, const double* left_xy,
                            const double* right_xy, double fx, double fy, double cx, double cy, double prob,
                            double threshold, int32_t* inliers, uint8_t* mask, int32_t* iterations);
+
+/* OR over the five-point samples of the context's last sfmhip_score_essential call: bit 0 = two Durand-Kerner
+ * iterates coincided bit for bit, bit 1 = the polynomial's leading coefficient was <= DBL_EPSILON -- the two corners
+ * of cv::solvePoly whose library behaviour (a cube-root branch; part of a work buffer returned as roots) is not
+ * reproduced.  0 = every sample went the documented way. */
+int sfmhip_score_last_flags(sfmhip_ctx* ctx);
 
 /* The homography side of the same loop: findHomographyInliers (reference src/Sfm.cpp:667-689) =
  *   cv::countNonZero(mask) of cv::findHomography(query_points, train_points, CV_RANSAC, 0.004 * maxVal, mask)

@@ -162,3 +162,80 @@ def solve_scipy(cams0, pts0, focal0, obs_cam, obs_pt, obs_xy, **kw):
                         gtol=1e-12, **kw)
     c, p, f = unpack(res.x)
     return c.copy(), p.copy(), float(f), float(res.cost)
+
+
+# ------------------------------------------------------------------ five-point problem, action-matrix route
+# (an independent check of the C restatement of OpenCV's polynomial route, oracle/sfm_oracle_score.c)
+MONO = [(3, 0, 0), (2, 1, 0), (2, 0, 1), (1, 2, 0), (1, 1, 1), (1, 0, 2), (0, 3, 0), (0, 2, 1), (0, 1, 2), (0, 0, 3),
+        (2, 0, 0), (1, 1, 0), (1, 0, 1), (0, 2, 0), (0, 1, 1), (0, 0, 2), (1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 0, 0)]
+
+
+def _pmul(a, b):
+    """product of two polynomials in (x, y, z) stored as c[i, j, k] (4 x 4 x 4: total degree <= 3 is all we form)"""
+    out = np.zeros((4, 4, 4))
+    for (i, j, k), v in np.ndenumerate(a):
+        if v != 0.0:
+            for (p, q, r), w in np.ndenumerate(b):
+                if w != 0.0 and i + p < 4 and j + q < 4 and k + r < 4:
+                    out[i + p, j + q, k + r] += v * w
+    return out
+
+
+def constraint_matrix(X, Y, Z, W):
+    """10 x 20 coefficients (monomials MONO) of det(E) = 0 and 2 E E^T E - tr(E E^T) E = 0, E = xX + yY + zZ + W."""
+    E = np.empty((3, 3), object)
+    for a in range(3):
+        for b in range(3):
+            c = np.zeros((4, 4, 4))
+            c[1, 0, 0], c[0, 1, 0], c[0, 0, 1], c[0, 0, 0] = X[a, b], Y[a, b], Z[a, b], W[a, b]
+            E[a, b] = c
+    det = (_pmul(_pmul(E[0, 0], E[1, 1]), E[2, 2]) + _pmul(_pmul(E[0, 1], E[1, 2]), E[2, 0]) + _pmul(_pmul(E[0, 2], E[1, 0]), E[2, 1])
+           - _pmul(_pmul(E[0, 2], E[1, 1]), E[2, 0]) - _pmul(_pmul(E[0, 1], E[1, 0]), E[2, 2]) - _pmul(_pmul(E[0, 0], E[1, 2]), E[2, 1]))
+    EEt = np.empty((3, 3), object)
+    for a in range(3):
+        for b in range(3):
+            EEt[a, b] = sum(_pmul(E[a, k], E[b, k]) for k in range(3))
+    tr = EEt[0, 0] + EEt[1, 1] + EEt[2, 2]
+    rows = [det]
+    for a in range(3):
+        for b in range(3):
+            rows.append(2.0 * sum(_pmul(EEt[a, k], E[k, b]) for k in range(3)) - _pmul(tr, E[a, b]))
+    return np.array([[r[m] for m in MONO] for r in rows])
+
+
+def canonical_order(models):
+    """A sample's models in an order that does not depend on the null-space basis: by the first entry of E / ||E||_F,
+    sign fixed so that the entry of largest magnitude is positive."""
+    def key(E):
+        n = E / np.linalg.norm(E)
+        k = np.argmax(np.abs(n))
+        return (n * np.sign(n.flat[k]))[0, 0]
+    return sorted(models, key=key)
+
+
+def five_point_action_matrix(q1, q2):
+    """Essential matrices E (q2^T E q1 = 0 for the five pairs, q = normalised image points) through the action matrix
+    of the ten cubic constraints (Stewenius): an independent check of oracle/sfm_oracle_score.c, in canonical_order."""
+    x1, y1, x2, y2 = q1[:, 0], q1[:, 1], q2[:, 0], q2[:, 1]
+    Q = np.stack([x1 * x2, x2 * y1, x2, x1 * y2, y1 * y2, y2, x1, y1, np.ones(5)], axis=1)
+    _, _, Vt = np.linalg.svd(Q)
+    X, Y, Z, W = (Vt[5 + k].reshape(3, 3) for k in range(4))
+    M = constraint_matrix(X, Y, Z, W)
+    try:
+        B = np.linalg.solve(M[:, :10], M[:, 10:])
+    except np.linalg.LinAlgError:
+        return []
+    A = np.zeros((10, 10))
+    A[:6] = -B[:6]
+    A[6, 0] = A[7, 1] = A[8, 2] = A[9, 6] = 1.0
+    w, V = np.linalg.eig(A)
+    sols = []
+    for k in range(10):
+        if abs(w[k].imag) > 1e-10 * max(1.0, abs(w[k].real)):
+            continue
+        v = V[:, k].real
+        if v[9] == 0:
+            continue
+        x, y, z = v[6] / v[9], v[7] / v[9], v[8] / v[9]
+        sols.append(x * X + y * Y + z * Z + W)
+    return canonical_order(sols)

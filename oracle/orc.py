@@ -20,7 +20,7 @@ CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
     srcs = [os.path.join(_HERE, f) for f in ("sfm_oracle_match.c", "sfm_oracle_ba.c", "sfm_oracle_incr.c",
-                                             "sfm_oracle.h", "Makefile")]
+                                             "sfm_oracle_score.c", "sfm_oracle.h", "Makefile")]
     if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs):
         return _SO
     subprocess.check_call(["make", "-C", _HERE, "-B", "libsfm_oracle.so"], stdout=subprocess.DEVNULL)
@@ -114,6 +114,16 @@ def lib():
         L.orc_find_2d3d.restype = C.c_int
         L.orc_merge_new_points.argtypes = [vp, C.c_int, vp, C.c_int, C.c_float, vp, vp]
         L.orc_merge_new_points.restype = C.c_int
+        L.orc_five_point.argtypes = [vp, vp, vp, vp]
+        L.orc_five_point.restype = C.c_int
+        L.orc_em_normalize.argtypes = [vp, C.c_int, vp, vp]
+        L.orc_em_normalize.restype = None
+        L.orc_ransac_update_num_iters.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
+        L.orc_ransac_update_num_iters.restype = C.c_int
+        L.orc_find_essential_mat.argtypes = [vp, vp, C.c_int, vp, C.c_double, C.c_double, C.c_int, vp, vp, vp, vp]
+        L.orc_find_essential_mat.restype = C.c_int
+        L.orc_score_essential_many.argtypes = [C.c_int, vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, C.c_int, vp]
+        L.orc_score_essential_many.restype = C.c_int
         _lib = L
     return _lib
 
@@ -352,3 +362,52 @@ def merge_new_points(cloud_xyz, new_xyz, min_dist=0.01):
     rc = lib().orc_merge_new_points(_p(cloud), len(cloud), _p(new), len(new), C.c_float(min_dist), _p(acc), C.byref(n))
     assert rc == 0
     return acc[:len(new)].astype(bool), n.value
+
+
+def five_point(q1, q2):
+    """EMEstimatorCallback::runKernel on five normalised correspondences: (list of 3x3 E in OpenCV's order, flags)."""
+    q1 = np.ascontiguousarray(q1, np.float64).reshape(5, 2)
+    q2 = np.ascontiguousarray(q2, np.float64).reshape(5, 2)
+    E = np.zeros((10, 3, 3))
+    fl = C.c_int(0)
+    n = lib().orc_five_point(_p(q1), _p(q2), _p(E), C.byref(fl))
+    return [E[i].copy() for i in range(n)], fl.value
+
+
+def em_normalize(xy, K):
+    xy = np.ascontiguousarray(xy, np.float64).reshape(-1, 2)
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    out = np.empty_like(xy)
+    lib().orc_em_normalize(_p(xy), len(xy), _p(K), _p(out))
+    return out
+
+
+def find_essential_mat(pts1, pts2, K, prob=0.999, threshold=1.0, max_iters=1000):
+    """cv::findEssentialMat(pts1, pts2, K, RANSAC, prob, threshold, mask) (reference src/Sfm.cpp:543-546):
+    (inlier count, mask, E or None, iterations run, flags)."""
+    a = np.ascontiguousarray(pts1, np.float64).reshape(-1, 2)
+    b = np.ascontiguousarray(pts2, np.float64).reshape(-1, 2)
+    Kc = np.ascontiguousarray(K, np.float64).reshape(9)
+    mask = np.zeros(max(len(a), 1), np.uint8)
+    E = np.zeros(9)
+    it, fl = C.c_int(0), C.c_int(0)
+    cnt = lib().orc_find_essential_mat(_p(a), _p(b), len(a), _p(Kc), prob, threshold, max_iters, _p(mask), _p(E),
+                                       C.byref(it), C.byref(fl))
+    return cnt, mask[:len(a)], (E.reshape(3, 3) if cnt > 0 else None), it.value, fl.value
+
+
+def score_essential_many(offsets, left_xy, right_xy, K, prob=0.999, threshold=1.0, threads=1, want_mask=False):
+    """the scoring of many pairs: (counts, iterations, masks or None, flags of any sample)"""
+    off = np.ascontiguousarray(offsets, np.int32)
+    a = np.ascontiguousarray(left_xy, np.float64).reshape(-1, 2)
+    b = np.ascontiguousarray(right_xy, np.float64).reshape(-1, 2)
+    Kc = np.ascontiguousarray(K, np.float64).reshape(9)
+    n = len(off) - 1
+    cnt = np.zeros(max(n, 1), np.int32)
+    its = np.zeros(max(n, 1), np.int32)
+    masks = np.zeros(max(len(a), 1), np.uint8) if want_mask else None
+    fl = C.c_int32(0)
+    rc = lib().orc_score_essential_many(n, _p(off), _p(a), _p(b), _p(Kc), prob, threshold, _p(cnt), _p(its), _p(masks),
+                                        int(threads), C.byref(fl))
+    assert rc == 0
+    return cnt[:n], its[:n], (masks[:len(a)] if want_mask else None), fl.value

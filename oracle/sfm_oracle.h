@@ -132,6 +132,17 @@ int orc_find_2d3d(const int32_t* trk_ptr, const int32_t* trk_view, const int32_t
 int orc_merge_new_points(const double* cloud_xyz, int n_cloud, const double* new_xyz, int n_new,
                          float min_dist, uint8_t* accept, int32_t* n_accepted);
 
+/* findBestPair's scoring (src/Sfm.cpp:543-546): cv::findEssentialMat(RANSAC) as OpenCV 3.4.1 runs it -- see
+ * sfm_oracle_score.c.  flags: bit 0 / bit 1 = a sample reached one of the two solvePoly corners that are not restated. */
+int orc_five_point(const double* q1, const double* q2, double* E, int* flags);
+void orc_em_normalize(const double* xy, int n, const double K[9], double* out);
+int orc_ransac_update_num_iters(double p, double ep, int model_points, int max_iters);
+int orc_find_essential_mat(const double* pts1, const double* pts2, int count, const double K[9], double prob,
+                           double threshold, int max_iters, uint8_t* mask, double* E_out, int* iters, int* flags);
+int orc_score_essential_many(int n_pairs, const int32_t* offsets, const double* left_xy, const double* right_xy,
+                             const double K[9], double prob, double threshold, int32_t* counts, int32_t* iters,
+                             uint8_t* masks, int threads, int32_t* flags_any);
+
 #ifdef __cplusplus
 }
 #endif

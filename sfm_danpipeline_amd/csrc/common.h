@@ -37,6 +37,7 @@ struct sfmhip_ctx {
   // two grow-only device blocks for entry points that would otherwise hipMalloc / hipFree per call (sift.hip)
   void* dev_scratch[2] = {nullptr, nullptr};
   size_t dev_scratch_bytes[2] = {0, 0};
+  int score_flags = 0;  // OR of the five-point samples' flags of the last sfmhip_score_essential call (score.hip)
 };
 
 int sfm_ctx_pinned(sfmhip_ctx* ctx, size_t bytes, void** out);

@@ -9,13 +9,14 @@
 // and the host replays ptsetreg's update rule over the counts in order -- with the host's libm, as the reference
 // does -- until every pair has reached its own iteration limit.
 //
-// The five-point solver is NOT OpenCV's code path (generated coefficient code + solvePoly): null space by Gauss-Jordan
-// (+ Gram-Schmidt), the ten cubic constraints expanded numerically, Nister's elimination order, the tenth-degree
-// polynomial in z, its real roots by the interlacing of the derivatives' roots (bisection), x and y from the
-// cofactors.  Same essential matrices up to scale and rounding; a sample's models are put in an order that does not
-// depend on the basis (first entry of E/||E||, sign fixed by the largest entry).  The inlier COUNT RANSAC ends with
-// does not depend on that order; which of two equally good models supplies the mask can.  The tests check this path
-// against a numpy restatement (test infrastructure; its header says what is pinned: nothing, OpenCV is not in the image).
+// The five-point solver follows OpenCV 3.4.1's EMEstimatorCallback::runKernel step by step (round 3; rounds 1-2 took
+// another route to the same matrices): the null space from the library's one-sided Jacobi SVD with its RNG-filled
+// singular vectors, the 10 x 20 constraint matrix in Nister's monomial order, Mat::inv() (LU against the identity)
+// times the right half, the 3 x 13 matrix B, the tenth-degree polynomial, cv::solvePoly's Durand-Kerner iteration, the
+// library's |imag| <= 1e-10 test, (x, y) from SVD::solveZ, E scaled to unit norm, models in root order.  What of the
+// library cannot be reproduced to the last bit (its generated coefficient sums) is listed in the header of the
+// checker (the CPU restatement of the same route: test infrastructure, never linked here); parity is unpinned (OpenCV is not in
+// the image).  sfmhip_score_last_flags reports samples that reached a corner of solvePoly that is not restated.
 #include "common.h"
 #include <algorithm>
 #include <cfloat>
@@ -42,118 +43,242 @@ __device__ void mul21(const double* a /*10*/, const double* b /*4*/, double* out
   for (int i = 0; i < 10; ++i)
     for (int j = 0; j < 4; ++j) out[T21[i][j]] += s * a[i] * b[j];
 }
-__device__ double horner(const double* c, int n, double z) {  // sum c[k] z^k, k <= n
-  double v = c[n];
-  for (int k = n - 1; k >= 0; --k) v = v * z + c[k];
-  return v;
-}
-// ascending real roots of sum c[k] z^k (k <= 10): the real roots of each derivative bracket those of the one before
-__device__ int real_roots(const double* c10, double* roots) {
-  int n = 10;
-  while (n > 0 && c10[n] == 0.0) --n;
-  if (n == 0) return 0;
-  double bound = 0.0;
-  for (int k = 0; k < n; ++k) bound = fmax(bound, fabs(c10[k] / c10[n]));
-  bound += 1.0;
-  if (!(bound < 1e300)) return 0;
-  double d[11];
-  double cur[12], nxt[12];
-  int ncur = 0;
-  for (int lvl = n - 1; lvl >= 0; --lvl) {
-    // the lvl-th derivative, degree n - lvl
-    const int deg = n - lvl;
-    for (int k = 0; k <= deg; ++k) {
-      double f = c10[k + lvl];
-      for (int t = 0; t < lvl; ++t) f *= (double)(k + lvl - t);
-      d[k] = f;
-    }
-    int nn = 0;
-    for (int s = 0; s <= ncur; ++s) {
-      const double a = s == 0 ? -bound : cur[s - 1], b = s == ncur ? bound : cur[s];
-      const double fa = horner(d, deg, a), fb = horner(d, deg, b);
-      if (fa == 0.0) {
-        nxt[nn++] = a;
-        continue;
-      }
-      if (!(fa * fb <= 0.0) || !(b > a)) continue;
-      double lo = a, hi = b;
-      for (int it = 0; it < 200; ++it) {
-        const double mid = 0.5 * (lo + hi);
-        if (mid == lo || mid == hi) break;
-        const double fm = horner(d, deg, mid);
-        if ((fm > 0.0) == (fa > 0.0)) lo = mid;
-        else hi = mid;
-      }
-      nxt[nn++] = 0.5 * (lo + hi);
-    }
-    ncur = nn;
-    for (int s = 0; s < nn; ++s) cur[s] = nxt[s];
+// ---- cv::RNG (multiply with carry), as JacobiSVDImpl_ seeds it
+struct DevRng {
+  unsigned long long state;
+  __device__ unsigned next() {
+    state = (unsigned long long)(unsigned)state * 4164903690U + (unsigned)(state >> 32);
+    return (unsigned)state;
   }
-  for (int s = 0; s < ncur; ++s) roots[s] = cur[s];
-  return ncur;
+};
+
+// ---- core/lapack.cpp JacobiSVDImpl_<double>: one-sided Jacobi on the N rows (length M, stride LDA) of At; rows N..N1-1
+// (and rows whose singular value is <= DBL_MIN) filled from RNG(0x12345678) sign vectors, orthogonalised twice against
+// the rows before them.  Vt (N x N) accumulates the rotations.  Operation for operation the restatement in
+// the CPU restatement used as checker (test infrastructure), which cites the library.
+template <int M, int N, int N1, int LDA>
+__device__ void jacobi_svd(double* At, double* W, double* Vt) {
+  const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
+  const int max_iter = M > 30 ? M : 30;
+  for (int i = 0; i < N; ++i) {
+    double sd = 0;
+    for (int k = 0; k < M; ++k) {
+      const double t = At[i * LDA + k];
+      sd += t * t;
+    }
+    W[i] = sd;
+    for (int k = 0; k < N; ++k) Vt[i * N + k] = 0;
+    Vt[i * N + i] = 1;
+  }
+  for (int iter = 0; iter < max_iter; ++iter) {
+    bool changed = false;
+    for (int i = 0; i < N - 1; ++i)
+      for (int j = i + 1; j < N; ++j) {
+        double *Ai = At + i * LDA, *Aj = At + j * LDA;
+        double a = W[i], p = 0, b = W[j];
+        for (int k = 0; k < M; ++k) p += Ai[k] * Aj[k];
+        if (fabs(p) <= eps * sqrt(a * b)) continue;
+        p *= 2;
+        const double beta = a - b, gamma = hypot(p, beta);
+        double c, sn;
+        if (beta < 0) {
+          const double delta = (gamma - beta) * 0.5;
+          sn = sqrt(delta / gamma);
+          c = p / (gamma * sn * 2);
+        } else {
+          c = sqrt((gamma + beta) / (gamma * 2));
+          sn = p / (gamma * c * 2);
+        }
+        a = b = 0;
+        for (int k = 0; k < M; ++k) {
+          const double t0 = c * Ai[k] + sn * Aj[k];
+          const double t1 = -sn * Ai[k] + c * Aj[k];
+          Ai[k] = t0;
+          Aj[k] = t1;
+          a += t0 * t0;
+          b += t1 * t1;
+        }
+        W[i] = a;
+        W[j] = b;
+        changed = true;
+        double *Vi = Vt + i * N, *Vj = Vt + j * N;
+        for (int k = 0; k < N; ++k) {
+          const double t0 = c * Vi[k] + sn * Vj[k];
+          const double t1 = -sn * Vi[k] + c * Vj[k];
+          Vi[k] = t0;
+          Vj[k] = t1;
+        }
+      }
+    if (!changed) break;
+  }
+  for (int i = 0; i < N; ++i) {
+    double sd = 0;
+    for (int k = 0; k < M; ++k) {
+      const double t = At[i * LDA + k];
+      sd += t * t;
+    }
+    W[i] = sqrt(sd);
+  }
+  for (int i = 0; i < N - 1; ++i) {
+    int j = i;
+    for (int k = i + 1; k < N; ++k)
+      if (W[j] < W[k]) j = k;
+    if (i != j) {
+      double t = W[i];
+      W[i] = W[j];
+      W[j] = t;
+      for (int k = 0; k < M; ++k) {
+        t = At[i * LDA + k];
+        At[i * LDA + k] = At[j * LDA + k];
+        At[j * LDA + k] = t;
+      }
+      for (int k = 0; k < N; ++k) {
+        t = Vt[i * N + k];
+        Vt[i * N + k] = Vt[j * N + k];
+        Vt[j * N + k] = t;
+      }
+    }
+  }
+  DevRng rng{0x12345678ull};
+  for (int i = 0; i < N1; ++i) {
+    double sd = i < N ? W[i] : 0;
+    for (int ii = 0; ii < 100 && sd <= minval; ++ii) {
+      const double val0 = 1. / M;
+      for (int k = 0; k < M; ++k) At[i * LDA + k] = (rng.next() & 256) != 0 ? val0 : -val0;
+      for (int it2 = 0; it2 < 2; ++it2)
+        for (int j = 0; j < i; ++j) {
+          sd = 0;
+          for (int k = 0; k < M; ++k) sd += At[i * LDA + k] * At[j * LDA + k];
+          double asum = 0;
+          for (int k = 0; k < M; ++k) {
+            const double t = At[i * LDA + k] - sd * At[j * LDA + k];
+            At[i * LDA + k] = t;
+            asum += fabs(t);
+          }
+          asum = asum > eps * 100 ? 1 / asum : 0;
+          for (int k = 0; k < M; ++k) At[i * LDA + k] *= asum;
+        }
+      sd = 0;
+      for (int k = 0; k < M; ++k) {
+        const double t = At[i * LDA + k];
+        sd += t * t;
+      }
+      sd = sqrt(sd);
+    }
+    const double sc = sd > minval ? 1 / sd : 0.;
+    for (int k = 0; k < M; ++k) At[i * LDA + k] *= sc;
+  }
 }
 
-// Essential matrices of five correspondences (q2^T E q1 = 0), row-major 9 doubles each; returns how many (<= 10)
-__device__ int five_point(const double (*q1)[2], const double (*q2)[2], double (*Eout)[9]) {
-  // ---- null space of the 5 x 9 epipolar constraints: Gauss-Jordan, full pivoting
-  double A[5][9];
-  int cols[9];
+// ---- hal::LU64f: A (10 x 10) against 10 right-hand sides b; false when a pivot is below 100 DBL_EPSILON
+__device__ bool lu_solve10(double* A, double* b) {
+  constexpr int m = 10, n = 10;
+  const double eps = DBL_EPSILON * 100;
+  for (int i = 0; i < m; ++i) {
+    int k = i;
+    for (int j = i + 1; j < m; ++j)
+      if (fabs(A[j * m + i]) > fabs(A[k * m + i])) k = j;
+    if (fabs(A[k * m + i]) < eps) return false;
+    if (k != i) {
+      for (int j = i; j < m; ++j) {
+        const double t = A[i * m + j];
+        A[i * m + j] = A[k * m + j];
+        A[k * m + j] = t;
+      }
+      for (int j = 0; j < n; ++j) {
+        const double t = b[i * n + j];
+        b[i * n + j] = b[k * n + j];
+        b[k * n + j] = t;
+      }
+    }
+    const double d = -1 / A[i * m + i];
+    for (int j = i + 1; j < m; ++j) {
+      const double alpha = A[j * m + i] * d;
+      for (int kk = i + 1; kk < m; ++kk) A[j * m + kk] += alpha * A[i * m + kk];
+      for (int kk = 0; kk < n; ++kk) b[j * n + kk] += alpha * b[i * n + kk];
+    }
+  }
+  for (int i = m - 1; i >= 0; --i)
+    for (int j = 0; j < n; ++j) {
+      double sum = b[i * n + j];
+      for (int k = i + 1; k < m; ++k) sum -= A[i * m + k] * b[k * n + j];
+      b[i * n + j] = sum / A[i * m + i];
+    }
+  return true;
+}
+
+// ---- cv::solvePoly for real coefficients c[0..10] ascending: Durand-Kerner, the roots updated in sequence, start
+// (1 + i)^k, 300 iterations or until no root moves.  flags: bit 0 = two iterates coincided (the library's
+// num_same_root branch, not restated: the zero factor is skipped), bit 1 = leading coefficients <= DBL_EPSILON down to
+// a degree n of 5..9 (the library then returns uninitialised memory as the missing roots: here they are marked
+// non-real).  For n <= 4 the missing roots are what the library's work buffer holds there, the coefficient pair
+// (c[2n], c[2n+1]) -- a singular sample (Mat::inv() = 0, all coefficients 0, n = 1) so gets root 0 = NaN and nine
+// roots (0, 0), i.e. nine times the model E = W, which RANSAC scores.
+struct Cplx {
+  double re, im;
+};
+__device__ __forceinline__ Cplx cmul(Cplx a, Cplx b) { return Cplx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ Cplx cdiv(Cplx a, Cplx b) {
+  const double t = 1. / (b.re * b.re + b.im * b.im);
+  return Cplx{(a.re * b.re + a.im * b.im) * t, (-a.re * b.im + a.im * b.re) * t};
+}
+__device__ void solve_poly10(const double* c, Cplx* roots, int* flags) {
+  int n = 10;
+  for (; n > 1; --n)
+    if (fabs(c[n]) + 0.0 > DBL_EPSILON) break;
+  if (n < 10 && 2 * n + 1 > 10) *flags |= 2;
+  Cplx p{1, 0};
+  const Cplx r{1, 1};
+  for (int i = 0; i < n; ++i) {
+    roots[i] = p;
+    p = cmul(p, r);
+  }
+  for (int iter = 0; iter < 300; ++iter) {
+    double max_diff = 0;
+    for (int i = 0; i < n; ++i) {
+      p = roots[i];
+      Cplx num{c[n], 0}, denom{c[n], 0};
+      for (int j = 0; j < n; ++j) {
+        num = cmul(num, p);
+        num.re += c[n - j - 1];
+        num.im += 0.0;
+        if (j != i) {
+          const Cplx d{p.re - roots[j].re, p.im - roots[j].im};
+          if (d.re != 0 || d.im != 0) denom = cmul(denom, d);
+          else *flags |= 1;
+        }
+      }
+      num = cdiv(num, denom);
+      roots[i] = Cplx{p.re - num.re, p.im - num.im};
+      max_diff = fmax(max_diff, sqrt(num.re * num.re + num.im * num.im));
+    }
+    if (max_diff <= 0) break;
+  }
+  for (int i = 0; i < n; ++i)
+    if (fabs(roots[i].im) < 1e-100) roots[i].im = 0;
+  for (int k = n; k < 10; ++k) roots[k] = 2 * n + 1 <= 10 ? Cplx{c[2 * n], c[2 * n + 1]} : Cplx{0, 1};
+}
+
+// EMEstimatorCallback::runKernel (OpenCV 3.4.1 calib3d/five-point.cpp) for five normalised correspondences
+// (q2^T E q1 = 0): up to ten row-major 3 x 3 models, unit Frobenius norm, in the order of solvePoly's roots.  The
+// checker (a CPU restatement, test infrastructure) restates the same steps with the host's libm; see its header for what of the
+// library is reproduced and what is not.
+__device__ int five_point(const double (*q1)[2], const double (*q2)[2], double (*Eout)[9], int* flags) {
+  double Q[9 * 9];
+  for (int k = 0; k < 81; ++k) Q[k] = 0.0;
   for (int i = 0; i < 5; ++i) {
     const double x1 = q1[i][0], y1 = q1[i][1], x2 = q2[i][0], y2 = q2[i][1];
-    A[i][0] = x1 * x2; A[i][1] = x2 * y1; A[i][2] = x2; A[i][3] = x1 * y2; A[i][4] = y1 * y2; A[i][5] = y2;
-    A[i][6] = x1; A[i][7] = y1; A[i][8] = 1.0;
+    double* r = Q + 9 * i;
+    r[0] = x1 * x2; r[1] = y1 * x2; r[2] = x2 * 1.0; r[3] = x1 * y2; r[4] = y1 * y2; r[5] = y2 * 1.0;
+    r[6] = x1 * 1.0; r[7] = y1 * 1.0; r[8] = 1.0;
   }
-  for (int c = 0; c < 9; ++c) cols[c] = c;
-  for (int i = 0; i < 5; ++i) {
-    int pr = i, pc = i;
-    double best = -1.0;
-    for (int r = i; r < 5; ++r)
-      for (int c = i; c < 9; ++c)
-        if (fabs(A[r][c]) > best) best = fabs(A[r][c]), pr = r, pc = c;
-    if (!(best > 0.0)) return 0;
-    for (int c = 0; c < 9; ++c) {
-      const double t = A[i][c];
-      A[i][c] = A[pr][c];
-      A[pr][c] = t;
-    }
-    for (int r = 0; r < 5; ++r) {
-      const double t = A[r][i];
-      A[r][i] = A[r][pc];
-      A[r][pc] = t;
-    }
-    {
-      const int t = cols[i];
-      cols[i] = cols[pc];
-      cols[pc] = t;
-    }
-    const double inv = 1.0 / A[i][i];
-    for (int c = 0; c < 9; ++c) A[i][c] *= inv;
-    for (int r = 0; r < 5; ++r)
-      if (r != i) {
-        const double f = A[r][i];
-        for (int c = 0; c < 9; ++c) A[r][c] -= f * A[i][c];
-      }
-  }
-  double basis[4][9];
-  for (int f = 0; f < 4; ++f) {
-    double v[9];
-    for (int c = 0; c < 9; ++c) v[c] = 0.0;
-    v[cols[5 + f]] = 1.0;
-    for (int i = 0; i < 5; ++i) v[cols[i]] = -A[i][5 + f];
-    for (int b = 0; b < f; ++b) {
-      double dot = 0.0;
-      for (int c = 0; c < 9; ++c) dot += v[c] * basis[b][c];
-      for (int c = 0; c < 9; ++c) v[c] -= dot * basis[b][c];
-    }
-    double nrm = 0.0;
-    for (int c = 0; c < 9; ++c) nrm += v[c] * v[c];
-    nrm = 1.0 / sqrt(nrm);
-    for (int c = 0; c < 9; ++c) basis[f][c] = v[c] * nrm;
-  }
+  double W5[5], V5[25];
+  jacobi_svd<9, 5, 9, 9>(Q, W5, V5);
+  const double* e = Q + 45;  // rows 5..8 of Vt: X, Y, Z, W
   // ---- the ten cubic constraints: det(E) = 0, 2 E E^T E - tr(E E^T) E = 0, E = x X + y Y + z Z + W
   double E1[9][4];
-  for (int e = 0; e < 9; ++e)
-    for (int k = 0; k < 4; ++k) E1[e][k] = basis[k][e];
+  for (int c = 0; c < 9; ++c)
+    for (int k = 0; k < 4; ++k) E1[c][k] = e[k * 9 + c];
   double M[10][20];
   for (int r = 0; r < 10; ++r)
     for (int c = 0; c < 20; ++c) M[r][c] = 0.0;
@@ -184,104 +309,88 @@ __device__ int five_point(const double (*q1)[2], const double (*q2)[2], double (
         mul21(tr, E1[3 * a + b], row, -1.0);
       }
   }
-  // ---- Gauss-Jordan on the first ten columns (partial pivoting)
-  for (int i = 0; i < 10; ++i) {
-    int p = i;
-    for (int r = i + 1; r < 10; ++r)
-      if (fabs(M[r][i]) > fabs(M[p][i])) p = r;
-    if (M[p][i] == 0.0) return 0;
-    if (p != i)
-      for (int c = 0; c < 20; ++c) {
-        const double t = M[i][c];
-        M[i][c] = M[p][c];
-        M[p][c] = t;
+  // ---- A = A.colRange(0, 10).inv() * A.colRange(10, 20): LU against the identity, then the product
+  double L[100], inv[100];
+  for (int i = 0; i < 10; ++i)
+    for (int j = 0; j < 10; ++j) {
+      L[i * 10 + j] = M[i][j];
+      inv[i * 10 + j] = i == j ? 1.0 : 0.0;
+    }
+  if (!lu_solve10(L, inv))
+    for (int k = 0; k < 100; ++k) inv[k] = 0.0;
+  // rows 4..9 of the product are all the 3 x 13 matrix B takes
+  double b[39];
+  for (int i = 0; i < 3; ++i) {
+    double a1[10], a2[10];
+    for (int j = 0; j < 10; ++j) {
+      double s1 = 0, s2 = 0;
+      for (int k = 0; k < 10; ++k) {
+        s1 += inv[(2 * i + 4) * 10 + k] * M[k][10 + j];
+        s2 += inv[(2 * i + 5) * 10 + k] * M[k][10 + j];
       }
-    const double inv = 1.0 / M[i][i];
-    for (int c = 0; c < 20; ++c) M[i][c] *= inv;
-    for (int r = 0; r < 10; ++r)
-      if (r != i) {
-        const double f = M[r][i];
-        if (f != 0.0)
-          for (int c = i; c < 20; ++c) M[r][c] -= f * M[i][c];
-      }
+      a1[j] = s1;
+      a2[j] = s2;
+    }
+    double row1[13], row2[13];
+    for (int k = 0; k < 13; ++k) row1[k] = row2[k] = 0.0;
+    for (int k = 0; k < 3; ++k) row1[1 + k] = a1[k], row1[5 + k] = a1[3 + k], row2[k] = a2[k], row2[4 + k] = a2[3 + k];
+    for (int k = 0; k < 4; ++k) row1[9 + k] = a1[6 + k], row2[8 + k] = a2[6 + k];
+    for (int k = 0; k < 13; ++k) b[13 * i + k] = row1[k] - row2[k];
   }
-  // ---- <row hi> - z <row lo> for (x2z, x2), (y2z, y2), (xyz, xy): B(z) [x, y, 1]^T = 0
-  double Bp[3][4], Bq[3][4], Br[3][5];
-  for (int t = 0; t < 3; ++t) {
-    const double* a = &M[4 + 2 * t][10];
-    const double* b = &M[5 + 2 * t][10];
-    Bp[t][0] = a[2]; Bp[t][1] = a[1] - b[2]; Bp[t][2] = a[0] - b[1]; Bp[t][3] = -b[0];
-    Bq[t][0] = a[5]; Bq[t][1] = a[4] - b[5]; Bq[t][2] = a[3] - b[4]; Bq[t][3] = -b[3];
-    Br[t][0] = a[9]; Br[t][1] = a[8] - b[9]; Br[t][2] = a[7] - b[8]; Br[t][3] = a[6] - b[7]; Br[t][4] = -b[6];
+  // ---- det B(z): row i = [P_i (deg 3) | Q_i (deg 3) | R_i (deg 4)], highest power first; c[k] = coefficient of z^k
+  double c[11];
+  for (int k = 0; k < 11; ++k) c[k] = 0.0;
+  {
+    const int perm[6][3] = {{0, 1, 2}, {2, 0, 1}, {1, 2, 0}, {2, 1, 0}, {0, 2, 1}, {1, 0, 2}};
+    const double sign[6] = {1, 1, 1, -1, -1, -1};
+    for (int t = 0; t < 6; ++t) {
+      const double* P = b + 13 * perm[t][0];
+      const double* Qq = b + 13 * perm[t][1] + 4;
+      const double* Rr = b + 13 * perm[t][2] + 8;
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+          const double pq = sign[t] * P[i] * Qq[j];
+          for (int k = 0; k < 5; ++k) c[(3 - i) + (3 - j) + (4 - k)] += pq * Rr[k];
+        }
+    }
   }
-  double det[11];
-  for (int k = 0; k < 11; ++k) det[k] = 0.0;
-  auto acc3 = [&](const double* u /*deg 3*/, const double* v /*deg 3*/, const double* w /*deg 4*/, double s) {
-    for (int i = 0; i < 4; ++i)
-      for (int j = 0; j < 4; ++j) {
-        const double uv = s * u[i] * v[j];
-        for (int k = 0; k < 5; ++k) det[i + j + k] += uv * w[k];
-      }
-  };
-  // det = p_k (q_l r_m - q_m r_l) - q_k (p_l r_m - p_m r_l) + r_k (p_l q_m - p_m q_l)
-  acc3(Bp[0], Bq[1], Br[2], 1.0);
-  acc3(Bp[0], Bq[2], Br[1], -1.0);
-  acc3(Bq[0], Bp[1], Br[2], -1.0);
-  acc3(Bq[0], Bp[2], Br[1], 1.0);
-  acc3(Bp[1], Bq[2], Br[0], 1.0);
-  acc3(Bp[2], Bq[1], Br[0], -1.0);
-  double roots[10];
-  const int nr = real_roots(det, roots);
+  Cplx roots[10];
+  solve_poly10(c, roots, flags);
   int n = 0;
-  double key[MAX_MODELS];
-  for (int s = 0; s < nr; ++s) {
-    const double z = roots[s];
-    double rw[3][3];
-    for (int t = 0; t < 3; ++t) {
-      rw[t][0] = horner(Bp[t], 3, z);
-      rw[t][1] = horner(Bq[t], 3, z);
-      rw[t][2] = horner(Br[t], 4, z);
+  for (int i = 0; i < 10; ++i) {
+    if (fabs(roots[i].im) > 1e-10) continue;
+    const double z1 = roots[i].re, z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
+    // SVD::solveZ(B(z)): JacobiSVD on the transpose, the row of Vt of the smallest singular value
+    double At[9], W3[3], Vt[9];
+    for (int j = 0; j < 3; ++j) {
+      const double* br = b + j * 13;
+      At[0 * 3 + j] = br[0] * z3 + br[1] * z2 + br[2] * z1 + br[3];
+      At[1 * 3 + j] = br[4] * z3 + br[5] * z2 + br[6] * z1 + br[7];
+      At[2 * 3 + j] = br[8] * z4 + br[9] * z3 + br[10] * z2 + br[11] * z1 + br[12];
     }
-    double bc[3] = {0.0, 0.0, 0.0};
-    const int pa[3] = {0, 0, 1}, pb[3] = {1, 2, 2};
-    for (int t = 0; t < 3; ++t) {
-      const double* u = rw[pa[t]];
-      const double* v = rw[pb[t]];
-      const double c0 = u[1] * v[2] - u[2] * v[1], c1 = u[2] * v[0] - u[0] * v[2], c2 = u[0] * v[1] - u[1] * v[0];
-      if (t == 0 || fabs(c2) > fabs(bc[2])) bc[0] = c0, bc[1] = c1, bc[2] = c2;
-    }
-    if (bc[2] == 0.0) continue;
-    const double x = bc[0] / bc[2], y = bc[1] / bc[2];
-    double E[9], nrm = 0.0, big = 0.0;
-    for (int e = 0; e < 9; ++e) {
-      E[e] = x * basis[0][e] + y * basis[1][e] + z * basis[2][e] + basis[3][e];
-      nrm += E[e] * E[e];
-    }
-    if (!(nrm > 0.0) || !(nrm < 1e300)) continue;
-    for (int e = 0; e < 9; ++e)
-      if (fabs(E[e]) > fabs(big)) big = E[e];
-    const double kk = E[0] / sqrt(nrm) * (big < 0.0 ? -1.0 : 1.0);
-    // insertion by the canonical key
-    int pos = n;
-    while (pos > 0 && key[pos - 1] > kk) {
-      key[pos] = key[pos - 1];
-      for (int e = 0; e < 9; ++e) Eout[pos][e] = Eout[pos - 1][e];
-      --pos;
-    }
-    key[pos] = kk;
-    for (int e = 0; e < 9; ++e) Eout[pos][e] = E[e];
+    jacobi_svd<3, 3, 3, 3>(At, W3, Vt);
+    if (fabs(Vt[8]) < 1e-10) continue;
+    const double x = Vt[6] / Vt[8], y = Vt[7] / Vt[8];
+    double* Ev = Eout[n];
+    for (int k = 0; k < 9; ++k) Ev[k] = ((e[k] * x + e[9 + k] * y) + e[18 + k] * z1) + e[27 + k];
+    double s = 0;
+    s += Ev[0] * Ev[0] + Ev[1] * Ev[1] + Ev[2] * Ev[2] + Ev[3] * Ev[3];
+    s += Ev[4] * Ev[4] + Ev[5] * Ev[5] + Ev[6] * Ev[6] + Ev[7] * Ev[7];
+    s += Ev[8] * Ev[8];
+    const double inv_n = 1. / sqrt(s);
+    for (int k = 0; k < 9; ++k) Ev[k] *= inv_n;
     ++n;
   }
   return n;
 }
 
 // ---------------------------------------------------------------- kernels
-// (p - c) / f per axis, as findEssentialMat does before RANSAC
-__global__ void score_normalize(const double* __restrict__ xy, double* __restrict__ out, long long n2, double fx, double fy,
-                                double cx, double cy) {
+// findEssentialMat's normalisation: the MatExpr (col - c) / f is evaluated as col * (1 / f) + (-c * (1 / f))
+__global__ void score_normalize(const double* __restrict__ xy, double* __restrict__ out, long long n2, double ax, double bx,
+                                double ay, double by) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n2) return;
-  out[i] = (i & 1) ? (xy[i] - cy) / fy : (xy[i] - cx) / fx;
+  out[i] = (i & 1) ? xy[i] * ay + by : xy[i] * ax + bx;
 }
 
 struct ScoreJob {  // one active pair of a chunk
@@ -309,8 +418,9 @@ __global__ __launch_bounds__(64) void score_solve(const ScoreJob* __restrict__ j
     q2[k][1] = p2[2 * m + 1];
   }
   double E[MAX_MODELS][9];
-  const int n = five_point(q1, q2, E);
-  n_models[t] = n;
+  int flags = 0;
+  const int n = five_point(q1, q2, E, &flags);
+  n_models[t] = n | (flags << 8);
   double* out = models + (size_t)t * (MAX_MODELS * 9);
   for (int m = 0; m < n; ++m)
     for (int e = 0; e < 9; ++e) out[m * 9 + e] = E[m][e];
@@ -338,7 +448,7 @@ __global__ __launch_bounds__(256) void score_count(const ScoreJob* __restrict__ 
   const int j = blockIdx.x / chunk;
   const int slot = blockIdx.x;
   const ScoreJob jb = jobs[j];
-  const int nm = n_models[slot];
+  const int nm = n_models[slot] & 0xff;
   if (threadIdx.x < MAX_MODELS) s_cnt[threadIdx.x] = 0;
   if ((int)threadIdx.x < nm * 9) sE[threadIdx.x] = models[(size_t)slot * (MAX_MODELS * 9) + threadIdx.x];
   __syncthreads();
@@ -668,6 +778,9 @@ extern "C" int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_
   constexpr int MAX_ITERS = 1000, MODEL_POINTS = 5;
   const double thr = threshold / ((fx + fy) / 2);
   const float t = (float)(thr * thr);
+  const double ax = 1. / fx, bx = -cx * ax, ay = 1. / fy, by = -cy * ay;
+  int flags_any = 0;
+  ctx->score_flags = 0;
 
   struct Bufs {
     std::vector<void*> v;
@@ -687,10 +800,10 @@ extern "C" int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_
   if (total > 0) {
     const int nb = (int)((2 * total + 255) / 256);
     SFM_HIP_TRY(hipMemcpyAsync(d_raw, left_xy, sizeof(double) * 2 * total, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(score_normalize, dim3(nb), dim3(256), 0, st, d_raw, d_p1, 2 * total, fx, fy, cx, cy);
+    hipLaunchKernelGGL(score_normalize, dim3(nb), dim3(256), 0, st, d_raw, d_p1, 2 * total, ax, bx, ay, by);
     SFM_HIP_TRY(hipStreamSynchronize(st));  // (d_raw is reused)
     SFM_HIP_TRY(hipMemcpyAsync(d_raw, right_xy, sizeof(double) * 2 * total, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(score_normalize, dim3(nb), dim3(256), 0, st, d_raw, d_p2, 2 * total, fx, fy, cx, cy);
+    hipLaunchKernelGGL(score_normalize, dim3(nb), dim3(256), 0, st, d_raw, d_p2, 2 * total, ax, bx, ay, by);
   }
   // per pair: the state of ptsetreg's loop
   struct PairState {
@@ -778,7 +891,8 @@ extern "C" int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_
       PairState& s = ps[job_pair[j]];
       if (s.count == MODEL_POINTS) {
         const size_t slot = j * chunk;
-        if (h_nm[slot] > 0) {
+        flags_any |= h_nm[slot] >> 8;
+        if ((h_nm[slot] & 0xff) > 0) {
           s.best = MODEL_POINTS;
           has[job_pair[j]] = 2;
           upd.push_back(int2{(int)(slot * MAX_MODELS), job_pair[j]});
@@ -789,7 +903,8 @@ extern "C" int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_
       long long keep = -1;  // the last model of this chunk that raised the best count
       for (int it = 0; it < chunk && s.iter < s.niters; ++it, ++s.iter) {
         const size_t slot = j * chunk + it;
-        for (int m = 0; m < h_nm[slot]; ++m) {
+        flags_any |= h_nm[slot] >> 8;
+        for (int m = 0; m < (h_nm[slot] & 0xff); ++m) {
           const int good = h_counts[slot * MAX_MODELS + m];
           if (good > std::max(s.best, MODEL_POINTS - 1)) {
             s.best = good;
@@ -813,6 +928,7 @@ extern "C" int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_
     inliers[p] = ps[p].best;
     if (iterations) iterations[p] = ps[p].iter;
   }
+  ctx->score_flags = flags_any;
   if (mask && total > 0) {
     int* d_off = nullptr;
     unsigned char *d_has = nullptr, *d_mask = nullptr;
@@ -828,6 +944,8 @@ extern "C" int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_
   SFM_HIP_TRY(hipStreamSynchronize(st));
   return SFMHIP_OK;
 }
+
+extern "C" int sfmhip_score_last_flags(sfmhip_ctx* ctx) { return ctx ? ctx->score_flags : 0; }
 
 extern "C" int sfmhip_score_homography(sfmhip_ctx* ctx, int n_pairs, const int32_t* offsets, const double* left_xy,
                                        const double* right_xy, const double* thresholds, double confidence, int max_iters,

@@ -30,6 +30,12 @@ def score_essential(pairs_points, K, prob=0.999, threshold=1.0, want_mask=False,
     return inl[:n], masks, its[:n]
 
 
+def last_flags(ctx=None):
+    """sfmhip_score_last_flags: non-zero when a five-point sample of the last score_essential call reached a corner of
+    cv::solvePoly whose library behaviour is not reproduced (include/sfmhip.h)."""
+    return int(lib().sfmhip_score_last_flags((ctx or default_context()).h))
+
+
 def score_homography(pairs_points, thresholds=None, confidence=0.995, max_iters=2000, want_mask=False, ctx=None):
     """findHomographyInliers (src/Sfm.cpp:667-689) for a batch: the RANSAC inlier count of cv::findHomography(left,
     right, RANSAC, threshold).  thresholds None: the reference's 0.004 * (largest coordinate of the pair's left points)."""

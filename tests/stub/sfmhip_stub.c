@@ -145,20 +145,19 @@ int sfmhip_triangulate(sfmhip_ctx* ctx, const double P1[12], const double P2[12]
   if (!err) free(e);
   return rc ? SFMHIP_ERR_ARG : SFMHIP_OK;
 }
-/* the scoring half of findBestPair: the stand-in counts every match as an inlier (the RANSAC itself is device code and
- * its checker is numpy; what the sanitizer run exercises is the host mirror's container handling around the call) */
+/* the scoring half of findBestPair, answered by the C restatement of cv::findEssentialMat(RANSAC) */
+static int g_score_flags;
 int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_t* offsets, const double* left_xy, const double* right_xy,
                            double fx, double fy, double cx, double cy, double prob, double threshold, int32_t* inliers,
                            uint8_t* mask, int32_t* iterations) {
-  (void)ctx; (void)left_xy; (void)right_xy; (void)fx; (void)fy; (void)cx; (void)cy; (void)prob; (void)threshold;
-  for (int p = 0; p < n_pairs; ++p) {
-    inliers[p] = offsets[p + 1] - offsets[p];
-    if (iterations) iterations[p] = 1;
-    if (mask)
-      for (int i = offsets[p]; i < offsets[p + 1]; ++i) mask[i] = 1;
-  }
+  (void)ctx;
+  const double K[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1};
+  int32_t fl = 0;
+  orc_score_essential_many(n_pairs, offsets, left_xy, right_xy, K, prob, threshold, inliers, iterations, mask, 1, &fl);
+  g_score_flags = fl;
   return SFMHIP_OK;
 }
+int sfmhip_score_last_flags(sfmhip_ctx* ctx) { (void)ctx; return g_score_flags; }
 
 /* the SIFT front end is device code (its checker is numpy): the stand-in finds no keypoints */
 int sfmhip_sift_detect_and_compute(sfmhip_ctx* ctx, const uint8_t* gray, int rows, int cols, int n_octave_layers,

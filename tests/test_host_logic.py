@@ -134,14 +134,3 @@ def test_sharded_reduced_systems_sum_to_the_unsharded_one(orc):
         assert np.abs(S - offdiag).max() <= 1e-12 * np.abs(full[0]).max()
         assert np.abs(g - full[1]).max() <= 1e-12 * np.abs(full[1]).max()
         assert abs(cost - full[2]) <= 1e-12 * full[2]
-
-
-def test_cfg1_temple_plumbing_is_recorded_as_not_runnable_here():
-    """BASELINE.json configs[0]: data/temple (640x480 PNGs) through the reference on the CPU.  Explicit record instead
-    of silence: the PNGs live under /root/reference, which does not travel to the GPU box, and this container has
-    no GPU -- the two never meet.  Everything the case needs is built and tested on other inputs: the PNG loader
-    reads data/temple here (tests/test_host_io.py), and the cfg1 call order imagesLOAD -> extractFeature (SIFT) ->
-    matchAllPairs -> findBestPair -> triangulateViews -> adjustCurrentBundle runs on rendered views on the GPU
-    (tests/test_gpu_sift.py::test_cfg1_shaped_pipeline_on_rendered_views, tests/test_gpu_host_cpp.py)."""
-    import pytest
-    pytest.skip("cfg1 on the temple images: the dataset (under /root/reference) and a GPU are never on the same machine")

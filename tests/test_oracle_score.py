@@ -1,8 +1,10 @@
-"""CPU: the numpy restatement of the findBestPair scoring path (oracle/sfm_oracle_score.py) checked against what can
-be checked without OpenCV: cv::RNG's recurrence, RANSACUpdateNumIters at hand-computed points, the two independent
-five-point routes against each other and against a known essential matrix."""
+"""CPU: the restatement of the findBestPair scoring path (oracle/sfm_oracle_score.{c,py}) checked against what can be
+checked without OpenCV: cv::RNG's recurrence, RANSACUpdateNumIters at hand-computed points, the models of the C
+restatement of OpenCV's five-point route against the constraints they solve, against an independent action-matrix
+solver (oracle/np_check.py) and against a known essential matrix."""
 import numpy as np
 
+from oracle import np_check, orc
 from oracle import sfm_oracle_score as S
 from sfm_danpipeline_amd import synth
 
@@ -30,22 +32,71 @@ def test_update_num_iters():
     assert S.ransac_update_num_iters(0.999, 0.5, 5, 100) == 100
 
 
-def test_the_two_five_point_routes_agree_and_recover_a_known_matrix():
+def test_update_num_iters_c_and_python_agree():
+    for ep in (0.0, 0.01, 0.2, 0.5, 0.77, 0.9, 1.0):
+        for mx in (1000, 100, 7):
+            assert orc.lib().orc_ransac_update_num_iters(0.999, ep, 5, mx) == S.ransac_update_num_iters(0.999, ep, 5, mx)
+
+
+def _unit(E):
+    return E / np.linalg.norm(E)
+
+
+def _dist(E, F):
+    return min(np.abs(_unit(E) - _unit(F)).max(), np.abs(_unit(E) + _unit(F)).max())
+
+
+def test_five_point_models_solve_the_constraints_and_recover_a_known_matrix():
     sc = synth.two_view_scene(m=40, seed=5, K=K, noise_px=0.0, outlier_frac=0.0)
     R, t = sc["P2"][:, :3], sc["P2"][:, 3]
     Et = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R
-    Et /= np.linalg.norm(Et)
-    n1 = (sc["xy1"] - K[:2, 2]) / np.array([K[0, 0], K[1, 1]])
-    n2 = (sc["xy2"] - K[:2, 2]) / np.array([K[0, 0], K[1, 1]])
-    errs = []
+    n1, n2 = orc.em_normalize(sc["xy1"], K), orc.em_normalize(sc["xy2"], K)
+    assert np.allclose(n1, (sc["xy1"] - K[:2, 2]) / np.array([K[0, 0], K[1, 1]]), rtol=0, atol=1e-15)
     for k in range(0, 35, 5):
-        a, b = S.five_point(n1[k:k + 5], n2[k:k + 5]), S.five_point_hidden_variable(n1[k:k + 5], n2[k:k + 5])
-        assert len(a) == len(b) >= 1
-        unit = lambda E: E / np.linalg.norm(E)
-        dist = lambda E, F: min(np.abs(unit(E) - unit(F)).max(), np.abs(unit(E) + unit(F)).max())
-        assert min(dist(E, Et) for E in a) < 1e-8 and min(dist(E, Et) for E in b) < 1e-8
-        errs += [min(dist(E, F) for F in b) for E in a]
-    assert np.median(errs) < 1e-10
+        models, flags = orc.five_point(n1[k:k + 5], n2[k:k + 5])
+        assert flags == 0 and 1 <= len(models) <= 10
+        assert min(_dist(E, Et) for E in models) < 1e-8
+        for E in models:
+            assert abs(np.linalg.norm(E) - 1.0) < 1e-14                                   # Evec /= norm(Evec)
+            x1 = np.concatenate([n1[k:k + 5], np.ones((5, 1))], 1)
+            x2 = np.concatenate([n2[k:k + 5], np.ones((5, 1))], 1)
+            assert np.abs(np.sum(x2 * (x1 @ E.T), axis=1)).max() < 1e-11                  # x2^T E x1 = 0
+            assert abs(np.linalg.det(E)) < 1e-10
+            assert np.abs(2 * E @ E.T @ E - np.trace(E @ E.T) * E).max() < 1e-9
+
+
+def test_five_point_models_equal_the_action_matrix_solver_on_random_samples():
+    """noisy data with outliers: every sample's model SET against the independent route (the order is OpenCV's: the
+    order of solvePoly's roots; compared as sets)"""
+    sc = synth.two_view_scene(m=300, seed=3, K=K, noise_px=0.3, outlier_frac=0.3)
+    n1, n2 = orc.em_normalize(sc["xy1"], K), orc.em_normalize(sc["xy2"], K)
+    rng = np.random.default_rng(0)
+    worst = []
+    for _ in range(120):
+        idx = rng.choice(300, 5, replace=False)
+        a, flags = orc.five_point(n1[idx], n2[idx])
+        b = np_check.five_point_action_matrix(n1[idx], n2[idx])
+        assert flags == 0
+        if len(a) != len(b):                      # a double root on the edge of real: rare, and must stay rare
+            worst.append(1.0)
+            continue
+        worst.append(max([min(_dist(E, F) for F in b) for E in a], default=0.0))
+    worst = np.array(worst)
+    assert np.median(worst) < 1e-10 and (worst > 1e-6).mean() < 0.05
+
+
+def test_null_space_rows_are_the_library_rng_completion():
+    """JacobiSVDImpl_ fills the singular vectors of the four zero singular values from RNG(0x12345678) sign vectors:
+    the models of a sample do not depend on that basis, but the basis is deterministic -- the same sample gives
+    bit-identical models twice, and a permuted sample (another Q, same null space) the same model set"""
+    sc = synth.two_view_scene(m=20, seed=11, K=K, noise_px=0.2, outlier_frac=0.0)
+    n1, n2 = orc.em_normalize(sc["xy1"], K), orc.em_normalize(sc["xy2"], K)
+    a, _ = orc.five_point(n1[:5], n2[:5])
+    b, _ = orc.five_point(n1[:5], n2[:5])
+    assert len(a) >= 1 and all(np.array_equal(x, y) for x, y in zip(a, b))
+    p = [3, 0, 4, 1, 2]
+    c, _ = orc.five_point(n1[:5][p], n2[:5][p])
+    assert len(c) == len(a) and max(min(_dist(E, F) for F in c) for E in a) < 1e-8
 
 
 def test_ransac_on_a_scene_with_outliers():
