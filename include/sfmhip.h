@@ -53,6 +53,9 @@ typedef struct sfmhip_matchplan sfmhip_matchplan;
 typedef struct sfmhip_ba sfmhip_ba;
 
 /* ---- context ---- */
+/* gfx950 devices visible to this process (>= 0), or a negative SFMHIP_ERR_*: what a one-process-per-GPU host program
+ * maps its rank onto (device = local rank % count) */
+int sfmhip_device_count(void);
 int sfmhip_init(int device, sfmhip_ctx** out);
 /* same, but all work is enqueued on an existing hipStream_t (e.g. torch's current stream) */
 int sfmhip_init_on_stream(int device, void* hip_stream, sfmhip_ctx** out);
@@ -104,6 +107,19 @@ int sfmhip_matchplan_run_async(sfmhip_matchplan* plan, float ratio);
  * queryIdx inside a pair); *total receives the number of matches over all pairs. */
 int sfmhip_matchplan_fetch(sfmhip_matchplan* plan, int32_t* counts, int32_t* out_q,
                            int32_t* out_t, float* out_dist, int64_t capacity, int64_t* total);
+/* Pipelined fetch -- what keeps getMatching's host-visible contract (a host Matching*, reference include/Sfm.h:89) from
+ * costing a stall per sweep when sweeps follow each other (the all-pairs loop of findBestPair, src/Sfm.cpp:511-515, over
+ * batches of pairs): once switched on, every sfmhip_matchplan_run_async is followed, on a second HIP stream, by a pass
+ * that packs counts and {queryIdx | trainIdx | distance} lists straight into one of two pinned host buffers while the
+ * first stream goes on with the next run.  capacity = matches a buffer holds (0: a quarter of n_pairs x max rows;
+ * negative: switch the pipeline off again).
+ * sfmhip_matchplan_fetch_wait(plan, back, ...) waits for the lists of the latest run (back = 0) or of the run before it
+ * (back = 1) and hands out pointers INTO the pinned buffer: counts[n_pairs], then total entries each of q, t, dist,
+ * pair-major -- valid until two more runs have been enqueued.  SFMHIP_ERR_ALLOC with *total set when a run found more
+ * matches than a buffer holds (switch the pipeline on again with that capacity; sfmhip_matchplan_fetch still works). */
+int sfmhip_matchplan_pipeline(sfmhip_matchplan* plan, int64_t capacity);
+int sfmhip_matchplan_fetch_wait(sfmhip_matchplan* plan, int back, const int32_t** counts, const int32_t** out_q,
+                                const int32_t** out_t, const float** out_dist, int64_t* total);
 /* raw k=2 lists of pair `pair`: idx[nq*2] (-1 padded), dist[nq*2] */
 int sfmhip_matchplan_fetch_knn(sfmhip_matchplan* plan, int pair, int32_t* idx, float* dist);
 /* seconds of device time of the last run's kernels, by stage (hipEvents on the ctx stream):
@@ -178,6 +194,12 @@ int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_t* offsets,
  * of cv::solvePoly whose library behaviour (a cube-root branch; part of a work buffer returned as roots) is not
  * reproduced.  0 = every sample went the documented way. */
 int sfmhip_score_last_flags(sfmhip_ctx* ctx);
+/* EMEstimatorCallback::runKernel (OpenCV 3.4.1 calib3d/five-point.cpp) for explicit samples: q1 / q2 = n_samples x five
+ * normalised points (x, y) each; models: n_samples x 10 row-major 3 x 3 matrices (unit Frobenius norm, the library's
+ * order: the order of solvePoly's roots); n_models[i] = count | flags << 8 (flags as sfmhip_score_last_flags).  What the
+ * RANSAC above runs per iteration, exposed for sample-level parity checks. */
+int sfmhip_score_five_point(sfmhip_ctx* ctx, int n_samples, const double* q1, const double* q2, double* models,
+                            int32_t* n_models);
 
 /* The homography side of the same loop: findHomographyInliers (reference src/Sfm.cpp:667-689) =
  *   cv::countNonZero(mask) of cv::findHomography(query_points, train_points, CV_RANSAC, 0.004 * maxVal, mask)

@@ -91,6 +91,8 @@ def lib():
         L.orc_match_many.restype = C.c_int
         L.orc_match_many_checksum.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp]
         L.orc_match_many_checksum.restype = C.c_int
+        L.orc_match_many_blocked.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp]
+        L.orc_match_many_blocked.restype = C.c_int
         L.orc_triangulate.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_float, vp, vp, vp]
         L.orc_triangulate.restype = C.c_int
         L.orc_ba_residual.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp, vp]
@@ -190,8 +192,47 @@ def match_many_checksum(imgs, pairs, norm=NORM_L2, ratio=0.8, threads=1):
     return counts[:len(pairs)], cs[:len(pairs)]
 
 
+def match_many_blocked(imgs, pairs, ratio=0.8, threads=1):
+    """bench.py's CPU-baseline matcher (f32 rows, L2): counts and (n_pairs, 2) uint64 checksums like
+    match_many_checksum, computed by the cache-blocked, SIMD, atomics-free organisation (sfm_oracle_match.c)."""
+    imgs = [np.ascontiguousarray(a, np.float32) for a in imgs]
+    ptrs = (C.c_void_p * len(imgs))(*[a.ctypes.data for a in imgs])
+    n_rows = np.array([a.shape[0] for a in imgs], np.int32)
+    pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    counts = np.zeros(max(len(pairs), 1), np.int32)
+    cs = np.zeros((max(len(pairs), 1), 2), np.uint64)
+    rc = lib().orc_match_many_blocked(ptrs, _p(n_rows), imgs[0].shape[1], _p(pairs), len(pairs), ratio, threads,
+                                      _p(counts), _p(cs))
+    if rc:
+        raise RuntimeError(f"orc_match_many_blocked rc={rc}")
+    return counts[:len(pairs)], cs[:len(pairs)]
+
+
+def physical_cores():
+    """(physical id, core id) pairs of /proc/cpuinfo; falls back to os.cpu_count()"""
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            seen.add((phys, core))
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
 def match_mix(q, t, dist):
-    """The per-match value of the pair checksums, vectorised (numpy arrays in, uint64 out)."""
+    """The per-match value of the pair checksums (orc_match_mix), vectorised; the same function as the product-side
+    helper sfm_danpipeline_amd.synth.match_mix, kept apart on purpose (tests compare the two)."""
     with np.errstate(over="ignore"):
         x = q.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) + t.astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F) + \
             np.ascontiguousarray(dist, np.float32).view(np.uint32).astype(np.uint64) * np.uint64(0x165667B19E3779F9)

@@ -49,6 +49,11 @@ int orc_match_many_checksum(const void* const* imgs, const int32_t* n_rows, int 
                             const int32_t* pairs, int n_pairs, float ratio, int threads, int32_t* counts,
                             uint64_t* checksums);
 uint64_t orc_match_mix(uint32_t q, uint32_t t, uint32_t dist_bits);
+/* bench.py's CPU-baseline matcher (L2, f32 rows): the same lists, organised as cv::batchDistance under parallel_for_ --
+ * blocks of query rows in parallel, train rows in cache-sized tiles, a SIMD sum of squared differences, per-thread
+ * counts / checksums merged once.  See sfm_oracle_match.c. */
+int orc_match_many_blocked(const void* const* imgs, const int32_t* n_rows, int dim, const int32_t* pairs, int n_pairs,
+                           float ratio, int threads, int32_t* counts, uint64_t* checksums);
 
 int orc_triangulate(const double P1[12], const double P2[12], const double K[9],
                     const double dist[5], const double* xy1, const double* xy2, int m,

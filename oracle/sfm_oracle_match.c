@@ -229,6 +229,130 @@ static int match_many_impl(const void* const* imgs, const int32_t* n_rows, int d
   return 0;
 }
 
+/* ---- the CPU-baseline matcher of bench.py: the same lists as match_many_impl, organised the way
+ * cv::BFMatcher::knnMatch runs on a multi-core host (core/batch_distance.cpp: BatchDistInvoker under parallel_for_):
+ * parallel over blocks of QUERY rows; a block's queries meet the train rows tile by tile (a tile of train rows stays
+ * in L1/L2 while the block's queries go over it); the sum of squared differences is a SIMD loop with independent
+ * accumulators (hal::normL2Sqr_; here four train rows per query at a time); every thread keeps its own counts / checksums, merged once at the end -- no atomics
+ * on the data path.  L2 / f32 rows only (cfg2); integer-valued rows make every summation order exact, so the lists and
+ * checksums equal those of the row-by-row restatement above (bench.py asserts it).  FMA contraction is allowed here:
+ * it is a timing leg, and on integer-valued rows FMAs change nothing. */
+#define MB_QB 8    /* query rows per block */
+#define MB_TB 64   /* train rows per tile: 64 x 128 floats = 32 KB */
+typedef float v16f __attribute__((vector_size(64), aligned(4)));
+static inline float hsum16(v16f v) {
+  float s = 0.f;
+  for (int l = 0; l < 16; ++l) s += v[l];
+  return s;
+}
+/* squared distances of one query row to four train rows: two independent accumulators per train row (eight FMA chains) */
+__attribute__((optimize("fp-contract=fast"))) static inline void ssd4_f32(const float* restrict a, const float* restrict b0,
+                                                                            const float* restrict b1, const float* restrict b2,
+                                                                            const float* restrict b3, int n, float out[4]) {
+  v16f s00 = {0}, s01 = {0}, s10 = {0}, s11 = {0}, s20 = {0}, s21 = {0}, s30 = {0}, s31 = {0};
+  int k = 0;
+  for (; k + 32 <= n; k += 32) {
+    const v16f a0 = *(const v16f*)(a + k), a1 = *(const v16f*)(a + k + 16);
+    v16f d;
+    d = a0 - *(const v16f*)(b0 + k); s00 += d * d;
+    d = a1 - *(const v16f*)(b0 + k + 16); s01 += d * d;
+    d = a0 - *(const v16f*)(b1 + k); s10 += d * d;
+    d = a1 - *(const v16f*)(b1 + k + 16); s11 += d * d;
+    d = a0 - *(const v16f*)(b2 + k); s20 += d * d;
+    d = a1 - *(const v16f*)(b2 + k + 16); s21 += d * d;
+    d = a0 - *(const v16f*)(b3 + k); s30 += d * d;
+    d = a1 - *(const v16f*)(b3 + k + 16); s31 += d * d;
+  }
+  out[0] = hsum16(s00 + s01);
+  out[1] = hsum16(s10 + s11);
+  out[2] = hsum16(s20 + s21);
+  out[3] = hsum16(s30 + s31);
+  for (; k < n; ++k) {
+    const float d0 = a[k] - b0[k], d1 = a[k] - b1[k], d2 = a[k] - b2[k], d3 = a[k] - b3[k];
+    out[0] += d0 * d0; out[1] += d1 * d1; out[2] += d2 * d2; out[3] += d3 * d3;
+  }
+}
+
+int orc_match_many_blocked(const void* const* imgs, const int32_t* n_rows, int dim, const int32_t* pairs, int n_pairs,
+                           float ratio, int threads, int32_t* counts, uint64_t* checksums) {
+  if (n_pairs < 0 || dim <= 0) return -1;
+  if (threads < 1) threads = 1;
+  int64_t* off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_pairs + 1)); /* blocks of query rows before pair p */
+  int32_t* cnt_t = (int32_t*)calloc((size_t)threads * (size_t)(n_pairs > 0 ? n_pairs : 1), sizeof(int32_t));
+  uint64_t* cs_t = (uint64_t*)calloc((size_t)threads * 2 * (size_t)(n_pairs > 0 ? n_pairs : 1), sizeof(uint64_t));
+  if (!off || !cnt_t || !cs_t) return -3;
+  off[0] = 0;
+  for (int p = 0; p < n_pairs; ++p) off[p + 1] = off[p] + (n_rows[pairs[2 * p]] + MB_QB - 1) / MB_QB;
+  const int64_t total = off[n_pairs];
+#pragma omp parallel num_threads(threads)
+  {
+    int tid = 0;
+#ifdef _OPENMP
+    extern int omp_get_thread_num(void);
+    tid = omp_get_thread_num();
+#endif
+    int32_t* my_cnt = cnt_t + (size_t)tid * n_pairs;
+    uint64_t* my_cs = cs_t + (size_t)tid * 2 * n_pairs;
+#pragma omp for schedule(dynamic, 4)
+    for (int64_t w = 0; w < total; ++w) {
+      int lo = 0, hi = n_pairs - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        if (off[mid] <= w) lo = mid; else hi = mid - 1;
+      }
+      const int p = lo, qi = pairs[2 * p], ti = pairs[2 * p + 1], nq = n_rows[qi], nt = n_rows[ti];
+      const int q0 = (int)(w - off[p]) * MB_QB, q1 = q0 + MB_QB < nq ? q0 + MB_QB : nq;
+      const float* Q = (const float*)imgs[qi];
+      const float* T = (const float*)imgs[ti];
+      float d0[MB_QB], d1[MB_QB];
+      int32_t i0[MB_QB], i1[MB_QB];
+      for (int r = 0; r < MB_QB; ++r) d0[r] = d1[r] = FLT_MAX, i0[r] = i1[r] = -1;
+      for (int t0 = 0; t0 < nt; t0 += MB_TB) {
+        const int t1 = t0 + MB_TB < nt ? t0 + MB_TB : nt;
+        for (int i = q0; i < q1; ++i) {
+          const float* a = Q + (size_t)i * dim;
+          const int r = i - q0;
+          float buf[MB_TB + 4];
+          for (int j = t0; j < t1; j += 4) { /* (the last group may repeat the tile's last row: its result is not read) */
+            const int j1 = j + 1 < t1 ? j + 1 : t1 - 1, j2 = j + 2 < t1 ? j + 2 : t1 - 1, j3 = j + 3 < t1 ? j + 3 : t1 - 1;
+            ssd4_f32(a, T + (size_t)j * dim, T + (size_t)j1 * dim, T + (size_t)j2 * dim, T + (size_t)j3 * dim, dim, buf + (j - t0));
+          }
+          for (int j = t0; j < t1; ++j) { /* batchDistL2_32f: sqrt of every entry, then the K-list insertion in j order */
+            const float d = sqrtf(buf[j - t0]);
+            KNN2_INSERT(d, j, d0[r], i0[r], d1[r], i1[r]);
+          }
+        }
+      }
+      for (int i = q0; i < q1; ++i) {
+        const int r = i - q0;
+        if (i1[r] >= 0 && d0[r] <= ratio * d1[r]) {
+          my_cnt[p]++;
+          uint32_t bits;
+          memcpy(&bits, &d0[r], 4);
+          const uint64_t x = orc_match_mix((uint32_t)i, (uint32_t)i0[r], bits);
+          my_cs[2 * p] += x;
+          my_cs[2 * p + 1] ^= x;
+        }
+      }
+    }
+  }
+  for (int p = 0; p < n_pairs; ++p) {
+    int32_t c = 0;
+    uint64_t a = 0, x = 0;
+    for (int t = 0; t < threads; ++t) {
+      c += cnt_t[(size_t)t * n_pairs + p];
+      a += cs_t[((size_t)t * n_pairs + p) * 2];
+      x ^= cs_t[((size_t)t * n_pairs + p) * 2 + 1];
+    }
+    counts[p] = c;
+    if (checksums) checksums[2 * p] = a, checksums[2 * p + 1] = x;
+  }
+  free(off);
+  free(cnt_t);
+  free(cs_t);
+  return 0;
+}
+
 /* ---- triangulation ---- */
 
 /* OpenCV core/lapack.cpp JacobiSVDImpl_<double> on At (n rows of length m), here m=n=4, giving

@@ -38,15 +38,16 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
 
 # every symbol include/sfmhip.h declares (tests check the built library exports all of them)
 SYMBOLS = [
+    "sfmhip_device_count",
     "sfmhip_init", "sfmhip_init_on_stream", "sfmhip_shutdown", "sfmhip_synchronize", "sfmhip_device", "sfmhip_stream", "sfmhip_set_timing", "sfmhip_error_string",
     "sfmhip_last_hip_error", "sfmhip_version", "sfmhip_match_knn2", "sfmhip_imageset_create",
     "sfmhip_imageset_upload", "sfmhip_imageset_adopt_device", "sfmhip_imageset_prepare_async",
     "sfmhip_imageset_destroy", "sfmhip_matchplan_create", "sfmhip_matchplan_set_pairs", "sfmhip_matchplan_run_async", "sfmhip_matchplan_fetch",
-    "sfmhip_matchplan_fetch_knn", "sfmhip_matchplan_last_timing", "sfmhip_matchplan_last_knn_kernel_time",
+    "sfmhip_matchplan_fetch_knn", "sfmhip_matchplan_pipeline", "sfmhip_matchplan_fetch_wait", "sfmhip_matchplan_last_timing", "sfmhip_matchplan_last_knn_kernel_time",
     "sfmhip_matchplan_destroy",
     "sfmhip_triangulate", "sfmhip_find_2d3d", "sfmhip_merge_new_points", "sfmhip_ba_default_opts", "sfmhip_ba_solve", "sfmhip_ba_create",
     "sfmhip_ba_set_allreduce", "sfmhip_ba_set_params", "sfmhip_ba_get_params", "sfmhip_ba_run",
-    "sfmhip_ba_iterate", "sfmhip_ba_reduced_system", "sfmhip_ba_linearize_obs", "sfmhip_ba_last_timing", "sfmhip_ba_reduced_layout", "sfmhip_ba_reduced_step", "sfmhip_score_essential", "sfmhip_score_last_flags", "sfmhip_score_homography", "sfmhip_sift_detect_and_compute", "sfmhip_ba_destroy",
+    "sfmhip_ba_iterate", "sfmhip_ba_reduced_system", "sfmhip_ba_linearize_obs", "sfmhip_ba_last_timing", "sfmhip_ba_reduced_layout", "sfmhip_ba_reduced_step", "sfmhip_score_essential", "sfmhip_score_last_flags", "sfmhip_score_five_point", "sfmhip_score_homography", "sfmhip_sift_detect_and_compute", "sfmhip_ba_destroy",
 ]
 
 _lib = None
@@ -84,6 +85,8 @@ def lib():
     L.sfmhip_matchplan_run_async.argtypes = [vp, C.c_float]
     L.sfmhip_matchplan_fetch.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.sfmhip_matchplan_fetch_knn.argtypes = [vp, cint, vp, vp]
+    L.sfmhip_matchplan_pipeline.argtypes = [vp, C.c_int64]
+    L.sfmhip_matchplan_fetch_wait.argtypes = [vp, cint, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]
     L.sfmhip_matchplan_last_timing.argtypes = [vp, vp]
     L.sfmhip_matchplan_last_knn_kernel_time.argtypes = [vp, C.POINTER(C.c_double)]
     L.sfmhip_matchplan_destroy.argtypes = [vp]
@@ -107,6 +110,7 @@ def lib():
         L.sfmhip_ba_reduced_layout.argtypes = [vp, vp]
         L.sfmhip_score_essential.argtypes = [vp, cint, vp, vp, vp, f64, f64, f64, f64, f64, f64, vp, vp, vp]
         L.sfmhip_score_last_flags.argtypes = [vp]
+        L.sfmhip_score_five_point.argtypes = [vp, cint, vp, vp, vp, vp]
         L.sfmhip_score_homography.argtypes = [vp, cint, vp, vp, vp, vp, f64, cint, vp, vp, vp]
         L.sfmhip_sift_detect_and_compute.argtypes = [vp, vp, cint, cint, cint, f64, f64, f64, cint, vp, vp, vp]
         L.sfmhip_ba_reduced_step.argtypes = [vp, f64, vp, vp]

@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(1024) void ba_finalize(BaDev d, double radius, doub
   for (int i = d.dim + threadIdx.x; i < d.ld; i += blockDim.x) S[(size_t)i * d.ld + i] = 1.0;  // padding
   for (int i = threadIdx.x; i < d.ld; i += blockDim.x) {
     d.xinv[(size_t)i * d.ld + i] = 1.0;  // (zeroed with the rest of the buffer at the linearisation)
-    d.z[i] = 0.0;                        // chol_apply_inverse accumulates
+    d.z[i] = 0.0;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_down(gm, o));
@@ -1930,26 +1930,24 @@ __global__ __launch_bounds__(C2_WAVES * 64) void chol_step2_chains(ChainSet cs, 
 #undef CHOL_MFMA
 
 // z = L^-T y = X y.  X (column-major like A: X(i, j) = X[j*ld + i]) is upper triangular by 32x32
-// tiles; one workgroup per (tile row, group of XG column tiles): thread (row i of the tile, column
-// slice) sums its columns, the eight slices are added through LDS, one atomic per row and workgroup.
-constexpr int XG = 4;
-__global__ __launch_bounds__(256) void chol_apply_inverse(const double* __restrict__ X, const double* __restrict__ y,
-                                                         double* __restrict__ z, int ld, int nt) {
-  __shared__ double s_part[8][CB];
-  const int tr = blockIdx.x, cg = blockIdx.y;
-  const int c_lo = std::max(tr, cg * XG) * CB, c_hi = std::min(nt, (cg + 1) * XG) * CB;
-  if (c_lo >= c_hi) return;
+// tiles; one workgroup per tile row: thread (row i of the tile, one of 32 column slices) sums its columns in
+// ascending order, the slices are added through LDS in slice order -- no atomics: the same S and g give the same z
+// bit for bit, run after run and rank after rank (the replicated cameras of the sharded solver stay identical).
+__global__ __launch_bounds__(1024) void chol_apply_inverse(const double* __restrict__ X, const double* __restrict__ y,
+                                                          double* __restrict__ z, int ld, int nt) {
+  __shared__ double s_part[32][CB + 1];
+  const int tr = blockIdx.x;
   const int i = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const double* xr = X + tr * CB + i;
   double acc = 0.0;
-  for (int j = c_lo + sl; j < c_hi; j += 8) acc += xr[(size_t)j * ld] * y[j];
+  for (int j = tr * CB + sl; j < nt * CB; j += 32) acc += xr[(size_t)j * ld] * y[j];
   s_part[sl][i] = acc;
   __syncthreads();
   if (sl == 0) {
     double v = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v += s_part[k][i];
-    atomic_add_f64(z + tr * CB + i, v);
+    for (int k = 0; k < 32; ++k) v += s_part[k][i];
+    z[tr * CB + i] = v;
   }
 }
 
@@ -2924,6 +2922,15 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
 extern "C" int sfmhip_ba_set_allreduce(sfmhip_ba* b, sfmhip_allreduce_fn fn, void* user, int rank, int world) {
   if (!b || world < 1 || rank < 0 || rank >= world || world > 64) return SFMHIP_ERR_ARG;
   if (world > 1 && !fn) return SFMHIP_ERR_ARG;
+  if (world != b->world || rank != b->rank) {
+    // the dissection plan and the sparse exchange list are built from the UNION of the ranks' camera graphs, and the
+    // Jacobi scale from the sum of their column norms: both belong to the (rank, world) they were made for
+    b->nd_ready = false;
+    b->nd_on = false;
+    b->n_xblocks = 0;
+    b->scale_ready = false;
+    b->lm = LmState();  // (an LM run in progress belongs to the old partition: the next iterate starts over)
+  }
   b->allreduce = fn;
   b->allreduce_user = user;
   b->rank = rank;
@@ -3590,7 +3597,7 @@ static int ba_reduced_solve(sfmhip_ba* b) {
     }
   }
   // z = L^-T y = X y
-  hipLaunchKernelGGL(chol_apply_inverse, dim3(nt, (nt + XG - 1) / XG), dim3(256), 0, st, d.xinv, y, d.z, d.ld, nt);
+  hipLaunchKernelGGL(chol_apply_inverse, dim3(nt), dim3(1024), 0, st, d.xinv, y, d.z, d.ld, nt);
   const int nbs = 1;
   SFM_HIP_TRY(hipGetLastError());
   b->launches += nchol + nbs;
@@ -3972,6 +3979,10 @@ extern "C" int sfmhip_ba_reduced_system(sfmhip_ba* b, double radius, double* S, 
   sfmhip_ba_opts o;
   sfmhip_ba_default_opts(&o);
   if (!b->scale_ready) SFM_TRY(ba_prepare_scale(b, o.jacobi_scaling));
+  // (a test hook on a live object: the LM loop's pending linearisation is read out first, and what the hook leaves in
+  // the reduced-system buffer is not that linearisation -- the next iterate linearises again)
+  SFM_TRY(ba_flush_lin(b));
+  b->lm.have_lin = false;
   // this rank's points only: no all-reduce, and the camera/focal LM diagonal (a global
   // quantity) is added only when there is a single rank
   const int world = b->world;
@@ -4004,6 +4015,8 @@ extern "C" int sfmhip_ba_reduced_step(sfmhip_ba* b, double radius, double* z, in
   sfmhip_ba_default_opts(&o);
   if (!b->nd_ready) SFM_TRY(ba_nd_build(b));
   if (!b->scale_ready) SFM_TRY(ba_prepare_scale(b, o.jacobi_scaling));
+  SFM_TRY(ba_flush_lin(b));  // (as in sfmhip_ba_reduced_system: the hook's system is not the LM loop's)
+  b->lm.have_lin = false;
   SFM_TRY(ba_linearize_eliminate(b, radius, &o, true));
   SFM_TRY(ba_reduced_solve(b));
   hipStream_t st = b->ctx->stream;

@@ -39,6 +39,16 @@ static int init_common(int device, hipStream_t stream, bool own, sfmhip_ctx** ou
   return SFMHIP_OK;
 }
 
+extern "C" int sfmhip_device_count(void) {
+  int n = 0;
+  const hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    g_sfmhip_last_hip_error = (int)e;
+    return SFMHIP_ERR_NO_DEVICE;
+  }
+  return n;
+}
+
 extern "C" int sfmhip_init(int device, sfmhip_ctx** out) { return init_common(device, nullptr, true, out); }
 
 extern "C" int sfmhip_init_on_stream(int device, void* hip_stream, sfmhip_ctx** out) {

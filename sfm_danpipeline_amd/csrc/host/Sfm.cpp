@@ -1,5 +1,6 @@
 // Sfm.cpp -- hot-path members of StructFromMotion over the sfmhip C ABI.
 #include "Sfm.h"
+#include <algorithm>
 #include <cstdlib>
 #include <iostream>
 #include "hip_backend.h"
@@ -227,31 +228,65 @@ void StructFromMotion::matchAllPairs() {
     }
   sfmhip_ctx* ctx = sfm_hip_context();
   sfmhip_imageset* set = nullptr;
-  sfmhip_matchplan* plan = nullptr;
   int rc = sfmhip_imageset_create(ctx, n, rows.data(), d0.cols, d0.type() == CV_32F ? SFMHIP_F32 : SFMHIP_U8, SFMHIP_L2, &set);
   for (int i = 0; rc == SFMHIP_OK && i < n; ++i)
     if (rows[i] > 0) rc = sfmhip_imageset_upload(set, i, imagesDescriptors[i].ptr());
   if (rc == SFMHIP_OK) rc = sfmhip_imageset_prepare_async(set);
+  // The pair list goes to the device in batches, two plans taking turns: while the device sweeps batch b, the lists of
+  // batch b-1 -- packed into pinned host memory by the plans' second stream (sfmhip_matchplan_pipeline) -- become the
+  // cache's vector<DMatch>s on the host.  Results do not depend on the batching (pairs are independent).
   const int n_pairs = (int)pairs.size() / 2;
-  if (rc == SFMHIP_OK) rc = sfmhip_matchplan_create(set, pairs.data(), n_pairs, &plan);
-  if (rc == SFMHIP_OK) rc = sfmhip_matchplan_run_async(plan, NN_MATCH_RATIO);
-  std::vector<int32_t> counts(n_pairs);
-  int64_t total = 0;
-  if (rc == SFMHIP_OK) rc = sfmhip_matchplan_fetch(plan, counts.data(), nullptr, nullptr, nullptr, 0, &total);
-  std::vector<int32_t> oq((size_t)total + 1), ot((size_t)total + 1);
-  std::vector<float> od((size_t)total + 1);
-  if (rc == SFMHIP_OK) rc = sfmhip_matchplan_fetch(plan, counts.data(), oq.data(), ot.data(), od.data(), total, &total);
-  if (rc == SFMHIP_OK) {
-    size_t off = 0;
-    for (int p = 0; p < n_pairs; ++p) {
-      Matching& m = pairCache[std::make_pair((int)pairs[2 * p], (int)pairs[2 * p + 1])];
-      for (int i = 0; i < counts[p]; ++i, ++off) m.push_back(cv::DMatch(oq[off], ot[off], od[off]));
+  const int batch = std::max(64, (n_pairs + 7) / 8);
+  const int n_batches = (n_pairs + batch - 1) / batch;
+  sfmhip_matchplan* plans[2] = {nullptr, nullptr};
+  auto collect = [&](int b) -> int {  // batch b's lists -> pairCache
+    const int32_t *cnt = nullptr, *oq = nullptr, *ot = nullptr;
+    const float* od = nullptr;
+    int64_t total = 0;
+    int r = sfmhip_matchplan_fetch_wait(plans[b & 1], 0, &cnt, &oq, &ot, &od, &total);
+    if (r == SFMHIP_ERR_ALLOC) {  // more matches than the pinned buffers hold: the copying fetch has no such limit
+      const int first = b * batch, np = std::min(batch, n_pairs - first);
+      std::vector<int32_t> c(np), q((size_t)total + 1), t((size_t)total + 1);
+      std::vector<float> d((size_t)total + 1);
+      r = sfmhip_matchplan_fetch(plans[b & 1], c.data(), q.data(), t.data(), d.data(), total, &total);
+      size_t off = 0;
+      for (int p = 0; r == SFMHIP_OK && p < np; ++p) {
+        Matching& m = pairCache[std::make_pair((int)pairs[2 * (first + p)], (int)pairs[2 * (first + p) + 1])];
+        for (int i = 0; i < c[p]; ++i, ++off) m.push_back(cv::DMatch(q[off], t[off], d[off]));
+      }
+      return r;
     }
+    if (r != SFMHIP_OK) return r;
+    const int first = b * batch, np = std::min(batch, n_pairs - first);
+    size_t off = 0;
+    for (int p = 0; p < np; ++p) {
+      Matching& m = pairCache[std::make_pair((int)pairs[2 * (first + p)], (int)pairs[2 * (first + p) + 1])];
+      m.reserve((size_t)cnt[p]);
+      for (int i = 0; i < cnt[p]; ++i, ++off) m.push_back(cv::DMatch(oq[off], ot[off], od[off]));
+    }
+    return SFMHIP_OK;
+  };
+  for (int b = 0; rc == SFMHIP_OK && b < n_batches; ++b) {
+    const int first = b * batch, np = std::min(batch, n_pairs - first);
+    sfmhip_matchplan*& pl = plans[b & 1];
+    if (!pl) {
+      rc = sfmhip_matchplan_create(set, pairs.data() + 2 * first, np, &pl);
+      if (rc == SFMHIP_OK) rc = sfmhip_matchplan_pipeline(pl, 0);
+    } else {
+      rc = sfmhip_matchplan_set_pairs(pl, pairs.data() + 2 * first, np);  // (np <= the batch it was created with)
+    }
+    if (rc == SFMHIP_OK) rc = sfmhip_matchplan_run_async(pl, NN_MATCH_RATIO);
+    if (rc == SFMHIP_OK && b > 0) rc = collect(b - 1);
+  }
+  if (rc == SFMHIP_OK && n_batches > 0) rc = collect(n_batches - 1);
+  if (rc == SFMHIP_OK) {
     pairCacheOn = true;
   } else {
+    pairCache.clear();
     std::cerr << "matchAllPairs: " << sfmhip_error_string(rc) << std::endl;
   }
-  sfmhip_matchplan_destroy(plan);
+  sfmhip_matchplan_destroy(plans[0]);
+  sfmhip_matchplan_destroy(plans[1]);
   sfmhip_imageset_destroy(set);
 }
 

@@ -70,7 +70,8 @@ struct Huffman {
     return -1;
   }
 };
-bool inflate_zlib(const std::vector<uint8_t>& in, std::vector<uint8_t>& out) {
+// max_out: the decoded size the caller expects; a stream that expands beyond it is corrupt (or hostile) and is refused
+bool inflate_zlib(const std::vector<uint8_t>& in, std::vector<uint8_t>& out, size_t max_out) {
   if (in.size() < 6 || (in[0] & 0x0F) != 8 || ((in[0] << 8) | in[1]) % 31 != 0 || (in[1] & 0x20)) return false;
   BitReader br(in.data() + 2, in.size() - 2);
   static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -88,7 +89,7 @@ bool inflate_zlib(const std::vector<uint8_t>& in, std::vector<uint8_t>& out) {
       if (br.pos + 4 > br.n) return false;
       const unsigned len = br.p[br.pos] | (br.p[br.pos + 1] << 8), nlen = br.p[br.pos + 2] | (br.p[br.pos + 3] << 8);
       br.pos += 4;
-      if ((len ^ 0xFFFFu) != nlen || br.pos + len > br.n) return false;
+      if ((len ^ 0xFFFFu) != nlen || br.pos + len > br.n || out.size() + len > max_out) return false;
       out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
       br.pos += len;
       continue;
@@ -136,8 +137,10 @@ bool inflate_zlib(const std::vector<uint8_t>& in, std::vector<uint8_t>& out) {
     for (;;) {
       const int sym = hl.decode(br);
       if (sym < 0 || !br.ok) return false;
-      if (sym < 256) out.push_back((uint8_t)sym);
-      else if (sym == 256) break;
+      if (sym < 256) {
+        if (out.size() >= max_out) return false;
+        out.push_back((uint8_t)sym);
+      } else if (sym == 256) break;
       else {
         const int s = sym - 257;
         if (s >= 29) return false;
@@ -145,7 +148,7 @@ bool inflate_zlib(const std::vector<uint8_t>& in, std::vector<uint8_t>& out) {
         const int ds = hd.decode(br);
         if (ds < 0 || ds >= 30) return false;
         const size_t dist = dbase[ds] + br.get(dext[ds]);
-        if (!br.ok || dist > out.size()) return false;
+        if (!br.ok || dist > out.size() || out.size() + (size_t)len > max_out) return false;
         const size_t from = out.size() - dist;
         for (int i = 0; i < len; ++i) out.push_back(out[from + i]);
       }
@@ -195,12 +198,22 @@ bool decode_png(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) {
     why = "unsupported colour type / bit depth";
     return false;
   }
+  // IHDR is not taken on trust: dimensions beyond 65535 (cv::Mat's int rows / cols, and size_t products that wrap) or a
+  // decoded size beyond 1 GiB are refused before anything is inflated, and the inflater stops at the expected size
+  if (w > 65535u || h > 65535u) {
+    why = "image dimensions out of range";
+    return false;
+  }
+  const size_t bpp_bits = (size_t)nch * depth, stride = ((size_t)w * bpp_bits + 7) / 8, bpp = std::max<size_t>(1, bpp_bits / 8);
+  if ((stride + 1) * (size_t)h > ((size_t)1 << 30)) {
+    why = "image too large";
+    return false;
+  }
   std::vector<uint8_t> raw;
-  if (!inflate_zlib(idat, raw)) {
+  if (!inflate_zlib(idat, raw, (stride + 1) * (size_t)h)) {
     why = "corrupt zlib stream";
     return false;
   }
-  const size_t bpp_bits = (size_t)nch * depth, stride = (w * bpp_bits + 7) / 8, bpp = std::max<size_t>(1, bpp_bits / 8);
   if (raw.size() < (stride + 1) * h) {
     why = "truncated image data";
     return false;

@@ -1585,8 +1585,11 @@ __global__ __launch_bounds__(256) void compact_kernel(const ImgDev* __restrict__
 
 // ---------------------------------------------------------------- packing for the host
 // exclusive scan of the pair counts (one workgroup) ...
+// h_counts / h_total (may be null): the same counts and the grand total written into mapped host memory (the
+// pipelined fetch: the host reads them after the copy stream's event, no hipMemcpy in between)
 __global__ __launch_bounds__(1024) void pack_offsets_kernel(const int* __restrict__ counts, int n_pairs,
-                                                            long long* __restrict__ offsets) {
+                                                            long long* __restrict__ offsets, int* __restrict__ h_counts = nullptr,
+                                                            long long* __restrict__ h_total = nullptr) {
   __shared__ long long wsum[16];
   __shared__ long long running;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1606,6 +1609,7 @@ __global__ __launch_bounds__(1024) void pack_offsets_kernel(const int* __restric
     long long before = running;
     for (int w = 0; w < wave; ++w) before += wsum[w];
     if (p < n_pairs) offsets[p] = before + x - c;
+    if (p < n_pairs && h_counts) h_counts[p] = (int)c;
     __syncthreads();
     if (threadIdx.x == 0) {
       long long t = 0;
@@ -1614,17 +1618,21 @@ __global__ __launch_bounds__(1024) void pack_offsets_kernel(const int* __restric
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) offsets[n_pairs] = running;
+  if (threadIdx.x == 0) {
+    offsets[n_pairs] = running;
+    if (h_total) *h_total = running;
+  }
 }
 // ... and the pairs' lists, gathered into three arrays back to back: queryIdx | trainIdx | distance bits, each of
 // offsets[n_pairs] entries (the host copies them out with three memcpy, not record by record)
 __global__ __launch_bounds__(256) void pack_lists_kernel(const int* __restrict__ counts, const long long* __restrict__ offsets,
                                                          int n_pairs, int maxq, const int* __restrict__ out_q,
                                                          const int* __restrict__ out_t, const float* __restrict__ out_d,
-                                                         int* __restrict__ packed) {
+                                                         int* __restrict__ packed, long long capacity = -1) {
   const int p = blockIdx.x;
   const int n = counts[p];
   const long long o = offsets[p], tot = offsets[n_pairs];
+  if (capacity >= 0 && tot > capacity) return;  // (the host sees total > capacity and reports it)
   for (int i = threadIdx.x; i < n; i += 256) {
     const size_t src = (size_t)p * maxq + i;
     packed[o + i] = out_q[src];
@@ -1683,6 +1691,15 @@ struct sfmhip_matchplan {
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_k = nullptr;  // end of the k-NN kernel proper (ev[0] .. ev_k = that one launch)
   bool timed = false;
+  // pipelined fetch (sfmhip_matchplan_pipeline): after every run a second stream packs the lists straight into one of
+  // two pinned host buffers while the first stream goes on with the next sweep
+  bool pipe_on = false;
+  hipStream_t pipe_st = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_host[2] = {nullptr, nullptr};
+  void* h_pipe[2] = {nullptr, nullptr};   // [int64 total | int64 capacity | int32 counts[cap_pairs] | int32 q[], t[], d[]]
+  int* dh_pipe[2] = {nullptr, nullptr};   // the same buffers as the device sees them
+  long long pipe_capacity = 0;            // matches per slot
+  long long runs = 0;                     // runs enqueued since the pipeline was switched on
 };
 
 static int pick_ks(int kind, int dim) {
@@ -1971,6 +1988,7 @@ extern "C" int sfmhip_matchplan_set_pairs(sfmhip_matchplan* pl, const int32_t* p
   if (items.size() > pl->cap_items) return SFMHIP_ERR_STATE;
   hipStream_t st = s->ctx->stream;
   SFM_HIP_TRY(hipStreamSynchronize(st));  // a previous run may still read the old lists
+  if (pl->pipe_st) SFM_HIP_TRY(hipStreamSynchronize(pl->pipe_st));
   pl->n_pairs = n_pairs;
   pl->n_items = (int)items.size();
   pl->h_pairs.assign(pairs, pairs + 2 * (size_t)n_pairs);
@@ -2047,6 +2065,9 @@ extern "C" int sfmhip_matchplan_run_async(sfmhip_matchplan* pl, float ratio) {
     }
   }
   if (timing) SFM_HIP_TRY(hipEventRecord(pl->ev[1], st));
+  // (pipelined fetch: the previous run's lists are still being packed off d_counts / d_out_* by the copy stream --
+  // in practice long done: that takes tens of microseconds and a sweep hundreds)
+  if (pl->pipe_on && pl->runs > 0) SFM_HIP_TRY(hipStreamWaitEvent(st, pl->ev_host[(pl->runs - 1) & 1], 0));
   if (pl->n_pairs > 0) {
     if (s->kind == KIND_F32_L2)
       hipLaunchKernelGGL((compact_kernel<KIND_F32_L2>), dim3(pl->n_pairs), dim3(256), 0, st, s->d_imgs, pl->d_pairs, pl->d_knn,
@@ -2061,6 +2082,77 @@ extern "C" int sfmhip_matchplan_run_async(sfmhip_matchplan* pl, float ratio) {
   }
   if (timing) SFM_HIP_TRY(hipEventRecord(pl->ev[2], st));
   pl->timed = timing;
+  if (pl->pipe_on) {
+    const int slot = (int)(pl->runs & 1);
+    SFM_HIP_TRY(hipEventRecord(pl->ev_ready, st));
+    SFM_HIP_TRY(hipStreamWaitEvent(pl->pipe_st, pl->ev_ready, 0));
+    long long* h_hdr = (long long*)pl->dh_pipe[slot];
+    int* h_counts = pl->dh_pipe[slot] + 4;
+    int* h_rec = h_counts + pl->cap_pairs;
+    if (pl->n_pairs > 0) {
+      hipLaunchKernelGGL(pack_offsets_kernel, dim3(1), dim3(1024), 0, pl->pipe_st, pl->d_counts, pl->n_pairs, pl->d_offsets, h_counts, h_hdr);
+      hipLaunchKernelGGL(pack_lists_kernel, dim3(pl->n_pairs), dim3(256), 0, pl->pipe_st, pl->d_counts, pl->d_offsets, pl->n_pairs,
+                         pl->maxq, pl->d_out_q, pl->d_out_t, pl->d_out_d, h_rec, pl->pipe_capacity);
+      SFM_HIP_TRY(hipGetLastError());
+    } else {
+      ((long long*)pl->h_pipe[slot])[0] = 0;
+    }
+    SFM_HIP_TRY(hipEventRecord(pl->ev_host[slot], pl->pipe_st));
+    ++pl->runs;
+  }
+  return SFMHIP_OK;
+}
+
+extern "C" int sfmhip_matchplan_pipeline(sfmhip_matchplan* pl, int64_t capacity) {
+  if (!pl) return SFMHIP_ERR_ARG;
+  sfmhip_imageset* s = pl->set;
+  SFM_HIP_TRY(hipSetDevice(s->ctx->device));
+  SFM_HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+  if (pl->pipe_st) SFM_HIP_TRY(hipStreamSynchronize(pl->pipe_st));
+  if (capacity < 0) {  // off: runs are no longer followed by the packing pass
+    pl->pipe_on = false;
+    pl->runs = 0;
+    return SFMHIP_OK;
+  }
+  if (capacity == 0) capacity = std::max<long long>(4096, (long long)pl->cap_pairs * pl->maxq / 4);
+  if (!pl->pipe_st) {
+    SFM_HIP_TRY(hipStreamCreateWithFlags(&pl->pipe_st, hipStreamNonBlocking));
+    SFM_HIP_TRY(hipEventCreateWithFlags(&pl->ev_ready, hipEventDisableTiming));
+    for (auto& e : pl->ev_host) SFM_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  if (!pl->d_offsets) SFM_TRY(sfm_dev_alloc(&pl->d_offsets, (size_t)pl->cap_pairs + 1));
+  if (capacity != pl->pipe_capacity || !pl->h_pipe[0]) {
+    for (int k = 0; k < 2; ++k) {
+      if (pl->h_pipe[k]) hipHostFree(pl->h_pipe[k]);
+      pl->h_pipe[k] = nullptr;
+      const size_t bytes = 16 + sizeof(int) * ((size_t)pl->cap_pairs + 3 * (size_t)capacity);
+      SFM_HIP_TRY(hipHostMalloc(&pl->h_pipe[k], bytes, hipHostMallocMapped));
+      void* dp = nullptr;
+      SFM_HIP_TRY(hipHostGetDevicePointer(&dp, pl->h_pipe[k], 0));
+      pl->dh_pipe[k] = (int*)dp;
+      memset(pl->h_pipe[k], 0, 16);
+    }
+    pl->pipe_capacity = capacity;
+  }
+  pl->pipe_on = true;
+  pl->runs = 0;
+  return SFMHIP_OK;
+}
+
+extern "C" int sfmhip_matchplan_fetch_wait(sfmhip_matchplan* pl, int back, const int32_t** counts, const int32_t** out_q,
+                                           const int32_t** out_t, const float** out_dist, int64_t* total) {
+  if (!pl || !pl->pipe_on || back < 0 || back > 1 || pl->runs <= back) return pl && pl->pipe_on ? SFMHIP_ERR_STATE : SFMHIP_ERR_ARG;
+  const int slot = (int)((pl->runs - 1 - back) & 1);
+  SFM_HIP_TRY(hipEventSynchronize(pl->ev_host[slot]));
+  const long long tot = ((const long long*)pl->h_pipe[slot])[0];
+  const int32_t* c = (const int32_t*)pl->h_pipe[slot] + 4;
+  const int32_t* rec = c + pl->cap_pairs;
+  if (total) *total = tot;
+  if (counts) *counts = c;
+  if (tot > pl->pipe_capacity) return SFMHIP_ERR_ALLOC;  // (total is set: switch the pipeline on again with that much room)
+  if (out_q) *out_q = rec;
+  if (out_t) *out_t = rec + tot;
+  if (out_dist) *out_dist = (const float*)(rec + 2 * tot);
   return SFMHIP_OK;
 }
 
@@ -2073,6 +2165,7 @@ extern "C" int sfmhip_matchplan_fetch(sfmhip_matchplan* pl, int32_t* counts, int
   const bool lists = out_q || out_t || out_dist;
   if (total) *total = 0;
   if (pl->n_pairs == 0) return SFMHIP_OK;
+  if (pl->pipe_st) SFM_HIP_TRY(hipStreamSynchronize(pl->pipe_st));  // (the pipelined packing shares d_offsets)
   // The lists leave the device packed: a scan of the counts and a gather into {q, t, dist} records on the
   // device, then two copies (counts + offsets, records) instead of three per pair.
   if (lists) {
@@ -2176,6 +2269,15 @@ extern "C" void sfmhip_matchplan_destroy(sfmhip_matchplan* pl) {
   hipFree(pl->d_fix_arrived);
   hipFree(pl->d_offsets);
   hipFree(pl->d_packed);
+  if (pl->pipe_st) {
+    hipStreamSynchronize(pl->pipe_st);
+    hipStreamDestroy(pl->pipe_st);
+  }
+  if (pl->ev_ready) hipEventDestroy(pl->ev_ready);
+  for (auto& e : pl->ev_host)
+    if (e) hipEventDestroy(e);
+  for (void* h : pl->h_pipe)
+    if (h) hipHostFree(h);
   for (auto& e : pl->ev)
     if (e) hipEventDestroy(e);
   if (pl->ev_k) hipEventDestroy(pl->ev_k);

@@ -64,7 +64,9 @@ int main(int argc, char** argv) {
     }
 
   sfmhip_ctx* ctx = nullptr;
-  CK(sfmhip_init(0, &ctx));
+  const int n_dev = sfmhip_device_count();  // one rank per GPU (RCCL refuses two ranks on one device)
+  if (n_dev <= 0) return 3;
+  CK(sfmhip_init(rank % n_dev, &ctx));
   unsigned char id[SFMHIP_RCCL_ID_BYTES];
   if (rank == 0) {
     CK(sfmhip_rccl_unique_id(id));

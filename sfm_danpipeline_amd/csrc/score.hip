@@ -18,6 +18,7 @@
 // checker (the CPU restatement of the same route: test infrastructure, never linked here); parity is unpinned (OpenCV is not in
 // the image).  sfmhip_score_last_flags reports samples that reached a corner of solvePoly that is not restated.
 #include "common.h"
+#include "hypot_glibc.h"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -79,7 +80,7 @@ __device__ void jacobi_svd(double* At, double* W, double* Vt) {
         for (int k = 0; k < M; ++k) p += Ai[k] * Aj[k];
         if (fabs(p) <= eps * sqrt(a * b)) continue;
         p *= 2;
-        const double beta = a - b, gamma = hypot(p, beta);
+        const double beta = a - b, gamma = sfm_hypot(p, beta);  // (the host libm's hypot, bit for bit: hypot_glibc.h)
         double c, sn;
         if (beta < 0) {
           const double delta = (gamma - beta) * 0.5;
@@ -942,6 +943,59 @@ extern "C" int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_
     SFM_HIP_TRY(hipMemcpyAsync(mask, d_mask, (size_t)total, hipMemcpyDeviceToHost, st));
   }
   SFM_HIP_TRY(hipStreamSynchronize(st));
+  return SFMHIP_OK;
+}
+
+// EMEstimatorCallback::runKernel for explicit samples (five normalised correspondences each): what score_solve runs per
+// (pair, iteration), exposed for sample-level parity checks
+__global__ __launch_bounds__(64) void five_point_samples(const double* __restrict__ q1, const double* __restrict__ q2, int n,
+                                                         double* __restrict__ models, int* __restrict__ n_models) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  double a[5][2], b[5][2];
+  for (int k = 0; k < 5; ++k) {
+    a[k][0] = q1[10 * (size_t)t + 2 * k];
+    a[k][1] = q1[10 * (size_t)t + 2 * k + 1];
+    b[k][0] = q2[10 * (size_t)t + 2 * k];
+    b[k][1] = q2[10 * (size_t)t + 2 * k + 1];
+  }
+  double E[MAX_MODELS][9];
+  int flags = 0;
+  const int nm = five_point(a, b, E, &flags);
+  n_models[t] = nm | (flags << 8);
+  for (int m = 0; m < nm; ++m)
+    for (int e = 0; e < 9; ++e) models[((size_t)t * MAX_MODELS + m) * 9 + e] = E[m][e];
+}
+
+extern "C" int sfmhip_score_five_point(sfmhip_ctx* ctx, int n_samples, const double* q1, const double* q2, double* models,
+                                       int32_t* n_models) {
+  if (!ctx || n_samples < 0 || (n_samples && (!q1 || !q2 || !models || !n_models))) return SFMHIP_ERR_ARG;
+  if (n_samples == 0) return SFMHIP_OK;
+  SFM_HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  double *d_q1 = nullptr, *d_q2 = nullptr, *d_m = nullptr;
+  int* d_n = nullptr;
+  int rc = SFMHIP_OK;
+  if ((rc = sfm_dev_alloc(&d_q1, 10 * (size_t)n_samples)) || (rc = sfm_dev_alloc(&d_q2, 10 * (size_t)n_samples)) ||
+      (rc = sfm_dev_alloc(&d_m, 90 * (size_t)n_samples)) || (rc = sfm_dev_alloc(&d_n, (size_t)n_samples))) {
+    hipFree(d_q1), hipFree(d_q2), hipFree(d_m), hipFree(d_n);
+    return rc;
+  }
+  hipError_t e = hipMemcpyAsync(d_q1, q1, sizeof(double) * 10 * n_samples, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_q2, q2, sizeof(double) * 10 * n_samples, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemsetAsync(d_m, 0, sizeof(double) * 90 * n_samples, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(five_point_samples, dim3((n_samples + 63) / 64), dim3(64), 0, st, d_q1, d_q2, n_samples, d_m, d_n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(models, d_m, sizeof(double) * 90 * n_samples, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(n_models, d_n, sizeof(int) * n_samples, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  hipFree(d_q1), hipFree(d_q2), hipFree(d_m), hipFree(d_n);
+  if (e != hipSuccess) {
+    g_sfmhip_last_hip_error = (int)e;
+    return SFMHIP_ERR_HIP;
+  }
   return SFMHIP_OK;
 }
 

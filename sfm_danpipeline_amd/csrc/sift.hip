@@ -591,16 +591,24 @@ extern "C" int sfmhip_sift_detect_and_compute(sfmhip_ctx* ctx, const uint8_t* gr
   SFM_HIP_TRY(hipStreamSynchronize(st));
   if (h_cnt[0] > cand_cap) return SFMHIP_ERR_UNSUPPORTED;
   const int n_cand = h_cnt[0];
-  const int kp_cap = 4 * n_cand + 16;
+  int kp_cap = 4 * n_cand + 16;
   KeyPt* d_kp = nullptr;
-  SFM_TRY(sfm_ctx_dev_scratch(ctx, 1, sizeof(KeyPt) * kp_cap, (void**)&d_kp));
-  if (n_cand > 0)
-    hipLaunchKernelGGL(sift_refine, dim3((n_cand + 3) / 4), dim3(256), 0, st, P, (const float*)G, (const float*)D,
-                       (const Cand*)d_cand, n_cand, (float)contrast_threshold, (float)edge_threshold, (float)sigma, d_kp,
-                       d_cnt + 1, kp_cap);
-  SFM_HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
-  SFM_HIP_TRY(hipStreamSynchronize(st));
-  int nk = std::min(h_cnt[1], kp_cap);
+  for (int attempt = 0;; ++attempt) {
+    // (a candidate can yield several orientation peaks; slots are claimed with atomics, so a list that overflowed
+    // would hold an arbitrary subset: the refinement is redone with room for the count it reported)
+    SFM_TRY(sfm_ctx_dev_scratch(ctx, 1, sizeof(KeyPt) * kp_cap, (void**)&d_kp));
+    if (n_cand > 0)
+      hipLaunchKernelGGL(sift_refine, dim3((n_cand + 3) / 4), dim3(256), 0, st, P, (const float*)G, (const float*)D,
+                         (const Cand*)d_cand, n_cand, (float)contrast_threshold, (float)edge_threshold, (float)sigma, d_kp,
+                         d_cnt + 1, kp_cap);
+    SFM_HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+    SFM_HIP_TRY(hipStreamSynchronize(st));
+    if (h_cnt[1] <= kp_cap) break;
+    if (attempt > 0) return SFMHIP_ERR_UNSUPPORTED;
+    kp_cap = h_cnt[1];
+    SFM_HIP_TRY(hipMemsetAsync(d_cnt + 1, 0, sizeof(int), st));
+  }
+  int nk = h_cnt[1];
   std::vector<KeyPt> kps(nk);
   if (nk) SFM_HIP_TRY(hipMemcpy(kps.data(), d_kp, sizeof(KeyPt) * nk, hipMemcpyDeviceToHost));
   // ---- KeyPointsFilter::removeDuplicatedSorted, then the rescale of the doubled first octave

@@ -8,6 +8,7 @@
 // HBM-bound by construction (2 x 16 B in, 24 B + 1 B (+8 B) out per match); the track /
 // visibility bookkeeping (Point3D::idxImage, src/Sfm.cpp:862-873) is the host mirror's job.
 #include "common.h"
+#include "hypot_glibc.h"
 #include <float.h>
 
 namespace {
@@ -81,7 +82,7 @@ __device__ __forceinline__ void dlt_null_vector(double At[4][4], double out[4]) 
         for (int k = 0; k < 4; ++k) p += At[i][k] * At[j][k];
         if (fabs(p) <= eps * sqrt(a * b)) continue;
         p *= 2;
-        const double beta = a - b, gamma = hypot(p, beta);
+        const double beta = a - b, gamma = sfm_hypot(p, beta);  // (the host libm's hypot, bit for bit: hypot_glibc.h)
         double c, s;
         if (beta < 0) {
           const double delta = (gamma - beta) * 0.5;

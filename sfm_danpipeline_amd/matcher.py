@@ -131,6 +131,23 @@ class MatchPlan:
                                            total, C.byref(tot)), "sfmhip_matchplan_fetch")
         return cnt, oq[:total], ot[:total], od[:total]
 
+    def pipeline(self, capacity=0):
+        """Switch the pipelined fetch on (sfmhip_matchplan_pipeline): every run_async is followed by a pass on a second
+        stream that packs the lists into one of two pinned host buffers; fetch_wait hands them out."""
+        check(lib().sfmhip_matchplan_pipeline(self.h, int(capacity)), "sfmhip_matchplan_pipeline")
+
+    def fetch_wait(self, back=0):
+        """counts and (queryIdx, trainIdx, distance) of the latest run (back=0) or the one before (back=1) as numpy
+        VIEWS of the pinned buffer: valid until two more runs have been enqueued (copy what must live longer)."""
+        pc, pq, pt, pd = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        tot = C.c_int64(0)
+        check(lib().sfmhip_matchplan_fetch_wait(self.h, back, C.byref(pc), C.byref(pq), C.byref(pt), C.byref(pd), C.byref(tot)),
+              "sfmhip_matchplan_fetch_wait")
+        n = int(tot.value)
+        view = lambda ptr, ct, dt, k: np.frombuffer((ct * max(k, 1)).from_address(ptr.value), dt, k)
+        return (view(pc, C.c_int32, np.int32, self.n_pairs), view(pq, C.c_int32, np.int32, n), view(pt, C.c_int32, np.int32, n),
+                view(pd, C.c_float, np.float32, n))
+
     def fetch_pair(self, p):
         cnt, oq, ot, od = self.fetch()
         off = int(cnt[:p].sum())

@@ -30,6 +30,19 @@ def score_essential(pairs_points, K, prob=0.999, threshold=1.0, want_mask=False,
     return inl[:n], masks, its[:n]
 
 
+def five_point(q1, q2, ctx=None):
+    """sfmhip_score_five_point: q1, q2 (n, 5, 2) normalised points -> (models (n, 10, 3, 3), counts (n,), flags (n,))"""
+    ctx = ctx or default_context()
+    q1 = np.ascontiguousarray(q1, np.float64).reshape(-1, 5, 2)
+    q2 = np.ascontiguousarray(q2, np.float64).reshape(-1, 5, 2)
+    n = len(q1)
+    models = np.zeros((max(n, 1), 10, 3, 3))
+    nm = np.zeros(max(n, 1), np.int32)
+    check(lib().sfmhip_score_five_point(ctx.h, n, q1.ctypes.data, q2.ctypes.data, models.ctypes.data, nm.ctypes.data),
+          "sfmhip_score_five_point")
+    return models[:n], nm[:n] & 0xff, nm[:n] >> 8
+
+
 def last_flags(ctx=None):
     """sfmhip_score_last_flags: non-zero when a five-point sample of the last score_essential call reached a corner of
     cv::solvePoly whose library behaviour is not reproduced (include/sfmhip.h)."""

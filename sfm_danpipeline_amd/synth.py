@@ -148,3 +148,29 @@ def tracks_to_csr(cloud):
             feats.append(tr[v])
         ptr[i + 1] = len(views)
     return ptr, np.asarray(views, np.int32), np.asarray(feats, np.int32)
+
+
+def match_mix(q, t, dist):
+    """A 64-bit mix of one match (queryIdx, trainIdx, bit pattern of the float distance), vectorised: the per-match value
+    of the pair checksums that full-size runs compare instead of whole lists (the C checker computes the same function)."""
+    with np.errstate(over="ignore"):
+        x = q.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) + t.astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F) + \
+            np.ascontiguousarray(dist, np.float32).view(np.uint32).astype(np.uint64) * np.uint64(0x165667B19E3779F9)
+        x ^= x >> np.uint64(29)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(32)
+    return x
+
+
+def pair_checksums(counts, oq, ot, od):
+    """(n_pairs, 2) uint64 [sum, xor] of match_mix over each pair's slice of concatenated match lists."""
+    x = match_mix(np.asarray(oq), np.asarray(ot), np.asarray(od))
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    cs = np.zeros((len(counts), 2), np.uint64)
+    with np.errstate(over="ignore"):
+        for p in range(len(counts)):
+            seg = x[off[p]:off[p + 1]]
+            if len(seg):
+                cs[p, 0] = np.sum(seg, dtype=np.uint64)
+                cs[p, 1] = np.bitwise_xor.reduce(seg)
+    return cs

@@ -20,8 +20,11 @@ struct sfmhip_matchplan {
   int32_t* counts;
   int32_t **q, **t;
   float** d;
+  int pipe_on;         /* sfmhip_matchplan_pipeline: fetch_wait hands out pointers into `packed` */
+  int32_t* packed;
 };
 
+int sfmhip_device_count(void) { return 1; }
 int sfmhip_init(int device, sfmhip_ctx** out) {
   (void)device;
   *out = (sfmhip_ctx*)calloc(1, sizeof(sfmhip_ctx));
@@ -126,9 +129,37 @@ int sfmhip_matchplan_fetch(sfmhip_matchplan* pl, int32_t* counts, int32_t* out_q
   }
   return SFMHIP_OK;
 }
+int sfmhip_matchplan_pipeline(sfmhip_matchplan* pl, int64_t capacity) {
+  (void)capacity;
+  pl->pipe_on = 1;
+  return SFMHIP_OK;
+}
+int sfmhip_matchplan_fetch_wait(sfmhip_matchplan* pl, int back, const int32_t** counts, const int32_t** out_q, const int32_t** out_t,
+                                const float** out_dist, int64_t* total) {
+  if (!pl->pipe_on || back != 0) return SFMHIP_ERR_STATE; /* (the stand-in keeps the latest run only) */
+  int64_t tot = 0;
+  for (int p = 0; p < pl->n_pairs; ++p) tot += pl->counts[p];
+  free(pl->packed);
+  pl->packed = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)(tot ? tot : 1));
+  int64_t off = 0;
+  for (int p = 0; p < pl->n_pairs; ++p) {
+    const size_t n = (size_t)pl->counts[p];
+    memcpy(pl->packed + off, pl->q[p], n * 4);
+    memcpy(pl->packed + tot + off, pl->t[p], n * 4);
+    memcpy(pl->packed + 2 * tot + off, pl->d[p], n * 4);
+    off += (int64_t)n;
+  }
+  if (total) *total = tot;
+  if (counts) *counts = pl->counts;
+  if (out_q) *out_q = pl->packed;
+  if (out_t) *out_t = pl->packed + tot;
+  if (out_dist) *out_dist = (const float*)(pl->packed + 2 * tot);
+  return SFMHIP_OK;
+}
 void sfmhip_matchplan_destroy(sfmhip_matchplan* pl) {
   if (!pl) return;
   plan_free_lists(pl);
+  free(pl->packed);
   free(pl->q);
   free(pl->t);
   free(pl->d);
@@ -158,6 +189,15 @@ int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_t* offsets,
   return SFMHIP_OK;
 }
 int sfmhip_score_last_flags(sfmhip_ctx* ctx) { (void)ctx; return g_score_flags; }
+int sfmhip_score_five_point(sfmhip_ctx* ctx, int n_samples, const double* q1, const double* q2, double* models, int32_t* n_models) {
+  (void)ctx;
+  for (int i = 0; i < n_samples; ++i) {
+    int fl = 0;
+    const int n = orc_five_point(q1 + 10 * (size_t)i, q2 + 10 * (size_t)i, models + 90 * (size_t)i, &fl);
+    n_models[i] = n | (fl << 8);
+  }
+  return SFMHIP_OK;
+}
 
 /* the SIFT front end is device code (its checker is numpy): the stand-in finds no keypoints */
 int sfmhip_sift_detect_and_compute(sfmhip_ctx* ctx, const uint8_t* gray, int rows, int cols, int n_octave_layers,

@@ -79,3 +79,44 @@ def test_rccl_library_exports_what_its_header_declares():
     assert re.search(r" U ncclAllReduce", syms) and re.search(r" U ncclCommInitRank", syms)
     needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True, check=True).stdout
     assert "librccl.so" in needed and "libsfmhip.so" in needed
+
+
+def test_device_hypot_restatement_equals_the_hosts_libm(tmp_path):
+    """csrc/hypot_glibc.h (what the device's Jacobi SVDs call instead of ocml's hypot) compiled for the host against
+    this image's libm: bit-equal on random arguments, the scaling branches and the non-finite corners -- the five-point
+    solver must follow its CPU checker to the last bit (an ill-conditioned sample amplifies one ulp to 1e-3 of E)"""
+    import subprocess
+    src = tmp_path / "h.cpp"
+    src.write_text(r"""
+#include "hypot_glibc.h"
+#include <cstdio>
+#include <cstring>
+#include <random>
+int main() {
+  std::mt19937_64 g(11);
+  long bad = 0;
+  for (int i = 0; i < 2000000; ++i) {
+    double a = std::ldexp(std::generate_canonical<double, 53>(g) + 0.5, (int)(g() % 60) - 30) * ((g() & 1) ? 1 : -1);
+    double b = std::ldexp(std::generate_canonical<double, 53>(g) + 0.5, (int)(g() % 60) - 30);
+    switch (i % 1000) {
+      case 0: a = std::ldexp(a, 520); break;
+      case 1: b = std::ldexp(b, -500); break;
+      case 2: a = b; break;
+      case 3: a = 0; break;
+      case 4: b = NAN; break;
+      case 5: a = INFINITY; b = NAN; break;
+      case 6: a = std::ldexp(a, -480); b = std::ldexp(b, -490); break;
+      case 7: a = std::ldexp(a, 530); b = std::ldexp(b, 525); break;
+    }
+    const double h = std::hypot(a, b), k = sfm_hypot(a, b);
+    if (std::memcmp(&h, &k, 8) != 0 && !(std::isnan(h) && std::isnan(k))) ++bad;
+  }
+  std::printf("%ld\n", bad);
+  return 0;
+}
+""")
+    exe = tmp_path / "h"
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "sfm_danpipeline_amd", "csrc"), "-o", str(exe), str(src)],
+                   check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    assert out.strip() == "0", out

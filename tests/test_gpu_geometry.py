@@ -442,7 +442,9 @@ def test_two_ranks_share_the_device_and_run_the_sharded_solver(ctx, tmp_path, mo
     assert int(r0["steps"]) == int(r1["steps"]) == s1.successful_steps
     assert abs(float(r0["cost"]) - s1.final_cost) <= 1e-9 * s1.final_cost and float(r0["cost"]) == float(r1["cost"])
     assert np.allclose(r0["c"], c1, rtol=1e-9, atol=1e-12) and abs(float(r0["f"]) - f1) <= 1e-9 * f1
-    assert np.allclose(r0["c"], r1["c"], rtol=1e-12, atol=1e-14)          # replicas stay together
+    # replicas are bitwise equal: after the all-reduce both ranks hold the same S and g, and nothing in the reduced
+    # solve sums in a run-dependent order (chol_apply_inverse is atomic-free since round 3)
+    assert np.array_equal(r0["c"], r1["c"]) and float(r0["f"]) == float(r1["f"])
     # (points: absolute tolerance -- coordinates near zero carry the f64 summation-order noise of the exchange)
     assert np.allclose(np.concatenate([r0["p"], r1["p"]]), p1, rtol=1e-8, atol=1e-9)
 

@@ -104,6 +104,20 @@ def test_non_integer_rows_use_the_exact_kernel(ctx, orc):
         _assert_pair(orc, pl, p, mixed[a], mixed[b], _lib.L2)
 
 
+@pytest.mark.parametrize("value", [300.0, -1.0, 256.0, 1e6])
+def test_integer_valued_rows_outside_the_sift_range_use_the_exact_kernel(ctx, orc, value):
+    """f32 rows that ARE integers but do not fit the centred-i8 operand (the range half of the device's guard): their
+    pairs go through the literal-f32 kernel and equal the oracle bit for bit"""
+    imgs = synth.sift_image_set(3, 200, 128, bank=300, seed=6)
+    bad = imgs[1].copy()
+    bad[17, 5] = value                                 # a single element out of 0..255
+    bad[150, :] = value if abs(value) < 1e5 else 255.0
+    mixed = [imgs[0], bad, imgs[2]]
+    s, pl = _plan(ctx, mixed, [[0, 1], [1, 2], [2, 0], [1, 0]])
+    for p, (a, b) in enumerate([(0, 1), (1, 2), (2, 0), (1, 0)]):
+        _assert_pair(orc, pl, p, mixed[a], mixed[b], _lib.L2)
+
+
 @pytest.mark.parametrize("dim", [32, 61, 64, 96, 200, 300])
 def test_other_descriptor_widths(ctx, orc, dim):
     rng = np.random.default_rng(dim)
@@ -268,3 +282,56 @@ def test_stage_timing_is_opt_in(ctx):
         ctx.set_timing(False)
         plan.close()
         iset.close()
+
+
+def test_pipelined_fetch_hands_out_the_same_lists(ctx, orc):
+    """sfmhip_matchplan_pipeline / _fetch_wait: a second stream packs every run's lists into one of two pinned host
+    buffers; the lists of the latest run and of the run before it equal the copying fetch's, run after run, also after
+    the plan is pointed at other pairs, and a run that outgrows the buffers says so instead of truncating"""
+    imgs = synth.sift_image_set(5, 300, 128, bank=420, seed=13)
+    pairs = synth.all_pairs(5)
+    s, pl = _plan(ctx, imgs, pairs)
+    want = {}
+    for ratio in (0.8, 0.6, 0.95):
+        pl.run_async(ratio)
+        want[ratio] = [a.copy() for a in pl.fetch()]
+    pl.pipeline()
+    prev = None
+    for ratio in (0.8, 0.6, 0.95, 0.6):
+        s.prepare_async()
+        pl.run_async(ratio)
+        got = pl.fetch_wait(0)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want[ratio])), ratio
+        assert got[3].view(np.uint32).tolist() == want[ratio][3].view(np.uint32).tolist()
+        if prev is not None:
+            before = pl.fetch_wait(1)
+            assert all(np.array_equal(a, b) for a, b in zip(before, want[prev])), (ratio, prev)
+        prev = ratio
+    # two runs in flight before the host looks: back = 1 is the older one
+    pl.run_async(0.8)
+    pl.run_async(0.95)
+    assert all(np.array_equal(a, b) for a, b in zip(pl.fetch_wait(1), want[0.8]))
+    assert all(np.array_equal(a, b) for a, b in zip(pl.fetch_wait(0), want[0.95]))
+    # re-targeted plan (fewer pairs), still pipelined
+    pl.set_pairs(pairs[3:6])
+    pl.run_async(0.8)
+    cnt, q, t, d = pl.fetch_wait(0)
+    off = 0
+    for p, (a, b) in enumerate(pairs[3:6]):
+        r = orc.match_knn2(imgs[a], imgs[b])
+        assert cnt[p] == len(r[0]) and np.array_equal(q[off:off + cnt[p]], r[0]) and np.array_equal(t[off:off + cnt[p]], r[1])
+        off += cnt[p]
+    # a buffer too small for the run: reported, the copying fetch still works, and a larger pipeline recovers
+    pl.set_pairs(pairs)
+    pl.pipeline(-1)
+    pl.pipeline(capacity=16)
+    pl.run_async(0.8)
+    with pytest.raises(_lib.SfmHipError):
+        pl.fetch_wait(0)
+    assert all(np.array_equal(a, b) for a, b in zip(pl.fetch(), want[0.8]))
+    pl.pipeline(capacity=int(want[0.8][0].sum()))
+    pl.run_async(0.8)
+    assert all(np.array_equal(a, b) for a, b in zip(pl.fetch_wait(0), want[0.8]))
+    pl.pipeline(-1)
+    with pytest.raises(_lib.SfmHipError):
+        pl.fetch_wait(0)

@@ -72,3 +72,27 @@ def test_non_integer_rows_keep_documented_order(orc):
     ref = np.sqrt(((q[:, None, :].astype(np.float64) - t[None, :, :]) ** 2).sum(-1))
     assert np.array_equal(r[3][:, 0], ref.argmin(1))
     assert np.allclose(r[4][:, 0], ref.min(1), rtol=1e-6)
+
+
+def test_blocked_baseline_matcher_gives_the_same_lists(orc):
+    """bench.py's CPU-baseline matcher (query blocks x train tiles, SIMD, per-thread merge) against the row-by-row
+    restatement: counts and per-pair checksums, ragged sizes around the block / tile / SIMD-group edges"""
+    imgs = synth.sift_image_set(5, 150, 128, bank=200, seed=7)
+    imgs = [imgs[0], imgs[1][:129], imgs[2][:65], imgs[3][:2], imgs[4][:1]]
+    pairs = np.array([[a, b] for a in range(5) for b in range(5) if a != b], np.int32)
+    c0, cs0 = orc.match_many_checksum(imgs, pairs, threads=1)
+    for threads in (1, 3):
+        c1, cs1 = orc.match_many_blocked(imgs, pairs, threads=threads)
+        assert np.array_equal(c0, c1) and np.array_equal(cs0, cs1)
+    assert c0.sum() > 50
+
+
+def test_product_side_checksum_helper_equals_the_checkers(orc):
+    """sfm_danpipeline_amd.synth.pair_checksums (what bench.py's cfg5 leg prints) against orc_match_mix in C"""
+    imgs = synth.sift_image_set(3, 120, 128, bank=150, seed=9)
+    pairs = np.array([[0, 1], [1, 2], [0, 2]], np.int32)
+    cnt, cs = orc.match_many_checksum(imgs, pairs)
+    lists = [orc.match_knn2(imgs[a], imgs[b]) for a, b in pairs]
+    q, t, d = (np.concatenate([l[k] for l in lists]) for k in range(3))
+    assert np.array_equal(synth.pair_checksums(cnt, q, t, d), cs)
+    assert np.array_equal(orc.pair_checksums(cnt, q, t, d), cs)
