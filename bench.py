@@ -53,6 +53,10 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs of cfg2 timed on the host cores")
     ap.add_argument("--cpu-ba-iters", type=int, default=8)
     ap.add_argument("--no-cfg5", action="store_true", help="skip the cfg5 strong-scaling leg")
+    ap.add_argument("--ba-batch", action="store_true",
+                    help="also at N = 1: the batch-mode BA leg (one independent cfg4 problem per rank, no collective); "
+                         "always on when N > 1 unless --no-ba-batch")
+    ap.add_argument("--no-ba-batch", action="store_true")
     ap.add_argument("--no-score", action="store_true", help="skip the findBestPair scoring leg (E-matrix RANSAC of 1225 pairs)")
     ap.add_argument("--lean", action="store_true",
                     help="timed regions and per-kernel samples only (no sustained / host-visible loops, no cfg5, no CPU "
@@ -205,7 +209,7 @@ def main():
         n_hv, t_hv = 0, 1.0
     else:
         plan.pipeline()
-        n_hv, t_hv = loop_for(1.0, match_and_fetch, 5)
+        n_hv, t_hv = loop_for(1.0, match_and_fetch, 50)
         c_, q_, t_, d_ = plan.fetch_wait(back=0)             # the last sweep's lists
         assert np.array_equal(c_, counts) and hv_seen[1] == hv_seen[0] - 1
         assert np.array_equal(synth.pair_checksums(c_, q_, t_, d_), synth.pair_checksums(*plan.fetch()))
@@ -248,6 +252,31 @@ def main():
         ba.iterate(100)
     barrier()
     sustained_ba_its = 100 * n_batches / (time.perf_counter() - t0)
+
+    # ------------------------------------------------------------------ BA in batch mode: one problem per rank
+    # The strong-scaled iteration above cannot scale (ba_amdahl: half of it is the replicated reduced solve).  What a
+    # node of N GPUs does scale is N independent problems -- one whole cfg4 problem per rank, no collective: the rate a
+    # reconstruction service sees.  Reported next to the strong-scaled figure, never instead of it.
+    ba_batch = None
+    if (world > 1 or args.ba_batch) and not args.no_ba_batch and not args.lean:
+        ba.close()
+        pb_r = synth.ba_problem(200, 100000, 10, seed=777 + rank) if world > 1 else pb      # rank r: its own problem
+        ba_b = bundle.BaProblem(200, len(pb_r["pts0"]), pb_r["obs_cam"], pb_r["obs_pt"], pb_r["obs_xy"], ctx=ctx)
+        ba_b.set_params(pb_r["cams0"], pb_r["pts0"], pb_r["focal0"])
+        ba_b.iterate(max(args.warmup, 1) + 20)
+        barrier()
+        t0 = time.perf_counter()
+        ba_b.iterate(args.steps)
+        barrier()
+        t_bb = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([t_bb], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_bb = float(tt[0])
+        ba_batch = {"workload": "one independent cfg4 problem (200 cams / 100k pts / 1M obs) per rank, no collective",
+                    "problems": world, "iterations_per_s_total": round(world * args.steps / t_bb, 2),
+                    "ms_per_iteration": round(1e3 * t_bb / args.steps, 4), "scaling": "weak"}
+        ba_b.close()
 
     # ------------------------------------------------------------------ cfg5, strong scaling over the ranks
     cfg5 = None
@@ -323,6 +352,35 @@ def main():
                      "cpu_restatement_pairs_per_s": round(1.0 / t_ck, 2), "cpu_sample": f"{n_ck} pairs, C restatement of OpenCV "
                      "3.4.1's route (Durand-Kerner solvePoly), 1 thread; counts and iteration numbers of the sample equal the "
                      "device's", "flags": scoring.last_flags(ctx), "parity": "unpinned (no OpenCV in the image)"}
+
+    # ------------------------------------------------------------------ SIFT front end, batched (rank 0)
+    sift_leg = None
+    if rank == 0 and not args.no_score:
+        from sfm_danpipeline_amd import features
+        frng = np.random.default_rng(99)
+        yy, xx = np.mgrid[0:480, 0:640]
+        frames = []
+        for _ in range(4):                                      # textured 640 x 480 frames: ~1.5 k keypoints each
+            img = np.zeros((480, 640))
+            for _b in range(900):
+                cx, cy, sg, am = frng.uniform(0, 640), frng.uniform(0, 480), frng.uniform(1.2, 5), frng.uniform(30, 160)
+                x0, x1, y0, y1 = int(max(cx - 4 * sg, 0)), int(min(cx + 4 * sg + 1, 640)), int(max(cy - 4 * sg, 0)), int(min(cy + 4 * sg + 1, 480))
+                img[y0:y1, x0:x1] += am * np.exp(-((xx[y0:y1, x0:x1] - cx) ** 2 + (yy[y0:y1, x0:x1] - cy) ** 2) / (2 * sg * sg))
+            frames.append(np.clip(img + frng.normal(0, 2.0, img.shape), 0, 255).astype(np.uint8))
+        frames = [frames[i % 4] for i in range(32)]
+        features.sift_batch(frames, ctx=ctx)                    # warm-up: worker contexts, scratch blocks
+        t0 = time.perf_counter()
+        outb = features.sift_batch(frames, ctx=ctx)
+        t_batch = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for fr in frames[:8]:
+            features.sift_detect_and_compute(fr, ctx=ctx)
+        t_one = (time.perf_counter() - t0) / 8
+        sift_leg = {"workload": "SIFT(0, 3, 0.04, 10, 1.6) detectAndCompute of 32 frames of 640 x 480 (synthetic texture), "
+                                "sfmhip_sift_batch: images in flight on 8 worker streams, descriptor rows left in HBM",
+                    "images": len(frames), "keypoints_mean": round(float(np.mean([len(k) for k, _ in outb])), 1),
+                    "images_per_s_batched": round(len(frames) / t_batch, 1), "images_per_s_one_at_a_time": round(1.0 / t_one, 1)}
+        del outb
 
     # max over ranks
     if world > 1:
@@ -402,7 +460,9 @@ def main():
         from oracle import orc   # the checker, timed as the reported host-CPU baseline ("port")
         orc.build()
         native = orc.use_native()               # -O3 -march=native, compiled on this host
-        cores = orc.physical_cores()            # threads = physical cores (SMT siblings share the FMA pipes)
+        # threads = physical cores (SMT siblings share the FMA pipes), capped by what the box's cgroup grants: more
+        # runnable threads than the CPU quota only get throttled
+        cores, host_cores, quota = orc.usable_cores(), orc.physical_cores(), orc.cpu_quota()
         # matcher: the cache-blocked, SIMD, atomics-free organisation of cv::batchDistance under parallel_for_
         # (orc_match_many_blocked); a bounded sample sized to ~4 s, three repetitions (min / max on the line); the
         # per-pair checksums of (queryIdx, trainIdx, distance bits) must equal those of the GPU lists
@@ -448,10 +508,10 @@ def main():
         cpu_step_ms = 1e3 * (len(pairs) / cpu_pairs_s + 1.0 / cpu_ba_its)
         cpu_baseline = {"value": round(cpu_pairs_s, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
                         "sample": f"first {npairs} of the 1225 cfg2 pairs, query-block-parallel / train-tiled / SIMD matcher on "
-                                  f"{cores} threads = physical cores (median of 3 runs, {cpu_match_s:.1f} s each), lists "
+                                  f"{cores} threads (host: {host_cores} physical cores, cgroup CPU quota {quota}; median of 3 runs, {cpu_match_s:.1f} s each), lists "
                                   f"checksum-equal to the GPU's; {args.cpu_ba_iters} LM iterations of cfg4 on 1 thread like "
                                   f"Ceres' default ({cpu_ba_s:.1f} s)",
-                        "march_native": bool(native), "logical_cpus": os.cpu_count(),
+                        "march_native": bool(native), "logical_cpus": os.cpu_count(), "physical_cores": host_cores, "cgroup_cpu_quota": quota,
                         "matcher_runs_pairs_per_s": {"min": round(npairs / max(reps), 3), "max": round(npairs / min(reps), 3)},
                         "matcher_1_thread_pairs_per_s": round(n1 / cpu_match1_s, 4),
                         "matcher_speedup_over_1_thread": round((npairs / cpu_match_s) / (n1 / cpu_match1_s), 1),
@@ -492,7 +552,7 @@ def main():
                                            "second stream packs sweep n into one of two pinned buffers while sweep n+1 runs "
                                            "(sfmhip_matchplan_pipeline / _fetch_wait); stop_and_copy = sfmhip_matchplan_fetch "
                                            "after every sweep"},
-            "cfg5_strong": cfg5, "find_best_pair_scoring": score_leg,
+            "cfg5_strong": cfg5, "find_best_pair_scoring": score_leg, "sift_front_end": sift_leg, "ba_batch": ba_batch,
             "ba_amdahl": {"sharded_ms": round(1e3 * (ba_t["eliminate_s"] + ba_t["backsub_s"]) / args.steps, 4),
                           "replicated_ms": round(1e3 * ba_t["solve_s"] / args.steps, 4),
                           "allreduce_ms": round(1e3 * ba_t["allreduce_s"] / args.steps, 4),

@@ -171,6 +171,24 @@ int sfmhip_merge_new_points(sfmhip_ctx* ctx, const double* cloud_xyz, int n_clou
 int sfmhip_sift_detect_and_compute(sfmhip_ctx* ctx, const uint8_t* gray, int rows, int cols, int n_octave_layers,
                                    double contrast_threshold, double edge_threshold, double sigma, int capacity,
                                    float* keypoints, float* descriptors, int32_t* n_keypoints);
+/* The same with the descriptors LEFT IN HBM: *d_descriptors receives a device array of n_keypoints x 128 f32 rows that
+ * the caller owns (sfmhip_device_free) and can hand to sfmhip_imageset_adopt_device -- the reference keeps keypoints and
+ * descriptors of an image in one container (src/Sfm.cpp:326) and matches them right away; here the rows never leave the
+ * device between extraction and matching.  keypoints: host, capacity x 6 floats as above (capacity 0: count only). */
+int sfmhip_sift_detect_and_compute_device(sfmhip_ctx* ctx, const uint8_t* gray, int rows, int cols, int n_octave_layers,
+                                          double contrast_threshold, double edge_threshold, double sigma, int capacity,
+                                          float* keypoints, void** d_descriptors, int32_t* n_keypoints);
+/* extractFeature's loop (reference src/Sfm.cpp:283-290) as one call: n_images gray images, several in flight on worker
+ * streams of the context (an image's front end is ~100 small launches and two read-backs: latency the next image hides).
+ * keypoints[i]: a host array of n_keypoints[i] x 6 floats allocated by the library (sfmhip_host_free); d_descriptors[i]: a
+ * device array of n_keypoints[i] x 128 f32 (sfmhip_device_free).  Image by image the results of the one-image entry. */
+int sfmhip_sift_batch(sfmhip_ctx* ctx, int n_images, const uint8_t* const* gray, const int32_t* rows, const int32_t* cols,
+                      int n_octave_layers, double contrast_threshold, double edge_threshold, double sigma, float** keypoints,
+                      void** d_descriptors, int32_t* n_keypoints);
+void sfmhip_device_free(void* device_ptr);
+void sfmhip_host_free(void* host_ptr);
+/* device -> host copy of bytes the library left in HBM (e.g. descriptor rows), on the context's stream, synchronous */
+int sfmhip_device_download(sfmhip_ctx* ctx, void* host_dst, const void* device_src, size_t bytes);
 
 /* ---- the scoring half of findBestPair (reference src/Sfm.cpp:536-563) ----
  * For every pair of a batch the inlier count of

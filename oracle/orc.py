@@ -230,6 +230,38 @@ def physical_cores():
     return os.cpu_count() or 1
 
 
+def cpu_quota():
+    """CPUs' worth of time the cgroup grants this process (cpu.max / cfs quota), or None when unlimited"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return q / per
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def usable_cores():
+    """threads a CPU-baseline leg should run: physical cores, capped by the affinity mask and the cgroup's CPU quota
+    (more runnable threads than the quota only get throttled)"""
+    n = physical_cores()
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    q = cpu_quota()
+    if q is not None:
+        n = min(n, max(1, int(q)))
+    return max(1, n)
+
+
 def match_mix(q, t, dist):
     """The per-match value of the pair checksums (orc_match_mix), vectorised; the same function as the product-side
     helper sfm_danpipeline_amd.synth.match_mix, kept apart on purpose (tests compare the two)."""

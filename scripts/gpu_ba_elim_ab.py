@@ -6,13 +6,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from sfm_danpipeline_amd import synth, bundle, _lib
 
-variants = sys.argv[1:] or ["", "8,500", "4,250", "2,100", "4,168", "2,125"]
+# a variant: "" (default), "waves,points" (SFMHIP_BA_ELIM), optionally prefixed "f0:" (SFMHIP_BA_ELIM_FILL=0: the plain cut)
+variants = sys.argv[1:] or ["", "f0:", "8,500", "4,250", "2,100", "4,168", "2,125"]
 ctx = _lib.default_context()
 pb = synth.ba_problem(200, 100000, 10, seed=777)
 probs = {}
 for v in variants:
-    if v:
-        os.environ["SFMHIP_BA_ELIM"] = v
+    fill0, shape = v.startswith("f0:"), v[3:] if v.startswith("f0:") else v
+    os.environ["SFMHIP_BA_ELIM_FILL"] = "0" if fill0 else "1"
+    if shape:
+        os.environ["SFMHIP_BA_ELIM"] = shape
     else:
         os.environ.pop("SFMHIP_BA_ELIM", None)
     probs[v] = bundle.BaProblem(200, 100000, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)

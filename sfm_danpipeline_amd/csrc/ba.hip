@@ -2728,6 +2728,39 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
       }
     }
   }
+  // One round of workgroups: when the runs cut at `target` leave resident slots empty (cfg4: 400 workgroups on 512
+  // slots, so 112 CUs hold one workgroup and idle half the launch while 144 hold two), the largest pieces are cut
+  // once more until the slots are full, and the launch lists the large pieces first: the dispatcher deals the first
+  // n_cu workgroups one per CU, so every CU ends up with a large and a small piece or two small ones.  The busiest
+  // SIMD then has 250 + 167 points instead of 500 (SFMHIP_BA_ELIM_FILL=0: the plain cut).
+  const int slots = 2 * std::max(b->ctx->n_cu, 1);
+  const bool fill_env = !(getenv("SFMHIP_BA_ELIM_FILL") && atoi(getenv("SFMHIP_BA_ELIM_FILL")) == 0);
+  std::vector<int> parts_of(gstart.size(), 0);
+  {
+    long long w = 0;
+    for (size_t gi = 0; gi + 1 < gstart.size(); ++gi) {
+      const int g = gstart[gi + 1] - gstart[gi];
+      if (g > SHORT_RUN) w += (parts_of[gi] = (g + target - 1) / target);
+    }
+    if (fill_env && w > slots / 2 && w < slots) {
+      // (a max-heap on the current piece size; a piece of fewer than 64 points is not worth another workgroup)
+      std::vector<std::pair<double, size_t>> heap;
+      for (size_t gi = 0; gi + 1 < gstart.size(); ++gi)
+        if (parts_of[gi]) heap.push_back({(double)(gstart[gi + 1] - gstart[gi]) / parts_of[gi], gi});
+      std::make_heap(heap.begin(), heap.end());
+      while (w < slots && !heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end());
+        const size_t gi = heap.back().second;
+        heap.pop_back();
+        const int g = gstart[gi + 1] - gstart[gi];
+        if (g / (parts_of[gi] + 1) < 64) continue;
+        ++parts_of[gi];
+        ++w;
+        heap.push_back({(double)g / parts_of[gi], gi});
+        std::push_heap(heap.begin(), heap.end());
+      }
+    }
+  }
   for (size_t gi = 0; gi + 1 < gstart.size(); ++gi) {
     const int sp = gstart[gi], e = gstart[gi + 1];
     const int n = optr[sp + 1] - optr[sp];
@@ -2741,7 +2774,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
         sig_cams.resize(so);  // (a camera list shared by few points: the pair path, per-pair instead of per-run sums)
         for (int q = sp; q < e; ++q) fb.push_back(q);
       } else {
-        const int parts = (e - sp + target - 1) / target;
+        const int parts = parts_of[gi];
         for (int q = 0; q < parts; ++q) {
           const int lo = sp + (int)((long long)(e - sp) * q / parts), hi = sp + (int)((long long)(e - sp) * (q + 1) / parts);
           ids[nb - 1].push_back((int)chunks.size());
@@ -2752,6 +2785,9 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
       for (int q = sp; q < e; ++q) fb.push_back(q);
     }
   }
+  if (fill_env)
+    for (auto& l : ids)  // large pieces first (stable: equal sizes keep the point order)
+      std::stable_sort(l.begin(), l.end(), [&](int a, int c) { return chunks[a].cnt > chunks[c].cnt; });
   lap_("chunks");
   // ---- camera co-visibility (one bit row per camera) for the dissection of the reduced system
   if (n_cam >= 64 && n_cam <= 4096) {

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <vector>
 #include "../../include/sfmhip.h"
 
 extern thread_local int g_sfmhip_last_hip_error;
@@ -37,6 +38,9 @@ struct sfmhip_ctx {
   // two grow-only device blocks for entry points that would otherwise hipMalloc / hipFree per call (sift.hip)
   void* dev_scratch[2] = {nullptr, nullptr};
   size_t dev_scratch_bytes[2] = {0, 0};
+  // worker contexts (own stream + scratch) of the batched entry points (sfmhip_sift_batch): created on demand, freed
+  // with the context
+  std::vector<sfmhip_ctx*> workers;
   int score_flags = 0;  // OR of the five-point samples' flags of the last sfmhip_score_essential call (score.hip)
 };
 

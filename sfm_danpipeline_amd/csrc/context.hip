@@ -55,8 +55,25 @@ extern "C" int sfmhip_init_on_stream(int device, void* hip_stream, sfmhip_ctx** 
   return init_common(device, (hipStream_t)hip_stream, false, out);
 }
 
+extern "C" void sfmhip_device_free(void* device_ptr) {
+  if (device_ptr) hipFree(device_ptr);
+}
+
+extern "C" void sfmhip_host_free(void* host_ptr) { free(host_ptr); }
+
+extern "C" int sfmhip_device_download(sfmhip_ctx* ctx, void* host_dst, const void* device_src, size_t bytes) {
+  if (!ctx || (bytes && (!host_dst || !device_src))) return SFMHIP_ERR_ARG;
+  if (!bytes) return SFMHIP_OK;
+  SFM_HIP_TRY(hipSetDevice(ctx->device));
+  SFM_HIP_TRY(hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return SFMHIP_OK;
+}
+
 extern "C" void sfmhip_shutdown(sfmhip_ctx* ctx) {
   if (!ctx) return;
+  for (sfmhip_ctx* w : ctx->workers) sfmhip_shutdown(w);
+  ctx->workers.clear();
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   if (ctx->pinned) hipHostFree(ctx->pinned);

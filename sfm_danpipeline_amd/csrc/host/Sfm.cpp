@@ -44,8 +44,7 @@ void StructFromMotion::getMatching(const int& idx_query, const int& idx_train, M
       for (const cv::Mat& d : imagesDescriptors) rows.push_back(d.rows);
       rc = sfmhip_imageset_create(ctx, (int)rows.size(), rows.data(), q.cols, q.type() == CV_32F ? SFMHIP_F32 : SFMHIP_U8,
                                   SFMHIP_L2, &devSet);
-      for (size_t i = 0; rc == SFMHIP_OK && i < rows.size(); ++i)
-        if (rows[i] > 0) rc = sfmhip_imageset_upload(devSet, (int)i, imagesDescriptors[i].ptr());
+      for (size_t i = 0; rc == SFMHIP_OK && i < rows.size(); ++i) rc = uploadOrAdopt(devSet, (int)i);
       if (rc == SFMHIP_OK) rc = sfmhip_imageset_prepare_async(devSet);
       const int32_t first[2] = {idx_query, idx_train};
       if (rc == SFMHIP_OK) rc = sfmhip_matchplan_create(devSet, first, 1, &devPlan);
@@ -57,6 +56,7 @@ void StructFromMotion::getMatching(const int& idx_query, const int& idx_train, M
     if (rc == SFMHIP_OK) rc = sfmhip_matchplan_fetch(devPlan, &n, oq.data(), ot.data(), od.data(), q.rows, &tot);
     if (rc != SFMHIP_OK) releaseDeviceSet();
   } else {
+    descriptors();  // (host rows wanted: download what lives in HBM only)
     rc = sfmhip_match_knn2(sfm_hip_context(), q.ptr(), q.rows, t.ptr(), t.rows, q.cols,
                            q.type() == CV_32F ? SFMHIP_F32 : SFMHIP_U8, SFMHIP_L2, NN_MATCH_RATIO, oq.data(), ot.data(),
                            od.data(), &n);
@@ -66,6 +66,30 @@ void StructFromMotion::getMatching(const int& idx_query, const int& idx_train, M
     return;
   }
   for (int i = 0; i < n; ++i) goodMatches->push_back(cv::DMatch(oq[i], ot[i], od[i]));  // appends
+}
+
+void StructFromMotion::releaseDeviceDescriptors() {
+  for (void* p : devDescriptors) sfmhip_device_free(p);
+  devDescriptors.clear();
+}
+
+// descriptor rows of one image into an image set: in place when extractFeature left them in HBM, else one upload
+int StructFromMotion::uploadOrAdopt(sfmhip_imageset* set, int image) {
+  if (imagesDescriptors[image].rows == 0) return SFMHIP_OK;
+  if ((size_t)image < devDescriptors.size() && devDescriptors[image]) return sfmhip_imageset_adopt_device(set, image, devDescriptors[image]);
+  return sfmhip_imageset_upload(set, image, imagesDescriptors[image].ptr());
+}
+
+const std::vector<cv::Mat>& StructFromMotion::descriptors() {
+  for (size_t i = 0; i < imagesDescriptors.size(); ++i) {
+    cv::Mat& m = imagesDescriptors[i];
+    if (m.rows > 0 && m.bytes.empty() && i < devDescriptors.size() && devDescriptors[i]) {
+      m.bytes.resize((size_t)m.rows * m.cols * m.elemSize());
+      const int rc = sfmhip_device_download(sfm_hip_context(), m.bytes.data(), devDescriptors[i], m.bytes.size());
+      if (rc != SFMHIP_OK) std::cerr << "descriptors: " << sfmhip_error_string(rc) << std::endl;
+    }
+  }
+  return imagesDescriptors;
 }
 
 void StructFromMotion::releaseDeviceSet() {
@@ -229,8 +253,7 @@ void StructFromMotion::matchAllPairs() {
   sfmhip_ctx* ctx = sfm_hip_context();
   sfmhip_imageset* set = nullptr;
   int rc = sfmhip_imageset_create(ctx, n, rows.data(), d0.cols, d0.type() == CV_32F ? SFMHIP_F32 : SFMHIP_U8, SFMHIP_L2, &set);
-  for (int i = 0; rc == SFMHIP_OK && i < n; ++i)
-    if (rows[i] > 0) rc = sfmhip_imageset_upload(set, i, imagesDescriptors[i].ptr());
+  for (int i = 0; rc == SFMHIP_OK && i < n; ++i) rc = uploadOrAdopt(set, i);
   if (rc == SFMHIP_OK) rc = sfmhip_imageset_prepare_async(set);
   // The pair list goes to the device in batches, two plans taking turns: while the device sweeps batch b, the lists of
   // batch b-1 -- packed into pinned host memory by the plans' second stream (sfmhip_matchplan_pipeline) -- become the

@@ -35,12 +35,20 @@ class StructFromMotion {
   sfmhip_imageset* devSet;
   sfmhip_matchplan* devPlan;
   void releaseDeviceSet();
+  // descriptor rows that extractFeature left in HBM (sfmhip_sift_batch), image by image (nullptr: host rows only).
+  // The matcher adopts them in place; imagesDescriptors[i] then carries the shape only until descriptors() is asked.
+  std::vector<void*> devDescriptors;
+  void releaseDeviceDescriptors();
+  int uploadOrAdopt(sfmhip_imageset* set, int image);
 
  public:
   std::vector<Point3D> nReconstructionCloud;
 
   StructFromMotion() : NN_MATCH_RATIO(0.8f), detector(1), pairCacheOn(false), devSet(nullptr), devPlan(nullptr) {}
-  ~StructFromMotion() { releaseDeviceSet(); }
+  ~StructFromMotion() {
+    releaseDeviceSet();
+    releaseDeviceDescriptors();
+  }
   StructFromMotion(const StructFromMotion&) = delete;
   StructFromMotion& operator=(const StructFromMotion&) = delete;
 
@@ -86,8 +94,10 @@ class StructFromMotion {
   void getFeature(const cv::Mat& image, const int& numImage);
   // reference include/Sfm.h:95, src/Sfm.cpp:397-403
   void keypointstoPoints(std::vector<cv::KeyPoint>& keypoints, Points2d& points2D);
+  void setKeypoints(int numImage, const float* kp, int n);
   const std::vector<std::vector<cv::KeyPoint>>& keypoints() const { return imagesKeypoints; }
-  const std::vector<cv::Mat>& descriptors() const { return imagesDescriptors; }
+  // (downloads the rows of images whose descriptors live in HBM only)
+  const std::vector<cv::Mat>& descriptors();
   const std::vector<std::vector<cv::Point2d>>& points2D() const { return imagesPts2D; }
 
   // ---- I/O and interchange formats (csrc/host/SfmIO.cpp)
@@ -117,6 +127,7 @@ class StructFromMotion {
   void setDescriptors(const std::vector<cv::Mat>& d) {
     imagesDescriptors = d;
     releaseDeviceSet();
+    releaseDeviceDescriptors();
     clearPairCache();
   }
   void setPoints2D(const std::vector<std::vector<cv::Point2d>>& p) { imagesPts2D = p; }

@@ -391,12 +391,68 @@ void StructFromMotion::extractFeature() {
               << "Parameters:" << "\n" << "nFeatures = 0\n" << "nOctaveLayers = 3\n" << "contrastThreshold = 0.04\n"
               << "edgeThreshold = 10\n" << "sigma = 1.6" << std::endl;
   std::cout << "*-- Features --*" << std::endl;
-  for (size_t n = 0; n < mGrayImages.size(); n++) {
+  releaseDeviceDescriptors();
+  bool batched = false;
+  if (detector == 1 && !mGrayImages.empty()) {
+    // the loop of :283-290 as ONE call: the images go through the device front end several at a time, and the descriptor
+    // rows stay in HBM, where the matcher adopts them (no download / upload between extraction and matching)
+    const int n = (int)mGrayImages.size();
+    std::vector<const uint8_t*> ptrs(n);
+    std::vector<int32_t> rows(n), cols(n), nk(n, 0);
+    std::vector<float*> kp(n, nullptr);
+    std::vector<void*> dd(n, nullptr);
+    bool ok = true;
+    for (int i = 0; i < n; ++i) {
+      const cv::Mat& g = mGrayImages[i];
+      ok = ok && g.channels() == 1 && g.depth == CV_8U && !g.empty();
+      ptrs[i] = g.ptr();
+      rows[i] = g.rows;
+      cols[i] = g.cols;
+    }
+    const int rc = ok ? sfmhip_sift_batch(sfm_hip_context(), n, ptrs.data(), rows.data(), cols.data(), 3, 0.04, 10, 1.6, kp.data(),
+                                          dd.data(), nk.data())
+                      : SFMHIP_ERR_ARG;
+    if (rc == SFMHIP_OK) {
+      batched = true;
+      devDescriptors = dd;
+      for (int i = 0; i < n; ++i) {
+        setKeypoints(i, kp[i], nk[i]);
+        imagesDescriptors[i] = cv::Mat();  // the shape only: the rows are in HBM until descriptors() is asked
+        imagesDescriptors[i].rows = nk[i];
+        imagesDescriptors[i].cols = 128;
+        imagesDescriptors[i].depth = CV_32F;
+        sfmhip_host_free(kp[i]);
+        std::cout << "Image:" << i << " --> " << imagesKeypoints.at(i).size() << " kps" << std::endl;
+      }
+    } else if (ok) {
+      std::cerr << "extractFeature: " << sfmhip_error_string(rc) << std::endl;
+    }
+  }
+  for (size_t n = 0; !batched && n < mGrayImages.size(); n++) {
     getFeature(mGrayImages.at(n), (int)n);
     std::cout << "Image:" << n << " --> " << imagesKeypoints.at(n).size() << " kps" << std::endl;
   }
   releaseDeviceSet();  // (new descriptors: what the matcher holds on the device is stale)
   clearPairCache();
+}
+
+// keypoint records of the C ABI (x, y, size, angle, response, octave bits) -> imagesKeypoints / imagesPts2D
+void StructFromMotion::setKeypoints(int numImage, const float* kp, int n) {
+  std::vector<cv::KeyPoint> kps((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    cv::KeyPoint& k = kps[i];
+    k.pt.x = kp[6 * i];
+    k.pt.y = kp[6 * i + 1];
+    k.size = kp[6 * i + 2];
+    k.angle = kp[6 * i + 3];
+    k.response = kp[6 * i + 4];
+    std::memcpy(&k.octave, &kp[6 * i + 5], 4);
+    k.class_id = -1;
+  }
+  std::vector<cv::Point2d> points2d;
+  keypointstoPoints(kps, points2d);
+  imagesKeypoints[numImage] = kps;
+  imagesPts2D[numImage] = points2d;
 }
 
 // reference src/Sfm.cpp:300-403
@@ -424,22 +480,12 @@ void StructFromMotion::getFeature(const cv::Mat& image, const int& numImage) {
     std::cerr << "getFeature: " << sfmhip_error_string(rc) << std::endl;
     return;
   }
-  std::vector<cv::KeyPoint> kps((size_t)n);
-  for (int i = 0; i < n; ++i) {
-    cv::KeyPoint& k = kps[i];
-    k.pt.x = kp[6 * i];
-    k.pt.y = kp[6 * i + 1];
-    k.size = kp[6 * i + 2];
-    k.angle = kp[6 * i + 3];
-    k.response = kp[6 * i + 4];
-    std::memcpy(&k.octave, &kp[6 * i + 5], 4);
-    k.class_id = -1;
+  setKeypoints(numImage, kp.data(), n);
+  if ((size_t)numImage < devDescriptors.size() && devDescriptors[numImage]) {  // (a device copy of older rows)
+    sfmhip_device_free(devDescriptors[numImage]);
+    devDescriptors[numImage] = nullptr;
   }
-  std::vector<cv::Point2d> points2d;
-  keypointstoPoints(kps, points2d);
-  imagesKeypoints[numImage] = kps;
   imagesDescriptors[numImage] = cv::Mat(n, 128, CV_32F, n ? desc.data() : nullptr);
-  imagesPts2D[numImage] = points2d;
 }
 
 // reference src/Sfm.cpp:397-403

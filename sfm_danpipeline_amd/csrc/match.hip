@@ -1629,15 +1629,17 @@ __global__ __launch_bounds__(256) void pack_lists_kernel(const int* __restrict__
                                                          int n_pairs, int maxq, const int* __restrict__ out_q,
                                                          const int* __restrict__ out_t, const float* __restrict__ out_d,
                                                          int* __restrict__ packed, long long capacity = -1) {
-  const int p = blockIdx.x;
-  const int n = counts[p];
-  const long long o = offsets[p], tot = offsets[n_pairs];
+  const long long tot = offsets[n_pairs];
   if (capacity >= 0 && tot > capacity) return;  // (the host sees total > capacity and reports it)
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const size_t src = (size_t)p * maxq + i;
-    packed[o + i] = out_q[src];
-    packed[tot + o + i] = out_t[src];
-    packed[2 * tot + o + i] = __float_as_int(out_d[src]);
+  for (int p = blockIdx.x; p < n_pairs; p += gridDim.x) {  // (the pipelined fetch launches few workgroups: they share the device with a sweep)
+    const int n = counts[p];
+    const long long o = offsets[p];
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const size_t src = (size_t)p * maxq + i;
+      packed[o + i] = out_q[src];
+      packed[tot + o + i] = out_t[src];
+      packed[2 * tot + o + i] = __float_as_int(out_d[src]);
+    }
   }
 }
 
@@ -2091,8 +2093,9 @@ extern "C" int sfmhip_matchplan_run_async(sfmhip_matchplan* pl, float ratio) {
     int* h_rec = h_counts + pl->cap_pairs;
     if (pl->n_pairs > 0) {
       hipLaunchKernelGGL(pack_offsets_kernel, dim3(1), dim3(1024), 0, pl->pipe_st, pl->d_counts, pl->n_pairs, pl->d_offsets, h_counts, h_hdr);
-      hipLaunchKernelGGL(pack_lists_kernel, dim3(pl->n_pairs), dim3(256), 0, pl->pipe_st, pl->d_counts, pl->d_offsets, pl->n_pairs,
-                         pl->maxq, pl->d_out_q, pl->d_out_t, pl->d_out_d, h_rec, pl->pipe_capacity);
+      static const int pipe_wgs = getenv("SFMHIP_PIPE_WGS") ? atoi(getenv("SFMHIP_PIPE_WGS")) : 8;  // (8 workgroups: 0.977 of the device-only sweep rate; 64 or more: 0.91 -- scripts/gpu_hostvisible_ab.py)
+      hipLaunchKernelGGL(pack_lists_kernel, dim3(std::max(1, std::min(pl->n_pairs, pipe_wgs))), dim3(256), 0, pl->pipe_st, pl->d_counts,
+                         pl->d_offsets, pl->n_pairs, pl->maxq, pl->d_out_q, pl->d_out_t, pl->d_out_d, h_rec, pl->pipe_capacity);
       SFM_HIP_TRY(hipGetLastError());
     } else {
       ((long long*)pl->h_pipe[slot])[0] = 0;

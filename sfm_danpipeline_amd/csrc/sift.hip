@@ -15,6 +15,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -464,12 +465,13 @@ static std::vector<float> gaussian_kernel(double sigma) {
 
 }  // namespace
 
-extern "C" int sfmhip_sift_detect_and_compute(sfmhip_ctx* ctx, const uint8_t* gray, int rows, int cols, int n_octave_layers,
-                                              double contrast_threshold, double edge_threshold, double sigma, int capacity,
-                                              float* keypoints, float* descriptors, int32_t* n_keypoints) {
-  if (!ctx || !gray || rows < 2 || cols < 2 || n_octave_layers < 1 || n_octave_layers > 8 || !(sigma > 0) || capacity < 0 ||
-      !n_keypoints || (capacity > 0 && (!keypoints || !descriptors)))
-    return SFMHIP_ERR_ARG;
+// One image through the whole front end on ctx's stream and scratch blocks.  Keypoints (sorted, de-duplicated, rescaled)
+// come back in kps; the descriptors go to host memory (descriptors, at most `capacity` rows: SFMHIP_ERR_ARG with the
+// count in *n_keypoints when there are more; capacity 0 = a count-only call) and / or stay in HBM (*d_desc_out: a
+// hipMalloc'ed n x 128 f32 array the caller owns; no limit).
+static int sift_impl(sfmhip_ctx* ctx, const uint8_t* gray, int rows, int cols, int n_octave_layers, double contrast_threshold,
+                     double edge_threshold, double sigma, int capacity, std::vector<KeyPt>& kps, float* descriptors,
+                     void** d_desc_out, int32_t* n_keypoints) {
   SFM_HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int nl = n_octave_layers;
@@ -609,7 +611,7 @@ extern "C" int sfmhip_sift_detect_and_compute(sfmhip_ctx* ctx, const uint8_t* gr
     SFM_HIP_TRY(hipMemsetAsync(d_cnt + 1, 0, sizeof(int), st));
   }
   int nk = h_cnt[1];
-  std::vector<KeyPt> kps(nk);
+  kps.assign((size_t)nk, KeyPt{});
   if (nk) SFM_HIP_TRY(hipMemcpy(kps.data(), d_kp, sizeof(KeyPt) * nk, hipMemcpyDeviceToHost));
   // ---- KeyPointsFilter::removeDuplicatedSorted, then the rescale of the doubled first octave
   std::sort(kps.begin(), kps.end(), [](const KeyPt& a, const KeyPt& b) {
@@ -634,26 +636,38 @@ extern "C" int sfmhip_sift_detect_and_compute(sfmhip_ctx* ctx, const uint8_t* gr
     k.size *= 0.5f;
   }
   *n_keypoints = nk;
-  if (nk > capacity) return capacity == 0 ? SFMHIP_OK : SFMHIP_ERR_ARG;  // (capacity 0: a count-only call)
+  if (d_desc_out) *d_desc_out = nullptr;
+  if (descriptors || !d_desc_out)
+    if (nk > capacity) return capacity == 0 ? SFMHIP_OK : SFMHIP_ERR_ARG;  // (capacity 0: a count-only call)
   if (nk == 0) return SFMHIP_OK;
   float* d_desc = nullptr;
   {
     // (block 1 again, now that the number of keypoints is known: the device copy of the unsorted keypoints is done
     // with -- the stream is idle -- and a growing call may move the block)
     size_t off = 0;
-    const size_t o_kp = carve(off, sizeof(KeyPt) * nk), o_desc = carve(off, sizeof(float) * 128 * (size_t)nk);
+    const size_t o_kp = carve(off, sizeof(KeyPt) * nk), o_desc = carve(off, d_desc_out ? 0 : sizeof(float) * 128 * (size_t)nk);
     char* base = nullptr;
     SFM_TRY(sfm_ctx_dev_scratch(ctx, 1, off, (void**)&base));
     d_kp = (KeyPt*)(base + o_kp);
     d_desc = (float*)(base + o_desc);
   }
+  if (d_desc_out) {  // the descriptors stay in HBM, in a buffer of their own that the caller hands to the matcher
+    void* own = nullptr;
+    if (hipMalloc(&own, sizeof(float) * 128 * (size_t)nk) != hipSuccess) return SFMHIP_ERR_ALLOC;
+    d_desc = (float*)own;
+    *d_desc_out = own;
+  }
   SFM_HIP_TRY(hipMemcpyAsync(d_kp, kps.data(), sizeof(KeyPt) * nk, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(sift_describe, dim3((nk + DESC_WAVES - 1) / DESC_WAVES), dim3(64 * DESC_WAVES), 0, st, P, (const float*)G, (const KeyPt*)d_kp, nk, d_desc);
   SFM_HIP_TRY(hipGetLastError());
-  SFM_HIP_TRY(hipMemcpyAsync(descriptors, d_desc, sizeof(float) * 128 * (size_t)nk, hipMemcpyDeviceToHost, st));
+  if (descriptors) SFM_HIP_TRY(hipMemcpyAsync(descriptors, d_desc, sizeof(float) * 128 * (size_t)nk, hipMemcpyDeviceToHost, st));
   SFM_HIP_TRY(hipStreamSynchronize(st));
-  for (int i = 0; i < nk; ++i) {
-    float* o = keypoints + 6 * (size_t)i;
+  return SFMHIP_OK;
+}
+
+static void sift_pack_keypoints(const std::vector<KeyPt>& kps, float* keypoints) {
+  for (size_t i = 0; i < kps.size(); ++i) {
+    float* o = keypoints + 6 * i;
     o[0] = kps[i].x;
     o[1] = kps[i].y;
     o[2] = kps[i].size;
@@ -661,5 +675,101 @@ extern "C" int sfmhip_sift_detect_and_compute(sfmhip_ctx* ctx, const uint8_t* gr
     o[4] = kps[i].response;
     std::memcpy(&o[5], &kps[i].octave, 4);
   }
+}
+
+static bool sift_args_ok(sfmhip_ctx* ctx, const uint8_t* gray, int rows, int cols, int nl, double sigma) {
+  return ctx && gray && rows >= 2 && cols >= 2 && nl >= 1 && nl <= 8 && sigma > 0;
+}
+
+extern "C" int sfmhip_sift_detect_and_compute(sfmhip_ctx* ctx, const uint8_t* gray, int rows, int cols, int n_octave_layers,
+                                              double contrast_threshold, double edge_threshold, double sigma, int capacity,
+                                              float* keypoints, float* descriptors, int32_t* n_keypoints) {
+  if (!sift_args_ok(ctx, gray, rows, cols, n_octave_layers, sigma) || capacity < 0 || !n_keypoints ||
+      (capacity > 0 && (!keypoints || !descriptors)))
+    return SFMHIP_ERR_ARG;
+  std::vector<KeyPt> kps;
+  SFM_TRY(sift_impl(ctx, gray, rows, cols, n_octave_layers, contrast_threshold, edge_threshold, sigma, capacity, kps,
+                    capacity > 0 ? descriptors : nullptr, nullptr, n_keypoints));
+  if (capacity > 0 && *n_keypoints <= capacity) sift_pack_keypoints(kps, keypoints);
+  return SFMHIP_OK;
+}
+
+extern "C" int sfmhip_sift_detect_and_compute_device(sfmhip_ctx* ctx, const uint8_t* gray, int rows, int cols, int n_octave_layers,
+                                                     double contrast_threshold, double edge_threshold, double sigma, int capacity,
+                                                     float* keypoints, void** d_descriptors, int32_t* n_keypoints) {
+  if (!sift_args_ok(ctx, gray, rows, cols, n_octave_layers, sigma) || capacity < 0 || !n_keypoints || !d_descriptors ||
+      (capacity > 0 && !keypoints))
+    return SFMHIP_ERR_ARG;
+  std::vector<KeyPt> kps;
+  *d_descriptors = nullptr;
+  SFM_TRY(sift_impl(ctx, gray, rows, cols, n_octave_layers, contrast_threshold, edge_threshold, sigma, capacity, kps, nullptr,
+                    capacity > 0 ? d_descriptors : nullptr, n_keypoints));
+  if (*n_keypoints > capacity) {  // the keypoint array is the caller's: too small -> nothing is kept
+    if (*d_descriptors) hipFree(*d_descriptors);
+    *d_descriptors = nullptr;
+    return capacity == 0 ? SFMHIP_OK : SFMHIP_ERR_ARG;
+  }
+  sift_pack_keypoints(kps, keypoints);
+  return SFMHIP_OK;
+}
+
+// A batch of images, several in flight: the front end of one image is ~100 small launches and two host read-backs --
+// latency, not throughput -- so the images are dealt to a few worker contexts (a stream and scratch blocks each, kept by
+// ctx between calls), one host thread per worker.  Results are those of the one-image entry, image by image.
+extern "C" int sfmhip_sift_batch(sfmhip_ctx* ctx, int n_images, const uint8_t* const* gray, const int32_t* rows, const int32_t* cols,
+                                 int n_octave_layers, double contrast_threshold, double edge_threshold, double sigma,
+                                 float** keypoints, void** d_descriptors, int32_t* n_keypoints) {
+  if (!ctx || n_images < 0 || (n_images && (!gray || !rows || !cols || !keypoints || !d_descriptors || !n_keypoints))) return SFMHIP_ERR_ARG;
+  for (int i = 0; i < n_images; ++i) {
+    if (!sift_args_ok(ctx, gray[i], rows[i], cols[i], n_octave_layers, sigma)) return SFMHIP_ERR_ARG;
+    keypoints[i] = nullptr;
+    d_descriptors[i] = nullptr;
+    n_keypoints[i] = 0;
+  }
+  if (n_images == 0) return SFMHIP_OK;
+  const int n_workers = std::min(n_images, 8);
+  while ((int)ctx->workers.size() < n_workers) {
+    sfmhip_ctx* w = nullptr;
+    SFM_TRY(sfmhip_init(ctx->device, &w));
+    ctx->workers.push_back(w);
+  }
+  std::vector<int> rcs(n_workers, SFMHIP_OK);
+  std::vector<std::thread> threads;
+  for (int t = 0; t < n_workers; ++t)
+    threads.emplace_back([&, t]() {
+      sfmhip_ctx* w = ctx->workers[t];
+      for (int i = t; i < n_images && rcs[t] == SFMHIP_OK; i += n_workers) {
+        std::vector<KeyPt> kps;
+        int32_t n = 0;
+        void* dd = nullptr;
+        int rc = sift_impl(w, gray[i], rows[i], cols[i], n_octave_layers, contrast_threshold, edge_threshold, sigma, 0, kps, nullptr, &dd, &n);
+        if (rc == SFMHIP_OK) {
+          float* k = (float*)malloc(sizeof(float) * 6 * (size_t)std::max(n, 1));
+          if (!k) rc = SFMHIP_ERR_ALLOC;
+          else {
+            sift_pack_keypoints(kps, k);
+            keypoints[i] = k;
+            d_descriptors[i] = dd;
+            n_keypoints[i] = n;
+          }
+        }
+        if (rc != SFMHIP_OK) {
+          if (dd) hipFree(dd);
+          rcs[t] = rc;
+        }
+      }
+    });
+  for (auto& th : threads) th.join();
+  for (int rc : rcs)
+    if (rc != SFMHIP_OK) {
+      for (int i = 0; i < n_images; ++i) {
+        free(keypoints[i]);
+        if (d_descriptors[i]) hipFree(d_descriptors[i]);
+        keypoints[i] = nullptr;
+        d_descriptors[i] = nullptr;
+        n_keypoints[i] = 0;
+      }
+      return rc;
+    }
   return SFMHIP_OK;
 }

@@ -56,6 +56,15 @@ int sfmhip_imageset_upload(sfmhip_imageset* s, int image, const void* host_rows)
   if (bytes) memcpy(s->rows[image], host_rows, bytes);
   return SFMHIP_OK;
 }
+/* (the stand-in's "device" is host memory) */
+int sfmhip_imageset_adopt_device(sfmhip_imageset* s, int image, const void* device_rows) { return sfmhip_imageset_upload(s, image, device_rows); }
+void sfmhip_device_free(void* p) { free(p); }
+void sfmhip_host_free(void* p) { free(p); }
+int sfmhip_device_download(sfmhip_ctx* ctx, void* host_dst, const void* device_src, size_t bytes) {
+  (void)ctx;
+  if (bytes) memcpy(host_dst, device_src, bytes);
+  return SFMHIP_OK;
+}
 int sfmhip_imageset_prepare_async(sfmhip_imageset* s) { (void)s; return SFMHIP_OK; }
 void sfmhip_imageset_destroy(sfmhip_imageset* s) {
   if (!s) return;
@@ -206,6 +215,18 @@ int sfmhip_sift_detect_and_compute(sfmhip_ctx* ctx, const uint8_t* gray, int row
   (void)ctx; (void)gray; (void)rows; (void)cols; (void)n_octave_layers; (void)contrast_threshold; (void)edge_threshold; (void)sigma;
   (void)capacity; (void)keypoints; (void)descriptors;
   *n_keypoints = 0;
+  return SFMHIP_OK;
+}
+
+int sfmhip_sift_batch(sfmhip_ctx* ctx, int n_images, const uint8_t* const* gray, const int32_t* rows, const int32_t* cols,
+                      int n_octave_layers, double contrast_threshold, double edge_threshold, double sigma, float** keypoints,
+                      void** d_descriptors, int32_t* n_keypoints) {
+  (void)ctx; (void)gray; (void)rows; (void)cols; (void)n_octave_layers; (void)contrast_threshold; (void)edge_threshold; (void)sigma;
+  for (int i = 0; i < n_images; ++i) {
+    keypoints[i] = (float*)malloc(6 * sizeof(float));
+    d_descriptors[i] = NULL;
+    n_keypoints[i] = 0;
+  }
   return SFMHIP_OK;
 }
 

@@ -144,3 +144,34 @@ def test_cfg1_shaped_pipeline_on_rendered_views(ctx):
     from oracle import sfm_oracle_score as SC
     want = SC.find_best_pair_scores([(pairs[i], pts[i][0], pts[i][1]) for i in range(3)], K, min_matches=40)
     assert [(float(r), v) for r, v in best] == [(float(r), v) for r, v in want]
+
+
+def test_batched_front_end_leaves_the_same_descriptors_in_hbm(ctx):
+    """sfmhip_sift_batch (several images in flight on worker streams, descriptor rows left in HBM) against the one-image
+    entry, image by image and bit for bit; the matcher adopts the device rows in place and finds the same matches as
+    from uploaded host rows"""
+    from sfm_danpipeline_amd import matcher
+    big = _blobs(150, 200, 70, 21, noise=1.0)
+    imgs = [big[10:130, 10:170], big[14:134, 18:178], _blobs(96, 128, 30, 3), np.full((40, 40), 7, np.uint8), _blobs(75, 101, 30, 4),
+            big[0:120, 0:160], _blobs(64, 64, 12, 6), _blobs(160, 120, 30, 2), big[20:140, 30:190], _blobs(50, 70, 9, 8), _blobs(88, 99, 25, 9)]
+    single = [features.sift_detect_and_compute(g, ctx=ctx) for g in imgs]
+    for rep in range(2):                                            # (the second call reuses the worker contexts)
+        batch = features.sift_batch(imgs, ctx=ctx)
+        assert len(batch) == len(imgs)
+        for i, ((K1, D1), (K2, dd)) in enumerate(zip(single, batch)):
+            assert np.array_equal(K1.view(np.int32), K2.view(np.int32)), i
+            assert dd.n == len(K1) and np.array_equal(D1, dd.download()), i
+    assert len(single[3][0]) == 0 and batch[3][1].ptr in (None, 0)     # the flat image: no keypoints, no device rows
+    use = [0, 1, 5, 8]
+    a = matcher.ImageSet([single[i][1] for i in use], ctx=ctx)          # uploaded host rows
+    b = matcher.ImageSet(n_rows=[batch[i][1].n for i in use], dim=128, dtype=matcher.F32, norm=matcher.L2, ctx=ctx)
+    for j, i in enumerate(use):
+        b.adopt_device(j, batch[i][1].ptr, keepalive=batch[i][1])
+    pairs = np.array([[0, 1], [0, 2], [1, 3], [2, 3]], np.int32)
+    res = []
+    for s_ in (a, b):
+        s_.prepare_async()
+        pl = matcher.MatchPlan(s_, pairs)
+        pl.run_async(0.8)
+        res.append(pl.fetch())
+    assert all(np.array_equal(x, y) for x, y in zip(*res)) and res[0][0].sum() > 30
