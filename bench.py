@@ -62,10 +62,10 @@ def main():
                     help="timed regions and per-kernel samples only (no sustained / host-visible loops, no cfg5, no CPU "
                          "baseline): the command to run under rocprofv3, whose traces grow with every dispatch")
     ap.add_argument("--sustain-s", type=float, default=2.0, help="seconds of the sustained loops")
-    ap.add_argument("--match-streams", type=int, default=1, choices=(1, 2),
-                    help="2: consecutive batches alternate between two resident buffers on two HIP streams "
-                         "(+5 %% pairs/s; per-kernel durations of overlapping launches are then not comparable "
-                         "with the single-launch figure the roofline uses, hence not the default)")
+    ap.add_argument("--match-streams", type=int, default=2, choices=(1, 2),
+                    help="2 (default): consecutive batches alternate between two resident buffers on two HIP streams -- the "
+                         "small prepare / fix-up / compaction kernels of one batch overlap the sweep of the other (+10 %% "
+                         "pairs/s); the roofline's launch_ms is sampled from single-stream steps either way.  1: one stream")
     args = ap.parse_args()
     if args.lean:
         args.no_cfg5 = args.no_cpu_baseline = args.no_score = True
@@ -200,20 +200,24 @@ def main():
     # buffers while sweep n + 1 runs; the host takes sweep n - 1's lists (fetch_wait) right after enqueueing sweep n + ...
     hv_seen = [0, 0]
     def match_and_fetch():
-        match_step(one_stream=True)
-        if hv_seen[0] > 0:
-            c_, q_, t_, d_ = plan.fetch_wait(back=1)
+        j = step_no[0] % N_STREAMS                     # the plan this step runs on (match_step alternates)
+        match_step()
+        if hv_seen[0] > 0:                             # the lists of the step before: its plan's latest run, or, with one
+            c_, q_, t_, d_ = plans[(j - 1) % N_STREAMS].fetch_wait(back=0 if N_STREAMS > 1 else 1)   # plan, the run before
             hv_seen[1] += int(c_.sum()) == len(q_) == len(t_) == len(d_)
         hv_seen[0] += 1
     if args.lean:
         n_hv, t_hv = 0, 1.0
     else:
-        plan.pipeline()
+        for pl_ in plans:
+            pl_.pipeline()
         n_hv, t_hv = loop_for(1.0, match_and_fetch, 50)
-        c_, q_, t_, d_ = plan.fetch_wait(back=0)             # the last sweep's lists
-        assert np.array_equal(c_, counts) and hv_seen[1] == hv_seen[0] - 1
-        assert np.array_equal(synth.pair_checksums(c_, q_, t_, d_), synth.pair_checksums(*plan.fetch()))
-        plan.pipeline(-1)
+        last = plans[(step_no[0] - 1) % N_STREAMS]
+        c_, q_, t_, d_ = last.fetch_wait(back=0)             # the last sweep's lists
+        assert int(c_.sum()) == len(q_) and hv_seen[1] == hv_seen[0] - 1
+        assert np.array_equal(synth.pair_checksums(c_, q_, t_, d_), synth.pair_checksums(*last.fetch()))
+        for pl_ in plans:
+            pl_.pipeline(-1)
     host_visible_pairs_s = n_hv * len(pairs) / t_hv
     # (and the stop-and-copy way, sfmhip_matchplan_fetch after every sweep: two synchronisations + two copies per sweep)
     def match_and_copy():

@@ -408,6 +408,7 @@ __device__ unsigned long long g_elim_dump[32];
 #define EL_STAMP(slot, cond)
 #define EL_STAMPW(slot)
 #endif
+constexpr int FP = 10;  // slots per row of the F^T F accumulators in LDS (the MFMA path takes signatures of n <= 10 cameras)
 constexpr int MP = 80;  // LDS row pitch (doubles) of a wave's M panel: the 4 k-rows of one
                         // fragment read sit 160 dwords apart -> disjoint banks
 
@@ -419,8 +420,11 @@ struct CamLds {  // camera table transposed in LDS: element e of camera slot o a
   __device__ __forceinline__ double operator[](int e) const { return e < 12 ? base[e * 16] : dbase[e * 16]; }
 };
 
+#ifndef SFM_ELIM_LB
+#define SFM_ELIM_LB __launch_bounds__(512)
+#endif
 template <int NB>
-__global__ __launch_bounds__(512) void ba_eliminate_mfma(BaDev d, const Chunk* __restrict__ chunks,
+__global__ SFM_ELIM_LB void ba_eliminate_mfma(BaDev d, const Chunk* __restrict__ chunks,
                                                          const int* __restrict__ chunk_ids,
                                                          const int* __restrict__ sig_cams, double inv_radius,
                                                          double lm_lo, double lm_hi, int rank,
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(512) void ba_eliminate_mfma(BaDev d, const Chunk* _
   }
   // dynamic LDS: the F^T F accumulators [wave][e][slot] (nw x 36 x 16) + [3][16] | the waves' panels, later the
   // cross-wave reduction and the staged Gram block
-  const int ff_sz = nw * 576 + 48;
+  const int ff_sz = nw * 36 * FP + 3 * FP;
   double* s_P = s_M + ff_sz;
   for (int idx = tid; idx < ff_sz + nw * 12 * MP; idx += (int)blockDim.x) s_M[idx] = 0.0;
   if (tid < 64) {
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(512) void ba_eliminate_mfma(BaDev d, const Chunk* _
   // F^T F part of a camera slot (the 6x6 block (upper, 21), the focal border (6), F^T b (6), Jf^2, Jf r, r^2 --
   // what ba_cam_blocks formed from a second linearisation) is accumulated in LDS, ds_add_f64 by the slot's four point
   // lanes: as registers the 36 sums cost the 72 VGPRs that keep the loop from spilling and from prefetching
-  lds_double* ffw = (lds_double*)s_M + wave * 576 + oc;
+  lds_double* ffw = (lds_double*)s_M + wave * (36 * FP) + oc;
   // point data of the next iteration is loaded one iteration ahead (a lone wave per SIMD otherwise waits a global
   // round trip per iteration)
   double nX[3], nsp[3] = {1.0, 1.0, 1.0};
@@ -518,7 +522,7 @@ __global__ __launch_bounds__(512) void ba_eliminate_mfma(BaDev d, const Chunk* _
     if (pv && valid_o) {
       // (Jc[4] = Jc[9] = 0: row 0 has no t_y column, row 1 no t_x column; entry (3,4) is identically zero)
       auto ff_add = [&](int e, double v) {
-        __hip_atomic_fetch_add(ffw + e * 16, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(ffw + e * FP, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       };
       int e = 0;
 #pragma unroll
@@ -546,18 +550,22 @@ __global__ __launch_bounds__(512) void ba_eliminate_mfma(BaDev d, const Chunk* _
       ff_add(35, fma(ol.r0, ol.r0, ol.r1 * ol.r1));
     }
     EL_STAMP(10, quad == wave + 2 * nw);
-    // point block C = sum Jp^T Jp (lower: 00 10 11 20 21 22), gp = Jp^T r, wf = Jp^T Jf
+    // point block C = sum Jp^T Jp (lower: 00 10 11 20 21 22), gp = Jp^T r, wf = Jp^T Jf.  Idle lanes (no such
+    // observation, or no such point in the last quad) carry Jp = 0: every product below -- the sums, W = Jc^T Jp, the
+    // panel rows -- has Jp as a factor, so six multiplications mask them all
+#pragma unroll
+    for (int a = 0; a < 6; ++a) ol.Jp[a] *= live;
     double red[12];
-    red[0] = live * (ol.Jp[0] * ol.Jp[0] + ol.Jp[3] * ol.Jp[3]);
-    red[1] = live * (ol.Jp[1] * ol.Jp[0] + ol.Jp[4] * ol.Jp[3]);
-    red[2] = live * (ol.Jp[1] * ol.Jp[1] + ol.Jp[4] * ol.Jp[4]);
-    red[3] = live * (ol.Jp[2] * ol.Jp[0] + ol.Jp[5] * ol.Jp[3]);
-    red[4] = live * (ol.Jp[2] * ol.Jp[1] + ol.Jp[5] * ol.Jp[4]);
-    red[5] = live * (ol.Jp[2] * ol.Jp[2] + ol.Jp[5] * ol.Jp[5]);
+    red[0] = ol.Jp[0] * ol.Jp[0] + ol.Jp[3] * ol.Jp[3];
+    red[1] = ol.Jp[1] * ol.Jp[0] + ol.Jp[4] * ol.Jp[3];
+    red[2] = ol.Jp[1] * ol.Jp[1] + ol.Jp[4] * ol.Jp[4];
+    red[3] = ol.Jp[2] * ol.Jp[0] + ol.Jp[5] * ol.Jp[3];
+    red[4] = ol.Jp[2] * ol.Jp[1] + ol.Jp[5] * ol.Jp[4];
+    red[5] = ol.Jp[2] * ol.Jp[2] + ol.Jp[5] * ol.Jp[5];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      red[6 + a] = live * (ol.Jp[a] * ol.r0 + ol.Jp[3 + a] * ol.r1);
-      red[9 + a] = live * (ol.Jp[a] * ol.Jf[0] + ol.Jp[3 + a] * ol.Jf[1]);
+      red[6 + a] = ol.Jp[a] * ol.r0 + ol.Jp[3 + a] * ol.r1;
+      red[9 + a] = ol.Jp[a] * ol.Jf[0] + ol.Jp[3 + a] * ol.Jf[1];
     }
 #pragma unroll
     for (int e = 0; e < 12; ++e) red[e] = row16_sum(red[e]);
@@ -582,9 +590,9 @@ __global__ __launch_bounds__(512) void ba_eliminate_mfma(BaDev d, const Chunk* _
       double* row0 = Mw + (3 * q) * MP + 6 * o;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        const double w0 = live * (ol.Jc[i] * ol.Jp[0] + ol.Jc[6 + i] * ol.Jp[3]);
-        const double w1 = live * (ol.Jc[i] * ol.Jp[1] + ol.Jc[6 + i] * ol.Jp[4]);
-        const double w2 = live * (ol.Jc[i] * ol.Jp[2] + ol.Jc[6 + i] * ol.Jp[5]);
+        const double w0 = ol.Jc[i] * ol.Jp[0] + ol.Jc[6 + i] * ol.Jp[3];
+        const double w1 = ol.Jc[i] * ol.Jp[1] + ol.Jc[6 + i] * ol.Jp[4];
+        const double w2 = ol.Jc[i] * ol.Jp[2] + ol.Jc[6 + i] * ol.Jp[5];
         row0[i] = w0 * Li[0];
         row0[MP + i] = w0 * Li[1] + w1 * Li[2];
         row0[2 * MP + i] = w0 * Li[3] + w1 * Li[4] + w2 * Li[5];
@@ -660,12 +668,12 @@ __global__ __launch_bounds__(512) void ba_eliminate_mfma(BaDev d, const Chunk* _
   auto g_sub = [&](int lr, int lc, double v) {
     __hip_atomic_fetch_add(s_G + g_slot(lr, lc), -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
-  for (int idx = tid; idx < 36 * 16; idx += (int)blockDim.x) {
-    const int e = idx >> 4, slot = idx & 15;
+  for (int idx = tid; idx < 36 * FP; idx += (int)blockDim.x) {
+    const int e = idx / FP, slot = idx - e * FP;
     if (slot >= n) continue;
     double v = 0.0;
-    for (int w = 0; w < nw; ++w) v += s_F[(w * 36 + e) * 16 + slot];
-    s_F[e * 16 + slot] = v;  // (the sum over the waves, for phases C and D)
+    for (int w = 0; w < nw; ++w) v += s_F[(w * 36 + e) * FP + slot];
+    s_F[e * FP + slot] = v;  // (the sum over the waves, for phases C and D)
     if (norms || e >= 33) continue;
     if (e < 21) {
       int i = 0, rem = e;
@@ -684,8 +692,8 @@ __global__ __launch_bounds__(512) void ba_eliminate_mfma(BaDev d, const Chunk* _
   EL_STAMP(4, true);
   if (tid < 3) {
     double v = 0.0;
-    for (int slot = 0; slot < n; ++slot) v += s_F[(33 + tid) * 16 + slot];
-    s_F[(nw * 36 + tid) * 16] = v;
+    for (int slot = 0; slot < n; ++slot) v += s_F[(33 + tid) * FP + slot];
+    s_F[(nw * 36 + tid) * FP] = v;
     if (!norms && tid < 2) g_sub(6 * n, 6 * n + tid, v);
   }
   __syncthreads();
@@ -695,8 +703,8 @@ __global__ __launch_bounds__(512) void ba_eliminate_mfma(BaDev d, const Chunk* _
     if (nfail) atomic_add_f64(scv + 2, (double)nfail);
     atomic_max_pos_f64(scv + SC + rank, gmax);
   }
-  for (int idx = tid; idx < 33 * 16; idx += (int)blockDim.x) {  // F^T F diagonal -> dc, F^T b -> gF
-    const int e = idx >> 4, slot = idx & 15;
+  for (int idx = tid; idx < 33 * FP; idx += (int)blockDim.x) {  // F^T F diagonal -> dc, F^T b -> gF
+    const int e = idx / FP, slot = idx - e * FP;
     if (slot >= n) continue;
     const int r0 = 6 * cams[slot];
     if (e < 21) {
@@ -705,13 +713,13 @@ __global__ __launch_bounds__(512) void ba_eliminate_mfma(BaDev d, const Chunk* _
         rem -= 6 - i;
         ++i;
       }
-      if (rem == 0) atomic_add_f64(red_dc(d) + r0 + i, s_F[e * 16 + slot]);
+      if (rem == 0) atomic_add_f64(red_dc(d) + r0 + i, s_F[e * FP + slot]);
     } else if (e >= 27 && !norms) {
-      atomic_add_f64(red_gF(d) + r0 + e - 27, s_F[e * 16 + slot]);
+      atomic_add_f64(red_gF(d) + r0 + e - 27, s_F[e * FP + slot]);
     }
   }
   if (tid < 3) {
-    const double v = s_F[(nw * 36 + tid) * 16];
+    const double v = s_F[(nw * 36 + tid) * FP];
     if (tid == 0) atomic_add_f64(red_dc(d) + fo, v);
     else if (norms) {
     } else if (tid == 1) atomic_add_f64(red_gF(d) + fo, v);
@@ -2733,7 +2741,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   // once more until the slots are full, and the launch lists the large pieces first: the dispatcher deals the first
   // n_cu workgroups one per CU, so every CU ends up with a large and a small piece or two small ones.  The busiest
   // SIMD then has 250 + 167 points instead of 500 (SFMHIP_BA_ELIM_FILL=0: the plain cut).
-  const int slots = 2 * std::max(b->ctx->n_cu, 1);
+  const int slots = (getenv("SFMHIP_BA_ELIM_SLOTS") ? atoi(getenv("SFMHIP_BA_ELIM_SLOTS")) : 2) * std::max(b->ctx->n_cu, 1);  // (resident workgroups per CU: a measurement knob)
   const bool fill_env = !(getenv("SFMHIP_BA_ELIM_FILL") && atoi(getenv("SFMHIP_BA_ELIM_FILL")) == 0);
   std::vector<int> parts_of(gstart.size(), 0);
   {
@@ -3098,7 +3106,7 @@ static int ba_launch_eliminate(sfmhip_ba* b, double inv_radius, double lm_lo, do
     if (!b->n_chunk_ids[li]) continue;                                                                                \
     /* wave panels | the cross-wave Gram reduction (NT x 4 x 64) | the F^T F reduction */                             \
     const size_t nw_ = nthreads / 64, gram_ = (size_t)(NB * (NB + 1) / 2) * 256;                                      \
-    const size_t lds = sizeof(double) * (nw_ * 576 + 48 + std::max(nw_ * 12 * MP, gram_));                            \
+    const size_t lds = sizeof(double) * (nw_ * 36 * FP + 3 * FP + std::max(nw_ * 12 * MP, gram_));                            \
     hipLaunchKernelGGL((ba_eliminate_mfma<NB>), dim3(b->n_chunk_ids[li]), dim3(nthreads), lds, st, b->d,              \
                        b->d_chunks, b->d_chunk_ids[li],                                                               \
                        b->d_sig_cams, inv_radius, lm_lo, lm_hi, b->rank, norms);                                      \
