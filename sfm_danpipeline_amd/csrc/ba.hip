@@ -408,6 +408,8 @@ __device__ unsigned long long g_elim_dump[32];
 #define EL_STAMP(slot, cond)
 #define EL_STAMPW(slot)
 #endif
+// a chunk's slab: [Gram block, MFMA layout, NT x 256 <= 2560 | F^T F sums 36 x FP | Jf^2, Jf r, r^2 | gmax | nfail]
+constexpr int ELIM_SLAB_FF = 2560, ELIM_SLAB = 2944;
 constexpr int FP = 10;  // slots per row of the F^T F accumulators in LDS (the MFMA path takes signatures of n <= 10 cameras)
 constexpr int MP = 80;  // LDS row pitch (doubles) of a wave's M panel: the 4 k-rows of one
                         // fragment read sit 160 dwords apart -> disjoint banks
@@ -428,11 +430,13 @@ __global__ SFM_ELIM_LB void ba_eliminate_mfma(BaDev d, const Chunk* __restrict__
                                                          const int* __restrict__ chunk_ids,
                                                          const int* __restrict__ sig_cams, double inv_radius,
                                                          double lm_lo, double lm_hi, int rank,
-                                                         int norms /* 1: unscaled squared column norms of the cameras and the focal into dc, nothing else */) {
+                                                         int norms /* 1: unscaled squared column norms of the cameras and the focal into dc, nothing else */,
+                                                         double* __restrict__ slab /* non-null: the workgroup's sums go to its slab (ELIM_SLAB doubles per chunk) instead of atomics on S */) {
   constexpr int NT = NB * (NB + 1) / 2;
   __shared__ __attribute__((aligned(16))) double s_cam[CAMD * 16];
   extern __shared__ __attribute__((aligned(16))) double s_M[];  // nw x 12 x MP panels; also the cross-wave reduction buffer
   __shared__ int s_gidx[64];  // local Gram index -> row/column of S; -2: the rhs column u; -1: padding
+  __shared__ double s_wv[16];  // per wave: gradient maximum, failed point blocks (slab epilogue)
   const int nw = blockDim.x >> 6;  // 4 waves for long runs, 1 for runs of a few points (unstructured visibility)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   EL_STAMP(0, true);
@@ -642,6 +646,10 @@ __global__ SFM_ELIM_LB void ba_eliminate_mfma(BaDev d, const Chunk* __restrict__
     gmax = fmax(gmax, __shfl_down(gmax, off));
     nfail += __shfl_down(nfail, off);
   }
+  if (lane == 0) {
+    s_wv[2 * wave] = gmax;
+    s_wv[2 * wave + 1] = (double)nfail;
+  }
   __syncthreads();
   EL_STAMP(15, true);
   if (wave == 0 && !norms) {
@@ -652,7 +660,18 @@ __global__ SFM_ELIM_LB void ba_eliminate_mfma(BaDev d, const Chunk* __restrict__
   }
   __syncthreads();
   EL_STAMP(16, true);
-  if (wave != 0 && !norms) {
+  if (slab && !norms) {
+    // (deterministic mode: the waves add their tiles one after the other -- the order they arrive in is not fixed)
+    for (int w = 1; w < nw; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) s_G[(t * 4 + g) * 64 + lane] += acc[t][g];
+      }
+      __syncthreads();
+    }
+  } else if (wave != 0 && !norms) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -698,6 +717,28 @@ __global__ SFM_ELIM_LB void ba_eliminate_mfma(BaDev d, const Chunk* __restrict__
   }
   __syncthreads();
   EL_STAMP(5, true);
+  if (slab) {
+    // ---- slab epilogue: every sum of this workgroup as plain stores into its own slab; ba_gather_slabs adds the
+    // slabs into S, g, F^T b, the diagonal and the scalars in a fixed order.  The atomic scatter this replaces took
+    // 36 k of a workgroup's 186 k cycles at cfg4 (all workgroups end together and ~25 of them add to the same entries:
+    // device-scope f64 atomics execute at the memory side, same-address ones one after the other) and made S depend
+    // on the order they landed in.
+    double* my = slab + (size_t)chunk_ids[blockIdx.x] * ELIM_SLAB;
+    if (!norms)
+      for (int k = tid; k < NT * 256; k += (int)blockDim.x) my[k] = s_G[k];
+    for (int idx = tid; idx < 36 * FP; idx += (int)blockDim.x) my[ELIM_SLAB_FF + idx] = s_F[idx];
+    if (tid < 3) my[ELIM_SLAB_FF + 36 * FP + tid] = s_F[(nw * 36 + tid) * FP];
+    if (tid == 0) {
+      double gm = 0.0, nf = 0.0;
+      for (int w = 0; w < nw; ++w) {
+        gm = fmax(gm, s_wv[2 * w]);
+        nf += s_wv[2 * w + 1];
+      }
+      my[ELIM_SLAB_FF + 36 * FP + 3] = gm;
+      my[ELIM_SLAB_FF + 36 * FP + 4] = nf;
+    }
+    return;
+  }
   double* scv = red_sc(d);
   if (lane == 0 && !norms) {
     if (nfail) atomic_add_f64(scv + 2, (double)nfail);
@@ -749,6 +790,38 @@ __global__ SFM_ELIM_LB void ba_eliminate_mfma(BaDev d, const Chunk* __restrict__
     }
   }
   EL_STAMP(6, true);
+}
+
+// Sums the slabs of ba_eliminate_mfma into the reduced-system buffer: one thread per destination (an entry of S's
+// upper triangle, of g, F^T b, the diagonal, a scalar), its sources listed by the host in chunk order (bit 31 of a
+// source = subtract).  dest < 0: the gradient maximum of this rank (a max, not a sum).  Nothing else writes `red` while
+// this runs (same stream), so the read-modify-write is plain -- and S is the same bit pattern run after run.
+__global__ __launch_bounds__(256) void ba_gather_slabs(const double* __restrict__ slab, const int* __restrict__ ptr,
+                                                       const unsigned* __restrict__ src, const int* __restrict__ dest, int nd,
+                                                       double* __restrict__ red, long long gmax_off) {
+  // sixteen lanes per destination (a destination has 10-30 sources, each in another chunk's slab: one load deep instead
+  // of a chain of dependent loads per thread); lane j takes sources j, j + 16, ... in order, the lanes meet by the
+  // fixed tree of row16_sum -- the same order every run
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, j = threadIdx.x & 15;
+  const bool live = i < nd;
+  const int d = live ? dest[i] : 0;
+  const int k0 = live ? ptr[i] : 0, k1 = live ? ptr[i + 1] : 0;
+  if (live && d < 0) {  // (one destination: this rank's gradient maximum)
+    double v = 0.0;
+    for (int k = k0 + j; k < k1; k += 16) v = fmax(v, slab[src[k]]);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 16));
+    if (j == 0) red[gmax_off] = fmax(red[gmax_off], v);
+    return;
+  }
+  double v = 0.0;
+  for (int k = k0 + j; k < k1; k += 16) {
+    const unsigned sk = src[k];
+    const double x = slab[sk & 0x7fffffffu];
+    v += (sk >> 31) ? -x : x;
+  }
+  v = row16_sum(v);
+  if (live && j == 0) red[d] += v;
 }
 
 // The camera's own blocks for the pair path's points, from the camera-major list of their observations: thread per
@@ -2453,6 +2526,13 @@ struct sfmhip_ba {
   bool chol_attr_set = false;
   // plan
   Chunk* d_chunks = nullptr;
+  bool elim_deterministic = getenv("SFMHIP_BA_DETERMINISTIC") && atoi(getenv("SFMHIP_BA_DETERMINISTIC")) == 1;
+  // slab epilogue of ba_eliminate_mfma + ba_gather_slabs: [0] the full linearisation, [1] the norms-only mode
+  double* d_slab = nullptr;
+  int* d_gth_ptr[2] = {nullptr, nullptr};
+  unsigned* d_gth_src[2] = {nullptr, nullptr};
+  int* d_gth_dest[2] = {nullptr, nullptr};
+  int n_gth[2] = {0, 0};
   int* d_chunk_ids[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int n_chunk_ids[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [NB-1]: 4-wave workgroups (long runs), [4 + NB-1]: 1-wave (short runs)
   int* d_sig_cams = nullptr;
@@ -2797,6 +2877,79 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
     for (auto& l : ids)  // large pieces first (stable: equal sizes keep the point order)
       std::stable_sort(l.begin(), l.end(), [&](int a, int c) { return chunks[a].cnt > chunks[c].cnt; });
   lap_("chunks");
+  // ---- the gather lists of the slab epilogue (ba_gather_slabs): for every destination in `red` the slab entries that
+  // add to it, in chunk order; list 0 for a full linearisation, list 1 for the norms-only mode (diagonal only)
+  std::vector<int> gth_ptr[2], gth_dest[2];
+  std::vector<unsigned> gth_src[2];
+  if (b->elim_deterministic && !chunks.empty() && chunks.size() * (size_t)ELIM_SLAB < ((size_t)1 << 31)) {
+    const int ld = b->ld, fo = 6 * n_cam;
+    const long long ssz = (long long)b->ssz, o_g = ssz, o_gF = ssz + ld, o_dc = ssz + 2LL * ld, o_sc = ssz + 3LL * ld;
+    std::vector<std::pair<long long, unsigned>> ent[2];  // (destination, source | sign)
+    const long long GMAX = -1;                            // (sorts first; the kernel takes the rank's slot as an argument)
+    for (size_t c = 0; c < chunks.size(); ++c) {
+      const Chunk& ch = chunks[c];
+      const int n = ch.n, NBc = (6 * n + 2 + 15) / 16, NTc = NBc * (NBc + 1) / 2;
+      const int* cams = sig_cams.data() + ch.sig_off;
+      const unsigned base = (unsigned)(c * (size_t)ELIM_SLAB);
+      auto gidx = [&](int l) { return l < 6 * n ? 6 * cams[l / 6] + l % 6 : l == 6 * n ? fo : l == 6 * n + 1 ? -2 : -1; };
+      for (int idx = 0; idx < NTc * 256; ++idx) {  // the Gram block, as the kernel lays it out
+        int t = idx >> 8, ti = 0;
+        while (t >= NBc - ti) {
+          t -= NBc - ti;
+          ++ti;
+        }
+        const int tj = ti + t, gg = (idx >> 6) & 3, ln = idx & 63;
+        const int lr = 16 * ti + (ln >> 4) + 4 * gg, lc = 16 * tj + (ln & 15);
+        const int gr = gidx(lr), gc = gidx(lc);
+        if (gr < 0 || lr > lc || gc == -1) continue;
+        ent[0].push_back({gc >= 0 ? (long long)gr * ld + gc : o_g + gr, (base + idx) | 0x80000000u});  // S -= Gram (F^T F folded in)
+      }
+      for (int e = 0; e < 33; ++e)
+        for (int slot = 0; slot < n; ++slot) {
+          const unsigned sidx = base + ELIM_SLAB_FF + e * FP + slot;
+          const int r0 = 6 * cams[slot];
+          if (e < 21) {
+            int i = 0, rem = e;
+            while (rem >= 6 - i) {
+              rem -= 6 - i;
+              ++i;
+            }
+            if (rem == 0) {
+              ent[0].push_back({o_dc + r0 + i, sidx});
+              ent[1].push_back({o_dc + r0 + i, sidx});
+            }
+          } else if (e >= 27) {
+            ent[0].push_back({o_gF + r0 + e - 27, sidx});
+          }
+        }
+      const unsigned tail = base + ELIM_SLAB_FF + 36 * FP;
+      ent[0].push_back({o_dc + fo, tail});
+      ent[1].push_back({o_dc + fo, tail});
+      ent[0].push_back({o_gF + fo, tail + 1});
+      ent[0].push_back({o_sc + 0, tail + 2});
+      ent[0].push_back({GMAX, tail + 3});
+      ent[0].push_back({o_sc + 2, tail + 4});
+    }
+    for (int m = 0; m < 2; ++m) {
+      // counting sort by destination (stable: a destination's sources stay in chunk order)
+      const size_t range = (size_t)(o_sc + SC + 64) + 2;   // destinations + the GMAX key shifted to 0
+      std::vector<int> cnt(range + 1, 0);
+      for (const auto& e : ent[m]) ++cnt[(size_t)(e.first + 1) + 1];
+      for (size_t k = 0; k < range; ++k) cnt[k + 1] += cnt[k];
+      gth_src[m].resize(ent[m].size());
+      {
+        std::vector<int> pos(cnt.begin(), cnt.end() - 1);
+        for (const auto& e : ent[m]) gth_src[m][(size_t)pos[(size_t)(e.first + 1)]++] = e.second;
+      }
+      for (size_t k = 0; k < range; ++k)
+        if (cnt[k + 1] > cnt[k]) {
+          gth_ptr[m].push_back(cnt[k]);
+          gth_dest[m].push_back((int)((long long)k - 1));
+        }
+      gth_ptr[m].push_back((int)ent[m].size());
+    }
+  }
+  lap_("gather lists");
   // ---- camera co-visibility (one bit row per camera) for the dissection of the reduced system
   if (n_cam >= 64 && n_cam <= 4096) {
     const int wpr = (n_cam + 63) / 64;
@@ -2906,6 +3059,14 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   BA_A(b->d_cam_used, n_cam);
   BA_A(b->d_flag, 2);
   BA_A(b->d_chunks, chunks.size());
+  if (!gth_dest[0].empty()) {
+    BA_A(b->d_slab, chunks.size() * (size_t)ELIM_SLAB);
+    for (int m = 0; m < 2; ++m) {
+      BA_A(b->d_gth_ptr[m], gth_ptr[m].size());
+      BA_A(b->d_gth_src[m], gth_src[m].size());
+      BA_A(b->d_gth_dest[m], gth_dest[m].size());
+    }
+  }
   for (int c = 0; c < 8; ++c) BA_A(b->d_chunk_ids[c], ids[c].size());
   BA_A(b->d_sig_cams, sig_cams.size());
   BA_A(b->d_cptr, cptr.size());
@@ -2940,6 +3101,12 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   SFM_HIP_TRY(up(d_oxy, oxy.data(), oxy.size() * 8));
   SFM_HIP_TRY(up(b->d_cam_used, b->h_cam_used.data(), n_cam));
   SFM_HIP_TRY(up(b->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk)));
+  for (int m = 0; m < 2 && b->d_slab; ++m) {
+    SFM_HIP_TRY(up(b->d_gth_ptr[m], gth_ptr[m].data(), gth_ptr[m].size() * 4));
+    SFM_HIP_TRY(up(b->d_gth_src[m], gth_src[m].data(), gth_src[m].size() * 4));
+    SFM_HIP_TRY(up(b->d_gth_dest[m], gth_dest[m].data(), gth_dest[m].size() * 4));
+    b->n_gth[m] = (int)gth_dest[m].size();
+  }
   for (int c = 0; c < 8; ++c) SFM_HIP_TRY(up(b->d_chunk_ids[c], ids[c].data(), ids[c].size() * 4));
   SFM_HIP_TRY(up(b->d_sig_cams, sig_cams.data(), sig_cams.size() * 4));
   SFM_HIP_TRY(up(b->d_cptr, cptr.data(), cptr.size() * 4));
@@ -3100,6 +3267,13 @@ static int ba_agree_flag(sfmhip_ba* b, int* flag) {
 static int ba_launch_eliminate(sfmhip_ba* b, double inv_radius, double lm_lo, double lm_hi, int norms) {
   hipStream_t st = b->ctx->stream;
   int nl = 0;
+  // Two epilogues.  Default: the workgroups scatter their sums into S with f64 atomics (order-dependent in the last
+  // bits).  SFMHIP_BA_DETERMINISTIC=1 (read when the problem is created): every workgroup stores its sums in a slab of
+  // its own and ba_gather_slabs adds the slabs in a fixed order -- S, g and the cost are then the same bit patterns run
+  // after run.  Measured at cfg4 (scripts/gpu_prof_elim_ab.sh): the elimination kernel 84.9 -> 73.3 us without the
+  // scatter, the gather kernel 22.5 us (1 M scattered 8-byte sources, three dependent loads deep): +11 us per
+  // linearisation, which is why it is an option and not the default.
+  double* slab = b->elim_deterministic ? b->d_slab : nullptr;
 #define BA_ELIM(NB)                                                                                                   \
   for (int cls = 0; cls < 2; ++cls) {                                                                                 \
     const int li = 4 * cls + NB - 1, nthreads = cls ? 64 : 64 * b->elim_waves;                                        \
@@ -3109,7 +3283,7 @@ static int ba_launch_eliminate(sfmhip_ba* b, double inv_radius, double lm_lo, do
     const size_t lds = sizeof(double) * (nw_ * 36 * FP + 3 * FP + std::max(nw_ * 12 * MP, gram_));                            \
     hipLaunchKernelGGL((ba_eliminate_mfma<NB>), dim3(b->n_chunk_ids[li]), dim3(nthreads), lds, st, b->d,              \
                        b->d_chunks, b->d_chunk_ids[li],                                                               \
-                       b->d_sig_cams, inv_radius, lm_lo, lm_hi, b->rank, norms);                                      \
+                       b->d_sig_cams, inv_radius, lm_lo, lm_hi, b->rank, norms, slab);                                \
     ++nl;                                                                                                             \
   }
   BA_ELIM(1)
@@ -3117,6 +3291,13 @@ static int ba_launch_eliminate(sfmhip_ba* b, double inv_radius, double lm_lo, do
   BA_ELIM(3)
   BA_ELIM(4)
 #undef BA_ELIM
+  const int m = norms ? 1 : 0;
+  if (slab && nl && b->n_gth[m]) {
+    hipLaunchKernelGGL(ba_gather_slabs, dim3((b->n_gth[m] + 15) / 16), dim3(256), 0, st, (const double*)slab,
+                       (const int*)b->d_gth_ptr[m], (const unsigned*)b->d_gth_src[m], (const int*)b->d_gth_dest[m], b->n_gth[m],
+                       b->d.red, (long long)(b->ssz + 3 * (size_t)b->ld + SC + b->rank));
+    ++nl;
+  }
   return nl;
 }
 

@@ -173,7 +173,7 @@ def test_cfg1_temple_sequence_end_to_end(tmp_path, orc):
     c = run2["cloud"]
     assert len(c) == len(kept) >= 50, (len(c), len(kept))
     assert np.array_equal(c["q"], m["q"][kept]) and np.array_equal(c["t"], m["t"][kept])
-    assert np.abs(c["X"] - Xo[kept]).max() <= 1e-9 * max(1.0, np.abs(Xo[kept]).max())
+    assert np.array_equal(c["X"].view(np.uint64), np.ascontiguousarray(Xo[kept]).view(np.uint64))   # bit for bit
     # ---- adjustCurrentBundle: the Python mirror of adjustBundle with the oracle as solver, same containers
     from tests.test_host_logic import _orc_solver
     cloud = [dict(pt=tuple(X), idxImage={q: int(fq), t: int(ft)}) for X, fq, ft in zip(c["X"], c["q"], c["t"])]
