@@ -200,11 +200,13 @@ def main():
     # buffers while sweep n + 1 runs; the host takes sweep n - 1's lists (fetch_wait) right after enqueueing sweep n + ...
     hv_seen = [0, 0]
     def match_and_fetch():
-        j = step_no[0] % N_STREAMS                     # the plan this step runs on (match_step alternates)
-        match_step()
-        if hv_seen[0] > 0:                             # the lists of the step before: its plan's latest run, or, with one
-            c_, q_, t_, d_ = plans[(j - 1) % N_STREAMS].fetch_wait(back=0 if N_STREAMS > 1 else 1)   # plan, the run before
+        # the lists of the run this plan did LAST (N_STREAMS steps ago), taken right before the plan is given its next run:
+        # that run is long done, the host does not block, and both streams keep a sweep queued
+        j = step_no[0] % N_STREAMS
+        if hv_seen[0] >= N_STREAMS:
+            c_, q_, t_, d_ = plans[j].fetch_wait(back=0)
             hv_seen[1] += int(c_.sum()) == len(q_) == len(t_) == len(d_)
+        match_step()
         hv_seen[0] += 1
     if args.lean:
         n_hv, t_hv = 0, 1.0
@@ -212,10 +214,11 @@ def main():
         for pl_ in plans:
             pl_.pipeline()
         n_hv, t_hv = loop_for(1.0, match_and_fetch, 50)
-        last = plans[(step_no[0] - 1) % N_STREAMS]
-        c_, q_, t_, d_ = last.fetch_wait(back=0)             # the last sweep's lists
-        assert int(c_.sum()) == len(q_) and hv_seen[1] == hv_seen[0] - 1
-        assert np.array_equal(synth.pair_checksums(c_, q_, t_, d_), synth.pair_checksums(*last.fetch()))
+        for pl_ in plans:                                     # the last runs' lists
+            c_, q_, t_, d_ = pl_.fetch_wait(back=0)
+            assert int(c_.sum()) == len(q_)
+            assert np.array_equal(synth.pair_checksums(c_, q_, t_, d_), synth.pair_checksums(*pl_.fetch()))
+        assert hv_seen[1] == hv_seen[0] - N_STREAMS
         for pl_ in plans:
             pl_.pipeline(-1)
     host_visible_pairs_s = n_hv * len(pairs) / t_hv
