@@ -23,6 +23,7 @@
 #include <cfloat>
 #include <cmath>
 #include <map>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -234,26 +235,52 @@ __device__ void solve_poly10(const double* c, Cplx* roots, int* flags) {
     roots[i] = p;
     p = cmul(p, r);
   }
-  for (int iter = 0; iter < 300; ++iter) {
+  // one pass over the roots R[0 .. nn) (nn = N when N > 0: compile-time, everything unrolled and in registers)
+  auto sweep = [&](auto NN, Cplx* R) {
+    constexpr int N = decltype(NN)::value;
+    const int nn = N ? N : n;
     double max_diff = 0;
-    for (int i = 0; i < n; ++i) {
-      p = roots[i];
-      Cplx num{c[n], 0}, denom{c[n], 0};
-      for (int j = 0; j < n; ++j) {
-        num = cmul(num, p);
-        num.re += c[n - j - 1];
+#pragma unroll
+    for (int i = 0; i < nn; ++i) {
+      const Cplx pi = R[i];
+      Cplx num{c[nn], 0}, denom{c[nn], 0};
+#pragma unroll
+      for (int j = 0; j < nn; ++j) {
+        num = cmul(num, pi);
+        num.re += c[nn - j - 1];
         num.im += 0.0;
         if (j != i) {
-          const Cplx d{p.re - roots[j].re, p.im - roots[j].im};
+          const Cplx d{pi.re - R[j].re, pi.im - R[j].im};
           if (d.re != 0 || d.im != 0) denom = cmul(denom, d);
           else *flags |= 1;
         }
       }
       num = cdiv(num, denom);
-      roots[i] = Cplx{p.re - num.re, p.im - num.im};
+      R[i] = Cplx{pi.re - num.re, pi.im - num.im};
       max_diff = fmax(max_diff, sqrt(num.re * num.re + num.im * num.im));
     }
-    if (max_diff <= 0) break;
+    return max_diff;
+  };
+  if (n == 10) {
+    // (the degree is ten unless leading coefficients vanish.  A copy of the roots indexed by compile-time constants
+    // only: it lives in registers -- the caller's array, indexed by the runtime n elsewhere, sits in scratch memory,
+    // and 300 x 10 x 10 reads of it per sample were the whole kernel's time)
+    Cplx rr[10];
+    {
+      Cplx q{1, 0};
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        rr[i] = q;
+        q = cmul(q, r);
+      }
+    }
+    for (int iter = 0; iter < 300; ++iter)
+      if (sweep(std::integral_constant<int, 10>{}, rr) <= 0) break;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) roots[i] = rr[i];
+  } else {
+    for (int iter = 0; iter < 300; ++iter)
+      if (sweep(std::integral_constant<int, 0>{}, roots) <= 0) break;
   }
   for (int i = 0; i < n; ++i)
     if (fabs(roots[i].im) < 1e-100) roots[i].im = 0;
@@ -264,7 +291,10 @@ __device__ void solve_poly10(const double* c, Cplx* roots, int* flags) {
 // (q2^T E q1 = 0): up to ten row-major 3 x 3 models, unit Frobenius norm, in the order of solvePoly's roots.  The
 // checker (a CPU restatement, test infrastructure) restates the same steps with the host's libm; see its header for what of the
 // library is reproduced and what is not.
-__device__ int five_point(const double (*q1)[2], const double (*q2)[2], double (*Eout)[9], int* flags) {
+// part 1 (register- and scratch-heavy): the null space, the constraints, the elimination, B and the polynomial.
+// work: e[36] (X, Y, Z, W row-major) | b[39] | c[11]
+constexpr int FP_WORK = 86;
+__device__ void five_point_setup(const double (*q1)[2], const double (*q2)[2], double* __restrict__ work) {
   double Q[9 * 9];
   for (int k = 0; k < 81; ++k) Q[k] = 0.0;
   for (int i = 0; i < 5; ++i) {
@@ -355,6 +385,19 @@ __device__ int five_point(const double (*q1)[2], const double (*q2)[2], double (
         }
     }
   }
+  for (int k = 0; k < 36; ++k) work[k] = e[k];
+  for (int k = 0; k < 39; ++k) work[36 + k] = b[k];
+  for (int k = 0; k < 11; ++k) work[75 + k] = c[k];
+}
+
+// part 2 (few registers: runs at four times part 1's occupancy, and solvePoly's 300 Durand-Kerner iterations are most
+// of a sample's time): the roots, (x, y) per real root, the models
+// WS = stride of work's entries (1: a thread's own array; 64: the sample-major blocks of score_setup); the models go
+// straight to Eout (9 doubles each, contiguous)
+template <int WS>
+__device__ int five_point_models(const double* __restrict__ work, double* __restrict__ Eout, int* flags) {
+  double c[11];
+  for (int k = 0; k < 11; ++k) c[k] = work[(size_t)(75 + k) * WS];
   Cplx roots[10];
   solve_poly10(c, roots, flags);
   int n = 0;
@@ -364,25 +407,32 @@ __device__ int five_point(const double (*q1)[2], const double (*q2)[2], double (
     // SVD::solveZ(B(z)): JacobiSVD on the transpose, the row of Vt of the smallest singular value
     double At[9], W3[3], Vt[9];
     for (int j = 0; j < 3; ++j) {
-      const double* br = b + j * 13;
-      At[0 * 3 + j] = br[0] * z3 + br[1] * z2 + br[2] * z1 + br[3];
-      At[1 * 3 + j] = br[4] * z3 + br[5] * z2 + br[6] * z1 + br[7];
-      At[2 * 3 + j] = br[8] * z4 + br[9] * z3 + br[10] * z2 + br[11] * z1 + br[12];
+      const double* br = work + (size_t)(36 + j * 13) * WS;
+      At[0 * 3 + j] = br[0 * WS] * z3 + br[1 * WS] * z2 + br[2 * WS] * z1 + br[3 * WS];
+      At[1 * 3 + j] = br[4 * WS] * z3 + br[5 * WS] * z2 + br[6 * WS] * z1 + br[7 * WS];
+      At[2 * 3 + j] = br[8 * WS] * z4 + br[9 * WS] * z3 + br[10 * WS] * z2 + br[11 * WS] * z1 + br[12 * WS];
     }
     jacobi_svd<3, 3, 3, 3>(At, W3, Vt);
     if (fabs(Vt[8]) < 1e-10) continue;
     const double x = Vt[6] / Vt[8], y = Vt[7] / Vt[8];
-    double* Ev = Eout[n];
-    for (int k = 0; k < 9; ++k) Ev[k] = ((e[k] * x + e[9 + k] * y) + e[18 + k] * z1) + e[27 + k];
-    double s = 0;
-    s += Ev[0] * Ev[0] + Ev[1] * Ev[1] + Ev[2] * Ev[2] + Ev[3] * Ev[3];
-    s += Ev[4] * Ev[4] + Ev[5] * Ev[5] + Ev[6] * Ev[6] + Ev[7] * Ev[7];
-    s += Ev[8] * Ev[8];
-    const double inv_n = 1. / sqrt(s);
-    for (int k = 0; k < 9; ++k) Ev[k] *= inv_n;
+    double Ev[9];
+    for (int k = 0; k < 9; ++k)
+      Ev[k] = ((work[(size_t)k * WS] * x + work[(size_t)(9 + k) * WS] * y) + work[(size_t)(18 + k) * WS] * z1) + work[(size_t)(27 + k) * WS];
+    double sq = 0;
+    sq += Ev[0] * Ev[0] + Ev[1] * Ev[1] + Ev[2] * Ev[2] + Ev[3] * Ev[3];
+    sq += Ev[4] * Ev[4] + Ev[5] * Ev[5] + Ev[6] * Ev[6] + Ev[7] * Ev[7];
+    sq += Ev[8] * Ev[8];
+    const double inv_n = 1. / sqrt(sq);
+    for (int k = 0; k < 9; ++k) Eout[9 * n + k] = Ev[k] * inv_n;
     ++n;
   }
   return n;
+}
+
+__device__ int five_point(const double (*q1)[2], const double (*q2)[2], double (*Eout)[9], int* flags) {
+  double work[FP_WORK];
+  five_point_setup(q1, q2, work);
+  return five_point_models<1>(work, &Eout[0][0], flags);
 }
 
 // ---------------------------------------------------------------- kernels
@@ -400,11 +450,11 @@ struct ScoreJob {  // one active pair of a chunk
   int samp;        // first row of its sample table (5 indices per iteration) for this chunk
 };
 
-// thread (job, iteration of the chunk): the sample's models
-__global__ __launch_bounds__(64) void score_solve(const ScoreJob* __restrict__ jobs, int n_jobs, int chunk,
+// thread (job, iteration of the chunk): part 1 of the sample's solve -> work (FP_WORK doubles per sample, sample-major
+// in blocks of 64 so that a wave's stores and loads are coalesced: work[(t / 64) * 64 * FP_WORK + k * 64 + t % 64])
+__global__ __launch_bounds__(64) void score_setup(const ScoreJob* __restrict__ jobs, int n_jobs, int chunk,
                                                   const int* __restrict__ samples, const double* __restrict__ p1,
-                                                  const double* __restrict__ p2, double* __restrict__ models,
-                                                  int* __restrict__ n_models) {
+                                                  const double* __restrict__ p2, double* __restrict__ work) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_jobs * chunk) return;
   const int j = t / chunk, it = t - j * chunk;
@@ -418,13 +468,20 @@ __global__ __launch_bounds__(64) void score_solve(const ScoreJob* __restrict__ j
     q2[k][0] = p2[2 * m];
     q2[k][1] = p2[2 * m + 1];
   }
-  double E[MAX_MODELS][9];
+  double w[FP_WORK];
+  five_point_setup(q1, q2, w);
+  double* out = work + (size_t)(t >> 6) * (64 * FP_WORK) + (t & 63);
+  for (int k = 0; k < FP_WORK; ++k) out[(size_t)k * 64] = w[k];
+}
+
+// thread (job, iteration of the chunk): part 2 -> the sample's models
+__global__ __launch_bounds__(256, 4) void score_roots(int n_samples, const double* __restrict__ work, double* __restrict__ models,
+                                                   int* __restrict__ n_models) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_samples) return;
   int flags = 0;
-  const int n = five_point(q1, q2, E, &flags);
+  const int n = five_point_models<64>(work + (size_t)(t >> 6) * (64 * FP_WORK) + (t & 63), models + (size_t)t * (MAX_MODELS * 9), &flags);
   n_models[t] = n | (flags << 8);
-  double* out = models + (size_t)t * (MAX_MODELS * 9);
-  for (int m = 0; m < n; ++m)
-    for (int e = 0; e < 9; ++e) out[m * 9 + e] = E[m][e];
 }
 
 // EMEstimatorCallback::computeError + findInliers for one correspondence
@@ -834,7 +891,7 @@ extern "C" int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_
   std::vector<int> job_pair, h_samples, h_nm, h_counts;
   ScoreJob* d_jobs = nullptr;
   int *d_samples = nullptr, *d_nm = nullptr, *d_counts = nullptr;
-  double* d_models = nullptr;
+  double *d_models = nullptr, *d_work = nullptr;
   size_t cap_jobs = 0, cap_slots = 0, cap_samples = 0;
   for (;;) {
     jobs.clear();
@@ -869,6 +926,7 @@ extern "C" int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_
       SFM_TRY(dalloc((void**)&d_nm, sizeof(int) * slots));
       SFM_TRY(dalloc((void**)&d_counts, sizeof(int) * slots * MAX_MODELS));
       SFM_TRY(dalloc((void**)&d_models, sizeof(double) * slots * MAX_MODELS * 9));
+      SFM_TRY(dalloc((void**)&d_work, sizeof(double) * ((slots + 63) / 64 * 64) * FP_WORK));
       cap_slots = slots;
     }
     if (h_samples.size() > cap_samples) {
@@ -877,8 +935,10 @@ extern "C" int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_
     }
     SFM_HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(ScoreJob) * nj, hipMemcpyHostToDevice, st));
     SFM_HIP_TRY(hipMemcpyAsync(d_samples, h_samples.data(), sizeof(int) * h_samples.size(), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(score_solve, dim3((unsigned)((slots + 63) / 64)), dim3(64), 0, st, d_jobs, (int)nj, chunk, d_samples, d_p1,
-                       d_p2, d_models, d_nm);
+    hipLaunchKernelGGL(score_setup, dim3((unsigned)((slots + 63) / 64)), dim3(64), 0, st, d_jobs, (int)nj, chunk, d_samples, d_p1,
+                       d_p2, d_work);
+    hipLaunchKernelGGL(score_roots, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, (int)slots, (const double*)d_work, d_models,
+                       d_nm);
     hipLaunchKernelGGL(score_count, dim3((unsigned)slots), dim3(256), 0, st, d_jobs, chunk, d_p1, d_p2, d_models, d_nm, t, d_counts);
     SFM_HIP_TRY(hipGetLastError());
     h_nm.resize(slots);
