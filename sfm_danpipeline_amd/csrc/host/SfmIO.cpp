@@ -340,6 +340,458 @@ bool read_file(const std::string& path, std::vector<uint8_t>& out) {
   fclose(f);
   return ok;
 }
+// ---------------------------------------------------------------- JPEG -> BGR (what cv::imread(path) returns)
+// Baseline / extended sequential Huffman JPEG (SOF0 / SOF1, 8 bit, 1 or 3 components, sampling factors 1 or 2, restart
+// intervals), decoded the way libjpeg (which cv::imread calls with its defaults) decodes it: dequantisation in natural
+// order, the accurate integer inverse DCT (jidctint.c "islow": 13-bit constants, PASS1_BITS 2, range-limit table), "fancy"
+// triangle-filter upsampling of 2:1 subsampled chroma (jdsample.c: h2v1 (3 a + b + 1|2) >> 2, h2v2 (3 (3 a + b) + (3 c + d)
+// + 8|7) >> 4, edge rows / columns replicated), YCbCr -> RGB with the 16-bit fixed-point tables of jdcolor.c.  Checked
+// against PIL's decoder (libjpeg-turbo, same algorithms) on generated files (tests/test_host_io.py).  Not decoded:
+// progressive (SOF2), arithmetic coding, 12 bit, CMYK -- the load fails with a message, as cv::imread would return an
+// empty Mat for a file its libjpeg cannot read.
+struct JpegHuff {
+  uint8_t bits[17];
+  uint8_t vals[256];
+  int mincode[17], maxcode[18], valptr[17];
+  bool present = false;
+  void build() {
+    int code = 0, k = 0;
+    for (int l = 1; l <= 16; ++l) {
+      valptr[l] = k;
+      mincode[l] = code;
+      code += bits[l];
+      k += bits[l];
+      maxcode[l] = bits[l] ? code - 1 : -1;
+      code <<= 1;
+    }
+    maxcode[17] = 0x7fffffff;
+  }
+};
+struct JpegBits {
+  const uint8_t* p;
+  size_t n, pos;
+  uint32_t acc = 0;
+  int cnt = 0;
+  bool hit_marker = false;
+  void fill() {
+    while (cnt <= 24) {
+      int b = 0;
+      if (!hit_marker && pos < n) {
+        b = p[pos];
+        if (b == 0xFF) {
+          const int b2 = pos + 1 < n ? p[pos + 1] : 0xD9;
+          if (b2 == 0) pos += 2;          // stuffed zero
+          else { hit_marker = true; b = 0; }  // a marker: feed zeros (libjpeg does the same past the data)
+        } else ++pos;
+      }
+      acc |= (uint32_t)b << (24 - cnt);
+      cnt += 8;
+    }
+  }
+  int get(int nb) {
+    if (nb == 0) return 0;
+    fill();
+    const int v = (int)(acc >> (32 - nb));
+    acc <<= nb;
+    cnt -= nb;
+    return v;
+  }
+  int decode(const JpegHuff& h) {
+    fill();
+    int code = 0;
+    for (int l = 1; l <= 16; ++l) {
+      code = (code << 1) | (int)(acc >> 31);
+      acc <<= 1;
+      --cnt;
+      if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
+    }
+    return -1;
+  }
+  void reset() { acc = 0; cnt = 0; hit_marker = false; }
+};
+inline int jpeg_extend(int v, int nb) { return v < (1 << (nb - 1)) ? v - (1 << nb) + 1 : v; }
+inline uint8_t jpeg_range_limit(int x) {  // libjpeg's range_limit[(x) & RANGE_MASK] for the IDCT output (+128)
+  const int i = x & 1023;
+  return (uint8_t)(i < 128 ? i + 128 : i < 512 ? 255 : i < 896 ? 0 : i - 896);
+}
+// jidctint.c jpeg_idct_islow on one dequantised block (natural order) -> 8 x 8 samples
+void jpeg_idct_islow(const int* in, uint8_t* out, int stride) {
+  constexpr int CB = 13, P1 = 2;
+  constexpr long F_0_298631336 = 2446, F_0_390180644 = 3196, F_0_541196100 = 4433, F_0_765366865 = 6270, F_0_899976223 = 7373,
+                 F_1_175875602 = 9633, F_1_501321110 = 12299, F_1_847759065 = 15137, F_1_961570560 = 16069,
+                 F_2_053119869 = 16819, F_2_562915447 = 20995, F_3_072711026 = 25172;
+  auto descale = [](long x, int n) { return (x + (1L << (n - 1))) >> n; };  // (arithmetic shift of a negative value: as libjpeg's RIGHT_SHIFT)
+  long ws[64];
+  for (int c = 0; c < 8; ++c) {
+    const int* ip = in + c;
+    if (!ip[8] && !ip[16] && !ip[24] && !ip[32] && !ip[40] && !ip[48] && !ip[56]) {
+      const long dc = (long)ip[0] * (1L << P1);
+      for (int r = 0; r < 8; ++r) ws[8 * r + c] = dc;
+      continue;
+    }
+    long z2 = ip[16], z3 = ip[48];
+    long z1 = (z2 + z3) * F_0_541196100;
+    long tmp2 = z1 + z3 * (-F_1_847759065), tmp3 = z1 + z2 * F_0_765366865;
+    z2 = ip[0];
+    z3 = ip[32];
+    long tmp0 = (z2 + z3) * (1L << CB), tmp1 = (z2 - z3) * (1L << CB);  // (a multiplication: shifting a negative value left is undefined)
+    const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = ip[56];
+    tmp1 = ip[40];
+    tmp2 = ip[24];
+    tmp3 = ip[8];
+    z1 = tmp0 + tmp3;
+    z2 = tmp1 + tmp2;
+    z3 = tmp0 + tmp2;
+    long z4 = tmp1 + tmp3;
+    const long z5 = (z3 + z4) * F_1_175875602;
+    tmp0 *= F_0_298631336;
+    tmp1 *= F_2_053119869;
+    tmp2 *= F_3_072711026;
+    tmp3 *= F_1_501321110;
+    z1 *= -F_0_899976223;
+    z2 *= -F_2_562915447;
+    z3 *= -F_1_961570560;
+    z4 *= -F_0_390180644;
+    z3 += z5;
+    z4 += z5;
+    tmp0 += z1 + z3;
+    tmp1 += z2 + z4;
+    tmp2 += z2 + z3;
+    tmp3 += z1 + z4;
+    ws[c] = descale(tmp10 + tmp3, CB - P1);
+    ws[56 + c] = descale(tmp10 - tmp3, CB - P1);
+    ws[8 + c] = descale(tmp11 + tmp2, CB - P1);
+    ws[48 + c] = descale(tmp11 - tmp2, CB - P1);
+    ws[16 + c] = descale(tmp12 + tmp1, CB - P1);
+    ws[40 + c] = descale(tmp12 - tmp1, CB - P1);
+    ws[24 + c] = descale(tmp13 + tmp0, CB - P1);
+    ws[32 + c] = descale(tmp13 - tmp0, CB - P1);
+  }
+  for (int r = 0; r < 8; ++r) {
+    const long* w = ws + 8 * r;
+    uint8_t* o = out + (size_t)r * stride;
+    long z2 = w[2], z3 = w[6];
+    long z1 = (z2 + z3) * F_0_541196100;
+    long tmp2 = z1 + z3 * (-F_1_847759065), tmp3 = z1 + z2 * F_0_765366865;
+    long tmp0 = (w[0] + w[4]) * (1L << CB), tmp1 = (w[0] - w[4]) * (1L << CB);
+    const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = w[7];
+    tmp1 = w[5];
+    tmp2 = w[3];
+    tmp3 = w[1];
+    z1 = tmp0 + tmp3;
+    z2 = tmp1 + tmp2;
+    z3 = tmp0 + tmp2;
+    long z4 = tmp1 + tmp3;
+    const long z5 = (z3 + z4) * F_1_175875602;
+    tmp0 *= F_0_298631336;
+    tmp1 *= F_2_053119869;
+    tmp2 *= F_3_072711026;
+    tmp3 *= F_1_501321110;
+    z1 *= -F_0_899976223;
+    z2 *= -F_2_562915447;
+    z3 *= -F_1_961570560;
+    z4 *= -F_0_390180644;
+    z3 += z5;
+    z4 += z5;
+    tmp0 += z1 + z3;
+    tmp1 += z2 + z4;
+    tmp2 += z2 + z3;
+    tmp3 += z1 + z4;
+    constexpr int SH = CB + P1 + 3;
+    o[0] = jpeg_range_limit((int)descale(tmp10 + tmp3, SH));
+    o[7] = jpeg_range_limit((int)descale(tmp10 - tmp3, SH));
+    o[1] = jpeg_range_limit((int)descale(tmp11 + tmp2, SH));
+    o[6] = jpeg_range_limit((int)descale(tmp11 - tmp2, SH));
+    o[2] = jpeg_range_limit((int)descale(tmp12 + tmp1, SH));
+    o[5] = jpeg_range_limit((int)descale(tmp12 - tmp1, SH));
+    o[3] = jpeg_range_limit((int)descale(tmp13 + tmp0, SH));
+    o[4] = jpeg_range_limit((int)descale(tmp13 - tmp0, SH));
+  }
+}
+
+bool decode_jpeg(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) {
+  static const uint8_t zz[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                 41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+  if (f.size() < 4 || f[0] != 0xFF || f[1] != 0xD8) {
+    why = "not a JPEG file";
+    return false;
+  }
+  uint16_t qt[4][64];
+  bool qt_set[4] = {false, false, false, false};
+  JpegHuff hdc[4], hac[4];
+  struct Comp {
+    int id, h, v, tq, td, ta;
+    int bw, bh;  // blocks per row / column of the padded plane
+    int dw, dhh; // downsampled_width / height (true sizes)
+    std::vector<uint8_t> plane;
+  } comp[3];
+  int ncomp = 0, width = 0, height = 0, restart = 0, adobe_transform = -1;
+  bool have_sof = false;
+  size_t pos = 2;
+  size_t scan_at = 0;
+  while (pos + 4 <= f.size()) {
+    if (f[pos] != 0xFF) {
+      why = "corrupt JPEG (marker expected)";
+      return false;
+    }
+    const int mk = f[pos + 1];
+    if (mk == 0xFF) {
+      ++pos;
+      continue;
+    }
+    if (mk == 0xD8 || (mk >= 0xD0 && mk <= 0xD7) || mk == 0x01) {
+      pos += 2;
+      continue;
+    }
+    const size_t len = ((size_t)f[pos + 2] << 8) | f[pos + 3];
+    if (len < 2 || pos + 2 + len > f.size()) {
+      why = "truncated JPEG segment";
+      return false;
+    }
+    const uint8_t* d = &f[pos + 4];
+    const size_t dl = len - 2;
+    if (mk == 0xDB) {  // DQT
+      size_t o = 0;
+      while (o < dl) {
+        const int pq = d[o] >> 4, tq = d[o] & 15;
+        ++o;
+        if (tq > 3 || o + (pq ? 128 : 64) > dl) {
+          why = "corrupt quantisation table";
+          return false;
+        }
+        for (int k = 0; k < 64; ++k) {
+          qt[tq][zz[k]] = pq ? (uint16_t)((d[o] << 8) | d[o + 1]) : d[o];
+          o += pq ? 2 : 1;
+        }
+        qt_set[tq] = true;
+      }
+    } else if (mk == 0xC4) {  // DHT
+      size_t o = 0;
+      while (o + 17 <= dl) {
+        const int tc = d[o] >> 4, th = d[o] & 15;
+        if (tc > 1 || th > 3) {
+          why = "corrupt Huffman table";
+          return false;
+        }
+        JpegHuff& h = tc ? hac[th] : hdc[th];
+        int total = 0;
+        h.bits[0] = 0;
+        for (int l = 1; l <= 16; ++l) total += (h.bits[l] = d[o + l]);
+        o += 17;
+        if (total > 256 || o + total > dl) {
+          why = "corrupt Huffman table";
+          return false;
+        }
+        memcpy(h.vals, d + o, total);
+        o += total;
+        h.build();
+        h.present = true;
+      }
+    } else if (mk == 0xC0 || mk == 0xC1) {  // SOF0 / SOF1
+      if (dl < 6 || d[0] != 8) {
+        why = "unsupported JPEG sample precision";
+        return false;
+      }
+      height = (d[1] << 8) | d[2];
+      width = (d[3] << 8) | d[4];
+      ncomp = d[5];
+      if ((ncomp != 1 && ncomp != 3) || dl < 6 + 3 * (size_t)ncomp || !width || !height) {
+        why = "unsupported JPEG component count";
+        return false;
+      }
+      for (int c = 0; c < ncomp; ++c) {
+        comp[c].id = d[6 + 3 * c];
+        comp[c].h = d[7 + 3 * c] >> 4;
+        comp[c].v = d[7 + 3 * c] & 15;
+        comp[c].tq = d[8 + 3 * c];
+        if (comp[c].h < 1 || comp[c].h > 2 || comp[c].v < 1 || comp[c].v > 2 || comp[c].tq > 3) {
+          why = "unsupported JPEG sampling factors";
+          return false;
+        }
+      }
+      have_sof = true;
+    } else if (mk == 0xC2 || (mk >= 0xC3 && mk <= 0xCF && mk != 0xC4 && mk != 0xC8 && mk != 0xCC)) {
+      why = mk == 0xC2 ? "progressive JPEG (not supported)" : "unsupported JPEG coding process";
+      return false;
+    } else if (mk == 0xDD) {
+      if (dl >= 2) restart = (d[0] << 8) | d[1];
+    } else if (mk == 0xEE) {
+      if (dl >= 12 && !memcmp(d, "Adobe", 5)) adobe_transform = d[11];
+    } else if (mk == 0xDA) {  // SOS: one interleaved scan over all components is what the encoder of such files writes
+      if (!have_sof || dl < 1 || d[0] != ncomp || dl < 1 + 2 * (size_t)ncomp + 3) {
+        why = "unsupported JPEG scan layout";
+        return false;
+      }
+      for (int k = 0; k < ncomp; ++k) {
+        int c = -1;
+        for (int j = 0; j < ncomp; ++j)
+          if (comp[j].id == d[1 + 2 * k]) c = j;
+        if (c != k) {
+          why = "unsupported JPEG scan layout";
+          return false;
+        }
+        comp[c].td = d[2 + 2 * k] >> 4;
+        comp[c].ta = d[2 + 2 * k] & 15;
+        if (comp[c].td > 3 || comp[c].ta > 3 || !hdc[comp[c].td].present || !hac[comp[c].ta].present || !qt_set[comp[c].tq]) {
+          why = "JPEG scan refers to a missing table";
+          return false;
+        }
+      }
+      scan_at = pos + 2 + len;
+      break;
+    } else if (mk == 0xD9) {
+      break;
+    }
+    pos += 2 + len;
+  }
+  if (!scan_at) {
+    why = "JPEG without a scan";
+    return false;
+  }
+  if ((size_t)width * height > ((size_t)1 << 28)) {
+    why = "image too large";
+    return false;
+  }
+  int hmax = 1, vmax = 1;
+  for (int c = 0; c < ncomp; ++c) hmax = std::max(hmax, comp[c].h), vmax = std::max(vmax, comp[c].v);
+  if (ncomp == 1) comp[0].h = comp[0].v = hmax = vmax = 1;  // (a single-component scan is not interleaved: 1 x 1 blocks)
+  const int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
+  for (int c = 0; c < ncomp; ++c) {
+    comp[c].bw = mcux * comp[c].h;
+    comp[c].bh = mcuy * comp[c].v;
+    comp[c].dw = (width * comp[c].h + hmax - 1) / hmax;
+    comp[c].dhh = (height * comp[c].v + vmax - 1) / vmax;
+    comp[c].plane.assign((size_t)comp[c].bw * 8 * comp[c].bh * 8, 0);
+  }
+  // ---- entropy-coded data: MCU by MCU
+  JpegBits br{f.data(), f.size(), scan_at};
+  int pred[3] = {0, 0, 0}, until_restart = restart;
+  for (int my = 0; my < mcuy; ++my)
+    for (int mx = 0; mx < mcux; ++mx) {
+      if (restart && until_restart == 0) {
+        // byte-align, expect RSTn
+        br.reset();
+        while (br.pos + 1 < f.size() && !(f[br.pos] == 0xFF && f[br.pos + 1] >= 0xD0 && f[br.pos + 1] <= 0xD7)) ++br.pos;
+        br.pos += 2;
+        pred[0] = pred[1] = pred[2] = 0;
+        until_restart = restart;
+      }
+      for (int c = 0; c < ncomp; ++c)
+        for (int by = 0; by < comp[c].v; ++by)
+          for (int bx = 0; bx < comp[c].h; ++bx) {
+            int blk[64];
+            memset(blk, 0, sizeof blk);
+            const int t = br.decode(hdc[comp[c].td]);
+            if (t < 0 || t > 11) {
+              why = "corrupt JPEG data (DC code)";
+              return false;
+            }
+            const int diff = t ? jpeg_extend(br.get(t), t) : 0;
+            pred[c] = std::max(-(1 << 20), std::min(1 << 20, pred[c] + diff));  // (a corrupt stream must not overflow; real DC values fit 12 bits)
+            blk[0] = (int)std::max(-(1L << 26), std::min(1L << 26, (long)pred[c] * qt[comp[c].tq][0]));
+            for (int k = 1; k < 64;) {
+              const int rs = br.decode(hac[comp[c].ta]);
+              if (rs < 0) {
+                why = "corrupt JPEG data (AC code)";
+                return false;
+              }
+              const int r = rs >> 4, sz = rs & 15;
+              if (sz == 0) {
+                if (r != 15) break;  // EOB
+                k += 16;
+                continue;
+              }
+              k += r;
+              if (k > 63) {
+                why = "corrupt JPEG data (run past the block)";
+                return false;
+              }
+              blk[zz[k]] = (int)std::max(-(1L << 26), std::min(1L << 26, (long)jpeg_extend(br.get(sz), sz) * qt[comp[c].tq][zz[k]]));
+              ++k;
+            }
+            const int px = (mx * comp[c].h + bx) * 8, py = (my * comp[c].v + by) * 8;
+            jpeg_idct_islow(blk, &comp[c].plane[(size_t)py * comp[c].bw * 8 + px], comp[c].bw * 8);
+          }
+      if (restart) --until_restart;
+    }
+  // ---- upsampling (jdsample.c) to full resolution planes of width x height
+  std::vector<uint8_t> full[3];
+  for (int c = 0; c < ncomp; ++c) {
+    const int hs = hmax / comp[c].h, vs = vmax / comp[c].v;  // expansion factors: 1 or 2
+    const int W = comp[c].dw, Hh = comp[c].dhh, pitch = comp[c].bw * 8;
+    const uint8_t* src = comp[c].plane.data();
+    full[c].assign((size_t)width * height, 0);
+    const bool fancy = W > 2;  // (libjpeg: fancy upsampling only when the component is more than two samples wide)
+    for (int y = 0; y < height; ++y) {
+      uint8_t* o = &full[c][(size_t)y * width];
+      if (hs == 1 && vs == 1) {
+        memcpy(o, src + (size_t)y * pitch, width);
+      } else if (hs == 2 && vs == 1) {
+        const uint8_t* in = src + (size_t)y * pitch;
+        for (int x = 0; x < width; ++x) {
+          const int i = x >> 1;
+          if (!fancy) o[x] = in[i];
+          else if ((x & 1) == 0) o[x] = i == 0 ? in[0] : (uint8_t)((in[i] * 3 + in[i - 1] + 1) >> 2);
+          else o[x] = i == W - 1 ? in[i] : (uint8_t)((in[i] * 3 + in[i + 1] + 2) >> 2);
+        }
+      } else if (hs == 2 && vs == 2 && fancy) {
+        const int iy = y >> 1, ny = (y & 1) ? std::min(iy + 1, Hh - 1) : std::max(iy - 1, 0);
+        const uint8_t* in0 = src + (size_t)iy * pitch;
+        const uint8_t* in1 = src + (size_t)ny * pitch;
+        for (int x = 0; x < width; ++x) {
+          const int i = x >> 1;
+          const int cur = in0[i] * 3 + in1[i];
+          if ((x & 1) == 0) {
+            if (i == 0) o[x] = (uint8_t)((cur * 4 + 8) >> 4);
+            else o[x] = (uint8_t)((cur * 3 + (in0[i - 1] * 3 + in1[i - 1]) + 8) >> 4);
+          } else {
+            if (i == W - 1) o[x] = (uint8_t)((cur * 4 + 7) >> 4);
+            else o[x] = (uint8_t)((cur * 3 + (in0[i + 1] * 3 + in1[i + 1]) + 7) >> 4);
+          }
+        }
+      } else {  // replication (h1v2, or a component too narrow for the triangle filter)
+        const uint8_t* in = src + (size_t)(y / vs) * pitch;
+        for (int x = 0; x < width; ++x) o[x] = in[x / hs];
+      }
+    }
+  }
+  // ---- colour conversion (jdcolor.c): gray -> B = G = R; YCbCr -> RGB with the 16-bit tables
+  bgr = cv::Mat(height, width, CV_8UC3);
+  uint8_t* out = bgr.ptr();
+  if (ncomp == 1) {
+    for (size_t i = 0; i < (size_t)width * height; ++i) out[3 * i] = out[3 * i + 1] = out[3 * i + 2] = full[0][i];
+    return true;
+  }
+  if (adobe_transform == 0) {  // Adobe marker: components are R, G, B
+    for (size_t i = 0; i < (size_t)width * height; ++i) {
+      out[3 * i] = full[2][i];
+      out[3 * i + 1] = full[1][i];
+      out[3 * i + 2] = full[0][i];
+    }
+    return true;
+  }
+  int cr_r[256], cb_b[256];
+  long cr_g[256], cb_g[256];
+  for (int i = 0; i < 256; ++i) {
+    const long x = i - 128;
+    cr_r[i] = (int)((91881L * x + 32768) >> 16);   // FIX(1.40200)
+    cb_b[i] = (int)((116130L * x + 32768) >> 16);  // FIX(1.77200)
+    cr_g[i] = -46802L * x;                         // FIX(0.71414)
+    cb_g[i] = -22554L * x + 32768;                 // FIX(0.34414) + ONE_HALF
+  }
+  auto clamp8 = [](int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); };
+  for (size_t i = 0; i < (size_t)width * height; ++i) {
+    const int y = full[0][i], cb = full[1][i], cr = full[2][i];
+    out[3 * i + 2] = clamp8(y + cr_r[cr]);
+    out[3 * i + 1] = clamp8(y + (int)((cb_g[cb] + cr_g[cr]) >> 16));
+    out[3 * i] = clamp8(y + cb_b[cb]);
+  }
+  return true;
+}
+
 std::string lower_ext(const std::string& p) {
   const size_t dot = p.find_last_of('.'), slash = p.find_last_of('/');
   if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) return "";
@@ -524,12 +976,8 @@ bool StructFromMotion::imagesLOAD(const std::string& directoryPath) {
     cv::Mat image;
     std::string why = "cannot read the file";
     bool ok = read_file(imageFilename, bytes);
-    if (ok && lower_ext(imageFilename) == ".jpg") {
-      ok = false;
-      why = "JPEG decoding is not part of this build";
-    } else if (ok) {
-      ok = decode_png(bytes, image, why);
-    }
+    if (ok && lower_ext(imageFilename) == ".jpg") ok = decode_jpeg(bytes, image, why);
+    else if (ok) ok = decode_png(bytes, image, why);
     if (!ok) {  // cv::imread returns an empty Mat; the reference then reports and fails (:158-161)
       std::cerr << "[x]" << "\n" << "Unable to read image from file: " << imageFilename << " (" << why << ")" << std::endl;
       return false;

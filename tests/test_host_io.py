@@ -328,3 +328,63 @@ def test_ply_to_pcd_conversion(tmp_path, binary):
     assert int(r.stdout) == 0
     r = subprocess.run([exe, "--ply2pcd", str(tmp_path / "none.ply"), str(tmp_path / "e.pcd")], capture_output=True, text=True, timeout=60)
     assert int(r.stdout) == 0
+
+
+def _jpeg_cases(rng):
+    yy, xx = np.mgrid[0:97, 0:131]
+    smooth = np.stack([128 + 100 * np.sin(xx / 9.0) * np.cos(yy / 13.0), 90 + 80 * np.cos(xx / 5.0 + yy / 7.0), 40 + yy * 1.5 + xx * 0.3], 2)
+    noisy = np.clip(smooth + rng.normal(0, 25, smooth.shape), 0, 255).astype(np.uint8)
+    smooth = np.clip(smooth, 0, 255).astype(np.uint8)
+    return [("a_444.jpg", smooth, dict(quality=92, subsampling=0)),
+            ("b_420.jpg", noisy, dict(quality=75, subsampling=2)),
+            ("c_422.jpg", noisy, dict(quality=60, subsampling=1)),
+            ("d_420_rst.jpg", smooth, dict(quality=85, subsampling=2, restart_marker_blocks=3)),
+            ("e_gray.jpg", noisy[:, :, 1], dict(quality=80)),
+            ("f_420_odd.jpg", noisy[:33, :17], dict(quality=95, subsampling=2)),          # odd sizes, two chroma columns wide ... nine
+            ("g_tiny.jpg", noisy[:5, :3], dict(quality=90, subsampling=2)),               # chroma two samples wide: no triangle filter
+            ("h_q100.jpg", rng.integers(0, 256, (64, 64, 3), dtype=np.uint8), dict(quality=100, subsampling=0)),   # saturating IDCT outputs
+            ("i_big_420.jpg", np.clip(rng.normal(128, 70, (481, 641, 3)), 0, 255).astype(np.uint8), dict(quality=70, subsampling=2))]
+
+
+def test_jpeg_decoder_matches_libjpeg(tmp_path):
+    """imagesLOAD takes .jpg too (reference src/Sfm.cpp:129-135): the mirror's baseline JPEG decoder against PIL's
+    (libjpeg-turbo with libjpeg's defaults: the accurate integer IDCT, fancy upsampling, the fixed-point YCbCr tables --
+    what cv::imread runs) on generated files: 4:4:4 / 4:2:2 / 4:2:0, restart intervals, grayscale, odd and tiny sizes,
+    saturating blocks, and one frame larger than 640 x 480 (which imagesLOAD then resizes by 0.6).  Byte for byte."""
+    rng = np.random.default_rng(7)
+    d = tmp_path / "jpgs"
+    d.mkdir()
+    cases = _jpeg_cases(rng)
+    for name, arr, kw in cases:
+        PIL.fromarray(arr).save(d / name, "JPEG", **kw)
+    (tmp_path / "cam.xml").write_text(XML)
+    ok_img, ok_cal, imgs, *_ = _run(tmp_path, d, tmp_path / "cam.xml")
+    assert ok_img == 1 and len(imgs) == len(cases)
+    for (name, arr, kw), (bgr, gray) in zip(cases, imgs):
+        want = _pil_bgr(d / name)
+        if want.shape[0] > 480 and want.shape[1] > 640:
+            want = _cv_resize_linear_u8(want, 0.6, 0.6)
+        assert bgr.shape == want.shape, name
+        assert np.array_equal(bgr, want), (name, int(np.abs(bgr.astype(int) - want.astype(int)).max()), float((bgr != want).mean()))
+        assert np.array_equal(gray, _cv_gray(bgr)), name
+
+
+def test_jpeg_failures_are_reported(tmp_path):
+    rng = np.random.default_rng(8)
+    (tmp_path / "cam.xml").write_text(XML)
+    arr = rng.integers(0, 256, (40, 40, 3), dtype=np.uint8)
+    for tag, mutate in (("prog", None), ("trunc", lambda b: b[:len(b) // 2]), ("garbage", lambda b: b"\xff\xd8" + b"junk" * 20)):
+        d = tmp_path / tag
+        d.mkdir()
+        PIL.fromarray(arr).save(d / "ok.png")
+        import io
+        buf = io.BytesIO()
+        PIL.fromarray(arr).save(buf, "JPEG", quality=80, progressive=(tag == "prog"))
+        data = buf.getvalue() if mutate is None else mutate(buf.getvalue())
+        (d / "x.jpg").write_bytes(data)
+        ok_img, _, _, _, _, r = _run(tmp_path, d, tmp_path / "cam.xml")
+        if tag == "trunc":
+            # (libjpeg pads a truncated scan with zeros and warns; the mirror decodes what is there the same way)
+            assert ok_img in (0, 1)
+        else:
+            assert ok_img == 0 and "Unable to read image" in r.stderr, tag

@@ -65,3 +65,39 @@ def test_host_io_under_asan_ubsan(tmp_path):
         r = subprocess.run([exe, str(bad), str(tmp_path / "cam.xml"), str(tmp_path / "o.bin")], capture_output=True, text=True,
                            timeout=600, env=ENV, cwd=tmp_path)
         _clean(r)
+
+
+def test_jpeg_decoder_under_asan_ubsan(tmp_path):
+    """the JPEG decoder of imagesLOAD on good, truncated and bit-flipped streams (headers, tables and entropy-coded data
+    alike): it fails cleanly or decodes garbage pixels, never reads or writes out of bounds"""
+    import io
+    import numpy as np
+    from PIL import Image
+    from tests import test_host_io as hio
+    _build()
+    exe = os.path.join(ROOT, "oracle", "_asan", "io_selftest_asan")
+    (tmp_path / "cam.xml").write_text(hio.XML)
+    rng = np.random.default_rng(10)
+    arr = np.clip(rng.normal(128, 60, (70, 90, 3)), 0, 255).astype(np.uint8)
+    goods = []
+    for kw in (dict(quality=80, subsampling=2), dict(quality=90, subsampling=0, restart_marker_blocks=2), dict(quality=70, subsampling=1)):
+        b = io.BytesIO()
+        Image.fromarray(arr).save(b, "JPEG", **kw)
+        goods.append(b.getvalue())
+    for k in range(36):
+        good = goods[k % 3]
+        bad = tmp_path / ("jbad%d" % k)
+        bad.mkdir()
+        (bad / "a.jpg").write_bytes(good)
+        b = bytearray(good)
+        if k % 4 == 0:
+            b = b[:int(rng.integers(4, len(b)))]
+        else:
+            lo = 2 if k % 4 == 1 else len(b) // 2            # headers / tables, or the scan
+            for _ in range(1 + k % 7):
+                b[int(rng.integers(lo, len(b)))] ^= int(rng.integers(1, 256))
+        (bad / "b.jpg").write_bytes(bytes(b))
+        r = subprocess.run([exe, str(bad), str(tmp_path / "cam.xml"), str(tmp_path / "o.bin")], capture_output=True, text=True,
+                           timeout=600, env=ENV, cwd=tmp_path)
+        bad_msgs = [m for m in ("ERROR: AddressSanitizer", "ERROR: LeakSanitizer", "runtime error:") if m in r.stderr]
+        assert not bad_msgs and r.returncode == 0, r.stderr[-3000:]
