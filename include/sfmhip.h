@@ -227,6 +227,9 @@ int sfmhip_score_five_point(sfmhip_ctx* ctx, int n_samples, const double* q1, co
  * confidence / max_iters as given (findHomography's defaults: 0.995, 2000); the mask is the RANSAC mask.
  * thresholds: one per pair (the reference: 0.004 * the largest coordinate among the pair's query points; <= 0: 3).
  * Pairs with fewer than 4 matches score 0.  Parity unpinned, like sfmhip_score_essential. */
+/* HomographyEstimatorCallback::runKernel (OpenCV 3.4.1 calib3d/fundam.cpp) for explicit samples: M / m = n_samples x four
+ * float points (x, y); H: n_samples x 9 doubles (scaled by 1 / H[8], as the library does); ok[i] = 0 for a degenerate sample.  For sample-level parity checks. */
+int sfmhip_score_homography_kernel(sfmhip_ctx* ctx, int n_samples, const float* M, const float* m, double* H, int32_t* ok);
 int sfmhip_score_homography(sfmhip_ctx* ctx, int n_pairs, const int32_t* offsets, const double* left_xy,
                             const double* right_xy, const double* thresholds, double confidence, int max_iters,
                             int32_t* inliers, uint8_t* mask, int32_t* iterations);

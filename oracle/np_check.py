@@ -239,3 +239,149 @@ def five_point_action_matrix(q1, q2):
         x, y, z = v[6] / v[9], v[7] / v[9], v[8] / v[9]
         sols.append(x * X + y * Y + z * Z + W)
     return canonical_order(sols)
+
+
+# ------------------------------------------------------------------ cv::findHomography(RANSAC), numpy route
+# (an independent check of the C restatement in oracle/sfm_oracle_score.c: the same bookkeeping, numpy's eigh where the
+# library -- and the C restatement -- run cv::eigen's Jacobi)
+class _CvRNG:
+    def __init__(self, state=(1 << 64) - 1):
+        self.state = state & ((1 << 64) - 1)
+
+    def next(self):
+        self.state = ((self.state & 0xFFFFFFFF) * 4164903690 + (self.state >> 32)) & ((1 << 64) - 1)
+        return self.state & 0xFFFFFFFF
+
+    def uniform(self, a, b):
+        return a if a == b else a + self.next() % (b - a)
+
+
+def _get_subset(rng, count, model_points):
+    idx = []
+    while len(idx) < model_points:
+        while True:
+            v = rng.uniform(0, count)
+            if v not in idx:
+                break
+        idx.append(v)
+    return idx
+
+
+def _ransac_update_num_iters(p, ep, model_points, max_iters):
+    p = min(max(p, 0.0), 1.0)
+    ep = min(max(ep, 0.0), 1.0)
+    num = max(1.0 - p, np.finfo(np.float64).tiny)
+    denom = 1.0 - (1.0 - ep) ** model_points
+    if denom < np.finfo(np.float64).tiny:
+        return 0
+    num, denom = np.log(num), np.log(denom)
+    if denom >= 0 or -num >= max_iters * (-denom):
+        return max_iters
+    return int(np.rint(num / denom))
+
+
+FLT_EPSILON = float(np.finfo(np.float32).eps)
+
+
+def _have_collinear(p, count):
+    i = count - 1
+    for j in range(i):
+        dx1, dy1 = float(p[j][0]) - float(p[i][0]), float(p[j][1]) - float(p[i][1])
+        for k in range(j):
+            dx2, dy2 = float(p[k][0]) - float(p[i][0]), float(p[k][1]) - float(p[i][1])
+            if abs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (abs(dx1) + abs(dy1) + abs(dx2) + abs(dy2)):
+                return True
+    return False
+
+
+def homography_check_subset(s1, s2):
+    """HomographyEstimatorCallback::checkSubset for four float correspondences"""
+    if _have_collinear(s1, 4) or _have_collinear(s2, 4):
+        return False
+    negative = 0
+    for t in ((0, 1, 2), (1, 2, 3), (0, 2, 3), (0, 1, 3)):
+        A = np.array([[s1[k][0], s1[k][1], 1.0] for k in t], np.float64)
+        B = np.array([[s2[k][0], s2[k][1], 1.0] for k in t], np.float64)
+        negative += _det3(A) * _det3(B) < 0
+    return negative in (0, 4)
+
+
+def _det3(m):          # cv::determinant for Matx33d: cofactor expansion along the first row
+    return (m[0, 0] * (m[1, 1] * m[2, 2] - m[1, 2] * m[2, 1]) - m[0, 1] * (m[1, 0] * m[2, 2] - m[1, 2] * m[2, 0])
+            + m[0, 2] * (m[1, 0] * m[2, 1] - m[1, 1] * m[2, 0]))
+
+
+def homography_subset(rng, m1, m2, max_attempts=10000):
+    count = len(m1)
+    for _ in range(max_attempts):
+        idx = _get_subset(rng, count, 4)
+        if homography_check_subset(m1[idx], m2[idx]):
+            return idx
+    return None
+
+
+def homography_kernel_np(M, m):
+    """HomographyEstimatorCallback::runKernel: M -> m, float points in, 3x3 double out (None if degenerate)"""
+    M = M.astype(np.float64)
+    m = m.astype(np.float64)
+    n = len(M)
+    cM, cm = M.sum(0) / n, m.sum(0) / n
+    sM, sm = np.abs(M - cM).sum(0), np.abs(m - cm).sum(0)
+    eps = np.finfo(np.float64).eps
+    if min(abs(sm[0]), abs(sm[1]), abs(sM[0]), abs(sM[1])) < eps:
+        return None
+    sm, sM = n / sm, n / sM
+    inv_hnorm = np.array([[1.0 / sm[0], 0, cm[0]], [0, 1.0 / sm[1], cm[1]], [0, 0, 1]])
+    hnorm2 = np.array([[sM[0], 0, -cM[0] * sM[0]], [0, sM[1], -cM[1] * sM[1]], [0, 0, 1]])
+    LtL = np.zeros((9, 9))
+    for i in range(n):
+        x, y = (m[i] - cm) * sm
+        X, Y = (M[i] - cM) * sM
+        Lx = np.array([X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x])
+        Ly = np.array([0, 0, 0, X, Y, 1, -y * X, -y * Y, -y])
+        LtL += np.outer(Lx, Lx) + np.outer(Ly, Ly)
+    w, V = np.linalg.eigh(LtL)
+    H0 = V[:, 0].reshape(3, 3)                  # the smallest eigenvalue's vector (cv::eigen sorts descending: row 8)
+    H = inv_hnorm @ H0 @ hnorm2
+    return H / H[2, 2]
+
+
+def homography_error(H, M, m):
+    """computeError: float arithmetic throughout"""
+    Hf = H.astype(np.float32).reshape(-1)
+    Mx, My, mx, my = (a.astype(np.float32) for a in (M[:, 0], M[:, 1], m[:, 0], m[:, 1]))
+    one = np.float32(1.0)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        ww = one / (Hf[6] * Mx + Hf[7] * My + one)
+        dx = (Hf[0] * Mx + Hf[1] * My + Hf[2]) * ww - mx
+        dy = (Hf[3] * Mx + Hf[4] * My + Hf[5]) * ww - my
+        return dx * dx + dy * dy
+
+
+def find_homography_ransac_np(pts1, pts2, threshold, confidence=0.995, max_iters=2000):
+    """(inlier count, mask, iterations run) of cv::findHomography(pts1, pts2, RANSAC, threshold, mask)"""
+    m1 = np.asarray(pts1, np.float64).reshape(-1, 2).astype(np.float32)
+    m2 = np.asarray(pts2, np.float64).reshape(-1, 2).astype(np.float32)
+    count = len(m1)
+    if threshold <= 0:
+        threshold = 3.0
+    if count < 4:
+        return 0, np.zeros(count, np.uint8), 0
+    if count == 4:
+        return (4, np.ones(4, np.uint8), 0) if homography_kernel_np(m1, m2) is not None else (0, np.zeros(4, np.uint8), 0)
+    t = np.float32(threshold * threshold)
+    rng = _CvRNG()
+    niters, best, best_mask, it = max(max_iters, 1), 0, np.zeros(count, np.uint8), 0
+    while it < niters:
+        idx = homography_subset(rng, m1, m2)
+        if idx is None:
+            break                                # (iter == 0: run() returns false; later: the loop ends)
+        H = homography_kernel_np(m1[idx], m2[idx])
+        if H is not None:
+            mask = homography_error(H, m1, m2) <= t
+            good = int(mask.sum())
+            if good > max(best, 3):
+                best, best_mask = good, mask.astype(np.uint8)
+                niters = _ransac_update_num_iters(confidence, (count - good) / count, 4, niters)
+        it += 1
+    return best, best_mask, it

@@ -124,6 +124,10 @@ def lib():
         L.orc_ransac_update_num_iters.restype = C.c_int
         L.orc_find_essential_mat.argtypes = [vp, vp, C.c_int, vp, C.c_double, C.c_double, C.c_int, vp, vp, vp, vp]
         L.orc_find_essential_mat.restype = C.c_int
+        L.orc_homography_kernel.argtypes = [vp, vp, C.c_int, vp]
+        L.orc_homography_kernel.restype = C.c_int
+        L.orc_find_homography.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, C.c_int, vp, vp]
+        L.orc_find_homography.restype = C.c_int
         L.orc_score_essential_many.argtypes = [C.c_int, vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, C.c_int, vp]
         L.orc_score_essential_many.restype = C.c_int
         _lib = L
@@ -484,3 +488,23 @@ def score_essential_many(offsets, left_xy, right_xy, K, prob=0.999, threshold=1.
                                         int(threads), C.byref(fl))
     assert rc == 0
     return cnt[:n], its[:n], (masks[:len(a)] if want_mask else None), fl.value
+
+
+def homography_kernel(M, m):
+    """HomographyEstimatorCallback::runKernel on float correspondences (n x 2 each): 3 x 3 H or None"""
+    M = np.ascontiguousarray(M, np.float32).reshape(-1, 2)
+    m = np.ascontiguousarray(m, np.float32).reshape(-1, 2)
+    H = np.zeros(9)
+    ok = lib().orc_homography_kernel(_p(M), _p(m), len(M), _p(H))
+    return H.reshape(3, 3) if ok else None
+
+
+def find_homography(pts1, pts2, threshold, confidence=0.995, max_iters=2000):
+    """cv::findHomography(pts1, pts2, RANSAC, threshold, mask): (inlier count, mask, iterations run)"""
+    a = np.ascontiguousarray(pts1, np.float64).reshape(-1, 2)
+    b = np.ascontiguousarray(pts2, np.float64).reshape(-1, 2)
+    mask = np.zeros(max(len(a), 1), np.uint8)
+    it = C.c_int(0)
+    cnt = lib().orc_find_homography(_p(a), _p(b), len(a), float(threshold), float(confidence), int(max_iters), _p(mask), C.byref(it))
+    return cnt, mask[:len(a)], it.value
+

@@ -144,6 +144,10 @@ void orc_em_normalize(const double* xy, int n, const double K[9], double* out);
 int orc_ransac_update_num_iters(double p, double ep, int model_points, int max_iters);
 int orc_find_essential_mat(const double* pts1, const double* pts2, int count, const double K[9], double prob,
                            double threshold, int max_iters, uint8_t* mask, double* E_out, int* iters, int* flags);
+/* findHomographyInliers (src/Sfm.cpp:667-689): cv::findHomography(RANSAC) as OpenCV 3.4.1 runs it -- see sfm_oracle_score.c */
+int orc_homography_kernel(const float* M, const float* m, int count, double* H);
+int orc_find_homography(const double* pts1, const double* pts2, int count, double threshold, double confidence, int max_iters,
+                        uint8_t* mask, int* iters);
 int orc_score_essential_many(int n_pairs, const int32_t* offsets, const double* left_xy, const double* right_xy,
                              const double K[9], double prob, double threshold, int32_t* counts, int32_t* iters,
                              uint8_t* masks, int threads, int32_t* flags_any);

@@ -532,3 +532,257 @@ int orc_score_essential_many(int n_pairs, const int32_t* offsets, const double* 
   if (flags_any) *flags_any = any;
   return 0;
 }
+
+/* ================================================================ findHomographyInliers (reference src/Sfm.cpp:667-689)
+ * cv::findHomography(query, train, CV_RANSAC, 0.004 * maxVal, mask) as OpenCV 3.4.1 (calib3d/fundam.cpp, ptsetreg.cpp,
+ * core/lapack.cpp) runs it: points converted to float; RANSAC with 4-point samples (getSubset redraws a sample that
+ * checkSubset rejects: the last point collinear with two others -- float differences, double products --, or the
+ * orientation of one of the four triples not preserved), confidence 0.995, at most 2000 iterations; runKernel =
+ * normalised DLT: L^T L (upper triangle accumulated, completeSymm), cv::eigen = JacobiImpl_<double> (pivot = the largest
+ * off-diagonal element, found through the row / column maximum indices; hypot-based rotation; eps = DBL_EPSILON,
+ * 30 n^2 rotations at most; eigenvalues sorted descending with their vector rows), H0 = the last row, H = invHnorm H0
+ * Hnorm2 by the 3 x 3 products' left-to-right sums, scaled by 1 / H[2][2]; the error and the threshold test in FLOAT
+ * arithmetic; the mask returned is the RANSAC mask (the refit on the inliers and the LM refinement change H only).
+ * PARITY UNPINNED like the rest of this file; one more unknown here: an OpenCV built WITH Eigen routes cv::eigen through
+ * Eigen::SelfAdjointEigenSolver instead of its own Jacobi. */
+static void jacobi_eigen9(double A[9][9], double W[9], double V[9][9]) {
+  const int n = 9;
+  const double eps = DBL_EPSILON;
+  int indR[9], indC[9];
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+  for (int k = 0; k < n; ++k) {
+    W[k] = A[k][k];
+    if (k < n - 1) {
+      int m = k + 1;
+      double mv = fabs(A[k][m]);
+      for (int i = k + 2; i < n; ++i) {
+        const double val = fabs(A[k][i]);
+        if (mv < val) mv = val, m = i;
+      }
+      indR[k] = m;
+    }
+    if (k > 0) {
+      int m = 0;
+      double mv = fabs(A[0][k]);
+      for (int i = 1; i < k; ++i) {
+        const double val = fabs(A[i][k]);
+        if (mv < val) mv = val, m = i;
+      }
+      indC[k] = m;
+    }
+  }
+  const int max_iters = n * n * 30;
+  for (int iters = 0; iters < max_iters; ++iters) {
+    int k = 0;
+    double mv = fabs(A[0][indR[0]]);
+    for (int i = 1; i < n - 1; ++i) {
+      const double val = fabs(A[i][indR[i]]);
+      if (mv < val) mv = val, k = i;
+    }
+    int l = indR[k];
+    for (int i = 1; i < n; ++i) {
+      const double val = fabs(A[indC[i]][i]);
+      if (mv < val) mv = val, k = indC[i], l = i;
+    }
+    const double p = A[k][l];
+    if (fabs(p) <= eps) break;
+    const double y = (W[l] - W[k]) * 0.5;
+    double t = fabs(y) + hypot(p, y);
+    double s = hypot(p, t);
+    const double c = t / s;
+    s = p / s;
+    t = (p / t) * p;
+    if (y < 0) s = -s, t = -t;
+    A[k][l] = 0;
+    W[k] -= t;
+    W[l] += t;
+    double a0, b0;
+#define ORC_ROT(v0, v1) a0 = v0, b0 = v1, v0 = a0 * c - b0 * s, v1 = a0 * s + b0 * c
+    for (int i = 0; i < k; ++i) ORC_ROT(A[i][k], A[i][l]);
+    for (int i = k + 1; i < l; ++i) ORC_ROT(A[k][i], A[i][l]);
+    for (int i = l + 1; i < n; ++i) ORC_ROT(A[k][i], A[l][i]);
+    for (int i = 0; i < n; ++i) ORC_ROT(V[k][i], V[l][i]);
+#undef ORC_ROT
+    for (int j = 0; j < 2; ++j) {
+      const int idx = j == 0 ? k : l;
+      if (idx < n - 1) {
+        int m = idx + 1;
+        double mx = fabs(A[idx][m]);
+        for (int i = idx + 2; i < n; ++i) {
+          const double val = fabs(A[idx][i]);
+          if (mx < val) mx = val, m = i;
+        }
+        indR[idx] = m;
+      }
+      if (idx > 0) {
+        int m = 0;
+        double mx = fabs(A[0][idx]);
+        for (int i = 1; i < idx; ++i) {
+          const double val = fabs(A[i][idx]);
+          if (mx < val) mx = val, m = i;
+        }
+        indC[idx] = m;
+      }
+    }
+  }
+  for (int k = 0; k < n - 1; ++k) {
+    int m = k;
+    for (int i = k + 1; i < n; ++i)
+      if (W[m] < W[i]) m = i;
+    if (k != m) {
+      double t = W[m];
+      W[m] = W[k];
+      W[k] = t;
+      for (int i = 0; i < n; ++i) {
+        t = V[m][i];
+        V[m][i] = V[k][i];
+        V[k][i] = t;
+      }
+    }
+  }
+}
+
+/* HomographyEstimatorCallback::runKernel: M -> m, `count` float correspondences; H: 9 doubles.  Returns 0 when degenerate. */
+int orc_homography_kernel(const float* M, const float* m, int count, double* H) {
+  double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
+  for (int i = 0; i < count; ++i) {
+    cmx += m[2 * i]; cmy += m[2 * i + 1];
+    cMx += M[2 * i]; cMy += M[2 * i + 1];
+  }
+  cmx /= count; cmy /= count; cMx /= count; cMy /= count;
+  for (int i = 0; i < count; ++i) {
+    smx += fabs(m[2 * i] - cmx); smy += fabs(m[2 * i + 1] - cmy);
+    sMx += fabs(M[2 * i] - cMx); sMy += fabs(M[2 * i + 1] - cMy);
+  }
+  if (fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON) return 0;
+  smx = count / smx; smy = count / smy; sMx = count / sMx; sMy = count / sMy;
+  double A[9][9], W[9], V[9][9];
+  memset(A, 0, sizeof A);
+  for (int i = 0; i < count; ++i) {
+    const double x = (m[2 * i] - cmx) * smx, y = (m[2 * i + 1] - cmy) * smy;
+    const double X = (M[2 * i] - cMx) * sMx, Y = (M[2 * i + 1] - cMy) * sMy;
+    const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+    const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+    for (int j = 0; j < 9; ++j)
+      for (int k = j; k < 9; ++k) A[j][k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+  }
+  for (int j = 0; j < 9; ++j)
+    for (int k = 0; k < j; ++k) A[j][k] = A[k][j];
+  jacobi_eigen9(A, W, V);
+  const double* h0 = V[8];
+  const double inv[9] = {1.0 / smx, 0, cmx, 0, 1.0 / smy, cmy, 0, 0, 1};
+  const double hn2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
+  double t[9], r[9];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) t[3 * a + b] = inv[3 * a] * h0[b] + inv[3 * a + 1] * h0[3 + b] + inv[3 * a + 2] * h0[6 + b];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) r[3 * a + b] = t[3 * a] * hn2[b] + t[3 * a + 1] * hn2[3 + b] + t[3 * a + 2] * hn2[6 + b];
+  const double sc = 1.0 / r[8];
+  for (int k = 0; k < 9; ++k) H[k] = r[k] * sc;
+  return 1;
+}
+
+static int h_have_collinear(const float (*p)[2], int count) {
+  const int i = count - 1;
+  for (int j = 0; j < i; ++j) {
+    const double dx1 = p[j][0] - p[i][0], dy1 = p[j][1] - p[i][1]; /* (float differences, widened) */
+    for (int k = 0; k < j; ++k) {
+      const double dx2 = p[k][0] - p[i][0], dy2 = p[k][1] - p[i][1];
+      if (fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) return 1;
+    }
+  }
+  return 0;
+}
+static double h_det3(const double* m) {
+  return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+static int h_check_subset(const float (*s1)[2], const float (*s2)[2]) {
+  if (h_have_collinear(s1, 4) || h_have_collinear(s2, 4)) return 0;
+  static const int tt[4][3] = {{0, 1, 2}, {1, 2, 3}, {0, 2, 3}, {0, 1, 3}};
+  int negative = 0;
+  for (int i = 0; i < 4; ++i) {
+    const int* t = tt[i];
+    const double A[9] = {s1[t[0]][0], s1[t[0]][1], 1., s1[t[1]][0], s1[t[1]][1], 1., s1[t[2]][0], s1[t[2]][1], 1.};
+    const double B[9] = {s2[t[0]][0], s2[t[0]][1], 1., s2[t[1]][0], s2[t[1]][1], 1., s2[t[2]][0], s2[t[2]][1], 1.};
+    negative += h_det3(A) * h_det3(B) < 0;
+  }
+  return negative == 0 || negative == 4;
+}
+static inline float h_error(const float* Hf, float Mx, float My, float mx, float my) {
+  const float ww = 1.f / (Hf[6] * Mx + Hf[7] * My + 1.f);
+  const float dx = (Hf[0] * Mx + Hf[1] * My + Hf[2]) * ww - mx;
+  const float dy = (Hf[3] * Mx + Hf[4] * My + Hf[5]) * ww - my;
+  return dx * dx + dy * dy;
+}
+
+/* cv::findHomography(pts1, pts2, RANSAC, threshold, mask, max_iters, confidence): the RANSAC inlier count, the mask and
+ * the iterations run.  pts: doubles (the reference hands over Point2d), converted to float as the library does. */
+int orc_find_homography(const double* pts1, const double* pts2, int count, double threshold, double confidence, int max_iters,
+                        uint8_t* mask, int* iters) {
+  if (iters) *iters = 0;
+  if (mask) memset(mask, 0, (size_t)(count > 0 ? count : 0));
+  if (threshold <= 0) threshold = 3;
+  if (count < 4) return 0;
+  float* m1 = (float*)malloc(sizeof(float) * 2 * (size_t)count);
+  float* m2 = (float*)malloc(sizeof(float) * 2 * (size_t)count);
+  uint8_t* cur = (uint8_t*)malloc((size_t)count);
+  uint8_t* best = (uint8_t*)calloc((size_t)count, 1);
+  for (int i = 0; i < 2 * count; ++i) m1[i] = (float)pts1[i], m2[i] = (float)pts2[i];
+  int max_good = 0;
+  double H[9];
+  if (count == 4) {
+    if (orc_homography_kernel(m1, m2, 4, H)) {
+      max_good = 4;
+      if (mask) memset(mask, 1, 4);
+    }
+  } else {
+    const float t = (float)(threshold * threshold);
+    cvrng rng = {~(uint64_t)0};
+    int niters = max_iters > 1 ? max_iters : 1, iter;
+    for (iter = 0; iter < niters; ++iter) {
+      int idx[4], found = 0;
+      float s1[4][2], s2[4][2];
+      for (int attempt = 0; attempt < 10000 && !found; ++attempt) {
+        for (int i = 0; i < 4;) {
+          const int v = cvrng_uniform(&rng, 0, count);
+          int j = 0;
+          for (; j < i; ++j)
+            if (idx[j] == v) break;
+          if (j < i) continue;
+          idx[i++] = v;
+        }
+        for (int k = 0; k < 4; ++k) {
+          s1[k][0] = m1[2 * idx[k]], s1[k][1] = m1[2 * idx[k] + 1];
+          s2[k][0] = m2[2 * idx[k]], s2[k][1] = m2[2 * idx[k] + 1];
+        }
+        found = h_check_subset(s1, s2);
+      }
+      if (!found) break; /* (iteration 0: run() returns false; later: the loop ends) */
+      if (!orc_homography_kernel(&s1[0][0], &s2[0][0], 4, H)) continue;
+      float Hf[9];
+      for (int k = 0; k < 9; ++k) Hf[k] = (float)H[k];
+      int good = 0;
+      for (int i = 0; i < count; ++i) {
+        const int f = h_error(Hf, m1[2 * i], m1[2 * i + 1], m2[2 * i], m2[2 * i + 1]) <= t;
+        cur[i] = (uint8_t)f;
+        good += f;
+      }
+      if (good > (max_good > 3 ? max_good : 3)) {
+        uint8_t* sw = cur;
+        cur = best;
+        best = sw;
+        max_good = good;
+        niters = orc_ransac_update_num_iters(confidence, (double)(count - good) / count, 4, niters);
+      }
+    }
+    if (iters) *iters = iter;
+    if (max_good > 0 && mask) memcpy(mask, best, (size_t)count);
+  }
+  free(m1);
+  free(m2);
+  free(cur);
+  free(best);
+  return max_good;
+}
+

@@ -588,7 +588,7 @@ int ransac_update_num_iters(double p, double ep, int model_points, int max_iters
 // ================================================================ homography (findHomographyInliers, src/Sfm.cpp:667-689)
 // cv::findHomography(query, train, RANSAC, threshold, mask) as OpenCV 3.4.1 (calib3d/fundam.cpp) runs it: FLOAT
 // points; 4-point samples, a sample drawn again when checkSubset rejects it (host, below); model = normalised DLT,
-// the eigenvector of the smallest eigenvalue of L^T L (here: cyclic Jacobi) scaled to H[2][2] = 1; the error and the
+// the eigenvector of the smallest eigenvalue of L^T L (cv::eigen's Jacobi, restated) scaled to H[2][2] = 1; the error and the
 // threshold test in float arithmetic; the mask is the RANSAC mask (the refit + LM refinement change H only).
 __device__ int homography_kernel(const float (*M)[2], const float (*m)[2], double* H) {
   const int count = 4;
@@ -617,43 +617,107 @@ __device__ int homography_kernel(const float (*M)[2], const float (*m)[2], doubl
   }
   for (int j = 0; j < 9; ++j)
     for (int k = 0; k < j; ++k) A[j][k] = A[k][j];
-  // cyclic Jacobi: A <- J^T A J, V <- V J
-  for (int sweep = 0; sweep < 40; ++sweep) {
-    double off = 0.0, diag = 0.0;
-    for (int j = 0; j < 9; ++j) {
-      diag += A[j][j] * A[j][j];
-      for (int k = j + 1; k < 9; ++k) off += A[j][k] * A[j][k];
+  // cv::eigen = JacobiImpl_<double> (core/lapack.cpp), operation for operation the CPU restatement used as checker:
+  // the pivot is the largest off-diagonal element (found through the row / column maximum indices indR / indC), the
+  // rotation comes from two hypots (the host libm's, hypot_glibc.h), only the upper triangle is touched, the
+  // eigenvector ROWS rotate along, at most 30 n^2 rotations; eigenvalues sorted descending with their rows
+  double Wv[9];
+  {
+    constexpr int n = 9;
+    const double eps = DBL_EPSILON;
+    int indR[9], indC[9];
+    for (int k = 0; k < n; ++k) {
+      Wv[k] = A[k][k];
+      if (k < n - 1) {
+        int mm = k + 1;
+        double mv = fabs(A[k][mm]);
+        for (int i = k + 2; i < n; ++i) {
+          const double val = fabs(A[k][i]);
+          if (mv < val) mv = val, mm = i;
+        }
+        indR[k] = mm;
+      }
+      if (k > 0) {
+        int mm = 0;
+        double mv = fabs(A[0][k]);
+        for (int i = 1; i < k; ++i) {
+          const double val = fabs(A[i][k]);
+          if (mv < val) mv = val, mm = i;
+        }
+        indC[k] = mm;
+      }
     }
-    if (off <= 1e-32 * diag) break;
-    for (int p = 0; p < 8; ++p)
-      for (int q = p + 1; q < 9; ++q) {
-        const double apq = A[p][q];
-        if (apq == 0.0) continue;
-        const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
-        const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
-        for (int k = 0; k < 9; ++k) {
-          const double akp = A[k][p], akq = A[k][q];
-          A[k][p] = c * akp - sn * akq;
-          A[k][q] = sn * akp + c * akq;
+    for (int iters = 0; iters < n * n * 30; ++iters) {
+      int k = 0;
+      double mv = fabs(A[0][indR[0]]);
+      for (int i = 1; i < n - 1; ++i) {
+        const double val = fabs(A[i][indR[i]]);
+        if (mv < val) mv = val, k = i;
+      }
+      int l = indR[k];
+      for (int i = 1; i < n; ++i) {
+        const double val = fabs(A[indC[i]][i]);
+        if (mv < val) mv = val, k = indC[i], l = i;
+      }
+      const double p = A[k][l];
+      if (fabs(p) <= eps) break;
+      const double y = (Wv[l] - Wv[k]) * 0.5;
+      double t = fabs(y) + sfm_hypot(p, y);
+      double sn = sfm_hypot(p, t);
+      const double c = t / sn;
+      sn = p / sn;
+      t = (p / t) * p;
+      if (y < 0) sn = -sn, t = -t;
+      A[k][l] = 0;
+      Wv[k] -= t;
+      Wv[l] += t;
+      double a0, b0;
+#define SFM_ROT(v0, v1) a0 = v0, b0 = v1, v0 = a0 * c - b0 * sn, v1 = a0 * sn + b0 * c
+      for (int i = 0; i < k; ++i) SFM_ROT(A[i][k], A[i][l]);
+      for (int i = k + 1; i < l; ++i) SFM_ROT(A[k][i], A[i][l]);
+      for (int i = l + 1; i < n; ++i) SFM_ROT(A[k][i], A[l][i]);
+      for (int i = 0; i < n; ++i) SFM_ROT(V[k][i], V[l][i]);
+#undef SFM_ROT
+      for (int j = 0; j < 2; ++j) {
+        const int idx = j == 0 ? k : l;
+        if (idx < n - 1) {
+          int mm = idx + 1;
+          double mx = fabs(A[idx][mm]);
+          for (int i = idx + 2; i < n; ++i) {
+            const double val = fabs(A[idx][i]);
+            if (mx < val) mx = val, mm = i;
+          }
+          indR[idx] = mm;
         }
-        for (int k = 0; k < 9; ++k) {
-          const double apk = A[p][k], aqk = A[q][k];
-          A[p][k] = c * apk - sn * aqk;
-          A[q][k] = sn * apk + c * aqk;
-        }
-        for (int k = 0; k < 9; ++k) {
-          const double vkp = V[k][p], vkq = V[k][q];
-          V[k][p] = c * vkp - sn * vkq;
-          V[k][q] = sn * vkp + c * vkq;
+        if (idx > 0) {
+          int mm = 0;
+          double mx = fabs(A[0][idx]);
+          for (int i = 1; i < idx; ++i) {
+            const double val = fabs(A[i][idx]);
+            if (mx < val) mx = val, mm = i;
+          }
+          indC[idx] = mm;
         }
       }
+    }
+    for (int k = 0; k < n - 1; ++k) {
+      int mm = k;
+      for (int i = k + 1; i < n; ++i)
+        if (Wv[mm] < Wv[i]) mm = i;
+      if (k != mm) {
+        double t = Wv[mm];
+        Wv[mm] = Wv[k];
+        Wv[k] = t;
+        for (int i = 0; i < n; ++i) {
+          t = V[mm][i];
+          V[mm][i] = V[k][i];
+          V[k][i] = t;
+        }
+      }
+    }
   }
-  int best = 0;
-  for (int j = 1; j < 9; ++j)
-    if (A[j][j] < A[best][best]) best = j;
   double h0[9];
-  for (int k = 0; k < 9; ++k) h0[k] = V[k][best];
+  for (int k = 0; k < 9; ++k) h0[k] = V[8][k];  // the row of the smallest eigenvalue
   // H = invHnorm * H0 * Hnorm2, then / H[2][2]
   const double inv[9] = {1.0 / smx, 0, cmx, 0, 1.0 / smy, cmy, 0, 0, 1};
   const double hn2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
@@ -1052,6 +1116,55 @@ extern "C" int sfmhip_score_five_point(sfmhip_ctx* ctx, int n_samples, const dou
   if (e == hipSuccess) e = hipMemcpyAsync(n_models, d_n, sizeof(int) * n_samples, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   hipFree(d_q1), hipFree(d_q2), hipFree(d_m), hipFree(d_n);
+  if (e != hipSuccess) {
+    g_sfmhip_last_hip_error = (int)e;
+    return SFMHIP_ERR_HIP;
+  }
+  return SFMHIP_OK;
+}
+
+// HomographyEstimatorCallback::runKernel for explicit 4-point samples (sample-level parity checks)
+__global__ __launch_bounds__(64) void homography_samples(const float* __restrict__ M, const float* __restrict__ m, int n,
+                                                         double* __restrict__ H, int* __restrict__ ok) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  float a[4][2], b[4][2];
+  for (int k = 0; k < 4; ++k) {
+    a[k][0] = M[8 * (size_t)t + 2 * k];
+    a[k][1] = M[8 * (size_t)t + 2 * k + 1];
+    b[k][0] = m[8 * (size_t)t + 2 * k];
+    b[k][1] = m[8 * (size_t)t + 2 * k + 1];
+  }
+  double h[9];
+  const int r = homography_kernel(a, b, h);
+  ok[t] = r;
+  for (int e = 0; e < 9; ++e) H[9 * (size_t)t + e] = r ? h[e] : 0.0;
+}
+
+extern "C" int sfmhip_score_homography_kernel(sfmhip_ctx* ctx, int n_samples, const float* M, const float* m, double* H, int32_t* ok) {
+  if (!ctx || n_samples < 0 || (n_samples && (!M || !m || !H || !ok))) return SFMHIP_ERR_ARG;
+  if (n_samples == 0) return SFMHIP_OK;
+  SFM_HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  float *d_M = nullptr, *d_m = nullptr;
+  double* d_H = nullptr;
+  int* d_ok = nullptr;
+  int rc = SFMHIP_OK;
+  if ((rc = sfm_dev_alloc(&d_M, 8 * (size_t)n_samples)) || (rc = sfm_dev_alloc(&d_m, 8 * (size_t)n_samples)) ||
+      (rc = sfm_dev_alloc(&d_H, 9 * (size_t)n_samples)) || (rc = sfm_dev_alloc(&d_ok, (size_t)n_samples))) {
+    hipFree(d_M), hipFree(d_m), hipFree(d_H), hipFree(d_ok);
+    return rc;
+  }
+  hipError_t e = hipMemcpyAsync(d_M, M, sizeof(float) * 8 * n_samples, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_m, m, sizeof(float) * 8 * n_samples, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(homography_samples, dim3((n_samples + 63) / 64), dim3(64), 0, st, d_M, d_m, n_samples, d_H, d_ok);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(H, d_H, sizeof(double) * 9 * n_samples, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(ok, d_ok, sizeof(int) * n_samples, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  hipFree(d_M), hipFree(d_m), hipFree(d_H), hipFree(d_ok);
   if (e != hipSuccess) {
     g_sfmhip_last_hip_error = (int)e;
     return SFMHIP_ERR_HIP;

@@ -43,6 +43,19 @@ def five_point(q1, q2, ctx=None):
     return models[:n], nm[:n] & 0xff, nm[:n] >> 8
 
 
+def homography_kernel(M, m, ctx=None):
+    """sfmhip_score_homography_kernel: M, m (n, 4, 2) float32 -> (H (n, 3, 3), ok (n,))"""
+    ctx = ctx or default_context()
+    M = np.ascontiguousarray(M, np.float32).reshape(-1, 4, 2)
+    m = np.ascontiguousarray(m, np.float32).reshape(-1, 4, 2)
+    n = len(M)
+    H = np.zeros((max(n, 1), 3, 3))
+    ok = np.zeros(max(n, 1), np.int32)
+    check(lib().sfmhip_score_homography_kernel(ctx.h, n, M.ctypes.data, m.ctypes.data, H.ctypes.data, ok.ctypes.data),
+          "sfmhip_score_homography_kernel")
+    return H[:n], ok[:n]
+
+
 def last_flags(ctx=None):
     """sfmhip_score_last_flags: non-zero when a five-point sample of the last score_essential call reached a corner of
     cv::solvePoly whose library behaviour is not reproduced (include/sfmhip.h)."""

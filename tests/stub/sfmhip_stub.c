@@ -198,6 +198,11 @@ int sfmhip_score_essential(sfmhip_ctx* ctx, int n_pairs, const int32_t* offsets,
   return SFMHIP_OK;
 }
 int sfmhip_score_last_flags(sfmhip_ctx* ctx) { (void)ctx; return g_score_flags; }
+int sfmhip_score_homography_kernel(sfmhip_ctx* ctx, int n_samples, const float* M, const float* m, double* H, int32_t* ok) {
+  (void)ctx;
+  for (int i = 0; i < n_samples; ++i) ok[i] = orc_homography_kernel(M + 8 * (size_t)i, m + 8 * (size_t)i, 4, H + 9 * (size_t)i);
+  return SFMHIP_OK;
+}
 int sfmhip_score_five_point(sfmhip_ctx* ctx, int n_samples, const double* q1, const double* q2, double* models, int32_t* n_models) {
   (void)ctx;
   for (int i = 0; i < n_samples; ++i) {

@@ -134,6 +134,28 @@ def test_homography_inliers_match_the_restatement(ctx):
     assert inl[0] > 0.6 * 600 and inl[3] < 0.5 * 400
 
 
+def test_homography_models_are_the_restatements_bit_for_bit(ctx):
+    """sfmhip_score_homography_kernel (normalised DLT + cv::eigen's Jacobi on the device) against the C restatement on
+    2000 random 4-point samples, near-degenerate ones among them: the same nine doubles, bit for bit"""
+    from oracle import orc
+    rng = np.random.default_rng(12)
+    M = rng.uniform(0, 640, (2000, 4, 2)).astype(np.float32)
+    A = np.array([[1.02, 0.05], [-0.03, 0.98]], np.float32)
+    m = (M @ A + rng.normal(0, 3.0, M.shape)).astype(np.float32)
+    M[10, 3] = M[10, 2] + np.float32(1e-3)          # two points almost on top of each other
+    M[11] = M[11, 0] + np.arange(4, dtype=np.float32)[:, None] * np.float32([1.0, 2.0])   # collinear
+    m[12] = m[12, 0]                                 # all four train points equal: no spread -> degenerate
+    H, ok = scoring.homography_kernel(M, m, ctx=ctx)
+    differ = []
+    for i in range(len(M)):
+        want = orc.homography_kernel(M[i], m[i])
+        if (want is None) != (ok[i] == 0) or (want is not None and not np.array_equal(H[i].view(np.uint64), want.view(np.uint64))):
+            if not (want is not None and np.isnan(want).all() and np.isnan(H[i]).all()):
+                differ.append(i)
+    assert not differ, (len(differ), differ[:10])
+    assert ok[12] == 0 and ok.sum() >= 1990
+
+
 def test_homography_degenerate_inputs(ctx):
     p, q = _planar(50, 9, 0.0)
     line = np.stack([np.arange(30.0), 2 * np.arange(30.0)], 1)      # every sample is collinear: getSubset gives up

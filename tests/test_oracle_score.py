@@ -108,3 +108,34 @@ def test_ransac_on_a_scene_with_outliers():
     a, b = sc["xy1"], sc["xy2"]
     m = S.find_best_pair_scores([((0, 1), a, b), ((0, 2), a[:100], b[:100]), ((1, 2), a, b)], K)
     assert [v for _, v in m] == [(1, 2)]
+
+
+def _planar(n, seed, outliers, noise=0.4):
+    rng = np.random.default_rng(seed)
+    Ht = np.array([[1.02, 0.05, 12.0], [-0.03, 0.98, -7.0], [1e-5, -2e-5, 1.0]])
+    p = rng.uniform(0, 640, (n, 2))
+    ph = np.concatenate([p, np.ones((n, 1))], 1) @ Ht.T
+    q = ph[:, :2] / ph[:, 2:] + rng.normal(0, noise, (n, 2))
+    out = rng.random(n) < outliers
+    q[out] = rng.uniform(0, 640, (int(out.sum()), 2))
+    return p, q
+
+
+def test_homography_restatement_against_the_independent_numpy_route():
+    """cv::findHomography(RANSAC) restated in C with cv::eigen's Jacobi (oracle/sfm_oracle_score.c) against the numpy
+    route with eigh (oracle/np_check.py): the same H up to rounding, the same counts, iteration numbers and masks"""
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        M = rng.uniform(0, 640, (4, 2)).astype(np.float32)
+        m = (M @ np.array([[1.01, 0.02], [-0.03, 0.99]], np.float32) + rng.uniform(-5, 5, 2).astype(np.float32)).astype(np.float32)
+        a, b = orc.homography_kernel(M, m), np_check.homography_kernel_np(M, m)
+        assert a is not None and b is not None and np.abs(a - b).max() <= 1e-6 * np.abs(b).max()     # (eigenvector of a 9 x 9 normal matrix: conditioning squares, the two eigen-solvers agree to ~1e-8)
+        assert abs(a[2, 2] - 1.0) <= 2.3e-16            # (H * (1 / H22), as the library scales it: H22 * (1 / H22) may miss 1 by an ulp)
+    assert orc.homography_kernel(np.zeros((4, 2), np.float32), np.ones((4, 2), np.float32)) is None      # degenerate: no spread
+    for n, seed, o in ((600, 0, 0.3), (150, 1, 0.6), (2000, 2, 0.1), (40, 3, 0.0), (300, 4, 0.85), (5, 5, 0.0), (4, 6, 0.0), (3, 7, 0.0)):
+        p, q = _planar(n, seed, o)
+        thr = 0.004 * float(p.max())
+        c, mask, it = S.find_homography_ransac(p, q, thr)
+        c2, mask2, it2 = np_check.find_homography_ransac_np(p, q, thr)
+        assert (c, it) == (c2, it2) and np.array_equal(mask, mask2), (n, o)
+        assert S.find_homography_inliers(p, q) == c
