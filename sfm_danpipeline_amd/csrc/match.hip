@@ -894,442 +894,6 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
 #endif
 }
 
-// ---------------------------------------------------------------- MFMA k-NN kernel, L2, 16x16x64 form (SIFT-128)
-// The same sweep on v_mfma_i32_16x16x64_i8: on random operands the chip holds a 13-20 % higher clock on this shape at
-// equal cycles per operation (scripts/ubench/mfma_shape_i8.hip).  What changes with the shape:
-//  * an MFMA tile is 16 train rows x 16 queries; lane (c = lane % 16, g = lane / 16) holds rows 4g..4g+3 of query c:
-//    FOUR lanes per query, each seeing 8 rows of a 32-row image tile;
-//  * a chain is one MFMA query tile against a BLOCK of 64 train rows (four MFMA tiles x two k-steps, 8 MFMAs, 16
-//    accumulator registers = the lane's 8 rows of image tile 2j and of tile 2j+1).  The value structures keep the 32x32
-//    form's op count per distance (19 ops per 16 values; every VALU op beside the MFMAs costs throughput on a
-//    power-limited clock): 8 slot maxima per lane and query, sl[e] = max3(sl[e], X[e], X[8 + e]) -- a slot is one
-//    in-tile row position, over BOTH tiles of every block -- and the top-2 of the per-BLOCK maxima (one tree of 16);
-//    a lane's candidates are (top-2 blocks) x (slots that reach the threshold) x (the block's two tiles), at most 8
-//    rows, all recomputed (which of the two tiles holds a known maximum is not known);
-//  * the chain's registers are half the 32x32 form's (16 accumulators, 8 fragments, 4 C inputs per 64 train rows).
-// The tile images, the parity order, the C inputs, the k-NN entries and everything after the sweep's structures are those
-// of knn_kernel (the resolve below is its resolve with 8 slots, four lanes per query and one candidate list per wave).
-#ifndef SFM_K16_NU
-#define SFM_K16_NU 2
-#endif
-constexpr int K16_NU = SFM_K16_NU;  // image query tiles per wave (4 fits the registers as well and is no faster)
-__device__ __forceinline__ int k16_med3(int a, int b, int c) { return imed3(a, b, c); }
-template <int I>
-__device__ __forceinline__ void epi16_op(const v4i (&D)[4], int (&sl)[8], int& k0, int& k1, int (&T)[8], int tag) {
-  // D[mt][r]: value 4 mt + r of the chain; image tile 0 of the block = values 0..7, image tile 1 = values 8..15
-  auto d = [&](int i) -> int { return D[i >> 2][i & 3]; };
-  if constexpr (I < 8) {
-    sl[I] = imax3(sl[I], d(I), d(8 + I));
-  } else {
-    constexpr int J = I - 8;
-    if constexpr (J == 0) T[0] = imax3(d(0), d(1), d(2));
-    if constexpr (J == 1) T[1] = imax3(d(3), d(4), d(5));
-    if constexpr (J == 2) T[2] = imax3(d(6), d(7), d(8));
-    if constexpr (J == 3) T[3] = imax3(d(9), d(10), d(11));
-    if constexpr (J == 4) T[4] = imax3(d(12), d(13), d(14));
-    if constexpr (J == 5) T[5] = imax3(T[0], T[1], T[2]);
-    if constexpr (J == 6) T[6] = imax3(T[3], T[4], d(15));
-    if constexpr (J == 7) T[7] = max(T[5], T[6]);
-    if constexpr (J == 8) T[7] = (T[7] << TAG_BITS) | tag;
-    if constexpr (J == 9) k1 = k16_med3(k0, k1, T[7]);
-    if constexpr (J == 10) k0 = max(k0, T[7]);
-  }
-}
-// issue order of the 19 ops over the chain's 8 MFMAs (3,3,3,2,2,2,2,2): the tree first, its dependent tail spread
-// between the independent slot maxima
-constexpr int EPI16_ORDER[19] = {8, 9, 10, 11, 12, 0, 13, 14, 1, 15, 2, 16, 3, 17, 4, 18, 5, 6, 7};
-constexpr int EPI16_LO[9] = {0, 3, 6, 9, 11, 13, 15, 17, 19};
-template <int LO, int HI>
-__device__ __forceinline__ void epi16_range(const v4i (&D)[4], int (&sl)[8], int& k0, int& k1, int (&T)[8], int tag) {
-  if constexpr (LO < HI) {
-    epi16_op<EPI16_ORDER[LO]>(D, sl, k0, k1, T, tag);
-    epi16_range<LO + 1, HI>(D, sl, k0, k1, T, tag);
-  }
-}
-
-__global__ __launch_bounds__(256, 2) void knn16_kernel(const ImgDev* __restrict__ imgs, const WorkItem* __restrict__ items,
-                                                       const int* __restrict__ nonintegral, int gen, int4* __restrict__ knn, int maxq,
-                                                       int* __restrict__ fix_count, int2* __restrict__ fix_items) {
-  constexpr int KS = 4, NC = 8, RB = 128, SR = 256, NT = 256;
-  constexpr int TILE_BYTES = TILE_ROWS * RB;
-  constexpr int STAGE_ROW_BYTES = SR * RB;
-  constexpr int CIN_COPIES = (SR + NT - 1) / NT;
-  constexpr int STAGE_BYTES = STAGE_ROW_BYTES + CIN_COPIES * NT * 4;
-  constexpr int TILES = SR / TILE_ROWS;            // image tiles per stage
-  constexpr int T64S = TILES / 2;                  // 64-row blocks per stage
-  constexpr int PIECES = STAGE_ROW_BYTES / (NT * 16);
-  constexpr int STAGES_PER_EPOCH = EPOCH_TILES / TILES;
-  constexpr int NQ = 2 * K16_NU;                   // MFMA query tiles per wave
-  constexpr int SCRATCH_W = STAGE_BYTES / 2;       // resolve scratch per wave: half a stage buffer
-  static_assert(SCRATCH_W >= 16384 && STAGES_PER_EPOCH % 2 == 0 && NQ % 2 == 0 && NQ * 8 * 64 <= 2048, "shape");
-  __shared__ __attribute__((aligned(16))) unsigned char ldsA[STAGE_BYTES];
-  __shared__ __attribute__((aligned(16))) unsigned char ldsB[STAGE_BYTES];
-
-  const WorkItem it = items[blockIdx.x];
-  if ((nonintegral[it.qimg] == gen) | (nonintegral[it.timg] == gen)) return;  // left to the exact kernel
-  const ImgDev Q = imgs[it.qimg];
-  const ImgDev T = imgs[it.timg];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int c = lane & 15, g = lane >> 4;
-  const int nqt = Q.n_pad / TILE_ROWS;
-  const int qt0 = it.qtile0 + K16_NU * wave;              // the wave's first image query tile
-  const int qt_last = nqt > 0 ? nqt - 1 : 0;
-  SFM_STAMP(0);
-
-  // per-lane byte offset of a fragment inside a 16-row half of an image tile: row c, logical chunk 4 ks + g
-  int aoff[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) aoff[ks] = c * RB + (((4 * ks + g) ^ ((c >> 1) & 7)) << 4);
-  const int coff = STAGE_ROW_BYTES + g * 16;   // C inputs of rows 4g .. 4g+3 of an MFMA tile
-  const int nstages = T.n_pad / SR;
-  const int tid = threadIdx.x;
-  const __amdgpu_buffer_rsrc_t rs_tiles = __builtin_amdgcn_make_buffer_rsrc((void*)T.tiles, 0, 0x7FFFFFFF, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_cin = __builtin_amdgcn_make_buffer_rsrc((void*)T.cin, 0, 0x7FFFFFFF, 0x00020000);
-  // (everything else the lanes read goes through buffer loads as well: one 32-bit offset register per access instead of
-  // 64-bit per-lane addresses that the compiler hoists out of the epoch loop and then spills)
-  const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)Q.tiles, 0, 0x7FFFFFFF, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_qperm = __builtin_amdgcn_make_buffer_rsrc((void*)Q.perm, 0, 0x7FFFFFFF, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_qnq = __builtin_amdgcn_make_buffer_rsrc((void*)Q.nq, 0, 0x7FFFFFFF, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_tperm = __builtin_amdgcn_make_buffer_rsrc((void*)T.perm, 0, 0x7FFFFFFF, 0x00020000);
-  auto stage_copy = [&](int stage, unsigned char* dstb) {
-    const int off = stage * STAGE_ROW_BYTES;
-#pragma unroll
-    for (int i = 0; i < PIECES; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_tiles, (__attribute__((address_space(3))) void*)(dstb + i * (NT * 16) + wave * 1024),
-                                               16, tid * 16, off + i * (NT * 16), 0, 0);
-#pragma unroll
-    for (int i = 0; i < CIN_COPIES; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_cin, (__attribute__((address_space(3))) void*)(dstb + STAGE_ROW_BYTES + i * (NT * 4) + wave * 256),
-                                               4, tid * 4, stage * SR * 4 + i * (NT * 4), 0, 0);
-  };
-  // fragment (mt, ks) of 64-row block j of a stage buffer: image tile 2j + mt/2, half mt%2
-  auto ld_frag = [&](const unsigned char* sb, int j, int mt, int ks) -> v4i {
-    const int4 x = *(const int4*)(sb + (2 * j + (mt >> 1)) * TILE_BYTES + (mt & 1) * (TILE_BYTES / 2) + aoff[ks]);
-    return v4i{x.x, x.y, x.z, x.w};
-  };
-  auto ld_cin = [&](const unsigned char* sb, int j, int mt) -> v4i {
-    const int4 x = *(const int4*)(sb + coff + (j * 64 + 16 * mt) * 4);
-    return v4i{x.x, x.y, x.z, x.w};
-  };
-  const int nodd_t = *(g_i32_p)T.nodd;
-
-  for (int ep0 = 0; ep0 < nstages; ep0 += STAGES_PER_EPOCH) {
-    const int ep1 = (ep0 + STAGES_PER_EPOCH < nstages) ? ep0 + STAGES_PER_EPOCH : nstages;
-    const int ep_tile0 = ep0 * TILES;
-    // query fragments (B operand): MFMA query tile u = image tile u / 2, half u % 2 (loaded per epoch: not live across the resolve)
-  v4i bq[NQ][2];
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-      const int tq = min(qt0 + (u >> 1), qt_last);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        bq[u][ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_q, aoff[ks], tq * TILE_BYTES + (u & 1) * (TILE_BYTES / 2), 0);
-    }
-    int sl[NQ][8], k0[NQ], k1[NQ];
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-      k0[u] = k1[u] = (int)0x80000000;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) sl[u][e] = HPAD;
-    }
-    if (ep0 > 0) __syncthreads();
-    stage_copy(ep0, ldsA);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    v4i F[4][2], C[4], X[2][4];
-    int TT[8];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      F[mt][0] = ld_frag(ldsA, 0, mt, 0);
-      F[mt][1] = ld_frag(ldsA, 0, mt, 1);
-      C[mt] = ld_cin(ldsA, 0, mt);
-      X[0][mt] = X[1][mt] = v4i{HPAD, HPAD, HPAD, HPAD};   // (draining these changes nothing)
-    }
-    // tag of the block being swept (the blocks of the epoch count down from EPOCH_TILES/2 - 1) and of the one before
-    int tag = EPOCH_TILES / 2 - 1, tagp = EPOCH_TILES / 2;
-    SFM_STAMP(1);
-
-    // One chain: the 8 MFMAs of query tile U against the block's fragments into X[U & 1]; the 22 epilogue ops of the chain
-    // before it (query tile U - 1, or the last query tile of the block before) ride between them.  RELOAD: the last chain of
-    // a block fetches the next block's fragments, each right after its last use (NSB, NJ: where they are).
-#define K16_CHAIN(U, RELOAD, NSB, NJ)                                                                                   \
-  do {                                                                                                                  \
-    constexpr int UD_ = ((U) + NQ - 1) % NQ;                                                                            \
-    const int tg0_ = ((U) == 0 ? tagp : tag) & TAG_MASK;                                                                \
-    _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                                                  \
-      const int mt_ = g_ & 3, ks_ = g_ >> 2;                                                                            \
-      X[(U) & 1][mt_] = __builtin_amdgcn_mfma_i32_16x16x64_i8(F[mt_][ks_], bq[U][ks_], ks_ == 0 ? C[mt_] : X[(U) & 1][mt_], 0, 0, 0); \
-      if (RELOAD) {                                                                                                     \
-        F[mt_][ks_] = ld_frag(NSB, NJ, mt_, ks_);                                                                       \
-        if (ks_ == 0) C[mt_] = ld_cin(NSB, NJ, mt_);                                                                    \
-      }                                                                                                                 \
-      switch (g_) {                                                                                                     \
-        case 0: epi16_range<EPI16_LO[0], EPI16_LO[1]>(X[((U) + 1) & 1], sl[UD_], k0[UD_], k1[UD_], TT, tg0_); break; \
-        case 1: epi16_range<EPI16_LO[1], EPI16_LO[2]>(X[((U) + 1) & 1], sl[UD_], k0[UD_], k1[UD_], TT, tg0_); break; \
-        case 2: epi16_range<EPI16_LO[2], EPI16_LO[3]>(X[((U) + 1) & 1], sl[UD_], k0[UD_], k1[UD_], TT, tg0_); break; \
-        case 3: epi16_range<EPI16_LO[3], EPI16_LO[4]>(X[((U) + 1) & 1], sl[UD_], k0[UD_], k1[UD_], TT, tg0_); break; \
-        case 4: epi16_range<EPI16_LO[4], EPI16_LO[5]>(X[((U) + 1) & 1], sl[UD_], k0[UD_], k1[UD_], TT, tg0_); break; \
-        case 5: epi16_range<EPI16_LO[5], EPI16_LO[6]>(X[((U) + 1) & 1], sl[UD_], k0[UD_], k1[UD_], TT, tg0_); break; \
-        case 6: epi16_range<EPI16_LO[6], EPI16_LO[7]>(X[((U) + 1) & 1], sl[UD_], k0[UD_], k1[UD_], TT, tg0_); break; \
-        case 7: epi16_range<EPI16_LO[7], EPI16_LO[8]>(X[((U) + 1) & 1], sl[UD_], k0[UD_], k1[UD_], TT, tg0_); break; \
-      }                                                                                                                 \
-      __builtin_amdgcn_sched_barrier(0);                                                                                \
-    }                                                                                                                   \
-  } while (0)
-
-    auto stage = [&](int s, const unsigned char* sb, unsigned char* nb) __attribute__((always_inline)) {
-      if (s + 1 < ep1) stage_copy(s + 1, nb);   // the other buffer was last read before the previous stage's barrier
-#define K16_BLOCK(J)                                                                            \
-  do {                                                                                         \
-    K16_CHAIN(0, false, sb, 0);                                                                \
-    K16_CHAIN(1, false, sb, 0);                                                                \
-    K16_CHAIN(2, false, sb, 0);                                                                \
-    if (NQ > 4) {                                                                              \
-      K16_CHAIN(3 % NQ, false, sb, 0);                                                         \
-      K16_CHAIN(4 % NQ, false, sb, 0);                                                         \
-    }                                                                                          \
-    if (NQ > 6) {                                                                              \
-      K16_CHAIN(5 % NQ, false, sb, 0);                                                         \
-      K16_CHAIN(6 % NQ, false, sb, 0);                                                         \
-    }                                                                                          \
-    if ((J) == T64S - 1) {                                                                     \
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's part of the next stage has landed */ \
-      __syncthreads();                                                                         \
-      K16_CHAIN(NQ - 1, true, nb, 0);                                                          \
-    } else {                                                                                   \
-      K16_CHAIN(NQ - 1, true, sb, (J) + 1);                                                    \
-    }                                                                                          \
-    tagp = tag;                                                                                \
-    tag -= 1;                                                                                  \
-  } while (0)
-      static_assert(T64S == 4, "blocks per stage");
-      K16_BLOCK(0);
-      K16_BLOCK(1);
-      K16_BLOCK(2);
-      K16_BLOCK(3);
-#undef K16_BLOCK
-    };
-    for (int s = ep0; s < ep1; s += 2) {
-      stage(s, ldsA, ldsB);
-      if (s + 1 < ep1) stage(s + 1, ldsB, ldsA);
-    }
-    SFM_STAMP(2);
-    // the block filled last (query tile NQ-1: X[1]) is still to be drained
-    epi16_range<0, 19>(X[(NQ - 1) & 1], sl[NQ - 1], k0[NQ - 1], k1[NQ - 1], TT, tagp & TAG_MASK);
-#undef K16_CHAIN
-
-    // ---- resolve the epoch (knn_kernel's resolve: 8 slots, four lanes per query, one candidate list per wave).  Scratch:
-    // half a stage buffer per wave -- past the last stage's barrier nothing reads the buffers (the last chain's reloads
-    // fetch fragments that are never used).
-    int lane_p = lane;
-    asm volatile("" : "+v"(lane_p));
-    const int c_p = lane_p & 15, g_p = lane_p >> 4;
-    typedef __attribute__((address_space(3))) int* lds_vi_p;
-#define K16_WAVE_LDS_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-    lds_vi_p wl = (lds_vi_p)((__attribute__((address_space(3))) unsigned char*)(wave < 2 ? ldsA : ldsB) + (wave & 1) * SCRATCH_W);
-    lds_vi_p wr = wl + 2048;
-    // candidates of the lane (index = 4 block + 2 slot + tile of the block): position (-1: none), slot in the wave's list
-    int cpos[NQ][8], slot_[NQ][8];
-    int qrow[NQ], nqq[NQ], ovf[NQ];
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-      const int tq = qt0 + (u >> 1);
-      const int q = min(tq, qt_last) * TILE_ROWS + 16 * (u & 1) + c_p;
-      qrow[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_qperm, q * 4, 0, 0);
-      nqq[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_qnq, q * 4, 0, 0);
-      if (tq >= nqt) qrow[u] = -1;  // (a query tile beyond the image: the wave swept a copy of the last one)
-    }
-    // phase A: thresholds, the slots that reach them, the candidate rows
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-      const int bv0 = k0[u] >> TAG_BITS, bv1 = k1[u] >> TAG_BITS;
-      const int tl0 = ep_tile0 + 2 * ((EPOCH_TILES / 2 - 1) - (k0[u] & TAG_MASK));   // first image tile of the block
-      const int tl1 = ep_tile0 + 2 * ((EPOCH_TILES / 2 - 1) - (k1[u] & TAG_MASK));
-      // second largest of the eight block maxima of the query's four lanes (eight different rows): a lower bound of the
-      // query's second-best h
-      int m0 = bv0, m1 = bv1;
-#pragma unroll
-      for (int xi = 0; xi < 2; ++xi) {
-        const int p0 = __shfl_xor(m0, 16 << xi), p1 = __shfl_xor(m1, 16 << xi);
-        const int n1 = max(min(m0, p0), max(m1, p1));
-        m0 = max(m0, p0);
-        m1 = n1;
-      }
-      int thr = m1;
-      unsigned lt = 0;  // bit 7-e: slot e stays below thr
-#pragma unroll
-      for (int e = 0; e < 8; ++e) lt = __builtin_amdgcn_alignbit(lt, (unsigned)(sl[u][e] - thr), 31);
-      unsigned ge = ~lt & 0xFFu;
-      if (__ballot(__popc(ge) > 2) != 0ull) {
-        int a0 = HPAD - 1, a1 = HPAD - 1;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          a1 = imed3(a0, a1, sl[u][e]);
-          a0 = max(a0, sl[u][e]);
-        }
-        thr = max(thr, a1);
-        lt = 0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) lt = __builtin_amdgcn_alignbit(lt, (unsigned)(sl[u][e] - thr), 31);
-        ge = ~lt & 0xFFu;
-      }
-      const bool t0in = bv0 >= thr && bv0 > HPAD, t1in = bv1 >= thr && bv1 > HPAD;
-      const int ns = __popc(ge);
-      const int bA = 31 - __clz((int)(ge | 1u));
-      const unsigned ge2 = ge & ~(1u << bA);
-      const int bB = ns >= 2 ? 31 - __clz((int)ge2) : bA;
-      const int eA = 7 - bA, eB = 7 - bB;
-      const int rhoA = 16 * (eA >> 2) + 4 * g_p + (eA & 3), rhoB = 16 * (eB >> 2) + 4 * g_p + (eB & 3);
-      int over = (ns > 2 && (t0in || t1in)) ? 1 : 0;
-      over |= __shfl_xor(over, 16);
-      over |= __shfl_xor(over, 32);
-      ovf[u] = over;
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        const int ps = ((kk & 4) ? tl1 : tl0) * TILE_ROWS + (kk & 1) * TILE_ROWS + ((kk & 2) ? rhoB : rhoA);
-        const bool ok = ((kk & 4) ? t1in : t0in) && ns >= ((kk & 2) ? 2 : 1) && ps < T.n_pad;
-        cpos[u][kk] = ok ? ps : -1;
-      }
-    }
-    SFM_STAMP(8);
-    // phase B: ONE packed list per wave: position | (query of the wave, 0..127) << 25
-    int count = 0;
-#pragma unroll
-    for (int u = 0; u < NQ; ++u)
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const bool ld = cpos[u][k] >= 0;
-        const unsigned long long bm = __ballot(ld);
-        slot_[u][k] = ld ? count + __popcll(bm & ((1ull << lane_p) - 1ull)) : -1;
-        if (ld) wl[slot_[u][k]] = cpos[u][k] | ((16 * u + c_p) << 25);
-        count += __popcll(bm);  // wave-uniform
-      }
-    K16_WAVE_LDS_FENCE();
-    SFM_STAMP(9);
-    // phase C: the listed rows recomputed, four lanes to a row, two 16-byte chunks per lane of the train row (one cache
-    // line per row) and of the query row (its image tile, through the vector cache as well)
-    {
-      const int grp = lane_p >> 2, cc = lane_p & 3;
-      for (int j0 = 0; j0 < count; j0 += 64) {
-        v4i xt[4][2], xq[4][2];
-        int ci[4];
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-          const int j = j0 + st * 16 + grp;
-          unsigned ent = (unsigned)wl[j & 2047];
-          if (j >= count) ent = 0u;
-          const unsigned ps = ent & ((1u << 25) - 1u), qid = ent >> 25;
-          const unsigned x = ((ps >> 1) ^ (qid >> 1)) & 7u;
-          const int tq = min(qt0 + (int)(qid >> 5), qt_last);
-          const int qb = tq * TILE_BYTES + (int)(qid & 31u) * RB;
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const int p_ = cc + 4 * i;
-            xt[st][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_tiles, (int)ps * RB + p_ * 16, 0, 0);
-            xq[st][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_q, qb + ((p_ ^ (int)x) << 4), 0, 0);
-          }
-          ci[st] = __builtin_amdgcn_raw_buffer_load_b32(rs_cin, (int)ps * 4, 0, 0);
-        }
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-          int dot = 0;
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int w = 0; w < 4; ++w) dot = __builtin_amdgcn_sdot4(xt[st][i][w], xq[st][i][w], dot, false);
-          dot = group_sum<4>(dot) + ci[st];
-          wr[(j0 + st * 16 + grp) & 2047] = dot;  // (every lane of the group writes the same value)
-        }
-      }
-    }
-    K16_WAVE_LDS_FENCE();
-    SFM_STAMP(10);
-    // phase D: lane top-2 by (h descending, position ascending); phase E: distances, merge of the query's four lanes by
-    // (d, position), the rows' original indices
-    long long best[NQ][2];
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-      long long lk[2] = {(long long)(HPAD - 1) << 32, (long long)(HPAD - 1) << 32};
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int hv = slot_[u][k] >= 0 ? wr[slot_[u][k] & 2047] : HPAD - 1;
-        const long long key = ((long long)hv << 32) | (unsigned)(0x7FFFFFFF - cpos[u][k]);  // larger = better
-        lk[1] = max(lk[1], min(lk[0], key));
-        lk[0] = max(lk[0], key);
-      }
-      long long dk[2];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int hv = (int)(lk[k] >> 32), ps = 0x7FFFFFFF - (int)(unsigned)lk[k];
-        const int d = nqq[u] - 2 * hv - (ps < nodd_t ? 1 : 0);
-        dk[k] = hv > HPAD ? (((long long)d << 32) | (unsigned)ps) : 0x7FFFFFFFFFFFFFFFll;  // smaller = better
-      }
-#pragma unroll
-      for (int xi = 0; xi < 2; ++xi) {
-        const long long o0 = __shfl_xor(dk[0], 16 << xi), o1 = __shfl_xor(dk[1], 16 << xi);
-        const long long n1 = min(max(dk[0], o0), min(dk[1], o1));
-        dk[0] = min(dk[0], o0);
-        dk[1] = n1;
-      }
-      best[u][0] = dk[0];
-      best[u][1] = dk[1];
-    }
-    int x0[NQ], x1[NQ];
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-      const unsigned p0 = (unsigned)best[u][0], p1 = (unsigned)best[u][1];
-      x0[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_tperm, (int)(p0 < (unsigned)T.n_pad ? p0 : 0u) * 4, 0, 0);
-      x1[u] = __builtin_amdgcn_raw_buffer_load_b32(rs_tperm, (int)(p1 < (unsigned)T.n_pad ? p1 : 0u) * 4, 0, 0);
-    }
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-      Best2 m;
-      m.d0 = (int)(best[u][0] >> 32), m.i0 = (int)(unsigned)best[u][0], m.x0 = x0[u];
-      m.d1 = (int)(best[u][1] >> 32), m.i1 = (int)(unsigned)best[u][1], m.x1 = x1[u];
-      if (best[u][0] == 0x7FFFFFFFFFFFFFFFll || m.x0 < 0) m.d0 = DIST_EMPTY, m.i0 = 0x7FFFFFFF, m.x0 = -1;
-      if (best[u][1] == 0x7FFFFFFFFFFFFFFFll || m.x1 < 0) m.d1 = DIST_EMPTY, m.i1 = 0x7FFFFFFF, m.x1 = -1;
-      if (g_p == 0 && qrow[u] >= 0) {
-        int4* dst = &knn[(size_t)it.pair * maxq + qrow[u]];
-        if (ep0 > 0) {
-          const int4 pv = *dst;
-          Best2 a;
-          a.d0 = pv.z, a.x0 = pv.x, a.i0 = -2, a.d1 = pv.w, a.x1 = pv.y, a.i1 = -1;
-          if (pv.y == FIX_FLAG) ovf[u] = 1;
-          if (m.d0 != DIST_EMPTY) best2_insert(a, m.d0, m.i0, m.x0);
-          if (m.d1 != DIST_EMPTY) best2_insert(a, m.d1, m.i1, m.x1);
-          m = a;
-        }
-        int4 o;
-        if (ep1 < nstages) {
-          o.x = m.x0;
-          o.y = ovf[u] ? FIX_FLAG : m.x1;
-          o.z = m.d0;
-          o.w = m.d1;
-        } else {
-          const bool v0 = m.d0 != DIST_EMPTY, v1 = m.d1 != DIST_EMPTY;
-          const float d0 = sqrtf((float)m.d0), d1 = sqrtf((float)m.d1);
-          const int fix = (v1 && m.d1 >= (1 << 22)) ? FIX_FLAG : 0;  // sqrtf may merge neighbouring integers: redone exactly
-          o.x = v0 ? m.x0 : -1;
-          o.y = v1 ? (m.x1 | fix) : -1;
-          if (ovf[u]) o.y = FIX_FLAG;
-          o.z = __float_as_int(v0 ? d0 : 3.402823466e+38f);
-          o.w = __float_as_int(v1 ? d1 : 3.402823466e+38f);
-          if (o.y >= 0 && (o.y & FIX_FLAG)) {
-            const int k = atomicAdd(fix_count, 1);
-            if (k < FIX_CAP) fix_items[k] = make_int2(it.pair, qrow[u]);
-          }
-        }
-        *dst = o;
-      }
-    }
-    SFM_STAMP(3);
-  }
-  SFM_STAMP(5);
-#undef K16_WAVE_LDS_FENCE
-}
-
 // ---------------------------------------------------------------- MFMA k-NN kernel, Hamming
 // Binary rows are stored as +-8 bytes.  With the query fragments negated the i8 MFMA yields
 // C - 64 q.t, and with C = 64 nbits + (row mod 128) that IS the key (128 hamming + row-in-chunk):
@@ -2088,7 +1652,6 @@ struct sfmhip_imageset {
   int kind, ks, sr, nu;  // ks==0: no MFMA instantiation -> exact kernel only; nu = query tiles per wave
   int nw = 4;            // waves per k-NN workgroup: 4 (two workgroups per CU, which drift half a sweep apart) or 8
   int late_start = 0;    // nw == 4: start delay of the second set of resident workgroups, in 8 k cycles
-  bool shape16 = false;  // 128-byte L2 rows: the 16x16x64 form of the sweep (knn16_kernel), 4 waves x 4 query tiles
   std::vector<int> n_rows, n_pad;
   std::vector<ImgDev> h_imgs;
   std::vector<void*> owned_raw;
@@ -2175,8 +1738,6 @@ extern "C" int sfmhip_imageset_create(sfmhip_ctx* ctx, int n_images, const int32
   if (const char* e = getenv("SFMHIP_KNN_NW")) s->nw = atoi(e) == 8 ? 8 : 4;          // (tuning knobs, not API)
   if (const char* e = getenv("SFMHIP_KNN_LATE")) s->late_start = std::max(0, atoi(e));
   if (s->kind == KIND_U8_HAMMING) s->nw = 4;
-  if (const char* e = getenv("SFMHIP_KNN_SHAPE")) s->shape16 = atoi(e) == 16 && s->ks == 4 && s->kind != KIND_U8_HAMMING;
-  if (s->shape16) s->nw = 4, s->nu = K16_NU;
   const int rb = 32 * (s->ks ? s->ks : 1);
   size_t tot_pad = 0;
   std::vector<int> tile_img, tile_first(n_images + 1, 0);
@@ -2445,10 +2006,7 @@ extern "C" int sfmhip_matchplan_set_pairs(sfmhip_matchplan* pl, const int32_t* p
 template <int KS, int MODE, int NU, int SR>
 static int launch_knn(sfmhip_matchplan* pl) {
   sfmhip_imageset* s = pl->set;
-  if (KS == 4 && s->shape16)
-    hipLaunchKernelGGL(knn16_kernel, dim3(pl->n_items), dim3(256), 0, s->ctx->stream, s->d_imgs, pl->d_items, s->d_nonintegral,
-                       s->gen, pl->d_knn, pl->maxq, pl->d_fix_count, pl->d_fix_items);
-  else if (s->nw == 4)
+  if (s->nw == 4)
     hipLaunchKernelGGL((knn_kernel<KS, MODE, NU, SR, 4>), dim3(pl->n_items), dim3(256), 0, s->ctx->stream, s->d_imgs,
                        pl->d_items, s->d_nonintegral, s->gen, s->dim, pl->d_knn, pl->maxq, s->late_start, pl->d_fix_count,
                        pl->d_fix_items);
