@@ -344,6 +344,20 @@ def test_cfg4_full_size_three_iterations_vs_oracle(ctx, orc):
     assert abs(f - fo) <= 1e-6 * fo
 
 
+def test_cfg4_full_size_twelve_iterations_vs_oracle(ctx, orc):
+    """BASELINE cfg4 at full size, twelve LM iterations (accepted and rejected steps, radius going both ways): the device
+    solver's decisions and numbers against the oracle's."""
+    pb = synth.ba_problem(200, 100000, 10, seed=777)
+    kw = dict(max_iterations=12, max_time_s=0.0)
+    c, p, f, s = bundle.ba_solve(*_ba_args(pb), ctx=ctx, opts=bundle.default_opts(**kw))
+    co, po, fo, so = orc.ba_solve(*_ba_args(pb), opts=orc.default_opts(**kw))
+    assert (s.termination, s.iterations, s.successful_steps) == (so.termination, so.iterations, so.successful_steps)
+    assert 0 < so.successful_steps < so.iterations          # (the run does contain rejected steps)
+    assert abs(s.final_cost - so.final_cost) <= 1e-9 * so.final_cost
+    assert np.allclose(c, co, rtol=1e-6, atol=1e-9) and np.allclose(p, po, rtol=1e-6, atol=1e-9)
+    assert abs(f - fo) <= 1e-6 * fo
+
+
 def test_cfg4_iterations_decrease_cost(ctx):
     """BASELINE cfg4 shape (200 cams / 100k points / 1M obs): LM iterations run and descend."""
     pb = synth.ba_problem(200, 100000, 10, seed=777)
