@@ -426,8 +426,7 @@ struct CamLds {  // camera table transposed in LDS: element e of camera slot o a
 #define SFM_ELIM_LB __launch_bounds__(512)
 #endif
 template <int NB>
-__global__ SFM_ELIM_LB void ba_eliminate_mfma(BaDev d, const Chunk* __restrict__ chunks,
-                                                         const int* __restrict__ chunk_ids,
+__device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restrict__ chunks, const int chunk_index,
                                                          const int* __restrict__ sig_cams, double inv_radius,
                                                          double lm_lo, double lm_hi, int rank,
                                                          int norms /* 1: unscaled squared column norms of the cameras and the focal into dc, nothing else */,
@@ -440,7 +439,7 @@ __global__ SFM_ELIM_LB void ba_eliminate_mfma(BaDev d, const Chunk* __restrict__
   const int nw = blockDim.x >> 6;  // 4 waves for long runs, 1 for runs of a few points (unstructured visibility)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   EL_STAMP(0, true);
-  const Chunk ch = chunks[chunk_ids[blockIdx.x]];
+  const Chunk ch = chunks[chunk_index];
   const int n = ch.n;
   const int* cams = sig_cams + ch.sig_off;
   const int sld = d.ld, fo = 6 * d.nc;
@@ -723,7 +722,7 @@ __global__ SFM_ELIM_LB void ba_eliminate_mfma(BaDev d, const Chunk* __restrict__
     // 36 k of a workgroup's 186 k cycles at cfg4 (all workgroups end together and ~25 of them add to the same entries:
     // device-scope f64 atomics execute at the memory side, same-address ones one after the other) and made S depend
     // on the order they landed in.
-    double* my = slab + (size_t)chunk_ids[blockIdx.x] * ELIM_SLAB;
+    double* my = slab + (size_t)chunk_index * ELIM_SLAB;
     if (!norms)
       for (int k = tid; k < NT * 256; k += (int)blockDim.x) my[k] = s_G[k];
     for (int idx = tid; idx < 36 * FP; idx += (int)blockDim.x) my[ELIM_SLAB_FF + idx] = s_F[idx];
@@ -736,6 +735,9 @@ __global__ SFM_ELIM_LB void ba_eliminate_mfma(BaDev d, const Chunk* __restrict__
       }
       my[ELIM_SLAB_FF + 36 * FP + 3] = gm;
       my[ELIM_SLAB_FF + 36 * FP + 4] = nf;
+      // (the focal parameter's diagonal entry and gradient once more, where ba_gather_rows finds them without knowing n)
+      my[ELIM_SLAB_FF + 36 * FP + 5] = norms ? 0.0 : s_G[g_slot(6 * n, 6 * n)];
+      my[ELIM_SLAB_FF + 36 * FP + 6] = norms ? 0.0 : s_G[g_slot(6 * n, 6 * n + 1)];
     }
     return;
   }
@@ -792,6 +794,17 @@ __global__ SFM_ELIM_LB void ba_eliminate_mfma(BaDev d, const Chunk* __restrict__
   EL_STAMP(6, true);
 }
 
+template <int NB>
+__global__ SFM_ELIM_LB void ba_eliminate_mfma(BaDev d, const Chunk* __restrict__ chunks, const int* __restrict__ chunk_ids,
+                                              const int* __restrict__ sig_cams, double inv_radius, double lm_lo, double lm_hi,
+                                              int rank, int norms, double* __restrict__ slab) {
+  // (one chunk per workgroup.  Round 3 tried several: with the slab epilogue a chunk's fixed cost is small, so the runs were cut
+  // into unequal pieces and the short ones packed two to a workgroup by a cost model -- 97-104 us per linearisation stage at
+  // cfg4 against 92 for this cut (scripts/gpu_ba_elim_pack.py at commit time): the loop around the body costs 35 VGPRs and SGPR
+  // spills, and a workgroup's time is not the sum the model assumed)
+  elim_chunk<NB>(d, chunks, chunk_ids[blockIdx.x], sig_cams, inv_radius, lm_lo, lm_hi, rank, norms, slab);
+}
+
 // Sums the slabs of ba_eliminate_mfma into the reduced-system buffer: one thread per destination (an entry of S's
 // upper triangle, of g, F^T b, the diagonal, a scalar), its sources listed by the host in chunk order (bit 31 of a
 // source = subtract).  dest < 0: the gradient maximum of this rank (a max, not a sum).  Nothing else writes `red` while
@@ -822,6 +835,147 @@ __global__ __launch_bounds__(256) void ba_gather_slabs(const double* __restrict_
   }
   v = row16_sum(v);
   if (live && j == 0) red[d] += v;
+}
+
+// The same sums, row by row (round 3: the slabs' Gram blocks are 97 % of the gather's sources, and a thread per destination
+// reads them 8 bytes at a time from a different cache line each).  Workgroups [0, row_wgs): a wave per row of S that the
+// MFMA path writes -- its sources are (chunk, local row) pairs in chunk order; the wave reads a source's row of the Gram block
+// with one lane per local column (four contiguous 128-byte segments in the MFMA layout), adds it into a row-long accumulator in
+// LDS at the column the chunk's camera list gives, and at the end subtracts the accumulator from S's row (and g's entry).
+// One wave adds a row's sources one after the other: the same order, the same bits, every run.  The workgroups behind them run
+// ba_gather_slabs' code on the few destinations that are no row of a Gram block (the F^T F diagonal, F^T b, the focal row,
+// the scalars).
+__global__ __launch_bounds__(256) void ba_gather_rows(const double* __restrict__ slab, const Chunk* __restrict__ chunks,
+                                                      const int* __restrict__ colmap, const int4* __restrict__ row_hdr,
+                                                      const int4* __restrict__ row_head, const int4* __restrict__ row_src, int nrows,
+                                                      int row_wgs, int ld, int fo, int nchunks, const int* __restrict__ ptr,
+                                                      const unsigned* __restrict__ src, const int* __restrict__ dest, int nd,
+                                                      double* __restrict__ red, long long gmax_off, int rmw) {
+  extern __shared__ double s_acc[];  // per wave: ld + 3 (the row of S | g's entry | the F^T F diagonal's | F^T b's)
+  if ((int)blockIdx.x == (int)gridDim.x - 1) {
+    // the last workgroup: the seven destinations that every chunk adds to (the focal parameter's diagonal entry and gradient
+    // from the Gram block's border, its F^T F diagonal and F^T b, the cost, the gradient maximum, the failed point blocks):
+    // thread t sums chunks t, t + T, ... in order, the threads meet by a fixed tree
+    const int T = blockDim.x, t = threadIdx.x;
+    double p[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int c0 = t; c0 < nchunks; c0 += 4 * T) {  // (four chunks' loads in flight; summed in chunk order)
+      double x[4][7];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double* tail = slab + (size_t)(c0 + u * T < nchunks ? c0 + u * T : c0) * ELIM_SLAB + ELIM_SLAB_FF + 36 * FP;
+        x[u][0] = tail[5];
+        x[u][1] = tail[6];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) x[u][2 + q] = tail[q];
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (c0 + u * T < nchunks) {
+#pragma unroll
+          for (int q = 0; q < 7; ++q) p[q] = q == 5 ? fmax(p[q], x[u][q]) : p[q] + x[u][q];
+        }
+    }
+    for (int q = 0; q < 7; ++q) s_acc[q * T + t] = p[q];
+    __syncthreads();
+    for (int h = T >> 1; h > 0; h >>= 1) {
+      if (t < h)
+        for (int q = 0; q < 7; ++q) s_acc[q * T + t] = q == 5 ? fmax(s_acc[q * T + t], s_acc[q * T + t + h]) : s_acc[q * T + t] + s_acc[q * T + t + h];
+      __syncthreads();
+    }
+    if (t < 7) {  // (seven different addresses: one read-modify-write each, side by side)
+      const size_t ssz = (size_t)ld * ld;
+      const size_t at[7] = {(size_t)fo * ld + fo, ssz + fo, ssz + 2 * (size_t)ld + fo, ssz + (size_t)ld + fo, ssz + 3 * (size_t)ld,
+                            (size_t)gmax_off, ssz + 3 * (size_t)ld + 2};
+      const double v = s_acc[t * T], o = red[at[t]];
+      red[at[t]] = t < 2 ? o - v : t == 5 ? fmax(o, v) : o + v;  // S -= Gram (F^T F folded in), g likewise; dc, F^T b, cost, nfail +=
+    }
+    return;
+  }
+  if ((int)blockIdx.x >= row_wgs) {
+    const int i = (((int)blockIdx.x - row_wgs) * blockDim.x + threadIdx.x) >> 4, j = threadIdx.x & 15;
+    const bool live = i < nd;
+    const int d = live ? dest[i] : 0;
+    const int k0 = live ? ptr[i] : 0, k1 = live ? ptr[i + 1] : 0;
+    if (live && d < 0) {  // (one destination: this rank's gradient maximum)
+      double v = 0.0;
+      for (int k = k0 + j; k < k1; k += 16) v = fmax(v, slab[src[k]]);
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 16));
+      if (j == 0) red[gmax_off] = fmax(red[gmax_off], v);
+      return;
+    }
+    double v = 0.0;
+    for (int k = k0 + j; k < k1; k += 64) {  // (four sources of the lane in flight; added in list order)
+      unsigned sk[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sk[u] = k + 16 * u < k1 ? src[k + 16 * u] : 0u;
+      double x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = slab[sk[u] & 0x7fffffffu];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (k + 16 * u < k1) v += (sk[u] >> 31) ? -x[u] : x[u];
+    }
+    v = row16_sum(v);
+    if (live && j == 0) red[d] += v;
+    return;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int w = blockIdx.x * nw + wave;
+  if (w >= nrows) return;
+  double* acc = s_acc + (size_t)wave * (ld + 3);
+  // (the row's header and its first 32 source records sit at addresses that follow from w alone: one round trip for both)
+  const int4 hdr = row_hdr[w];                      // {row of S, sources, first source record beyond the head, -}
+  int4 my = lane < 32 ? row_head[(size_t)w * 32 + lane] : make_int4(0, 0, 0, 0);
+  for (int c = lane; c < ld + 3; c += 64) acc[c] = 0.0;
+  const int gr = hdr.x, nsrc = hdr.y;
+  // per-lane constants: where local column `lane` sits inside a row of the Gram block's MFMA layout
+  const int lane_off = (lane >> 4) * 256 + (lane & 15);
+  for (int kb = 0; kb < nsrc; kb += 32) {
+    // source records: {slab offset of the chunk, local row | n << 8 | offset of the row inside the Gram block << 16, offset of
+    // the signature's column map, offsets of the row's F^T F diagonal / F^T b sums}; up to GB sources in flight, each one load
+    // of the Gram row and one of the column map (no load depends on another: a batch is one round trip to memory, and a cfg4
+    // row has 25 sources)
+    constexpr int GB = 32;
+    const int m = nsrc - kb < 32 ? nsrc - kb : 32;
+    if (kb > 0) my = lane < m ? row_src[hdr.z + (kb - 32) + lane] : make_int4(0, 0, 0, 0);  // (beyond the head: the overflow list)
+    for (int u0 = 0; u0 < m; u0 += GB) {
+      double v[GB];
+      int col[GB];
+      bool ok[GB];
+      // phase 1: every load of the batch is issued (both unconditional, at clamped addresses) ...
+#pragma unroll
+      for (int u = 0; u < GB; ++u) {
+        const int uu = u0 + u < m ? u0 + u : m - 1;  // (wave-uniform)
+        const int base = __builtin_amdgcn_readlane(my.x, uu), rec = __builtin_amdgcn_readlane(my.y, uu);
+        const int cm = __builtin_amdgcn_readlane(my.z, uu), ff = __builtin_amdgcn_readlane(my.w, uu);
+        const int lr = rec & 255, n = (rec >> 8) & 255, roff = (int)((unsigned)rec >> 16);
+        ok[u] = u0 + u < m && ((lane >= lr && lane < 6 * n + 2) || lane >= 62);
+        // lanes 62, 63 (beyond any Gram block of n <= 10 cameras): the row's entry of the F^T F diagonal and of F^T b
+        const int idx = lane >= 62 ? ELIM_SLAB_FF + (lane == 62 ? (ff & 0xFFFF) : (int)((unsigned)ff >> 16)) : roff + lane_off;
+        v[u] = slab[(size_t)(unsigned)base + (ok[u] ? idx : 0)];
+        col[u] = colmap[cm + lane];
+      }
+      // ... before the first of them is waited for (a use next to its load makes the row's sources go to memory one after
+      // the other)
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < GB; ++u)  // (ds_add_f64: a wave's LDS operations execute in order -- the sources add one after the other)
+        if (ok[u]) __hip_atomic_fetch_add((lds_double*)acc + col[u], v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  double* Srow = red + (size_t)gr * ld;
+  const size_t ssz = (size_t)ld * ld;
+  for (int c = lane; c < ld + 3; c += 64) {
+    const double a = acc[c];
+    if (a != 0.0) {
+      double* at = c < ld ? Srow + c : c == ld ? red + ssz + gr : c == ld + 1 ? red + ssz + 2 * (size_t)ld + gr : red + ssz + (size_t)ld + gr;
+      // (rmw == 0: the MFMA path is the only writer of these entries between the memset and here -- no pair-path points)
+      const double o = rmw ? *at : 0.0;
+      *at = c <= ld ? o - a : o + a;  // S -= Gram (F^T F folded in), g likewise; the diagonal and F^T b +=
+    }
+  }
 }
 
 // The camera's own blocks for the pair path's points, from the camera-major list of their observations: thread per
@@ -2526,13 +2680,19 @@ struct sfmhip_ba {
   bool chol_attr_set = false;
   // plan
   Chunk* d_chunks = nullptr;
-  bool elim_deterministic = getenv("SFMHIP_BA_DETERMINISTIC") && atoi(getenv("SFMHIP_BA_DETERMINISTIC")) == 1;
+  bool elim_deterministic = !(getenv("SFMHIP_BA_DETERMINISTIC") && atoi(getenv("SFMHIP_BA_DETERMINISTIC")) == 0);  // (the default since round 3)
   // slab epilogue of ba_eliminate_mfma + ba_gather_slabs: [0] the full linearisation, [1] the norms-only mode
   double* d_slab = nullptr;
   int* d_gth_ptr[2] = {nullptr, nullptr};
   unsigned* d_gth_src[2] = {nullptr, nullptr};
   int* d_gth_dest[2] = {nullptr, nullptr};
   int n_gth[2] = {0, 0};
+  // the row lists of ba_gather_rows (full linearisation): rows of S the MFMA path writes, their (chunk, local row) sources
+  int4* d_grow_hdr = nullptr;
+  int4* d_grow_head = nullptr;
+  int4* d_grow_src = nullptr;
+  int* d_grow_colmap = nullptr;
+  int n_grow = 0, grow_waves = 4, n_chunks = 0;
   int* d_chunk_ids[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int n_chunk_ids[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [NB-1]: 4-wave workgroups (long runs), [4 + NB-1]: 1-wave (short runs)
   int* d_sig_cams = nullptr;
@@ -2879,12 +3039,60 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   lap_("chunks");
   // ---- the gather lists of the slab epilogue (ba_gather_slabs): for every destination in `red` the slab entries that
   // add to it, in chunk order; list 0 for a full linearisation, list 1 for the norms-only mode (diagonal only)
-  std::vector<int> gth_ptr[2], gth_dest[2];
+  std::vector<int> gth_ptr[2], gth_dest[2], grow_ptr, grow_id, grow_colmap;
   std::vector<unsigned> gth_src[2];
+  std::vector<int4> grow_src, grow_hdr, grow_head, grow_over;
   if (b->elim_deterministic && !chunks.empty() && chunks.size() * (size_t)ELIM_SLAB < ((size_t)1 << 31)) {
     const int ld = b->ld, fo = 6 * n_cam;
     const long long ssz = (long long)b->ssz, o_g = ssz, o_gF = ssz + ld, o_dc = ssz + 2LL * ld, o_sc = ssz + 3LL * ld;
     std::vector<std::pair<long long, unsigned>> ent[2];  // (destination, source | sign)
+    // rows of S by their own kernel role while a row-long accumulator per wave fits the default LDS limit
+    const bool use_rows = (size_t)(ld + 3) * 8 <= 65536 && !(getenv("SFMHIP_BA_GATHER_ROWS") && atoi(getenv("SFMHIP_BA_GATHER_ROWS")) == 0);
+    b->grow_waves = (size_t)(ld + 3) * 8 * 4 <= 65536 ? 4 : (size_t)(ld + 3) * 8 * 2 <= 65536 ? 2 : 1;
+    if (use_rows) {
+      std::vector<int> cntr((size_t)fo + 1, 0);
+      for (const Chunk& ch : chunks)
+        for (int sl = 0; sl < ch.n; ++sl)
+          for (int i = 0; i < 6; ++i) ++cntr[(size_t)6 * sig_cams[ch.sig_off + sl] + i + 1];
+      for (int r = 0; r < fo; ++r) cntr[r + 1] += cntr[r];
+      grow_src.resize((size_t)cntr[fo]);
+      std::vector<int> pos(cntr.begin(), cntr.end() - 1);
+      std::map<int, int> cmap_of;  // signature (offset of its camera list) -> offset of its column map
+      for (size_t c = 0; c < chunks.size(); ++c) {  // chunk order inside every row
+        const Chunk& ch = chunks[c];
+        const int n = ch.n, NBc = (6 * n + 2 + 15) / 16;
+        auto itc = cmap_of.find(ch.sig_off);
+        if (itc == cmap_of.end()) {
+          // local column -> where it adds: a column of S, the focal column, g's entry (ld); 62, 63: the diagonal's and F^T b's
+          itc = cmap_of.emplace(ch.sig_off, (int)grow_colmap.size()).first;
+          for (int lc = 0; lc < 64; ++lc)
+            grow_colmap.push_back(lc >= 62 ? ld + lc - 61 : lc < 6 * n ? 6 * sig_cams[ch.sig_off + lc / 6] + lc % 6 : lc == 6 * n ? fo : ld);
+        }
+        for (int sl = 0; sl < n; ++sl)
+          for (int i = 0; i < 6; ++i) {
+            const int lr = 6 * sl + i, ti = lr >> 4;
+            const int t0 = ti * NBc - ti * (ti - 1) / 2;  // tile (ti, ti)
+            const int roff = (t0 * 4 + ((lr & 15) >> 2)) * 64 + (lr & 3) * 16 - 256 * ti;
+            const int dcr = (i * 6 - i * (i - 1) / 2) * FP + sl, gfr = (27 + i) * FP + sl;
+            grow_src[(size_t)pos[(size_t)6 * sig_cams[ch.sig_off + sl] + i]++] =
+                make_int4((int)(unsigned)(c * (size_t)ELIM_SLAB), lr | (n << 8) | (roff << 16), itc->second, dcr | (gfr << 16));
+          }
+      }
+      for (int r = 0; r < fo; ++r)
+        if (cntr[r + 1] > cntr[r]) {
+          grow_ptr.push_back(cntr[r]);
+          grow_id.push_back(r);
+        }
+      grow_ptr.push_back(cntr[fo]);
+      // a row's first 32 records in a table of their own (fixed stride), the rest in one overflow list
+      for (size_t r = 0; r < grow_id.size(); ++r) {
+        const int k0 = grow_ptr[r], cnt = grow_ptr[r + 1] - k0;
+        grow_hdr.push_back(make_int4(grow_id[r], cnt, (int)grow_over.size(), 0));
+        for (int k = 0; k < 32; ++k) grow_head.push_back(k < cnt ? grow_src[(size_t)k0 + k] : make_int4(0, 0, 0, 0));
+        for (int k = 32; k < cnt; ++k) grow_over.push_back(grow_src[(size_t)k0 + k]);
+      }
+      if (grow_over.empty()) grow_over.push_back(make_int4(0, 0, 0, 0));
+    }
     const long long GMAX = -1;                            // (sorts first; the kernel takes the rank's slot as an argument)
     for (size_t c = 0; c < chunks.size(); ++c) {
       const Chunk& ch = chunks[c];
@@ -2902,6 +3110,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
         const int lr = 16 * ti + (ln >> 4) + 4 * gg, lc = 16 * tj + (ln & 15);
         const int gr = gidx(lr), gc = gidx(lc);
         if (gr < 0 || lr > lc || gc == -1) continue;
+        if (use_rows) continue;  // (ba_gather_rows: the cameras' rows from the row lists below, the focal row chunk by chunk)
         ent[0].push_back({gc >= 0 ? (long long)gr * ld + gc : o_g + gr, (base + idx) | 0x80000000u});  // S -= Gram (F^T F folded in)
       }
       for (int e = 0; e < 33; ++e)
@@ -2915,20 +3124,22 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
               ++i;
             }
             if (rem == 0) {
-              ent[0].push_back({o_dc + r0 + i, sidx});
+              if (!use_rows) ent[0].push_back({o_dc + r0 + i, sidx});
               ent[1].push_back({o_dc + r0 + i, sidx});
             }
           } else if (e >= 27) {
-            ent[0].push_back({o_gF + r0 + e - 27, sidx});
+            if (!use_rows) ent[0].push_back({o_gF + r0 + e - 27, sidx});
           }
         }
       const unsigned tail = base + ELIM_SLAB_FF + 36 * FP;
-      ent[0].push_back({o_dc + fo, tail});
       ent[1].push_back({o_dc + fo, tail});
-      ent[0].push_back({o_gF + fo, tail + 1});
-      ent[0].push_back({o_sc + 0, tail + 2});
-      ent[0].push_back({GMAX, tail + 3});
-      ent[0].push_back({o_sc + 2, tail + 4});
+      if (!use_rows) {
+        ent[0].push_back({o_dc + fo, tail});
+        ent[0].push_back({o_gF + fo, tail + 1});
+        ent[0].push_back({o_sc + 0, tail + 2});
+        ent[0].push_back({GMAX, tail + 3});
+        ent[0].push_back({o_sc + 2, tail + 4});
+      }
     }
     for (int m = 0; m < 2; ++m) {
       // counting sort by destination (stable: a destination's sources stay in chunk order)
@@ -3059,12 +3270,18 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   BA_A(b->d_cam_used, n_cam);
   BA_A(b->d_flag, 2);
   BA_A(b->d_chunks, chunks.size());
-  if (!gth_dest[0].empty()) {
+  if (!gth_dest[0].empty() || !gth_dest[1].empty() || !grow_id.empty()) {
     BA_A(b->d_slab, chunks.size() * (size_t)ELIM_SLAB);
     for (int m = 0; m < 2; ++m) {
       BA_A(b->d_gth_ptr[m], gth_ptr[m].size());
       BA_A(b->d_gth_src[m], gth_src[m].size());
       BA_A(b->d_gth_dest[m], gth_dest[m].size());
+    }
+    if (!grow_id.empty()) {
+      BA_A(b->d_grow_hdr, grow_hdr.size());
+      BA_A(b->d_grow_head, grow_head.size());
+      BA_A(b->d_grow_src, grow_over.size());
+      BA_A(b->d_grow_colmap, grow_colmap.size());
     }
   }
   for (int c = 0; c < 8; ++c) BA_A(b->d_chunk_ids[c], ids[c].size());
@@ -3101,11 +3318,19 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   SFM_HIP_TRY(up(d_oxy, oxy.data(), oxy.size() * 8));
   SFM_HIP_TRY(up(b->d_cam_used, b->h_cam_used.data(), n_cam));
   SFM_HIP_TRY(up(b->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk)));
+  b->n_chunks = (int)chunks.size();
   for (int m = 0; m < 2 && b->d_slab; ++m) {
     SFM_HIP_TRY(up(b->d_gth_ptr[m], gth_ptr[m].data(), gth_ptr[m].size() * 4));
     SFM_HIP_TRY(up(b->d_gth_src[m], gth_src[m].data(), gth_src[m].size() * 4));
     SFM_HIP_TRY(up(b->d_gth_dest[m], gth_dest[m].data(), gth_dest[m].size() * 4));
     b->n_gth[m] = (int)gth_dest[m].size();
+  }
+  if (b->d_slab && !grow_id.empty()) {
+    SFM_HIP_TRY(up(b->d_grow_hdr, grow_hdr.data(), grow_hdr.size() * sizeof(int4)));
+    SFM_HIP_TRY(up(b->d_grow_head, grow_head.data(), grow_head.size() * sizeof(int4)));
+    SFM_HIP_TRY(up(b->d_grow_src, grow_over.data(), grow_over.size() * sizeof(int4)));
+    SFM_HIP_TRY(up(b->d_grow_colmap, grow_colmap.data(), grow_colmap.size() * 4));
+    b->n_grow = (int)grow_id.size();
   }
   for (int c = 0; c < 8; ++c) SFM_HIP_TRY(up(b->d_chunk_ids[c], ids[c].data(), ids[c].size() * 4));
   SFM_HIP_TRY(up(b->d_sig_cams, sig_cams.data(), sig_cams.size() * 4));
@@ -3267,12 +3492,12 @@ static int ba_agree_flag(sfmhip_ba* b, int* flag) {
 static int ba_launch_eliminate(sfmhip_ba* b, double inv_radius, double lm_lo, double lm_hi, int norms) {
   hipStream_t st = b->ctx->stream;
   int nl = 0;
-  // Two epilogues.  Default: the workgroups scatter their sums into S with f64 atomics (order-dependent in the last
-  // bits).  SFMHIP_BA_DETERMINISTIC=1 (read when the problem is created): every workgroup stores its sums in a slab of
-  // its own and ba_gather_slabs adds the slabs in a fixed order -- S, g and the cost are then the same bit patterns run
-  // after run.  Measured at cfg4 (scripts/gpu_prof_elim_ab.sh): the elimination kernel 84.9 -> 73.3 us without the
-  // scatter, the gather kernel 22.5 us (1 M scattered 8-byte sources, three dependent loads deep): +11 us per
-  // linearisation, which is why it is an option and not the default.
+  // Two epilogues.  Default (since round 3): every workgroup stores its sums in a slab of its own and ba_gather_rows adds the
+  // slabs in a fixed order -- S, g and the cost are the same bit patterns run after run.  SFMHIP_BA_DETERMINISTIC=0 (read when
+  // the problem is created): the workgroups scatter their sums into S with f64 atomics (order-dependent in the last bits).
+  // Measured at cfg4 (scripts/gpu_prof_elim_ab.sh): the elimination kernel 84.5 us with the scatter, 74.5 without; the gather
+  // 22.5 us as a thread per destination (1 M scattered 8-byte sources), 10.9 us row by row (ba_gather_rows): the stage
+  // 92.2 us against 91.3.
   double* slab = b->elim_deterministic ? b->d_slab : nullptr;
 #define BA_ELIM(NB)                                                                                                   \
   for (int cls = 0; cls < 2; ++cls) {                                                                                 \
@@ -3292,7 +3517,16 @@ static int ba_launch_eliminate(sfmhip_ba* b, double inv_radius, double lm_lo, do
   BA_ELIM(4)
 #undef BA_ELIM
   const int m = norms ? 1 : 0;
-  if (slab && nl && b->n_gth[m]) {
+  if (slab && nl && m == 0 && b->n_grow) {
+    const int rw = (b->n_grow + b->grow_waves - 1) / b->grow_waves, gw = (b->n_gth[0] * 16 + 64 * b->grow_waves - 1) / (64 * b->grow_waves);
+    const size_t lds_g = sizeof(double) * std::max((size_t)(b->ld + 3) * b->grow_waves, (size_t)7 * 64 * b->grow_waves);
+    hipLaunchKernelGGL(ba_gather_rows, dim3(rw + gw + 1), dim3(64 * b->grow_waves), lds_g, st,
+                       (const double*)slab, (const Chunk*)b->d_chunks, (const int*)b->d_grow_colmap, (const int4*)b->d_grow_hdr,
+                       (const int4*)b->d_grow_head, (const int4*)b->d_grow_src, b->n_grow, rw, b->ld, 6 * b->nc, b->n_chunks, (const int*)b->d_gth_ptr[0],
+                       (const unsigned*)b->d_gth_src[0], (const int*)b->d_gth_dest[0], b->n_gth[0], b->d.red,
+                       (long long)(b->ssz + 3 * (size_t)b->ld + SC + b->rank), b->n_fb ? 1 : 0);
+    ++nl;
+  } else if (slab && nl && b->n_gth[m]) {
     hipLaunchKernelGGL(ba_gather_slabs, dim3((b->n_gth[m] + 15) / 16), dim3(256), 0, st, (const double*)slab,
                        (const int*)b->d_gth_ptr[m], (const unsigned*)b->d_gth_src[m], (const int*)b->d_gth_dest[m], b->n_gth[m],
                        b->d.red, (long long)(b->ssz + 3 * (size_t)b->ld + SC + b->rank));

@@ -505,15 +505,16 @@ def test_solver_on_a_busy_device_walks_the_same_iterates(ctx):
     ctx2.close()                                      # (after everything that lives on it)
 
 
-def test_deterministic_linearisation_option_is_bitwise_reproducible(ctx, monkeypatch):
-    """SFMHIP_BA_DETERMINISTIC=1: the elimination's workgroups store their sums in slabs and ba_gather_slabs adds them
-    in a fixed order -- S, g and the cost come out as the same bit patterns on every run (the default epilogue scatters
-    with f64 atomics: same values to ~1e-15, not the same bits), and they are the default path's values"""
+def test_linearisation_is_bitwise_reproducible(ctx, monkeypatch):
+    """The default epilogue: the elimination's workgroups store their sums in slabs and ba_gather_rows adds them in a fixed
+    order -- S, g and the cost come out as the same bit patterns on every run; SFMHIP_BA_DETERMINISTIC=0 scatters with f64
+    atomics instead (same values to ~1e-15, not the same bits), and the two agree"""
     pb = synth.ba_problem(60, 30000, 10, seed=19)
-    monkeypatch.setenv("SFMHIP_BA_DETERMINISTIC", "1")
+    monkeypatch.delenv("SFMHIP_BA_DETERMINISTIC", raising=False)
     det = bundle.BaProblem(60, 30000, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
-    monkeypatch.delenv("SFMHIP_BA_DETERMINISTIC")
+    monkeypatch.setenv("SFMHIP_BA_DETERMINISTIC", "0")
     ref = bundle.BaProblem(60, 30000, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
+    monkeypatch.delenv("SFMHIP_BA_DETERMINISTIC")
     runs = []
     for _ in range(3):
         det.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
@@ -525,7 +526,7 @@ def test_deterministic_linearisation_option_is_bitwise_reproducible(ctx, monkeyp
     S1, g1, c1 = ref.reduced_system(1e4)
     assert np.abs(S1 - runs[0][0]).max() <= 1e-12 * np.abs(S1).max() and np.abs(g1 - runs[0][1]).max() <= 1e-12 * np.abs(g1).max()
     assert abs(c1 - runs[0][2]) <= 1e-13 * c1
-    # and the LM iterates follow the default path's
+    # and the LM iterates follow the atomic path's
     det.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
     ref.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
     sd, sr = det.iterate(5), ref.iterate(5)
