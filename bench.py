@@ -463,7 +463,10 @@ def main():
     ba_stream_s = (ba_t["eliminate_s"] + ba_t["backsub_s"]) / max(args.steps, 1)
     ba_gbs = ba_bytes / ba_stream_s / 1e9
     tr_ba = [hbm_bytes(k) for k in ("ba_eliminate_mfma", "ba_backsub")]
-    roofline_ba = {"kernels": "ba_eliminate_mfma (one linearisation: F^T F + Schur correction) + ba_backsub (per LM iteration, "
+    if hbm_bytes("ba_gather_rows") is not None:      # (the default slab epilogue's second kernel; absent from older profiles)
+        tr_ba.append(hbm_bytes("ba_gather_rows"))
+    roofline_ba = {"kernels": "ba_eliminate_mfma + ba_gather_rows (one linearisation: F^T F + Schur correction, per-workgroup slabs "
+                              "summed in a fixed order: S, g and the cost are bitwise reproducible) + ba_backsub (per LM iteration, "
                               "this rank's shard)",
                    "bound": "hbm", "achieved": round(ba_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": round(ba_gbs / HBM_PEAK_GBS, 4),
