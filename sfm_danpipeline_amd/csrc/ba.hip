@@ -838,14 +838,17 @@ __global__ __launch_bounds__(256) void ba_gather_slabs(const double* __restrict_
 }
 
 // The same sums, row by row (round 3: the slabs' Gram blocks are 97 % of the gather's sources, and a thread per destination
-// reads them 8 bytes at a time from a different cache line each).  Workgroups [0, row_wgs): a wave per row of S that the
-// MFMA path writes -- its sources are (chunk, local row) pairs in chunk order; the wave reads a source's row of the Gram block
-// with one lane per local column (four contiguous 128-byte segments in the MFMA layout), adds it into a row-long accumulator in
-// LDS at the column the chunk's camera list gives, and at the end subtracts the accumulator from S's row (and g's entry).
-// One wave adds a row's sources one after the other: the same order, the same bits, every run.  The workgroups behind them run
-// ba_gather_slabs' code on the few destinations that are no row of a Gram block (the F^T F diagonal, F^T b, the focal row,
-// the scalars).
-__global__ __launch_bounds__(256) void ba_gather_rows(const double* __restrict__ slab, const Chunk* __restrict__ chunks,
+// reads them 8 bytes at a time from a different cache line each).  Three roles by workgroup index:
+//  * [0, row_wgs): a wave per row of S that the MFMA path writes.  Its sources are (chunk, local row) records in chunk order
+//    (header + first 32 records at addresses that follow from the row number: one round trip; the rest in an overflow list).
+//    The wave reads a source's row of the Gram block with one lane per local column (four contiguous 128-byte segments in the
+//    MFMA layout; lanes 62 / 63 take the row's F^T F diagonal and F^T b sums instead), adds it (ds_add_f64) into a row-long
+//    accumulator in LDS at the column the signature's column map gives, and at the end writes S's row, g's, the diagonal's and
+//    F^T b's entries.  One wave adds a row's sources one after the other: the same order, the same bits, every run.
+//  * the workgroups behind them: ba_gather_slabs' code for whatever else the host lists (nothing at present).
+//  * the last workgroup: the seven sums that every chunk adds to (the focal parameter's entries, the cost, the gradient
+//    maximum, the failed point blocks), thread t over chunks t, t + T, ..., a fixed tree across the threads.
+__global__ __launch_bounds__(256) void ba_gather_rows(const double* __restrict__ slab,
                                                       const int* __restrict__ colmap, const int4* __restrict__ row_hdr,
                                                       const int4* __restrict__ row_head, const int4* __restrict__ row_src, int nrows,
                                                       int row_wgs, int ld, int fo, int nchunks, const int* __restrict__ ptr,
@@ -3521,7 +3524,7 @@ static int ba_launch_eliminate(sfmhip_ba* b, double inv_radius, double lm_lo, do
     const int rw = (b->n_grow + b->grow_waves - 1) / b->grow_waves, gw = (b->n_gth[0] * 16 + 64 * b->grow_waves - 1) / (64 * b->grow_waves);
     const size_t lds_g = sizeof(double) * std::max((size_t)(b->ld + 3) * b->grow_waves, (size_t)7 * 64 * b->grow_waves);
     hipLaunchKernelGGL(ba_gather_rows, dim3(rw + gw + 1), dim3(64 * b->grow_waves), lds_g, st,
-                       (const double*)slab, (const Chunk*)b->d_chunks, (const int*)b->d_grow_colmap, (const int4*)b->d_grow_hdr,
+                       (const double*)slab, (const int*)b->d_grow_colmap, (const int4*)b->d_grow_hdr,
                        (const int4*)b->d_grow_head, (const int4*)b->d_grow_src, b->n_grow, rw, b->ld, 6 * b->nc, b->n_chunks, (const int*)b->d_gth_ptr[0],
                        (const unsigned*)b->d_gth_src[0], (const int*)b->d_gth_dest[0], b->n_gth[0], b->d.red,
                        (long long)(b->ssz + 3 * (size_t)b->ld + SC + b->rank), b->n_fb ? 1 : 0);
