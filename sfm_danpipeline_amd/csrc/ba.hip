@@ -2219,9 +2219,19 @@ struct NdSet {
 // fin != 0: ba_finalize's work rides along (one launch less per LM iteration) -- the LM diagonal is added to the
 // diagonal elements as the tiles are copied (S itself stays undamped), and one more workgroup (job kind 4) leaves the
 // clamped column norms, the gradient maximum and a zeroed z.
-__global__ __launch_bounds__(256) void nd_gather(NdSet ns, const int4* __restrict__ jobs, const double* __restrict__ S,
+constexpr int ND_ZERO_SLICE = 8192;  // doubles per workgroup of nd_gather's zeroing role
+__global__ __launch_bounds__(256) void nd_gather(NdSet ns, const int4* __restrict__ jobs, int n_jobs, const double* __restrict__ S,
                                                  const double* __restrict__ g, int ldS, BaDev d, int fin, double radius,
-                                                 double lm_lo, double lm_hi, int world) {
+                                                 double lm_lo, double lm_hi, int world, double* __restrict__ zero_ptr, long long zero_n) {
+  if ((int)blockIdx.x >= n_jobs) {
+    // the workgroups behind the jobs zero the OTHER reduced-system buffer, slice by slice: the next linearisation starts on it
+    // without a memset of its own (an 11.8 MB fill is 5 us as a launch in the stream, nothing beside this kernel's jobs)
+    const long long lo = (long long)((int)blockIdx.x - n_jobs) * ND_ZERO_SLICE;
+    double2* p2 = (double2*)(zero_ptr + lo);
+    const long long n2 = (zero_n - lo < ND_ZERO_SLICE ? zero_n - lo : ND_ZERO_SLICE) / 2;
+    for (long long i = threadIdx.x; i < n2; i += 256) p2[i] = make_double2(0.0, 0.0);
+    return;
+  }
   const int4 job = jobs[blockIdx.x];
   if (job.w == 4) {
     if (!fin) return;
@@ -2734,6 +2744,10 @@ struct sfmhip_ba {
   // device storage owned
   std::vector<void*> allocs;
   size_t red_count = 0;
+  // dissected solve: a second [S | g | ... | red2] buffer that nd_gather's spare workgroups zero while they are at it, so
+  // that the next linearisation starts on a clean buffer instead of behind a memset launch
+  double* red_alt = nullptr;
+  bool alt_clean = false, red_is_alt = false;
   double* d_red_pack = nullptr;  // world > 1: the all-reduce payload (packed upper triangle of S + tail)
   int2* d_xblocks = nullptr;     // world > 1, sparse camera graph: the co-visible camera pairs (a <= b) that are exchanged
   int n_xblocks = 0;             // 0: the dense exchange
@@ -3588,7 +3602,22 @@ static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_o
     b->ev_on[0] = true;
   }
   // (X, the last ld*ld doubles, belongs to the dense factorisation only)
-  SFM_HIP_TRY(hipMemsetAsync(d.red, 0, sizeof(double) * (b->nd_on ? b->red_count - b->ssz : b->red_count), st));
+  auto swap_red = [&]() {
+    std::swap(d.red, b->red_alt);
+    b->red_is_alt = !b->red_is_alt;
+    d.red2 = d.red + b->ssz + 3 * (size_t)b->ld + SC + 64;
+    d.info = (int*)(d.red2 + RED2_INFO);
+  };
+  bool filled = true;
+  if (b->nd_on && b->alt_clean) {
+    swap_red();  // (the last nd_gather zeroed it; stream order is the only dependency)
+    b->alt_clean = false;
+    filled = false;
+  } else {
+    if (!b->nd_on && b->red_is_alt) swap_red();  // (the dense factorisation's X lives behind the first buffer)
+    b->alt_clean = false;
+    SFM_HIP_TRY(hipMemsetAsync(d.red, 0, sizeof(double) * (b->nd_on ? b->red_count - b->ssz : b->red_count), st));
+  }
   if (!b->camd_valid) {
     hipLaunchKernelGGL(ba_cam_prep, dim3((b->nc + 63) / 64), dim3(64), 0, st, d.cams, d.camd, b->nc, 1);
     b->camd_valid = true;
@@ -3608,7 +3637,7 @@ static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_o
     nl += 3;
   }
   SFM_HIP_TRY(hipGetLastError());
-  b->launches += 1 + nl;
+  b->launches += (filled ? 1 : 0) + nl;
   if (b->ctx->timing) {
     SFM_HIP_TRY(hipEventRecord(b->ev[1], st));
     b->ev_on[1] = true;
@@ -3974,8 +4003,14 @@ static int ba_reduced_solve_nd(sfmhip_ba* b) {
     SFM_HIP_TRY(hipFuncSetAttribute((const void*)chol_step2, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS_BYTES));
     b->chol_chains_attr_set = true;
   }
-  hipLaunchKernelGGL(nd_gather, dim3(b->nd_n_gather), dim3(256), 0, st, ns, b->nd_gather_jobs, d.red, d.red + b->ssz, d.ld, d,
-                     b->fin_pending ? 1 : 0, b->fin_radius, b->fin_lo, b->fin_hi, b->world);
+  static const bool prezero = !(getenv("SFMHIP_BA_PREZERO") && atoi(getenv("SFMHIP_BA_PREZERO")) == 0);
+  const size_t nz = b->red_count - b->ssz;  // everything but X (an even number of doubles: ld is a multiple of 64, SC + 64 + RED2_N even)
+  if (prezero && !b->red_alt && nz % 2 == 0) SFM_TRY(ba_alloc(b, &b->red_alt, nz));
+  const int zwg = prezero && b->red_alt ? (int)((nz + ND_ZERO_SLICE - 1) / ND_ZERO_SLICE) : 0;
+  hipLaunchKernelGGL(nd_gather, dim3(b->nd_n_gather + zwg), dim3(256), 0, st, ns, b->nd_gather_jobs, b->nd_n_gather, d.red,
+                     d.red + b->ssz, d.ld, d, b->fin_pending ? 1 : 0, b->fin_radius, b->fin_lo, b->fin_hi, b->world, b->red_alt,
+                     (long long)nz);
+  if (zwg) b->alt_clean = true;
   b->fin_pending = false;
   int nl = 1;
   if (dbg) nd_census(b, "gather");
