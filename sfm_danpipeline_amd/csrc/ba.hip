@@ -2748,6 +2748,7 @@ struct sfmhip_ba {
   // that the next linearisation starts on a clean buffer instead of behind a memset launch
   double* red_alt = nullptr;
   bool alt_clean = false, red_is_alt = false;
+  bool prezero = !(getenv("SFMHIP_BA_PREZERO") && atoi(getenv("SFMHIP_BA_PREZERO")) == 0);  // (read when the problem is created)
   double* d_red_pack = nullptr;  // world > 1: the all-reduce payload (packed upper triangle of S + tail)
   int2* d_xblocks = nullptr;     // world > 1, sparse camera graph: the co-visible camera pairs (a <= b) that are exchanged
   int n_xblocks = 0;             // 0: the dense exchange
@@ -4003,7 +4004,7 @@ static int ba_reduced_solve_nd(sfmhip_ba* b) {
     SFM_HIP_TRY(hipFuncSetAttribute((const void*)chol_step2, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS_BYTES));
     b->chol_chains_attr_set = true;
   }
-  static const bool prezero = !(getenv("SFMHIP_BA_PREZERO") && atoi(getenv("SFMHIP_BA_PREZERO")) == 0);
+  const bool prezero = b->prezero;
   const size_t nz = b->red_count - b->ssz;  // everything but X (an even number of doubles: ld is a multiple of 64, SC + 64 + RED2_N even)
   if (prezero && !b->red_alt && nz % 2 == 0) SFM_TRY(ba_alloc(b, &b->red_alt, nz));
   const int zwg = prezero && b->red_alt ? (int)((nz + ND_ZERO_SLICE - 1) / ND_ZERO_SLICE) : 0;

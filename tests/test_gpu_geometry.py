@@ -505,6 +505,32 @@ def test_solver_on_a_busy_device_walks_the_same_iterates(ctx):
     ctx2.close()                                      # (after everything that lives on it)
 
 
+def test_second_reduced_system_buffer_changes_nothing(ctx, monkeypatch):
+    """The dissected solve's gather zeroes a second [S | g | ...] buffer on the side and the next linearisation swaps the two
+    instead of filling one (SFMHIP_BA_PREZERO=0: a memset per linearisation): the same systems bit for bit, the same LM run --
+    through accepted and rejected steps, a parameter reset in between, and a look at the reduced system afterwards"""
+    pb = synth.ba_problem(80, 40000, 10, seed=23)
+    monkeypatch.delenv("SFMHIP_BA_PREZERO", raising=False)
+    a = bundle.BaProblem(80, 40000, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
+    monkeypatch.setenv("SFMHIP_BA_PREZERO", "0")
+    b = bundle.BaProblem(80, 40000, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
+    monkeypatch.delenv("SFMHIP_BA_PREZERO")
+    for prob in (a, b):
+        prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+    sa, sb = a.iterate(9), b.iterate(9)
+    assert 0 < sa.successful_steps and (sa.successful_steps, sa.iterations) == (sb.successful_steps, sb.iterations)
+    assert abs(sa.final_cost - sb.final_cost) <= 1e-12 * sb.final_cost
+    for prob in (a, b):                                # a new start on the same objects
+        prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+    sa, sb = a.iterate(4), b.iterate(4)
+    assert abs(sa.final_cost - sb.final_cost) <= 1e-12 * sb.final_cost
+    (Sa, ga, ca), (Sb, gb, cb) = a.reduced_system(1e4), b.reduced_system(1e4)
+    assert np.abs(Sa - Sb).max() <= 1e-12 * np.abs(Sb).max() and np.abs(ga - gb).max() <= 1e-12 * np.abs(gb).max()
+    assert abs(ca - cb) <= 1e-12 * cb
+    a.close()
+    b.close()
+
+
 def test_linearisation_is_bitwise_reproducible(ctx, monkeypatch):
     """The default epilogue: the elimination's workgroups store their sums in slabs and ba_gather_rows adds them in a fixed
     order -- S, g and the cost come out as the same bit patterns on every run; SFMHIP_BA_DETERMINISTIC=0 scatters with f64
