@@ -797,7 +797,10 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
     // phase D: lane top-2 by (h descending, position ascending) as 64-bit keys; phase E: distances, merge of
     // the query's two lanes by (d, position) -- the same order as (d, original row): equal d means equal
     // parity class, and positions keep the original order inside a class -- then the rows' original indices
-    long long best[NU][2];  // query level: (d << 32 | position), ascending; 0x7FFF...: none
+    // (NU == 2: the half-wave h_p finalises query tile h_p -- every lane ends up with ONE query to merge, look up and
+    // emit, so that part of the code runs once per wave instead of once per query tile; the resolve's instructions compete
+    // with the SIMD partner's sweep for issue slots, and this half was a fifth of them.  NU == 1: lanes h_p == 0 emit.)
+    long long lane_dk[NU][2];  // the lane's best two of query tile u: (d << 32 | position), ascending; 0x7FFF...: none
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       long long key[4];
@@ -809,42 +812,45 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
       }
       const long long a = max(key[0], key[1]), b = min(key[0], key[1]);
       const long long c = max(key[2], key[3]), dd = min(key[2], key[3]);
-      const long long l0 = max(a, c), l1 = max(min(a, c), max(b, dd));
-      long long dk[2];
-      const long long lk[2] = {l0, l1};
+      const long long lk[2] = {max(a, c), max(min(a, c), max(b, dd))};
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int hv = (int)(lk[k] >> 32), ps = 0x7FFFFFFF - (int)(unsigned)lk[k];
         const int d = MODE == 0 ? nqq[u] - 2 * hv - (ps < nodd_t ? 1 : 0) : (nbits - hv) >> 1;
-        dk[k] = hv > HPAD ? (((long long)d << 32) | (unsigned)ps) : 0x7FFFFFFFFFFFFFFFll;  // smaller = better
+        lane_dk[u][k] = hv > HPAD ? (((long long)d << 32) | (unsigned)ps) : 0x7FFFFFFFFFFFFFFFll;  // smaller = better
       }
-      const long long o0 = __shfl_xor(dk[0], 32), o1 = __shfl_xor(dk[1], 32);
-      best[u][0] = min(dk[0], o0);
-      best[u][1] = min(max(dk[0], o0), min(dk[1], o1));
     }
-    int x0[NU], x1[NU];
+    // the query this lane finalises: tile UM = h_p (NU == 2) or tile 0; its other lane's pair comes by one exchange
+    constexpr bool SPLIT = NU == 2;
+    const bool um = SPLIT && h_p != 0;
+    long long mine[2], give[2];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const unsigned p0 = (unsigned)best[u][0], p1 = (unsigned)best[u][1];
-      x0[u] = ((g_i32_p)T.perm)[p0 < (unsigned)T.n_pad ? p0 : 0u];
-      x1[u] = ((g_i32_p)T.perm)[p1 < (unsigned)T.n_pad ? p1 : 0u];
+    for (int k = 0; k < 2; ++k) {
+      mine[k] = um ? lane_dk[NU - 1][k] : lane_dk[0][k];
+      give[k] = SPLIT ? (um ? lane_dk[0][k] : lane_dk[NU - 1][k]) : lane_dk[0][k];  // what the partner lane merges with ITS pair
     }
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
+    const long long o0 = __shfl_xor(give[0], 32), o1 = __shfl_xor(give[1], 32);
+    const long long best0 = min(mine[0], o0), best1 = min(max(mine[0], o0), min(mine[1], o1));
+    const int my_qrow = um ? qrow[NU - 1] : qrow[0];
+    int my_ovf = um ? ovf[NU - 1] : ovf[0];
+    const unsigned p0 = (unsigned)best0, p1 = (unsigned)best1;
+    const int px0 = ((g_i32_p)T.perm)[p0 < (unsigned)T.n_pad ? p0 : 0u];
+    const int px1 = ((g_i32_p)T.perm)[p1 < (unsigned)T.n_pad ? p1 : 0u];
+    {
       Best2 m;
-      m.d0 = (int)(best[u][0] >> 32), m.i0 = (int)(unsigned)best[u][0], m.x0 = x0[u];
-      m.d1 = (int)(best[u][1] >> 32), m.i1 = (int)(unsigned)best[u][1], m.x1 = x1[u];
-      if (best[u][0] == 0x7FFFFFFFFFFFFFFFll || m.x0 < 0) m.d0 = DIST_EMPTY, m.i0 = 0x7FFFFFFF, m.x0 = -1;  // (a padding position is no row)
-      if (best[u][1] == 0x7FFFFFFFFFFFFFFFll || m.x1 < 0) m.d1 = DIST_EMPTY, m.i1 = 0x7FFFFFFF, m.x1 = -1;
+      m.d0 = (int)(best0 >> 32), m.i0 = (int)(unsigned)best0, m.x0 = px0;
+      m.d1 = (int)(best1 >> 32), m.i1 = (int)(unsigned)best1, m.x1 = px1;
+      if (best0 == 0x7FFFFFFFFFFFFFFFll || m.x0 < 0) m.d0 = DIST_EMPTY, m.i0 = 0x7FFFFFFF, m.x0 = -1;  // (a padding position is no row)
+      if (best1 == 0x7FFFFFFFFFFFFFFFll || m.x1 < 0) m.d1 = DIST_EMPTY, m.i1 = 0x7FFFFFFF, m.x1 = -1;
       // emit.  Between epochs the entry holds {row0, row1, d0, d1} as integers (an earlier epoch's rows have the
       // lower indices: on equal d they stay); the last epoch turns it into the final {row0, row1|flag, dist bits}.
-      if (h_p == 0 && qrow[u] >= 0) {
-        int4* dst = &knn[(size_t)it.pair * maxq + qrow[u]];
+      if ((SPLIT || h_p == 0) && my_qrow >= 0) {
+        int4* dst = &knn[(size_t)it.pair * maxq + my_qrow];
         if (ep0 > 0) {
           const int4 pv = *dst;
           Best2 a;
           a.d0 = pv.z, a.x0 = pv.x, a.i0 = -2, a.d1 = pv.w, a.x1 = pv.y, a.i1 = -1;  // (positions below any of this epoch)
-          if (pv.y == FIX_FLAG) ovf[u] = 1;
+          if (pv.y == FIX_FLAG) my_ovf = 1;
           if (m.d0 != DIST_EMPTY) best2_insert(a, m.d0, m.i0, m.x0);
           if (m.d1 != DIST_EMPTY) best2_insert(a, m.d1, m.i1, m.x1);
           m = a;
@@ -852,7 +858,7 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
         int4 o;
         if (ep1 < nstages) {
           o.x = m.x0;
-          o.y = ovf[u] ? FIX_FLAG : m.x1;
+          o.y = my_ovf ? FIX_FLAG : m.x1;
           o.z = m.d0;
           o.w = m.d1;
         } else {
@@ -869,12 +875,12 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
           }
           o.x = v0 ? m.x0 : -1;
           o.y = v1 ? (m.x1 | fix) : -1;
-          if (ovf[u]) o.y = FIX_FLAG;  // (any non-negative flagged value: the compaction kernel recomputes the query)
+          if (my_ovf) o.y = FIX_FLAG;  // (any non-negative flagged value: the compaction kernel recomputes the query)
           o.z = __float_as_int(v0 ? d0 : 3.402823466e+38f);
           o.w = __float_as_int(v1 ? d1 : 3.402823466e+38f);
           if (o.y >= 0 && (o.y & FIX_FLAG)) {
             const int k = atomicAdd(fix_count, 1);
-            if (k < FIX_CAP) fix_items[k] = make_int2(it.pair, qrow[u]);
+            if (k < FIX_CAP) fix_items[k] = make_int2(it.pair, my_qrow);
           }
         }
         *dst = o;
