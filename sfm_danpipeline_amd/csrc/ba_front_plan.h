@@ -1,0 +1,436 @@
+// ba_front_plan.h -- host-side plan of the multifrontal ("front tree") factorisation of the reduced camera system.
+//
+// Replaces, for camera graphs with small vertex separators, what Eigen's LLT does behind ceres::Solve(DENSE_SCHUR)
+// (reference src/BundleAdjustment.cpp:116,123): S z = g with S = the Schur complement on cameras + focal.  S is
+// dense by storage only; its block pattern is the camera co-visibility graph.  The graph is dissected recursively
+// (separator, components, separators of the components, ...); every tree node ("front") owns the columns of its
+// separator (a leaf: of its component) and carries as its border ("struct") the columns of ancestors that its
+// subtree's elimination fills.  A front is small enough (own <= FP_NO_MAX tiles, own + struct <= FP_T_MAX tiles
+// of 32 columns) to be factored by ONE workgroup with its panels in LDS and its tiles in registers (ba_front.h):
+//      [ D_vv  .    ]   L_vv = chol(D_vv), L_bv = D_bv L_vv^-T, contribution U_bb = -L_bv L_bv^T goes to the parent
+//      [ D_bv  U_bb ]
+// The dependency chain is one root-to-leaf path of the tree, not all columns (cfg4's ring of 200 cameras: 3 + 2 + 2
+// + 4 tile steps instead of 16 with one level of dissection, 38 dense).
+//
+// Pure host C++ (no HIP): tests/test_front_plan.py compiles it with g++ and checks the plan's index maps by running a
+// numpy multifrontal factorisation over them against a dense solve.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <numeric>
+#include <vector>
+
+namespace fplan {
+
+constexpr int FP_TILE = 32;
+constexpr int FP_NO_MAX = 4;      // own tiles of a front (the chain wave walks them one after the other)
+constexpr int FP_T_MAX = 7;       // own + struct tiles (two panel generations of T - 1 tiles each live in LDS)
+constexpr int FP_WAVES = 12;      // waves of a front's workgroup
+constexpr int FP_SLOTS = 3;       // register tiles per tile wave
+// wave roles: 0 the factorisation chain, 4 the right-hand side, 8 polls the children's flags (SIMD 0 keeps its
+// matrix pipe free for the chain wave); the other nine hold tiles
+static inline bool fp_is_tile_wave(int w) { return (w & 3) != 0; }
+
+struct Front {
+  int parent = -1, level = 0;
+  std::vector<int> cams;      // own cameras, ascending
+  bool has_focal = false;     // the root owns the focal column (last own column)
+  std::vector<int> own;       // own parameter indices (6 c + j, focal = 6 nc) in front order
+  std::vector<int> strct;     // border parameter indices in elimination order
+  std::vector<int> children;
+  int no = 0, ns = 0, T = 0, nb_last = 8;
+  std::vector<int> inv;       // 32 T: front index -> parameter index, -1 = padding
+  std::vector<int> pmap;      // 32 ns: border index -> index in the parent's front (-1 = padding)
+  std::vector<uint8_t> sched; // FP_WAVES x FP_SLOTS x 2: (r, c) of the tile a wave slot holds, 0xFF = empty
+};
+
+struct Plan {
+  bool ok = false;
+  int nc = 0;
+  std::vector<Front> fronts;      // children before parents (post-order)
+  std::vector<int> up_order;      // front indices, deepest level first
+  int levels = 0;
+  int chain_blocks = 0;           // 4-column block steps on the longest leaf-to-root path
+  int chain_tiles = 0;            // tile steps on that path
+  int max_T = 0;
+  const char* why = "";
+};
+
+struct Builder {
+  int nc;
+  const std::vector<std::vector<int>>& nb;
+  int leaf_cols;
+  Plan plan;
+  std::vector<int> node_of_cam;
+  Builder(int nc_, const std::vector<std::vector<int>>& nb_, int leaf_cols_) : nc(nc_), nb(nb_), leaf_cols(leaf_cols_), node_of_cam(nc_, -1) {}
+
+  // components of the subgraph induced by `in` (mask) restricted to `verts`
+  std::vector<std::vector<int>> components(const std::vector<int>& verts, const std::vector<char>& in) {
+    std::vector<std::vector<int>> out;
+    std::vector<char> seen(nc, 0);
+    for (int s : verts) {
+      if (!in[s] || seen[s]) continue;
+      out.emplace_back();
+      std::vector<int>& comp = out.back();
+      comp.push_back(s);
+      seen[s] = 1;
+      for (size_t h = 0; h < comp.size(); ++h)
+        for (int v : nb[comp[h]])
+          if (in[v] && !seen[v]) {
+            seen[v] = 1;
+            comp.push_back(v);
+          }
+      std::sort(comp.begin(), comp.end());
+    }
+    return out;
+  }
+
+  // separator of a CONNECTED vertex set: reverse Cuthill-McKee positions from a pseudo-peripheral start, a cut at
+  // position p puts every vertex at or behind p that sees a vertex before p into the separator
+  bool find_cut(const std::vector<int>& V, bool root, std::vector<int>& sep, std::vector<std::vector<int>>& comps) {
+    std::vector<char> in(nc, 0);
+    for (int v : V) in[v] = 1;
+    std::vector<int> lvl(nc, -1), order, deg(nc, 0);
+    for (int v : V)
+      for (int u : nb[v]) deg[v] += in[u];  // degree inside V: the end of a band has the fewest neighbours
+    auto bfs = [&](int start) {
+      order.clear();
+      for (int v : V) lvl[v] = -1;
+      order.push_back(start);
+      lvl[start] = 0;
+      for (size_t h = 0; h < order.size(); ++h) {
+        const int u = order[h];
+        std::vector<int> nx;
+        for (int v : nb[u])
+          if (in[v] && lvl[v] < 0) {
+            lvl[v] = lvl[u] + 1;
+            nx.push_back(v);
+          }
+        // ties in the degree: the vertex that shares more neighbours with u is the closer one (a ring's start sees
+        // both directions: u+1, u-1, u+2, ... keeps every prefix of the order one contiguous arc)
+        std::vector<int> common(nx.size(), 0);
+        for (size_t i = 0; i < nx.size(); ++i)
+          for (int w : nb[nx[i]])
+            if (in[w] && std::binary_search(nb[u].begin(), nb[u].end(), w)) ++common[i];
+        std::vector<int> idx(nx.size());
+        std::iota(idx.begin(), idx.end(), 0);
+        std::sort(idx.begin(), idx.end(), [&](int a, int c) {
+          if (deg[nx[a]] != deg[nx[c]]) return deg[nx[a]] < deg[nx[c]];
+          if (common[a] != common[c]) return common[a] > common[c];
+          return nx[a] < nx[c];
+        });
+        for (int i : idx) order.push_back(nx[i]);
+      }
+    };
+    int start = V[0];
+    for (int rep = 0; rep < 2; ++rep) {
+      bfs(start);
+      start = order.back();
+    }
+    bfs(start);
+    if (order.size() != V.size()) return false;  // (not connected: the caller splits into components first)
+    std::vector<int> pos(nc, -1), minpos(nc, 0);
+    for (size_t i = 0; i < order.size(); ++i) pos[order[i]] = (int)i;
+    for (int v : V) {
+      int m = pos[v];
+      for (int u : nb[v])
+        if (in[u]) m = std::min(m, pos[u]);
+      minpos[v] = m;
+    }
+    const int n = (int)V.size();
+    long best = -1;
+    int best_p = -1;
+    const int G = std::min(n - 1, 384);  // (every position up to 385 vertices: one camera off balance can cost a level)
+    for (int k = 1; k <= G; ++k) {
+      const int p = (int)((long long)n * k / (G + 1));
+      if (p < 1 || p >= n) continue;
+      std::vector<char> keep(nc, 0);
+      int nsep = 0;
+      for (int v : V) {
+        if (pos[v] >= p && minpos[v] < p) ++nsep;
+        else keep[v] = 1;
+      }
+      const int sep_cols = 6 * nsep + (root ? 1 : 0);
+      if (sep_cols > FP_TILE * FP_NO_MAX) continue;
+      auto cs = components(V, keep);
+      if (cs.size() < 2) continue;
+      size_t mx = 0;
+      for (auto& c : cs) mx = std::max(mx, c.size());
+      const long score = 6 * (long)mx + 2 * (long)sep_cols;
+      if (best < 0 || score < best) best = score, best_p = p;
+    }
+    if (best_p < 0) return false;
+    std::vector<char> keep(nc, 0);
+    sep.clear();
+    for (int v : V) {
+      if (pos[v] >= best_p && minpos[v] < best_p) sep.push_back(v);
+      else keep[v] = 1;
+    }
+    std::sort(sep.begin(), sep.end());
+    comps = components(V, keep);
+    return true;
+  }
+
+  // returns the node index, -1 on failure
+  int build(const std::vector<int>& V, bool root, int level) {
+    const int cols = 6 * (int)V.size() + (root ? 1 : 0);
+    std::vector<int> sep;
+    std::vector<std::vector<int>> comps;
+    bool split = false;
+    if (root) {
+      std::vector<char> in(nc, 0);
+      for (int v : V) in[v] = 1;
+      auto cs = components(V, in);
+      if (cs.size() > 1) {  // cameras that share no point: only the focal couples them
+        comps = cs;
+        split = true;
+      }
+    }
+    if (!split && cols > leaf_cols) {
+      split = find_cut(V, root, sep, comps);
+      if (!split && cols > FP_TILE * FP_NO_MAX) return -1;
+    }
+    std::vector<int> kids;
+    if (split)
+      for (auto& c : comps) {
+        const int k = build(c, false, level + 1);
+        if (k < 0) return -1;
+        kids.push_back(k);
+      }
+    const int id = (int)plan.fronts.size();
+    plan.fronts.emplace_back();
+    Front& f = plan.fronts.back();
+    f.level = level;
+    f.cams = split ? sep : V;
+    f.has_focal = root;
+    f.children = kids;
+    for (int k : kids) plan.fronts[k].parent = id;
+    for (int c : f.cams) node_of_cam[c] = id;
+    return id;
+  }
+};
+
+// adjacency as nc x wpr bit rows (the layout sfmhip_ba keeps); leaf_cols: components up to this many columns become leaves
+static inline Plan build_plan(int nc, const unsigned long long* adj_bits, int wpr, int leaf_cols) {
+  std::vector<std::vector<int>> nb(nc);
+  for (int i = 0; i < nc; ++i)
+    for (int j = 0; j < nc; ++j)
+      if (j != i && (((adj_bits[(size_t)i * wpr + (j >> 6)] >> (j & 63)) & 1ull) || ((adj_bits[(size_t)j * wpr + (i >> 6)] >> (i & 63)) & 1ull)))
+        nb[i].push_back(j);
+  Builder B(nc, nb, leaf_cols);
+  std::vector<int> all(nc);
+  std::iota(all.begin(), all.end(), 0);
+  const int root = B.build(all, true, 0);
+  Plan& P = B.plan;
+  P.nc = nc;
+  if (root < 0) {
+    P.why = "a component without a small separator";
+    return P;
+  }
+  const int F = (int)P.fronts.size();
+  // elimination position of every camera: fronts are in post-order, cameras ascending inside a front
+  std::vector<int> epos(nc + 1, -1);
+  {
+    int k = 0;
+    for (int f = 0; f < F; ++f)
+      for (int c : P.fronts[f].cams) epos[c] = k++;
+    epos[nc] = k;  // the focal, last
+  }
+  // border cameras, bottom-up: (neighbours of the own cameras + the children's borders) minus the subtree
+  std::vector<std::vector<int>> bcams(F);
+  for (int f = 0; f < F; ++f) {
+    Front& fr = P.fronts[f];
+    std::vector<int> acc;
+    for (int c : fr.cams)
+      for (int u : nb[c])
+        if (epos[u] > epos[c] && B.node_of_cam[u] != f) acc.push_back(u);
+    for (int k : fr.children)
+      for (int u : bcams[k])
+        if (B.node_of_cam[u] != f) acc.push_back(u);
+    std::sort(acc.begin(), acc.end(), [&](int a, int c) { return epos[a] < epos[c]; });
+    acc.erase(std::unique(acc.begin(), acc.end()), acc.end());
+    // every border camera must belong to an ancestor (a proper dissection guarantees it)
+    for (int u : acc) {
+      int a = fr.parent;
+      while (a >= 0 && B.node_of_cam[u] != a) a = P.fronts[a].parent;
+      if (a < 0) {
+        P.why = "border outside the ancestors";
+        return P;
+      }
+    }
+    bcams[f] = acc;
+  }
+  for (int f = 0; f < F; ++f) {
+    Front& fr = P.fronts[f];
+    for (int c : fr.cams)
+      for (int j = 0; j < 6; ++j) fr.own.push_back(6 * c + j);
+    if (fr.has_focal) fr.own.push_back(6 * nc);
+    for (int c : bcams[f])
+      for (int j = 0; j < 6; ++j) fr.strct.push_back(6 * c + j);
+    if (!fr.has_focal) fr.strct.push_back(6 * nc);
+    const int oc = (int)fr.own.size(), sc = (int)fr.strct.size();
+    if (oc == 0) {
+      P.why = "empty front";
+      return P;
+    }
+    fr.no = (oc + FP_TILE - 1) / FP_TILE;
+    fr.ns = (sc + FP_TILE - 1) / FP_TILE;
+    fr.T = fr.no + fr.ns;
+    fr.nb_last = (oc - FP_TILE * (fr.no - 1) + 3) / 4;
+    if (fr.no > FP_NO_MAX || fr.T > FP_T_MAX) {
+      P.why = "a front exceeds the tile limits";
+      return P;
+    }
+    P.max_T = std::max(P.max_T, fr.T);
+    fr.inv.assign((size_t)FP_TILE * fr.T, -1);
+    for (int i = 0; i < oc; ++i) fr.inv[i] = fr.own[i];
+    for (int i = 0; i < sc; ++i) fr.inv[(size_t)FP_TILE * fr.no + i] = fr.strct[i];
+  }
+  // border index -> index in the parent's front
+  for (int f = 0; f < F; ++f) {
+    Front& fr = P.fronts[f];
+    fr.pmap.assign((size_t)FP_TILE * fr.ns, -1);
+    if (fr.parent < 0) continue;
+    const Front& pa = P.fronts[fr.parent];
+    std::map<int, int> where;
+    for (size_t i = 0; i < pa.inv.size(); ++i)
+      if (pa.inv[i] >= 0) where[pa.inv[i]] = (int)i;
+    int last = -1;
+    for (size_t i = 0; i < fr.strct.size(); ++i) {
+      auto it = where.find(fr.strct[i]);
+      if (it == where.end() || it->second <= last) {
+        P.why = "a border column is missing from the parent's front, or out of order";
+        return P;
+      }
+      fr.pmap[i] = last = it->second;
+    }
+  }
+  // tile -> (wave, slot): every tile (r, c), c <= r < T, but (0, 0) (the chain wave assembles it); a wave holds at most
+  // one tile of an own column below the diagonal (one triangular solve per step and wave), loads balanced by the number
+  // of rank-32 updates a tile receives
+  const int tile_waves[9] = {1, 2, 3, 5, 6, 7, 9, 10, 11};
+  for (int f = 0; f < F; ++f) {
+    Front& fr = P.fronts[f];
+    fr.sched.assign((size_t)FP_WAVES * FP_SLOTS * 2, 0xFF);
+    int used[FP_WAVES] = {0}, load[FP_WAVES] = {0};
+    std::vector<std::vector<int>> cols_of(FP_WAVES);
+    for (int c = 0; c < fr.T; ++c)
+      for (int r = c; r < fr.T; ++r) {
+        if (r == 0 && c == 0) continue;
+        const int w_tile = std::min(c, fr.no) * 4 + (c < fr.no && r > c ? 3 : 0) + 1;
+        int best = -1;
+        for (int k = 0; k < 9; ++k) {
+          const int w = tile_waves[k];
+          if (used[w] >= FP_SLOTS) continue;
+          if (c < fr.no && r > c && std::find(cols_of[w].begin(), cols_of[w].end(), c) != cols_of[w].end()) continue;
+          if (best < 0 || load[w] < load[best]) best = w;
+        }
+        if (best < 0) {
+          P.why = "no wave slot left for a tile";
+          return P;
+        }
+        fr.sched[((size_t)best * FP_SLOTS + used[best]) * 2] = (uint8_t)r;
+        fr.sched[((size_t)best * FP_SLOTS + used[best]) * 2 + 1] = (uint8_t)c;
+        ++used[best];
+        load[best] += w_tile;
+        if (c < fr.no && r > c) cols_of[best].push_back(c);
+      }
+  }
+  // levels, the up-sweep order (deepest first) and the chain length
+  int maxl = 0;
+  for (auto& fr : P.fronts) maxl = std::max(maxl, fr.level);
+  P.levels = maxl + 1;
+  for (int l = maxl; l >= 0; --l)
+    for (int f = 0; f < F; ++f)
+      if (P.fronts[f].level == l) P.up_order.push_back(f);
+  std::vector<int> cb(F, 0), ct(F, 0);
+  for (int f = 0; f < F; ++f) {  // post-order: children first
+    const Front& fr = P.fronts[f];
+    int mb = 0, mt = 0;
+    for (int k : fr.children) mb = std::max(mb, cb[k]), mt = std::max(mt, ct[k]);
+    cb[f] = mb + 8 * (fr.no - 1) + fr.nb_last;
+    ct[f] = mt + fr.no;
+  }
+  P.chain_blocks = cb[root];
+  P.chain_tiles = ct[root];
+  P.ok = true;
+  return P;
+}
+
+}  // namespace fplan
+
+// ---- the flat form the device reads (and the test checks): one int pool + offsets into one pool of doubles
+namespace fplan {
+
+constexpr int FD_INTS = 24;  // ints per front descriptor
+enum {
+  FD_NO = 0, FD_NS, FD_T, FD_NB_LAST, FD_PARENT, FD_LEVEL, FD_NCHILD, FD_CHILD_OFF, FD_INV_OFF, FD_CINV_OFF, FD_SCHED_OFF,
+  FD_NCAM, FD_CAM_OFF, FD_HAS_FOCAL, FD_OFF_L, FD_OFF_U, FD_OFF_Y, FD_OWN_COLS, FD_USED
+};
+static_assert(FD_USED <= FD_INTS, "descriptor size");
+
+struct Flat {
+  int n_fronts = 0, levels = 0, max_T = 0;
+  std::vector<int> ints;       // [FD_INTS x fronts | pools]
+  std::vector<int> up_order;   // deepest level first
+  std::vector<int> down_order; // root first
+  size_t n_doubles = 0;        // per front: L (32 T x 32 no, row-major), U ((32 ns)^2 column-major), y (32 T)
+};
+
+static inline Flat flatten(const Plan& P) {
+  Flat fl;
+  const int F = (int)P.fronts.size();
+  fl.n_fronts = F;
+  fl.levels = P.levels;
+  fl.max_T = P.max_T;
+  fl.up_order = P.up_order;
+  fl.down_order.assign(P.up_order.rbegin(), P.up_order.rend());
+  fl.ints.assign((size_t)FD_INTS * F, 0);
+  size_t nd = 0;
+  for (int f = 0; f < F; ++f) {
+    const Front& fr = P.fronts[f];
+    auto put = [&](int k, int v) { fl.ints[(size_t)FD_INTS * f + k] = v; };
+    put(FD_NO, fr.no);
+    put(FD_NS, fr.ns);
+    put(FD_T, fr.T);
+    put(FD_NB_LAST, fr.nb_last);
+    put(FD_PARENT, fr.parent);
+    put(FD_LEVEL, fr.level);
+    put(FD_NCHILD, (int)fr.children.size());
+    put(FD_HAS_FOCAL, fr.has_focal ? 1 : 0);
+    put(FD_OWN_COLS, (int)fr.own.size());
+    put(FD_CHILD_OFF, (int)fl.ints.size());
+    for (int k : fr.children) fl.ints.push_back(k);
+    put(FD_INV_OFF, (int)fl.ints.size());
+    fl.ints.insert(fl.ints.end(), fr.inv.begin(), fr.inv.end());
+    put(FD_CINV_OFF, (int)fl.ints.size());
+    for (int k : fr.children) {
+      const Front& ch = P.fronts[k];
+      std::vector<int> cinv((size_t)FP_TILE * fr.T, -1);
+      for (size_t i = 0; i < ch.pmap.size(); ++i)
+        if (ch.pmap[i] >= 0) cinv[ch.pmap[i]] = (int)i;
+      fl.ints.insert(fl.ints.end(), cinv.begin(), cinv.end());
+    }
+    put(FD_SCHED_OFF, (int)fl.ints.size());
+    for (int i = 0; i < FP_WAVES * FP_SLOTS; ++i) {
+      const int r = fr.sched[2 * i], c = fr.sched[2 * i + 1];
+      fl.ints.push_back(r == 0xFF ? -1 : (r | (c << 8)));
+    }
+    put(FD_NCAM, (int)fr.cams.size());
+    put(FD_CAM_OFF, (int)fl.ints.size());
+    fl.ints.insert(fl.ints.end(), fr.cams.begin(), fr.cams.end());
+    put(FD_OFF_L, (int)nd);
+    nd += (size_t)FP_TILE * fr.T * FP_TILE * fr.no;
+    put(FD_OFF_U, (int)nd);
+    nd += (size_t)FP_TILE * fr.ns * FP_TILE * fr.ns;
+    put(FD_OFF_Y, (int)nd);
+    nd += (size_t)FP_TILE * fr.T;
+    nd = (nd + 15) & ~(size_t)15;
+  }
+  fl.n_doubles = nd;
+  return fl;
+}
+
+}  // namespace fplan

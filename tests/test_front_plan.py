@@ -1,0 +1,208 @@
+"""The front-tree plan of the reduced camera solve (csrc/ba_front_plan.h), on the CPU: the plan's index maps drive a numpy
+multifrontal factorisation (assemble from S, extend-add of the children's contribution blocks, partial Cholesky, forward
+and backward substitution along the tree) whose solution must equal a dense solve.  Replaces Eigen's LLT behind
+ceres::Solve(DENSE_SCHUR), reference src/BundleAdjustment.cpp:116,123; the device kernels (csrc/ba_front.h) walk the same
+maps."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FD_INTS = 24
+(FD_NO, FD_NS, FD_T, FD_NB_LAST, FD_PARENT, FD_LEVEL, FD_NCHILD, FD_CHILD_OFF, FD_INV_OFF, FD_CINV_OFF, FD_SCHED_OFF,
+ FD_NCAM, FD_CAM_OFF, FD_HAS_FOCAL, FD_OFF_L, FD_OFF_U, FD_OFF_Y, FD_OWN_COLS) = range(18)
+
+
+@pytest.fixture(scope="module")
+def fp(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("fplan") / "libfplan.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so,
+                           os.path.join(ROOT, "tests", "stub", "front_plan_capi.cpp")])
+    lib = C.CDLL(so)
+    lib.fplan_build_flat.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    return lib
+
+
+def ring_adj(nc, k):
+    """cfg3 / cfg4's co-visibility: every point is seen by k consecutive cameras of a ring (synth.ba_problem)."""
+    a = np.zeros((nc, nc), bool)
+    for i in range(nc):
+        for d in range(1, k):
+            a[i, (i + d) % nc] = a[(i + d) % nc, i] = True
+    return a
+
+
+def band_adj(nc, k):
+    a = np.zeros((nc, nc), bool)
+    for i in range(nc):
+        for d in range(1, k):
+            if i + d < nc:
+                a[i, i + d] = a[i + d, i] = True
+    return a
+
+
+def build(fp, adj, leaf_cols=96):
+    nc = len(adj)
+    wpr = (nc + 63) // 64
+    bits = np.zeros((nc, wpr), np.uint64)
+    for i in range(nc):
+        for j in np.nonzero(adj[i])[0]:
+            bits[i, j >> 6] |= np.uint64(1) << np.uint64(j & 63)
+    header = np.zeros(8, np.int32)
+    ints = np.zeros(4 << 20, np.int32)
+    order = np.zeros(4096, np.int32)
+    rc = fp.fplan_build_flat(nc, bits.ctypes.data, wpr, leaf_cols, header.ctypes.data, ints.ctypes.data, len(ints),
+                             order.ctypes.data, len(order))
+    assert rc == 0
+    if not header[0]:
+        return None
+    F = int(header[1])
+    return dict(F=F, levels=int(header[2]), max_T=int(header[3]), ints=ints[:header[4]].copy(), n_doubles=int(header[5]),
+                chain_blocks=int(header[6]), chain_tiles=int(header[7]), up=order[:F].copy())
+
+
+def desc(pl, f):
+    return pl["ints"][FD_INTS * f: FD_INTS * (f + 1)]
+
+
+def random_system(adj, seed):
+    nc = len(adj)
+    dim = 6 * nc + 1
+    rng = np.random.default_rng(seed)
+    S = np.zeros((dim, dim))
+    for i in range(nc):
+        for j in range(i + 1, nc):
+            if adj[i, j]:
+                b = rng.normal(size=(6, 6))
+                S[6 * i:6 * i + 6, 6 * j:6 * j + 6] = b
+                S[6 * j:6 * j + 6, 6 * i:6 * i + 6] = b.T
+    S[-1, :-1] = S[:-1, -1] = rng.normal(size=dim - 1)
+    S += np.diag(np.abs(S).sum(axis=1) + 1.0)   # diagonally dominant: positive definite
+    return S, rng.normal(size=dim)
+
+
+def multifrontal_solve(pl, S, g):
+    ints, F = pl["ints"], pl["F"]
+    L, U, Y = {}, {}, {}
+    for f in pl["up"]:                        # deepest level first: children before parents
+        d = desc(pl, f)
+        no, ns, T = int(d[FD_NO]), int(d[FD_NS]), int(d[FD_T])
+        n, o = 32 * T, 32 * no
+        inv = ints[d[FD_INV_OFF]: d[FD_INV_OFF] + n]
+        Fm = np.zeros((n, n))
+        y = np.zeros(n)
+        for b in range(o):                    # own columns: entries of S, the identity on the padding
+            if inv[b] < 0:
+                Fm[b, b] = 1.0
+                continue
+            y[b] = g[inv[b]]
+            for a in range(b, n):
+                if inv[a] >= 0:
+                    Fm[a, b] = S[inv[a], inv[b]]
+        for k in range(int(d[FD_NCHILD])):    # extend-add
+            ch = int(ints[d[FD_CHILD_OFF] + k])
+            cinv = ints[d[FD_CINV_OFF] + k * n: d[FD_CINV_OFF] + (k + 1) * n]
+            dc = desc(pl, ch)
+            assert int(dc[FD_PARENT]) == f
+            idx = np.nonzero(cinv >= 0)[0]
+            assert np.all(np.diff(cinv[idx]) > 0)      # monotone: a lower triangle maps onto a lower triangle
+            Uc, yc, oc = U[ch], Y[ch], 32 * int(dc[FD_NO])
+            for a in idx:
+                y[a] += yc[oc + cinv[a]]
+                for b in idx:
+                    if a >= b:
+                        Fm[a, b] += Uc[cinv[a], cinv[b]]
+        Lvv = np.linalg.cholesky(Fm[:o, :o] + np.tril(Fm[:o, :o], -1).T)
+        Lbv = np.linalg.solve(Lvv, Fm[o:, :o].T).T
+        L[f] = np.vstack([Lvv, Lbv])
+        low = np.tril(Fm[o:, o:])
+        U[f] = low + np.tril(low, -1).T - Lbv @ Lbv.T
+        y[:o] = np.linalg.solve(Lvv, y[:o])
+        y[o:] -= Lbv @ y[:o]
+        Y[f] = y
+    z = np.zeros(len(g))
+    seen = np.zeros(len(g), int)
+    for f in pl["up"][::-1]:                  # root first
+        d = desc(pl, f)
+        no, T = int(d[FD_NO]), int(d[FD_T])
+        n, o = 32 * T, 32 * no
+        inv = ints[d[FD_INV_OFF]: d[FD_INV_OFF] + n]
+        zb = np.array([z[i] if i >= 0 else 0.0 for i in inv[o:]])
+        w = Y[f][:o] - L[f][o:].T @ zb
+        zv = np.linalg.solve(L[f][:o].T, w)
+        for b in range(o):
+            if inv[b] >= 0:
+                z[inv[b]] = zv[b]
+                seen[inv[b]] += 1
+    assert np.all(seen == 1)                  # every parameter is owned by exactly one front
+    return z
+
+
+def check_schedule(pl):
+    ints = pl["ints"]
+    for f in range(pl["F"]):
+        d = desc(pl, f)
+        no, T = int(d[FD_NO]), int(d[FD_T])
+        assert 1 <= no <= 4 and T <= 7 and 1 <= d[FD_NB_LAST] <= 8
+        sched = ints[d[FD_SCHED_OFF]: d[FD_SCHED_OFF] + 36].reshape(12, 3)
+        tiles = []
+        for w in range(12):
+            cols = []
+            for s in range(3):
+                if sched[w, s] < 0:
+                    continue
+                assert w % 4 != 0                 # waves 0, 4, 8 hold no tiles
+                r, c = int(sched[w, s]) & 255, int(sched[w, s]) >> 8
+                tiles.append((r, c))
+                if c < no and r > c:
+                    cols.append(c)
+            assert len(cols) == len(set(cols))    # one triangular solve per step and wave
+        want = [(r, c) for c in range(T) for r in range(c, T) if (r, c) != (0, 0)]
+        assert sorted(tiles) == sorted(want)
+
+
+@pytest.mark.parametrize("nc,k", [(200, 10), (50, 10), (96, 6), (560, 8), (30, 4)])
+def test_ring_plans_solve_the_system(fp, nc, k):
+    adj = ring_adj(nc, k)
+    pl = build(fp, adj)
+    assert pl is not None
+    check_schedule(pl)
+    S, g = random_system(adj, nc)
+    z = multifrontal_solve(pl, S, g)
+    zr = np.linalg.solve(S, g)
+    assert np.abs(z - zr).max() <= 1e-10 * np.abs(zr).max()
+    if (nc, k) == (200, 10):                  # cfg4: 8 leaves of 3 tiles, two levels of 2-tile separators, a 4-tile root
+        assert pl["levels"] == 4 and pl["F"] == 15 and pl["chain_tiles"] == 11 and pl["max_T"] == 7
+
+
+def test_band_and_disconnected_graphs(fp):
+    adj = band_adj(120, 7)
+    pl = build(fp, adj)
+    assert pl is not None
+    check_schedule(pl)
+    S, g = random_system(adj, 1)
+    assert np.abs(multifrontal_solve(pl, S, g) - np.linalg.solve(S, g)).max() <= 1e-10
+    # two groups of cameras that share no point: only the focal couples them
+    adj2 = np.zeros((40, 40), bool)
+    adj2[:20, :20] = band_adj(20, 5)
+    adj2[20:, 20:] = band_adj(20, 5)
+    pl2 = build(fp, adj2)
+    assert pl2 is not None
+    S, g = random_system(adj2, 2)
+    assert np.abs(multifrontal_solve(pl2, S, g) - np.linalg.solve(S, g)).max() <= 1e-10
+
+
+def test_small_and_dense_graphs(fp):
+    # a handful of cameras: one front holds everything
+    adj = np.ones((8, 8), bool) & ~np.eye(8, dtype=bool)
+    pl = build(fp, adj)
+    assert pl is not None and pl["F"] == 1
+    S, g = random_system(adj, 3)
+    assert np.abs(multifrontal_solve(pl, S, g) - np.linalg.solve(S, g)).max() <= 1e-10
+    # random visibility: no small separator exists, the plan is refused (the dense factorisation stays)
+    rng = np.random.default_rng(0)
+    a = rng.random((200, 200)) < 0.4
+    assert build(fp, a | a.T) is None
