@@ -315,6 +315,12 @@ int sfmhip_ba_reduced_step(sfmhip_ba* ba, double radius, double* z, int* chol_fa
  * instead of layout[3].  Replaces nothing in the reference (Eigen's dense LLT, src/BundleAdjustment.cpp:116,
  * has no such choice); SFMHIP_BA_ND=0 in the environment keeps the dense factorisation. */
 int sfmhip_ba_reduced_layout(sfmhip_ba* ba, int32_t layout[4]);
+/* The front tree, when the camera graph dissects recursively into fronts that fit one compute unit each (the default
+ * where it exists; SFMHIP_BA_ND=1 keeps the chains + separator plan, =0 the dense factorisation, =2 tree or dense):
+ * tree[0] = fronts (0: no tree), tree[1] = levels, tree[2] = 32-column tile steps on the longest leaf-to-root path (the
+ * dependency chain), tree[3] = tiles (own + border) of the largest front.  sfmhip_ba_reduced_layout then reports no
+ * chains.  Behind Eigen's LLT, reference src/BundleAdjustment.cpp:116. */
+int sfmhip_ba_reduced_tree(sfmhip_ba* ba, int32_t tree[4]);
 /* device seconds of the last run/iterate by kernel group:
  * [0]=linearise+eliminate [1]=allreduce [2]=reduced solve [3]=back-substitute+cost */
 int sfmhip_ba_last_timing(sfmhip_ba* ba, double seconds[4], int* launches);

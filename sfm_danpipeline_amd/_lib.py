@@ -47,7 +47,7 @@ SYMBOLS = [
     "sfmhip_matchplan_destroy",
     "sfmhip_triangulate", "sfmhip_find_2d3d", "sfmhip_merge_new_points", "sfmhip_ba_default_opts", "sfmhip_ba_solve", "sfmhip_ba_create",
     "sfmhip_ba_set_allreduce", "sfmhip_ba_set_params", "sfmhip_ba_get_params", "sfmhip_ba_run",
-    "sfmhip_ba_iterate", "sfmhip_ba_reduced_system", "sfmhip_ba_linearize_obs", "sfmhip_ba_last_timing", "sfmhip_ba_reduced_layout", "sfmhip_ba_reduced_step", "sfmhip_score_essential", "sfmhip_score_last_flags", "sfmhip_score_five_point", "sfmhip_score_homography_kernel", "sfmhip_score_homography", "sfmhip_sift_detect_and_compute", "sfmhip_sift_detect_and_compute_device", "sfmhip_sift_batch", "sfmhip_device_free", "sfmhip_host_free", "sfmhip_device_download", "sfmhip_ba_destroy",
+    "sfmhip_ba_iterate", "sfmhip_ba_reduced_system", "sfmhip_ba_linearize_obs", "sfmhip_ba_last_timing", "sfmhip_ba_reduced_layout", "sfmhip_ba_reduced_tree", "sfmhip_ba_reduced_step", "sfmhip_score_essential", "sfmhip_score_last_flags", "sfmhip_score_five_point", "sfmhip_score_homography_kernel", "sfmhip_score_homography", "sfmhip_sift_detect_and_compute", "sfmhip_sift_detect_and_compute_device", "sfmhip_sift_batch", "sfmhip_device_free", "sfmhip_host_free", "sfmhip_device_download", "sfmhip_ba_destroy",
 ]
 
 _lib = None
@@ -108,6 +108,7 @@ def lib():
         L.sfmhip_ba_linearize_obs.argtypes = [vp, cint, vp, vp, f64, vp, vp, vp, vp, vp]
         L.sfmhip_ba_last_timing.argtypes = [vp, vp, vp]
         L.sfmhip_ba_reduced_layout.argtypes = [vp, vp]
+        L.sfmhip_ba_reduced_tree.argtypes = [vp, vp]
         L.sfmhip_score_essential.argtypes = [vp, cint, vp, vp, vp, f64, f64, f64, f64, f64, f64, vp, vp, vp]
         L.sfmhip_score_last_flags.argtypes = [vp]
         L.sfmhip_score_five_point.argtypes = [vp, cint, vp, vp, vp, vp]

@@ -43,9 +43,10 @@ def build(force=False, verbose=False):
         src = os.path.join(CSRC, name)
         obj = os.path.join(objdir, name.replace(".hip", ".o"))
         objs.append(obj)
+        hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]  # (common.h, hypot_glibc.h, ba_front*.h)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(
-                os.path.getmtime(src), os.path.getmtime(os.path.join(CSRC, "common.h")),
-                os.path.getmtime(os.path.join(HERE, "..", "include", "sfmhip.h"))):
+                [os.path.getmtime(src), os.path.getmtime(os.path.join(HERE, "..", "include", "sfmhip.h"))] +
+                [os.path.getmtime(h) for h in hdrs]):
             continue
         cmd = [_hipcc()] + FLAGS + [f"-ffp-contract={contract}", "-c", src, "-o", obj]
         if verbose:

@@ -191,6 +191,12 @@ class BaProblem:
         check(lib().sfmhip_ba_reduced_layout(self.h, a.ctypes.data), "sfmhip_ba_reduced_layout")
         return dict(chains=int(a[0]), chain_tiles=int(a[1]), separator_tiles=int(a[2]), dense_tiles=int(a[3]))
 
+    def reduced_tree(self):
+        """The front tree of the reduced solve (sfmhip_ba_reduced_tree): fronts = 0 when the chains / dense plans run."""
+        a = np.zeros(4, np.int32)
+        check(lib().sfmhip_ba_reduced_tree(self.h, a.ctypes.data), "sfmhip_ba_reduced_tree")
+        return dict(fronts=int(a[0]), levels=int(a[1]), chain_tiles=int(a[2]), max_front_tiles=int(a[3]))
+
     def close(self):
         if self.h:
             lib().sfmhip_ba_destroy(self.h)

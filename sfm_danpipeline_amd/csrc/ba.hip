@@ -33,6 +33,7 @@
 // diag | scalars] is summed by the caller's all-reduce (RCCL over xGMI) once per iteration,
 // every rank then solves the same reduced system and back-substitutes its own points.
 #include "common.h"
+#include "ba_front_plan.h"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -2455,6 +2456,8 @@ __global__ __launch_bounds__(256) void nd_w(NdSet ns, NdCols cols) {
   if (lane == 0) ch.y[k] = yk - acc;
 }
 
+#include "ba_front.h"
+
 // ---------------------------------------------------------------- step application
 // candidate cameras / focal: x + (-z)*scale, their tables, and the camera part of the norms
 __global__ void ba_cand_cams(BaDev d, const unsigned char* __restrict__ cam_used, int rank) {
@@ -2738,6 +2741,12 @@ struct sfmhip_ba {
   int4* nd_gather_jobs = nullptr;
   int nd_n_gather = 0;
   bool chol_chains_attr_set = false;
+  // front tree (ba_front_plan.h / ba_front.h): the multifrontal factorisation, one workgroup per front
+  bool tree_on = false, tree_attr_set = false, solve_cand = false;
+  FrontSet tree_fs{};
+  unsigned tree_epoch = 0;
+  int tree_stride = 1, tree_levels = 0, tree_chain_tiles = 0, tree_chain_blocks = 0, tree_max_T = 0;
+  std::vector<int> tree_level_of_wg;
   // ba_finalize deferred to the next nd_gather (the LM loop's linearisations, when the dissected solve follows)
   bool fin_pending = false, defer_fin = false;
   double fin_radius = 0, fin_lo = 0, fin_hi = 0;
@@ -2805,6 +2814,16 @@ static int ba_alloc(sfmhip_ba* b, T** p, size_t n) {
   return SFMHIP_OK;
 }
 
+#ifdef SFM_FRONT_STAMPS
+extern "C" int sfmhip_debug_front_stamps(unsigned long long* out, int n_fronts) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_front_stamps), sizeof(unsigned long long) * 32 * (size_t)std::min(n_fronts, 128)) == hipSuccess ? 0 : -2;
+}
+#endif
+#ifdef SFM_FRONT_STAMPS
+extern "C" int sfmhip_debug_down_stamps(unsigned long long* out, int n_fronts) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_down_stamps), sizeof(unsigned long long) * 8 * (size_t)std::min(n_fronts, 128)) == hipSuccess ? 0 : -2;
+}
+#endif
 #ifdef SFM_ELIM_STAMPS
 extern "C" int sfmhip_debug_elim_stamps(unsigned long long* out32) {
   return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_elim_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -2;
@@ -3180,7 +3199,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   }
   lap_("gather lists");
   // ---- camera co-visibility (one bit row per camera) for the dissection of the reduced system
-  if (n_cam >= 64 && n_cam <= 4096) {
+  if (n_cam <= 4096) {  // (from one camera on: a small system is one front)
     const int wpr = (n_cam + 63) / 64;
     b->h_adj.assign((size_t)n_cam * wpr, 0ull);
     auto add_clique = [&](const int* cs, int n) {
@@ -3736,6 +3755,60 @@ static int ba_nd_build(sfmhip_ba* b) {
     }
   }
   if (env && env[0] == '0') return SFMHIP_OK;
+  // ---- the front tree first (SFMHIP_BA_ND=2 or unset): every front on one CU; "1" keeps the chains + separator plan below
+  if (!(env && env[0] == '1')) {
+    // components up to this many columns become leaves: the largest size whose fronts fit (a leaf of three tiles under a
+    // border of five does not); SFMHIP_BA_TREE_LEAF fixes it (experiments)
+    const char* lc = getenv("SFMHIP_BA_TREE_LEAF");
+    fplan::Plan P;
+    for (int leaf : {96, 64, 32}) {
+      P = fplan::build_plan(nc, adj.data(), wpr, lc ? atoi(lc) : leaf);
+      if (P.ok || lc) break;
+    }
+    if (P.ok) {
+      fplan::Flat fl = fplan::flatten(P);
+      int* d_ints = nullptr;
+      int* d_up = nullptr;
+      int* d_down = nullptr;
+      unsigned* d_flags = nullptr;
+      double* pool = nullptr;
+      SFM_TRY(ba_alloc(b, &d_ints, fl.ints.size()));
+      SFM_TRY(ba_alloc(b, &d_up, fl.up_order.size()));
+      SFM_TRY(ba_alloc(b, &d_down, fl.down_order.size()));
+      const size_t n_flags = (size_t)fl.n_fronts + (size_t)fl.n_tflags;  // down-sweep: one per front; up-sweep: one per contribution tile
+      SFM_TRY(ba_alloc(b, &d_flags, n_flags));
+      SFM_TRY(ba_alloc(b, &pool, fl.n_doubles));
+      SFM_HIP_TRY(hipMemcpy(d_ints, fl.ints.data(), fl.ints.size() * sizeof(int), hipMemcpyHostToDevice));
+      SFM_HIP_TRY(hipMemcpy(d_up, fl.up_order.data(), fl.up_order.size() * sizeof(int), hipMemcpyHostToDevice));
+      SFM_HIP_TRY(hipMemcpy(d_down, fl.down_order.data(), fl.down_order.size() * sizeof(int), hipMemcpyHostToDevice));
+      SFM_HIP_TRY(hipMemset(d_flags, 0, n_flags * sizeof(unsigned)));
+      SFM_HIP_TRY(hipMemset(pool, 0, fl.n_doubles * sizeof(double)));
+      b->tree_fs.ints = d_ints;
+      b->tree_fs.up_order = d_up;
+      b->tree_fs.down_order = d_down;
+      b->tree_fs.pool = pool;
+      b->tree_fs.flag_down = d_flags;
+      b->tree_fs.tflag = d_flags + fl.n_fronts;
+      double* zq = nullptr;
+      SFM_TRY(ba_alloc(b, &zq, (size_t)b->ld));
+      b->tree_fs.zq = zq;
+      b->tree_fs.n_fronts = fl.n_fronts;
+      b->tree_levels = fl.levels;
+      b->tree_chain_tiles = P.chain_tiles;
+      b->tree_chain_blocks = P.chain_blocks;
+      b->tree_max_T = P.max_T;
+      const char* se = getenv("SFMHIP_BA_TREE_STRIDE");
+      b->tree_stride = se ? std::max(1, atoi(se)) : 1;
+      b->tree_on = true;
+      b->nd_on = true;  // (what the two share: the deferred ba_finalize, the pre-zeroed second buffer)
+      if (getenv("SFMHIP_BA_ND_VERBOSE"))
+        fprintf(stderr, "[sfmhip] reduced system as a front tree: %d fronts, %d levels, %d tile steps (%d block steps) on the chain, fronts of up to %d tiles; dense %d tiles\n",
+                fl.n_fronts, fl.levels, P.chain_tiles, P.chain_blocks, P.max_T, b->ld / CB);
+      return SFMHIP_OK;
+    }
+    if (getenv("SFMHIP_BA_ND_VERBOSE")) fprintf(stderr, "[sfmhip] no front tree: %s\n", P.why);
+    if (env && env[0] == '2') return SFMHIP_OK;
+  }
   std::vector<std::vector<int>> nb(nc);
   for (int i = 0; i < nc; ++i)
     for (int j = 0; j < nc; ++j)
@@ -3992,7 +4065,47 @@ static void nd_census(sfmhip_ba* b, const char* stage) {
   }
 }
 
+// the front tree: one up-sweep launch (assembly, factorisation, forward substitution; its spare workgroups zero the other
+// reduced-system buffer and do ba_finalize's bookkeeping), one down-sweep launch (backward substitution, candidate cameras)
+static int ba_reduced_solve_tree(sfmhip_ba* b) {
+  hipStream_t st = b->ctx->stream;
+  BaDev& d = b->d;
+  if (!b->tree_attr_set) {
+    SFM_HIP_TRY(hipFuncSetAttribute((const void*)front_up, hipFuncAttributeMaxDynamicSharedMemorySize, FR_LDS_BYTES));
+    b->tree_attr_set = true;
+  }
+  const bool prezero = b->prezero;
+  const size_t nz = b->red_count - b->ssz;
+  if (prezero && !b->red_alt && nz % 2 == 0) SFM_TRY(ba_alloc(b, &b->red_alt, nz));
+  const int zwg = prezero && b->red_alt ? (int)((nz + ND_ZERO_SLICE - 1) / ND_ZERO_SLICE) : 0;
+  const int nF = b->tree_fs.n_fronts, stride = b->tree_stride;
+  // grid: the fronts at multiples of `stride`; the zeroing workgroups fill the gaps and follow; one more for the bookkeeping
+  const int gaps = (stride - 1) * nF;
+  const int grid = stride * nF + std::max(0, zwg + 1 - gaps);
+  const unsigned epoch = ++b->tree_epoch;
+  static const bool by_level = getenv("SFMHIP_BA_TREE_BY_LEVEL") != nullptr;  // (diagnostic: one launch per tree level)
+  int nl = 0;
+  if (by_level) {
+    for (int l = b->tree_levels - 1; l >= 0; --l, ++nl)
+      hipLaunchKernelGGL(front_up, dim3(l == b->tree_levels - 1 ? grid : stride * nF), dim3(FR_WAVES * 64), FR_LDS_BYTES, st, b->tree_fs, d.red,
+                         d.red + b->ssz, d.ld, d, b->fin_pending ? 1 : 0, b->fin_radius, b->fin_lo, b->fin_hi, b->world, epoch, stride, l, l,
+                         b->red_alt, (long long)nz, l == b->tree_levels - 1 ? zwg : 0);
+  } else {
+    hipLaunchKernelGGL(front_up, dim3(grid), dim3(FR_WAVES * 64), FR_LDS_BYTES, st, b->tree_fs, d.red, d.red + b->ssz, d.ld, d,
+                       b->fin_pending ? 1 : 0, b->fin_radius, b->fin_lo, b->fin_hi, b->world, epoch, stride, 0, 1 << 30, b->red_alt,
+                       (long long)nz, zwg);
+    nl = 1;
+  }
+  if (zwg) b->alt_clean = true;
+  b->fin_pending = false;
+  hipLaunchKernelGGL(front_down, dim3(nF), dim3(FD_THREADS), 0, st, b->tree_fs, d, b->d_cam_used, b->rank, epoch, b->solve_cand ? 1 : 0);
+  SFM_HIP_TRY(hipGetLastError());
+  b->launches += nl + 1;
+  return SFMHIP_OK;
+}
+
 static int ba_reduced_solve_nd(sfmhip_ba* b) {
+  if (b->tree_on) return ba_reduced_solve_tree(b);
   const bool dbg = getenv("SFMHIP_BA_ND_DEBUG") != nullptr;
   hipStream_t st = b->ctx->stream;
   BaDev& d = b->d;
@@ -4105,7 +4218,7 @@ static int ba_reduced_solve(sfmhip_ba* b) {
 static int ba_step_eval(sfmhip_ba* b, double radius, const sfmhip_ba_opts* o) {
   hipStream_t st = b->ctx->stream;
   BaDev& d = b->d;
-  hipLaunchKernelGGL(ba_cand_cams, dim3((b->nc + 1 + 63) / 64), dim3(64), 0, st, d, b->d_cam_used, b->rank);
+  if (!b->tree_on) hipLaunchKernelGGL(ba_cand_cams, dim3((b->nc + 1 + 63) / 64), dim3(64), 0, st, d, b->d_cam_used, b->rank);
   if (b->np)
   {
     static const int wpp_env = getenv("SFMHIP_BA_BACKSUB_WPP") ? atoi(getenv("SFMHIP_BA_BACKSUB_WPP")) : 2;  // (measurement)
@@ -4121,7 +4234,7 @@ static int ba_step_eval(sfmhip_ba* b, double radius, const sfmhip_ba_opts* o) {
                          o->max_lm_diagonal);
   }
   SFM_HIP_TRY(hipGetLastError());
-  b->launches += 2;
+  b->launches += b->tree_on ? 1 : 2;
   SFM_TRY(ba_allreduce(b, d.red2, RED2_SUM_N));
   return SFMHIP_OK;
 }
@@ -4240,7 +4353,10 @@ static int ba_one_iteration(sfmhip_ba* b, const sfmhip_ba_opts* o, bool timing_o
   if (!s.have_lin) SFM_TRY(ba_linearize_eliminate(b, s.radius, o, true));
   b->defer_fin = false;
   s.have_lin = false;
-  SFM_TRY(ba_reduced_solve(b));
+  b->solve_cand = true;  // (the front tree's down-sweep leaves the candidate cameras and their tables)
+  const int rc_solve = ba_reduced_solve(b);
+  b->solve_cand = false;
+  SFM_TRY(rc_solve);
   if (b->ctx->timing) {
     SFM_HIP_TRY(hipEventRecord(b->ev[3], st));
     b->ev_on[3] = true;
@@ -4398,6 +4514,8 @@ extern "C" int sfmhip_ba_iterate(sfmhip_ba* b, int iters, sfmhip_ba_summary* sum
   const auto t0 = clk::now();
   sfmhip_ba_opts o;
   sfmhip_ba_default_opts(&o);
+  static const bool verbose_env = getenv("SFMHIP_BA_VERBOSE") != nullptr;  // (diagnostics: a line per iteration on stderr)
+  if (verbose_env) o.verbose = 1;
   sfmhip_ba_summary sm;
   memset(&sm, 0, sizeof sm);
   if (!b->lm.started) SFM_TRY(ba_begin(b, &o));
@@ -4528,10 +4646,20 @@ extern "C" int sfmhip_ba_reduced_step(sfmhip_ba* b, double radius, double* z, in
 
 extern "C" int sfmhip_ba_reduced_layout(sfmhip_ba* b, int32_t layout[4]) {
   if (!b || !layout) return SFMHIP_ERR_ARG;
-  layout[0] = b->nd_on ? b->nd.n : 0;
-  layout[1] = b->nd_on ? b->nd_max_ni : 0;
-  layout[2] = b->nd_on ? b->nd.c[b->nd.n].N : 0;
+  const bool chains = b->nd_on && !b->tree_on;
+  layout[0] = chains ? b->nd.n : 0;
+  layout[1] = chains ? b->nd_max_ni : 0;
+  layout[2] = chains ? b->nd.c[b->nd.n].N : 0;
   layout[3] = b->nd_ready ? b->ld / CB : 0;
+  return SFMHIP_OK;
+}
+
+extern "C" int sfmhip_ba_reduced_tree(sfmhip_ba* b, int32_t tree[4]) {
+  if (!b || !tree) return SFMHIP_ERR_ARG;
+  tree[0] = b->tree_on ? b->tree_fs.n_fronts : 0;
+  tree[1] = b->tree_on ? b->tree_levels : 0;
+  tree[2] = b->tree_on ? b->tree_chain_tiles : 0;
+  tree[3] = b->tree_on ? b->tree_max_T : 0;
   return SFMHIP_OK;
 }
 

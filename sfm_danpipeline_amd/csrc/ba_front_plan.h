@@ -31,19 +31,22 @@ constexpr int FP_WAVES = 12;      // waves of a front's workgroup
 constexpr int FP_SLOTS = 3;       // register tiles per tile wave
 // wave roles: 0 the factorisation chain, 4 the right-hand side, 8 polls the children's flags (SIMD 0 keeps its
 // matrix pipe free for the chain wave); the other nine hold tiles
-static inline bool fp_is_tile_wave(int w) { return (w & 3) != 0; }
+static inline bool fp_is_tile_wave(int w) { return (w & 3) != 0 || w == 8; }
 
 struct Front {
   int parent = -1, level = 0;
   std::vector<int> cams;      // own cameras, ascending
   bool has_focal = false;     // the root owns the focal column (last own column)
   std::vector<int> own;       // own parameter indices (6 c + j, focal = 6 nc) in front order
-  std::vector<int> strct;     // border parameter indices in elimination order
+  std::vector<int> strct;     // the TRUE border parameters (what the elimination fills), in elimination order
+  std::vector<std::pair<int, int>> btiles;  // the border as whole tiles of ancestors' own layouts: (front, tile), in elimination order
   std::vector<int> children;
   int no = 0, ns = 0, T = 0, nb_last = 8;
   std::vector<int> inv;       // 32 T: front index -> parameter index, -1 = padding
-  std::vector<int> pmap;      // 32 ns: border index -> index in the parent's front (-1 = padding)
+  std::vector<int> ptile;     // ns: border tile -> tile of the parent's front (the same 32 parameters in the same order)
+  unsigned live = 0;          // bit 2 t + h: row half h of front tile t holds an own or a true border parameter
   std::vector<uint8_t> sched; // FP_WAVES x FP_SLOTS x 2: (r, c) of the tile a wave slot holds, 0xFF = empty
+  std::vector<uint8_t> turn;  // FP_WAVES x FP_SLOTS: a border tile's place in its SIMD's queue when the tiles are folded at the end
 };
 
 struct Plan {
@@ -262,81 +265,178 @@ static inline Plan build_plan(int nc, const unsigned long long* adj_bits, int wp
     }
     bcams[f] = acc;
   }
+  // ---- own layouts: a front's own parameters in tiles of 32 (the last one padded)
+  std::vector<int> owner_of(6 * (size_t)nc + 1, -1), pos_in_owner(6 * (size_t)nc + 1, -1);
   for (int f = 0; f < F; ++f) {
     Front& fr = P.fronts[f];
-    for (int c : fr.cams)
-      for (int j = 0; j < 6; ++j) fr.own.push_back(6 * c + j);
-    if (fr.has_focal) fr.own.push_back(6 * nc);
-    for (int c : bcams[f])
-      for (int j = 0; j < 6; ++j) fr.strct.push_back(6 * c + j);
-    if (!fr.has_focal) fr.strct.push_back(6 * nc);
-    const int oc = (int)fr.own.size(), sc = (int)fr.strct.size();
-    if (oc == 0) {
+    if (fr.has_focal) {
+      // the root: every front's border holds the focal, so it goes where its tile is in those borders anyway -- behind the
+      // first connected group of the root's cameras (a ring's root is two arcs: [arc | focal | arc])
+      std::vector<char> in(nc, 0);
+      for (int c : fr.cams) in[c] = 1;
+      auto groups = B.components(fr.cams, in);
+      for (size_t gi = 0; gi < groups.size(); ++gi) {
+        for (int c : groups[gi])
+          for (int j = 0; j < 6; ++j) fr.own.push_back(6 * c + j);
+        if (gi == 0) fr.own.push_back(6 * nc);
+      }
+      if (groups.empty()) fr.own.push_back(6 * nc);
+    } else {
+      for (int c : fr.cams)
+        for (int j = 0; j < 6; ++j) fr.own.push_back(6 * c + j);
+    }
+    if (fr.own.empty()) {
       P.why = "empty front";
       return P;
     }
-    fr.no = (oc + FP_TILE - 1) / FP_TILE;
-    fr.ns = (sc + FP_TILE - 1) / FP_TILE;
+    for (size_t i = 0; i < fr.own.size(); ++i) owner_of[fr.own[i]] = f, pos_in_owner[fr.own[i]] = (int)i;
+    fr.no = ((int)fr.own.size() + FP_TILE - 1) / FP_TILE;
+    fr.nb_last = ((int)fr.own.size() - FP_TILE * (fr.no - 1) + 3) / 4;
+  }
+  // ---- borders as WHOLE TILES of the ancestors' own layouts: every tile that holds a true border parameter, in
+  // elimination order.  A border tile of a child is then, parameter for parameter, a tile of its parent's front, and the
+  // child's contribution block adds onto the parent tile by tile with no index map (the parameters of such a tile that the
+  // elimination does not reach are zero rows of the front: work, not error).
+  auto tile_params = [&](int fo, int t, int k) -> int {
+    const Front& o = P.fronts[fo];
+    const size_t i = (size_t)FP_TILE * t + k;
+    return i < o.own.size() ? o.own[i] : -1;
+  };
+  for (int f = 0; f < F; ++f) {
+    Front& fr = P.fronts[f];
+    for (int c : bcams[f])
+      for (int j = 0; j < 6; ++j) fr.strct.push_back(6 * c + j);
+    if (!fr.has_focal) fr.strct.push_back(6 * nc);
+    for (int p : fr.strct) fr.btiles.emplace_back(owner_of[p], pos_in_owner[p] / FP_TILE);
+    std::sort(fr.btiles.begin(), fr.btiles.end());  // (fronts are in post-order: ancestors have the larger indices)
+    fr.btiles.erase(std::unique(fr.btiles.begin(), fr.btiles.end()), fr.btiles.end());
+    fr.ns = (int)fr.btiles.size();
     fr.T = fr.no + fr.ns;
-    fr.nb_last = (oc - FP_TILE * (fr.no - 1) + 3) / 4;
     if (fr.no > FP_NO_MAX || fr.T > FP_T_MAX) {
       P.why = "a front exceeds the tile limits";
       return P;
     }
     P.max_T = std::max(P.max_T, fr.T);
     fr.inv.assign((size_t)FP_TILE * fr.T, -1);
-    for (int i = 0; i < oc; ++i) fr.inv[i] = fr.own[i];
-    for (int i = 0; i < sc; ++i) fr.inv[(size_t)FP_TILE * fr.no + i] = fr.strct[i];
+    for (size_t i = 0; i < fr.own.size(); ++i) fr.inv[i] = fr.own[i];
+    std::vector<char> truly(6 * (size_t)nc + 1, 0);
+    for (int p : fr.strct) truly[p] = 1;
+    fr.live = 0;
+    for (int t = 0; t < fr.no; ++t)
+      for (int h = 0; h < 2; ++h)
+        if ((size_t)FP_TILE * t + 16 * h < fr.own.size()) fr.live |= 1u << (2 * t + h);
+    for (int i = 0; i < fr.ns; ++i)
+      for (int k = 0; k < FP_TILE; ++k) {
+        const int p = tile_params(fr.btiles[i].first, fr.btiles[i].second, k);
+        fr.inv[(size_t)FP_TILE * (fr.no + i) + k] = p;
+        if (p >= 0 && truly[p]) fr.live |= 1u << (2 * (fr.no + i) + k / 16);
+      }
   }
-  // border index -> index in the parent's front
+  // ---- border tile -> tile of the parent's front
   for (int f = 0; f < F; ++f) {
     Front& fr = P.fronts[f];
-    fr.pmap.assign((size_t)FP_TILE * fr.ns, -1);
+    fr.ptile.assign(fr.ns, -1);
     if (fr.parent < 0) continue;
     const Front& pa = P.fronts[fr.parent];
-    std::map<int, int> where;
-    for (size_t i = 0; i < pa.inv.size(); ++i)
-      if (pa.inv[i] >= 0) where[pa.inv[i]] = (int)i;
     int last = -1;
-    for (size_t i = 0; i < fr.strct.size(); ++i) {
-      auto it = where.find(fr.strct[i]);
-      if (it == where.end() || it->second <= last) {
-        P.why = "a border column is missing from the parent's front, or out of order";
+    for (int i = 0; i < fr.ns; ++i) {
+      int at = -1;
+      if (fr.btiles[i].first == fr.parent) {
+        at = fr.btiles[i].second;
+      } else {
+        for (int k = 0; k < pa.ns; ++k)
+          if (pa.btiles[k] == fr.btiles[i]) at = pa.no + k;
+      }
+      if (at <= last) {
+        P.why = "a border tile is missing from the parent's front, or out of order";
         return P;
       }
-      fr.pmap[i] = last = it->second;
+      fr.ptile[i] = last = at;
     }
   }
-  // tile -> (wave, slot): every tile (r, c), c <= r < T, but (0, 0) (the chain wave assembles it); a wave holds at most
-  // one tile of an own column below the diagonal (one triangular solve per step and wave), loads balanced by the number
-  // of rank-32 updates a tile receives
-  const int tile_waves[9] = {1, 2, 3, 5, 6, 7, 9, 10, 11};
+  // tile -> (wave, slot): every tile (r, c), c <= r < T, but (0, 0) (the chain wave assembles it).  A triangular solve
+  // is a chain of dependent f64 vector operations, and a wave that streams f64 MFMAs on the same SIMD lets it issue one
+  // of them per MFMA (MI355X: the f64 matrix instructions run on the vector lanes) -- so the tiles below the diagonal of
+  // the own columns (one solve each) go to the waves of SIMD 1 first, then SIMD 2, and the border x border tiles (all
+  // updates, no solve) to SIMD 3 first.  A wave holds at most one tile of an own column below the diagonal (one solve
+  // per step and wave).
+  const int simd_waves[3][3] = {{1, 5, 9}, {2, 6, 10}, {3, 7, 11}};
   for (int f = 0; f < F; ++f) {
     Front& fr = P.fronts[f];
     fr.sched.assign((size_t)FP_WAVES * FP_SLOTS * 2, 0xFF);
+    fr.turn.assign((size_t)FP_WAVES * FP_SLOTS, 0);
     int used[FP_WAVES] = {0}, load[FP_WAVES] = {0};
     std::vector<std::vector<int>> cols_of(FP_WAVES);
-    for (int c = 0; c < fr.T; ++c)
-      for (int r = c; r < fr.T; ++r) {
-        if (r == 0 && c == 0) continue;
-        const int w_tile = std::min(c, fr.no) * 4 + (c < fr.no && r > c ? 3 : 0) + 1;
-        int best = -1;
-        for (int k = 0; k < 9; ++k) {
-          const int w = tile_waves[k];
+    // pref: the three SIMD classes in order of preference; the least loaded wave among the first nbal classes, a later
+    // class only when those have no slot left
+    auto place = [&](int r, int c, const int* pref, int nbal) -> bool {
+      const bool solve = c < fr.no && r > c;
+      const int w_tile = std::min(c, fr.no) * 4 + (solve ? 3 : 0) + 1;
+      int best = -1, best_simd_load = 0;
+      for (int pi = 0; pi < 3 && (best < 0 || pi < nbal); ++pi) {
+        const int cls = pref[pi];
+        const int sl = load[simd_waves[cls][0]] + load[simd_waves[cls][1]] + load[simd_waves[cls][2]];  // the SIMD's load first
+        for (int k = 0; k < 3; ++k) {
+          const int w = simd_waves[cls][k];
           if (used[w] >= FP_SLOTS) continue;
-          if (c < fr.no && r > c && std::find(cols_of[w].begin(), cols_of[w].end(), c) != cols_of[w].end()) continue;
-          if (best < 0 || load[w] < load[best]) best = w;
+          if (solve && std::find(cols_of[w].begin(), cols_of[w].end(), c) != cols_of[w].end()) continue;
+          if (best < 0 || sl < best_simd_load || (sl == best_simd_load && load[w] < load[best])) best = w, best_simd_load = sl;
         }
-        if (best < 0) {
-          P.why = "no wave slot left for a tile";
-          return P;
-        }
-        fr.sched[((size_t)best * FP_SLOTS + used[best]) * 2] = (uint8_t)r;
-        fr.sched[((size_t)best * FP_SLOTS + used[best]) * 2 + 1] = (uint8_t)c;
-        ++used[best];
-        load[best] += w_tile;
-        if (c < fr.no && r > c) cols_of[best].push_back(c);
       }
+      if (best < 0) return false;
+      fr.sched[((size_t)best * FP_SLOTS + used[best]) * 2] = (uint8_t)r;
+      fr.sched[((size_t)best * FP_SLOTS + used[best]) * 2 + 1] = (uint8_t)c;
+      ++used[best];
+      load[best] += w_tile;
+      if (solve) cols_of[best].push_back(c);
+      return true;
+    };
+    const int pref_solve[3] = {1, 2, 0}, pref_crit[3] = {0, 1, 2}, pref_upd[3] = {2, 1, 0};
+    bool ok = true;
+    // the own columns, nearest the diagonal first (the next step's diagonal tile waits for them)
+    for (int c = 0; c < fr.no && ok; ++c)
+      for (int r = c; r < fr.T && ok; ++r) {
+        if (r == 0 && c == 0) continue;
+        // the tile next to the diagonal gates the next step's factorisation: SIMD 1; the other solves two per SIMD on 2 and 3
+        ok = r == c + 1 ? place(r, c, pref_crit, 1) : place(r, c, pref_solve, 2);
+      }
+    // border x border tiles.  A front of one or two own tiles keeps both panel generations to the end, and front_up folds
+    // the panels into these tiles only when the factorisation is over ("deferred"): nothing streams MFMAs beside the
+    // solves, and the tiles can sit on any SIMD -- wave 8 included -- in column order (the parent wants the low columns
+    // first), dealt round-robin over the SIMDs.  A front of more own tiles folds as it goes: SIMDs 3 and 2, then 1.
+    if (fr.no <= 2) {
+      // in column order (the order in which the parent wants them), dealt round-robin over the four SIMDs; on a SIMD the
+      // tiles are folded one after the other ("turn": one wave streaming MFMAs has the matrix pipe to itself, three waves
+      // at once would all finish late), so tile p is done about p / 4 + 1 folds after the factorisation's end
+      // A wave sends a tile and waits for the stores to leave before it raises the tile's flag, so the first tiles go to
+      // ten different waves (rounds: every wave gets its t-th border tile before any gets its (t+1)-th).
+      const int simd_of[4][3] = {{8, -1, -1}, {1, 5, 9}, {2, 6, 10}, {3, 7, 11}};
+      int turn[4] = {0, 0, 0, 0}, ndef[FP_WAVES] = {0};
+      std::vector<std::pair<int, int>> todo;
+      for (int c = fr.no; c < fr.T; ++c)
+        for (int r = c; r < fr.T; ++r) todo.emplace_back(r, c);
+      size_t p = 0;
+      for (int round = 0; round < FP_SLOTS && p < todo.size(); ++round)
+        for (int k = 0; k < 3 && p < todo.size(); ++k)
+          for (int q = 0; q < 4 && p < todo.size(); ++q) {
+            const int w = simd_of[q][k];
+            if (w < 0 || used[w] >= FP_SLOTS || ndef[w] != round) continue;
+            fr.sched[((size_t)w * FP_SLOTS + used[w]) * 2] = (uint8_t)todo[p].first;
+            fr.sched[((size_t)w * FP_SLOTS + used[w]) * 2 + 1] = (uint8_t)todo[p].second;
+            fr.turn[(size_t)w * FP_SLOTS + used[w]] = (uint8_t)turn[q]++;
+            ++used[w];
+            ++ndef[w];
+            ++p;
+          }
+      if (p < todo.size()) ok = false;
+    } else {
+      for (int c = fr.no; c < fr.T && ok; ++c)
+        for (int r = c; r < fr.T && ok; ++r) ok = place(r, c, pref_upd, 2);
+    }
+    if (!ok) {
+      P.why = "no wave slot left for a tile";
+      return P;
+    }
   }
   // levels, the up-sweep order (deepest first) and the chain length
   int maxl = 0;
@@ -366,8 +466,8 @@ namespace fplan {
 
 constexpr int FD_INTS = 24;  // ints per front descriptor
 enum {
-  FD_NO = 0, FD_NS, FD_T, FD_NB_LAST, FD_PARENT, FD_LEVEL, FD_NCHILD, FD_CHILD_OFF, FD_INV_OFF, FD_CINV_OFF, FD_SCHED_OFF,
-  FD_NCAM, FD_CAM_OFF, FD_HAS_FOCAL, FD_OFF_L, FD_OFF_U, FD_OFF_Y, FD_OWN_COLS, FD_USED
+  FD_NO = 0, FD_NS, FD_T, FD_NB_LAST, FD_PARENT, FD_LEVEL, FD_NCHILD, FD_CHILD_OFF, FD_INV_OFF, FD_PTINV_OFF, FD_SCHED_OFF,
+  FD_NCAM, FD_CAM_OFF, FD_HAS_FOCAL, FD_OFF_L, FD_OFF_Y, FD_OWN_COLS, FD_OFF_PBUF, FD_PTILE_OFF, FD_LIVE, FD_FOCAL_POS, FD_TFLAG_OFF, FD_USED
 };
 static_assert(FD_USED <= FD_INTS, "descriptor size");
 
@@ -376,7 +476,10 @@ struct Flat {
   std::vector<int> ints;       // [FD_INTS x fronts | pools]
   std::vector<int> up_order;   // deepest level first
   std::vector<int> down_order; // root first
-  size_t n_doubles = 0;        // per front: L (32 T x 32 no, row-major), U ((32 ns)^2 column-major), y (32 T)
+  int n_tflags = 0;            // per front: a flag per tile of its contribution block + one for the rhs (FD_TFLAG_OFF)
+  size_t n_doubles = 0;        // per front: L (32 T x 32 no, row-major), y (32 T), and the buffer in which it hands its
+                               // contribution block to its parent: the lower-triangle tiles of its border x border block,
+                               // tile (i, j) at (i (i + 1) / 2 + j) * 1024, each in the accumulator layout by register pairs
 };
 
 static inline Flat flatten(const Plan& P) {
@@ -401,33 +504,45 @@ static inline Flat flatten(const Plan& P) {
     put(FD_NCHILD, (int)fr.children.size());
     put(FD_HAS_FOCAL, fr.has_focal ? 1 : 0);
     put(FD_OWN_COLS, (int)fr.own.size());
+    put(FD_LIVE, (int)fr.live);
     put(FD_CHILD_OFF, (int)fl.ints.size());
     for (int k : fr.children) fl.ints.push_back(k);
     put(FD_INV_OFF, (int)fl.ints.size());
     fl.ints.insert(fl.ints.end(), fr.inv.begin(), fr.inv.end());
-    put(FD_CINV_OFF, (int)fl.ints.size());
+    // per child: tile of this front -> border tile of the child (-1: the child's border does not reach it)
+    put(FD_PTINV_OFF, (int)fl.ints.size());
     for (int k : fr.children) {
       const Front& ch = P.fronts[k];
-      std::vector<int> cinv((size_t)FP_TILE * fr.T, -1);
-      for (size_t i = 0; i < ch.pmap.size(); ++i)
-        if (ch.pmap[i] >= 0) cinv[ch.pmap[i]] = (int)i;
-      fl.ints.insert(fl.ints.end(), cinv.begin(), cinv.end());
+      std::vector<int> ptinv(FP_T_MAX + 1, -1);
+      for (int i = 0; i < ch.ns; ++i) ptinv[ch.ptile[i]] = i;
+      fl.ints.insert(fl.ints.end(), ptinv.begin(), ptinv.end());
     }
+    put(FD_PTILE_OFF, (int)fl.ints.size());
+    fl.ints.insert(fl.ints.end(), fr.ptile.begin(), fr.ptile.end());
     put(FD_SCHED_OFF, (int)fl.ints.size());
     for (int i = 0; i < FP_WAVES * FP_SLOTS; ++i) {
       const int r = fr.sched[2 * i], c = fr.sched[2 * i + 1];
-      fl.ints.push_back(r == 0xFF ? -1 : (r | (c << 8)));
+      fl.ints.push_back(r == 0xFF ? -1 : (r | (c << 8) | (fr.turn[i] << 16)));
     }
     put(FD_NCAM, (int)fr.cams.size());
-    put(FD_CAM_OFF, (int)fl.ints.size());
+    put(FD_CAM_OFF, (int)fl.ints.size());  // the own cameras, then where each one's six columns start in the front
     fl.ints.insert(fl.ints.end(), fr.cams.begin(), fr.cams.end());
+    int focal_pos = -1;
+    for (int c : fr.cams)
+      for (size_t i = 0; i < fr.own.size(); ++i)
+        if (fr.own[i] == 6 * c) fl.ints.push_back((int)i);
+    for (size_t i = 0; i < fr.own.size(); ++i)
+      if (fr.own[i] == 6 * P.nc) focal_pos = (int)i;
+    put(FD_FOCAL_POS, focal_pos);
     put(FD_OFF_L, (int)nd);
     nd += (size_t)FP_TILE * fr.T * FP_TILE * fr.no;
-    put(FD_OFF_U, (int)nd);
-    nd += (size_t)FP_TILE * fr.ns * FP_TILE * fr.ns;
     put(FD_OFF_Y, (int)nd);
     nd += (size_t)FP_TILE * fr.T;
     nd = (nd + 15) & ~(size_t)15;
+    put(FD_OFF_PBUF, (int)nd);
+    nd += (size_t)(fr.ns * (fr.ns + 1) / 2) * FP_TILE * FP_TILE;
+    put(FD_TFLAG_OFF, fl.n_tflags);
+    fl.n_tflags += fr.ns * (fr.ns + 1) / 2 + 1;
   }
   fl.n_doubles = nd;
   return fl;

@@ -12,8 +12,9 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FD_INTS = 24
-(FD_NO, FD_NS, FD_T, FD_NB_LAST, FD_PARENT, FD_LEVEL, FD_NCHILD, FD_CHILD_OFF, FD_INV_OFF, FD_CINV_OFF, FD_SCHED_OFF,
- FD_NCAM, FD_CAM_OFF, FD_HAS_FOCAL, FD_OFF_L, FD_OFF_U, FD_OFF_Y, FD_OWN_COLS) = range(18)
+(FD_NO, FD_NS, FD_T, FD_NB_LAST, FD_PARENT, FD_LEVEL, FD_NCHILD, FD_CHILD_OFF, FD_INV_OFF, FD_PTINV_OFF, FD_SCHED_OFF,
+ FD_NCAM, FD_CAM_OFF, FD_HAS_FOCAL, FD_OFF_L, FD_OFF_Y, FD_OWN_COLS, FD_OFF_PBUF, FD_PTILE_OFF, FD_LIVE) = range(20)
+T_MAX = 7
 
 
 @pytest.fixture(scope="module")
@@ -44,7 +45,14 @@ def band_adj(nc, k):
     return a
 
 
-def build(fp, adj, leaf_cols=96):
+def build(fp, adj, leaf_cols=None):
+    """leaf_cols None: the solver's own rule (sfmhip_ba's set-up) -- the largest of 96, 64, 32 whose fronts fit."""
+    if leaf_cols is None:
+        for lc in (96, 64, 32):
+            pl = build(fp, adj, lc)
+            if pl is not None:
+                return pl
+        return None
     nc = len(adj)
     wpr = (nc + 63) // 64
     bits = np.zeros((nc, wpr), np.uint64)
@@ -102,19 +110,27 @@ def multifrontal_solve(pl, S, g):
             for a in range(b, n):
                 if inv[a] >= 0:
                     Fm[a, b] = S[inv[a], inv[b]]
-        for k in range(int(d[FD_NCHILD])):    # extend-add
+        for k in range(int(d[FD_NCHILD])):    # extend-add, tile by tile: a child's border tile IS a tile of this front
             ch = int(ints[d[FD_CHILD_OFF] + k])
-            cinv = ints[d[FD_CINV_OFF] + k * n: d[FD_CINV_OFF] + (k + 1) * n]
+            ptinv = ints[d[FD_PTINV_OFF] + k * (T_MAX + 1): d[FD_PTINV_OFF] + (k + 1) * (T_MAX + 1)]
             dc = desc(pl, ch)
             assert int(dc[FD_PARENT]) == f
-            idx = np.nonzero(cinv >= 0)[0]
-            assert np.all(np.diff(cinv[idx]) > 0)      # monotone: a lower triangle maps onto a lower triangle
-            Uc, yc, oc = U[ch], Y[ch], 32 * int(dc[FD_NO])
-            for a in idx:
-                y[a] += yc[oc + cinv[a]]
-                for b in idx:
-                    if a >= b:
-                        Fm[a, b] += Uc[cinv[a], cinv[b]]
+            cno, cns = int(dc[FD_NO]), int(dc[FD_NS])
+            ptile = ints[dc[FD_PTILE_OFF]: dc[FD_PTILE_OFF] + cns]
+            assert np.all(np.diff(ptile) > 0)          # monotone: a lower triangle maps onto a lower triangle
+            cinvd = ints[dc[FD_INV_OFF]: dc[FD_INV_OFF] + 32 * int(dc[FD_T])]
+            Uc, yc = U[ch], Y[ch]
+            for i in range(cns):
+                R = int(ptile[i])
+                assert ptinv[R] == i
+                # the same 32 parameters, padding included, in the same order
+                assert np.array_equal(cinvd[32 * (cno + i): 32 * (cno + i + 1)], inv[32 * R: 32 * (R + 1)])
+                y[32 * R: 32 * R + 32] += yc[32 * (cno + i): 32 * (cno + i + 1)]
+                for j in range(i + 1):
+                    C_ = int(ptile[j])
+                    blk = Uc[32 * i: 32 * i + 32, 32 * j: 32 * j + 32]
+                    Fm[32 * R: 32 * R + 32, 32 * C_: 32 * C_ + 32] += np.tril(blk) if i == j else blk
+            assert sum(1 for t in range(T) if ptinv[t] >= 0) == cns
         Lvv = np.linalg.cholesky(Fm[:o, :o] + np.tril(Fm[:o, :o], -1).T)
         Lbv = np.linalg.solve(Lvv, Fm[o:, :o].T).T
         L[f] = np.vstack([Lvv, Lbv])
@@ -146,6 +162,11 @@ def check_schedule(pl):
     for f in range(pl["F"]):
         d = desc(pl, f)
         no, T = int(d[FD_NO]), int(d[FD_T])
+        inv = ints[d[FD_INV_OFF]: d[FD_INV_OFF] + 32 * T]
+        for t in range(T):                        # a row half that is not live holds no own parameter
+            for h in range(2):
+                if not (int(d[FD_LIVE]) >> (2 * t + h)) & 1 and t < no:
+                    assert np.all(inv[32 * t + 16 * h: 32 * t + 16 * h + 16] < 0)
         assert 1 <= no <= 4 and T <= 7 and 1 <= d[FD_NB_LAST] <= 8
         sched = ints[d[FD_SCHED_OFF]: d[FD_SCHED_OFF] + 36].reshape(12, 3)
         tiles = []
@@ -154,8 +175,10 @@ def check_schedule(pl):
             for s in range(3):
                 if sched[w, s] < 0:
                     continue
-                assert w % 4 != 0                 # waves 0, 4, 8 hold no tiles
-                r, c = int(sched[w, s]) & 255, int(sched[w, s]) >> 8
+                assert w % 4 != 0 or w == 8       # waves 0 and 4 hold no tiles
+                if w == 8:
+                    assert no <= 2 and ((int(sched[w, s]) >> 8) & 255) >= no   # wave 8: border tiles of a front that folds them at the end
+                r, c = int(sched[w, s]) & 255, (int(sched[w, s]) >> 8) & 255
                 tiles.append((r, c))
                 if c < no and r > c:
                     cols.append(c)
@@ -174,8 +197,8 @@ def test_ring_plans_solve_the_system(fp, nc, k):
     z = multifrontal_solve(pl, S, g)
     zr = np.linalg.solve(S, g)
     assert np.abs(z - zr).max() <= 1e-10 * np.abs(zr).max()
-    if (nc, k) == (200, 10):                  # cfg4: 8 leaves of 3 tiles, two levels of 2-tile separators, a 4-tile root
-        assert pl["levels"] == 4 and pl["F"] == 15 and pl["chain_tiles"] == 11 and pl["max_T"] == 7
+    if (nc, k) == (200, 10):                  # cfg4: 16 leaves of one tile, three levels of 2-tile separators, a 4-tile root
+        assert pl["levels"] == 5 and pl["F"] == 31 and pl["chain_tiles"] == 11 and pl["max_T"] == 7
 
 
 def test_band_and_disconnected_graphs(fp):

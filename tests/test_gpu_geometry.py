@@ -150,14 +150,18 @@ def test_dissected_reduced_system_walks_the_dense_iterates(ctx, orc, monkeypatch
     pb = synth.ba_problem(96, 12000, 6, seed=5)
     opts = dict(max_time_s=0.0, max_iterations=6)
     out = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "2"):
         monkeypatch.setenv("SFMHIP_BA_ND", mode)      # read when the problem plans its first solve
         prob = bundle.BaProblem(96, 12000, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
         prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
         s = prob.run(bundle.default_opts(**opts))
         out[mode] = (s, prob.get_params(), prob.reduced_layout())
         prob.close()
-    (s0, (c0, p0, f0), l0), (s1, (c1, p1, f1), l1) = out["0"], out["1"]
+    (s0, (c0, p0, f0), l0), (s1, (c1, p1, f1), l1), (s2, (c2, p2, f2), l2) = out["0"], out["1"], out["2"]
+    assert l2["chains"] == 0                       # (the front tree; its shape is asserted in test_reduced_layout_...)
+    assert (s0.termination, s0.iterations, s0.successful_steps) == (s2.termination, s2.iterations, s2.successful_steps)
+    assert abs(s0.final_cost - s2.final_cost) <= 1e-11 * s0.final_cost
+    assert np.allclose(c0, c2, rtol=1e-9, atol=1e-12) and np.allclose(p0, p2, rtol=1e-8, atol=1e-10) and abs(f0 - f2) <= 1e-10 * f0
     assert l0["chains"] == 0 and l0["dense_tiles"] == 20
     assert l1["chains"] >= 2 and l1["chain_tiles"] + l1["separator_tiles"] < l1["dense_tiles"]
     assert (s0.termination, s0.iterations, s0.successful_steps) == (s1.termination, s1.iterations, s1.successful_steps)
@@ -170,12 +174,14 @@ def test_dissected_reduced_system_walks_the_dense_iterates(ctx, orc, monkeypatch
 
 
 @pytest.mark.parametrize("shape,nd", [((96, 6000, 6), "0"), ((96, 6000, 6), "1"), ((180, 8000, 8), "0"), ((560, 8000, 8), "1"),
-                                      ((1400, 9000, 8), "0")])
+                                      ((1400, 9000, 8), "0"), ((6, 300, 4), "2"), ((50, 5000, 10), "2"), ((96, 6000, 6), "2"),
+                                      ((200, 20000, 10), "2"), ((560, 8000, 8), "2"), ((1400, 9000, 8), "2")])
 def test_reduced_step_solves_the_reduced_system(ctx, monkeypatch, shape, nd):
-    """(S + D/r) z = g, z from the solver's own factorisation (dense; dissected: chains + separator), against
-    numpy on the system the solver hands out.  560 cameras: six chains whose launches exceed one round of
+    """(S + D/r) z = g, z from the solver's own factorisation (dense; dissected: chains + separator; the front tree),
+    against numpy on the system the solver hands out.  560 cameras: six chains whose launches exceed one round of
     workgroups; 1400 cameras dense: 266 panel workgroups on 256 CUs (no workgroup of a launch may depend on another
-    one's being resident: until round 2 the owner overwrote the diagonal tiles the others read)."""
+    one's being resident: until round 2 the owner overwrote the diagonal tiles the others read); the front tree from one
+    front (6 cameras) to 127 fronts in seven levels (1400 cameras)."""
     monkeypatch.setenv("SFMHIP_BA_ND", nd)
     nc, npt, k = shape
     pb = synth.ba_problem(nc, npt, k, seed=5)
@@ -183,8 +189,8 @@ def test_reduced_step_solves_the_reduced_system(ctx, monkeypatch, shape, nd):
     prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
     z, failed = prob.reduced_step(1e4)
     S, g, _ = prob.reduced_system(1e4)
-    lay = prob.reduced_layout()
-    assert failed == 0 and (lay["chains"] >= 2) == (nd == "1")
+    lay, tree = prob.reduced_layout(), prob.reduced_tree()
+    assert failed == 0 and (lay["chains"] >= 2) == (nd == "1") and (tree["fronts"] >= 1) == (nd == "2")
     assert np.linalg.norm(S @ z - g) <= 1e-12 * np.linalg.norm(g)
     zr = np.linalg.solve(S, g)
     assert np.abs(z - zr).max() <= 1e-9 * np.abs(zr).max()
@@ -201,19 +207,28 @@ def test_reduced_layout_follows_the_camera_graph(ctx, monkeypatch):
     ring.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
     assert ring.reduced_layout()["dense_tiles"] == 0          # not planned yet
     ring.iterate(1)
-    lay = ring.reduced_layout()
-    assert lay["chains"] == 4 and lay["dense_tiles"] == 38 and lay["chain_tiles"] + lay["separator_tiles"] <= 16
+    lay, tree = ring.reduced_layout(), ring.reduced_tree()
+    # the front tree: 8 leaves of 3 tiles, two levels of 2-tile separators, a 4-tile root -- 11 tile steps on the chain
+    assert lay["chains"] == 0 and lay["dense_tiles"] == 38
+    assert tree == dict(fronts=15, levels=4, chain_tiles=11, max_front_tiles=7)
+    monkeypatch.setenv("SFMHIP_BA_ND", "1")                   # the chains + separator plan of round 2
+    ring1 = bundle.BaProblem(200, 20000, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
+    ring1.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+    ring1.iterate(1)
+    lay = ring1.reduced_layout()
+    assert lay["chains"] == 4 and lay["chain_tiles"] + lay["separator_tiles"] <= 16 and ring1.reduced_tree()["fronts"] == 0
+    monkeypatch.delenv("SFMHIP_BA_ND", raising=False)
     rng = np.random.default_rng(0)
     oc = np.concatenate([np.sort(rng.choice(200, 10, replace=False)) for _ in range(20000)]).astype(np.int32)
     rnd = bundle.BaProblem(200, 20000, oc, pb["obs_pt"], pb["obs_xy"], ctx=ctx)
     rnd.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
     rnd.iterate(1)
-    assert rnd.reduced_layout()["chains"] == 0
+    assert rnd.reduced_layout()["chains"] == 0 and rnd.reduced_tree()["fronts"] == 0
     small = synth.ba_problem(50, 5000, 10, seed=4)
     sm = bundle.BaProblem(50, 5000, small["obs_cam"], small["obs_pt"], small["obs_xy"], ctx=ctx)
     sm.set_params(small["cams0"], small["pts0"], small["focal0"])
     sm.iterate(1)
-    assert sm.reduced_layout()["chains"] == 0
+    assert sm.reduced_layout()["chains"] == 0 and sm.reduced_tree() == dict(fronts=3, levels=2, chain_tiles=7, max_front_tiles=7)
 
 
 def test_tracks_longer_than_a_wave(ctx, orc):
