@@ -43,6 +43,6 @@ L.sfmhip_debug_down_stamps.argtypes = [C.c_void_p, C.c_int]
 assert L.sfmhip_debug_down_stamps(dn.ctypes.data, F) == 0
 dn = dn.astype(np.int64)
 d0 = dn[:, 0][dn[:, 0] > 0].min()
-print("down-sweep (us since the first workgroup's start): start | L prefetched | parent's flag | z_b read | w ready | z_v solved | flag stored | cameras done")
+print("down-sweep (us since the first workgroup's start): start | L prefetched + inverted | z_b arrived | w ready | z_v solved | flag stored | cameras done")
 for f in range(len(dn)):
-    print(f"  front {f}: " + " ".join(f"{(dn[f, k] - d0) / 100.0:7.2f}" for k in range(7)))
+    print(f"  front {f}: " + " ".join(f"{(dn[f, k] - d0) / 100.0:7.2f}" for k in (0, 1, 2, 3, 4, 5, 6)))

@@ -2746,7 +2746,6 @@ struct sfmhip_ba {
   FrontSet tree_fs{};
   unsigned tree_epoch = 0;
   int tree_stride = 1, tree_levels = 0, tree_chain_tiles = 0, tree_chain_blocks = 0, tree_max_T = 0;
-  std::vector<int> tree_level_of_wg;
   // ba_finalize deferred to the next nd_gather (the LM loop's linearisations, when the dissected solve follows)
   bool fin_pending = false, defer_fin = false;
   double fin_radius = 0, fin_lo = 0, fin_hi = 0;
@@ -3775,7 +3774,7 @@ static int ba_nd_build(sfmhip_ba* b) {
       SFM_TRY(ba_alloc(b, &d_ints, fl.ints.size()));
       SFM_TRY(ba_alloc(b, &d_up, fl.up_order.size()));
       SFM_TRY(ba_alloc(b, &d_down, fl.down_order.size()));
-      const size_t n_flags = (size_t)fl.n_fronts + (size_t)fl.n_tflags;  // down-sweep: one per front; up-sweep: one per contribution tile
+      const size_t n_flags = (size_t)fl.n_fronts + (size_t)fl.n_tflags;  // per front: z in place; per contribution tile
       SFM_TRY(ba_alloc(b, &d_flags, n_flags));
       SFM_TRY(ba_alloc(b, &pool, fl.n_doubles));
       SFM_HIP_TRY(hipMemcpy(d_ints, fl.ints.data(), fl.ints.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -3790,8 +3789,13 @@ static int ba_nd_build(sfmhip_ba* b) {
       b->tree_fs.flag_down = d_flags;
       b->tree_fs.tflag = d_flags + fl.n_fronts;
       double* zq = nullptr;
-      SFM_TRY(ba_alloc(b, &zq, (size_t)b->ld));
+      SFM_TRY(ba_alloc(b, &zq, 2 * (size_t)b->ld));
+      {
+        std::vector<unsigned long long> pend(2 * (size_t)b->ld, FR_Z_PENDING);
+        SFM_HIP_TRY(hipMemcpy(zq, pend.data(), pend.size() * 8, hipMemcpyHostToDevice));
+      }
       b->tree_fs.zq = zq;
+      b->tree_fs.zq_ld = b->ld;
       b->tree_fs.n_fronts = fl.n_fronts;
       b->tree_levels = fl.levels;
       b->tree_chain_tiles = P.chain_tiles;

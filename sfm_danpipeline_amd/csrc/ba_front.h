@@ -74,7 +74,9 @@ struct FrontSet {
   double* pool;           // per front: L | U | y
   unsigned* tflag;        // per tile of a front's contribution block (+ one for its rhs): the epoch of the solve that finished it
   unsigned* flag_down;    // per front: the epoch of the solve whose z is in place
-  double* zq;             // the down-sweep's mailbox: z per parameter, FR_Z_PENDING until its front has solved it
+  double* zq;             // the down-sweep's mailbox, two generations of ld doubles (solve e uses e & 1): z per parameter,
+                          // FR_Z_PENDING until its front has solved it; a front resets its entries of the OTHER generation
+  int zq_ld;
   int n_fronts;
 };
 
@@ -218,9 +220,10 @@ __device__ __forceinline__ unsigned fr_live_subs(unsigned live, int r, int c) {
 // POTRF of the diagonal tile in acc ([0] = rows 0-15 x cols 0-15, [1] = rows 16-31 x cols 0-15, [2] = rows 16-31 x cols
 // 16-31), nb blocks of four columns (the last own tile of a front stops at its last real column).  sD receives L
 // (row-major; above the diagonal and right of column 4 nb: unspecified), sdi 1/diag, *prog = base + finished blocks;
-// gL: the copy in memory, row-major with leading dimension ldk.
+// gL_bytes: where the copy in memory starts in the pool (row-major, leading dimension ldk; the down-sweep, a later
+// launch, reads it).
 __device__ __forceinline__ void fr_potrf(v4d (&acc)[3], double* sD, double* sdi, int* prog, int base, int nb, bool& bad, int lane,
-                                         double* gL, int ldk) {
+                                         __amdgpu_buffer_rsrc_t pool, int gL_bytes, int ldk) {
   const int i = lane & 31, j16 = lane & 15, q = lane >> 4;
   double* const rowp = sD + i * CBP;
   double* const op0 = sD + j16 * CBP + q;
@@ -253,8 +256,8 @@ __device__ __forceinline__ void fr_potrf(v4d (&acc)[3], double* sD, double* sdi,
       lds_flag_set(prog, base + b + 1);
       if (lane < CB) {
         // (the row's four entries of this block; above the diagonal: what the registers hold, never read)
-        *(v2d*)(gL + (size_t)i * ldk + c) = v2d{l[0], l[1]};
-        *(v2d*)(gL + (size_t)i * ldk + c + 2) = v2d{l[2], l[3]};
+        __builtin_amdgcn_raw_buffer_store_b128(fr_pack2(l[0], l[1]), pool, gL_bytes + (i * ldk + c) * 8, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(fr_pack2(l[2], l[3]), pool, gL_bytes + (i * ldk + c + 2) * 8, 0, 0);
       }
       if (b + 1 < nb) {
         const double L0 = op0[c], L1 = op1[c];
@@ -269,10 +272,10 @@ __device__ __forceinline__ void fr_potrf(v4d (&acc)[3], double* sD, double* sdi,
 }
 
 // X = T L^-T for the tile in acc ([2 * ci + ri]), trailing the factorisation of L block by block through *prog.  sT: the
-// tile's LDS home (scratch for the layout changes, X when done, row-major); *oflag = base + finished blocks; out: the
-// lane's row of the copy in memory (its columns of this block column are contiguous).
+// tile's LDS home (scratch for the layout changes, X when done, row-major); *oflag = base + finished blocks; out_bytes:
+// the lane's row of the copy in memory, as an offset into the pool (its columns of this block column are contiguous).
 __device__ __forceinline__ void fr_trsm(v4d (&acc)[4], double* sT, const double* sL, const double* sdi, const int* prog, int* oflag,
-                                        int base, int nb, double* out, int lane) {
+                                        int base, int nb, __amdgpu_buffer_rsrc_t pool, int out_bytes, int lane) {
   const int i = lane & 31, j16 = lane & 15, q = lane >> 4;
   double* const rowp = sT + i * CBP;
   double* const op0 = sT + j16 * CBP + q;
@@ -305,8 +308,8 @@ __device__ __forceinline__ void fr_trsm(v4d (&acc)[4], double* sT, const double*
       *(v2d*)(rowp + c + 2) = v2d{x2, x3};
       lds_flag_set(oflag, base + b + 1);
       if (lane < CB) {
-        *(v2d*)(out + c) = v2d{x0, x1};
-        *(v2d*)(out + c + 2) = v2d{x2, x3};
+        __builtin_amdgcn_raw_buffer_store_b128(fr_pack2(x0, x1), pool, out_bytes + c * 8, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(fr_pack2(x2, x3), pool, out_bytes + (c + 2) * 8, 0, 0);
       }
       if (b + 1 < nb) {
         const double X0 = op0[c], X1 = op1[c];
@@ -420,7 +423,6 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
   double* const sy = sAll + FR_OFF_Y;
   int* const sInv = (int*)(sAll + FR_OFF_INV);
   int* const s_flag = (int*)(sAll + FR_OFF_FLAG);
-  double* const Lg = fs.pool + D.offL;
   const __amdgpu_buffer_rsrc_t pool_rs = __builtin_amdgcn_make_buffer_rsrc((void*)fs.pool, 0, 0x7FFFFFFF, 0x00020000);
   const unsigned live = (unsigned)D.live;
   double* const yg = fs.pool + D.offy;
@@ -430,7 +432,6 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
   for (int i = threadIdx.x; i < nrow; i += FR_WAVES * 64) {
     const int gi = fs.ints[D.inv_off + i];
     sInv[i] = gi;
-    if (i < ldk && gi >= 0) ((unsigned long long*)fs.zq)[gi] = FR_Z_PENDING;  // (the down-sweep is a later launch)
   }
   if (wave == 0) {
     FR_STAMP(0);
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
       const int gen = j & 1, base = 8 * (j >> 1), nbj = j == no - 1 ? D.nb_last : 8;
       if (j >= 2) lds_wait_ge(s_flag + FRC_CONS + gen, FR_WAVES * (j >> 1));  // (everybody is done with the tiles of step j - 2)
       FR_STAMP(4 + 3 * j);
-      fr_potrf(dacc, sD + gen * FR_TILE, sdi + gen * CB, progL_of(gen), base, nbj, bad, lane, Lg + (size_t)(CB * j) * ldk + CB * j, ldk);
+      fr_potrf(dacc, sD + gen * FR_TILE, sdi + gen * CB, progL_of(gen), base, nbj, bad, lane, pool_rs, (D.offL + (CB * j) * ldk + CB * j) * 8, ldk);
       FR_STAMP(5 + 3 * j);
       if (j + 1 < no) {
         // the next diagonal tile: its owner left it in the staging tile with every panel but this one folded in
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
           need(s);
           if (j >= 2) lds_wait_ge(s_flag + FRC_CONS + gen, FR_WAVES * (j >> 1));
           fr_trsm(t[s], panel_tile(gen, sr[s]), sD + gen * FR_TILE, sdi + gen * CB, progL_of(gen), prog_of(gen, sr[s]), base, nbj,
-                  Lg + (size_t)(CB * sr[s] + (lane & 31)) * ldk + CB * j, lane);
+                  pool_rs, (D.offL + (CB * sr[s] + (lane & 31)) * ldk + CB * j) * 8, lane);
         }
 #pragma unroll
       for (int s = 0; s < FR_SLOTS; ++s)
@@ -736,6 +737,9 @@ __global__ __launch_bounds__(FD_THREADS) void front_down(FrontSet fs, BaDev d, c
   __shared__ double szv[CB * fplan::FP_NO_MAX];  // z of the own columns
   __shared__ double spart[4][CB * fplan::FP_NO_MAX];
   __shared__ double sred[2][FD_THREADS / 64];
+  __shared__ double sLd[fplan::FP_NO_MAX][CB * CB];  // the diagonal tiles of L (wave j: tile j), [row][col]
+  __shared__ double sRd[fplan::FP_NO_MAX][CB];        // 1 / their diagonals
+  __shared__ double sT[fplan::FP_NO_MAX][CB];         // t_j, for the product with the inverse
   __shared__ int s_to;
   const int f = fs.down_order[blockIdx.x];
   const FrDesc D = fr_desc(fs.ints, f);
@@ -744,6 +748,9 @@ __global__ __launch_bounds__(FD_THREADS) void front_down(FrontSet fs, BaDev d, c
   const int valid = CB * (no - 1) + 4 * D.nb_last;  // columns of L that were written
   const double* const Lt = fs.pool + D.offL;
   const double* const yg = fs.pool + D.offy;
+  const double* const zq_cur = fs.zq + (size_t)(epoch & 1) * fs.zq_ld;
+  double* const zq_mine = fs.zq + (size_t)(epoch & 1) * fs.zq_ld;
+  double* const zq_next = fs.zq + (size_t)((epoch + 1) & 1) * fs.zq_ld;
   for (int i = threadIdx.x; i < CB * D.T; i += FD_THREADS) sInv[i] = fs.ints[D.inv_off + i];
   if (threadIdx.x == 0) s_to = 0;
   FD_STAMP(0);
@@ -751,7 +758,8 @@ __global__ __launch_bounds__(FD_THREADS) void front_down(FrontSet fs, BaDev d, c
   // lane + 64), and, waves 0..no-1, their column tile of the own block (lane = column k + 32 h: half h of the rows of
   // every tile)
   constexpr int QR = CB * (FR_TMAX - 1) / 4;  // border rows per wave, at most
-  double RB[2 * QR], RC[48], Ld[CB];
+  double RB[2 * QR], RC[48];
+  double Y[CB];  // waves 0..no-1, lane i < 32: row i of L_jj^-T (= column i of L_jj^-1); the root: its column of L_jj
   double rdi = 1.0;
   const int qrows = nsr / 4;  // (nsr is a multiple of 32)
   const int kc = lane & 31, hc = lane >> 5;
@@ -775,9 +783,42 @@ __global__ __launch_bounds__(FD_THREADS) void front_down(FrontSet fs, BaDev d, c
         const int r = j + 1 + rr;
         RC[16 * rr + a] = (live && r < no) ? Lt[(size_t)(CB * r + 16 * hc + a) * ldk + col] : 0.0;
       }
+    // ---- the inverse of the diagonal tile, while the parent's z is still on its way: lane i solves L y = e_i column by
+    // column (every lane its own right-hand side, L broadcast from LDS: no traffic between lanes), which leaves row i of
+    // L^-T in its registers -- the backward substitution of the tile is then ONE product z_i = sum_k y_k t_k instead of a
+    // chain of 32 dependent steps.  Rows / columns past the last real column count as the identity.
+    // (the ROOT waits for nobody: the inversion would be time on the critical path -- it keeps its column below the
+    // diagonal instead, Y[i] = L(32 j + i, col), and substitutes column by column)
+    if (D.parent < 0) {
 #pragma unroll
-    for (int i = 0; i < CB; ++i) Ld[i] = (live && i > kc && CB * j + i < valid) ? Lt[(size_t)(CB * j + i) * ldk + col] : 0.0;
-    if (live) rdi = rcp_f64(Lt[(size_t)col * ldk + col]);
+      for (int i = 0; i < CB; ++i) Y[i] = (live && i > kc && CB * j + i < valid) ? Lt[(size_t)(CB * j + i) * ldk + col] : 0.0;
+      rdi = live ? rcp_f64(Lt[(size_t)col * ldk + col]) : 1.0;
+    } else {
+    // (staged TRANSPOSED, [column][row]: the rows below the diagonal of a column are contiguous, two per LDS read)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = lane + 64 * u, i = e >> 5, k = e & 31;  // coalesced along a row of L
+      const bool in = CB * j + i < valid && CB * j + k < valid;
+      sLd[j][k * CB + i] = in ? (k <= i ? Lt[(size_t)(CB * j + i) * ldk + CB * j + k] : 0.0) : (i == k ? 1.0 : 0.0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (lane < CB) sRd[j][lane] = rcp_f64(sLd[j][lane * CB + lane]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < CB; ++k) Y[k] = k == kc ? 1.0 : 0.0;
+#pragma unroll
+    for (int m = 0; m < CB; ++m) {
+      Y[m] *= sRd[j][m];
+      const double* const colm = &sLd[j][m * CB];  // L(., m)
+      if ((m + 1) & 1) Y[m + 1 < CB ? m + 1 : m] -= (m + 1 < CB ? colm[m + 1] : 0.0) * Y[m];  // (an odd first row, then pairs)
+#pragma unroll
+      for (int k = (m + 2) & ~1; k < CB; k += 2) {
+        const v2d l = *(const v2d*)(colm + k);
+        Y[k] -= l.x * Y[m];
+        Y[k + 1] -= l.y * Y[m];
+      }
+    }
+    }
   }
   const double y_own = (int)threadIdx.x < o ? yg[threadIdx.x] : 0.0;  // (o <= 128 < FD_THREADS)
   __syncthreads();
@@ -790,7 +831,7 @@ __global__ __launch_bounds__(FD_THREADS) void front_down(FrontSet fs, BaDev d, c
     if (gi >= 0) {
       int budget = 1 << 17;
       for (;;) {
-        v = fr_ld_sc1(fs.zq + gi);
+        v = fr_ld_sc1(zq_cur + gi);
         if ((unsigned long long)__double_as_longlong(v) != FR_Z_PENDING) break;
         if (--budget == 0) {
           s_to = 1;
@@ -830,14 +871,21 @@ __global__ __launch_bounds__(FD_THREADS) void front_down(FrontSet fs, BaDev d, c
           for (int a = 0; a < 16; ++a) tv -= RC[16 * rr + a] * szv[CB * (j + 1 + rr) + 16 * hc + a];
         }
       tv += __shfl_xor(tv, 32);  // (both halves now hold the whole sum)
-      // L_jj^T z = t, last column first: z_i = t_i / L_ii, t_k -= L_ik z_i for k < i -- one multiply, one broadcast, one
-      // fused multiply-add on the chain per column
+      if (lane < CB) sT[j][lane] = tv;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       double zv = 0.0;
+      if (D.parent < 0) {
+        // L_jj^T z = t, last column first: z_i = t_i / L_ii, t_k -= L_ik z_i for k < i
 #pragma unroll
-      for (int i = CB - 1; i >= 0; --i) {
-        const double zi = readlane_f64(tv * rdi, i);
-        if (kc == i) zv = zi;
-        tv -= Ld[i] * zi;
+        for (int i = CB - 1; i >= 0; --i) {
+          const double zi = readlane_f64(tv * rdi, i);
+          if (kc == i) zv = zi;
+          tv -= Y[i] * zi;
+        }
+      } else {
+        // z_j = L_jj^-T t_j: lane i holds row i of the inverse
+#pragma unroll
+        for (int k = 0; k < CB; ++k) zv += Y[k] * sT[j][k];
       }
       if (lane < CB) szv[CB * j + lane] = zv;
     }
@@ -847,8 +895,9 @@ __global__ __launch_bounds__(FD_THREADS) void front_down(FrontSet fs, BaDev d, c
   for (int k = threadIdx.x; k < o; k += FD_THREADS) {
     const int gi = sInv[k];
     if (gi >= 0) {
-      fr_st_sc1(fs.zq + gi, szv[k]);  // the children poll this one
-      d.z[gi] = szv[k];               // ba_backsub (a later launch) reads this one
+      fr_st_sc1(zq_mine + gi, szv[k]);  // the children poll this one
+      d.z[gi] = szv[k];                 // ba_backsub (a later launch) reads this one
+      ((unsigned long long*)zq_next)[gi] = FR_Z_PENDING;  // (the next solve's generation: nobody reads it before the next launch)
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

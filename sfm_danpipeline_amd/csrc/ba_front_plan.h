@@ -398,7 +398,9 @@ static inline Plan build_plan(int nc, const unsigned long long* adj_bits, int wp
       for (int r = c; r < fr.T && ok; ++r) {
         if (r == 0 && c == 0) continue;
         // the tile next to the diagonal gates the next step's factorisation: SIMD 1; the other solves two per SIMD on 2 and 3
-        ok = r == c + 1 ? place(r, c, pref_crit, 1) : place(r, c, pref_solve, 2);
+        // (the LAST own column has no next diagonal tile to protect: its solves spread over SIMDs 1 to 3 -- the border
+        // tiles cannot be folded before they are through)
+        ok = r == c + 1 ? place(r, c, pref_crit, 1) : place(r, c, pref_solve, c == fr.no - 1 && r > c ? 3 : 2);
       }
     // border x border tiles.  A front of one or two own tiles keeps both panel generations to the end, and front_up folds
     // the panels into these tiles only when the factorisation is over ("deferred"): nothing streams MFMAs beside the

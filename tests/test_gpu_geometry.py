@@ -208,9 +208,9 @@ def test_reduced_layout_follows_the_camera_graph(ctx, monkeypatch):
     assert ring.reduced_layout()["dense_tiles"] == 0          # not planned yet
     ring.iterate(1)
     lay, tree = ring.reduced_layout(), ring.reduced_tree()
-    # the front tree: 8 leaves of 3 tiles, two levels of 2-tile separators, a 4-tile root -- 11 tile steps on the chain
+    # the front tree: 16 leaves of one tile, three levels of 2-tile separators, a 4-tile root -- 11 tile steps on the chain
     assert lay["chains"] == 0 and lay["dense_tiles"] == 38
-    assert tree == dict(fronts=15, levels=4, chain_tiles=11, max_front_tiles=7)
+    assert tree == dict(fronts=31, levels=5, chain_tiles=11, max_front_tiles=7)
     monkeypatch.setenv("SFMHIP_BA_ND", "1")                   # the chains + separator plan of round 2
     ring1 = bundle.BaProblem(200, 20000, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
     ring1.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
