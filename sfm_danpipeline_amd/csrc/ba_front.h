@@ -217,6 +217,11 @@ __device__ __forceinline__ unsigned fr_live_subs(unsigned live, int r, int c) {
   return m;
 }
 
+// (keeps the optimiser from cloning a step's body per value: the kernel is larger than the instruction cache as it is)
+__device__ __forceinline__ int opaque_s(int v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
 // POTRF of the diagonal tile in acc ([0] = rows 0-15 x cols 0-15, [1] = rows 16-31 x cols 0-15, [2] = rows 16-31 x cols
 // 16-31), nb blocks of four columns (the last own tile of a front stops at its last real column).  sD receives L
 // (row-major; above the diagonal and right of column 4 nb: unspecified), sdi 1/diag, *prog = base + finished blocks;
@@ -508,8 +513,9 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
     __builtin_amdgcn_s_setprio(3);
     v4d dacc[3] = {t[0][0], t[0][1], t[0][3]};
     bool bad = false;
+#pragma unroll 1
     for (int j = 0; j < no; ++j) {
-      const int gen = j & 1, base = 8 * (j >> 1), nbj = j == no - 1 ? D.nb_last : 8;
+      const int gen = j & 1, base = 8 * (j >> 1), nbj = opaque_s(j == no - 1 ? D.nb_last : 8);
       if (j >= 2) lds_wait_ge(s_flag + FRC_CONS + gen, FR_WAVES * (j >> 1));  // (everybody is done with the tiles of step j - 2)
       FR_STAMP(4 + 3 * j);
       fr_potrf(dacc, sD + gen * FR_TILE, sdi + gen * CB, progL_of(gen), base, nbj, bad, lane, pool_rs, (D.offL + (CB * j) * ldk + CB * j) * 8, ldk);
@@ -542,8 +548,9 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
   } else if (rhs) {
     // ---- the right-hand side: y_j = L_jj^-1 y_j four columns at a time behind the factorisation (lane = column),
     // then y_r -= X_rj y_j for the rows below
+#pragma unroll 1
     for (int j = 0; j < no; ++j) {
-      const int gen = j & 1, base = 8 * (j >> 1), nbj = j == no - 1 ? D.nb_last : 8;
+      const int gen = j & 1, base = 8 * (j >> 1), nbj = opaque_s(j == no - 1 ? D.nb_last : 8);
       const double* const sL = sD + gen * FR_TILE;
       const double* const sdj = sdi + gen * CB;
       double* const yj = sy + CB * j;
@@ -616,8 +623,9 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
         need(s);
         publish_diag(t[s], 1);
       }
+#pragma unroll 1
     for (int j = 0; j < no; ++j) {
-      const int gen = j & 1, base = 8 * (j >> 1), nbj = j == no - 1 ? D.nb_last : 8;
+      const int gen = j & 1, base = 8 * (j >> 1), nbj = opaque_s(j == no - 1 ? D.nb_last : 8);
 #pragma unroll
       for (int s = 0; s < FR_SLOTS; ++s)
         if (sc[s] == j && sr[s] > j) {
