@@ -2510,13 +2510,15 @@ __global__ void ba_cand_cams(BaDev d, const unsigned char* __restrict__ cam_used
 // waves and nothing to overlap them with.
 constexpr int BS_SUMS = 14;
 template <int WPP>
-__global__ __launch_bounds__(256) void ba_backsub(BaDev d, double radius, double lm_lo, double lm_hi) {
+__global__ __launch_bounds__(256) void ba_backsub(BaDev d, double radius, double lm_lo, double lm_hi, const int* __restrict__ plist, int npl) {
   constexpr int BLOCKS = 4 / WPP;  // blocks of 64 points per workgroup
   __shared__ double s_part[WPP > 1 ? 4 * BS_SUMS * 64 : 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wb = wave / WPP, sub = wave % WPP;
-  const int p = (blockIdx.x * BLOCKS + wb) * 64 + lane;
-  const bool active = p < d.np;
+  // (plist: the points that ba_backsub_runs does not take -- those of the pair path; null: all of them)
+  const int pidx = (blockIdx.x * BLOCKS + wb) * 64 + lane;
+  const bool active = pidx < npl;
+  const int p = active ? (plist ? plist[pidx] : pidx) : 0;
   double mcc = 0, cost_c = 0, sn2 = 0, cn2 = 0;
   double X[3] = {0, 0, 0}, sp[3] = {1, 1, 1};
   double sm[BS_SUMS];  // C (6: 00 10 11 20 21 22), Jp^T r (3), Jp^T a (3), a.r, |a|^2
@@ -2652,6 +2654,162 @@ __global__ __launch_bounds__(256) void ba_backsub(BaDev d, double radius, double
   }
 }
 
+// The same step for the points in runs (ba_eliminate_mfma's chunks: contiguous points that see the same ascending camera list, at most
+// 10 cameras), still a thread per point -- 64 points per wave is what keeps the arithmetic per observation small; a row of 16 lanes per
+// point, the elimination's layout, was measured at 36 us: 4 points per wave-instruction -- but with the run's structure used for the
+// memory side, which is what bounds ba_backsub (K7): every lane of the workgroup wants the SAME camera at the same time, so the run's
+// tables, scales and steps sit in LDS and are read by broadcast (no vector-memory instruction per table entry, no scalar-cache misses),
+// and the observations, point-major in memory (a wave's load of "observation k of my point" touches 64 lines), are staged through LDS by
+// coalesced loads, every line fetched once, and read back transposed ([k][point]: conflict-free).
+constexpr int BSR_PTS = 256;  // points per block of a workgroup (a thread each)
+// bs_desc: 16 ints per run, large runs first: n, p0, cnt, the first observation's index, the n <= 10 cameras -- everything the
+// workgroup's loads depend on in ONE record (chunk id -> chunk -> camera list -> tables was four dependent round trips)
+__global__ __launch_bounds__(256) void ba_backsub_runs(BaDev d, const int4* __restrict__ bs_desc, double radius, double lm_lo, double lm_hi,
+                                                      int split) {
+  __shared__ __attribute__((aligned(16))) double s_tab[10 * CAMD];  // the run's camera tables ...
+  __shared__ __attribute__((aligned(16))) double s_tabc[10 * 12];   // ... the candidates' R, t ...
+  __shared__ __attribute__((aligned(16))) double s_zs[10 * 12];     // ... and per camera: scale (6), step (6)
+  __shared__ __attribute__((aligned(16))) double2 s_xy[10 * BSR_PTS];
+  __shared__ double sh[4][4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int pt = tid;  // (a thread per point: every lane of a wave is at the same observation index, hence the same camera)
+  __shared__ int s_cams[12];
+  const int4* const rec = bs_desc + 4 * (size_t)(blockIdx.x / split);
+  const int4 hd = rec[0];  // n, p0, cnt, first observation
+  struct { int n, p0, cnt; } ch = {hd.x, hd.y, hd.z};
+  const int kobs0 = hd.w;
+  if (tid < 12) s_cams[tid] = ((const int*)(rec + 1))[tid];
+  const int part = blockIdx.x % split;
+  const int pt_lo = (int)((long long)ch.cnt * part / split), pt_hi = (int)((long long)ch.cnt * (part + 1) / split);
+  const int n = ch.n;
+  const double sf = *d.scale_f, focal = *d.focal, focal_c = *d.focal_c, zf = d.z[6 * d.nc];
+  __syncthreads();
+  for (int idx = tid; idx < n * CAMD; idx += 256) {
+    const int o = idx / CAMD, e = idx - o * CAMD;
+    s_tab[idx] = d.camd[(size_t)CAMD * s_cams[o] + e];
+    if (e < 12) s_tabc[o * 12 + e] = d.camd_c[(size_t)CAMD * s_cams[o] + e];
+  }
+  for (int idx = tid; idx < n * 12; idx += 256) {
+    const int o = idx / 12, e = idx - o * 12;
+    s_zs[idx] = e < 6 ? d.scale_c[6 * s_cams[o] + e] : d.z[6 * s_cams[o] + e - 6];
+  }
+  double mcc = 0, cost_c = 0, sn2 = 0, cn2 = 0;
+  for (int blk = pt_lo; blk < pt_hi; blk += BSR_PTS) {
+    const int npts = min(BSR_PTS, pt_hi - blk);
+    const bool active = pt < npts;
+    const int p = ch.p0 + blk + (active ? pt : 0);
+    // (the point, its scale and the block's observations are asked for together: one round trip, not three)
+    double X[3], sp[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) X[j] = d.pts[3 * p + j], sp[j] = d.scale_p[3 * p + j];
+    const double2* src = d.oxy + kobs0 + (size_t)blk * n;  // npts x n records, point-major: coalesced
+    double2 stage[10];
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+      const int e = tid + 256 * u;
+      stage[u] = e < npts * n ? src[e] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();  // (the previous block's observations are read)
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+      const int e = tid + 256 * u;
+      if (e < npts * n) {
+        const int pl = e / n, k = e - pl * n;
+        s_xy[k * BSR_PTS + pl] = stage[u];
+      }
+    }
+    __syncthreads();  // (and, the first time round, the tables are in)
+    double sm[BS_SUMS];  // C (6: 00 10 11 20 21 22), Jp^T r (3), Jp^T a (3), a.r, |a|^2 -- as in ba_backsub
+#pragma unroll
+    for (int e = 0; e < BS_SUMS; ++e) sm[e] = 0.0;
+    for (int k = 0; k < n; ++k) {
+      const double2 xy = s_xy[k * BSR_PTS + pt];
+      // (the same address for every lane: LDS broadcasts.  Scalar loads instead -- operands in SGPRs -- were measured slower here,
+      // 25.7 us against 21.0: K7)
+      const lds_double* const tab = (const lds_double*)s_tab + k * CAMD;
+      const lds_double* const zs = (const lds_double*)s_zs + k * 12;
+      ObsLin o;
+      obs_linearize_g(tab, X, focal, xy.x, xy.y, zs, sp, sf, o);
+      double a0 = -o.Jf[0] * zf, a1 = -o.Jf[1] * zf;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const double zj = zs[6 + j];
+        a0 -= o.Jc[j] * zj;
+        a1 -= o.Jc[6 + j] * zj;
+      }
+      sm[0] += o.Jp[0] * o.Jp[0] + o.Jp[3] * o.Jp[3];
+      sm[1] += o.Jp[1] * o.Jp[0] + o.Jp[4] * o.Jp[3];
+      sm[2] += o.Jp[1] * o.Jp[1] + o.Jp[4] * o.Jp[4];
+      sm[3] += o.Jp[2] * o.Jp[0] + o.Jp[5] * o.Jp[3];
+      sm[4] += o.Jp[2] * o.Jp[1] + o.Jp[5] * o.Jp[4];
+      sm[5] += o.Jp[2] * o.Jp[2] + o.Jp[5] * o.Jp[5];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        sm[6 + a] += o.Jp[a] * o.r0 + o.Jp[3 + a] * o.r1;
+        sm[9 + a] += o.Jp[a] * a0 + o.Jp[3 + a] * a1;
+      }
+      sm[12] += a0 * o.r0 + a1 * o.r1;
+      sm[13] += a0 * a0 + a1 * a1;
+    }
+    double C[6] = {sm[0], sm[1], sm[2], sm[3], sm[4], sm[5]};
+    const double* pr = sm + 6;
+    const double* pa = sm + 9;
+    const double ar = sm[12], aa = sm[13];
+    const double e3[3] = {pr[0] + pa[0], pr[1] + pa[1], pr[2] + pa[2]};
+    C[0] += fmin(fmax(C[0], lm_lo), lm_hi) / radius;
+    C[2] += fmin(fmax(C[2], lm_lo), lm_hi) / radius;
+    C[5] += fmin(fmax(C[5], lm_lo), lm_hi) / radius;
+    double Li[6];
+    if (!chol3_inv(C, Li)) Li[0] = Li[1] = Li[2] = Li[3] = Li[4] = Li[5] = 0;
+    const double t0 = Li[0] * e3[0], t1 = Li[1] * e3[0] + Li[2] * e3[1], t2 = Li[3] * e3[0] + Li[4] * e3[1] + Li[5] * e3[2];
+    const double stp[3] = {-(Li[0] * t0 + Li[1] * t1 + Li[3] * t2), -(Li[2] * t1 + Li[4] * t2), -(Li[5] * t2)};
+    double Xc[3];
+    const bool head = active;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double dl = stp[j] * sp[j];
+      Xc[j] = X[j] + dl;
+      if (head) {
+        d.pts_c[3 * p + j] = Xc[j];
+        sn2 += dl * dl;
+        cn2 += Xc[j] * Xc[j];
+      }
+    }
+    if (head) {
+      const double qd = stp[0] * (sm[0] * stp[0] + 2.0 * (sm[1] * stp[1] + sm[3] * stp[2])) +
+                        stp[1] * (sm[2] * stp[1] + 2.0 * sm[4] * stp[2]) + stp[2] * sm[5] * stp[2];
+      mcc += ar + (stp[0] * pr[0] + stp[1] * pr[1] + stp[2] * pr[2]) + 0.5 * aa + (stp[0] * pa[0] + stp[1] * pa[1] + stp[2] * pa[2]) + 0.5 * qd;
+    }
+    for (int k = 0; k < n; ++k) {
+      const double2 xy = s_xy[k * BSR_PTS + pt];
+      double r0, r1;
+      obs_residual((const lds_double*)s_tabc + k * 12, Xc, focal_c, xy.x, xy.y, r0, r1);
+      if (active) cost_c += r0 * r0 + r1 * r1;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mcc += __shfl_down(mcc, off);
+    cost_c += __shfl_down(cost_c, off);
+    sn2 += __shfl_down(sn2, off);
+    cn2 += __shfl_down(cn2, off);
+  }
+  if (lane == 0) {
+    sh[0][wave] = mcc;
+    sh[1][wave] = cost_c;
+    sh[2][wave] = sn2;
+    sh[3][wave] = cn2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* slot = d.red2 + 8 + 4 * (blockIdx.x % RED2_SLOTS);
+    atomic_add_f64(slot + 0, sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+    atomic_add_f64(slot + 1, sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
+    atomic_add_f64(slot + 2, sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3]);
+    atomic_add_f64(slot + 3, sh[3][0] + sh[3][1] + sh[3][2] + sh[3][3]);
+  }
+}
+
 __global__ void ba_cam_norm(BaDev d, const unsigned char* __restrict__ cam_used, double* out) {
   // ||x||^2 over used cameras + focal (single block)
   double s = 0;
@@ -2728,6 +2886,7 @@ struct sfmhip_ba {
   int2* d_pair_cams = nullptr;
   int2* d_pair_ent = nullptr;
   int n_pairs_pp = 0;
+  int* d_bs_ids = nullptr;  // ba_backsub_runs' records, 16 ints per chunk, large chunks first
   int elim_waves = 4;  // waves per workgroup of the long-run class of ba_eliminate_mfma (8, 4 or 2)
   // dissected reduced system (NdPlan below): built at the first solve (with world > 1 the camera graph is the
   // union over the ranks, which needs the all-reduce)
@@ -3355,6 +3514,20 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   SFM_HIP_TRY(up(b->d_cam_used, b->h_cam_used.data(), n_cam));
   SFM_HIP_TRY(up(b->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk)));
   b->n_chunks = (int)chunks.size();
+  if (!chunks.empty()) {
+    std::vector<int> all(chunks.size());
+    for (size_t i = 0; i < all.size(); ++i) all[i] = (int)i;
+    std::stable_sort(all.begin(), all.end(), [&](int a, int c) { return chunks[a].cnt > chunks[c].cnt; });
+    std::vector<int> desc(16 * all.size(), 0);
+    for (size_t i = 0; i < all.size(); ++i) {
+      const Chunk& c = chunks[all[i]];
+      int* r = &desc[16 * i];
+      r[0] = c.n, r[1] = c.p0, r[2] = c.cnt, r[3] = optr[c.p0];
+      for (int k = 0; k < c.n && k < 10; ++k) r[4 + k] = sig_cams[c.sig_off + k];
+    }
+    SFM_TRY(ba_alloc(b, &b->d_bs_ids, desc.size()));
+    SFM_HIP_TRY(hipMemcpy(b->d_bs_ids, desc.data(), desc.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   for (int m = 0; m < 2 && b->d_slab; ++m) {
     SFM_HIP_TRY(up(b->d_gth_ptr[m], gth_ptr[m].data(), gth_ptr[m].size() * 4));
     SFM_HIP_TRY(up(b->d_gth_src[m], gth_src[m].data(), gth_src[m].size() * 4));
@@ -4223,22 +4396,37 @@ static int ba_step_eval(sfmhip_ba* b, double radius, const sfmhip_ba_opts* o) {
   hipStream_t st = b->ctx->stream;
   BaDev& d = b->d;
   if (!b->tree_on) hipLaunchKernelGGL(ba_cand_cams, dim3((b->nc + 1 + 63) / 64), dim3(64), 0, st, d, b->d_cam_used, b->rank);
-  if (b->np)
-  {
+  int nbs = 0;
+  if (b->np) {
+    // the points in runs: a row of 16 lanes per point (ba_backsub_runs); the pair path's points (or, SFMHIP_BA_BACKSUB_RUNS=0,
+    // all of them): a thread per point
+    static const bool runs_env = !(getenv("SFMHIP_BA_BACKSUB_RUNS") && atoi(getenv("SFMHIP_BA_BACKSUB_RUNS")) == 0);
     static const int wpp_env = getenv("SFMHIP_BA_BACKSUB_WPP") ? atoi(getenv("SFMHIP_BA_BACKSUB_WPP")) : 2;  // (measurement)
-    const size_t nblk = ((size_t)b->np + 63) / 64;  // blocks of 64 points
-    if (wpp_env == 1)
-      hipLaunchKernelGGL(ba_backsub<1>, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, st, d, radius, o->min_lm_diagonal,
-                         o->max_lm_diagonal);
-    else if (wpp_env == 2)
-      hipLaunchKernelGGL(ba_backsub<2>, dim3((unsigned)((nblk + 1) / 2)), dim3(256), 0, st, d, radius, o->min_lm_diagonal,
-                         o->max_lm_diagonal);
-    else
-      hipLaunchKernelGGL(ba_backsub<4>, dim3((unsigned)nblk), dim3(256), 0, st, d, radius, o->min_lm_diagonal,
-                         o->max_lm_diagonal);
+    const bool runs = runs_env && b->n_chunks > 0 && b->d_bs_ids;
+    if (runs) {
+      static const int split_env = getenv("SFMHIP_BA_BACKSUB_SPLIT") ? std::max(1, atoi(getenv("SFMHIP_BA_BACKSUB_SPLIT"))) : 1;  // (measured at cfg4: 21.0 us / 33 / 53 for 1 / 2 / 4 workgroups per run)
+      hipLaunchKernelGGL(ba_backsub_runs, dim3(b->n_chunks * split_env), dim3(256), 0, st, d, (const int4*)b->d_bs_ids, radius,
+                         o->min_lm_diagonal, o->max_lm_diagonal, split_env);
+      ++nbs;
+    }
+    const int* plist = runs ? b->d_fb_points : nullptr;
+    const int npl = runs ? b->n_fb : b->np;
+    if (npl > 0) {
+      const size_t nblk = ((size_t)npl + 63) / 64;  // blocks of 64 points
+      if (wpp_env == 1)
+        hipLaunchKernelGGL(ba_backsub<1>, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, st, d, radius, o->min_lm_diagonal,
+                           o->max_lm_diagonal, plist, npl);
+      else if (wpp_env == 2)
+        hipLaunchKernelGGL(ba_backsub<2>, dim3((unsigned)((nblk + 1) / 2)), dim3(256), 0, st, d, radius, o->min_lm_diagonal,
+                           o->max_lm_diagonal, plist, npl);
+      else
+        hipLaunchKernelGGL(ba_backsub<4>, dim3((unsigned)nblk), dim3(256), 0, st, d, radius, o->min_lm_diagonal,
+                           o->max_lm_diagonal, plist, npl);
+      ++nbs;
+    }
   }
   SFM_HIP_TRY(hipGetLastError());
-  b->launches += b->tree_on ? 1 : 2;
+  b->launches += (b->tree_on ? 0 : 1) + nbs;
   SFM_TRY(ba_allreduce(b, d.red2, RED2_SUM_N));
   return SFMHIP_OK;
 }
