@@ -154,6 +154,20 @@ def main():
     for _ in range(max(args.warmup, 1)):
         match_step()
     barrier()
+    # the measured ceiling of THIS box, right before the timed region: bare i8 MFMAs on random operands for 50 ms (the chip
+    # lowers its clock under matrix load; the nominal 5 POP/s assumes 2.4 GHz), and the shader clock while the sweep itself
+    # runs (a one-wave sampler on the second stream beside 30 single-stream sweeps)
+    sustained_peak_ops, sustained_peak_ghz = ctx.probe_i8_mfma_peak(0.05)
+    for _ in range(10):
+        match_step(one_stream=True)
+    torch.cuda.synchronize(dev)
+    ctxs[1].probe_clock_start(0.012)
+    for _ in range(30):
+        match_step(one_stream=True)
+    sweep_clock_ghz = ctxs[1].probe_clock_read()
+    for _ in range(max(args.warmup, 1)):
+        match_step()
+    barrier()
 
     # ------------------------------------------------------------------ timed: matching, K steps
     knn_s = prep_s = comp_s = 0.0
@@ -243,7 +257,7 @@ def main():
     ba_t0 = ba.last_timing()
     ba.iterate(args.steps)
     ba_t = {k: v - ba_t0[k] for k, v in ba.last_timing().items()}
-    ba_layout = ba.reduced_layout()
+    ba_layout = dict(ba.reduced_layout(), front_tree=ba.reduced_tree())
     ctx.set_timing(False)
     barrier()
     # sustained BA rate: every ba.iterate issues all-reduces, so the number of batches must be THE SAME on every rank --
@@ -339,11 +353,20 @@ def main():
                 part = np.array([np.sum([g[0] for g in gathered], dtype=np.uint64),
                                  np.bitwise_xor.reduce(np.array([g[1] for g in gathered], np.uint64)),
                                  np.sum([g[2] for g in gathered], dtype=np.uint64)], np.uint64)
+        # every pair of this rank against the oracle's answer (tests/golden/cfg5_checksums.npz: the C restatement's match count
+        # and [sum, xor] of the match mix per pair, generated once by tests/golden/make_cfg5_checksums.py -- data, not code)
+        gold = np.load(os.path.join(ROOT, "tests", "golden", "cfg5_checksums.npz"))
+        idx = np.asarray(shards[rank])
+        cfg5_ok = bool(np.array_equal(o_cnt, gold["counts"][idx]) and np.array_equal(cs, gold["checksums"][idx]))
+        assert cfg5_ok, "cfg5: the device's match lists differ from the oracle's (per-pair counts / checksums)"
         cfg5 = {"workload": "cfg5: 500 img x 5000 ORB-256, all 124750 pairs, Hamming; pairs dealt over the ranks "
                             "(sharding.shard_pairs), descriptors resident on every rank",
                 "pairs": int(len(o_pairs)), "pairs_this_rank": int(len(mine)), "seconds_per_sweep": round(t_cfg5, 5),
                 "pairs_per_s": round(len(o_pairs) / t_cfg5, 1), "scaling": "strong", "matches": int(part[2]),
-                "checksum": [int(part[0]), int(part[1])]}
+                "checksum": [int(part[0]), int(part[1])],
+                "oracle_checked_pairs": int(len(o_pairs)), "oracle_match": cfg5_ok,
+                "oracle": "every pair's count and checksum equal the C restatement's (tests/golden/cfg5_checksums.npz); "
+                          "on N > 1 every rank asserts its own share"}
         o_plan.close()
         o_set.close()
         del o_dev
@@ -447,6 +470,13 @@ def main():
                           "value-only slot / tile-maximum epilogue, exact resolve of the candidates)", "bound": "mfma",
                 "achieved": round(knn_tops, 2), "peak": I8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
                 "frac": round(knn_tops / I8_DENSE_PEAK_TOPS, 4), "traffic": hbm_bytes("knn_kernel"),
+                "sustained_peak": round(sustained_peak_ops / 1e12, 1), "sustained_peak_clock_ghz": round(sustained_peak_ghz, 3),
+                "frac_of_sustained": round(knn_tops / max(sustained_peak_ops / 1e12, 1e-9), 4),
+                "sweep_clock_ghz": round(sweep_clock_ghz, 3),
+                "sustained_note": "sustained_peak = what this box held for bare v_mfma_i32_32x32x32_i8 on random operands, every "
+                                  "SIMD busy, 50 ms, measured right before the timed region (csrc/probe.hip); sweep_clock_ghz = the "
+                                  "shader clock while the sweep ran (s_memtime / s_memrealtime of a one-wave sampler on the "
+                                  "second stream); frac stays against the nominal 5 POP/s",
                 "f32_equivalent_frac": round(knn_tops / F32_MFMA_PEAK_TFLOPS, 3),
                 "valu_epilogue": {"achieved": round(valu_tlops, 2), "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
                                   "frac": round(valu_tlops / VALU_PEAK_TLANEOPS, 4),
@@ -478,9 +508,9 @@ def main():
                    "launches_per_iter": round(ba_t["launches"] / max(args.steps, 1), 1),
                    "reduced_layout": ba_layout,
                    "note": "instruction-issue / latency-bound in the per-point linearisation; the reduced system is factored "
-                           "as independent chains of the dissected camera graph + separator (reduced_layout: tiles of 32 "
-                           "columns; the dependency chain is chain_tiles + separator_tiles instead of dense_tiles; "
-                           "DESIGN.md section 3)"}
+                           "as a tree of fronts of the recursively dissected camera graph, one workgroup per front "
+                           "(reduced_layout.front_tree: the dependency chain is chain_tiles tile steps of 32 columns instead "
+                           "of dense_tiles), or, where no such tree exists, as chains + separator / dense; DESIGN.md section 3"}
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only)
     cpu_baseline = None

@@ -68,6 +68,16 @@ void* sfmhip_stream(sfmhip_ctx* ctx);
  * records between the stages of a run cost ~5-10 us of stream bubble each (3-4 % of a cfg2 sweep
  * or a cfg4 LM iteration).  Off by default; while off the *_last_timing calls report zeros. */
 int sfmhip_set_timing(sfmhip_ctx* ctx, int enable);
+/* Measurement probes (csrc/probe.hip; bench.py runs them on the box it benches, nothing on the product path calls them).
+ * sfmhip_probe_i8_mfma_peak: what the chip sustains for bare v_mfma_i32_32x32x32_i8 on random operands, every SIMD busy, for
+ * `seconds` (one launch): multiply-add operations per second (2 per MAC) and the shader clock that launch held -- the ceiling
+ * to read the k-NN sweep's roofline fraction against, next to the nominal peak.  sfmhip_probe_clock_start / _read: a
+ * one-wave kernel on THIS context's stream that watches the shader and the 100 MHz counters for `seconds` while the caller runs
+ * the load to be qualified on another stream; _read waits for it and returns the shader clock in GHz.  Qualify the matcher
+ * behind cv::BFMatcher::knnMatch, reference src/Sfm.cpp:593-599. */
+int sfmhip_probe_i8_mfma_peak(sfmhip_ctx* ctx, double seconds, double* ops_per_s, double* shader_ghz);
+int sfmhip_probe_clock_start(sfmhip_ctx* ctx, double seconds);
+int sfmhip_probe_clock_read(sfmhip_ctx* ctx, double* shader_ghz);
 const char* sfmhip_error_string(int status);
 int sfmhip_last_hip_error(void);
 int sfmhip_version(void);

@@ -47,7 +47,7 @@ SYMBOLS = [
     "sfmhip_matchplan_destroy",
     "sfmhip_triangulate", "sfmhip_find_2d3d", "sfmhip_merge_new_points", "sfmhip_ba_default_opts", "sfmhip_ba_solve", "sfmhip_ba_create",
     "sfmhip_ba_set_allreduce", "sfmhip_ba_set_params", "sfmhip_ba_get_params", "sfmhip_ba_run",
-    "sfmhip_ba_iterate", "sfmhip_ba_reduced_system", "sfmhip_ba_linearize_obs", "sfmhip_ba_last_timing", "sfmhip_ba_reduced_layout", "sfmhip_ba_reduced_tree", "sfmhip_ba_reduced_step", "sfmhip_score_essential", "sfmhip_score_last_flags", "sfmhip_score_five_point", "sfmhip_score_homography_kernel", "sfmhip_score_homography", "sfmhip_sift_detect_and_compute", "sfmhip_sift_detect_and_compute_device", "sfmhip_sift_batch", "sfmhip_device_free", "sfmhip_host_free", "sfmhip_device_download", "sfmhip_ba_destroy",
+    "sfmhip_ba_iterate", "sfmhip_ba_reduced_system", "sfmhip_ba_linearize_obs", "sfmhip_ba_last_timing", "sfmhip_ba_reduced_layout", "sfmhip_ba_reduced_tree", "sfmhip_probe_i8_mfma_peak", "sfmhip_probe_clock_start", "sfmhip_probe_clock_read", "sfmhip_ba_reduced_step", "sfmhip_score_essential", "sfmhip_score_last_flags", "sfmhip_score_five_point", "sfmhip_score_homography_kernel", "sfmhip_score_homography", "sfmhip_sift_detect_and_compute", "sfmhip_sift_detect_and_compute_device", "sfmhip_sift_batch", "sfmhip_device_free", "sfmhip_host_free", "sfmhip_device_download", "sfmhip_ba_destroy",
 ]
 
 _lib = None
@@ -109,6 +109,9 @@ def lib():
         L.sfmhip_ba_last_timing.argtypes = [vp, vp, vp]
         L.sfmhip_ba_reduced_layout.argtypes = [vp, vp]
         L.sfmhip_ba_reduced_tree.argtypes = [vp, vp]
+        L.sfmhip_probe_i8_mfma_peak.argtypes = [vp, C.c_double, vp, vp]
+        L.sfmhip_probe_clock_start.argtypes = [vp, C.c_double]
+        L.sfmhip_probe_clock_read.argtypes = [vp, vp]
         L.sfmhip_score_essential.argtypes = [vp, cint, vp, vp, vp, f64, f64, f64, f64, f64, f64, vp, vp, vp]
         L.sfmhip_score_last_flags.argtypes = [vp]
         L.sfmhip_score_five_point.argtypes = [vp, cint, vp, vp, vp, vp]
@@ -153,6 +156,22 @@ class Context:
         """Record hipEvents between the stages of a run (MatchPlan.last_timing / BaProblem.last_timing);
         off by default: each event costs a few microseconds of stream bubble."""
         check(lib().sfmhip_set_timing(self.h, int(bool(enable))), "sfmhip_set_timing")
+
+    def probe_i8_mfma_peak(self, seconds=0.05):
+        """(operations/s, shader GHz) the chip sustains for bare i8 MFMAs on random operands (sfmhip_probe_i8_mfma_peak):
+        the measured ceiling bench.py prints next to the nominal one."""
+        ops, ghz = C.c_double(0.0), C.c_double(0.0)
+        check(lib().sfmhip_probe_i8_mfma_peak(self.h, float(seconds), C.addressof(ops), C.addressof(ghz)), "sfmhip_probe_i8_mfma_peak")
+        return ops.value, ghz.value
+
+    def probe_clock_start(self, seconds):
+        """A one-wave sampler on THIS context's stream for `seconds`; run the load to be qualified on another stream."""
+        check(lib().sfmhip_probe_clock_start(self.h, float(seconds)), "sfmhip_probe_clock_start")
+
+    def probe_clock_read(self):
+        ghz = C.c_double(0.0)
+        check(lib().sfmhip_probe_clock_read(self.h, C.addressof(ghz)), "sfmhip_probe_clock_read")
+        return ghz.value
 
     def close(self):
         if self.h:

@@ -14,7 +14,7 @@ SO = os.path.join(HERE, "libsfmhip.so")
 # OpenCV's operation order (no compiler-chosen FMAs); the BA kernels are tolerance-level f64
 # and want v_fma_f64
 SOURCES = {"context.hip": "off", "match.hip": "off", "triangulate.hip": "off", "incremental.hip": "off",
-           "score.hip": "off", "sift.hip": "off", "ba.hip": "fast"}
+           "score.hip": "off", "sift.hip": "off", "ba.hip": "fast", "probe.hip": "off"}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
 
 

@@ -224,6 +224,24 @@ def test_cfg5_orb_shard_properties(ctx, orc):
     print(f"[cfg5 shard] {len(mine)} pairs incl. upload + first run: {dt:.2f} s")
 
 
+def test_cfg5_every_pair_against_the_oracle(ctx, golden):
+    """BASELINE cfg5 at full size, ALL 124 750 pairs of the 500 x 5000 x ORB-256 set under Hamming k-NN-2 + ratio, against
+    the C restatement's answer for every single pair: match count and [sum, xor] of the match mix (queryIdx, trainIdx,
+    distance bits).  The oracle's side was computed once in the build container (tests/golden/make_cfg5_checksums.py,
+    half an hour on 8 cores) and is committed as data; the device's side is one sweep."""
+    gold = golden["cfg5_checksums"]
+    imgs = synth.orb_image_set()
+    pairs = synth.all_pairs(len(imgs))
+    assert len(pairs) == 124750 == len(gold["counts"])
+    s, pl = _plan(ctx, imgs, pairs, _lib.HAMMING)
+    cnt, oq, ot, od = pl.fetch()
+    cs = synth.pair_checksums(cnt, oq, ot, od)
+    assert np.array_equal(cnt, gold["counts"])
+    bad = np.nonzero(np.any(cs != gold["checksums"], axis=1))[0]
+    assert len(bad) == 0, f"{len(bad)} pairs differ, first {bad[:5]}"
+    assert int(cnt.sum()) == int(gold["counts"].sum())
+
+
 @pytest.mark.parametrize("nq,nt,levels,seed", [(300, 700, 1, 1), (65, 513, 2, 2), (1000, 1031, 3, 3)])
 def test_heavy_ties_across_tiles_and_chunks(ctx, orc, nq, nt, levels, seed):
     """Rows from very few distinct values: thousands of exact distance ties per query, spread over
