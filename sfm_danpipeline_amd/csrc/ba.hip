@@ -3237,7 +3237,14 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   std::vector<int> gth_ptr[2], gth_dest[2], grow_ptr, grow_id, grow_colmap;
   std::vector<unsigned> gth_src[2];
   std::vector<int4> grow_src, grow_hdr, grow_head, grow_over;
-  if (b->elim_deterministic && !chunks.empty() && chunks.size() * (size_t)ELIM_SLAB < ((size_t)1 << 31)) {
+  if (b->elim_deterministic && chunks.size() * (size_t)ELIM_SLAB >= ((size_t)1 << 31)) {
+    // the gather lists address a slab entry with 31 bits (bit 31 carries the sign): past ~740 000 chunks the elimination goes
+    // back to the atomic epilogue -- said out loud, because the sums are then no longer the same bit patterns run after run
+    fprintf(stderr, "sfmhip_ba: %zu chunks exceed the slab epilogue's 31-bit offsets; atomic epilogue (not run-to-run identical)\n",
+            chunks.size());
+    b->elim_deterministic = false;
+  }
+  if (b->elim_deterministic && !chunks.empty()) {
     const int ld = b->ld, fo = 6 * n_cam;
     const long long ssz = (long long)b->ssz, o_g = ssz, o_gF = ssz + ld, o_dc = ssz + 2LL * ld, o_sc = ssz + 3LL * ld;
     std::vector<std::pair<long long, unsigned>> ent[2];  // (destination, source | sign)

@@ -262,23 +262,38 @@ void StructFromMotion::matchAllPairs() {
   const int batch = std::max(64, (n_pairs + 7) / 8);
   const int n_batches = (n_pairs + batch - 1) / batch;
   sfmhip_matchplan* plans[2] = {nullptr, nullptr};
+  // Pinned memory is bounded: each of the four buffers (two plans, two slots) holds at most kPipeBytes of {q, t, dist}
+  // records, sized for a quarter of the batch's query rows surviving the ratio test.  A batch with more matches than that,
+  // or a host that will not pin the buffers at all, takes the copying fetch for that batch -- slower, never wrong.
+  const int64_t kPipeBytes = (int64_t)256 << 20;
+  int maxRows = 0;
+  for (int r : rows) maxRows = std::max(maxRows, r);
+  const int64_t pipeCapacity = std::max<int64_t>(4096, std::min<int64_t>((int64_t)batch * maxRows / 4, kPipeBytes / 12));
+  bool piped = true;
+  auto collectCopying = [&](int b) -> int {
+    const int first = b * batch, np = std::min(batch, n_pairs - first);
+    std::vector<int32_t> c(np);
+    int64_t total = 0;
+    int r = sfmhip_matchplan_fetch(plans[b & 1], c.data(), nullptr, nullptr, nullptr, 0, &total);  // (counts first: the sizes)
+    if (r != SFMHIP_OK) return r;
+    std::vector<int32_t> q((size_t)total + 1), t((size_t)total + 1);
+    std::vector<float> d((size_t)total + 1);
+    r = sfmhip_matchplan_fetch(plans[b & 1], c.data(), q.data(), t.data(), d.data(), total, &total);
+    size_t off = 0;
+    for (int p = 0; r == SFMHIP_OK && p < np; ++p) {
+      Matching& m = pairCache[std::make_pair((int)pairs[2 * (first + p)], (int)pairs[2 * (first + p) + 1])];
+      m.reserve((size_t)c[p]);
+      for (int i = 0; i < c[p]; ++i, ++off) m.push_back(cv::DMatch(q[off], t[off], d[off]));
+    }
+    return r;
+  };
   auto collect = [&](int b) -> int {  // batch b's lists -> pairCache
+    if (!piped) return collectCopying(b);
     const int32_t *cnt = nullptr, *oq = nullptr, *ot = nullptr;
     const float* od = nullptr;
     int64_t total = 0;
     int r = sfmhip_matchplan_fetch_wait(plans[b & 1], 0, &cnt, &oq, &ot, &od, &total);
-    if (r == SFMHIP_ERR_ALLOC) {  // more matches than the pinned buffers hold: the copying fetch has no such limit
-      const int first = b * batch, np = std::min(batch, n_pairs - first);
-      std::vector<int32_t> c(np), q((size_t)total + 1), t((size_t)total + 1);
-      std::vector<float> d((size_t)total + 1);
-      r = sfmhip_matchplan_fetch(plans[b & 1], c.data(), q.data(), t.data(), d.data(), total, &total);
-      size_t off = 0;
-      for (int p = 0; r == SFMHIP_OK && p < np; ++p) {
-        Matching& m = pairCache[std::make_pair((int)pairs[2 * (first + p)], (int)pairs[2 * (first + p) + 1])];
-        for (int i = 0; i < c[p]; ++i, ++off) m.push_back(cv::DMatch(q[off], t[off], d[off]));
-      }
-      return r;
-    }
+    if (r == SFMHIP_ERR_ALLOC) return collectCopying(b);  // more matches than a pinned buffer holds
     if (r != SFMHIP_OK) return r;
     const int first = b * batch, np = std::min(batch, n_pairs - first);
     size_t off = 0;
@@ -294,7 +309,13 @@ void StructFromMotion::matchAllPairs() {
     sfmhip_matchplan*& pl = plans[b & 1];
     if (!pl) {
       rc = sfmhip_matchplan_create(set, pairs.data() + 2 * first, np, &pl);
-      if (rc == SFMHIP_OK) rc = sfmhip_matchplan_pipeline(pl, 0);
+      if (rc == SFMHIP_OK && piped && sfmhip_matchplan_pipeline(pl, pipeCapacity) != SFMHIP_OK) {
+        // no pinned memory to be had: the pass goes on without the overlap
+        std::cerr << "matchAllPairs: pinned buffers refused (" << pipeCapacity * 12 << " bytes each); copying fetch" << std::endl;
+        piped = false;
+        for (sfmhip_matchplan* q : plans)
+          if (q) sfmhip_matchplan_pipeline(q, -1);
+      }
     } else {
       rc = sfmhip_matchplan_set_pairs(pl, pairs.data() + 2 * first, np);  // (np <= the batch it was created with)
     }

@@ -345,7 +345,8 @@ bool read_file(const std::string& path, std::vector<uint8_t>& out) {
 // intervals), decoded the way libjpeg (which cv::imread calls with its defaults) decodes it: dequantisation in natural
 // order, the accurate integer inverse DCT (jidctint.c "islow": 13-bit constants, PASS1_BITS 2, range-limit table), "fancy"
 // triangle-filter upsampling of 2:1 subsampled chroma (jdsample.c: h2v1 (3 a + b + 1|2) >> 2, h2v2 (3 (3 a + b) + (3 c + d)
-// + 8|7) >> 4, edge rows / columns replicated), YCbCr -> RGB with the 16-bit fixed-point tables of jdcolor.c.  Checked
+// + 8|7) >> 4, h1v2 (3 a + b + 1|2) >> 2 down the columns, edge rows / columns replicated), scans interleaved or one per
+// component, 0xFF fill bytes before markers, YCbCr -> RGB with the 16-bit fixed-point tables of jdcolor.c.  Checked
 // against PIL's decoder (libjpeg-turbo, same algorithms) on generated files (tests/test_host_io.py).  Not decoded:
 // progressive (SOF2), arithmetic coding, 12 bit, CMYK -- the load fails with a message, as cv::imread would return an
 // empty Mat for a file its libjpeg cannot read.
@@ -379,6 +380,7 @@ struct JpegBits {
       if (!hit_marker && pos < n) {
         b = p[pos];
         if (b == 0xFF) {
+          while (pos + 1 < n && p[pos + 1] == 0xFF) ++pos;  // fill bytes: any run of 0xFF may precede a marker (T.81 B.1.1.2)
           const int b2 = pos + 1 < n ? p[pos + 1] : 0xD9;
           if (b2 == 0) pos += 2;          // stuffed zero
           else { hit_marker = true; b = 0; }  // a marker: feed zeros (libjpeg does the same past the data)
@@ -526,12 +528,13 @@ bool decode_jpeg(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) 
     int id, h, v, tq, td, ta;
     int bw, bh;  // blocks per row / column of the padded plane
     int dw, dhh; // downsampled_width / height (true sizes)
+    bool coded = false;  // a scan has carried this component
     std::vector<uint8_t> plane;
   } comp[3];
   int ncomp = 0, width = 0, height = 0, restart = 0, adobe_transform = -1;
-  bool have_sof = false;
+  int hmax = 1, vmax = 1, n_scans = 0;
+  bool have_sof = false, planes_ready = false;
   size_t pos = 2;
-  size_t scan_at = 0;
   while (pos + 4 <= f.size()) {
     if (f[pos] != 0xFF) {
       why = "corrupt JPEG (marker expected)";
@@ -591,6 +594,10 @@ bool decode_jpeg(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) 
         h.present = true;
       }
     } else if (mk == 0xC0 || mk == 0xC1) {  // SOF0 / SOF1
+      if (have_sof) {
+        why = "corrupt JPEG (second frame header)";
+        return false;
+      }
       if (dl < 6 || d[0] != 8) {
         why = "unsupported JPEG sample precision";
         return false;
@@ -620,19 +627,25 @@ bool decode_jpeg(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) 
       if (dl >= 2) restart = (d[0] << 8) | d[1];
     } else if (mk == 0xEE) {
       if (dl >= 12 && !memcmp(d, "Adobe", 5)) adobe_transform = d[11];
-    } else if (mk == 0xDA) {  // SOS: one interleaved scan over all components is what the encoder of such files writes
-      if (!have_sof || dl < 1 || d[0] != ncomp || dl < 1 + 2 * (size_t)ncomp + 3) {
+    } else if (mk == 0xDA) {
+      // SOS.  A baseline file is one interleaved scan over all components (what cv::imwrite and cameras write) or several
+      // scans of fewer components each (jpegtran -scans, some scanners): a scan of ONE component is not interleaved -- its
+      // MCU is a single block and the block grid is the component's own ceil(size / 8), not the frame's MCU grid (T.81 A.2.2).
+      const int ns = dl >= 1 ? d[0] : 0;
+      if (!have_sof || ns < 1 || ns > ncomp || dl < 1 + 2 * (size_t)ns + 3) {
         why = "unsupported JPEG scan layout";
         return false;
       }
-      for (int k = 0; k < ncomp; ++k) {
+      int sc[3];
+      for (int k = 0; k < ns; ++k) {
         int c = -1;
         for (int j = 0; j < ncomp; ++j)
           if (comp[j].id == d[1 + 2 * k]) c = j;
-        if (c != k) {
+        if (c < 0 || (k > 0 && c <= sc[k - 1]) || comp[c].coded) {  // (frame order, every component coded once: a sequential file)
           why = "unsupported JPEG scan layout";
           return false;
         }
+        sc[k] = c;
         comp[c].td = d[2 + 2 * k] >> 4;
         comp[c].ta = d[2 + 2 * k] & 15;
         if (comp[c].td > 3 || comp[c].ta > 3 || !hdc[comp[c].td].present || !hac[comp[c].ta].present || !qt_set[comp[c].tq]) {
@@ -640,83 +653,100 @@ bool decode_jpeg(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) 
           return false;
         }
       }
-      scan_at = pos + 2 + len;
-      break;
+      if (!planes_ready) {
+        if ((size_t)width * height > ((size_t)1 << 28)) {
+          why = "image too large";
+          return false;
+        }
+        for (int c = 0; c < ncomp; ++c) hmax = std::max(hmax, comp[c].h), vmax = std::max(vmax, comp[c].v);
+        if (ncomp == 1) comp[0].h = comp[0].v = hmax = vmax = 1;  // (a single-component frame: 1 x 1 blocks)
+        const int fx = (width + 8 * hmax - 1) / (8 * hmax), fy = (height + 8 * vmax - 1) / (8 * vmax);
+        for (int c = 0; c < ncomp; ++c) {
+          comp[c].bw = fx * comp[c].h;
+          comp[c].bh = fy * comp[c].v;
+          comp[c].dw = (width * comp[c].h + hmax - 1) / hmax;
+          comp[c].dhh = (height * comp[c].v + vmax - 1) / vmax;
+          // (blocks no scan reaches stay at the level shift, as libjpeg's zeroed coefficient arrays decode)
+          comp[c].plane.assign((size_t)comp[c].bw * 8 * comp[c].bh * 8, 128);
+        }
+        planes_ready = true;
+      }
+      const bool inter = ns > 1;
+      const int mcux = inter ? (width + 8 * hmax - 1) / (8 * hmax) : (comp[sc[0]].dw + 7) / 8;
+      const int mcuy = inter ? (height + 8 * vmax - 1) / (8 * vmax) : (comp[sc[0]].dhh + 7) / 8;
+      // ---- entropy-coded data: MCU by MCU
+      JpegBits br{f.data(), f.size(), pos + 2 + len};
+      int pred[3] = {0, 0, 0}, until_restart = restart;
+      for (int my = 0; my < mcuy; ++my)
+        for (int mx = 0; mx < mcux; ++mx) {
+          if (restart && until_restart == 0) {
+            // byte-align, expect RSTn
+            br.reset();
+            while (br.pos + 1 < f.size() && !(f[br.pos] == 0xFF && f[br.pos + 1] >= 0xD0 && f[br.pos + 1] <= 0xD7)) ++br.pos;
+            br.pos += 2;
+            pred[0] = pred[1] = pred[2] = 0;
+            until_restart = restart;
+          }
+          for (int k = 0; k < ns; ++k) {
+            const int c = sc[k];
+            const int nbx = inter ? comp[c].h : 1, nby = inter ? comp[c].v : 1;
+            for (int by = 0; by < nby; ++by)
+              for (int bx = 0; bx < nbx; ++bx) {
+                int blk[64];
+                memset(blk, 0, sizeof blk);
+                const int t = br.decode(hdc[comp[c].td]);
+                if (t < 0 || t > 11) {
+                  why = "corrupt JPEG data (DC code)";
+                  return false;
+                }
+                const int diff = t ? jpeg_extend(br.get(t), t) : 0;
+                pred[c] = std::max(-(1 << 20), std::min(1 << 20, pred[c] + diff));  // (a corrupt stream must not overflow; real DC values fit 12 bits)
+                blk[0] = (int)std::max(-(1L << 26), std::min(1L << 26, (long)pred[c] * qt[comp[c].tq][0]));
+                for (int kk = 1; kk < 64;) {
+                  const int rs = br.decode(hac[comp[c].ta]);
+                  if (rs < 0) {
+                    why = "corrupt JPEG data (AC code)";
+                    return false;
+                  }
+                  const int r = rs >> 4, sz = rs & 15;
+                  if (sz == 0) {
+                    if (r != 15) break;  // EOB
+                    kk += 16;
+                    continue;
+                  }
+                  kk += r;
+                  if (kk > 63) {
+                    why = "corrupt JPEG data (run past the block)";
+                    return false;
+                  }
+                  blk[zz[kk]] = (int)std::max(-(1L << 26), std::min(1L << 26, (long)jpeg_extend(br.get(sz), sz) * qt[comp[c].tq][zz[kk]]));
+                  ++kk;
+                }
+                const int px = (mx * nbx + bx) * 8, py = (my * nby + by) * 8;
+                jpeg_idct_islow(blk, &comp[c].plane[(size_t)py * comp[c].bw * 8 + px], comp[c].bw * 8);
+              }
+          }
+          if (restart) --until_restart;
+        }
+      for (int k = 0; k < ns; ++k) comp[sc[k]].coded = true;
+      ++n_scans;
+      // the next marker: the reader never steps over one, so it lies at or behind its position
+      pos = br.pos;
+      while (pos + 1 < f.size() && !(f[pos] == 0xFF && f[pos + 1] != 0 && f[pos + 1] != 0xFF && !(f[pos + 1] >= 0xD0 && f[pos + 1] <= 0xD7))) ++pos;
+      bool all = true;
+      for (int c = 0; c < ncomp; ++c) all = all && comp[c].coded;
+      if (all) break;
+      continue;
     } else if (mk == 0xD9) {
       break;
     }
     pos += 2 + len;
   }
-  if (!scan_at) {
+  if (!n_scans) {
     why = "JPEG without a scan";
     return false;
   }
-  if ((size_t)width * height > ((size_t)1 << 28)) {
-    why = "image too large";
-    return false;
-  }
-  int hmax = 1, vmax = 1;
-  for (int c = 0; c < ncomp; ++c) hmax = std::max(hmax, comp[c].h), vmax = std::max(vmax, comp[c].v);
-  if (ncomp == 1) comp[0].h = comp[0].v = hmax = vmax = 1;  // (a single-component scan is not interleaved: 1 x 1 blocks)
-  const int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
-  for (int c = 0; c < ncomp; ++c) {
-    comp[c].bw = mcux * comp[c].h;
-    comp[c].bh = mcuy * comp[c].v;
-    comp[c].dw = (width * comp[c].h + hmax - 1) / hmax;
-    comp[c].dhh = (height * comp[c].v + vmax - 1) / vmax;
-    comp[c].plane.assign((size_t)comp[c].bw * 8 * comp[c].bh * 8, 0);
-  }
-  // ---- entropy-coded data: MCU by MCU
-  JpegBits br{f.data(), f.size(), scan_at};
-  int pred[3] = {0, 0, 0}, until_restart = restart;
-  for (int my = 0; my < mcuy; ++my)
-    for (int mx = 0; mx < mcux; ++mx) {
-      if (restart && until_restart == 0) {
-        // byte-align, expect RSTn
-        br.reset();
-        while (br.pos + 1 < f.size() && !(f[br.pos] == 0xFF && f[br.pos + 1] >= 0xD0 && f[br.pos + 1] <= 0xD7)) ++br.pos;
-        br.pos += 2;
-        pred[0] = pred[1] = pred[2] = 0;
-        until_restart = restart;
-      }
-      for (int c = 0; c < ncomp; ++c)
-        for (int by = 0; by < comp[c].v; ++by)
-          for (int bx = 0; bx < comp[c].h; ++bx) {
-            int blk[64];
-            memset(blk, 0, sizeof blk);
-            const int t = br.decode(hdc[comp[c].td]);
-            if (t < 0 || t > 11) {
-              why = "corrupt JPEG data (DC code)";
-              return false;
-            }
-            const int diff = t ? jpeg_extend(br.get(t), t) : 0;
-            pred[c] = std::max(-(1 << 20), std::min(1 << 20, pred[c] + diff));  // (a corrupt stream must not overflow; real DC values fit 12 bits)
-            blk[0] = (int)std::max(-(1L << 26), std::min(1L << 26, (long)pred[c] * qt[comp[c].tq][0]));
-            for (int k = 1; k < 64;) {
-              const int rs = br.decode(hac[comp[c].ta]);
-              if (rs < 0) {
-                why = "corrupt JPEG data (AC code)";
-                return false;
-              }
-              const int r = rs >> 4, sz = rs & 15;
-              if (sz == 0) {
-                if (r != 15) break;  // EOB
-                k += 16;
-                continue;
-              }
-              k += r;
-              if (k > 63) {
-                why = "corrupt JPEG data (run past the block)";
-                return false;
-              }
-              blk[zz[k]] = (int)std::max(-(1L << 26), std::min(1L << 26, (long)jpeg_extend(br.get(sz), sz) * qt[comp[c].tq][zz[k]]));
-              ++k;
-            }
-            const int px = (mx * comp[c].h + bx) * 8, py = (my * comp[c].v + by) * 8;
-            jpeg_idct_islow(blk, &comp[c].plane[(size_t)py * comp[c].bw * 8 + px], comp[c].bw * 8);
-          }
-      if (restart) --until_restart;
-    }
+  // (a file that ends before every component was coded decodes like libjpeg's premature-EOI case: what is missing is gray)
   // ---- upsampling (jdsample.c) to full resolution planes of width x height
   std::vector<uint8_t> full[3];
   for (int c = 0; c < ncomp; ++c) {
@@ -752,7 +782,15 @@ bool decode_jpeg(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) 
             else o[x] = (uint8_t)((cur * 3 + (in0[i + 1] * 3 + in1[i + 1]) + 7) >> 4);
           }
         }
-      } else {  // replication (h1v2, or a component too narrow for the triangle filter)
+      } else if (hs == 1 && vs == 2) {
+        // h1v2 (a 4:2:2 frame turned by 90 degrees): libjpeg-turbo's h1v2_fancy_upsample, the triangle filter down the
+        // columns -- 3/4 of the nearer row, 1/4 of the farther one, rounding bias 1 above and 2 below; no width condition
+        const int iy = y >> 1, ny = (y & 1) ? std::min(iy + 1, Hh - 1) : std::max(iy - 1, 0);
+        const uint8_t* in0 = src + (size_t)iy * pitch;
+        const uint8_t* in1 = src + (size_t)ny * pitch;
+        const int bias = (y & 1) ? 2 : 1;
+        for (int x = 0; x < width; ++x) o[x] = (uint8_t)((in0[x] * 3 + in1[x] + bias) >> 2);
+      } else {  // replication (a component too narrow for the triangle filter)
         const uint8_t* in = src + (size_t)(y / vs) * pitch;
         for (int x = 0; x < width; ++x) o[x] = in[x / hs];
       }
@@ -933,6 +971,10 @@ void StructFromMotion::getFeature(const cv::Mat& image, const int& numImage) {
     return;
   }
   setKeypoints(numImage, kp.data(), n);
+  // new rows for this image: what the matcher holds on the device (a set that may have ADOPTED the old rows' pointer) and
+  // every cached pair list are stale -- let go of them before the old device copy is freed
+  releaseDeviceSet();
+  clearPairCache();
   if ((size_t)numImage < devDescriptors.size() && devDescriptors[numImage]) {  // (a device copy of older rows)
     sfmhip_device_free(devDescriptors[numImage]);
     devDescriptors[numImage] = nullptr;

@@ -2130,7 +2130,9 @@ extern "C" int sfmhip_matchplan_pipeline(sfmhip_matchplan* pl, int64_t capacity)
     for (auto& e : pl->ev_host) SFM_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   if (!pl->d_offsets) SFM_TRY(sfm_dev_alloc(&pl->d_offsets, (size_t)pl->cap_pairs + 1));
-  if (capacity != pl->pipe_capacity || !pl->h_pipe[0]) {
+  if (capacity != pl->pipe_capacity || !pl->h_pipe[0] || !pl->h_pipe[1]) {
+    pl->pipe_on = false;  // (a refused allocation leaves the plan usable without the pipeline)
+    pl->pipe_capacity = 0;
     for (int k = 0; k < 2; ++k) {
       if (pl->h_pipe[k]) hipHostFree(pl->h_pipe[k]);
       pl->h_pipe[k] = nullptr;

@@ -657,12 +657,21 @@ static int sift_impl(sfmhip_ctx* ctx, const uint8_t* gray, int rows, int cols, i
     d_desc = (float*)own;
     *d_desc_out = own;
   }
-  SFM_HIP_TRY(hipMemcpyAsync(d_kp, kps.data(), sizeof(KeyPt) * nk, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(sift_describe, dim3((nk + DESC_WAVES - 1) / DESC_WAVES), dim3(64 * DESC_WAVES), 0, st, P, (const float*)G, (const KeyPt*)d_kp, nk, d_desc);
-  SFM_HIP_TRY(hipGetLastError());
-  if (descriptors) SFM_HIP_TRY(hipMemcpyAsync(descriptors, d_desc, sizeof(float) * 128 * (size_t)nk, hipMemcpyDeviceToHost, st));
-  SFM_HIP_TRY(hipStreamSynchronize(st));
-  return SFMHIP_OK;
+  // (a failure from here on must not leave the caller with a live allocation behind an error code)
+  auto finish = [&]() -> int {
+    SFM_HIP_TRY(hipMemcpyAsync(d_kp, kps.data(), sizeof(KeyPt) * nk, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(sift_describe, dim3((nk + DESC_WAVES - 1) / DESC_WAVES), dim3(64 * DESC_WAVES), 0, st, P, (const float*)G, (const KeyPt*)d_kp, nk, d_desc);
+    SFM_HIP_TRY(hipGetLastError());
+    if (descriptors) SFM_HIP_TRY(hipMemcpyAsync(descriptors, d_desc, sizeof(float) * 128 * (size_t)nk, hipMemcpyDeviceToHost, st));
+    SFM_HIP_TRY(hipStreamSynchronize(st));
+    return SFMHIP_OK;
+  };
+  const int rc = finish();
+  if (rc != SFMHIP_OK && d_desc_out && *d_desc_out) {
+    hipFree(*d_desc_out);
+    *d_desc_out = nullptr;
+  }
+  return rc;
 }
 
 static void sift_pack_keypoints(const std::vector<KeyPt>& kps, float* keypoints) {
@@ -733,7 +742,7 @@ extern "C" int sfmhip_sift_batch(sfmhip_ctx* ctx, int n_images, const uint8_t* c
     SFM_TRY(sfmhip_init(ctx->device, &w));
     ctx->workers.push_back(w);
   }
-  std::vector<int> rcs(n_workers, SFMHIP_OK);
+  std::vector<int> rcs(n_workers, SFMHIP_OK), hip_errs(n_workers, 0);  // (g_sfmhip_last_hip_error is per thread: carried back by hand)
   std::vector<std::thread> threads;
   for (int t = 0; t < n_workers; ++t)
     threads.emplace_back([&, t]() {
@@ -756,12 +765,15 @@ extern "C" int sfmhip_sift_batch(sfmhip_ctx* ctx, int n_images, const uint8_t* c
         if (rc != SFMHIP_OK) {
           if (dd) hipFree(dd);
           rcs[t] = rc;
+          hip_errs[t] = g_sfmhip_last_hip_error;
         }
       }
     });
   for (auto& th : threads) th.join();
-  for (int rc : rcs)
-    if (rc != SFMHIP_OK) {
+  for (int t = 0; t < n_workers; ++t)
+    if (rcs[t] != SFMHIP_OK) {
+      const int rc = rcs[t];
+      if (hip_errs[t]) g_sfmhip_last_hip_error = hip_errs[t];  // (the caller's sfmhip_last_hip_error() reports the worker's)
       for (int i = 0; i < n_images; ++i) {
         free(keypoints[i]);
         if (d_descriptors[i]) hipFree(d_descriptors[i]);

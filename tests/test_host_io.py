@@ -4,6 +4,7 @@
 fixed-point arithmetic of OpenCV 3.4.1 restated in numpy here (no cv2 in the image) and with a float
 bilinear / float luma as a tolerance cross-check; the PMVS files with text built from the reference's
 own format statements."""
+import io
 import os
 import struct
 import subprocess
@@ -367,6 +368,86 @@ def test_jpeg_decoder_matches_libjpeg(tmp_path):
         assert bgr.shape == want.shape, name
         assert np.array_equal(bgr, want), (name, int(np.abs(bgr.astype(int) - want.astype(int)).max()), float((bgr != want).mean()))
         assert np.array_equal(gray, _cv_gray(bgr)), name
+
+
+def _jpeg_segments(data):
+    """[(marker, payload)] up to the first scan, the first scan's entropy-coded bytes, and the rest."""
+    pos, segs = 2, []
+    while True:
+        assert data[pos] == 0xFF
+        mk = data[pos + 1]
+        ln = (data[pos + 2] << 8) | data[pos + 3]
+        segs.append((mk, data[pos + 4:pos + 2 + ln]))
+        pos += 2 + ln
+        if mk == 0xDA:
+            break
+    end = pos
+    while not (data[end] == 0xFF and data[end + 1] not in (0,) + tuple(range(0xD0, 0xD8))):
+        end += 1
+    return segs, data[pos:end], data[end:]
+
+
+def _seg(mk, payload):
+    return bytes([0xFF, mk]) + struct.pack(">H", len(payload) + 2) + bytes(payload)
+
+
+def _jpeg_bytes(arr, **kw):
+    buf = io.BytesIO()
+    PIL.fromarray(arr).save(buf, "JPEG", **kw)
+    return buf.getvalue()
+
+
+def test_jpeg_rarer_layouts_match_libjpeg(tmp_path):
+    """Layouts no encoder setting of PIL writes, assembled from files it does write, against PIL's decoder byte for byte:
+    h1v2 (luma 1 x 2: a 4:2:2 frame turned on its side -- libjpeg-turbo's h1v2 fancy upsampling), a baseline file whose
+    components come in three scans of their own (not interleaved: the block grid is each component's own), the same with
+    a 2 x 2 luma (so the luma scan's grid differs from the frame's MCU grid), and 0xFF fill bytes before markers."""
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:64, 0:64]
+    base = np.stack([128 + 100 * np.sin(xx / 7.0) * np.cos(yy / 5.0), 90 + 80 * np.cos(xx / 4.0 + yy / 6.0), 40 + yy * 2.5 + xx * 0.7], 2)
+    img = np.clip(base + rng.normal(0, 12, base.shape), 0, 255).astype(np.uint8)
+    d = tmp_path / "jpgs"
+    d.mkdir()
+    files = {}
+    # h1v2: a square 4:2:2 file has as many MCUs either way; swapping the luma's factors re-reads the same blocks as 8 x 16 MCUs
+    raw = bytearray(_jpeg_bytes(img, quality=85, subsampling=1))
+    sof = raw.index(b"\xff\xc0")
+    assert raw[sof + 11] == 0x21
+    raw[sof + 11] = 0x12
+    files["a_h1v2.jpg"] = bytes(raw)
+    # one scan per component: three grayscale files' scans behind one three-component frame header
+    for tag, size, fac in (("b_scans_444.jpg", (61, 45), (0x11, 0x11, 0x11)), ("c_scans_420.jpg", (75, 53), (0x22, 0x11, 0x11))):
+        w, h = size
+        planes = [np.clip(rng.normal(128, 50, (h, w)), 0, 255).astype(np.uint8)]
+        cw, chh = (w, h) if fac[0] == 0x11 else ((w + 1) // 2, (h + 1) // 2)
+        planes += [np.clip(rng.normal(128, 30, (chh, cw)), 0, 255).astype(np.uint8) for _ in range(2)]
+        parts = [_jpeg_segments(_jpeg_bytes(pl, quality=88)) for pl in planes]
+        out = b"\xff\xd8"
+        for mk, pay in parts[0][0]:
+            if mk in (0xDB, 0xC4):                 # the gray files share one set of tables
+                out += _seg(mk, pay)
+        out += _seg(0xC0, bytes([8]) + struct.pack(">HH", h, w) + bytes([3, 1, fac[0], 0, 2, fac[1], 0, 3, fac[2], 0]))
+        for k, (segs, ecs, _) in enumerate(parts):
+            out += _seg(0xDA, bytes([1, k + 1, 0x00, 0, 63, 0])) + ecs
+            if k == 1:
+                out += b"\xff\xff\xff"           # fill bytes before the next marker
+        files[tag] = out + b"\xff\xd9"
+    # fill bytes before a restart marker and before EOI of an ordinary interleaved file
+    raw = _jpeg_bytes(img, quality=80, subsampling=2, restart_marker_blocks=2)
+    segs, ecs, tail = _jpeg_segments(raw)
+    head = raw[:raw.index(ecs[:16])]
+    ecs2 = ecs.replace(b"\xff\xd1", b"\xff\xff\xff\xd1", 1).replace(b"\xff\xd3", b"\xff\xff\xd3", 1)
+    assert len(ecs2) == len(ecs) + 3
+    files["d_fill.jpg"] = head + ecs2 + b"\xff\xff" + tail
+    for name, data in files.items():
+        (d / name).write_bytes(data)
+    (tmp_path / "cam.xml").write_text(XML)
+    ok_img, ok_cal, imgs, *_ = _run(tmp_path, d, tmp_path / "cam.xml")
+    assert ok_img == 1 and len(imgs) == len(files)
+    for name, (bgr, gray) in zip(sorted(files), imgs):
+        want = _pil_bgr(d / name)
+        assert bgr.shape == want.shape, name
+        assert np.array_equal(bgr, want), (name, int(np.abs(bgr.astype(int) - want.astype(int)).max()), float((bgr != want).mean()))
 
 
 def test_jpeg_failures_are_reported(tmp_path):
