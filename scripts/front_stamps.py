@@ -17,7 +17,7 @@ prob.iterate(6)
 ctx.synchronize()
 tree = prob.reduced_tree()
 F = tree["fronts"]
-out = np.zeros((min(F, 128), 32), np.uint64)
+out = np.zeros((min(F, 128), 128), np.uint64)
 L = _lib.lib()
 L.sfmhip_debug_front_stamps.argtypes = [C.c_void_p, C.c_int]
 assert L.sfmhip_debug_front_stamps(out.ctypes.data, F) == 0
@@ -36,6 +36,16 @@ for f in range(len(t)):
         if t[f, sl] > 0:
             line.append(f"{names[sl]} {t[f, sl] - t[f, 0]}")
     print("  ".join(line))
+
+# ---- the deferred phase of the tile waves: per wave, loop end | ahead-fetch done | (turn start, fold end) per slot
+for f in (int(a) for a in os.environ.get("STAMP_FRONTS", "0,2,6,14").split(",")):
+    if f >= len(t):
+        continue
+    print(f"front {f}: deferred phase (clk since the front's start)")
+    for w in (8, 0, 1, 5, 9, 2, 6, 10, 3, 7, 11):
+        b = 32 + 8 * w
+        v = [int(t[f, b + k] - t[f, 0]) if t[f, b + k] > 0 else -1 for k in range(8)]
+        print(f"  wave {w:2d} (SIMD {w & 3}): fetch> {v[6]:7d} fetch< {v[7]:7d}  slots " + "  ".join(f"[{v[2 * k]:7d} {v[2 * k + 1]:7d}]" for k in range(3)))
 
 # ---- the down-sweep (s_memrealtime, 100 MHz): per front, us from the earliest start
 dn = np.zeros((min(F, 128), 8), np.uint64)

@@ -2886,6 +2886,7 @@ struct sfmhip_ba {
   int2* d_pair_cams = nullptr;
   int2* d_pair_ent = nullptr;
   int n_pairs_pp = 0;
+  long long tree_dbg_ints = 0, tree_dbg_doubles = 0;  // (sizes of the front tree's tables and pool: diagnostic builds)
   int* d_bs_ids = nullptr;  // ba_backsub_runs' records, 16 ints per chunk, large chunks first
   int elim_waves = 4;  // waves per workgroup of the long-run class of ba_eliminate_mfma (8, 4 or 2)
   // dissected reduced system (NdPlan below): built at the first solve (with world > 1 the camera graph is the
@@ -2974,7 +2975,34 @@ static int ba_alloc(sfmhip_ba* b, T** p, size_t n) {
 
 #ifdef SFM_FRONT_STAMPS
 extern "C" int sfmhip_debug_front_stamps(unsigned long long* out, int n_fronts) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_front_stamps), sizeof(unsigned long long) * 32 * (size_t)std::min(n_fronts, 128)) == hipSuccess ? 0 : -2;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_front_stamps), sizeof(unsigned long long) * 128 * (size_t)std::min(n_fronts, 128)) == hipSuccess ? 0 : -2;
+}
+#endif
+#ifdef SFM_FRONT_STAMPS
+// the front tree's tables and its pool (L | y | contribution tiles per front) as they are after the last solve
+extern "C" int sfmhip_debug_tree_dump(sfmhip_ba* b, int* ints, long long n_ints, double* pool, long long n_doubles, long long sizes[2]) {
+  if (!b || !b->tree_on) return -1;
+  sizes[0] = b->tree_dbg_ints, sizes[1] = b->tree_dbg_doubles;
+  hipDeviceSynchronize();
+  if (ints && n_ints >= sizes[0]) hipMemcpy(ints, b->tree_fs.ints, sizes[0] * sizeof(int), hipMemcpyDeviceToHost);
+  if (pool && n_doubles >= sizes[1]) hipMemcpy(pool, b->tree_fs.pool, sizes[1] * sizeof(double), hipMemcpyDeviceToHost);
+  return 0;
+}
+extern "C" int sfmhip_debug_front_ubench(int mode, unsigned long long* out24) {
+  unsigned long long* d_out = nullptr;
+  double* d_sink = nullptr;
+  if (hipMalloc(&d_out, 24 * 8) != hipSuccess || hipMalloc(&d_sink, 768 * 8) != hipSuccess) return -1;
+  hipMemset(d_out, 0, 24 * 8);
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)front_ubench, hipFuncAttributeMaxDynamicSharedMemorySize, FR_LDS_BYTES);
+    attr = true;
+  }
+  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(front_ubench, dim3(1), dim3(FR_WAVES * 64), FR_LDS_BYTES, 0, d_out, d_sink, mode);
+  const hipError_t e = hipMemcpy(out24, d_out, 24 * 8, hipMemcpyDeviceToHost);
+  hipFree(d_out);
+  hipFree(d_sink);
+  return e == hipSuccess ? 0 : -2;
 }
 #endif
 #ifdef SFM_FRONT_STAMPS
@@ -3966,6 +3994,7 @@ static int ba_nd_build(sfmhip_ba* b) {
       b->tree_fs.up_order = d_up;
       b->tree_fs.down_order = d_down;
       b->tree_fs.pool = pool;
+      b->tree_dbg_ints = (long long)fl.ints.size(), b->tree_dbg_doubles = (long long)fl.n_doubles;
       b->tree_fs.flag_down = d_flags;
       b->tree_fs.tflag = d_flags + fl.n_fronts;
       double* zq = nullptr;

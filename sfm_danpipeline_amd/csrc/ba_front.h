@@ -16,11 +16,14 @@
 // Replaces Eigen's LLT / triangular solves behind ceres::Solve(DENSE_SCHUR), reference src/BundleAdjustment.cpp:116,123.
 #pragma once
 
-#define FR_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0)
+// acc -= a b: the f64 MFMA reads its blgp field as neg:[a, b, c].  Negating an operand with a vector instruction instead ties
+// the MFMA to the LDS read that produced it -- the compiler put the next block's negations (and the wait for their loads)
+// ahead of this block's MFMAs in every update loop.
+#define FR_MFMA_SUB(acc, a, b) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 1)
 
 #ifdef SFM_FRONT_STAMPS
 // diagnostic build only (scripts/front_stamps.py): shader-clock stamps of the chain wave and a few others, per front
-__device__ unsigned long long g_front_stamps[128][32];
+__device__ unsigned long long g_front_stamps[128][128];  // [32 + 8 wave + ...]: the tile waves' deferred phase
 #define FR_STAMP(slot)                                                            \
   do {                                                                            \
     unsigned long long t_;                                                        \
@@ -267,10 +270,10 @@ __device__ __forceinline__ void fr_potrf(v4d (&acc)[3], double* sD, double* sdi,
       if (b + 1 < nb) {
         const double L0 = op0[c], L1 = op1[c];
         if (b < 3) {
-          FR_MFMA(acc[0], -L0, L0);
-          FR_MFMA(acc[1], -L0, L1);
+          FR_MFMA_SUB(acc[0], L0, L0);
+          FR_MFMA_SUB(acc[1], L0, L1);
         }
-        FR_MFMA(acc[2], -L1, L1);
+        FR_MFMA_SUB(acc[2], L1, L1);
       }
     }
   }
@@ -302,8 +305,8 @@ __device__ __forceinline__ void fr_trsm(v4d (&acc)[4], double* sT, const double*
       const v2d r01 = *(const v2d*)(sdi + c), r23 = *(const v2d*)(sdi + c + 2);
       double La0 = 0.0, La1 = 0.0;
       if (b + 1 < nb) {
-        if (b < 3) La0 = -lop0[c];
-        La1 = -lop1[c];
+        if (b < 3) La0 = lop0[c];
+        La1 = lop1[c];
       }
       const double x0 = lo.x * r01.x;
       const double x1 = (lo.y - x0 * l10) * r01.y;
@@ -319,11 +322,11 @@ __device__ __forceinline__ void fr_trsm(v4d (&acc)[4], double* sT, const double*
       if (b + 1 < nb) {
         const double X0 = op0[c], X1 = op1[c];
         if (b < 3) {
-          FR_MFMA(acc[0], La0, X0);
-          FR_MFMA(acc[1], La0, X1);
+          FR_MFMA_SUB(acc[0], La0, X0);
+          FR_MFMA_SUB(acc[1], La0, X1);
         }
-        FR_MFMA(acc[2], La1, X0);
-        FR_MFMA(acc[3], La1, X1);
+        FR_MFMA_SUB(acc[2], La1, X0);
+        FR_MFMA_SUB(acc[3], La1, X1);
       }
     }
   }
@@ -348,20 +351,66 @@ __device__ __forceinline__ void fr_update(v4d (&acc)[4], const double* Xr, const
   };
   if (nb <= 0) return;
   ready(0);
-  double R0 = r0[0], R1 = r0[16 * CBP], C0 = -c0[0], C1 = -c0[16 * CBP];
+  double R0 = r0[0], R1 = r0[16 * CBP], C0 = c0[0], C1 = c0[16 * CBP];
 #pragma unroll 1  // (instantiated per register slot: code size, not loop overhead, is what counts here)
   for (int kb = 0; kb < nb; ++kb) {
     double nR0 = 0, nR1 = 0, nC0 = 0, nC1 = 0;
     if (kb + 1 < nb) {
       ready(kb + 1);
       nR0 = r0[4 * (kb + 1)], nR1 = r0[16 * CBP + 4 * (kb + 1)];
-      nC0 = -c0[4 * (kb + 1)], nC1 = -c0[16 * CBP + 4 * (kb + 1)];
+      nC0 = c0[4 * (kb + 1)], nC1 = c0[16 * CBP + 4 * (kb + 1)];
     }
-    if (subs & 1) FR_MFMA(acc[0], C0, R0);
-    if (subs & 2) FR_MFMA(acc[1], C0, R1);
-    if (subs & 4) FR_MFMA(acc[2], C1, R0);
-    if (subs & 8) FR_MFMA(acc[3], C1, R1);
+    if (subs & 1) FR_MFMA_SUB(acc[0], C0, R0);
+    if (subs & 2) FR_MFMA_SUB(acc[1], C0, R1);
+    if (subs & 4) FR_MFMA_SUB(acc[2], C1, R0);
+    if (subs & 8) FR_MFMA_SUB(acc[3], C1, R1);
     R0 = nR0, R1 = nR1, C0 = nC0, C1 = nC1;
+  }
+}
+
+// The same update for a panel that is COMPLETE (the deferred border tiles): four blocks' operands are read, then their sixteen
+// MFMAs issued back to back.  Measured on one wave (scripts/front_ubench.py): an f64 MFMA leaves the pipe every 64 cycles when
+// its operands sit in registers, but LDS reads do not complete under a stream of them -- the one-block-ahead loop above takes
+// 470 cycles per block of four MFMAs (256 of matrix pipe), four blocks at a time 294, eight at a time 272 (64 operand registers).
+__device__ __forceinline__ void fr_fold(v4d (&acc)[4], const double* Xr, const double* Xc, int nb, unsigned subs, int lane) {
+  typedef const __attribute__((address_space(3))) double* ldsp;
+  const int j16 = lane & 15, q = lane >> 4;
+  const ldsp xr = (ldsp)(Xr + j16 * CBP + q);
+  const ldsp xc = (ldsp)(Xc + j16 * CBP + q);
+  int kb = 0;
+  if (subs == 15u || subs == 11u) {
+#pragma unroll 1
+    for (; kb + 4 <= nb; kb += 4) {
+      double R0[4], R1[4], C0[4], C1[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) R0[k] = xr[4 * (kb + k)], R1[k] = xr[16 * CBP + 4 * (kb + k)], C0[k] = xc[4 * (kb + k)], C1[k] = xc[16 * CBP + 4 * (kb + k)];
+      __builtin_amdgcn_sched_barrier(0);
+      if (subs == 15u) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          FR_MFMA_SUB(acc[0], C0[k], R0[k]);
+          FR_MFMA_SUB(acc[1], C0[k], R1[k]);
+          FR_MFMA_SUB(acc[2], C1[k], R0[k]);
+          FR_MFMA_SUB(acc[3], C1[k], R1[k]);
+        }
+      } else {  // a diagonal tile: nothing above the diagonal
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          FR_MFMA_SUB(acc[0], C0[k], R0[k]);
+          FR_MFMA_SUB(acc[1], C0[k], R1[k]);
+          FR_MFMA_SUB(acc[3], C1[k], R1[k]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll 1
+  for (; kb < nb; ++kb) {  // what is left of a short last panel, and tiles with dead row halves
+    const double R0 = xr[4 * kb], R1 = xr[16 * CBP + 4 * kb], C0 = xc[4 * kb], C1 = xc[16 * CBP + 4 * kb];
+    if (subs & 1) FR_MFMA_SUB(acc[0], C0, R0);
+    if (subs & 2) FR_MFMA_SUB(acc[1], C0, R1);
+    if (subs & 4) FR_MFMA_SUB(acc[2], C1, R0);
+    if (subs & 8) FR_MFMA_SUB(acc[3], C1, R1);
   }
 }
 
@@ -502,7 +551,14 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
       }
     }
   }
-  bool got[FR_SLOTS] = {false, false, false};  // (tile waves: which slots have the children's parts already)
+  bool got[FR_SLOTS] = {false, false, false};  // (which slots have the children's parts already)
+  const bool defer = no <= 2;  // (ba_front_plan.h: both panel generations are intact at the end; the border tiles wait for it)
+  auto need = [&](int s) {  // (s is a compile-time constant at every call: the loops over the slots are unrolled)
+    if (!got[s]) {
+      recv_tile(t[s], sr[s], sc[s]);
+      got[s] = true;
+    }
+  };
 
   if (wave == 0) FR_STAMP(3);
   // ---- the factorisation: no barrier from here to the end, LDS counters only
@@ -535,9 +591,9 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
           if (kb < nbj) {
             if (seen < base + kb + 1) seen = __builtin_amdgcn_readfirstlane(lds_wait_ge(pr, base + kb + 1));
             const double Y0 = y0[4 * kb], Y1 = y0[16 * CBP + 4 * kb];
-            FR_MFMA(dacc[0], -Y0, Y0);
-            FR_MFMA(dacc[1], -Y0, Y1);
-            FR_MFMA(dacc[2], -Y1, Y1);
+            FR_MFMA_SUB(dacc[0], Y0, Y0);
+            FR_MFMA_SUB(dacc[1], Y0, Y1);
+            FR_MFMA_SUB(dacc[2], Y1, Y1);
           }
         }
       }
@@ -551,6 +607,7 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
 #pragma unroll 1
     for (int j = 0; j < no; ++j) {
       const int gen = j & 1, base = 8 * (j >> 1), nbj = opaque_s(j == no - 1 ? D.nb_last : 8);
+      if (j >= 2) lds_wait_ge(s_flag + FRC_CONS + gen, FR_WAVES * (j >> 1));  // (see the tile waves' loop)
       const double* const sL = sD + gen * FR_TILE;
       const double* const sdj = sdi + gen * CB;
       double* const yj = sy + CB * j;
@@ -603,19 +660,12 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
     fr_raise_flag(fs.tflag + D.tflag_off + D.ns * (D.ns + 1) / 2, epoch, lane);
   } else {
     // ---- tile waves (wave 8 holds border tiles only, and only where they are folded at the end)
-    const bool defer = no <= 2;  // (ba_front_plan.h: both panel generations are intact at the end; the border tiles wait for it)
     auto publish_diag = [&](v4d (&tt)[4], int c) {
       lds_wait_ge(s_flag + FRC_DTAKEN, c - 1);  // (the chain wave has taken the tile before this one out of the staging tile)
       chol2_put(sDg, 0, lane, tt[0]);
       chol2_put(sDg, 2, lane, tt[1]);
       chol2_put(sDg, 3, lane, tt[3]);
       lds_flag_set(s_flag + FRC_DREADY, c);
-    };
-    auto need = [&](int s) {  // (s is a compile-time constant at every call: the loops over the slots are unrolled)
-      if (!got[s]) {
-        recv_tile(t[s], sr[s], sc[s]);
-        got[s] = true;
-      }
     };
 #pragma unroll
     for (int s = 0; s < FR_SLOTS; ++s)
@@ -626,11 +676,15 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
 #pragma unroll 1
     for (int j = 0; j < no; ++j) {
       const int gen = j & 1, base = 8 * (j >> 1), nbj = opaque_s(j == no - 1 ? D.nb_last : 8);
+      // Step j reuses the panel generation of step j - 2: nobody enters it before EVERY wave has left step j - 2.  Every
+      // wave waits here, also one with nothing to do in this step -- it would otherwise add its count for step j to the
+      // generation's counter at once, the counter would reach a full round with a slow wave (the right-hand side's, when the
+      // children's y came late) still reading step j - 2's panel, and the solves of step j would overwrite it under its hands.
+      if (j >= 2) lds_wait_ge(s_flag + FRC_CONS + gen, FR_WAVES * (j >> 1));
 #pragma unroll
       for (int s = 0; s < FR_SLOTS; ++s)
         if (sc[s] == j && sr[s] > j) {
           need(s);
-          if (j >= 2) lds_wait_ge(s_flag + FRC_CONS + gen, FR_WAVES * (j >> 1));
           fr_trsm(t[s], panel_tile(gen, sr[s]), sD + gen * FR_TILE, sdi + gen * CB, progL_of(gen), prog_of(gen, sr[s]), base, nbj,
                   pool_rs, (D.offL + (CB * sr[s] + (lane & 31)) * ldk + CB * j) * 8, lane);
         }
@@ -644,33 +698,34 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
         }
       lds_flag_add(s_flag + FRC_CONS + gen, lane);
     }
-    // the border tiles, now that nothing solves beside them, a tile at a time in column order: fold, send, raise its flag
+    // the border tiles.  A front that folded them as it went sends them; a front of one or two own tiles folds both panels into
+    // them now that nothing solves beside them, a tile at a time per SIMD in the plan's order (ba_front_plan.h: the order in
+    // which the ancestors need them), sends each and raises its flag
     if (wave == 1) FR_STAMP(17);
     if (wave == 11) FR_STAMP(18);
-    if (wave == 2) FR_STAMP(23);
-    if (wave == 3) FR_STAMP(24);
-    if (wave == 6) FR_STAMP(25);
-    if (wave == 7) FR_STAMP(26);
+    FR_STAMP(32 + 8 * wave + 7);
 #pragma unroll
     for (int s = 0; s < FR_SLOTS; ++s)
       if (sc[s] >= no) {
         const unsigned subs = fr_live_subs(live, sr[s], sc[s]);
         need(s);
         if (defer) {
-          // one tile at a time per SIMD, in the plan's order; none before the last diagonal tile is factored, and on the
-          // SIMDs that hold the last step's solves (2 and 3) none before those are through (an MFMA stream beside a solve
-          // lets it issue one vector instruction per MFMA)
+          // none before the last diagonal tile is factored, and on the SIMDs that hold the last step's solves (2 and 3) none
+          // before those are through (an MFMA stream beside a solve lets it issue one vector instruction per MFMA)
           int* const turn = s_flag + FRC_TURN + (wave & 3);
           lds_wait_ge(progL_of((no - 1) & 1), D.nb_last);
           if ((wave & 3) >= 2)
             for (int r = no; r < T; ++r) lds_wait_ge(prog_of((no - 1) & 1, r), D.nb_last);
           lds_wait_ge(turn, sturn[s]);
-          for (int j = 0; j < no; ++j)
-            fr_update(t[s], panel_tile(j, sr[s]), prog_of(j, sr[s]), panel_tile(j, sc[s]), prog_of(j, sc[s]), 0, j == no - 1 ? D.nb_last : 8,
-                      subs, lane);
+          FR_STAMP(32 + 8 * wave + 2 * s);
+          for (int j = 0; j < no; ++j) {
+            const int nbj = j == no - 1 ? D.nb_last : 8;
+            lds_wait_ge(prog_of(j, sr[s]), nbj);  // (both rows of the panel complete: the fold reads them four blocks at a time)
+            lds_wait_ge(prog_of(j, sc[s]), nbj);
+            fr_fold(t[s], panel_tile(j, sr[s]), panel_tile(j, sc[s]), nbj, subs, lane);
+          }
           lds_flag_set(turn, sturn[s] + 1);
-          if (wave == 8 && sturn[s] == 0) FR_STAMP(27);
-          if (wave == 1 && sturn[s] == 0) FR_STAMP(28);
+          FR_STAMP(32 + 8 * wave + 2 * s + 1);
         }
         const int i = sr[s] - no, j = sc[s] - no;
         fr_send(t[s], pool_rs, (D.off_pbuf + (i * (i + 1) / 2 + j) * (CB * CB)) * 8, subs, lane);
@@ -919,3 +974,225 @@ __global__ __launch_bounds__(FD_THREADS) void front_down(FrontSet fs, BaDev d, c
   FD_STAMP(6);
 }
 #undef FR_MFMA
+
+#ifdef SFM_FRONT_STAMPS
+// diagnostic build only (scripts/front_ubench.py): the update loop of fr_update on one wave of SIMD 0, alone or beside other
+// work on the CU.  mode bits: 1 = a wave of f64 vector FMAs on the same SIMD (the right-hand side's wave), 2 = a wave that
+// polls an LDS counter with s_sleep 1 on the same SIMD, 4 = waves folding on the other three SIMDs, 8 = a second folding wave
+// on the same SIMD, 16 = two waves polling with s_sleep 8, 32 = a third folding wave on the SIMD.  out[0] = shader clocks of 64 x 8 blocks, out[1] = the same, real time (100 MHz).
+__global__ __launch_bounds__(FR_WAVES * 64) void front_ubench(unsigned long long* __restrict__ out, double* __restrict__ sink, int mode) {
+  extern __shared__ __attribute__((aligned(16))) double sAll[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int* const s_flag = (int*)(sAll + FR_OFF_FLAG);
+  for (int i = threadIdx.x; i < FR_OFF_FLAG; i += FR_WAVES * 64) sAll[i] = 1e-3 * ((i * 37) % 101 - 50);
+  if (threadIdx.x < 32) s_flag[threadIdx.x] = threadIdx.x < 14 ? 8 : 0;  // (every panel row complete)
+  __syncthreads();
+  v4d acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = v4d{0.0, 0.0, 0.0, 0.0};
+  const bool folder = wave == 8 || ((mode & 4) && wave >= 1 && wave <= 3) || ((mode & 8) && wave == 0) || ((mode & 32) && wave == 4);
+  if (folder) {
+    unsigned long long t0, t1, r0, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
+    const unsigned subs = 15u;
+#pragma unroll 1
+    for (int rep = 0; rep < 64; ++rep)
+      fr_update(acc, sAll + FR_OFF_PANEL + (size_t)(1 + (rep & 1)) * FR_TILE, s_flag + 1, sAll + FR_OFF_PANEL + (size_t)(3 + (rep & 1)) * FR_TILE, s_flag + 3, 0,
+                8, opaque_s((int)subs), lane);
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+    if (lane == 0) {
+      out[2 * wave] = t1 - t0;
+      out[2 * wave + 1] = r1 - r0;
+    }
+    if (wave == 8) lds_flag_set(s_flag + 20, 1);
+    if (wave == 8 && (mode & 64)) {
+      // bare MFMAs from registers: 4 per iteration / 8 per iteration on the same four accumulators
+      double a0 = sAll[lane], a1 = sAll[64 + lane], b0 = sAll[128 + lane], b1 = sAll[192 + lane];
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+#pragma unroll 1
+      for (int it = 0; it < 512; ++it) {
+        FR_MFMA_SUB(acc[0], a0, b0);
+        FR_MFMA_SUB(acc[1], a0, b1);
+        FR_MFMA_SUB(acc[2], a1, b0);
+        FR_MFMA_SUB(acc[3], a1, b1);
+      }
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+      if (lane == 0) out[18] = t1 - t0;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+#pragma unroll 1
+      for (int it = 0; it < 256; ++it) {
+        FR_MFMA_SUB(acc[0], a0, b0);
+        FR_MFMA_SUB(acc[1], a0, b1);
+        FR_MFMA_SUB(acc[2], a1, b0);
+        FR_MFMA_SUB(acc[3], a1, b1);
+        FR_MFMA_SUB(acc[0], b0, a0);
+        FR_MFMA_SUB(acc[1], b0, a1);
+        FR_MFMA_SUB(acc[2], b1, a0);
+        FR_MFMA_SUB(acc[3], b1, a1);
+      }
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+      if (lane == 0) out[19] = t1 - t0;
+      // one accumulator only: the dependent-issue latency
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+#pragma unroll 1
+      for (int it = 0; it < 512; ++it) {
+        FR_MFMA_SUB(acc[0], a0, b0);
+        FR_MFMA_SUB(acc[0], a1, b1);
+      }
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+      if (lane == 0) out[20] = t1 - t0;
+      // LDS reads issued before four MFMAs that do not use them, waited for after: do the reads complete under the MFMAs?
+      const double* lp = sAll + FR_OFF_PANEL + (lane & 15) * CBP + (lane >> 4);
+      double x0 = 0, x1 = 0, x2 = 0, x3 = 0, sacc = 0;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+#pragma unroll 1
+      for (int it = 0; it < 512; ++it) {
+        const double* q = lp + 4 * (it & 7);
+        x0 = *(volatile const __attribute__((address_space(3))) double*)(const __attribute__((address_space(3))) double*)q;
+        x1 = *(volatile const __attribute__((address_space(3))) double*)(const __attribute__((address_space(3))) double*)(q + 16 * CBP);
+        x2 = *(volatile const __attribute__((address_space(3))) double*)(const __attribute__((address_space(3))) double*)(q + FR_TILE);
+        x3 = *(volatile const __attribute__((address_space(3))) double*)(const __attribute__((address_space(3))) double*)(q + FR_TILE + 16 * CBP);
+        __builtin_amdgcn_sched_barrier(0);
+        FR_MFMA_SUB(acc[0], a0, b0);
+        FR_MFMA_SUB(acc[1], a0, b1);
+        FR_MFMA_SUB(acc[2], a1, b0);
+        FR_MFMA_SUB(acc[3], a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        sacc += x0 + x1 + x2 + x3;
+      }
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+      if (lane == 0) out[21] = t1 - t0;
+      acc[0][1] += sacc;
+      // the same with the reads' results feeding the NEXT iteration's MFMAs (what fr_update does), operands copied after the MFMAs
+      double n0 = a0, n1 = a1, m0 = b0, m1 = b1;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+#pragma unroll 1
+      for (int it = 0; it < 512; ++it) {
+        const double* q = lp + 4 * (it & 7);
+        x0 = *(volatile const __attribute__((address_space(3))) double*)(const __attribute__((address_space(3))) double*)q;
+        x1 = *(volatile const __attribute__((address_space(3))) double*)(const __attribute__((address_space(3))) double*)(q + 16 * CBP);
+        x2 = *(volatile const __attribute__((address_space(3))) double*)(const __attribute__((address_space(3))) double*)(q + FR_TILE);
+        x3 = *(volatile const __attribute__((address_space(3))) double*)(const __attribute__((address_space(3))) double*)(q + FR_TILE + 16 * CBP);
+        __builtin_amdgcn_sched_barrier(0);
+        FR_MFMA_SUB(acc[0], n0, m0);
+        FR_MFMA_SUB(acc[1], n0, m1);
+        FR_MFMA_SUB(acc[2], n1, m0);
+        FR_MFMA_SUB(acc[3], n1, m1);
+        __builtin_amdgcn_sched_barrier(0);
+        n0 = x0, n1 = x1, m0 = x2, m1 = x3;
+      }
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+      if (lane == 0) out[22] = t1 - t0;
+      // candidate update loops over a panel pair of 8 blocks, 64 repetitions each (clocks per block = total / 512)
+      typedef const __attribute__((address_space(3))) double* ldsp;
+      const ldsp xr = (ldsp)(sAll + FR_OFF_PANEL + FR_TILE + (lane & 15) * CBP + (lane >> 4));
+      const ldsp xc = (ldsp)(sAll + FR_OFF_PANEL + 3 * FR_TILE + (lane & 15) * CBP + (lane >> 4));
+      // V2: one block ahead, no branches, reads / MFMAs / copies kept apart
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+#pragma unroll 1
+      for (int rep = 0; rep < 64; ++rep) {
+        double R0 = xr[0], R1 = xr[16 * CBP], C0 = xc[0], C1 = xc[16 * CBP];
+#pragma unroll 1
+        for (int kb = 0; kb < 8; ++kb) {
+          const int nk = kb + 1 < 8 ? kb + 1 : kb;
+          const double nR0 = xr[4 * nk], nR1 = xr[16 * CBP + 4 * nk], nC0 = xc[4 * nk], nC1 = xc[16 * CBP + 4 * nk];
+          __builtin_amdgcn_sched_barrier(0);
+          FR_MFMA_SUB(acc[0], C0, R0);
+          FR_MFMA_SUB(acc[1], C0, R1);
+          FR_MFMA_SUB(acc[2], C1, R0);
+          FR_MFMA_SUB(acc[3], C1, R1);
+          __builtin_amdgcn_sched_barrier(0);
+          R0 = nR0, R1 = nR1, C0 = nC0, C1 = nC1;
+        }
+      }
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+      if (lane == 0) out[0] = t1 - t0;
+      // V4: four blocks' operands at a time, then their sixteen MFMAs
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+#pragma unroll 1
+      for (int rep = 0; rep < 64; ++rep) {
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+          double R0[4], R1[4], C0[4], C1[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) R0[k] = xr[16 * h + 4 * k], R1[k] = xr[16 * CBP + 16 * h + 4 * k], C0[k] = xc[16 * h + 4 * k], C1[k] = xc[16 * CBP + 16 * h + 4 * k];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            FR_MFMA_SUB(acc[0], C0[k], R0[k]);
+            FR_MFMA_SUB(acc[1], C0[k], R1[k]);
+            FR_MFMA_SUB(acc[2], C1[k], R0[k]);
+            FR_MFMA_SUB(acc[3], C1[k], R1[k]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+      if (lane == 0) out[1] = t1 - t0;
+      // V5: the whole panel pair's operands (8 blocks), then 32 MFMAs
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+#pragma unroll 1
+      for (int rep = 0; rep < 64; ++rep) {
+        double R0[8], R1[8], C0[8], C1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) R0[k] = xr[4 * k], R1[k] = xr[16 * CBP + 4 * k], C0[k] = xc[4 * k], C1[k] = xc[16 * CBP + 4 * k];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          FR_MFMA_SUB(acc[0], C0[k], R0[k]);
+          FR_MFMA_SUB(acc[1], C0[k], R1[k]);
+          FR_MFMA_SUB(acc[2], C1[k], R0[k]);
+          FR_MFMA_SUB(acc[3], C1[k], R1[k]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+      if (lane == 0) out[2] = t1 - t0;
+      // V6: four blocks at a time, the next four's reads issued before this four's MFMAs (two register sets)
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+#pragma unroll 1
+      for (int rep = 0; rep < 64; ++rep) {
+        double A0[4], A1[4], B0[4], B1[4], P0[4], P1[4], Q0[4], Q1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) A0[k] = xr[4 * k], A1[k] = xr[16 * CBP + 4 * k], B0[k] = xc[4 * k], B1[k] = xc[16 * CBP + 4 * k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) P0[k] = xr[16 + 4 * k], P1[k] = xr[16 * CBP + 16 + 4 * k], Q0[k] = xc[16 + 4 * k], Q1[k] = xc[16 * CBP + 16 + 4 * k];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          FR_MFMA_SUB(acc[0], B0[k], A0[k]);
+          FR_MFMA_SUB(acc[1], B0[k], A1[k]);
+          FR_MFMA_SUB(acc[2], B1[k], A0[k]);
+          FR_MFMA_SUB(acc[3], B1[k], A1[k]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          FR_MFMA_SUB(acc[0], Q0[k], P0[k]);
+          FR_MFMA_SUB(acc[1], Q0[k], P1[k]);
+          FR_MFMA_SUB(acc[2], Q1[k], P0[k]);
+          FR_MFMA_SUB(acc[3], Q1[k], P1[k]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+      if (lane == 0) out[3] = t1 - t0;
+    }
+  } else if ((mode & 1) && wave == 4) {
+    double a = 1.0 + lane, b = 0.5;
+    while (*(volatile lds_int*)(s_flag + 20) == 0) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a = fma(a, 0.999, b);
+    }
+    acc[0][0] = a;
+  } else if (((mode & 2) && wave == 0 && !(mode & 8)) || ((mode & 2) && wave == 4 && !(mode & 1))) {
+    lds_wait_ge(s_flag + 20, 1);
+  } else if ((mode & 16) && (wave == 0 || wave == 4)) {
+    while (__builtin_amdgcn_readfirstlane(*(volatile lds_int*)(s_flag + 20)) == 0) __builtin_amdgcn_s_sleep(8);
+  }
+  double sum = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  sink[threadIdx.x] = sum;
+}
+#endif

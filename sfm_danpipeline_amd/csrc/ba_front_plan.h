@@ -414,9 +414,32 @@ static inline Plan build_plan(int nc, const unsigned long long* adj_bits, int wp
       // ten different waves (rounds: every wave gets its t-th border tile before any gets its (t+1)-th).
       const int simd_of[4][3] = {{8, -1, -1}, {1, 5, 9}, {2, 6, 10}, {3, 7, 11}};
       int turn[4] = {0, 0, 0, 0}, ndef[FP_WAVES] = {0};
-      std::vector<std::pair<int, int>> todo;
+      struct Item { int d, cls, a, b, r, c; };
+      std::vector<Item> items;
       for (int c = fr.no; c < fr.T; ++c)
-        for (int r = c; r < fr.T; ++r) todo.emplace_back(r, c);
+        for (int r = c; r < fr.T; ++r) {
+          Item it{1, 2, c, r, r, c};
+          int cur = f, R = r, C = c, d = 1;
+          while (P.fronts[cur].parent >= 0) {
+            const Front& cf = P.fronts[cur];
+            const Front& pf = P.fronts[cf.parent];
+            const int Rp = cf.ptile[R - cf.no], Cp = cf.ptile[C - cf.no];
+            if (Cp < pf.no) {
+              it = Rp < pf.no ? Item{d, 0, Rp, Cp, r, c} : Item{d, 1, Cp, Rp, r, c};
+              break;
+            }
+            cur = cf.parent, R = Rp, C = Cp, ++d;
+          }
+          items.push_back(it);
+        }
+      std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) {
+        if (x.d != y.d) return x.d < y.d;
+        if (x.cls != y.cls) return x.cls < y.cls;
+        if (x.a != y.a) return x.a < y.a;
+        return x.b < y.b;
+      });
+      std::vector<std::pair<int, int>> todo;
+      for (const Item& it : items) todo.emplace_back(it.r, it.c);
       size_t p = 0;
       for (int round = 0; round < FP_SLOTS && p < todo.size(); ++round)
         for (int k = 0; k < 3 && p < todo.size(); ++k)

@@ -197,6 +197,30 @@ def test_reduced_step_solves_the_reduced_system(ctx, monkeypatch, shape, nd):
     prob.close()
 
 
+def test_front_tree_gives_the_same_answer_every_time(ctx, monkeypatch):
+    """The front tree's workgroups hand tiles to each other inside one launch, and inside a workgroup twelve waves share two
+    panel generations through counters: 150 solves of the same system must be the same bit pattern every time, and right.
+    (Round 4 found a wave with no work in a step adding its count for the step at once, so that the counter reached a full
+    round while the right-hand side's wave was still reading the panel the next step overwrote -- one solve in ten at 200
+    cameras once the children's right-hand sides arrived late.)"""
+    monkeypatch.setenv("SFMHIP_BA_ND", "2")
+    for (nc, npt, k) in ((200, 20000, 10), (560, 8000, 8)):
+        pb = synth.ba_problem(nc, npt, k, seed=5)
+        prob = bundle.BaProblem(nc, npt, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
+        prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+        S, g, _ = prob.reduced_system(1e4)
+        zr = np.linalg.solve(S, g)
+        z0 = None
+        for rep in range(150):
+            z, failed = prob.reduced_step(1e4)
+            assert failed == 0
+            if z0 is None:
+                z0 = z.copy()
+                assert np.abs(z - zr).max() <= 1e-9 * np.abs(zr).max()
+            assert np.array_equal(z, z0), rep
+        prob.close()
+
+
 def test_reduced_layout_follows_the_camera_graph(ctx, monkeypatch):
     """cfg4's co-visibility (a ring, every point seen by 10 consecutive cameras) is dissected by default; cameras
     that all see each other (random visibility) leave no separator and keep the dense factorisation; small
