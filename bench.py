@@ -492,11 +492,11 @@ def main():
     ba_bytes = 3 * n_obs_l * 24 + 2 * n_pt_l * 24 + 2 * red_dim * red_dim * 8 + n_cam * 48   # section 8d
     ba_stream_s = (ba_t["eliminate_s"] + ba_t["backsub_s"]) / max(args.steps, 1)
     ba_gbs = ba_bytes / ba_stream_s / 1e9
-    tr_ba = [hbm_bytes(k) for k in ("ba_eliminate_mfma", "ba_backsub")]
+    tr_ba = [hbm_bytes("ba_eliminate_mfma"), hbm_bytes("ba_backsub_runs") if hbm_bytes("ba_backsub_runs") is not None else hbm_bytes("ba_backsub")]
     if hbm_bytes("ba_gather_rows") is not None:      # (the default slab epilogue's second kernel; absent from older profiles)
         tr_ba.append(hbm_bytes("ba_gather_rows"))
     roofline_ba = {"kernels": "ba_eliminate_mfma + ba_gather_rows (one linearisation: F^T F + Schur correction, per-workgroup slabs "
-                              "summed in a fixed order: S, g and the cost are bitwise reproducible) + ba_backsub (per LM iteration, "
+                              "summed in a fixed order: S, g and the cost are bitwise reproducible) + ba_backsub_runs (per LM iteration, "
                               "this rank's shard)",
                    "bound": "hbm", "achieved": round(ba_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": round(ba_gbs / HBM_PEAK_GBS, 4),
@@ -611,12 +611,21 @@ def main():
                                            "(sfmhip_matchplan_pipeline / _fetch_wait); stop_and_copy = sfmhip_matchplan_fetch "
                                            "after every sweep"},
             "cfg5_strong": cfg5, "find_best_pair_scoring": score_leg, "sift_front_end": sift_leg, "ba_batch": ba_batch,
-            "ba_amdahl": {"sharded_ms": round(1e3 * (ba_t["eliminate_s"] + ba_t["backsub_s"]) / args.steps, 4),
-                          "replicated_ms": round(1e3 * ba_t["solve_s"] / args.steps, 4),
-                          "allreduce_ms": round(1e3 * ba_t["allreduce_s"] / args.steps, 4),
-                          "note": "linearise + eliminate + back-substitute shard with the points; the reduced solve "
-                                  "runs on every rank; the exchange is added: BA iterations/s do not scale with N "
-                                  "(DESIGN.md section 5)"},
+            "ba_amdahl": (lambda sh, rep, ar: {
+                "sharded_ms": round(sh, 4), "replicated_ms": round(rep, 4), "allreduce_ms": round(ar, 4),
+                # what sharding the reduced solve over ranks could reach: nothing below the dependency chain.  The front tree
+                # already runs every front at once on one GPU (31 workgroups at cfg4); its time IS the leaf-to-root chain
+                # (reduced_layout.front_tree.chain_tiles tile steps), which every subtree-per-rank split leaves whole and
+                # lengthens by an exchange of the cut level's contribution tiles over xGMI.
+                "replicated_ms_sharded": round(rep, 4),
+                "bound_8gpu_speedup": round((sh + rep) / (sh / 8 + rep + ar), 2),
+                "note": "linearise + eliminate + back-substitute shard with the points; the reduced solve runs on every "
+                        "rank: as a front tree it is bound by its dependency chain, not by work, so splitting its subtrees over "
+                        "ranks cannot shorten it (replicated_ms_sharded = replicated_ms: an estimate, unmeasured on hardware); "
+                        "bound_8gpu_speedup = (sharded + replicated) / (sharded / 8 + replicated + allreduce): BA iterations/s "
+                        "do not scale with N, independent BA problems do (ba_batch; DESIGN.md section 5)"})(
+                1e3 * (ba_t["eliminate_s"] + ba_t["backsub_s"]) / args.steps, 1e3 * ba_t["solve_s"] / args.steps,
+                1e3 * ba_t["allreduce_s"] / args.steps),
             "roofline": roofline, "roofline_ba": roofline_ba, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
