@@ -985,16 +985,21 @@ __global__ __launch_bounds__(256) void ba_gather_rows(const double* __restrict__
 // The camera's own blocks for the pair path's points, from the camera-major list of their observations: thread per
 // observation, register accumulation of the 6x6 block (upper, 21), the focal border (6) and the rhs (6) -- F^T F
 // from a linearisation, minus the Schur terms T T^T, T t_f, T u from what ba_pp_points stored --; block-reduced,
-// 33 (+ 12) atomics per workgroup.
+// 33 (+ 12) atomics per camera: one addend per entry, the slices of a long camera list summed in slice order first, so
+// that -- ba_pp_pairs adding one addend per entry too, and the kernels following each other in stream order -- the pair
+// path's S, g and norms are the same bit patterns run after run, like the runs' (slab epilogue).
 __global__ __launch_bounds__(256) void ba_cam_blocks(BaDev d, const int* __restrict__ cptr,
                                                      const int* __restrict__ cpt,
                                                      const double2* __restrict__ cxy, int nsplit,
                                                      int norms_only /* unscaled diagonal into dc only */,
                                                      const int2* __restrict__ cslot /* (T row, point slot) per entry */,
                                                      const double* __restrict__ T, const double* __restrict__ tfu,
-                                                     const double* __restrict__ pp_part, int n_part, int rank) {
+                                                     const double* __restrict__ pp_part, int n_part, int rank,
+                                                     double* __restrict__ cb_part /* nsplit > 1: 66 sums per (camera, slice) */,
+                                                     int* __restrict__ cb_cnt /* nsplit > 1: slices of the camera that have stored theirs */) {
   __shared__ double sh[4][36];
   __shared__ double sh2[4][33];
+  __shared__ int s_last;
   double q[33];  // the Schur part of the same 33 slots: T T^T (upper 21), T t_f (6), T u (6)
 #pragma unroll
   for (int e = 0; e < 33; ++e) q[e] = 0.0;
@@ -1058,10 +1063,41 @@ __global__ __launch_bounds__(256) void ba_cam_blocks(BaDev d, const int* __restr
     if (n > 0) sh2[wave][base] = o1[0];
   }
   __syncthreads();
-  if (threadIdx.x < 33 && len > 0) {
+  // A camera with many observations is cut into nsplit slices, a workgroup each.  Their sums meet in a fixed order: every
+  // slice stores its 66 sums (write-through), the last one to arrive -- whichever it is -- adds them up slice by slice and
+  // issues the camera's atomics, so S, g and the norms get ONE addend per entry from this kernel and the result does not
+  // depend on which slice finished first (the elimination's slabs do the same for the runs: bitwise reproducible sums).
+  bool mine = len > 0;
+  if (nsplit > 1 && len > 0) {
+    if (threadIdx.x < 33) {
+      const int e = threadIdx.x;
+      double* my = cb_part + ((size_t)c * nsplit + part) * 66;
+      __hip_atomic_store(my + e, sh[0][e] + sh[1][e] + sh[2][e] + sh[3][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(my + 33 + e, sh2[0][e] + sh2[1][e] + sh2[2][e] + sh2[3][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int prev = atomicAdd(cb_cnt + c, 1);
+      s_last = prev == nsplit - 1;
+      if (s_last) cb_cnt[c] = 0;  // (nobody else touches it before the next launch)
+    }
+    __syncthreads();
+    mine = s_last != 0;
+    if (mine) __threadfence();
+  }
+  if (threadIdx.x < 33 && mine) {
     const int e = threadIdx.x;
-    const double v = sh[0][e] + sh[1][e] + sh[2][e] + sh[3][e];
-    const double sq = sh2[0][e] + sh2[1][e] + sh2[2][e] + sh2[3][e];
+    double v = sh[0][e] + sh[1][e] + sh[2][e] + sh[3][e];
+    double sq = sh2[0][e] + sh2[1][e] + sh2[2][e] + sh2[3][e];
+    if (nsplit > 1) {
+      v = 0.0, sq = 0.0;
+      for (int sl = 0; sl < nsplit; ++sl) {
+        const double* pt = cb_part + ((size_t)c * nsplit + sl) * 66;
+        v += __hip_atomic_load(pt + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sq += __hip_atomic_load(pt + 33 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     double* S = red_S(d);
     double* g = red_g(d);
     double* gF = red_gF(d);
@@ -2874,6 +2910,8 @@ struct sfmhip_ba {
   int* d_cpt = nullptr;
   double2* d_cxy = nullptr;
   int cam_split = 1;
+  double* d_cb_part = nullptr;  // ba_cam_blocks with cam_split > 1: 66 sums per (camera, slice); d_cb_cnt: arrivals per camera
+  int* d_cb_cnt = nullptr;
   int* d_fb_points = nullptr;  // the pair path's points (sorted indices), their first T row
   int* d_pp_obase = nullptr;
   int n_fb = 0;
@@ -3526,6 +3564,11 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   BA_A(b->d_tfu, 6 * fb.size());
   b->n_pp_part = (int)((fb.size() * PP_LANES + 255) / 256);
   BA_A(b->d_pp_part, 8 * (size_t)b->n_pp_part);
+  if (b->cam_split > 1) {
+    BA_A(b->d_cb_part, 66 * (size_t)n_cam * b->cam_split);
+    BA_A(b->d_cb_cnt, n_cam);
+    if (rc == SFMHIP_OK && hipMemset(b->d_cb_cnt, 0, sizeof(int) * (size_t)n_cam) != hipSuccess) rc = SFMHIP_ERR_HIP;
+  }
   BA_A(b->d_pair_ptr, pair_ptr.size());
   BA_A(b->d_pair_cams, pair_cams.size());
   BA_A(b->d_pair_ent, pair_ent.size());
@@ -3793,7 +3836,7 @@ static int ba_prepare_scale(sfmhip_ba* b, int jacobi) {
       hipLaunchKernelGGL(ba_pp_points, dim3((unsigned)(((size_t)b->n_fb * PP_LANES + 255) / 256)), dim3(256), 0, st, d, b->d_fb_points, b->d_pp_obase, b->n_fb, 1.0,
                          1e-6, 1e32, b->rank, b->d_ppT, b->d_tfu, 1, b->d_pp_part);
       hipLaunchKernelGGL(ba_cam_blocks, dim3(b->nc * b->cam_split), dim3(256), 0, st, d, b->d_cptr, b->d_cpt, b->d_cxy,
-                         b->cam_split, 1, b->d_cslot, b->d_ppT, b->d_tfu, b->d_pp_part, b->n_pp_part, b->rank);
+                         b->cam_split, 1, b->d_cslot, b->d_ppT, b->d_tfu, b->d_pp_part, b->n_pp_part, b->rank, b->d_cb_part, b->d_cb_cnt);
     }
   }
   SFM_HIP_TRY(hipGetLastError());
@@ -3860,7 +3903,7 @@ static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_o
       hipLaunchKernelGGL(ba_pp_pairs, dim3(b->n_pairs_pp), dim3(64), 0, st, d, b->d_pair_ptr, b->d_pair_cams, b->d_pair_ent,
                          (const double*)b->d_ppT);
     hipLaunchKernelGGL(ba_cam_blocks, dim3(b->nc * b->cam_split), dim3(256), 0, st, d, b->d_cptr, b->d_cpt, b->d_cxy,
-                       b->cam_split, 0, b->d_cslot, b->d_ppT, b->d_tfu, b->d_pp_part, b->n_pp_part, b->rank);
+                       b->cam_split, 0, b->d_cslot, b->d_ppT, b->d_tfu, b->d_pp_part, b->n_pp_part, b->rank, b->d_cb_part, b->d_cb_cnt);
     nl += 3;
   }
   SFM_HIP_TRY(hipGetLastError());

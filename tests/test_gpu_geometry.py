@@ -597,3 +597,37 @@ def test_linearisation_is_bitwise_reproducible(ctx, monkeypatch):
     ref.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
     sd, sr = det.iterate(5), ref.iterate(5)
     assert sd.successful_steps == sr.successful_steps and abs(sd.final_cost - sr.final_cost) <= 1e-10 * sr.final_cost
+    det.close()
+    ref.close()
+
+
+@pytest.mark.parametrize("case", ["ragged", "many_per_camera"])
+def test_linearisation_of_ragged_tracks_is_bitwise_reproducible(ctx, monkeypatch, case):
+    """The same for the points the runs do not take (the pair path: ba_pp_points / ba_pp_pairs / ba_cam_blocks): ragged,
+    shuffled tracks with a camera seen twice, and random visibility at 12 cameras x 60 000 points -- 25 000 observations per
+    camera, which ba_cam_blocks cuts into slices of a workgroup each (their sums meet in slice order, whichever finishes
+    last; one addend per entry of S from each of the three kernels, which follow each other in stream order)."""
+    monkeypatch.delenv("SFMHIP_BA_DETERMINISTIC", raising=False)
+    rng = np.random.default_rng(23)
+    if case == "ragged":
+        pb = synth.ba_problem(40, 20000, 8, seed=31)
+        keep = rng.random(pb["n_obs"]) < 0.7
+        oc, op, xy = pb["obs_cam"][keep], pb["obs_pt"][keep], pb["obs_xy"][keep]
+        oc, op, xy = np.concatenate([oc, oc[:3]]), np.concatenate([op, op[:3]]), np.concatenate([xy, xy[:3] + 0.25])
+        perm = rng.permutation(len(oc))
+        oc, op, xy = oc[perm], op[perm], xy[perm]
+        nc, npt = 40, 20000
+    else:
+        nc, npt = 12, 60000
+        pb = synth.ba_problem(nc, npt, 5, seed=37)
+        perm = rng.permutation(pb["n_obs"])          # (unsorted tracks: none of these points is taken by a run)
+        oc, op, xy = pb["obs_cam"][perm], pb["obs_pt"][perm], pb["obs_xy"][perm]
+    prob = bundle.BaProblem(nc, npt, oc, op, xy, ctx=ctx)
+    runs = []
+    for _ in range(4):
+        prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+        runs.append(prob.reduced_system(1e4))
+    for S, g, cost in runs[1:]:
+        assert np.array_equal(S.view(np.uint64), runs[0][0].view(np.uint64)) and np.array_equal(g.view(np.uint64), runs[0][1].view(np.uint64))
+        assert cost == runs[0][2]
+    prob.close()
