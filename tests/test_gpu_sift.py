@@ -28,10 +28,11 @@ def test_keypoints_and_descriptors_match_the_restatement(ctx, shape, seed):
     Ko, Do = S.detect_and_compute(img)
     assert len(Ko) > 20
     assert K.shape == Ko.shape and D.shape == Do.shape, (K.shape, Ko.shape)
-    assert np.array_equal(K[:, 5].view(np.int32), Ko[:, 5].view(np.int32))               # octave / layer / xi bits
-    assert np.allclose(K[:, :5], Ko[:, :5], rtol=2e-5, atol=2e-4)
-    diff = np.abs(D - Do)
-    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3                                  # integers; a rounding boundary at most
+    # the same bit patterns: coordinates, size, angle, response, the octave / layer / xi word, and every descriptor entry (the
+    # device follows the restatement's order of operations stage by stage; round 4 measured 8428 keypoints of the temple
+    # frames identical in all six fields and 1 078 784 descriptor entries without one difference)
+    assert np.array_equal(K.view(np.int32), Ko.astype(np.float32).view(np.int32))
+    assert np.array_equal(D, Do.astype(np.float32))
     n = np.linalg.norm(D, axis=1)
     assert np.all((n > 480) & (n < 540)) and D.min() >= 0 and D.max() <= 255 and np.array_equal(D, np.rint(D))
 
@@ -42,7 +43,7 @@ def test_flat_and_tiny_images(ctx):
     img = _blobs(24, 20, 3, 5)
     K, D = features.sift_detect_and_compute(img, ctx=ctx)
     Ko, Do = S.detect_and_compute(img)
-    assert K.shape == Ko.shape and (len(K) == 0 or np.allclose(K[:, :5], Ko[:, :5], rtol=2e-5, atol=2e-4))
+    assert K.shape == Ko.shape and np.array_equal(K.view(np.int32), Ko.astype(np.float32).view(np.int32))
 
 
 def test_descriptors_feed_the_matcher(ctx):
