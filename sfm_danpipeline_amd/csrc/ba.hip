@@ -2924,6 +2924,7 @@ struct sfmhip_ba {
   int2* d_pair_cams = nullptr;
   int2* d_pair_ent = nullptr;
   int n_pairs_pp = 0;
+  int tree_xoff = 0;  // which of every `tree_stride` workgroups holds a front: a different one for every problem of the process
   long long tree_dbg_ints = 0, tree_dbg_doubles = 0;  // (sizes of the front tree's tables and pool: diagnostic builds)
   int* d_bs_ids = nullptr;  // ba_backsub_runs' records, 16 ints per chunk, large chunks first
   int elim_waves = 4;  // waves per workgroup of the long-run class of ba_eliminate_mfma (8, 4 or 2)
@@ -4038,6 +4039,10 @@ static int ba_nd_build(sfmhip_ba* b) {
       b->tree_fs.down_order = d_down;
       b->tree_fs.pool = pool;
       b->tree_dbg_ints = (long long)fl.ints.size(), b->tree_dbg_doubles = (long long)fl.n_doubles;
+      {
+        static std::atomic<int> n_trees{0};
+        b->tree_xoff = n_trees.fetch_add(1) & 7;
+      }
       b->tree_fs.flag_down = d_flags;
       b->tree_fs.tflag = d_flags + fl.n_fronts;
       double* zq = nullptr;
@@ -4345,11 +4350,11 @@ static int ba_reduced_solve_tree(sfmhip_ba* b) {
     for (int l = b->tree_levels - 1; l >= 0; --l, ++nl)
       hipLaunchKernelGGL(front_up, dim3(l == b->tree_levels - 1 ? grid : stride * nF), dim3(FR_WAVES * 64), FR_LDS_BYTES, st, b->tree_fs, d.red,
                          d.red + b->ssz, d.ld, d, b->fin_pending ? 1 : 0, b->fin_radius, b->fin_lo, b->fin_hi, b->world, epoch, stride, l, l,
-                         b->red_alt, (long long)nz, l == b->tree_levels - 1 ? zwg : 0);
+                         b->red_alt, (long long)nz, l == b->tree_levels - 1 ? zwg : 0, b->tree_xoff % stride);
   } else {
     hipLaunchKernelGGL(front_up, dim3(grid), dim3(FR_WAVES * 64), FR_LDS_BYTES, st, b->tree_fs, d.red, d.red + b->ssz, d.ld, d,
                        b->fin_pending ? 1 : 0, b->fin_radius, b->fin_lo, b->fin_hi, b->world, epoch, stride, 0, 1 << 30, b->red_alt,
-                       (long long)nz, zwg);
+                       (long long)nz, zwg, b->tree_xoff % stride);
     nl = 1;
   }
   if (zwg) b->alt_clean = true;

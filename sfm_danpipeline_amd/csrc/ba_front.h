@@ -422,17 +422,19 @@ __device__ __forceinline__ void fr_report_timeout(const int* s_flag, int* __rest
 __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const double* __restrict__ S, const double* __restrict__ g, int ldS,
                                                           BaDev d, int fin, double radius, double lm_lo, double lm_hi, int world,
                                                           unsigned epoch, int stride, int lvl_lo, int lvl_hi, double* __restrict__ zero_ptr,
-                                                          long long zero_n, int n_zero) {
+                                                          long long zero_n, int n_zero, int xoff /* the fronts' place in every `stride` workgroups */) {
   extern __shared__ __attribute__((aligned(16))) double sAll[];
   const int nF = fs.n_fronts;
   {
     // ---- which role: the fronts sit at multiples of `stride` (stride 8: one XCD's L2 under round-robin placement,
     // speed only), the workgroups between and behind them zero the other reduced-system buffer slice by slice (the next
     // linearisation starts on it without a memset of its own), one more does ba_finalize's bookkeeping
+    // (xoff: problems that run side by side -- one per stream -- put their fronts on different XCDs)
     const int b = (int)blockIdx.x;
-    const bool is_front = b < stride * nF && b % stride == 0;
+    const bool is_front = b < stride * nF && b % stride == xoff;
     if (!is_front) {
-      const int zi = b < stride * nF ? b - (b / stride + 1) : b - nF;
+      const int before = b > xoff ? (b - xoff - 1) / stride + 1 : 0;  // fronts among the workgroups before this one
+      const int zi = b < stride * nF ? b - before : b - nF;
       if (zi < n_zero) {
         const long long lo = (long long)zi * ND_ZERO_SLICE;
         double2* p2 = (double2*)(zero_ptr + lo);
