@@ -221,6 +221,50 @@ def test_front_tree_gives_the_same_answer_every_time(ctx, monkeypatch):
         prob.close()
 
 
+def test_reduced_solve_on_many_camera_graphs(ctx, monkeypatch):
+    """Whatever plan a camera graph gets -- front trees of one to six levels, chains + separator, dense --: the step solves the
+    system the solver hands out, and is the same bit pattern when asked again.  Rings and open bands of several widths,
+    irregular tracks, long-range edges (scripts/gpu_tree_fuzz.py runs hundreds of these)."""
+    monkeypatch.delenv("SFMHIP_BA_ND", raising=False)
+    rng = np.random.default_rng(1)
+    plans = set()
+    for case in range(14):
+        nc = int(rng.choice([12, 24, 40, 64, 90, 130, 200, 260, 330, 420]))
+        k = int(rng.integers(3, 11))
+        npt = int(rng.integers(20, 60)) * nc
+        pb = synth.ba_problem(nc, npt, k, seed=int(rng.integers(1 << 30)))
+        oc, op, xy = pb["obs_cam"].copy(), pb["obs_pt"].copy(), pb["obs_xy"].copy()
+        kind = case % 4
+        kk = min(k, nc)
+        if kind == 1:      # an open band: the tracks that wrap around the ring go
+            cams = oc.reshape(-1, kk)
+            keep = np.repeat((cams[:, -1] - cams[:, 0]) < kk, kk)
+            oc, op, xy = oc[keep], op[keep], xy[keep]
+        elif kind == 2:    # irregular tracks
+            keep = rng.random(len(oc)) < 0.8
+            keep[np.unique(op, return_index=True)[1]] = True
+            oc, op, xy = oc[keep], op[keep], xy[keep]
+        elif kind == 3:    # a few points also seen from the other side of the ring: long-range edges
+            idx = np.nonzero((np.arange(npt) % 7 == 0) & (rng.random(npt) < 0.15))[0]
+            fc = ((oc.reshape(-1, kk)[idx, 0] + nc // 2) % nc).astype(np.int32)
+            oc, op, xy = np.concatenate([oc, fc]), np.concatenate([op, idx.astype(np.int32)]), np.concatenate([xy, rng.normal(0, 50, (len(idx), 2))])
+        prob = bundle.BaProblem(nc, npt, oc, op, xy, ctx=ctx)
+        prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+        S, g, _ = prob.reduced_system(1e3)
+        zr = np.linalg.solve(S, g)
+        z0 = None
+        for rep in range(6):
+            z, failed = prob.reduced_step(1e3)
+            assert failed == 0, (case, nc, k, kind)
+            assert np.abs(z - zr).max() <= 1e-8 * np.abs(zr).max(), (case, nc, k, kind)
+            z0 = z.copy() if z0 is None else z0
+            assert np.array_equal(z, z0), (case, nc, k, kind, rep)
+        tree, lay = prob.reduced_tree(), prob.reduced_layout()
+        plans.add("tree" if tree["fronts"] else "chains" if lay["chains"] else "dense")
+        prob.close()
+    assert "tree" in plans and len(plans) >= 2
+
+
 def test_reduced_layout_follows_the_camera_graph(ctx, monkeypatch):
     """cfg4's co-visibility (a ring, every point seen by 10 consecutive cameras) is dissected by default; cameras
     that all see each other (random visibility) leave no separator and keep the dense factorisation; small
