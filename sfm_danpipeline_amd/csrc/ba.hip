@@ -2704,9 +2704,9 @@ constexpr int BSR_PTS = 256;  // points per block of a workgroup (a thread each)
 // workgroup's loads depend on in ONE record (chunk id -> chunk -> camera list -> tables was four dependent round trips)
 __global__ __launch_bounds__(256) void ba_backsub_runs(BaDev d, const int4* __restrict__ bs_desc, double radius, double lm_lo, double lm_hi,
                                                       int split) {
-  __shared__ __attribute__((aligned(16))) double s_tab[10 * CAMD];  // the run's camera tables ...
+  __shared__ __attribute__((aligned(16))) double s_tab[10 * 12];    // the run's cameras: R, t ...
   __shared__ __attribute__((aligned(16))) double s_tabc[10 * 12];   // ... the candidates' R, t ...
-  __shared__ __attribute__((aligned(16))) double s_zs[10 * 12];     // ... and per camera: scale (6), step (6)
+  __shared__ __attribute__((aligned(16))) double s_zs[10 * 12];     // ... and per camera: M = sum_j scale_j z_j dR/dw_j (9), scale z of the translation (3)
   __shared__ __attribute__((aligned(16))) double2 s_xy[10 * BSR_PTS];
   __shared__ double sh[4][4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -2722,14 +2722,26 @@ __global__ __launch_bounds__(256) void ba_backsub_runs(BaDev d, const int4* __re
   const int n = ch.n;
   const double sf = *d.scale_f, focal = *d.focal, focal_c = *d.focal_c, zf = d.z[6 * d.nc];
   __syncthreads();
-  for (int idx = tid; idx < n * CAMD; idx += 256) {
-    const int o = idx / CAMD, e = idx - o * CAMD;
-    s_tab[idx] = d.camd[(size_t)CAMD * s_cams[o] + e];
-    if (e < 12) s_tabc[o * 12 + e] = d.camd_c[(size_t)CAMD * s_cams[o] + e];
-  }
   for (int idx = tid; idx < n * 12; idx += 256) {
     const int o = idx / 12, e = idx - o * 12;
-    s_zs[idx] = e < 6 ? d.scale_c[6 * s_cams[o] + e] : d.z[6 * s_cams[o] + e - 6];
+    s_tab[idx] = d.camd[(size_t)CAMD * s_cams[o] + e];
+    s_tabc[idx] = d.camd_c[(size_t)CAMD * s_cams[o] + e];
+  }
+  // The model cost change needs a = -Jc z_c - Jf z_f per observation, not Jc itself: Jc z_c = dr/dP (M X + t_z) with, per
+  // camera, M = sum_j scale_j z_j dR/dw_j and t_z = (scale z) of the translation -- formed once here, so that an observation
+  // reads 12 doubles of them where it read the 27 of the three derivative matrices and 12 of scale and step, and forms
+  // one 3 x 3 product where it formed three (the kernel is bound by instructions per observation, K7).
+  for (int idx = tid; idx < n * 12; idx += 256) {
+    const int o = idx / 12, e = idx - o * 12, c = s_cams[o];
+    double v;
+    if (e < 9) {
+      v = 0.0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) v += d.camd[(size_t)CAMD * c + 12 + 9 * j + e] * (d.scale_c[6 * c + j] * d.z[6 * c + j]);
+    } else {
+      v = d.scale_c[6 * c + e - 6] * d.z[6 * c + e - 6];
+    }
+    s_zs[idx] = v;
   }
   double mcc = 0, cost_c = 0, sn2 = 0, cn2 = 0;
   for (int blk = pt_lo; blk < pt_hi; blk += BSR_PTS) {
@@ -2764,16 +2776,30 @@ __global__ __launch_bounds__(256) void ba_backsub_runs(BaDev d, const int4* __re
       const double2 xy = s_xy[k * BSR_PTS + pt];
       // (the same address for every lane: LDS broadcasts.  Scalar loads instead -- operands in SGPRs -- were measured slower here,
       // 25.7 us against 21.0: K7)
-      const lds_double* const tab = (const lds_double*)s_tab + k * CAMD;
-      const lds_double* const zs = (const lds_double*)s_zs + k * 12;
-      ObsLin o;
-      obs_linearize_g(tab, X, focal, xy.x, xy.y, zs, sp, sf, o);
-      double a0 = -o.Jf[0] * zf, a1 = -o.Jf[1] * zf;
+      const lds_double* const tab = (const lds_double*)s_tab + k * 12;
+      const lds_double* const mz = (const lds_double*)s_zs + k * 12;
+      struct { double Jp[6], r0, r1; } o;
+      double a0, a1;
+      {
+        const double px = tab[0] * X[0] + tab[1] * X[1] + tab[2] * X[2] + tab[9];
+        const double py = tab[3] * X[0] + tab[4] * X[1] + tab[5] * X[2] + tab[10];
+        const double pz = tab[6] * X[0] + tab[7] * X[1] + tab[8] * X[2] + tab[11];
+        const double iz = rcp_f64(pz);
+        const double xp = px * iz, yp = py * iz;
+        o.r0 = focal * xp - xy.x;
+        o.r1 = focal * yp - xy.y;
+        const double d00 = focal * iz, d02 = -focal * xp * iz, d12 = -focal * yp * iz;  // dr/dP rows
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const double zj = zs[6 + j];
-        a0 -= o.Jc[j] * zj;
-        a1 -= o.Jc[6 + j] * zj;
+        for (int j = 0; j < 3; ++j) {
+          o.Jp[j] = (d00 * tab[j] + d02 * tab[6 + j]) * sp[j];
+          o.Jp[3 + j] = (d00 * tab[3 + j] + d12 * tab[6 + j]) * sp[j];
+        }
+        const double qx = mz[0] * X[0] + mz[1] * X[1] + mz[2] * X[2] + mz[9];   // dP = M X + t_z
+        const double qy = mz[3] * X[0] + mz[4] * X[1] + mz[5] * X[2] + mz[10];
+        const double qz = mz[6] * X[0] + mz[7] * X[1] + mz[8] * X[2] + mz[11];
+        const double fz = sf * zf;
+        a0 = -(d00 * qx + d02 * qz) - xp * fz;
+        a1 = -(d00 * qy + d12 * qz) - yp * fz;
       }
       sm[0] += o.Jp[0] * o.Jp[0] + o.Jp[3] * o.Jp[3];
       sm[1] += o.Jp[1] * o.Jp[0] + o.Jp[4] * o.Jp[3];
