@@ -2789,10 +2789,11 @@ __global__ __launch_bounds__(256) void ba_backsub_runs(BaDev d, const int4* __re
         o.r0 = focal * xp - xy.x;
         o.r1 = focal * yp - xy.y;
         const double d00 = focal * iz, d02 = -focal * xp * iz, d12 = -focal * yp * iz;  // dr/dP rows
+        // (Jp without the point's column scale: the sums below are scaled once per point, not every entry per observation)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          o.Jp[j] = (d00 * tab[j] + d02 * tab[6 + j]) * sp[j];
-          o.Jp[3 + j] = (d00 * tab[3 + j] + d12 * tab[6 + j]) * sp[j];
+          o.Jp[j] = d00 * tab[j] + d02 * tab[6 + j];
+          o.Jp[3 + j] = d00 * tab[3 + j] + d12 * tab[6 + j];
         }
         const double qx = mz[0] * X[0] + mz[1] * X[1] + mz[2] * X[2] + mz[9];   // dP = M X + t_z
         const double qy = mz[3] * X[0] + mz[4] * X[1] + mz[5] * X[2] + mz[10];
@@ -2807,19 +2808,18 @@ __global__ __launch_bounds__(256) void ba_backsub_runs(BaDev d, const int4* __re
       sm[3] += o.Jp[2] * o.Jp[0] + o.Jp[5] * o.Jp[3];
       sm[4] += o.Jp[2] * o.Jp[1] + o.Jp[5] * o.Jp[4];
       sm[5] += o.Jp[2] * o.Jp[2] + o.Jp[5] * o.Jp[5];
+      // (Jp^T r and Jp^T a only ever appear as their sum: in the step and in the model cost change)
+      const double u0 = o.r0 + a0, u1 = o.r1 + a1;
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        sm[6 + a] += o.Jp[a] * o.r0 + o.Jp[3 + a] * o.r1;
-        sm[9 + a] += o.Jp[a] * a0 + o.Jp[3 + a] * a1;
-      }
+      for (int a = 0; a < 3; ++a) sm[6 + a] += o.Jp[a] * u0 + o.Jp[3 + a] * u1;
       sm[12] += a0 * o.r0 + a1 * o.r1;
       sm[13] += a0 * a0 + a1 * a1;
     }
+    sm[0] *= sp[0] * sp[0], sm[1] *= sp[1] * sp[0], sm[2] *= sp[1] * sp[1];
+    sm[3] *= sp[2] * sp[0], sm[4] *= sp[2] * sp[1], sm[5] *= sp[2] * sp[2];
     double C[6] = {sm[0], sm[1], sm[2], sm[3], sm[4], sm[5]};
-    const double* pr = sm + 6;
-    const double* pa = sm + 9;
     const double ar = sm[12], aa = sm[13];
-    const double e3[3] = {pr[0] + pa[0], pr[1] + pa[1], pr[2] + pa[2]};
+    const double e3[3] = {sm[6] * sp[0], sm[7] * sp[1], sm[8] * sp[2]};
     C[0] += fmin(fmax(C[0], lm_lo), lm_hi) / radius;
     C[2] += fmin(fmax(C[2], lm_lo), lm_hi) / radius;
     C[5] += fmin(fmax(C[5], lm_lo), lm_hi) / radius;
@@ -2842,7 +2842,7 @@ __global__ __launch_bounds__(256) void ba_backsub_runs(BaDev d, const int4* __re
     if (head) {
       const double qd = stp[0] * (sm[0] * stp[0] + 2.0 * (sm[1] * stp[1] + sm[3] * stp[2])) +
                         stp[1] * (sm[2] * stp[1] + 2.0 * sm[4] * stp[2]) + stp[2] * sm[5] * stp[2];
-      mcc += ar + (stp[0] * pr[0] + stp[1] * pr[1] + stp[2] * pr[2]) + 0.5 * aa + (stp[0] * pa[0] + stp[1] * pa[1] + stp[2] * pa[2]) + 0.5 * qd;
+      mcc += ar + 0.5 * aa + (stp[0] * e3[0] + stp[1] * e3[1] + stp[2] * e3[2]) + 0.5 * qd;
     }
     for (int k = 0; k < n; ++k) {
       const double2 xy = s_xy[k * BSR_PTS + pt];
