@@ -21,6 +21,7 @@ struct sfmhip_matchplan {
   int32_t **q, **t;
   float** d;
   int pipe_on;         /* sfmhip_matchplan_pipeline: fetch_wait hands out pointers into `packed` */
+  int pipe_small;      /* (test switch: every batch overflows the pinned buffers) */
   int32_t* packed;
 };
 
@@ -139,7 +140,15 @@ int sfmhip_matchplan_fetch(sfmhip_matchplan* pl, int32_t* counts, int32_t* out_q
   return SFMHIP_OK;
 }
 int sfmhip_matchplan_pipeline(sfmhip_matchplan* pl, int64_t capacity) {
-  (void)capacity;
+  /* SFMHIP_STUB_PIPELINE=refuse: no pinned memory to be had; =small: buffers that overflow on the first batch -- the two
+   * ways matchAllPairs must fall back to the copying fetch (csrc/host/Sfm.cpp) */
+  const char* mode = getenv("SFMHIP_STUB_PIPELINE");
+  if (capacity < 0) {
+    pl->pipe_on = 0;
+    return SFMHIP_OK;
+  }
+  if (mode && !strcmp(mode, "refuse")) return SFMHIP_ERR_ALLOC;
+  pl->pipe_small = mode && !strcmp(mode, "small");
   pl->pipe_on = 1;
   return SFMHIP_OK;
 }
@@ -148,6 +157,11 @@ int sfmhip_matchplan_fetch_wait(sfmhip_matchplan* pl, int back, const int32_t** 
   if (!pl->pipe_on || back != 0) return SFMHIP_ERR_STATE; /* (the stand-in keeps the latest run only) */
   int64_t tot = 0;
   for (int p = 0; p < pl->n_pairs; ++p) tot += pl->counts[p];
+  if (pl->pipe_small && tot > 0) {
+    if (total) *total = tot;
+    if (counts) *counts = pl->counts;
+    return SFMHIP_ERR_ALLOC;
+  }
   free(pl->packed);
   pl->packed = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)(tot ? tot : 1));
   int64_t off = 0;

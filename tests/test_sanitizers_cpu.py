@@ -36,6 +36,25 @@ def test_cpp_host_mirror_under_asan_ubsan(tmp_path, orc):
     hostcpp_io.check_output(tmp_path, orc, w, scored_by_stub=True)     # and the containers it filled are the oracle's results
 
 
+def test_match_all_pairs_falls_back_to_the_copying_fetch(tmp_path, orc):
+    """matchAllPairs (csrc/host/Sfm.cpp) when the pinned buffers of the pipelined fetch are refused, and when a batch holds
+    more matches than they do: the pass goes on through sfmhip_matchplan_fetch and fills the same containers (round-3
+    advisor: a refused hipHostMalloc aborted the whole pass).  Under ASan / UBSan, against the stub."""
+    from tests import hostcpp_io
+    _build()
+    w = hostcpp_io.write_input(tmp_path)
+    exe = os.path.join(ROOT, "oracle", "_asan", "host_selftest_asan")
+    outs = {}
+    for mode in ("", "refuse", "small"):
+        out = tmp_path / f"out_{mode or 'piped'}.bin"
+        r = subprocess.run([exe, str(tmp_path / "in.bin"), str(out)], capture_output=True, text=True, timeout=600,
+                           env=dict(ENV, SFMHIP_STUB_PIPELINE=mode))
+        _clean(r)
+        assert ("copying fetch" in r.stderr) == (mode == "refuse"), r.stderr[-500:]
+        outs[mode] = out.read_bytes()
+    assert outs["refuse"] == outs[""] and outs["small"] == outs[""]
+
+
 def test_host_io_under_asan_ubsan(tmp_path):
     """imagesLOAD / getCameraMatrix / PMVS2 (csrc/host/SfmIO.cpp: PNG inflate + unfilter, XML, file export) on
     good, truncated and corrupt inputs."""
