@@ -606,16 +606,17 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
     gmax = fmax(gmax, pvf * fmax(fabs(red[6] * isp[0]), fmax(fabs(red[7] * isp[1]), fabs(red[8] * isp[2]))));
     EL_STAMP(12, quad == wave + 2 * nw);
     if (valid_o) {
-      // W = Jc^T Jp (6x3); T = W Li^T : T[i][k] = sum_{a<=k} W[i][a] Li[k][a]; row k of the panel
+      // T = (Jc^T Jp) Li^T = Jc^T (Jp Li^T): Q = Jp Li^T first (2 x 3, twelve operations), then T[i][k] = Jc[0][i] Q[0][k] +
+      // Jc[1][i] Q[1][k] -- 48 operations where forming W = Jc^T Jp and then W Li^T took 72; row k of the panel
       double* row0 = Mw + (3 * q) * MP + 6 * o;
+      const double q00 = ol.Jp[0] * Li[0], q10 = ol.Jp[3] * Li[0];
+      const double q01 = ol.Jp[0] * Li[1] + ol.Jp[1] * Li[2], q11 = ol.Jp[3] * Li[1] + ol.Jp[4] * Li[2];
+      const double q02 = ol.Jp[0] * Li[3] + ol.Jp[1] * Li[4] + ol.Jp[2] * Li[5], q12 = ol.Jp[3] * Li[3] + ol.Jp[4] * Li[4] + ol.Jp[5] * Li[5];
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        const double w0 = ol.Jc[i] * ol.Jp[0] + ol.Jc[6 + i] * ol.Jp[3];
-        const double w1 = ol.Jc[i] * ol.Jp[1] + ol.Jc[6 + i] * ol.Jp[4];
-        const double w2 = ol.Jc[i] * ol.Jp[2] + ol.Jc[6 + i] * ol.Jp[5];
-        row0[i] = w0 * Li[0];
-        row0[MP + i] = w0 * Li[1] + w1 * Li[2];
-        row0[2 * MP + i] = w0 * Li[3] + w1 * Li[4] + w2 * Li[5];
+        row0[i] = ol.Jc[i] * q00 + ol.Jc[6 + i] * q10;
+        row0[MP + i] = ol.Jc[i] * q01 + ol.Jc[6 + i] * q11;
+        row0[2 * MP + i] = ol.Jc[i] * q02 + ol.Jc[6 + i] * q12;
       }
     }
     if (o == 0) {
