@@ -2067,18 +2067,22 @@ __device__ __forceinline__ void chol2_report_timeout(double* sAll, int* __restri
 // (bid: the workgroup's index within its matrix -- blockIdx.x when a launch factors one matrix)
 // (nxc: the tile columns of X that are wanted -- nt for a whole matrix, the interior tiles for a chain, whose X is
 // only used up to there: the trailing tiles of X right of that are not formed)
+// (xb: 0, or the width in tile columns (even) of the diagonal blocks of X that are wanted: the inverse of a diagonal block of L
+// is made of that block alone, so the rows and columns of X outside it need not be formed -- chol_back_block)
 __device__ __forceinline__ void chol_step2_body(double* __restrict__ A, double* __restrict__ y, double* __restrict__ X,
                                                 int ld, int nt, int nxc, int k2, int tiles_per_wg, int* __restrict__ info,
-                                                const int bid, double* sAll) {
+                                                const int bid, double* sAll, const int xb = 0) {
   const int m2 = nt - 2 * k2 - 2;  // tile rows below the two panels (the rhs row comes on top)
   const int npanel = m2 + 2;       // owner, m2 tile rows, rhs
-  const int nx = 2 * k2 + 2;       // rows 0..b of the identity block X (see below) take part as tile rows
+  const int xlo = xb ? 2 * k2 / xb * xb : 0;  // first row block of X that takes part
+  if (xb) nxc = min(nxc, xlo + xb);
+  const int nx = 2 * k2 + 2 - xlo;  // rows xlo..b of the identity block X (see below) take part as tile rows
   if (bid < npanel + nx) {
     if (bid >= npanel) {
       // X starts as the identity and rides along as nt more tile rows: X <- X L^-T, i.e. L^-T when the
       // factorisation ends, and the backward substitution becomes the product z = X y.  (Row block
       // r' is all zero left of column block r' and untouched until its own panel: rows 0..b here.)
-      chol2_panel<false>(A, y, X, ld, k2, info, false, (bid - npanel) * CB, sAll);
+      chol2_panel<false>(A, y, X, ld, k2, info, false, (xlo + bid - npanel) * CB, sAll);
       chol2_report_timeout(sAll, info);
       return;
     }
@@ -2101,14 +2105,14 @@ __device__ __forceinline__ void chol_step2_body(double* __restrict__ A, double* 
   int t = (bid - npanel - nx) * tiles_per_wg + wave;
   const int ntrail = m2 * (m2 + 1) / 2 + m2;
   const int mx = max(0, nxc - 2 * k2 - 2);  // column blocks of X right of the panels
-  if (t >= ntrail + 2 * k2 * mx) return;
+  if (t >= ntrail + (2 * k2 - xlo) * mx) return;
   int ti_rel = 0;
   const double* Rrow = A;  // the tile's row space
   double* Wrow = A;
   int rb_x = -1;
   if (t >= ntrail) {
     t -= ntrail;
-    rb_x = (t / mx) * CB;
+    rb_x = (xlo + t / mx) * CB;
     t %= mx;
     Rrow = X;
     Wrow = X;
@@ -2152,11 +2156,18 @@ __device__ __forceinline__ void chol_step2_body(double* __restrict__ A, double* 
     return;
   }
   const size_t st = 4 * (size_t)ld;
+#ifdef SFM_DENSE_EXP_NOLOAD
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) a[h][ks] = 1e-9 * (lane + ks), b[h][ks] = 1e-9 * (lane - ks + h);
+#else
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     ld_strided<16>(a[h], A + (size_t)(p0 + q) * ld + cb + 16 * h + j16, st);
     ld_strided<16>(b[h], Rrow + (size_t)(p0 + q) * ld + rb + 16 * h + j16, st);
   }
+#endif
 #pragma unroll
   for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
@@ -2166,6 +2177,10 @@ __device__ __forceinline__ void chol_step2_body(double* __restrict__ A, double* 
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[2 * ci + ri][g] = t4[g];
     }
+#ifdef SFM_DENSE_EXP_NOMFMA
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) acc[ks & 3][0] += a[0][ks] + b[0][ks] + a[1][ks] + b[1][ks];
+#else
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
     CHOL_MFMA(acc[0], -a[0][ks], b[0][ks]);
@@ -2173,6 +2188,7 @@ __device__ __forceinline__ void chol_step2_body(double* __restrict__ A, double* 
     CHOL_MFMA(acc[2], -a[1][ks], b[0][ks]);
     CHOL_MFMA(acc[3], -a[1][ks], b[1][ks]);
   }
+#endif
 #pragma unroll
   for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
@@ -2189,9 +2205,9 @@ __device__ __forceinline__ void chol_step2_body(double* __restrict__ A, double* 
 
 __global__ __launch_bounds__(C2_WAVES * 64) void chol_step2(double* __restrict__ A, double* __restrict__ y,
                                                             double* __restrict__ X, int ld, int nt, int k2,
-                                                            int tiles_per_wg, int* __restrict__ info) {
+                                                            int tiles_per_wg, int* __restrict__ info, int xb) {
   extern __shared__ __attribute__((aligned(16))) double sAll[];  // C2_LDS_BYTES, see C2_OFF_*
-  chol_step2_body(A, y, X, ld, nt, nt, k2, tiles_per_wg, info, (int)blockIdx.x, sAll);
+  chol_step2_body(A, y, X, ld, nt, nt, k2, tiles_per_wg, info, (int)blockIdx.x, sAll, xb);
 }
 
 // Several independent matrices ("chains": the interiors of a dissected camera graph, see NdPlan) at the same
@@ -2243,6 +2259,90 @@ __global__ __launch_bounds__(1024) void chol_apply_inverse(const double* __restr
     for (int k = 0; k < 32; ++k) v += s_part[k][i];
     z[tr * CB + i] = v;
   }
+}
+
+// ---------------------------------------------------------------- backward substitution by diagonal blocks
+// Large dense systems (no dissection, nt >= DENSE_XB_MIN_NT): the rows of X outside the diagonal blocks of xb tile columns are
+// half of all trailing tiles of the factorisation and buy only the one-product backward substitution; with X kept inside the
+// diagonal blocks (chol_step2_body, xb) the substitution walks the blocks from the last to the first, one launch each:
+//   z_K = (L_KK)^-T w_K,   w_J -= L(K, J)^T z_K for every block J < K       (w = y on entry)
+// Launch K applies z_{K+1} to every tile column left of block K+1 (one workgroup per tile column, sums in a fixed order) and the
+// workgroups of block K's own columns then write their part X(., j) w_j of z_K; the parts are added, in column order, by every
+// workgroup of the next launch (one more launch for z_0): no counters, and the same S and g give the same z bit for bit.
+constexpr int DENSE_XB = 8, DENSE_XB_MIN_NT = 64;
+__global__ __launch_bounds__(256) void chol_x_reset(double* __restrict__ X, int ld, int nt, int xb) {
+  const int j = blockIdx.x, r0 = j / xb * xb * CB, r1 = min(nt, (j / xb + 1) * xb) * CB;
+  for (int e = threadIdx.x; e < CB * (r1 - r0); e += 256) {
+    const int c = e / (r1 - r0), r = e % (r1 - r0);
+    X[(size_t)(j * CB + c) * ld + r0 + r] = 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void chol_back_block(const double* __restrict__ A, const double* __restrict__ X,
+                                                       double* __restrict__ w, double* __restrict__ z, int ld, int nt, int xb, int K,
+                                                       const double* __restrict__ part_in, double* __restrict__ part_out) {
+  __shared__ double s_z[DENSE_XB * CB];
+  __shared__ double s_w[CB];
+  __shared__ double s_red[CB];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int nk = K >= 0 ? min(xb, nt - K * xb) : 0;  // tile columns of block K
+  // the workgroups of block K's columns come first: tile column j
+  const bool own = (int)blockIdx.x < nk;
+  const int j = own ? K * xb + (int)blockIdx.x : (int)blockIdx.x - nk;
+  const int rb = (K + 1) * xb * CB, nkn = max(0, min(xb, nt - (K + 1) * xb)), nr = nkn * CB;  // block K+1: first row, tile columns, rows
+  // every load first (none depends on another): L(rows of block K+1, the column's 32), the column's part of X_KK, w_j, the parts of z_{K+1}
+  double a[8][4], x[CB], wj = 0.0, zt = 0.0;
+  if (K >= 0) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const double* col = A + (size_t)(j * CB + 8 * wave + c) * ld + rb;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) a[c][m] = lane + 64 * m < nr ? col[lane + 64 * m] : 0.0;
+    }
+    const int jj = (int)blockIdx.x, i0 = K * xb * CB;
+#pragma unroll
+    for (int c = 0; c < CB; ++c) x[c] = own && t < (jj + 1) * CB ? X[(size_t)(j * CB + c) * ld + i0 + t] : 0.0;
+    if (t < CB) wj = w[j * CB + t];
+  }
+  if (t < nr) {
+    // z_{K+1} = the sum of its columns' parts (written by the launch before), in column order: every workgroup forms it
+#pragma unroll
+    for (int q = 0; q < DENSE_XB; ++q)
+      if (q >= t / CB && q < nkn) zt += part_in[q * (DENSE_XB * CB) + t];
+    if (blockIdx.x == 0) z[rb + t] = zt;
+  }
+  if (K < 0) return;
+  s_z[t] = zt;
+  __syncthreads();
+  if (nr > 0) {
+    // lanes along the rows (contiguous in memory), a wave per eight columns
+    double acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      acc[c] = 0.0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[c] += a[c][m] * s_z[lane + 64 * m];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) s_red[8 * wave + c] = acc[c];
+    }
+    __syncthreads();
+    if (t < CB) wj -= s_red[t];
+  }
+  if (!own) {
+    if (t < CB && nr > 0) w[j * CB + t] = wj;
+    return;
+  }
+  // ---- block K's own columns: this column's part of z_K = X_KK w_K, the rows of the block up to the column's own tile
+  if (t < CB) s_w[t] = wj;
+  __syncthreads();
+  double p = 0.0;
+#pragma unroll
+  for (int c = 0; c < CB; ++c) p += x[c] * s_w[c];
+  part_out[(int)blockIdx.x * (DENSE_XB * CB) + t] = p;
 }
 
 // ---------------------------------------------------------------- dissected reduced system
@@ -2955,6 +3055,8 @@ struct sfmhip_ba {
   int* d_cpt = nullptr;
   double2* d_cxy = nullptr;
   int cam_split = 1;
+  int dense_xb = 0;              // dense factorisation: X kept inside diagonal blocks of this many tile columns (0: all of X)
+  double* d_back_part = nullptr;  // chol_back_block: the columns' parts of z_K
   double* d_cb_part = nullptr;  // ba_cam_blocks with cam_split > 1: 66 sums per (camera, slice); d_cb_cnt: arrivals per camera
   int* d_cb_cnt = nullptr;
   int* d_fb_points = nullptr;  // the pair path's points (sorted indices), their first T row
@@ -3616,6 +3718,14 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
     BA_A(b->d_cb_cnt, n_cam);
     if (rc == SFMHIP_OK && hipMemset(b->d_cb_cnt, 0, sizeof(int) * (size_t)n_cam) != hipSuccess) rc = SFMHIP_ERR_HIP;
   }
+  {
+    static const int xb_env = getenv("SFMHIP_BA_DENSE_XB") ? atoi(getenv("SFMHIP_BA_DENSE_XB")) : -1;  // (measurement: 0 = all of X)
+    const int nt = b->ld / CB;
+    b->dense_xb = xb_env == 0 ? 0 : (xb_env > 0 || nt >= DENSE_XB_MIN_NT) ? DENSE_XB : 0;
+    if (b->dense_xb) {
+      BA_A(b->d_back_part, 2 * DENSE_XB * DENSE_XB * CB);  // (two sets: a launch reads the one the launch before wrote)
+    }
+  }
   BA_A(b->d_pair_ptr, pair_ptr.size());
   BA_A(b->d_pair_cams, pair_cams.size());
   BA_A(b->d_pair_ent, pair_ent.size());
@@ -3933,7 +4043,12 @@ static int ba_linearize_eliminate(sfmhip_ba* b, double radius, const sfmhip_ba_o
   } else {
     if (!b->nd_on && b->red_is_alt) swap_red();  // (the dense factorisation's X lives behind the first buffer)
     b->alt_clean = false;
-    SFM_HIP_TRY(hipMemsetAsync(d.red, 0, sizeof(double) * (b->nd_on ? b->red_count - b->ssz : b->red_count), st));
+    const bool all_x = !b->nd_on && !b->dense_xb;
+    SFM_HIP_TRY(hipMemsetAsync(d.red, 0, sizeof(double) * (all_x ? b->red_count : b->red_count - b->ssz), st));
+    if (!b->nd_on && b->dense_xb) {  // (only the diagonal blocks of X are formed and read)
+      hipLaunchKernelGGL(chol_x_reset, dim3(b->ld / CB), dim3(256), 0, st, d.xinv, b->ld, b->ld / CB, b->dense_xb);
+      b->launches += 1;
+    }
   }
   if (!b->camd_valid) {
     hipLaunchKernelGGL(ba_cam_prep, dim3((b->nc + 63) / 64), dim3(64), 0, st, d.cams, d.camd, b->nc, 1);
@@ -4477,7 +4592,7 @@ static int ba_reduced_solve_nd(sfmhip_ba* b) {
     chol_launch_shape(sp.N, sp.N, k2, &npan, &ntrail);
     while (tpw < C2_WAVES && npan + (ntrail + tpw - 1) / tpw > b->ctx->n_cu) ++tpw;
     hipLaunchKernelGGL(chol_step2, dim3(npan + (ntrail + tpw - 1) / tpw), dim3(C2_WAVES * 64), C2_LDS_BYTES, st, sp.M, sp.y,
-                       sp.X, sp.ld, sp.N, k2, tpw, d.info);
+                       sp.X, sp.ld, sp.N, k2, tpw, d.info, 0);
   }
   // z_S = L_SS^-T y_S;  w_i = y_i - L_Si^T z_S;  z_i = L_ii^-T w_i
   hipLaunchKernelGGL(nd_xy, dim3(sp.N, 1), dim3(1024), 0, st, ns, P, d.z);
@@ -4503,20 +4618,32 @@ static int ba_reduced_solve(sfmhip_ba* b) {
       SFM_HIP_TRY(hipFuncSetAttribute((const void*)chol_step2, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS_BYTES));
       b->chol_attr_set = true;
     }
+    const int xb = b->dense_xb;
     for (int k2 = 0; 2 * k2 < nt; ++k2, ++nchol) {
       const int m2 = nt - 2 * k2 - 2;
       // launch 0 has no pending update; later launches: the tiles right of the panels, and those of X
-      const int ntrail = k2 == 0 ? 0 : m2 * (m2 + 1) / 2 + m2 + 2 * k2 * m2;
-      const int npan = m2 + 2 + 2 * k2 + 2;
+      const int xlo = xb ? 2 * k2 / xb * xb : 0, mx = xb ? std::max(0, std::min(nt, xlo + xb) - 2 * k2 - 2) : m2;
+      const int ntrail = k2 == 0 ? 0 : m2 * (m2 + 1) / 2 + m2 + (2 * k2 - xlo) * mx;
+      const int npan = m2 + 2 + 2 * k2 + 2 - xlo;
       int tpw = 4;  // trailing tiles per workgroup: the fewest that keep the launch to one round of workgroups
       while (tpw < C2_WAVES && npan + (ntrail + tpw - 1) / tpw > b->ctx->n_cu) ++tpw;
       hipLaunchKernelGGL(chol_step2, dim3(npan + (ntrail + tpw - 1) / tpw), dim3(C2_WAVES * 64), C2_LDS_BYTES, st, A, y,
-                         d.xinv, d.ld, nt, k2, tpw, d.info);
+                         d.xinv, d.ld, nt, k2, tpw, d.info, xb);
     }
   }
-  // z = L^-T y = X y
-  hipLaunchKernelGGL(chol_apply_inverse, dim3(nt), dim3(1024), 0, st, d.xinv, y, d.z, d.ld, nt);
-  const int nbs = 1;
+  int nbs = 1;
+  if (b->dense_xb) {
+    // z block by block from the last (chol_back_block)
+    const int xb = b->dense_xb, nB = (nt + xb - 1) / xb;
+    const size_t pn = (size_t)DENSE_XB * DENSE_XB * CB;
+    for (int K = nB - 1; K >= -1; --K)
+      hipLaunchKernelGGL(chol_back_block, dim3(K < 0 ? 1 : K == nB - 1 ? nt - K * xb : (K + 1) * xb), dim3(256), 0, st, A, d.xinv, y, d.z,
+                         d.ld, nt, xb, K, b->d_back_part + ((K + 1) & 1) * pn, b->d_back_part + (K & 1) * pn);
+    nbs = nB + 1;
+  } else {
+    // z = L^-T y = X y
+    hipLaunchKernelGGL(chol_apply_inverse, dim3(nt), dim3(1024), 0, st, d.xinv, y, d.z, d.ld, nt);
+  }
   SFM_HIP_TRY(hipGetLastError());
   b->launches += nchol + nbs;
   return SFMHIP_OK;
