@@ -2067,55 +2067,47 @@ __device__ __forceinline__ void chol2_report_timeout(double* sAll, int* __restri
 // (bid: the workgroup's index within its matrix -- blockIdx.x when a launch factors one matrix)
 // (nxc: the tile columns of X that are wanted -- nt for a whole matrix, the interior tiles for a chain, whose X is
 // only used up to there: the trailing tiles of X right of that are not formed)
-// (xb: 0, or the width in tile columns (even) of the diagonal blocks of X that are wanted: the inverse of a diagonal block of L
-// is made of that block alone, so the rows and columns of X outside it need not be formed -- chol_back_block)
-__device__ __forceinline__ void chol_step2_body(double* __restrict__ A, double* __restrict__ y, double* __restrict__ X,
-                                                int ld, int nt, int nxc, int k2, int tiles_per_wg, int* __restrict__ info,
-                                                const int bid, double* sAll, const int xb = 0) {
-  const int m2 = nt - 2 * k2 - 2;  // tile rows below the two panels (the rhs row comes on top)
-  const int npanel = m2 + 2;       // owner, m2 tile rows, rhs
-  const int xlo = xb ? 2 * k2 / xb * xb : 0;  // first row block of X that takes part
-  if (xb) nxc = min(nxc, xlo + xb);
-  const int nx = 2 * k2 + 2 - xlo;  // rows xlo..b of the identity block X (see below) take part as tile rows
-  if (bid < npanel + nx) {
-    if (bid >= npanel) {
-      // X starts as the identity and rides along as nt more tile rows: X <- X L^-T, i.e. L^-T when the
-      // factorisation ends, and the backward substitution becomes the product z = X y.  (Row block
-      // r' is all zero left of column block r' and untouched until its own panel: rows 0..b here.)
-      chol2_panel<false>(A, y, X, ld, k2, info, false, (xlo + bid - npanel) * CB, sAll);
-      chol2_report_timeout(sAll, info);
-      return;
-    }
-    const bool owner = bid == 0;
-    const int r0 = (2 * k2 + 1 + bid) * CB;
-    if (bid == npanel - 1)
-      chol2_panel<true>(A, y, A, ld, k2, info, false, r0, sAll);
-    else
-      chol2_panel<false>(A, y, A, ld, k2, info, owner, r0, sAll);
-    chol2_report_timeout(sAll, info);
-    return;
-  }
-  // ---- trailing tiles (k2 >= 1), one wave each (its four sub-tiles share the operands): tile row
-  // ti_rel in [0, m2] (m2 = rhs) has min(ti_rel + 1, m2) tiles; then the tiles of X: rows 0..a-1 (the
-  // rows that are nonzero in the pending panels) x the m2 column blocks right of the panels
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // (four tiles per workgroup -- one wave per SIMD: a tile is 64 MFMAs -- while that fits one round of
-  // workgroups on the device; every workgroup of this kernel holds a CU's LDS)
-  if (wave >= tiles_per_wg) return;
-  int t = (bid - npanel - nx) * tiles_per_wg + wave;
-  const int ntrail = m2 * (m2 + 1) / 2 + m2;
-  const int mx = max(0, nxc - 2 * k2 - 2);  // column blocks of X right of the panels
-  if (t >= ntrail + (2 * k2 - xlo) * mx) return;
+// Deferred trailing updates (dfr = D > 1, large matrices): a launch rewrites every trailing tile for 64 columns of update, and at
+// 100+ tile rows that traffic -- not the MFMAs -- is what a launch waits for.  A tile column is only needed up to date when it becomes
+// the panel, so launch k2 touches the columns whose distance to the panels, counted in column pairs, is a multiple of D, and folds
+// the min(D, k2) pairs of panels they have missed (K = 64 D per visit): the columns next to the panels are among them every time.
+// chol_trail_tiles: the tiles of those columns (tc counted from the first column right of the panels), column by column.
+__host__ __device__ inline int chol_trail_tiles(int m2, int D) {
+  int n = 0;
+  for (int tc = 0; tc < m2; tc += (tc & 1) ? 2 * D - 1 : 1) n += m2 - tc;
+  return n;
+}
+
+// one trailing tile (t: its index in the launch's list -- the tiles of S, the rhs row, the tiles of X), one wave
+__device__ __forceinline__ void chol2_trailing_tile(double* __restrict__ A, double* __restrict__ y, double* __restrict__ X, const int ld,
+                                                    const int k2, const int m2, const int xlo, const int mx, const int ntile,
+                                                    const int dfr, int t, const int lane) {
+  const int ntrail = ntile + m2;
   int ti_rel = 0;
   const double* Rrow = A;  // the tile's row space
   double* Wrow = A;
   int rb_x = -1;
+  int npend = 1;  // pairs of panels to fold
   if (t >= ntrail) {
     t -= ntrail;
     rb_x = (xlo + t / mx) * CB;
     t %= mx;
     Rrow = X;
     Wrow = X;
+  } else if (dfr > 1) {
+    if (t >= ntile) {
+      t -= ntile;  // the rhs row: every column, every launch
+      ti_rel = m2;
+    } else {
+      int tc = 0;
+      while (t >= m2 - tc) {
+        t -= m2 - tc;
+        tc += (tc & 1) ? 2 * dfr - 1 : 1;
+      }
+      ti_rel = tc + t;
+      t = tc;
+      npend = min(dfr, k2);
+    }
   } else {
     while (true) {
       const int w = ti_rel < m2 ? ti_rel + 1 : m2;
@@ -2125,7 +2117,8 @@ __device__ __forceinline__ void chol_step2_body(double* __restrict__ A, double* 
     }
   }
   const int c0 = (2 * k2 + 2) * CB;
-  const int rb = rb_x >= 0 ? rb_x : c0 + ti_rel * CB, cb = c0 + t * CB, p0 = (2 * k2 - 2) * CB;
+  const int rb = rb_x >= 0 ? rb_x : c0 + ti_rel * CB, cb = c0 + t * CB;
+  int p0 = (2 * k2 - 2 * npend) * CB;
   const int j16 = lane & 15, q = lane >> 4;
   double a[2][16], b[2][16];
   v4d acc[4];  // [2 * ci + ri]
@@ -2156,18 +2149,6 @@ __device__ __forceinline__ void chol_step2_body(double* __restrict__ A, double* 
     return;
   }
   const size_t st = 4 * (size_t)ld;
-#ifdef SFM_DENSE_EXP_NOLOAD
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) a[h][ks] = 1e-9 * (lane + ks), b[h][ks] = 1e-9 * (lane - ks + h);
-#else
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    ld_strided<16>(a[h], A + (size_t)(p0 + q) * ld + cb + 16 * h + j16, st);
-    ld_strided<16>(b[h], Rrow + (size_t)(p0 + q) * ld + rb + 16 * h + j16, st);
-  }
-#endif
 #pragma unroll
   for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
@@ -2177,18 +2158,21 @@ __device__ __forceinline__ void chol_step2_body(double* __restrict__ A, double* 
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[2 * ci + ri][g] = t4[g];
     }
-#ifdef SFM_DENSE_EXP_NOMFMA
+#pragma unroll 1
+  for (; npend > 0; --npend, p0 += 2 * CB) {
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) acc[ks & 3][0] += a[0][ks] + b[0][ks] + a[1][ks] + b[1][ks];
-#else
+    for (int h = 0; h < 2; ++h) {
+      ld_strided<16>(a[h], A + (size_t)(p0 + q) * ld + cb + 16 * h + j16, st);
+      ld_strided<16>(b[h], Rrow + (size_t)(p0 + q) * ld + rb + 16 * h + j16, st);
+    }
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
-    CHOL_MFMA(acc[0], -a[0][ks], b[0][ks]);
-    CHOL_MFMA(acc[1], -a[0][ks], b[1][ks]);
-    CHOL_MFMA(acc[2], -a[1][ks], b[0][ks]);
-    CHOL_MFMA(acc[3], -a[1][ks], b[1][ks]);
+    for (int ks = 0; ks < 16; ++ks) {
+      CHOL_MFMA(acc[0], -a[0][ks], b[0][ks]);
+      CHOL_MFMA(acc[1], -a[0][ks], b[1][ks]);
+      CHOL_MFMA(acc[2], -a[1][ks], b[0][ks]);
+      CHOL_MFMA(acc[3], -a[1][ks], b[1][ks]);
+    }
   }
-#endif
 #pragma unroll
   for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
@@ -2203,11 +2187,54 @@ __device__ __forceinline__ void chol_step2_body(double* __restrict__ A, double* 
     }
 }
 
+// (xb: 0, or the width in tile columns (even) of the diagonal blocks of X that are wanted: the inverse of a diagonal block of L
+// is made of that block alone, so the rows and columns of X outside it need not be formed -- chol_back_block)
+__device__ __forceinline__ void chol_step2_body(double* __restrict__ A, double* __restrict__ y, double* __restrict__ X,
+                                                int ld, int nt, int nxc, int k2, int tiles_per_wg, int* __restrict__ info,
+                                                const int bid, double* sAll, const int xb = 0, const int dfr = 1) {
+  const int m2 = nt - 2 * k2 - 2;  // tile rows below the two panels (the rhs row comes on top)
+  const int npanel = m2 + 2;       // owner, m2 tile rows, rhs
+  const int xlo = xb ? 2 * k2 / xb * xb : 0;  // first row block of X that takes part
+  if (xb) nxc = min(nxc, xlo + xb);
+  const int nx = 2 * k2 + 2 - xlo;  // rows xlo..b of the identity block X (see below) take part as tile rows
+  if (bid < npanel + nx) {
+    if (bid >= npanel) {
+      // X starts as the identity and rides along as nt more tile rows: X <- X L^-T, i.e. L^-T when the
+      // factorisation ends, and the backward substitution becomes the product z = X y.  (Row block
+      // r' is all zero left of column block r' and untouched until its own panel: rows 0..b here.)
+      chol2_panel<false>(A, y, X, ld, k2, info, false, (xlo + bid - npanel) * CB, sAll);
+      chol2_report_timeout(sAll, info);
+      return;
+    }
+    const bool owner = bid == 0;
+    const int r0 = (2 * k2 + 1 + bid) * CB;
+    if (bid == npanel - 1)
+      chol2_panel<true>(A, y, A, ld, k2, info, false, r0, sAll);
+    else
+      chol2_panel<false>(A, y, A, ld, k2, info, owner, r0, sAll);
+    chol2_report_timeout(sAll, info);
+    return;
+  }
+  // ---- trailing tiles (k2 >= 1), one wave each (its four sub-tiles share the operands): tile row
+  // ti_rel in [0, m2] (m2 = rhs) has min(ti_rel + 1, m2) tiles; then the tiles of X: rows 0..a-1 (the
+  // rows that are nonzero in the pending panels) x the m2 column blocks right of the panels
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ntile = dfr > 1 ? chol_trail_tiles(m2, dfr) : m2 * (m2 + 1) / 2;
+  const int mx = max(0, nxc - 2 * k2 - 2);  // column blocks of X right of the panels
+  const int total = ntile + m2 + (2 * k2 - xlo) * mx;
+  // (four tiles per workgroup -- one wave per SIMD: a tile is 64 MFMAs -- while that fits one round of
+  // workgroups on the device; every workgroup of this kernel holds a CU's LDS)
+  if (wave >= tiles_per_wg) return;
+  const int t = (bid - npanel - nx) * tiles_per_wg + wave;
+  if (t >= total) return;
+  chol2_trailing_tile(A, y, X, ld, k2, m2, xlo, mx, ntile, dfr, t, lane);
+}
+
 __global__ __launch_bounds__(C2_WAVES * 64) void chol_step2(double* __restrict__ A, double* __restrict__ y,
                                                             double* __restrict__ X, int ld, int nt, int k2,
-                                                            int tiles_per_wg, int* __restrict__ info, int xb) {
+                                                            int tiles_per_wg, int* __restrict__ info, int xb, int dfr) {
   extern __shared__ __attribute__((aligned(16))) double sAll[];  // C2_LDS_BYTES, see C2_OFF_*
-  chol_step2_body(A, y, X, ld, nt, nt, k2, tiles_per_wg, info, (int)blockIdx.x, sAll, xb);
+  chol_step2_body(A, y, X, ld, nt, nt, k2, tiles_per_wg, info, (int)blockIdx.x, sAll, xb, dfr);
 }
 
 // Several independent matrices ("chains": the interiors of a dissected camera graph, see NdPlan) at the same
@@ -2269,7 +2296,7 @@ __global__ __launch_bounds__(1024) void chol_apply_inverse(const double* __restr
 // Launch K applies z_{K+1} to every tile column left of block K+1 (one workgroup per tile column, sums in a fixed order) and the
 // workgroups of block K's own columns then write their part X(., j) w_j of z_K; the parts are added, in column order, by every
 // workgroup of the next launch (one more launch for z_0): no counters, and the same S and g give the same z bit for bit.
-constexpr int DENSE_XB = 8, DENSE_XB_MIN_NT = 64;
+constexpr int DENSE_XB = 8, DENSE_XB_MIN_NT = 64, DENSE_DEFER4_MIN_NT = 100;
 __global__ __launch_bounds__(256) void chol_x_reset(double* __restrict__ X, int ld, int nt, int xb) {
   const int j = blockIdx.x, r0 = j / xb * xb * CB, r1 = min(nt, (j / xb + 1) * xb) * CB;
   for (int e = threadIdx.x; e < CB * (r1 - r0); e += 256) {
@@ -4592,7 +4619,7 @@ static int ba_reduced_solve_nd(sfmhip_ba* b) {
     chol_launch_shape(sp.N, sp.N, k2, &npan, &ntrail);
     while (tpw < C2_WAVES && npan + (ntrail + tpw - 1) / tpw > b->ctx->n_cu) ++tpw;
     hipLaunchKernelGGL(chol_step2, dim3(npan + (ntrail + tpw - 1) / tpw), dim3(C2_WAVES * 64), C2_LDS_BYTES, st, sp.M, sp.y,
-                       sp.X, sp.ld, sp.N, k2, tpw, d.info, 0);
+                       sp.X, sp.ld, sp.N, k2, tpw, d.info, 0, 1);
   }
   // z_S = L_SS^-T y_S;  w_i = y_i - L_Si^T z_S;  z_i = L_ii^-T w_i
   hipLaunchKernelGGL(nd_xy, dim3(sp.N, 1), dim3(1024), 0, st, ns, P, d.z);
@@ -4618,17 +4645,21 @@ static int ba_reduced_solve(sfmhip_ba* b) {
       SFM_HIP_TRY(hipFuncSetAttribute((const void*)chol_step2, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS_BYTES));
       b->chol_attr_set = true;
     }
-    const int xb = b->dense_xb;
+    static const int dfr_env = getenv("SFMHIP_BA_DENSE_DEFER") ? atoi(getenv("SFMHIP_BA_DENSE_DEFER")) : 0;  // (measurement)
+    const int xb = b->dense_xb, dfr = !xb ? 1 : dfr_env > 0 ? dfr_env : nt >= DENSE_DEFER4_MIN_NT ? 4 : 2;
     for (int k2 = 0; 2 * k2 < nt; ++k2, ++nchol) {
       const int m2 = nt - 2 * k2 - 2;
       // launch 0 has no pending update; later launches: the tiles right of the panels, and those of X
       const int xlo = xb ? 2 * k2 / xb * xb : 0, mx = xb ? std::max(0, std::min(nt, xlo + xb) - 2 * k2 - 2) : m2;
-      const int ntrail = k2 == 0 ? 0 : m2 * (m2 + 1) / 2 + m2 + (2 * k2 - xlo) * mx;
+      const int ntrail = k2 == 0 ? 0 : (dfr > 1 ? chol_trail_tiles(m2, dfr) : m2 * (m2 + 1) / 2) + m2 + (2 * k2 - xlo) * mx;
       const int npan = m2 + 2 + 2 * k2 + 2 - xlo;
       int tpw = 4;  // trailing tiles per workgroup: the fewest that keep the launch to one round of workgroups
       while (tpw < C2_WAVES && npan + (ntrail + tpw - 1) / tpw > b->ctx->n_cu) ++tpw;
-      hipLaunchKernelGGL(chol_step2, dim3(npan + (ntrail + tpw - 1) / tpw), dim3(C2_WAVES * 64), C2_LDS_BYTES, st, A, y,
-                         d.xinv, d.ld, nt, k2, tpw, d.info, xb);
+      // (deferred updates, K = 256 per visit: a workgroup of eleven such visits outlasts the panel workgroups twice over and
+      // the launch ends on the stragglers of a second round -- four visits, one per SIMD, measured best: scripts/gpu_dense_sizes.py)
+      if (dfr >= 4) tpw = 4;
+      hipLaunchKernelGGL(chol_step2, dim3(npan + (ntrail + tpw - 1) / tpw), dim3(C2_WAVES * 64), C2_LDS_BYTES, st, A, y, d.xinv, d.ld, nt, k2,
+                         tpw, d.info, xb, dfr);
     }
   }
   int nbs = 1;

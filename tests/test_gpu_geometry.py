@@ -174,14 +174,16 @@ def test_dissected_reduced_system_walks_the_dense_iterates(ctx, orc, monkeypatch
 
 
 @pytest.mark.parametrize("shape,nd", [((96, 6000, 6), "0"), ((96, 6000, 6), "1"), ((180, 8000, 8), "0"), ((560, 8000, 8), "1"),
-                                      ((1400, 9000, 8), "0"), ((6, 300, 4), "2"), ((50, 5000, 10), "2"), ((96, 6000, 6), "2"),
+                                      ((350, 6000, 8), "0"), ((560, 8000, 8), "0"), ((1400, 9000, 8), "0"), ((6, 300, 4), "2"), ((50, 5000, 10), "2"), ((96, 6000, 6), "2"),
                                       ((200, 20000, 10), "2"), ((560, 8000, 8), "2"), ((1400, 9000, 8), "2")])
 def test_reduced_step_solves_the_reduced_system(ctx, monkeypatch, shape, nd):
     """(S + D/r) z = g, z from the solver's own factorisation (dense; dissected: chains + separator; the front tree),
     against numpy on the system the solver hands out.  560 cameras: six chains whose launches exceed one round of
     workgroups; 1400 cameras dense: 266 panel workgroups on 256 CUs (no workgroup of a launch may depend on another
     one's being resident: until round 2 the owner overwrote the diagonal tiles the others read); the front tree from one
-    front (6 cameras) to 127 fronts in seven levels (1400 cameras)."""
+    front (6 cameras) to 127 fronts in seven levels (1400 cameras).  Dense from 64 tile columns on: X only inside diagonal
+    blocks of 8 tile columns, block-by-block backward substitution, trailing tiles visited every 2nd (350 cameras: 66 tile
+    columns, a last block of two) or 4th launch (560: 106 columns; 1400: 264) with the panels they missed folded at once."""
     monkeypatch.setenv("SFMHIP_BA_ND", nd)
     nc, npt, k = shape
     pb = synth.ba_problem(nc, npt, k, seed=5)
@@ -195,6 +197,22 @@ def test_reduced_step_solves_the_reduced_system(ctx, monkeypatch, shape, nd):
     zr = np.linalg.solve(S, g)
     assert np.abs(z - zr).max() <= 1e-9 * np.abs(zr).max()
     prob.close()
+
+
+def test_large_dense_solve_gives_the_same_answer_every_time(ctx, monkeypatch):
+    """The block-by-block backward substitution adds its parts in a fixed order and the deferred trailing updates fold the
+    panels a tile missed in panel order: the same system must give the same bits, launch after launch."""
+    monkeypatch.setenv("SFMHIP_BA_ND", "0")
+    for (nc, npt, k) in ((350, 6000, 8), (560, 8000, 8)):
+        pb = synth.ba_problem(nc, npt, k, seed=5)
+        prob = bundle.BaProblem(nc, npt, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
+        prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+        z0, failed = prob.reduced_step(1e4)
+        assert failed == 0
+        for rep in range(20):
+            z, failed = prob.reduced_step(1e4)
+            assert failed == 0 and np.array_equal(z, z0), (nc, rep)
+        prob.close()
 
 
 def test_front_tree_gives_the_same_answer_every_time(ctx, monkeypatch):
