@@ -3489,8 +3489,12 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
     const int ld = b->ld, fo = 6 * n_cam;
     const long long ssz = (long long)b->ssz, o_g = ssz, o_gF = ssz + ld, o_dc = ssz + 2LL * ld, o_sc = ssz + 3LL * ld;
     std::vector<std::pair<long long, unsigned>> ent[2];  // (destination, source | sign)
-    // rows of S by their own kernel role while a row-long accumulator per wave fits the default LDS limit
-    const bool use_rows = (size_t)(ld + 3) * 8 <= 65536 && !(getenv("SFMHIP_BA_GATHER_ROWS") && atoi(getenv("SFMHIP_BA_GATHER_ROWS")) == 0);
+    // rows of S by their own kernel role while a row-long accumulator per wave fits the default LDS limit -- and while the row is
+    // short: a wave zeroes and scans its row's ld entries whatever the row holds, and at 640 cameras (ld 3904) that outweighs what
+    // the row-wise reads save (rings, scripts/gpu_gather_ab.py: 400 cameras 5111 it/s by rows against 5006 by destinations, 640:
+    // 3458 / 3811, 1000: 2426 / 2964).  SFMHIP_BA_GATHER_ROWS = 0 / 2: never / whenever it fits (measurement)
+    const int rows_env = getenv("SFMHIP_BA_GATHER_ROWS") ? atoi(getenv("SFMHIP_BA_GATHER_ROWS")) : 1;
+    const bool use_rows = (size_t)(ld + 3) * 8 <= 65536 && rows_env != 0 && (ld <= 3072 || rows_env == 2);
     b->grow_waves = (size_t)(ld + 3) * 8 * 4 <= 65536 ? 4 : (size_t)(ld + 3) * 8 * 2 <= 65536 ? 2 : 1;
     if (use_rows) {
       std::vector<int> cntr((size_t)fo + 1, 0);
