@@ -554,6 +554,24 @@ def main():
         _, csr = orc.match_many_checksum(imgs, pairs[:1], threads=1)
         cpu_rowwise1_s = time.perf_counter() - t0
         assert np.array_equal(csr, g_cs[:1])
+        # the library the reference links, where the box has it (it does not in the build image nor on the GPU boxes: SURVEY 8d's
+        # optional "library CPU path"): the reference's own call, src/Sfm.cpp:590-608, on the head of the same sample
+        library = None
+        try:
+            import cv2
+        except Exception:
+            cv2 = None
+        if cv2 is not None:
+            bf, nlib, lib_counts = cv2.BFMatcher(cv2.NORM_L2), min(npairs, 64), []
+            f32 = {i: np.asarray(imgs[i], dtype=np.float32) for ij in pairs[:nlib] for i in ij}
+            t0 = time.perf_counter()
+            for (i, j) in pairs[:nlib]:
+                knn = bf.knnMatch(f32[i], f32[j], k=2)
+                lib_counts.append(sum(1 for m in knn if len(m) == 2 and m[0].distance <= 0.8 * m[1].distance))
+            lib_s = time.perf_counter() - t0
+            library = {"what": "cv2.BFMatcher(NORM_L2).knnMatch(k=2) + 0.8 ratio test per pair (src/Sfm.cpp:590-608)",
+                       "pairs": nlib, "pairs_per_s": round(nlib / lib_s, 3), "threads": int(cv2.getNumThreads()),
+                       "opencv": cv2.__version__, "match_counts_equal_gpu": bool(lib_counts == [int(c) for c in g_cnt[:nlib]])}
         # BA: one thread (Ceres' default num_threads, nothing at src/BundleAdjustment.cpp:115-121 overrides it) and all cores
         ba_args = (pb["cams0"], pb["pts0"], pb["focal0"], pb["obs_cam"], pb["obs_pt"], pb["obs_xy"])
         cpu_ba_s, _ = orc.ba_time_iterations(*ba_args, args.cpu_ba_iters)
@@ -578,6 +596,7 @@ def main():
                         "ba_threaded_iterations_per_s": round(args.cpu_ba_iters / cpu_ba_all_s, 4), "ba_threads": ba_threads,
                         "ms_per_step_extrapolated": round(cpu_step_ms, 1),
                         "gpu_over_cpu_step": round(cpu_step_ms / (ms_match + ms_ba), 1),
+                        "library": library,   # (None: no OpenCV on this box)
                         "note": "a reported baseline, not the target: the matcher leg is organised as cv::batchDistance under "
                                 "parallel_for_ (query rows in parallel, train tiles in cache, AVX FMA sum of squared "
                                 "differences, no atomics); the BA leg restates Ceres' DENSE_SCHUR iteration (Eigen-style "

@@ -347,9 +347,10 @@ bool read_file(const std::string& path, std::vector<uint8_t>& out) {
 // triangle-filter upsampling of 2:1 subsampled chroma (jdsample.c: h2v1 (3 a + b + 1|2) >> 2, h2v2 (3 (3 a + b) + (3 c + d)
 // + 8|7) >> 4, h1v2 (3 a + b + 1|2) >> 2 down the columns, edge rows / columns replicated), scans interleaved or one per
 // component, 0xFF fill bytes before markers, YCbCr -> RGB with the 16-bit fixed-point tables of jdcolor.c.  Checked
-// against PIL's decoder (libjpeg-turbo, same algorithms) on generated files (tests/test_host_io.py).  Not decoded:
-// progressive (SOF2), arithmetic coding, 12 bit, CMYK -- the load fails with a message, as cv::imread would return an
-// empty Mat for a file its libjpeg cannot read.
+// against PIL's decoder (libjpeg-turbo, same algorithms) on generated files (tests/test_host_io.py).  Progressive frames
+// (SOF2; round 4): the scans of jdphuff.c -- DC / AC, first pass / refinement, end-of-band runs -- summed into the blocks'
+// coefficients, transformed when the last scan is in.  Not decoded: arithmetic coding, 12 bit, CMYK, lossless -- the load
+// fails with a message, as cv::imread would return an empty Mat for a file its libjpeg cannot read.
 struct JpegHuff {
   uint8_t bits[17];
   uint8_t vals[256];
@@ -530,7 +531,13 @@ bool decode_jpeg(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) 
     int dw, dhh; // downsampled_width / height (true sizes)
     bool coded = false;  // a scan has carried this component
     std::vector<uint8_t> plane;
+    // progressive frames: the coefficients of every block (natural order), summed up scan by scan; the quantisation table as it
+    // stood at the component's first scan (jdinput.c latch_quant_tables)
+    std::vector<int32_t> coef;
+    uint16_t q[64];
+    bool q_latched = false;
   } comp[3];
+  bool progressive = false;
   int ncomp = 0, width = 0, height = 0, restart = 0, adobe_transform = -1;
   int hmax = 1, vmax = 1, n_scans = 0;
   bool have_sof = false, planes_ready = false;
@@ -593,7 +600,8 @@ bool decode_jpeg(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) 
         h.build();
         h.present = true;
       }
-    } else if (mk == 0xC0 || mk == 0xC1) {  // SOF0 / SOF1
+    } else if (mk == 0xC0 || mk == 0xC1 || mk == 0xC2) {  // SOF0 / SOF1 / SOF2 (progressive, Huffman)
+      progressive = mk == 0xC2;
       if (have_sof) {
         why = "corrupt JPEG (second frame header)";
         return false;
@@ -620,8 +628,8 @@ bool decode_jpeg(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) 
         }
       }
       have_sof = true;
-    } else if (mk == 0xC2 || (mk >= 0xC3 && mk <= 0xCF && mk != 0xC4 && mk != 0xC8 && mk != 0xCC)) {
-      why = mk == 0xC2 ? "progressive JPEG (not supported)" : "unsupported JPEG coding process";
+    } else if (mk >= 0xC3 && mk <= 0xCF && mk != 0xC4 && mk != 0xC8 && mk != 0xCC) {
+      why = "unsupported JPEG coding process";  // (lossless, hierarchical, arithmetic coding)
       return false;
     } else if (mk == 0xDD) {
       if (dl >= 2) restart = (d[0] << 8) | d[1];
@@ -641,15 +649,27 @@ bool decode_jpeg(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) 
         int c = -1;
         for (int j = 0; j < ncomp; ++j)
           if (comp[j].id == d[1 + 2 * k]) c = j;
-        if (c < 0 || (k > 0 && c <= sc[k - 1]) || comp[c].coded) {  // (frame order, every component coded once: a sequential file)
+        if (c < 0 || (k > 0 && c <= sc[k - 1]) || (comp[c].coded && !progressive)) {  // (frame order; sequential: every component coded once)
           why = "unsupported JPEG scan layout";
           return false;
         }
         sc[k] = c;
         comp[c].td = d[2 + 2 * k] >> 4;
         comp[c].ta = d[2 + 2 * k] & 15;
-        if (comp[c].td > 3 || comp[c].ta > 3 || !hdc[comp[c].td].present || !hac[comp[c].ta].present || !qt_set[comp[c].tq]) {
+        if (comp[c].td > 3 || comp[c].ta > 3 || !qt_set[comp[c].tq] ||
+            (!progressive && (!hdc[comp[c].td].present || !hac[comp[c].ta].present))) {
           why = "JPEG scan refers to a missing table";
+          return false;
+        }
+      }
+      // spectral selection and successive approximation (progressive scans; a sequential scan carries 0, 63, 0, 0)
+      const int Ss = d[1 + 2 * ns], Se = d[2 + 2 * ns], Ah = d[3 + 2 * ns] >> 4, Al = d[3 + 2 * ns] & 15;
+      if (progressive) {
+        bool ok = Ss <= Se && Se <= 63 && Al <= 13 && Ah <= 13 && (Ah == 0 || Ah == Al + 1) && (Ss == 0 ? Se == 0 : ns == 1);
+        for (int k = 0; ok && k < ns; ++k)
+          ok = Ss == 0 ? (Ah != 0 || hdc[comp[sc[k]].td].present) : hac[comp[sc[k]].ta].present;
+        if (!ok) {
+          why = "unsupported progressive JPEG scan";
           return false;
         }
       }
@@ -668,15 +688,23 @@ bool decode_jpeg(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) 
           comp[c].dhh = (height * comp[c].v + vmax - 1) / vmax;
           // (blocks no scan reaches stay at the level shift, as libjpeg's zeroed coefficient arrays decode)
           comp[c].plane.assign((size_t)comp[c].bw * 8 * comp[c].bh * 8, 128);
+          if (progressive) comp[c].coef.assign((size_t)comp[c].bw * comp[c].bh * 64, 0);
         }
         planes_ready = true;
       }
+      for (int k = 0; k < ns; ++k)
+        if (!comp[sc[k]].q_latched) {
+          memcpy(comp[sc[k]].q, qt[comp[sc[k]].tq], sizeof comp[sc[k]].q);
+          comp[sc[k]].q_latched = true;
+        }
       const bool inter = ns > 1;
       const int mcux = inter ? (width + 8 * hmax - 1) / (8 * hmax) : (comp[sc[0]].dw + 7) / 8;
       const int mcuy = inter ? (height + 8 * vmax - 1) / (8 * vmax) : (comp[sc[0]].dhh + 7) / 8;
       // ---- entropy-coded data: MCU by MCU
       JpegBits br{f.data(), f.size(), pos + 2 + len};
       int pred[3] = {0, 0, 0}, until_restart = restart;
+      unsigned eobrun = 0;  // (progressive AC scans: blocks still to come that the last end-of-band code covers)
+      auto sat = [](long v) { return (int32_t)std::max(-(1L << 20), std::min(1L << 20, v)); };  // (corrupt streams must not overflow)
       for (int my = 0; my < mcuy; ++my)
         for (int mx = 0; mx < mcux; ++mx) {
           if (restart && until_restart == 0) {
@@ -685,6 +713,7 @@ bool decode_jpeg(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) 
             while (br.pos + 1 < f.size() && !(f[br.pos] == 0xFF && f[br.pos + 1] >= 0xD0 && f[br.pos + 1] <= 0xD7)) ++br.pos;
             br.pos += 2;
             pred[0] = pred[1] = pred[2] = 0;
+            eobrun = 0;
             until_restart = restart;
           }
           for (int k = 0; k < ns; ++k) {
@@ -692,6 +721,91 @@ bool decode_jpeg(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) 
             const int nbx = inter ? comp[c].h : 1, nby = inter ? comp[c].v : 1;
             for (int by = 0; by < nby; ++by)
               for (int bx = 0; bx < nbx; ++bx) {
+                if (progressive) {
+                  // jdphuff.c: the four kinds of scan, into the block's coefficients
+                  int32_t* cf = &comp[c].coef[((size_t)(my * nby + by) * comp[c].bw + (mx * nbx + bx)) * 64];
+                  if (Ss == 0) {
+                    if (Ah == 0) {  // DC, first pass: the difference, scaled
+                      const int t = br.decode(hdc[comp[c].td]);
+                      if (t < 0 || t > 15) {
+                        why = "corrupt JPEG data (DC code)";
+                        return false;
+                      }
+                      pred[c] = sat((long)pred[c] + (t ? jpeg_extend(br.get(t), t) : 0));
+                      cf[0] = sat((long)pred[c] * (1L << Al));
+                    } else if (br.get(1)) {  // DC, refinement: one more bit
+                      cf[0] |= 1 << Al;
+                    }
+                    continue;
+                  }
+                  const int32_t p1 = 1 << Al, m1 = -(1 << Al);
+                  if (Ah == 0) {  // AC, first pass
+                    if (eobrun > 0) {
+                      --eobrun;
+                      continue;
+                    }
+                    for (int kk = Ss; kk <= Se; ++kk) {
+                      const int rs = br.decode(hac[comp[c].ta]);
+                      if (rs < 0) {
+                        why = "corrupt JPEG data (AC code)";
+                        return false;
+                      }
+                      const int r = rs >> 4, sz = rs & 15;
+                      if (sz) {
+                        kk += r;
+                        if (kk > 63) {
+                          why = "corrupt JPEG data (run past the block)";
+                          return false;
+                        }
+                        cf[zz[kk]] = sat((long)jpeg_extend(br.get(sz), sz) * (1L << Al));
+                      } else if (r == 15) {
+                        kk += 15;
+                      } else {  // end of band for this and the next eobrun blocks
+                        eobrun = 1u << r;
+                        if (r) eobrun += (unsigned)br.get(r);
+                        --eobrun;
+                        break;
+                      }
+                    }
+                    continue;
+                  }
+                  // AC, refinement: new coefficients of magnitude 1 << Al, and one correction bit for every coefficient that is
+                  // already nonzero, in the order the runs pass over them
+                  auto correct = [&](int32_t& v) {
+                    if (br.get(1) && (v & p1) == 0) v += v >= 0 ? p1 : m1;
+                  };
+                  int kk = Ss;
+                  if (eobrun == 0) {
+                    for (; kk <= Se; ++kk) {
+                      const int rs = br.decode(hac[comp[c].ta]);
+                      if (rs < 0) {
+                        why = "corrupt JPEG data (AC code)";
+                        return false;
+                      }
+                      int r = rs >> 4;
+                      int32_t nv = 0;
+                      if (rs & 15) {
+                        nv = br.get(1) ? p1 : m1;  // (the size is 1 in a valid stream)
+                      } else if (r != 15) {
+                        eobrun = 1u << r;
+                        if (r) eobrun += (unsigned)br.get(r);
+                        break;
+                      }
+                      for (; kk <= Se; ++kk) {
+                        int32_t& v = cf[zz[kk]];
+                        if (v != 0) correct(v);
+                        else if (--r < 0) break;
+                      }
+                      if (nv && kk <= 63) cf[zz[kk]] = nv;
+                    }
+                  }
+                  if (eobrun > 0) {
+                    for (; kk <= Se; ++kk)
+                      if (cf[zz[kk]] != 0) correct(cf[zz[kk]]);
+                    --eobrun;
+                  }
+                  continue;
+                }
                 int blk[64];
                 memset(blk, 0, sizeof blk);
                 const int t = br.decode(hdc[comp[c].td]);
@@ -735,7 +849,7 @@ bool decode_jpeg(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) 
       while (pos + 1 < f.size() && !(f[pos] == 0xFF && f[pos + 1] != 0 && f[pos + 1] != 0xFF && !(f[pos + 1] >= 0xD0 && f[pos + 1] <= 0xD7))) ++pos;
       bool all = true;
       for (int c = 0; c < ncomp; ++c) all = all && comp[c].coded;
-      if (all) break;
+      if (all && !progressive) break;  // (a progressive frame goes on until EOI)
       continue;
     } else if (mk == 0xD9) {
       break;
@@ -745,6 +859,19 @@ bool decode_jpeg(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) 
   if (!n_scans) {
     why = "JPEG without a scan";
     return false;
+  }
+  if (progressive) {
+    // every scan is in: dequantise and transform what the blocks hold.  (libjpeg smooths blocks whose first five AC
+    // coefficients are not fully refined when output starts, jdcoefct.c; for a file that carries all its scans -- what
+    // encoders write -- there are none, and the output is that of the sequential path on the same coefficients.)
+    for (int c = 0; c < ncomp; ++c)
+      for (int by = 0; by < comp[c].bh; ++by)
+        for (int bx = 0; bx < comp[c].bw; ++bx) {
+          const int32_t* cf = &comp[c].coef[((size_t)by * comp[c].bw + bx) * 64];
+          int blk[64];
+          for (int j = 0; j < 64; ++j) blk[j] = (int)std::max(-(1L << 26), std::min(1L << 26, (long)cf[j] * comp[c].q[j]));
+          jpeg_idct_islow(blk, &comp[c].plane[(size_t)by * 8 * comp[c].bw * 8 + bx * 8], comp[c].bw * 8);
+        }
   }
   // (a file that ends before every component was coded decodes like libjpeg's premature-EOI case: what is missing is gray)
   // ---- upsampling (jdsample.c) to full resolution planes of width x height

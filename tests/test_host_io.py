@@ -450,17 +450,63 @@ def test_jpeg_rarer_layouts_match_libjpeg(tmp_path):
         assert np.array_equal(bgr, want), (name, int(np.abs(bgr.astype(int) - want.astype(int)).max()), float((bgr != want).mean()))
 
 
+def test_progressive_jpeg_matches_libjpeg(tmp_path):
+    """cv::imread reads progressive files (src/Sfm.cpp:150); SOF2 frames as PIL's libjpeg-turbo writes them (its standard
+    scan script: DC first / refinement, AC bands first / refinement with end-of-band runs) at several samplings, qualities and
+    sizes incl. ones that are not a multiple of the MCU, with restart intervals, and gray: byte-equal to PIL's decode."""
+    import io
+    rng = np.random.default_rng(21)
+    d = tmp_path / "imgs"
+    d.mkdir()
+    yy, xx = np.mgrid[0:97, 0:131]
+    smooth = np.stack([128 + 100 * np.sin(xx / 9.0 + c) * np.cos(yy / 7.0 - c) for c in range(3)], axis=-1)
+    base = np.clip(smooth + rng.normal(0, 12, smooth.shape), 0, 255).astype(np.uint8)
+    cases = [("a444", dict(quality=90, subsampling=0), base), ("b422", dict(quality=75, subsampling=1), base),
+             ("c420", dict(quality=60, subsampling=2), base), ("d420_q30", dict(quality=30, subsampling=2), base[:50, :70]),
+             ("e420_q98", dict(quality=98, subsampling=2), base[:33, :17]), ("f_tiny", dict(quality=85, subsampling=2), base[:9, :5]),
+             ("g_gray", dict(quality=80), base[:, :, 0]), ("h_noise", dict(quality=85, subsampling=0), rng.integers(0, 256, (40, 56, 3), dtype=np.uint8))]
+    names = []
+    for name, kw, arr in cases:
+        buf = io.BytesIO()
+        PIL.fromarray(arr).save(buf, "JPEG", progressive=True, **kw)
+        data = buf.getvalue()
+        assert b"\xff\xc2" in data
+        (d / f"{name}.jpg").write_bytes(data)
+        names.append(f"{name}.jpg")
+    # restart intervals inside progressive scans: DRI inserted by hand is not possible without re-encoding; PIL's encoder takes
+    # `restart_marker_blocks` / `restart_marker_rows` from Pillow 9.4 on -- used when it does
+    try:
+        buf = io.BytesIO()
+        PIL.fromarray(base).save(buf, "JPEG", progressive=True, quality=80, subsampling=2, restart_marker_blocks=5)
+        if b"\xff\xdd" in buf.getvalue():
+            (d / "i_restart.jpg").write_bytes(buf.getvalue())
+            names.append("i_restart.jpg")
+    except TypeError:
+        pass
+    (tmp_path / "cam.xml").write_text(XML)
+    ok_img, ok_cal, imgs, *_ = _run(tmp_path, d, tmp_path / "cam.xml")
+    assert ok_img == 1 and len(imgs) == len(names)
+    for name, (bgr, gray) in zip(sorted(names), imgs):
+        want = _pil_bgr(d / name)
+        assert bgr.shape == want.shape, name
+        assert np.array_equal(bgr, want), (name, int(np.abs(bgr.astype(int) - want.astype(int)).max()), float((bgr != want).mean()))
+
+
 def test_jpeg_failures_are_reported(tmp_path):
     rng = np.random.default_rng(8)
     (tmp_path / "cam.xml").write_text(XML)
     arr = rng.integers(0, 256, (40, 40, 3), dtype=np.uint8)
-    for tag, mutate in (("prog", None), ("trunc", lambda b: b[:len(b) // 2]), ("garbage", lambda b: b"\xff\xd8" + b"junk" * 20)):
+    def to_arithmetic(b):
+        # (no encoder here writes arithmetic-coded files: the frame marker alone is turned into SOF9, which the loader must refuse)
+        i = b.index(b"\xff\xc0")
+        return b[:i] + b"\xff\xc9" + b[i + 2:]
+    for tag, mutate in (("arith", to_arithmetic), ("trunc", lambda b: b[:len(b) // 2]), ("garbage", lambda b: b"\xff\xd8" + b"junk" * 20)):
         d = tmp_path / tag
         d.mkdir()
         PIL.fromarray(arr).save(d / "ok.png")
         import io
         buf = io.BytesIO()
-        PIL.fromarray(arr).save(buf, "JPEG", quality=80, progressive=(tag == "prog"))
+        PIL.fromarray(arr).save(buf, "JPEG", quality=80)
         data = buf.getvalue() if mutate is None else mutate(buf.getvalue())
         (d / "x.jpg").write_bytes(data)
         ok_img, _, _, _, _, r = _run(tmp_path, d, tmp_path / "cam.xml")

@@ -87,8 +87,8 @@ def test_host_io_under_asan_ubsan(tmp_path):
 
 
 def test_jpeg_decoder_under_asan_ubsan(tmp_path):
-    """the JPEG decoder of imagesLOAD on good, truncated and bit-flipped streams (headers, tables and entropy-coded data
-    alike): it fails cleanly or decodes garbage pixels, never reads or writes out of bounds"""
+    """the JPEG decoder of imagesLOAD on good, truncated and bit-flipped streams (sequential and progressive; headers, tables
+    and entropy-coded data alike): it fails cleanly or decodes garbage pixels, never reads or writes out of bounds"""
     import io
     import numpy as np
     from PIL import Image
@@ -99,12 +99,13 @@ def test_jpeg_decoder_under_asan_ubsan(tmp_path):
     rng = np.random.default_rng(10)
     arr = np.clip(rng.normal(128, 60, (70, 90, 3)), 0, 255).astype(np.uint8)
     goods = []
-    for kw in (dict(quality=80, subsampling=2), dict(quality=90, subsampling=0, restart_marker_blocks=2), dict(quality=70, subsampling=1)):
+    for kw in (dict(quality=80, subsampling=2), dict(quality=90, subsampling=0, restart_marker_blocks=2), dict(quality=70, subsampling=1),
+               dict(quality=85, subsampling=2, progressive=True), dict(quality=60, subsampling=0, progressive=True, restart_marker_blocks=3)):
         b = io.BytesIO()
         Image.fromarray(arr).save(b, "JPEG", **kw)
         goods.append(b.getvalue())
-    for k in range(36):
-        good = goods[k % 3]
+    for k in range(60):
+        good = goods[k % 5]
         bad = tmp_path / ("jbad%d" % k)
         bad.mkdir()
         (bad / "a.jpg").write_bytes(good)
