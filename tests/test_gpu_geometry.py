@@ -522,9 +522,10 @@ def _two_rank_worker(rank, world, port, out_dir, shape=(16, 6000, 6, 44)):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shape,nd", [((16, 6000, 6, 44), None), ((96, 9000, 5, 45), "1")])
+@pytest.mark.parametrize("shape,nd", [((16, 6000, 6, 44), None), ((96, 9000, 5, 45), "1"), ((350, 5000, 6, 46), "0")])
 def test_two_ranks_share_the_device_and_run_the_sharded_solver(ctx, tmp_path, monkeypatch, shape, nd):
-    """(second case: the dissected reduced system, whose camera graph is the union over the ranks)
+    """(second case: the dissected reduced system, whose camera graph is the union over the ranks; third: a large dense
+    one -- X in diagonal blocks, block-by-block backward substitution, deferred trailing updates -- replicated on both ranks)
     The N>1 data path with the device kernels as the per-rank engine: two processes (gloo, the all-reduce
     staged through the host because RCCL refuses two ranks on one device) each hold half the points; pack,
     exchange, unpack, redundant reduced solve and per-rank back-substitution must walk the iterates of one
