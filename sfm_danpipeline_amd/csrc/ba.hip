@@ -2289,14 +2289,14 @@ __global__ __launch_bounds__(1024) void chol_apply_inverse(const double* __restr
 }
 
 // ---------------------------------------------------------------- backward substitution by diagonal blocks
-// Large dense systems (no dissection, nt >= DENSE_XB_MIN_NT): the rows of X outside the diagonal blocks of xb tile columns are
+// Large dense systems (no dissection, nt >= DENSE_XB_MIN_NT -- 250 cameras: +3 % there, +5 % at 330, +55 % at 640): the rows of X outside the diagonal blocks of xb tile columns are
 // half of all trailing tiles of the factorisation and buy only the one-product backward substitution; with X kept inside the
 // diagonal blocks (chol_step2_body, xb) the substitution walks the blocks from the last to the first, one launch each:
 //   z_K = (L_KK)^-T w_K,   w_J -= L(K, J)^T z_K for every block J < K       (w = y on entry)
 // Launch K applies z_{K+1} to every tile column left of block K+1 (one workgroup per tile column, sums in a fixed order) and the
 // workgroups of block K's own columns then write their part X(., j) w_j of z_K; the parts are added, in column order, by every
 // workgroup of the next launch (one more launch for z_0): no counters, and the same S and g give the same z bit for bit.
-constexpr int DENSE_XB = 8, DENSE_XB_MIN_NT = 64, DENSE_DEFER4_MIN_NT = 100;
+constexpr int DENSE_XB = 8, DENSE_XB_MIN_NT = 48, DENSE_DEFER4_MIN_NT = 100;
 __global__ __launch_bounds__(256) void chol_x_reset(double* __restrict__ X, int ld, int nt, int xb) {
   const int j = blockIdx.x, r0 = j / xb * xb * CB, r1 = min(nt, (j / xb + 1) * xb) * CB;
   for (int e = threadIdx.x; e < CB * (r1 - r0); e += 256) {
