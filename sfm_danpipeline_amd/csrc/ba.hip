@@ -3755,6 +3755,10 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
     b->dense_xb = xb_env == 0 ? 0 : (xb_env > 0 || nt >= DENSE_XB_MIN_NT) ? DENSE_XB : 0;
     if (b->dense_xb) {
       BA_A(b->d_back_part, 2 * DENSE_XB * DENSE_XB * CB);  // (two sets: a launch reads the one the launch before wrote)
+      // X outside its diagonal blocks is never written -- but the panel workgroups of a block's first pair of panels read the
+      // block's rows at the pending columns, which lie in the block before: zero once and for all (chol_x_reset clears the
+      // blocks themselves at every linearisation)
+      if (rc == SFMHIP_OK && hipMemset(d.xinv, 0, sizeof(double) * b->ssz) != hipSuccess) rc = SFMHIP_ERR_HIP;
     }
   }
   BA_A(b->d_pair_ptr, pair_ptr.size());

@@ -208,7 +208,8 @@ def test_large_dense_solve_gives_the_same_answer_every_time(ctx, monkeypatch):
         prob = bundle.BaProblem(nc, npt, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
         prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
         z0, failed = prob.reduced_step(1e4)
-        assert failed == 0
+        S, g, _ = prob.reduced_system(1e4)
+        assert failed == 0 and np.linalg.norm(S @ z0 - g) <= 1e-12 * np.linalg.norm(g)
         for rep in range(20):
             z, failed = prob.reduced_step(1e4)
             assert failed == 0 and np.array_equal(z, z0), (nc, rep)
