@@ -189,8 +189,8 @@ bool decode_png(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) {
     else if (!memcmp(tag, "IEND", 4)) break;
     pos += 12 + len;
   }
-  if (!w || !h || interlace) {
-    why = interlace ? "interlaced PNG (not supported)" : "no IHDR";
+  if (!w || !h || interlace > 1) {
+    why = interlace ? "unknown PNG interlace method" : "no IHDR";
     return false;
   }
   const int nch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
@@ -209,34 +209,70 @@ bool decode_png(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) {
     why = "image too large";
     return false;
   }
+  // Adam7 (interlace method 1, which libpng / cv::imread read like any other file): seven reduced images, each filtered on
+  // its own -- pass p holds the pixels (x0 + i dx, y0 + j dy)
+  static const int a7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+  struct Pass { uint32_t x0, y0, dx, dy, pw, ph; size_t ps; };
+  std::vector<Pass> passes;
+  size_t raw_need = 0;
+  if (!interlace) {
+    passes.push_back({0, 0, 1, 1, w, h, stride});
+    raw_need = (stride + 1) * (size_t)h;
+  } else {
+    for (const auto& a : a7) {
+      if (w <= (uint32_t)a[0] || h <= (uint32_t)a[1]) continue;  // (an empty pass carries no rows at all)
+      Pass ps{(uint32_t)a[0], (uint32_t)a[1], (uint32_t)a[2], (uint32_t)a[3], (w - a[0] + a[2] - 1) / a[2], (h - a[1] + a[3] - 1) / a[3], 0};
+      ps.ps = ((size_t)ps.pw * bpp_bits + 7) / 8;
+      raw_need += (ps.ps + 1) * (size_t)ps.ph;
+      passes.push_back(ps);
+    }
+  }
   std::vector<uint8_t> raw;
-  if (!inflate_zlib(idat, raw, (stride + 1) * (size_t)h)) {
+  if (!inflate_zlib(idat, raw, raw_need)) {
     why = "corrupt zlib stream";
     return false;
   }
-  if (raw.size() < (stride + 1) * h) {
+  if (raw.size() < raw_need) {
     why = "truncated image data";
     return false;
   }
-  std::vector<uint8_t> img(stride * h), zero(stride, 0);
-  for (uint32_t y = 0; y < h; ++y) {
-    const uint8_t* in = &raw[(stride + 1) * y];
-    uint8_t* cur = &img[stride * y];
-    const uint8_t* up = y ? &img[stride * (y - 1)] : zero.data();
-    const int ft = in[0];
-    for (size_t x = 0; x < stride; ++x) {
-      const int a = x >= bpp ? cur[x - bpp] : 0, b = up[x], c = x >= bpp ? up[x - bpp] : 0;
-      int v = in[1 + x];
-      if (ft == 1) v += a;
-      else if (ft == 2) v += b;
-      else if (ft == 3) v += (a + b) >> 1;
-      else if (ft == 4) v += paeth(a, b, c);
-      else if (ft != 0) {
-        why = "bad filter type";
-        return false;
+  std::vector<uint8_t> img(stride * h, 0), zero(stride, 0), sub;
+  size_t off = 0;
+  for (const Pass& ps : passes) {
+    // the pass's rows, unfiltered: straight into the image when it is the only one
+    uint8_t* dst = interlace ? (sub.assign(ps.ps * ps.ph, 0), sub.data()) : img.data();
+    for (uint32_t y = 0; y < ps.ph; ++y) {
+      const uint8_t* in = &raw[off + (ps.ps + 1) * y];
+      uint8_t* cur = dst + ps.ps * y;
+      const uint8_t* up = y ? dst + ps.ps * (y - 1) : zero.data();
+      const int ft = in[0];
+      for (size_t x = 0; x < ps.ps; ++x) {
+        const int a = x >= bpp ? cur[x - bpp] : 0, b = up[x], c = x >= bpp ? up[x - bpp] : 0;
+        int v = in[1 + x];
+        if (ft == 1) v += a;
+        else if (ft == 2) v += b;
+        else if (ft == 3) v += (a + b) >> 1;
+        else if (ft == 4) v += paeth(a, b, c);
+        else if (ft != 0) {
+          why = "bad filter type";
+          return false;
+        }
+        cur[x] = (uint8_t)v;
       }
-      cur[x] = (uint8_t)v;
     }
+    off += (ps.ps + 1) * (size_t)ps.ph;
+    if (!interlace) break;
+    for (uint32_t j = 0; j < ps.ph; ++j)
+      for (uint32_t i = 0; i < ps.pw; ++i) {
+        const size_t X = ps.x0 + (size_t)i * ps.dx, Y = ps.y0 + (size_t)j * ps.dy;
+        if (bpp_bits >= 8) {
+          memcpy(&img[stride * Y + X * bpp], &sub[ps.ps * j + (size_t)i * bpp], bpp);
+        } else {  // 1, 2 or 4 bits per pixel, most significant bits first
+          const int per = 8 / (int)bpp_bits, mask = (1 << bpp_bits) - 1;
+          const int v = (sub[ps.ps * j + i / per] >> ((per - 1 - (int)(i % per)) * (int)bpp_bits)) & mask;
+          img[stride * Y + X / per] |= (uint8_t)(v << ((per - 1 - (int)(X % per)) * (int)bpp_bits));
+        }
+      }
   }
   bgr = cv::Mat((int)h, (int)w, CV_8UC3);
   for (uint32_t y = 0; y < h; ++y) {

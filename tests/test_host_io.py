@@ -59,6 +59,52 @@ def _png_bytes(arr, ctype, depth=8, palette=None, filters=(0, 1, 2, 3, 4), level
     return png + chunk(b"IDAT", comp[:half]) + chunk(b"IDAT", comp[half:]) + chunk(b"IEND", b"")
 
 
+def _png_interlaced(samples, ctype, depth=8, palette=None, filters=(0, 1, 2, 3, 4)):
+    """An Adam7 PNG (PIL reads them, no writer here makes them): `samples` (h, w, channels) holds the sample values, below 8
+    bits one per pixel; every pass is a reduced image filtered on its own."""
+    h, w, nch = samples.shape
+
+    def pack(sub):                      # rows of bytes of a reduced image
+        ph, pw = sub.shape[:2]
+        if depth == 16:
+            return np.stack([sub >> 8, sub & 255], axis=-1).reshape(ph, -1).astype(np.uint8)
+        if depth == 8:
+            return sub.reshape(ph, -1).astype(np.uint8)
+        per = 8 // depth
+        flat = np.zeros((ph, (pw + per - 1) // per * per), np.int64)
+        flat[:, :pw] = sub[:, :, 0]
+        sh = (per - 1 - np.arange(per)) * depth
+        return (flat.reshape(ph, -1, per) << sh).sum(-1).astype(np.uint8)
+
+    out, n = bytearray(), 0
+    bpp = max(1, nch * depth // 8)
+    for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+        sub = samples[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        rows = pack(sub.astype(np.int64))
+        prev = np.zeros(rows.shape[1], np.int32)
+        for y in range(rows.shape[0]):
+            cur = rows[y].astype(np.int32)
+            left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]) if cur.size > bpp else np.zeros_like(cur)
+            ul = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]]) if cur.size > bpp else np.zeros_like(cur)
+            ft = filters[n % len(filters)]
+            n += 1
+            p = left + prev - ul
+            pa, pb, pc = abs(p - left), abs(p - prev), abs(p - ul)
+            pred = [0, left, prev, (left + prev) >> 1, np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))][ft]
+            out.append(ft)
+            out += ((cur - pred) & 255).astype(np.uint8).tobytes()
+            prev = cur
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data))
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1))
+    if palette is not None:
+        png += chunk(b"PLTE", palette.astype(np.uint8).tobytes())
+    return png + chunk(b"IDAT", zlib.compress(bytes(out), 6)) + chunk(b"IEND", b"")
+
+
 def _pil_bgr(path):
     return np.asarray(PIL.open(path).convert("RGB"))[:, :, ::-1].copy()
 
@@ -205,6 +251,35 @@ def test_images_load_matches_pil_and_the_opencv_arithmetic(tmp_path):
     # calibration: the numbers the file holds, zero skew / 1 at (2,2), coefficient slots in file order (:230-236)
     assert np.array_equal(K, np.array([[1520.40, 0, 302.32], [0, 1525.90, 246.87], [0, 0, 1]]))
     assert np.array_equal(dist, np.array([-0.125, 0.25, 1e-3, -2.5e-4, 0.0625]))
+
+
+def test_interlaced_png_matches_pil(tmp_path):
+    """cv::imread (libpng) reads Adam7 files like any other: every colour type and bit depth the decoder takes, sizes from
+    one pixel (six of the seven passes empty) to ones that leave the passes ragged, every row filter inside the passes."""
+    rng = np.random.default_rng(31)
+    d = tmp_path / "imgs"
+    d.mkdir()
+    pal = rng.integers(0, 256, (16, 3)).astype(np.uint8)
+    cases = [("a_rgb", 2, 8, 3, (37, 45)), ("b_rgba", 6, 8, 4, (16, 16)), ("c_gray", 0, 8, 1, (9, 23)), ("d_ga", 4, 8, 2, (13, 7)),
+             ("e_rgb16", 2, 16, 3, (11, 12)), ("f_gray16", 0, 16, 1, (5, 9)), ("g_pal4", 3, 4, 1, (19, 21)), ("h_pal8", 3, 8, 1, (8, 8)),
+             ("i_gray1", 0, 1, 1, (17, 29)), ("j_gray2", 0, 2, 1, (10, 13)), ("k_gray4", 0, 4, 1, (7, 6)), ("l_one", 2, 8, 3, (1, 1)),
+             ("m_row", 2, 8, 3, (1, 9)), ("n_col", 0, 8, 1, (9, 1)), ("o_2x3", 6, 8, 4, (2, 3)), ("p_pal1", 3, 1, 1, (12, 33))]
+    truth = {}
+    for name, ctype, depth, nch, (h, w) in cases:
+        hi = 16 if ctype == 3 and depth >= 4 else 1 << depth
+        arr = rng.integers(0, hi, (h, w, nch))
+        truth[name] = arr
+        (d / f"{name}.png").write_bytes(_png_interlaced(arr, ctype, depth, palette=pal if ctype == 3 else None))
+    (tmp_path / "cam.xml").write_text(XML)
+    ok_img, ok_cal, imgs, *_ = _run(tmp_path, d, tmp_path / "cam.xml")
+    assert ok_img == 1 and len(imgs) == len(cases)
+    for (name, *_), (bgr, gray) in zip(sorted(cases), imgs):
+        want = _pil_bgr(d / f"{name}.png")
+        assert bgr.shape == want.shape, name
+        if "16" in name:   # (cv::imread strips 16 bit to the high byte -- png_set_strip_16 --, PIL's conversion differs)
+            hi8 = (truth[name] >> 8).astype(np.uint8)
+            want = hi8[:, :, ::-1] if hi8.shape[2] == 3 else np.repeat(hi8, 3, axis=2)
+        assert np.array_equal(bgr, want), (name, int(np.abs(bgr.astype(int) - want.astype(int)).max()))
 
 
 def _fmt(v):

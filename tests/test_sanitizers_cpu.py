@@ -68,9 +68,12 @@ def test_host_io_under_asan_ubsan(tmp_path):
                        timeout=600, env=ENV, cwd=tmp_path)
     _clean(r)
     assert os.path.exists(tmp_path / "denseCloud" / "txt" / "0000.txt")
-    good = (d / "b_rgb.PNG").read_bytes()
     rng = np.random.default_rng(9)
-    for k in range(24):                      # corrupt / truncated streams must fail cleanly, never read out of bounds
+    goods = [(d / "b_rgb.PNG").read_bytes(),
+             hio._png_interlaced(rng.integers(0, 256, (23, 31, 3)), 2, 8),           # Adam7: ragged passes
+             hio._png_interlaced(rng.integers(0, 4, (9, 14, 1)), 0, 2)]               # ... below a byte per pixel
+    for k in range(36):                      # corrupt / truncated streams must fail cleanly, never read out of bounds
+        good = goods[k % 3]
         bad = tmp_path / ("bad%d" % k)
         bad.mkdir()
         (bad / "a.png").write_bytes(good)
