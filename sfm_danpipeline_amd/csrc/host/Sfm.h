@@ -105,7 +105,8 @@ class StructFromMotion {
   // x0.6 bilinear iff rows > 480 and cols > 640, colour + gray copies.  PNG and Huffman-coded 8-bit JPEG -- sequential and
   // progressive -- are decoded here (no OpenCV, no libpng / libjpeg; the JPEG path follows libjpeg's integer IDCT, fancy
   // upsampling and colour tables byte for byte, interleaved or one scan per component, any of the 1x1 / 2x1 / 1x2 / 2x2
-  // samplings); an arithmetic-coded, lossless or 12-bit JPEG is reported and fails the load.
+  // samplings; a JPEG is turned as its EXIF orientation says, like cv::imread's default; PNG: Adam7 too); an arithmetic-coded,
+  // lossless or 12-bit JPEG is reported and fails the load.
   bool imagesLOAD(const std::string& directoryPath);
   // reference include/Sfm.h:99, src/Sfm.cpp:203-252: the OpenCV FileStorage XML with Camera_Matrix and
   // Distortion_Coefficients.  Values are read as the numbers the file holds (the reference reads a `dt f`

@@ -993,6 +993,73 @@ bool decode_jpeg(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) 
   return true;
 }
 
+// cv::imread(path) turns a JPEG the way its EXIF orientation says (OpenCV >= 3.1, loadsave.cpp ApplyExifOrientation; the
+// reference's call, src/Sfm.cpp:150, carries no IMREAD_IGNORE_ORIENTATION): phone and camera photos taken upright come
+// back upright.  The tag is found as modules/imgcodecs/src/exif.cpp finds it: the markers are walked from the start of the
+// file, the FIRST APP1 segment is taken, six bytes ("Exif\0\0") are skipped, and behind them a TIFF header (II / MM, 42, the
+// offset of IFD0) leads to the directory whose entry 0x0112 holds the orientation as a SHORT.  Returns 1 (nothing to do)
+// whenever anything is missing or out of bounds.
+int jpeg_exif_orientation(const std::vector<uint8_t>& f) {
+  size_t pos = 0;
+  const uint8_t* t = nullptr;
+  size_t tn = 0;
+  while (pos + 2 <= f.size()) {
+    const int mk = f[pos + 1];
+    pos += 2;
+    if (mk == 0xD8 || mk == 0xD9) continue;  // SOI, EOI: no size field
+    const bool sized = mk == 0xC0 || mk == 0xC2 || mk == 0xC4 || mk == 0xDB || mk == 0xDD || mk == 0xDA || (mk >= 0xD0 && mk <= 0xD7) ||
+                       mk == 0xE0 || (mk >= 0xE2 && mk <= 0xEF) || mk == 0xFE;
+    if (!sized && mk != 0xE1) return 1;  // (any other marker ends the search)
+    if (pos + 2 > f.size()) return 1;
+    const size_t len = ((size_t)f[pos] << 8) | f[pos + 1];
+    if (len < 2) return 1;
+    if (mk != 0xE1) {
+      pos += len;
+      continue;
+    }
+    if (len <= 6 + 2 || pos + len > f.size()) return 1;
+    t = &f[pos + 2 + 6];
+    tn = len - 2 - 6;
+    break;
+  }
+  if (!t || tn < 8 || t[0] != t[1] || (t[0] != 'I' && t[0] != 'M')) return 1;
+  const bool le = t[0] == 'I';
+  auto u16 = [&](size_t o) -> uint32_t { return le ? (uint32_t)(t[o] | (t[o + 1] << 8)) : (uint32_t)((t[o] << 8) | t[o + 1]); };
+  auto u32 = [&](size_t o) -> uint32_t { return le ? (u16(o) | (u16(o + 2) << 16)) : ((u16(o) << 16) | u16(o + 2)); };
+  if (u16(2) != 0x002A) return 1;
+  size_t off = u32(4);
+  if (off + 2 > tn) return 1;
+  const size_t n = u16(off);
+  off += 2;
+  for (size_t i = 0; i < n && off + 12 <= tn; ++i, off += 12)
+    if (u16(off) == 0x0112) {
+      const int o = (int)u16(off + 8);
+      return o >= 1 && o <= 8 ? o : 1;
+    }
+  return 1;
+}
+// loadsave.cpp ExifTransform: 2 mirror, 3 half turn, 4 upside down, 5 transpose, 6 transpose + mirror (a quarter turn clockwise),
+// 7 transpose + half turn, 8 transpose + upside down
+void apply_exif_orientation(cv::Mat& img, int o) {
+  if (o <= 1 || o > 8) return;
+  const int H = img.rows, W = img.cols;
+  const bool tr = o >= 5;
+  const int fl = o == 2 || o == 6 ? 1 : o == 3 || o == 7 ? -1 : o == 4 || o == 8 ? 0 : 2;  // cv::flip code (2: none)
+  cv::Mat out(tr ? W : H, tr ? H : W, CV_8UC3);
+  const uint8_t* s = img.ptr();
+  uint8_t* d = out.ptr();
+  for (int y = 0; y < out.rows; ++y)
+    for (int x = 0; x < out.cols; ++x) {
+      // undo the flip, then the transpose: where the output pixel comes from
+      int ty = y, tx = x;
+      if (fl == 1 || fl == -1) tx = out.cols - 1 - x;
+      if (fl == 0 || fl == -1) ty = out.rows - 1 - y;
+      const int sy = tr ? tx : ty, sx = tr ? ty : tx;
+      memcpy(d + ((size_t)y * out.cols + x) * 3, s + ((size_t)sy * W + sx) * 3, 3);
+    }
+  img = out;
+}
+
 std::string lower_ext(const std::string& p) {
   const size_t dot = p.find_last_of('.'), slash = p.find_last_of('/');
   if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) return "";
@@ -1181,8 +1248,14 @@ bool StructFromMotion::imagesLOAD(const std::string& directoryPath) {
     cv::Mat image;
     std::string why = "cannot read the file";
     bool ok = read_file(imageFilename, bytes);
-    if (ok && lower_ext(imageFilename) == ".jpg") ok = decode_jpeg(bytes, image, why);
-    else if (ok) ok = decode_png(bytes, image, why);
+    // (cv::imread picks the decoder by the file's signature, not by its name)
+    const bool is_jpeg = bytes.size() >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8;
+    if (ok && is_jpeg) {
+      ok = decode_jpeg(bytes, image, why);
+      if (ok) apply_exif_orientation(image, jpeg_exif_orientation(bytes));
+    } else if (ok) {
+      ok = decode_png(bytes, image, why);
+    }
     if (!ok) {  // cv::imread returns an empty Mat; the reference then reports and fails (:158-161)
       std::cerr << "[x]" << "\n" << "Unable to read image from file: " << imageFilename << " (" << why << ")" << std::endl;
       return false;

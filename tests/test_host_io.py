@@ -567,6 +567,71 @@ def test_progressive_jpeg_matches_libjpeg(tmp_path):
         assert np.array_equal(bgr, want), (name, int(np.abs(bgr.astype(int) - want.astype(int)).max()), float((bgr != want).mean()))
 
 
+def test_jpeg_exif_orientation_is_applied(tmp_path):
+    """cv::imread turns a JPEG as its EXIF orientation says (OpenCV >= 3.1; the reference passes no IMREAD_IGNORE_ORIENTATION,
+    src/Sfm.cpp:150): the eight orientations, big- and little-endian TIFF headers, a file whose first APP1 is not EXIF, and one
+    that is resized afterwards -- against PIL's exif_transpose of PIL's own decode."""
+    import io
+    from PIL import ImageOps
+    rng = np.random.default_rng(41)
+    d = tmp_path / "imgs"
+    d.mkdir()
+    yy, xx = np.mgrid[0:37, 0:58]
+    arr = np.clip(np.stack([xx * 4, yy * 6, (xx + yy) * 2], axis=-1) + rng.normal(0, 6, (37, 58, 3)), 0, 255).astype(np.uint8)
+    names = []
+    for o in range(1, 9):
+        ex = PIL.Exif()
+        ex[0x0112] = o
+        buf = io.BytesIO()
+        PIL.fromarray(arr).save(buf, "JPEG", quality=90, exif=ex.tobytes())
+        data = buf.getvalue()
+        if o % 2 == 0:
+            # the same directory with a little-endian TIFF header (PIL writes big-endian ones)
+            i = data.index(b"Exif\x00\x00") + 6
+            assert data[i:i + 4] == b"MM\x00*"
+            off = struct.unpack(">I", data[i + 4:i + 8])[0]
+            n = struct.unpack(">H", data[i + off:i + off + 2])[0]
+            tiff = bytearray(b"II*\x00" + struct.pack("<I", 8) + struct.pack("<H", n))
+            for k in range(n):
+                e = i + off + 2 + 12 * k
+                tag, typ, cnt = struct.unpack(">HHI", data[e:e + 8])
+                assert typ == 3 and cnt == 1
+                tiff += struct.pack("<HHI", tag, typ, cnt) + struct.pack("<H", struct.unpack(">H", data[e + 8:e + 10])[0]) + b"\x00\x00"
+            tiff += b"\x00" * 4
+            seglen = struct.unpack(">H", data[i - 8:i - 6])[0]
+            body = b"Exif\x00\x00" + bytes(tiff)
+            assert len(body) <= seglen - 2
+            body += b"\x00" * (seglen - 2 - len(body))
+            data = data[:i - 6] + body + data[i - 6 + len(body):]
+        (d / f"o{o}.jpg").write_bytes(data)
+        names.append(f"o{o}.jpg")
+    # an XMP-like APP1 in front of the EXIF one: the reader takes the first APP1 and finds no TIFF header in it
+    ex = PIL.Exif()
+    ex[0x0112] = 6
+    buf = io.BytesIO()
+    PIL.fromarray(arr).save(buf, "JPEG", quality=90, exif=ex.tobytes())
+    data = buf.getvalue()
+    xmp = b"http://ns.adobe.com/xap/1.0/\x00<x/>"
+    data = data[:2] + b"\xff\xe1" + struct.pack(">H", len(xmp) + 2) + xmp + data[2:]
+    (d / "p_xmp_first.jpg").write_bytes(data)
+    # 700 rows x 500 columns on file, a quarter turn makes it 500 x 700: turned first, THEN rows > 480 and cols > 640 -> x0.6
+    big = np.clip(rng.normal(128, 50, (700, 500, 3)), 0, 255).astype(np.uint8)
+    ex = PIL.Exif()
+    ex[0x0112] = 6
+    PIL.fromarray(big).save(d / "q_big.jpg", quality=85, exif=ex.tobytes())
+    (tmp_path / "cam.xml").write_text(XML)
+    ok_img, ok_cal, imgs, *_ = _run(tmp_path, d, tmp_path / "cam.xml")
+    assert ok_img == 1 and len(imgs) == 10
+    for name, (bgr, gray) in zip(sorted(names + ["p_xmp_first.jpg", "q_big.jpg"]), imgs):
+        im = PIL.open(d / name)
+        want = np.asarray((im if name.startswith("p_") else ImageOps.exif_transpose(im)).convert("RGB"))[:, :, ::-1]
+        if name == "q_big.jpg":
+            assert want.shape[:2] == (500, 700)
+            want = _cv_resize_linear_u8(np.ascontiguousarray(want), 0.6, 0.6)
+        assert bgr.shape == want.shape, (name, bgr.shape, want.shape)
+        assert np.array_equal(bgr, want), name
+
+
 def test_jpeg_failures_are_reported(tmp_path):
     rng = np.random.default_rng(8)
     (tmp_path / "cam.xml").write_text(XML)

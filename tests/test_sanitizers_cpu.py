@@ -107,8 +107,14 @@ def test_jpeg_decoder_under_asan_ubsan(tmp_path):
         b = io.BytesIO()
         Image.fromarray(arr).save(b, "JPEG", **kw)
         goods.append(b.getvalue())
-    for k in range(60):
-        good = goods[k % 5]
+    ex = Image.Exif()                      # an EXIF directory in front (orientation 6): the tag reader's bounds
+    ex[0x0112] = 6
+    ex[0x010F] = "a camera maker's name, so that the directory points past its entries"
+    b = io.BytesIO()
+    Image.fromarray(arr).save(b, "JPEG", quality=75, exif=ex.tobytes())
+    goods.append(b.getvalue())
+    for k in range(72):
+        good = goods[k % 6]
         bad = tmp_path / ("jbad%d" % k)
         bad.mkdir()
         (bad / "a.jpg").write_bytes(good)
@@ -116,7 +122,7 @@ def test_jpeg_decoder_under_asan_ubsan(tmp_path):
         if k % 4 == 0:
             b = b[:int(rng.integers(4, len(b)))]
         else:
-            lo = 2 if k % 4 == 1 else len(b) // 2            # headers / tables, or the scan
+            lo = 2 if k % 4 == 1 or k % 6 == 5 else len(b) // 2            # headers / tables (the EXIF file: always), or the scan
             for _ in range(1 + k % 7):
                 b[int(rng.integers(lo, len(b)))] ^= int(rng.integers(1, 256))
         (bad / "b.jpg").write_bytes(bytes(b))
