@@ -4854,6 +4854,21 @@ static int ba_one_iteration(sfmhip_ba* b, const sfmhip_ba_opts* o, bool timing_o
     SFM_HIP_TRY(hipEventRecord(b->ev[4], st));
     b->ev_on[4] = true;
   }
+#ifdef SFM_DBG_NOWAIT
+  // diagnostic build only (scripts/gpu_ba_nowait.py): the loop with the host taken out of it -- every step accepted unseen, the
+  // next linearisation enqueued at once -- to measure what the publish kernel, the PCIe round trip, the host's decision and the
+  // launch latency behind it cost per iteration.  The iterates are meaningless.
+  if (getenv("SFMHIP_DBG_NOWAIT") && s.iter > 2) {
+    ba_swap_candidate(b);
+    b->defer_fin = true;
+    SFM_TRY(ba_linearize_eliminate(b, s.radius, o, true));
+    b->defer_fin = false;
+    s.have_lin = true;
+    s.lin_unread = true;
+    if (s.iter % 64 == 0) SFM_HIP_TRY(hipStreamSynchronize(st));
+    return SFMHIP_OK;
+  }
+#endif
   SFM_TRY(ba_read_scalars(b, &sc, true));
   ba_acc_timing(b);
   if (s.lin_unread) {
