@@ -2081,7 +2081,7 @@ __host__ __device__ inline int chol_trail_tiles(int m2, int D) {
 // one trailing tile (t: its index in the launch's list -- the tiles of S, the rhs row, the tiles of X), one wave
 __device__ __forceinline__ void chol2_trailing_tile(double* __restrict__ A, double* __restrict__ y, double* __restrict__ X, const int ld,
                                                     const int k2, const int m2, const int xlo, const int mx, const int ntile,
-                                                    const int dfr, int t, const int lane) {
+                                                    const int dfr, int t, const int lane, const int catchup = 0) {
   const int ntrail = ntile + m2;
   int ti_rel = 0;
   const double* Rrow = A;  // the tile's row space
@@ -2115,6 +2115,9 @@ __device__ __forceinline__ void chol2_trailing_tile(double* __restrict__ A, doub
       t -= w;
       ++ti_rel;
     }
+    // (the launch that ends a run of deferred updates visits every column and folds what each has missed: a column whose
+    // distance to the panels is r pairs was last visited when that distance was the next multiple of `catchup` above r)
+    if (catchup > 1 && ti_rel < m2) npend = min(catchup - (t / 2) % catchup, k2);
   }
   const int c0 = (2 * k2 + 2) * CB;
   const int rb = rb_x >= 0 ? rb_x : c0 + ti_rel * CB, cb = c0 + t * CB;
@@ -2191,7 +2194,7 @@ __device__ __forceinline__ void chol2_trailing_tile(double* __restrict__ A, doub
 // is made of that block alone, so the rows and columns of X outside it need not be formed -- chol_back_block)
 __device__ __forceinline__ void chol_step2_body(double* __restrict__ A, double* __restrict__ y, double* __restrict__ X,
                                                 int ld, int nt, int nxc, int k2, int tiles_per_wg, int* __restrict__ info,
-                                                const int bid, double* sAll, const int xb = 0, const int dfr = 1) {
+                                                const int bid, double* sAll, const int xb = 0, const int dfr = 1, const int catchup = 0) {
   const int m2 = nt - 2 * k2 - 2;  // tile rows below the two panels (the rhs row comes on top)
   const int npanel = m2 + 2;       // owner, m2 tile rows, rhs
   const int xlo = xb ? 2 * k2 / xb * xb : 0;  // first row block of X that takes part
@@ -2227,14 +2230,14 @@ __device__ __forceinline__ void chol_step2_body(double* __restrict__ A, double* 
   if (wave >= tiles_per_wg) return;
   const int t = (bid - npanel - nx) * tiles_per_wg + wave;
   if (t >= total) return;
-  chol2_trailing_tile(A, y, X, ld, k2, m2, xlo, mx, ntile, dfr, t, lane);
+  chol2_trailing_tile(A, y, X, ld, k2, m2, xlo, mx, ntile, dfr, t, lane, catchup);
 }
 
 __global__ __launch_bounds__(C2_WAVES * 64) void chol_step2(double* __restrict__ A, double* __restrict__ y,
                                                             double* __restrict__ X, int ld, int nt, int k2,
-                                                            int tiles_per_wg, int* __restrict__ info, int xb, int dfr) {
+                                                            int tiles_per_wg, int* __restrict__ info, int xb, int dfr, int catchup) {
   extern __shared__ __attribute__((aligned(16))) double sAll[];  // C2_LDS_BYTES, see C2_OFF_*
-  chol_step2_body(A, y, X, ld, nt, nt, k2, tiles_per_wg, info, (int)blockIdx.x, sAll, xb, dfr);
+  chol_step2_body(A, y, X, ld, nt, nt, k2, tiles_per_wg, info, (int)blockIdx.x, sAll, xb, dfr, catchup);
 }
 
 // Several independent matrices ("chains": the interiors of a dissected camera graph, see NdPlan) at the same
@@ -2296,7 +2299,7 @@ __global__ __launch_bounds__(1024) void chol_apply_inverse(const double* __restr
 // Launch K applies z_{K+1} to every tile column left of block K+1 (one workgroup per tile column, sums in a fixed order) and the
 // workgroups of block K's own columns then write their part X(., j) w_j of z_K; the parts are added, in column order, by every
 // workgroup of the next launch (one more launch for z_0): no counters, and the same S and g give the same z bit for bit.
-constexpr int DENSE_XB = 8, DENSE_XB_MIN_NT = 48, DENSE_DEFER4_MIN_NT = 100;
+constexpr int DENSE_XB = 8, DENSE_XB_MIN_NT = 48, DENSE_DEFER4_MIN_NT = 100, DENSE_SWITCH_M2 = 40;
 __global__ __launch_bounds__(256) void chol_x_reset(double* __restrict__ X, int ld, int nt, int xb) {
   const int j = blockIdx.x, r0 = j / xb * xb * CB, r1 = min(nt, (j / xb + 1) * xb) * CB;
   for (int e = threadIdx.x; e < CB * (r1 - r0); e += 256) {
@@ -4627,7 +4630,7 @@ static int ba_reduced_solve_nd(sfmhip_ba* b) {
     chol_launch_shape(sp.N, sp.N, k2, &npan, &ntrail);
     while (tpw < C2_WAVES && npan + (ntrail + tpw - 1) / tpw > b->ctx->n_cu) ++tpw;
     hipLaunchKernelGGL(chol_step2, dim3(npan + (ntrail + tpw - 1) / tpw), dim3(C2_WAVES * 64), C2_LDS_BYTES, st, sp.M, sp.y,
-                       sp.X, sp.ld, sp.N, k2, tpw, d.info, 0, 1);
+                       sp.X, sp.ld, sp.N, k2, tpw, d.info, 0, 1, 0);
   }
   // z_S = L_SS^-T y_S;  w_i = y_i - L_Si^T z_S;  z_i = L_ii^-T w_i
   hipLaunchKernelGGL(nd_xy, dim3(sp.N, 1), dim3(1024), 0, st, ns, P, d.z);
@@ -4654,9 +4657,19 @@ static int ba_reduced_solve(sfmhip_ba* b) {
       b->chol_attr_set = true;
     }
     static const int dfr_env = getenv("SFMHIP_BA_DENSE_DEFER") ? atoi(getenv("SFMHIP_BA_DENSE_DEFER")) : 0;  // (measurement)
-    const int xb = b->dense_xb, dfr = !xb ? 1 : dfr_env > 0 ? dfr_env : nt >= DENSE_DEFER4_MIN_NT ? 4 : 2;
+    const int xb = b->dense_xb, dfr0 = !xb ? 1 : dfr_env > 0 ? dfr_env : nt >= DENSE_DEFER4_MIN_NT ? 4 : 2;
+    static const int sw_env = getenv("SFMHIP_BA_DENSE_SWITCH") ? atoi(getenv("SFMHIP_BA_DENSE_SWITCH")) : -1;  // (measurement)
+    // (measured, scripts/gpu_dense_sizes.py: worth it only behind visits of four pairs -- 640 cameras 624 -> 643 it/s at 40 tile
+    // rows, 618 at 72; behind visits of two pairs the undeferred tail is slower: 400 cameras 1433 -> 1407)
+    const int sw_m2 = sw_env >= 0 ? sw_env : dfr0 >= 4 ? DENSE_SWITCH_M2 : 0;
+    bool deferred = false;  // some earlier launch of this factorisation left columns behind
     for (int k2 = 0; 2 * k2 < nt; ++k2, ++nchol) {
       const int m2 = nt - 2 * k2 - 2;
+      // the updates are deferred while the trailing matrix is large; once a launch's visits of 64 dfr MFMAs would outlast its
+      // panel chain (few tiles left: m2 <= DENSE_SWITCH_M2 tile rows) one launch catches every column up and the rest run undeferred
+      const int dfr = m2 > sw_m2 ? dfr0 : 1;
+      const int catchup = dfr == 1 && deferred ? dfr0 : 0;
+      if (k2 > 0) deferred = dfr > 1;
       // launch 0 has no pending update; later launches: the tiles right of the panels, and those of X
       const int xlo = xb ? 2 * k2 / xb * xb : 0, mx = xb ? std::max(0, std::min(nt, xlo + xb) - 2 * k2 - 2) : m2;
       const int ntrail = k2 == 0 ? 0 : (dfr > 1 ? chol_trail_tiles(m2, dfr) : m2 * (m2 + 1) / 2) + m2 + (2 * k2 - xlo) * mx;
@@ -4665,9 +4678,9 @@ static int ba_reduced_solve(sfmhip_ba* b) {
       while (tpw < C2_WAVES && npan + (ntrail + tpw - 1) / tpw > b->ctx->n_cu) ++tpw;
       // (deferred updates, K = 256 per visit: a workgroup of eleven such visits outlasts the panel workgroups twice over and
       // the launch ends on the stragglers of a second round -- four visits, one per SIMD, measured best: scripts/gpu_dense_sizes.py)
-      if (dfr >= 4) tpw = 4;
+      if (dfr >= 4 || catchup >= 4) tpw = 4;
       hipLaunchKernelGGL(chol_step2, dim3(npan + (ntrail + tpw - 1) / tpw), dim3(C2_WAVES * 64), C2_LDS_BYTES, st, A, y, d.xinv, d.ld, nt, k2,
-                         tpw, d.info, xb, dfr);
+                         tpw, d.info, xb, dfr, catchup);
     }
   }
   int nbs = 1;
