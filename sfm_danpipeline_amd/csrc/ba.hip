@@ -4679,6 +4679,10 @@ static int ba_reduced_solve(sfmhip_ba* b) {
       // (deferred updates, K = 256 per visit: a workgroup of eleven such visits outlasts the panel workgroups twice over and
       // the launch ends on the stragglers of a second round -- four visits, one per SIMD, measured best: scripts/gpu_dense_sizes.py)
       if (dfr >= 4 || catchup >= 4) tpw = 4;
+      // (... unless that makes many rounds of workgroups: then two visits per SIMD, one's loads under the other's MFMAs -- 1400
+      // cameras 118.7 -> 125 it/s; at 640 cameras, under two rounds, the same choice loses 1-2 %)
+      static const int rounds_env = getenv("SFMHIP_BA_DENSE_TPW8_ROUNDS") ? atoi(getenv("SFMHIP_BA_DENSE_TPW8_ROUNDS")) : 4;  // (measurement)
+      if (dfr >= 4 && (ntrail + 3) / 4 > rounds_env * b->ctx->n_cu) tpw = 8;
       hipLaunchKernelGGL(chol_step2, dim3(npan + (ntrail + tpw - 1) / tpw), dim3(C2_WAVES * 64), C2_LDS_BYTES, st, A, y, d.xinv, d.ld, nt, k2,
                          tpw, d.info, xb, dfr, catchup);
     }
