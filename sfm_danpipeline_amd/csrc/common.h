@@ -60,7 +60,12 @@ static inline int sfm_dev_alloc(T** p, size_t n) {
   // SFMHIP_POISON=1 (tests): fresh device memory holds 0xFF bytes (NaN as float / double, -1 as int) instead of
   // whatever the driver hands out -- a kernel that reads before it writes shows up as NaN, not as a rare flake
   static const bool poison = getenv("SFMHIP_POISON") != nullptr;
-  if (poison) hipMemset(v, 0xFF, (n ? n : 1) * sizeof(T));
+  if (poison) {
+    // (the fill runs on the null stream: it must be over before a kernel on one of the library's own streams touches the
+    // buffer -- an allocation made between two launches, like the front tree's second reduced-system buffer, raced with it)
+    hipMemset(v, 0xFF, (n ? n : 1) * sizeof(T));
+    hipDeviceSynchronize();
+  }
   *p = (T*)v;
   return SFMHIP_OK;
 }

@@ -216,6 +216,35 @@ def test_large_dense_solve_gives_the_same_answer_every_time(ctx, monkeypatch):
         prob.close()
 
 
+def test_reduced_solve_on_poisoned_allocations():
+    """SFMHIP_POISON=1 (csrc/common.h: fresh device memory holds 0xFF bytes) in a process of its own: whatever a reduced solve
+    reads it must have written or zeroed itself.  (Round 4: with X kept in diagonal blocks only, the panel workgroups of a
+    block's first panels read the block's rows of X at the pending columns of the block before -- memory nothing had ever
+    written; right by luck while the driver hands out zeroed pages.)"""
+    import subprocess, sys, os
+    code = (
+        "import os, sys, numpy as np\n"
+        "from sfm_danpipeline_amd import synth, bundle, _lib\n"
+        "ctx = _lib.default_context()\n"
+        "for nd, nc, npt, k in (('0', 350, 5000, 6), ('0', 560, 6000, 8), ('0', 180, 6000, 8), ('1', 96, 6000, 6), ('2', 260, 4000, 4), ('2', 560, 6000, 8)):\n"
+        "    os.environ['SFMHIP_BA_ND'] = nd\n"
+        "    pb = synth.ba_problem(nc, npt, k, seed=5)\n"
+        "    prob = bundle.BaProblem(nc, npt, pb['obs_cam'], pb['obs_pt'], pb['obs_xy'], ctx=ctx)\n"
+        "    prob.set_params(pb['cams0'], pb['pts0'], pb['focal0'])\n"
+        "    S, g, _ = prob.reduced_system(1e4)\n"
+        "    for rep in range(4):\n"
+        "        z, failed = prob.reduced_step(1e4)\n"
+        "        assert failed == 0 and np.linalg.norm(S @ z - g) <= 1e-12 * np.linalg.norm(g), (nd, nc, rep, failed)\n"
+        "    s = prob.iterate(4)\n"
+        "    assert np.isfinite(s.final_cost) and s.final_cost < s.initial_cost, (nd, nc)\n"
+        "    prob.close()\n"
+        "print('poisoned solves ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root,
+                       env=dict(os.environ, SFMHIP_POISON="1", PYTHONPATH=root))
+    assert r.returncode == 0 and "poisoned solves ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_front_tree_gives_the_same_answer_every_time(ctx, monkeypatch):
     """The front tree's workgroups hand tiles to each other inside one launch, and inside a workgroup twelve waves share two
     panel generations through counters: 150 solves of the same system must be the same bit pattern every time, and right.
