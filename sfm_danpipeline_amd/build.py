@@ -82,7 +82,7 @@ def _build_host_exe(exe, files, force):
     if not force and os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(s) for s in deps):
         return exe
     build()
-    cmd = ["g++", "-O2", "-std=c++14", "-I", os.path.join(HERE, "..", "include"), "-I", host, "-o", exe] + srcs + \
+    cmd = ["g++", "-O2", "-std=c++14", "-pthread", "-I", os.path.join(HERE, "..", "include"), "-I", host, "-o", exe] + srcs + \
           ["-L", HERE, "-lsfmhip", "-Wl,-rpath,$ORIGIN"]
     subprocess.check_call(cmd)
     return exe

@@ -6,6 +6,7 @@
 #include <dirent.h>
 #include <sys/stat.h>
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cmath>
 #include <cstdint>
@@ -15,6 +16,7 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <thread>
 #include "Sfm.h"
 #include "hip_backend.h"
 
@@ -1243,25 +1245,44 @@ bool StructFromMotion::imagesLOAD(const std::string& directoryPath) {
     return false;
   }
   std::cout << "Found " << nImagesPath.size() << " image files in directory." << std::endl;
-  for (const std::string& imageFilename : nImagesPath) {
-    std::vector<uint8_t> bytes;
-    cv::Mat image;
-    std::string why = "cannot read the file";
-    bool ok = read_file(imageFilename, bytes);
-    // (cv::imread picks the decoder by the file's signature, not by its name)
-    const bool is_jpeg = bytes.size() >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8;
-    if (ok && is_jpeg) {
-      ok = decode_jpeg(bytes, image, why);
-      if (ok) apply_exif_orientation(image, jpeg_exif_orientation(bytes));
-    } else if (ok) {
-      ok = decode_png(bytes, image, why);
+  // the loop of :146-170, the files decoded side by side (the decoders here are plain scalar code: a camera JPEG takes a few
+  // hundred milliseconds); the images are kept, and the first unreadable one is reported, in the sorted order of the loop
+  const size_t nfiles = nImagesPath.size();
+  std::vector<cv::Mat> decoded(nfiles);
+  std::vector<std::string> whys(nfiles, "cannot read the file");
+  std::vector<char> oks(nfiles, 0);
+  std::atomic<size_t> next{0};
+  auto worker = [&]() {
+    for (size_t i = next.fetch_add(1); i < nfiles; i = next.fetch_add(1)) {
+      std::vector<uint8_t> bytes;
+      cv::Mat image;
+      bool ok = read_file(nImagesPath[i], bytes);
+      // (cv::imread picks the decoder by the file's signature, not by its name)
+      const bool is_jpeg = bytes.size() >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8;
+      if (ok && is_jpeg) {
+        ok = decode_jpeg(bytes, image, whys[i]);
+        if (ok) apply_exif_orientation(image, jpeg_exif_orientation(bytes));
+      } else if (ok) {
+        ok = decode_png(bytes, image, whys[i]);
+      }
+      if (ok) decoded[i] = image.rows > 480 && image.cols > 640 ? resize_linear_8u(image, 0.60, 0.60) : image;  // :153-155
+      oks[i] = ok ? 1 : 0;
     }
-    if (!ok) {  // cv::imread returns an empty Mat; the reference then reports and fails (:158-161)
-      std::cerr << "[x]" << "\n" << "Unable to read image from file: " << imageFilename << " (" << why << ")" << std::endl;
+  };
+  {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t nthreads = std::min<size_t>(std::min<size_t>(hw, 16), nfiles);
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+    worker();
+    for (std::thread& t : pool) t.join();
+  }
+  for (size_t i = 0; i < nfiles; ++i) {
+    if (!oks[i]) {  // cv::imread returns an empty Mat; the reference then reports and fails (:158-161)
+      std::cerr << "[x]" << "\n" << "Unable to read image from file: " << nImagesPath[i] << " (" << whys[i] << ")" << std::endl;
       return false;
     }
-    if (image.rows > 480 && image.cols > 640) nImages.push_back(resize_linear_8u(image, 0.60, 0.60));  // :153-155
-    else nImages.push_back(image);
+    nImages.push_back(decoded[i]);
   }
   if (nImages.size() < 2) {
     std::cerr << "Sorry. is not enough images, 6 minimum" << std::endl;  // :172-175
