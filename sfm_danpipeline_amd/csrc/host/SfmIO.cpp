@@ -394,11 +394,24 @@ struct JpegHuff {
   uint8_t vals[256];
   int mincode[17], maxcode[18], valptr[17];
   bool present = false;
+  // the codes of up to LOOK bits resolved by one table look-up on the next LOOK bits (libjpeg's jdhuff.c does the same with 8):
+  // look[bits] = length << 8 | symbol, 0 where the code is longer
+  static constexpr int LOOK = 9;
+  uint16_t look[1 << LOOK];
   void build() {
     int code = 0, k = 0;
+    memset(look, 0, sizeof look);
     for (int l = 1; l <= 16; ++l) {
       valptr[l] = k;
       mincode[l] = code;
+      for (int i = 0; i < bits[l] && l <= LOOK; ++i) {
+        const int c = code + i;
+        if (c >= (1 << l)) break;  // (an over-subscribed table of a corrupt file: the slow path rejects what is wrong with it)
+        for (int pad = 0; pad < (1 << (LOOK - l)); ++pad) {
+          uint16_t& e = look[(c << (LOOK - l)) | pad];
+          if (!e) e = (uint16_t)((l << 8) | vals[k + i]);  // (the shortest code wins, as in the bit-by-bit search)
+        }
+      }
       code += bits[l];
       k += bits[l];
       maxcode[l] = bits[l] ? code - 1 : -1;
@@ -439,6 +452,12 @@ struct JpegBits {
   }
   int decode(const JpegHuff& h) {
     fill();
+    const uint16_t e = h.look[acc >> (32 - JpegHuff::LOOK)];
+    if (e) {
+      acc <<= e >> 8;
+      cnt -= e >> 8;
+      return e & 255;
+    }
     int code = 0;
     for (int l = 1; l <= 16; ++l) {
       code = (code << 1) | (int)(acc >> 31);
