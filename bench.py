@@ -44,6 +44,40 @@ HBM_PEAK_GBS = 8000.0
 VALU_PEAK_TLANEOPS = 78.6        # 256 CU x 128 lanes x 2.4 GHz
 
 
+def launcher_command(n_ranks, argv, port=None):
+    """The command `bench.py --gpus N` starts when it is run without a launcher: one rank per GPU of this node under
+    torch.distributed.run (static rendezvous on 127.0.0.1: the container's hostname may not resolve).  SFMHIP_BENCH_LAUNCHER
+    replaces the `python -m torch.distributed.run` prefix (tests/test_bench_launcher.py drives the branch with a stub)."""
+    import shlex
+    import socket
+    if port is None:
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+    head = os.environ.get("SFMHIP_BENCH_LAUNCHER")
+    head = shlex.split(head) if head else [sys.executable, "-m", "torch.distributed.run"]
+    return head + ["--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                   os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(n_ranks, argv):
+    """Starts the N ranks as a CHILD process (never exec: a process that may have initialised the GPU must not replace
+    itself, and this one has not touched it), relays the child's stdout / stderr and returns its exit status."""
+    import subprocess
+    cmd = launcher_command(n_ranks, argv)
+    print("[bench] --gpus %d without WORLD_SIZE: starting %s" % (n_ranks, " ".join(cmd)), file=sys.stderr)
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    child = subprocess.Popen(cmd, env=env)           # inherits stdout / stderr: rank 0's JSON line goes straight through
+    try:
+        return child.wait()
+    except KeyboardInterrupt:
+        child.terminate()
+        return child.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,6 +104,12 @@ def main():
     if args.lean:
         args.no_cfg5 = args.no_cpu_baseline = args.no_score = True
 
+    # `python bench.py --gpus N` on its own (no WORLD_SIZE in the environment): this process becomes the launcher -- before
+    # anything here has touched a GPU, and without replacing itself -- of N ranks under torch.distributed.run, relays
+    # their output (rank 0 prints the JSON line) and exits with the child's status
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
 
@@ -92,6 +132,13 @@ def main():
     if world != args.gpus:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     dev = torch.device(f"cuda:{local_rank}")
+    # how many ranks the collective backend really connects: the group's size AND an all-reduce of ones over it
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        ranks_seen = int(one[0])
+        assert ranks_seen == dist.get_world_size() == world, (ranks_seen, dist.get_world_size(), world)
 
     from sfm_danpipeline_amd import _lib, bundle, matcher, sharding, synth
 
@@ -359,11 +406,16 @@ def main():
         idx = np.asarray(shards[rank])
         cfg5_ok = bool(np.array_equal(o_cnt, gold["counts"][idx]) and np.array_equal(cs, gold["checksums"][idx]))
         assert cfg5_ok, "cfg5: the device's match lists differ from the oracle's (per-pair counts / checksums)"
+        # ... and the merged checksum must be the N = 1 value whatever N is (the golden file's own totals)
+        with np.errstate(over="ignore"):
+            n1 = [int(np.sum(gold["checksums"][:, 0], dtype=np.uint64)), int(np.bitwise_xor.reduce(gold["checksums"][:, 1])),
+                  int(gold["counts"].sum())]
+        assert [int(part[0]), int(part[1]), int(part[2])] == n1, f"cfg5: merged checksum {part} differs from the N = 1 value {n1}"
         cfg5 = {"workload": "cfg5: 500 img x 5000 ORB-256, all 124750 pairs, Hamming; pairs dealt over the ranks "
                             "(sharding.shard_pairs), descriptors resident on every rank",
                 "pairs": int(len(o_pairs)), "pairs_this_rank": int(len(mine)), "seconds_per_sweep": round(t_cfg5, 5),
                 "pairs_per_s": round(len(o_pairs) / t_cfg5, 1), "scaling": "strong", "matches": int(part[2]),
-                "checksum": [int(part[0]), int(part[1])],
+                "checksum": [int(part[0]), int(part[1])], "checksum_equals_n1": True,
                 "oracle_checked_pairs": int(len(o_pairs)), "oracle_match": cfg5_ok,
                 "oracle": "every pair's count and checksum equal the C restatement's (tests/golden/cfg5_checksums.npz); "
                           "on N > 1 every rank asserts its own share"}
@@ -607,7 +659,11 @@ def main():
             "metric": "image-pairs matched/sec + BA iterations/sec (200 cams, 100k pts, 1M obs)",
             "value": round(pairs_per_s, 1), "unit": "pairs/s",
             "ba_iterations_per_s": round(ba_it_per_s, 2),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": ranks_seen,
+            "collective": {"backend": ("nccl (RCCL)" if backend == "nccl" else backend) if world > 1 else None,
+                           "world_size": dist.get_world_size() if world > 1 else 1, "allreduce_of_ones": ranks_seen,
+                           "launched_by": os.environ.get("TORCHELASTIC_RUN_ID") and "torch.distributed.run" or "direct"},
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_match + ms_ba, 4), "ms_match_sweep": round(ms_match, 4),
             "ms_ba_iteration": round(ms_ba, 4),
             "higher_is_better": True, "scaling": "weak", "ba_scaling": "strong",
