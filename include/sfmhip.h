@@ -38,7 +38,10 @@ enum {
   SFMHIP_ERR_ALLOC = -4,
   SFMHIP_ERR_UNSUPPORTED = -5,
   SFMHIP_ERR_STATE = -6,
-  SFMHIP_ERR_COMM = -7
+  SFMHIP_ERR_COMM = -7,
+  SFMHIP_ERR_TIMEOUT = -8    /* a bounded spin inside a kernel ran out and the level-by-level fallback did too: a scheduling
+                                fault or a bug, never a property of the data (a matrix that is not positive definite is an
+                                invalid LM step, not an error) */
 };
 
 /* descriptor element type of a cv::Mat row (reference include/Sfm.h:29, src/Sfm.cpp:326) */
@@ -274,6 +277,8 @@ typedef struct {
   double final_radius;
   double gradient_max_norm;
   double time_s;
+  int spin_timeouts; /* reduced solves whose hand-off between fronts timed out (a busy device) and were repeated level by level;
+                        0 in every run this build has measured.  They never change the LM trajectory. */
 } sfmhip_ba_summary;
 
 void sfmhip_ba_default_opts(sfmhip_ba_opts* o);

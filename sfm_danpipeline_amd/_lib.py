@@ -30,7 +30,7 @@ class BaSummary(C.Structure):
     _fields_ = [
         ("termination", C.c_int), ("iterations", C.c_int), ("successful_steps", C.c_int),
         ("initial_cost", C.c_double), ("final_cost", C.c_double), ("final_radius", C.c_double),
-        ("gradient_max_norm", C.c_double), ("time_s", C.c_double),
+        ("gradient_max_norm", C.c_double), ("time_s", C.c_double), ("spin_timeouts", C.c_int),
     ]
 
 

@@ -12,9 +12,10 @@ CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libsfmhip.so")
 # per-source floating-point contraction: the matcher's exact kernel and the triangulation restate
 # OpenCV's operation order (no compiler-chosen FMAs); the BA kernels are tolerance-level f64
-# and want v_fma_f64
+# and want v_fma_f64 -- "fast-honor-pragmas", not "fast": the one function that must NOT contract, the trust-region decision
+# lm_decide (the same bits on the host and on the device), says so with a pragma, which plain "fast" ignores
 SOURCES = {"context.hip": "off", "match.hip": "off", "triangulate.hip": "off", "incremental.hip": "off",
-           "score.hip": "off", "sift.hip": "off", "ba.hip": "fast", "probe.hip": "off"}
+           "score.hip": "off", "sift.hip": "off", "ba.hip": "fast-honor-pragmas", "probe.hip": "off"}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
 
 

@@ -89,9 +89,156 @@ struct BaDev {
   double* red;
   double* z;     // dim solution
   double* xinv;  // ld x ld, column-major like S's triangle: the identity on entry to the factorisation, L^-T after it
-  double* red2;  // 16 scalars of the step evaluation + RED2_SLOTS x 4 partial sums of ba_backsub
+  double* red2;  // 16 scalars of the step evaluation (the slots behind them are no longer used: step_part)
   int* info;     // cholesky failure flag
+  // trust-region loop on the device (round 5)
+  struct LmDev* lm;   // null: the host decides (radius by kernel argument, the host swaps the parameter sets)
+  double* step_part;  // the step evaluation's sums per workgroup, 4 each (candidate cost, model cost change, |step|^2, |candidate|^2),
+                      // then the camera parts (cam_parts x 2: |step|^2, |candidate|^2), added up in a FIXED order by the workgroup that
+                      // arrives last (step_finish): the sums -- hence rho, the radius, the trajectory -- are the same bits every run
+  int step_total;     // workgroups of the step evaluation's kernels
+  int cam_parts;
+  int decide_here;    // 1: that last workgroup also takes the LM decision (single rank); 0: ba_decide does, after the all-reduce
+  int rank;           // of this process (the camera parts of the norms are counted by rank 0 only)
+  int step_last;      // this launch is the step evaluation's last kernel (behind a stop its first thread still counts the decision)
+  double* lm_host;    // pinned, as the device sees it: the host's copies of the record, a ring of LM_RING
 };
+
+// ---------------------------------------------------------------- the trust-region decision (host and device alike)
+// TrustRegionMinimizer::Minimize + LevenbergMarquardtStrategy of Ceres 1.13 with the options of reference
+// src/BundleAdjustment.cpp:115-121: one function, compiled for the host (the loop behind SFMHIP_BA_HOST_LOOP=1, and stage
+// timing) and for the device (the default: the last workgroup of the step evaluation calls it, the next linearisation reads
+// the radius and which parameter set is x from the record -- the host enqueues iterations ahead and reads records behind
+// the GPU).  Contraction is off in it: +, *, /, sqrt of gfx950 are bit-equal to the host's (scripts/ubench/f64_rounding.hip),
+// so both loops walk the same trajectory bit for bit (tests/test_gpu_geometry.py::test_device_loop_equals_host_loop).
+enum { LM_RUNNING = -1, LM_STOP_TIMEOUT = 100 };
+enum { LM_KIND_NONE = 0, LM_KIND_INVALID = 1, LM_KIND_ACCEPTED = 2, LM_KIND_REJECTED = 3, LM_KIND_STOP = 4 };
+constexpr int LM_RING = 64;
+struct LmDev {
+  // options of the run (written by the host when a run starts)
+  double gtol, ptol, ftol, min_rel_dec, max_radius, min_radius;
+  int max_invalid, max_iter, timing_only, pad0;
+  // state
+  double radius, dec_factor, cost, gmax, x_norm, initial_cost;
+  int iter, nsucc, invalid, lin_unread;
+  int parity;    // 1: the "candidate" buffers hold x (kernels swap their view, lm_view); the host puts it back to 0 when it takes over
+  int stop;      // LM_RUNNING, SFMHIP_BA_* once a stopping rule has fired (later decisions change nothing), LM_STOP_TIMEOUT
+  int timeouts;  // reduced solves that reported a spin that ran out (info < 0): the step is neither taken nor counted
+  unsigned seq;  // decisions made on this problem (the host waits for a value of it)
+  unsigned stop_seq;  // the decision that set `stop`
+  int pad1;
+  // the last decision, for the log
+  double log_cost0, log_cost_c, log_rho, log_step_norm, log_mcc, log_nfail;
+  int log_kind, log_info;
+};
+struct LmIn {
+  double lin_cost, lin_nfail, lin_gmax;      // of the linearisation at x (its cost is 0.5 * sum r^2)
+  double cost_c, mcc, step_n2, cand_n2;      // of the step evaluation
+  int info;                                  // of the reduced solve: > 0 a pivot was not positive, < 0 a bounded spin ran out
+};
+
+__host__ __device__ inline void lm_decide_step(LmDev& s, const LmIn& in) {
+#pragma clang fp contract(off)
+  s.seq += 1u;
+  s.log_kind = LM_KIND_NONE;
+  if (s.stop != LM_RUNNING) return;  // (iterations enqueued past a stop: nothing is accepted, nothing changes)
+  s.log_info = in.info;
+  if (in.info < 0) {  // a scheduling artefact, not a property of the matrix: the host repeats the solve level by level
+    s.timeouts += 1;
+    s.stop = LM_STOP_TIMEOUT;
+    return;
+  }
+  s.iter += 1;
+  const bool t_only = s.timing_only != 0;
+  s.log_kind = LM_KIND_STOP;
+  if (s.lin_unread) {
+    // cost / gradient of the linearisation enqueued behind the last accepted step; Ceres tests the gradient tolerance
+    // right after accepting a step, so a converged gradient discards the step evaluated since
+    s.lin_unread = 0;
+    s.cost = in.lin_cost;
+    s.gmax = in.lin_gmax;
+    if (!t_only && s.gmax <= s.gtol) {
+      s.iter -= 1;
+      s.stop = SFMHIP_BA_CONVERGENCE;
+      return;
+    }
+  }
+  s.log_cost0 = s.cost, s.log_cost_c = in.cost_c, s.log_mcc = in.mcc, s.log_nfail = in.lin_nfail, s.log_rho = 0.0, s.log_step_norm = 0.0;
+  const bool finite = __builtin_isfinite(in.step_n2) && __builtin_isfinite(in.mcc) && __builtin_isfinite(in.cost_c);
+  const bool bad = in.info != 0 || in.lin_nfail > 0 || !finite;
+  if (bad || !(in.mcc > 0.0)) {  // HandleInvalidStep
+    s.invalid += 1;
+    if (s.invalid >= s.max_invalid && !t_only) {
+      s.stop = SFMHIP_BA_FAILURE;
+      return;
+    }
+    s.radius = s.radius / s.dec_factor;
+    s.dec_factor = s.dec_factor * 2.0;
+    s.log_kind = LM_KIND_INVALID;
+    s.log_step_norm = in.step_n2;
+  } else {
+    s.invalid = 0;
+    const double step_norm = sqrt(in.step_n2);
+    s.log_step_norm = step_norm;
+    if (!t_only) {
+      if (step_norm <= s.ptol * (s.x_norm + s.ptol)) {  // ParameterToleranceReached: candidate not taken
+        s.stop = SFMHIP_BA_CONVERGENCE;
+        return;
+      }
+      if (fabs(s.cost - in.cost_c) <= s.ftol * s.cost) {  // FunctionToleranceReached: candidate not taken
+        s.stop = SFMHIP_BA_CONVERGENCE;
+        return;
+      }
+    }
+    const double rho = (s.cost - in.cost_c) / in.mcc;
+    s.log_rho = rho;
+    if (rho > s.min_rel_dec) {  // HandleSuccessfulStep
+      s.parity ^= 1;
+      s.x_norm = sqrt(in.cand_n2);
+      s.nsucc += 1;
+      const double q = 2.0 * rho - 1.0;
+      s.radius = s.radius / fmax(1.0 / 3.0, 1.0 - q * q * q);
+      s.radius = fmin(s.max_radius, s.radius);
+      s.dec_factor = 2.0;
+      s.cost = in.cost_c;  // provisional (same residuals, other summation order) until the next linearisation's scalars
+      s.lin_unread = 1;
+      s.log_kind = LM_KIND_ACCEPTED;
+    } else {  // HandleUnsuccessfulStep
+      s.radius = s.radius / s.dec_factor;
+      s.dec_factor = s.dec_factor * 2.0;
+      s.log_kind = LM_KIND_REJECTED;
+    }
+  }
+  // what TrustRegionMinimizer tests before it starts the next iteration (the wall clock is the host's)
+  if (!t_only) {
+    if (s.iter >= s.max_iter) s.stop = SFMHIP_BA_NO_CONVERGENCE;
+    else if (s.radius < s.min_radius) s.stop = SFMHIP_BA_CONVERGENCE;
+  }
+}
+
+__host__ __device__ inline void lm_decide(LmDev& s, const LmIn& in) {
+  const int was = s.stop;
+  lm_decide_step(s, in);
+  if (was == LM_RUNNING && s.stop != LM_RUNNING) s.stop_seq = s.seq;
+}
+
+// iterations enqueued behind a stop: their kernels return at once
+__device__ __forceinline__ bool lm_stopped(const BaDev& d) { return d.lm && d.lm->stop != LM_RUNNING; }
+
+// a kernel's view of the parameter sets and the radius: the record's, when the loop runs on the device
+__device__ __forceinline__ void lm_view(BaDev& d, double& radius) {
+  if (d.lm) {
+    const int par = d.lm->parity;
+    radius = d.lm->radius;
+    if (par) {
+      double* t;
+      t = d.cams, d.cams = d.cams_c, d.cams_c = t;
+      t = d.pts, d.pts = d.pts_c, d.pts_c = t;
+      t = d.focal, d.focal = d.focal_c, d.focal_c = t;
+      t = d.camd, d.camd = d.camd_c, d.camd_c = t;
+    }
+  }
+}
 
 __device__ __forceinline__ double* red_S(const BaDev& d) { return d.red; }
 __device__ __forceinline__ double* red_g(const BaDev& d) { return d.red + (size_t)d.ld * d.ld; }
@@ -820,6 +967,12 @@ __global__ SFM_ELIM_LB void ba_eliminate_mfma(BaDev d, const Chunk* __restrict__
   // into unequal pieces and the short ones packed two to a workgroup by a cost model -- 97-104 us per linearisation stage at
   // cfg4 against 92 for this cut (scripts/gpu_ba_elim_pack.py at commit time): the loop around the body costs 35 VGPRs and SGPR
   // spills, and a workgroup's time is not the sum the model assumed)
+  if (lm_stopped(d)) return;
+  if (d.lm) {  // (the loop on the device: the radius and which parameter set is x come from the record of the last decision)
+    double radius;
+    lm_view(d, radius);
+    inv_radius = 1.0 / radius;
+  }
   elim_chunk<NB>(d, chunks, chunk_ids[blockIdx.x], sig_cams, inv_radius, lm_lo, lm_hi, rank, norms, slab);
 }
 
@@ -829,7 +982,8 @@ __global__ SFM_ELIM_LB void ba_eliminate_mfma(BaDev d, const Chunk* __restrict__
 // this runs (same stream), so the read-modify-write is plain -- and S is the same bit pattern run after run.
 __global__ __launch_bounds__(256) void ba_gather_slabs(const double* __restrict__ slab, const int* __restrict__ ptr,
                                                        const unsigned* __restrict__ src, const int* __restrict__ dest, int nd,
-                                                       double* __restrict__ red, long long gmax_off) {
+                                                       double* __restrict__ red, long long gmax_off, const LmDev* __restrict__ lm) {
+  if (lm && lm->stop != LM_RUNNING) return;
   // sixteen lanes per destination (a destination has 10-30 sources, each in another chunk's slab: one load deep instead
   // of a chain of dependent loads per thread); lane j takes sources j, j + 16, ... in order, the lanes meet by the
   // fixed tree of row16_sum -- the same order every run
@@ -871,8 +1025,9 @@ __global__ __launch_bounds__(256) void ba_gather_rows(const double* __restrict__
                                                       const int4* __restrict__ row_head, const int4* __restrict__ row_src, int nrows,
                                                       int row_wgs, int ld, int fo, int nchunks, const int* __restrict__ ptr,
                                                       const unsigned* __restrict__ src, const int* __restrict__ dest, int nd,
-                                                      double* __restrict__ red, long long gmax_off, int rmw) {
+                                                      double* __restrict__ red, long long gmax_off, int rmw, const LmDev* __restrict__ lm) {
   extern __shared__ double s_acc[];  // per wave: ld + 3 (the row of S | g's entry | the F^T F diagonal's | F^T b's)
+  if (lm && lm->stop != LM_RUNNING) return;
   if ((int)blockIdx.x == (int)gridDim.x - 1) {
     // the last workgroup: the seven destinations that every chunk adds to (the focal parameter's diagonal entry and gradient
     // from the Gram block's border, its F^T F diagonal and F^T b, the cost, the gradient maximum, the failed point blocks):
@@ -1017,6 +1172,10 @@ __global__ __launch_bounds__(256) void ba_cam_blocks(BaDev d, const int* __restr
   __shared__ double sh[4][36];
   __shared__ double sh2[4][33];
   __shared__ int s_last;
+  {
+    double radius_unused;
+    lm_view(d, radius_unused);
+  }
   double q[33];  // the Schur part of the same 33 slots: T T^T (upper 21), T t_f (6), T u (6)
 #pragma unroll
   for (int e = 0; e < 33; ++e) q[e] = 0.0;
@@ -1202,6 +1361,7 @@ __global__ __launch_bounds__(256) void ba_pp_points(BaDev d, const int* __restri
                                                     int n_list, double radius, double lm_lo, double lm_hi, int rank,
                                                     double* __restrict__ T, double* __restrict__ tfu, int norms,
                                                     double* __restrict__ part /* 8 per workgroup */) {
+  lm_view(d, radius);
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = gt / PP_LANES, sub = gt % PP_LANES;
   double sff = 0, gf = 0, jf2 = 0, jfr = 0, rr = 0, gmax = 0, nfail = 0;
@@ -1348,6 +1508,7 @@ __global__ __launch_bounds__(64) void ba_pp_pairs(BaDev d, const int* __restrict
 __global__ __launch_bounds__(1024) void ba_finalize(BaDev d, double radius, double lm_lo, double lm_hi, int world,
                                                     int add_diag) {
   __shared__ double sh[16];
+  if (d.lm) radius = d.lm->radius;
   double* S = red_S(d);
   const double* gF = red_gF(d);
   const double* dc = red_dc(d);
@@ -2418,6 +2579,7 @@ __global__ __launch_bounds__(256) void nd_gather(NdSet ns, const int4* __restric
     for (long long i = threadIdx.x; i < n2; i += 256) p2[i] = make_double2(0.0, 0.0);
     return;
   }
+  if (d.lm) radius = d.lm->radius;
   const int4 job = jobs[blockIdx.x];
   if (job.w == 4) {
     if (!fin) return;
@@ -2646,6 +2808,11 @@ __global__ __launch_bounds__(256) void nd_w(NdSet ns, NdCols cols) {
 // ---------------------------------------------------------------- step application
 // candidate cameras / focal: x + (-z)*scale, their tables, and the camera part of the norms
 __global__ void ba_cand_cams(BaDev d, const unsigned char* __restrict__ cam_used, int rank) {
+  if (lm_stopped(d)) return;
+  {
+    double radius_unused;
+    lm_view(d, radius_unused);
+  }
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   double sn2 = 0, cn2 = 0;
   if (c < d.nc) {
@@ -2669,16 +2836,15 @@ __global__ void ba_cand_cams(BaDev d, const unsigned char* __restrict__ cam_used
     sn2 += dl * dl;
     cn2 += f * f;
   }
-  // (one atomic pair per wave: 201 threads adding to the same two addresses drain at ~44 ns each, which was the
-  // kernel's whole 8.8 us)
+  // (the camera part of the norms: a pair of sums per wave -- one workgroup is one wave here -- that step_finish adds in wave order)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     sn2 += __shfl_down(sn2, o);
     cn2 += __shfl_down(cn2, o);
   }
-  if (rank == 0 && (threadIdx.x & 63) == 0 && (sn2 != 0 || cn2 != 0)) {
-    atomic_add_f64(d.red2 + 2, sn2);
-    atomic_add_f64(d.red2 + 3, cn2);
+  if ((threadIdx.x & 63) == 0) {
+    double* cp = d.step_part + 4 * (size_t)d.step_total + 2 * (size_t)blockIdx.x;
+    cp[0] = sn2, cp[1] = cn2;
   }
 }
 
@@ -2694,8 +2860,143 @@ __global__ void ba_cand_cams(BaDev d, const unsigned char* __restrict__ cam_used
 // wave alike.  A thread walks a chain of dependent loads per observation; with one wave per block a SIMD has 1.5
 // waves and nothing to overlap them with.
 constexpr int BS_SUMS = 14;
+
+// A record on its way to the host: LmDev into slot seq % LM_RING of the pinned ring, its seq word last (the host spins on the
+// slot of the decision it waits for, and reads the ring for the log).
+__device__ __forceinline__ void lm_publish(const BaDev& d, const LmDev& s) {
+  constexpr int NW = (int)(sizeof(LmDev) / 4);
+  static_assert(sizeof(LmDev) % 8 == 0 && offsetof(LmDev, seq) % 4 == 0, "LmDev is copied word by word");
+  volatile unsigned* dst = (volatile unsigned*)(d.lm_host) + (size_t)(s.seq % LM_RING) * NW;
+  const unsigned* src = (const unsigned*)&s;
+  constexpr int SEQ_W = (int)(offsetof(LmDev, seq) / 4);
+  for (int w = 0; w < NW; ++w)
+    if (w != SEQ_W) dst[w] = src[w];
+  __threadfence_system();
+  dst[SEQ_W] = s.seq;
+  __threadfence_system();
+}
+
+// the decision itself, by ONE thread, once every sum it reads is final (the last workgroup of the step evaluation, or
+// ba_decide behind the all-reduce): the linearisation's scalars, the step evaluation's sums, the reduced solve's status
+__device__ __forceinline__ void lm_decide_here(const BaDev& d) {
+  const double* scv = red_sc(d);
+  LmIn in;
+  in.lin_cost = 0.5 * scv[0];
+  in.lin_nfail = scv[2];
+  in.lin_gmax = scv[3];
+  in.cost_c = 0.5 * d.red2[0];
+  in.mcc = -d.red2[1];
+  in.step_n2 = d.red2[2];
+  in.cand_n2 = d.red2[3];
+  in.info = *(volatile int*)d.info;
+  LmDev s = *d.lm;
+  lm_decide(s, in);
+  *d.lm = s;
+}
+
+__global__ void ba_decide(BaDev d) {
+  if (threadIdx.x == 0) lm_decide_here(d);
+}
+
+// the record as it stands, into the host's ring: behind the last iteration of a batch (the host waits for it there), behind
+// every iteration when the log is on -- not inside the decision, whose kernel every next kernel waits for
+__global__ void ba_lm_publish(BaDev d) {
+  if (threadIdx.x == 0) {
+    const LmDev s = *d.lm;
+    lm_publish(d, s);
+  }
+}
+
+// End of a step-evaluation workgroup: its four sums (thread 0 holds them) go to the workgroup's own slot, fire and forget.
+// The FINISHER -- the last workgroup of the step evaluation's last kernel -- then adds all slots, and the cameras' parts, in
+// a fixed order (a tree over the slot index) and leaves the totals in red2[0..3] (what the all-reduce, the decision and the
+// host read): the sums -- hence rho, the radius, the whole trajectory -- are the same bits every run, which atomics on
+// shared words were not.  The data is its own flag (as in the down-sweep's mailbox): a slot holds a NaN no sum produces
+// until its workgroup has written it, the finisher polls a slot until it is something else and puts the NaN back.  No
+// fence, no counter, no wait on the writers' side: slots are written and read with agent-scope accesses (they bypass the
+// non-coherent cache levels); the polls are bounded (a spin that runs out reports info = -1).  With the loop on the device
+// and one rank the finisher takes the LM decision too.
+#define STEP_PENDING 0x7FF8DEADBEEF0001ull
+template <bool DECIDE>
+__device__ __forceinline__ void step_finish(const BaDev& d, int slot, double cost_c, double mcc, double sn2, double cn2, int rank) {
+  __shared__ double s_fin[4][4];
+  __shared__ int s_to;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) {
+    gbl_double* my = (gbl_double*)(d.step_part + 4 * (size_t)slot);
+    double v[4] = {cost_c, mcc, sn2, cn2};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if ((unsigned long long)__double_as_longlong(v[k]) == STEP_PENDING) v[k] = __longlong_as_double(0x7FF8000000000000ll);
+      __hip_atomic_store(my + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_to = 0;
+  }
+  if (!(d.step_last && blockIdx.x == gridDim.x - 1)) return;
+  __syncthreads();
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = tid; i < d.step_total; i += (int)blockDim.x) {
+    gbl_double* q = (gbl_double*)(d.step_part + 4 * (size_t)i);
+    double v[4];
+    int budget = 1 << 16;
+    for (;;) {
+      bool pending = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[k] = __hip_atomic_load(q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pending |= (unsigned long long)__double_as_longlong(v[k]) == STEP_PENDING;
+      }
+      if (!pending) break;
+      if (--budget == 0) {
+        s_to = 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = 0.0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      __hip_atomic_store(q + k, __longlong_as_double((long long)STEP_PENDING), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next step evaluation)
+      a[k] += v[k];
+    }
+  }
+  if (rank == 0) {  // (the cameras and the focal are every rank's: counted once)
+    const double* cp = d.step_part + 4 * (size_t)d.step_total;  // (written by an earlier kernel of the stream)
+    for (int i = tid; i < d.cam_parts; i += (int)blockDim.x) a[2] += cp[2 * i], a[3] += cp[2 * i + 1];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] += __shfl_down(a[k], off);
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_fin[k][wave] = a[k];
+  __syncthreads();
+  if (tid == 0) {
+    const int nw = (int)blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double v = s_fin[k][0];
+      for (int w = 1; w < nw; ++w) v += s_fin[k][w];
+      d.red2[k] = v;
+    }
+    if (s_to) atomicExch(d.info, -1);  // (a workgroup of the step evaluation never wrote its slot: not a state the data can cause)
+    if (DECIDE && d.lm && d.decide_here) lm_decide_here(d);
+  }
+}
+
+// a step evaluation enqueued behind a stop: nothing is evaluated; the decision is still counted (the host waits for its number)
+template <bool DECIDE>
+__device__ __forceinline__ void step_skip(const BaDev& d) {
+  if (DECIDE && d.step_last && d.decide_here && blockIdx.x == 0 && threadIdx.x == 0) lm_decide_here(d);
+}
+
 template <int WPP>
-__global__ __launch_bounds__(256) void ba_backsub(BaDev d, double radius, double lm_lo, double lm_hi, const int* __restrict__ plist, int npl) {
+__global__ __launch_bounds__(256) void ba_backsub(BaDev d, double radius, double lm_lo, double lm_hi, const int* __restrict__ plist, int npl,
+                                                  int slot0 /* this kernel's first slot of step_part */) {
+  if (lm_stopped(d)) return;  // (the decision of a launch of this kernel is ba_decide's: the kernel sits at its register limit)
+  lm_view(d, radius);
   constexpr int BLOCKS = 4 / WPP;  // blocks of 64 points per workgroup
   __shared__ double s_part[WPP > 1 ? 4 * BS_SUMS * 64 : 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -2830,13 +3131,8 @@ __global__ __launch_bounds__(256) void ba_backsub(BaDev d, double radius, double
     sh[3][wave] = cn2;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double* slot = d.red2 + 8 + 4 * (blockIdx.x % RED2_SLOTS);
-    atomic_add_f64(slot + 0, sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
-    atomic_add_f64(slot + 1, sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
-    atomic_add_f64(slot + 2, sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3]);
-    atomic_add_f64(slot + 3, sh[3][0] + sh[3][1] + sh[3][2] + sh[3][3]);
-  }
+  step_finish<false>(d, slot0 + (int)blockIdx.x, sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3],
+              sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3], sh[3][0] + sh[3][1] + sh[3][2] + sh[3][3], d.rank);
 }
 
 // The same step for the points in runs (ba_eliminate_mfma's chunks: contiguous points that see the same ascending camera list, at most
@@ -2851,6 +3147,11 @@ constexpr int BSR_PTS = 256;  // points per block of a workgroup (a thread each)
 // workgroup's loads depend on in ONE record (chunk id -> chunk -> camera list -> tables was four dependent round trips)
 __global__ __launch_bounds__(256) void ba_backsub_runs(BaDev d, const int4* __restrict__ bs_desc, double radius, double lm_lo, double lm_hi,
                                                       int split) {
+  if (lm_stopped(d)) {
+    step_skip<true>(d);
+    return;
+  }
+  lm_view(d, radius);
   __shared__ __attribute__((aligned(16))) double s_tab[10 * 12];    // the run's cameras: R, t ...
   __shared__ __attribute__((aligned(16))) double s_tabc[10 * 12];   // ... the candidates' R, t ...
   __shared__ __attribute__((aligned(16))) double s_zs[10 * 12];     // ... and per camera: M = sum_j scale_j z_j dR/dw_j (9), scale z of the translation (3)
@@ -3012,13 +3313,8 @@ __global__ __launch_bounds__(256) void ba_backsub_runs(BaDev d, const int4* __re
     sh[3][wave] = cn2;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double* slot = d.red2 + 8 + 4 * (blockIdx.x % RED2_SLOTS);
-    atomic_add_f64(slot + 0, sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
-    atomic_add_f64(slot + 1, sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
-    atomic_add_f64(slot + 2, sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3]);
-    atomic_add_f64(slot + 3, sh[3][0] + sh[3][1] + sh[3][2] + sh[3][3]);
-  }
+  step_finish<true>(d, (int)blockIdx.x, sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3],
+              sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3], sh[3][0] + sh[3][1] + sh[3][2] + sh[3][3], d.rank);
 }
 
 __global__ void ba_cam_norm(BaDev d, const unsigned char* __restrict__ cam_used, double* out) {
@@ -3042,16 +3338,23 @@ __global__ void ba_cam_norm(BaDev d, const unsigned char* __restrict__ cam_used,
 
 // ================================================================= host side
 struct LmState {
-  bool started = false, have_lin = false;
-  bool lin_unread = false;  // cost / gradient of the enqueued linearisation not read back yet
-  double radius = 1e4, decrease_factor = 2.0;
-  int invalid = 0, iter = 0, nsucc = 0;
-  double x_norm = 0, cost = 0, initial_cost = 0, gmax = 0;
+  bool started = false;
+  bool have_lin = false;  // the reduced system in `red` is the linearisation at the current x with the current radius
+  LmDev s{};              // the trust-region record (the host's copy; the device's own while a device loop runs)
 };
 
 struct sfmhip_ba {
   sfmhip_ctx* ctx = nullptr;
   LmState lm;
+  // the loop on the device (round 5): the record, the host's ring of copies, the step evaluation's slots
+  LmDev* d_lm = nullptr;
+  LmDev* h_ring = nullptr;      // pinned, LM_RING records
+  LmDev* h_ring_dev = nullptr;  // the same as the device sees it
+  unsigned lm_seq = 0;          // decisions made on this problem so far (monotonic: a stale ring slot never matches)
+  double* d_step_part = nullptr;
+  size_t step_part_n = 0;
+  bool tree_by_level = false;   // a hand-off between fronts timed out once: one launch per tree level from then on
+  int spin_timeouts = 0;
   int nc = 0, np_in = 0, no_in = 0;  // as given
   int np = 0, no = 0;                // with >= 1 observation, sorted order
   int dim = 0, ld = 0;
@@ -3830,6 +4133,22 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   SFM_HIP_TRY(hipHostMalloc((void**)&b->h_sc, sizeof(double) * (SC + 64 + RED2_N + 1), hipHostMallocDefault));
   SFM_HIP_TRY(hipHostGetDevicePointer((void**)&b->h_sc_dev, b->h_sc, 0));
   b->h_sc[SC + 64 + RED2_N] = 0.0;
+  // the trust-region record, the host's ring of copies of it, the step evaluation's slots (runs x split <= 8, blocks of 64
+  // points of ba_backsub, then a pair per front / per wave of ba_cand_cams)
+  SFM_HIP_TRY(hipHostMalloc((void**)&b->h_ring, sizeof(LmDev) * LM_RING, hipHostMallocDefault));
+  memset(b->h_ring, 0, sizeof(LmDev) * LM_RING);
+  SFM_HIP_TRY(hipHostGetDevicePointer((void**)&b->h_ring_dev, b->h_ring, 0));
+  SFM_TRY(ba_alloc(b, &b->d_lm, 1));
+  b->step_part_n = 4 * ((size_t)b->n_chunks * 8 + ((size_t)b->np + 63) / 64 + 8) + 2 * ((size_t)n_cam + 64);
+  SFM_TRY(ba_alloc(b, &b->d_step_part, b->step_part_n));
+  {
+    std::vector<unsigned long long> pend(b->step_part_n, STEP_PENDING);  // (a slot is a NaN no sum produces until its workgroup has written it)
+    SFM_HIP_TRY(hipMemcpy(b->d_step_part, pend.data(), sizeof(double) * b->step_part_n, hipMemcpyHostToDevice));
+  }
+  d.lm = nullptr;
+  d.step_part = b->d_step_part;
+  d.step_total = 0, d.cam_parts = 0, d.decide_here = 0, d.rank = 0;
+  d.lm_host = (double*)b->h_ring_dev;
   for (auto& e : b->ev) SFM_HIP_TRY(hipEventCreate(&e));
   b->h_pts_in.assign(3 * (size_t)n_pt, 0.0);
   lap_("pinned + events");
@@ -3852,6 +4171,7 @@ extern "C" int sfmhip_ba_set_allreduce(sfmhip_ba* b, sfmhip_allreduce_fn fn, voi
   b->allreduce = fn;
   b->allreduce_user = user;
   b->rank = rank;
+  b->d.rank = rank;
   b->world = world;
   if (world > 1 && !b->d_red_pack) {
     SFM_HIP_TRY(hipSetDevice(b->ctx->device));
@@ -4006,12 +4326,12 @@ static int ba_launch_eliminate(sfmhip_ba* b, double inv_radius, double lm_lo, do
                        (const double*)slab, (const int*)b->d_grow_colmap, (const int4*)b->d_grow_hdr,
                        (const int4*)b->d_grow_head, (const int4*)b->d_grow_src, b->n_grow, rw, b->ld, 6 * b->nc, b->n_chunks, (const int*)b->d_gth_ptr[0],
                        (const unsigned*)b->d_gth_src[0], (const int*)b->d_gth_dest[0], b->n_gth[0], b->d.red,
-                       (long long)(b->ssz + 3 * (size_t)b->ld + SC + b->rank), b->n_fb ? 1 : 0);
+                       (long long)(b->ssz + 3 * (size_t)b->ld + SC + b->rank), b->n_fb ? 1 : 0, (const LmDev*)b->d.lm);
     ++nl;
   } else if (slab && nl && b->n_gth[m]) {
     hipLaunchKernelGGL(ba_gather_slabs, dim3((b->n_gth[m] + 15) / 16), dim3(256), 0, st, (const double*)slab,
                        (const int*)b->d_gth_ptr[m], (const unsigned*)b->d_gth_src[m], (const int*)b->d_gth_dest[m], b->n_gth[m],
-                       b->d.red, (long long)(b->ssz + 3 * (size_t)b->ld + SC + b->rank));
+                       b->d.red, (long long)(b->ssz + 3 * (size_t)b->ld + SC + b->rank), (const LmDev*)b->d.lm);
     ++nl;
   }
   return nl;
@@ -4705,42 +5025,83 @@ static int ba_reduced_solve(sfmhip_ba* b) {
   return SFMHIP_OK;
 }
 
+// (no point carries an observation: the step evaluation has no kernel of its own, the camera parts are still summed -- and the
+// decision still taken -- by the one workgroup of this)
+__global__ __launch_bounds__(256) void ba_step_nopoints(BaDev d) {
+  if (lm_stopped(d)) {
+    step_skip<true>(d);
+    return;
+  }
+  step_finish<true>(d, 0, 0.0, 0.0, 0.0, 0.0, d.rank);
+}
+
+// the slots of the step evaluation's sums: a slot per workgroup of its kernels, then a pair per front of the down-sweep (or per
+// wave of ba_cand_cams).  Fixed per problem; set before the reduced solve, whose down-sweep writes the camera parts.
+struct StepLayout {
+  bool runs;
+  int n_runs_wg, npl, n_bs_wg, split, wpp;
+  const int* plist;
+};
+static StepLayout ba_step_layout(sfmhip_ba* b) {
+  static const bool runs_env = !(getenv("SFMHIP_BA_BACKSUB_RUNS") && atoi(getenv("SFMHIP_BA_BACKSUB_RUNS")) == 0);
+  static const int wpp_env = getenv("SFMHIP_BA_BACKSUB_WPP") ? atoi(getenv("SFMHIP_BA_BACKSUB_WPP")) : 2;  // (measurement)
+  static const int split_env = getenv("SFMHIP_BA_BACKSUB_SPLIT") ? std::min(8, std::max(1, atoi(getenv("SFMHIP_BA_BACKSUB_SPLIT")))) : 1;  // (measured at cfg4: 21.0 us / 33 / 53 for 1 / 2 / 4 workgroups per run)
+  StepLayout L;
+  // the points in runs: a thread per point, the run's cameras in LDS (ba_backsub_runs); the pair path's points (or,
+  // SFMHIP_BA_BACKSUB_RUNS=0, all of them): ba_backsub
+  L.runs = runs_env && b->n_chunks > 0 && b->d_bs_ids && b->np > 0;
+  L.split = split_env, L.wpp = wpp_env;
+  L.n_runs_wg = L.runs ? b->n_chunks * split_env : 0;
+  L.plist = L.runs ? b->d_fb_points : nullptr;
+  L.npl = b->np ? (L.runs ? b->n_fb : b->np) : 0;
+  const size_t nblk = ((size_t)L.npl + 63) / 64;  // blocks of 64 points
+  L.n_bs_wg = L.npl <= 0 ? 0 : wpp_env == 1 ? (int)((nblk + 3) / 4) : wpp_env == 2 ? (int)((nblk + 1) / 2) : (int)nblk;
+  b->d.step_total = std::max(1, L.n_runs_wg + L.n_bs_wg);
+  b->d.cam_parts = b->tree_on ? b->tree_fs.n_fronts : (b->nc + 1 + 63) / 64;
+  return L;
+}
+
 static int ba_step_eval(sfmhip_ba* b, double radius, const sfmhip_ba_opts* o) {
   hipStream_t st = b->ctx->stream;
   BaDev& d = b->d;
+  const StepLayout L = ba_step_layout(b);
+  const bool runs = L.runs;
+  const int n_runs_wg = L.n_runs_wg, npl = L.npl, n_bs_wg = L.n_bs_wg, split_env = L.split, wpp_env = L.wpp;
+  const int* plist = L.plist;
+  // (the decision: by the finisher of ba_backsub_runs when that is the step evaluation's last kernel and there is one
+  // rank; else by ba_decide behind the all-reduce)
+  d.decide_here = d.lm && b->world == 1 && npl <= 0 ? 1 : 0;
+  if (4 * (size_t)d.step_total + 2 * (size_t)d.cam_parts > b->step_part_n) return SFMHIP_ERR_STATE;
   if (!b->tree_on) hipLaunchKernelGGL(ba_cand_cams, dim3((b->nc + 1 + 63) / 64), dim3(64), 0, st, d, b->d_cam_used, b->rank);
   int nbs = 0;
-  if (b->np) {
-    // the points in runs: a row of 16 lanes per point (ba_backsub_runs); the pair path's points (or, SFMHIP_BA_BACKSUB_RUNS=0,
-    // all of them): a thread per point
-    static const bool runs_env = !(getenv("SFMHIP_BA_BACKSUB_RUNS") && atoi(getenv("SFMHIP_BA_BACKSUB_RUNS")) == 0);
-    static const int wpp_env = getenv("SFMHIP_BA_BACKSUB_WPP") ? atoi(getenv("SFMHIP_BA_BACKSUB_WPP")) : 2;  // (measurement)
-    const bool runs = runs_env && b->n_chunks > 0 && b->d_bs_ids;
-    if (runs) {
-      static const int split_env = getenv("SFMHIP_BA_BACKSUB_SPLIT") ? std::max(1, atoi(getenv("SFMHIP_BA_BACKSUB_SPLIT"))) : 1;  // (measured at cfg4: 21.0 us / 33 / 53 for 1 / 2 / 4 workgroups per run)
-      hipLaunchKernelGGL(ba_backsub_runs, dim3(b->n_chunks * split_env), dim3(256), 0, st, d, (const int4*)b->d_bs_ids, radius,
-                         o->min_lm_diagonal, o->max_lm_diagonal, split_env);
-      ++nbs;
-    }
-    const int* plist = runs ? b->d_fb_points : nullptr;
-    const int npl = runs ? b->n_fb : b->np;
-    if (npl > 0) {
-      const size_t nblk = ((size_t)npl + 63) / 64;  // blocks of 64 points
-      if (wpp_env == 1)
-        hipLaunchKernelGGL(ba_backsub<1>, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, st, d, radius, o->min_lm_diagonal,
-                           o->max_lm_diagonal, plist, npl);
-      else if (wpp_env == 2)
-        hipLaunchKernelGGL(ba_backsub<2>, dim3((unsigned)((nblk + 1) / 2)), dim3(256), 0, st, d, radius, o->min_lm_diagonal,
-                           o->max_lm_diagonal, plist, npl);
-      else
-        hipLaunchKernelGGL(ba_backsub<4>, dim3((unsigned)nblk), dim3(256), 0, st, d, radius, o->min_lm_diagonal,
-                           o->max_lm_diagonal, plist, npl);
-      ++nbs;
-    }
+  if (runs) {
+    d.step_last = npl > 0 ? 0 : 1;
+    hipLaunchKernelGGL(ba_backsub_runs, dim3(n_runs_wg), dim3(256), 0, st, d, (const int4*)b->d_bs_ids, radius, o->min_lm_diagonal,
+                       o->max_lm_diagonal, split_env);
+    ++nbs;
+  }
+  d.step_last = 1;
+  if (npl > 0) {
+    if (wpp_env == 1)
+      hipLaunchKernelGGL(ba_backsub<1>, dim3(n_bs_wg), dim3(256), 0, st, d, radius, o->min_lm_diagonal, o->max_lm_diagonal, plist, npl, n_runs_wg);
+    else if (wpp_env == 2)
+      hipLaunchKernelGGL(ba_backsub<2>, dim3(n_bs_wg), dim3(256), 0, st, d, radius, o->min_lm_diagonal, o->max_lm_diagonal, plist, npl, n_runs_wg);
+    else
+      hipLaunchKernelGGL(ba_backsub<4>, dim3(n_bs_wg), dim3(256), 0, st, d, radius, o->min_lm_diagonal, o->max_lm_diagonal, plist, npl, n_runs_wg);
+    ++nbs;
+  }
+  if (!nbs) {
+    hipLaunchKernelGGL(ba_step_nopoints, dim3(1), dim3(256), 0, st, d);
+    ++nbs;
   }
   SFM_HIP_TRY(hipGetLastError());
   b->launches += (b->tree_on ? 0 : 1) + nbs;
-  SFM_TRY(ba_allreduce(b, d.red2, RED2_SUM_N));
+  SFM_TRY(ba_allreduce(b, d.red2, 8));
+  if (d.lm && !d.decide_here) {  // (several ranks: every rank takes the same decision from the same all-reduced sums)
+    hipLaunchKernelGGL(ba_decide, dim3(1), dim3(64), 0, st, d);
+    SFM_HIP_TRY(hipGetLastError());
+    b->launches += 1;
+  }
   return SFMHIP_OK;
 }
 
@@ -4801,13 +5162,11 @@ static int ba_read_scalars(sfmhip_ba* b, IterScalars* s, bool with_step) {
   s->nfail = b->h_sc[2];
   s->gmax = b->h_sc[3];
   if (with_step) {
-    const double* step = b->h_sc + SC + 64;
-    double sum[4] = {step[0], step[1], step[2], step[3]};
-    for (int k = 0; k < 4 * RED2_SLOTS; ++k) sum[k & 3] += step[8 + k];
-    s->cost_c = 0.5 * sum[0];
-    s->mcc = -sum[1];
-    s->step_n2 = sum[2];
-    s->cand_n2 = sum[3];
+    const double* step = b->h_sc + SC + 64;  // (red2[0..3]: the totals step_finish left, all-reduced)
+    s->cost_c = 0.5 * step[0];
+    s->mcc = -step[1];
+    s->step_n2 = step[2];
+    s->cand_n2 = step[3];
     memcpy(&s->info, step + RED2_INFO, sizeof(int));
   }
   return SFMHIP_OK;
@@ -4823,18 +5182,28 @@ static void ba_acc_timing(sfmhip_ba* b) {
   for (bool& on : b->ev_on) on = false;
 }
 
-// TrustRegionMinimizer::Minimize (Ceres 1.13) + LevenbergMarquardtStrategy, host control loop.
-// The loop state lives in the sfmhip_ba object so that sfmhip_ba_iterate can be called one
-// iteration at a time (bench.py interleaves it with matching sweeps).
+// TrustRegionMinimizer::Minimize (Ceres 1.13) + LevenbergMarquardtStrategy.  The decision itself is lm_decide (above),
+// taken on the device by default; the loop state lives in the sfmhip_ba object so that sfmhip_ba_iterate can be called a
+// few iterations at a time (bench.py interleaves it with matching sweeps).
+static void lm_set_options(LmDev& s, const sfmhip_ba_opts* o, bool timing_only) {
+  s.gtol = o->gradient_tolerance, s.ptol = o->parameter_tolerance, s.ftol = o->function_tolerance;
+  s.min_rel_dec = o->min_relative_decrease, s.max_radius = o->max_radius, s.min_radius = o->min_radius;
+  s.max_invalid = o->max_consecutive_invalid;
+  s.max_iter = timing_only ? 0x7FFFFFFF : o->max_iterations;
+  s.timing_only = timing_only ? 1 : 0;
+  s.stop = LM_RUNNING;
+}
+
 static int ba_begin(sfmhip_ba* b, const sfmhip_ba_opts* o) {
   SFM_HIP_TRY(hipSetDevice(b->ctx->device));
   for (double& t : b->t_acc) t = 0;
   b->launches = 0;
   if (!b->nd_ready) SFM_TRY(ba_nd_build(b));
   SFM_TRY(ba_prepare_scale(b, o->jacobi_scaling));
-  LmState& s = b->lm;
-  s = LmState();
+  b->lm = LmState();
+  LmDev& s = b->lm.s;
   s.radius = o->initial_radius;
+  s.dec_factor = 2.0;
   s.x_norm = b->x_norm;
   // iteration 0: cost + gradient at x0 (the same pass also forms the first reduced system)
   IterScalars sc{};
@@ -4842,23 +5211,45 @@ static int ba_begin(sfmhip_ba* b, const sfmhip_ba_opts* o) {
   SFM_TRY(ba_read_scalars(b, &sc, false));
   s.cost = s.initial_cost = sc.cost;
   s.gmax = sc.gmax;
-  s.have_lin = true;
-  s.started = true;
+  b->lm.have_lin = true;
+  b->lm.started = true;
   return SFMHIP_OK;
 }
 
-// one LM iteration; *stop receives the termination type once a stopping rule fires (-1 else)
-static int ba_one_iteration(sfmhip_ba* b, const sfmhip_ba_opts* o, bool timing_only, int* stop) {
-  hipStream_t st = b->ctx->stream;
-  LmState& s = b->lm;
-  IterScalars sc{};
-  *stop = -1;
-  ++s.iter;
+static void lm_log(const sfmhip_ba* b, const LmDev& r) {
+  if (r.log_kind == LM_KIND_NONE) return;
+  if (r.log_kind == LM_KIND_INVALID)
+    fprintf(stderr, "[sfmhip-ba] it %d invalid step (info %d, point blocks not PD %.0f, model cost change %.6e, candidate cost %.6e, |step|^2 %.6e), radius %.3e\n",
+            r.iter, r.log_info, r.log_nfail, r.log_mcc, r.log_cost_c, r.log_step_norm, r.radius);
+  else if (r.log_kind == LM_KIND_STOP && r.stop == LM_STOP_TIMEOUT)
+    fprintf(stderr, "[sfmhip-ba] a bounded spin of the reduced solve ran out (info %d): the solve is repeated level by level\n", r.log_info);
+  else
+    fprintf(stderr, "[sfmhip-ba] it %d cost %.9e -> %.9e rho %.3e radius %.3e |step| %.3e%s\n", r.iter, r.log_cost0, r.log_cost_c, r.log_rho,
+            r.radius, r.log_step_norm, r.log_kind == LM_KIND_ACCEPTED ? "" : r.log_kind == LM_KIND_REJECTED ? " (rejected)" : " (stop)");
+  static const bool bits = getenv("SFMHIP_BA_VERBOSE_BITS") != nullptr;  // (diagnostics: the decision's inputs to the last bit)
+  if (bits) fprintf(stderr, "[sfmhip-ba-bits] it %d cost %a cost_c %a mcc %a rho %a radius %a |step| %a\n", r.iter, r.log_cost0, r.log_cost_c, r.log_mcc, r.log_rho, r.radius, r.log_step_norm);
+  (void)b;
+}
+
+// the linearisation at the current x with the current radius, if the reduced-system buffer does not hold it
+static int ba_ensure_lin(sfmhip_ba* b, const sfmhip_ba_opts* o) {
+  if (b->lm.have_lin) return SFMHIP_OK;
   b->defer_fin = true;  // (the dissected solve follows: its gather does ba_finalize's part)
-  if (!s.have_lin) SFM_TRY(ba_linearize_eliminate(b, s.radius, o, true));
+  const int rc = ba_linearize_eliminate(b, b->lm.s.radius, o, true);
   b->defer_fin = false;
-  s.have_lin = false;
+  SFM_TRY(rc);
+  b->lm.have_lin = true;
+  return SFMHIP_OK;
+}
+
+// one iteration body, enqueued: [the linearisation, unless the buffer holds it] + reduced solve + step evaluation
+// (+ the decision, when the loop runs on the device)
+static int ba_enqueue_body(sfmhip_ba* b, const sfmhip_ba_opts* o) {
+  hipStream_t st = b->ctx->stream;
+  SFM_TRY(ba_ensure_lin(b, o));
+  b->lm.have_lin = false;
   b->solve_cand = true;  // (the front tree's down-sweep leaves the candidate cameras and their tables)
+  ba_step_layout(b);     // (... and the camera parts of the step's norms, in the slots behind the step evaluation's)
   const int rc_solve = ba_reduced_solve(b);
   b->solve_cand = false;
   SFM_TRY(rc_solve);
@@ -4866,109 +5257,190 @@ static int ba_one_iteration(sfmhip_ba* b, const sfmhip_ba_opts* o, bool timing_o
     SFM_HIP_TRY(hipEventRecord(b->ev[3], st));
     b->ev_on[3] = true;
   }
-  SFM_TRY(ba_step_eval(b, s.radius, o));
+  SFM_TRY(ba_step_eval(b, b->lm.s.radius, o));
   if (b->ctx->timing) {
     SFM_HIP_TRY(hipEventRecord(b->ev[4], st));
     b->ev_on[4] = true;
   }
-#ifdef SFM_DBG_NOWAIT
-  // diagnostic build only (scripts/gpu_ba_nowait.py): the loop with the host taken out of it -- every step accepted unseen, the
-  // next linearisation enqueued at once -- to measure what the publish kernel, the PCIe round trip, the host's decision and the
-  // launch latency behind it cost per iteration.  The iterates are meaningless.
-  if (getenv("SFMHIP_DBG_NOWAIT") && s.iter > 2) {
-    ba_swap_candidate(b);
-    b->defer_fin = true;
-    SFM_TRY(ba_linearize_eliminate(b, s.radius, o, true));
-    b->defer_fin = false;
-    s.have_lin = true;
-    s.lin_unread = true;
-    if (s.iter % 64 == 0) SFM_HIP_TRY(hipStreamSynchronize(st));
+  return SFMHIP_OK;
+}
+
+// the record of decision `seq`, as soon as the device has written it into the host's ring
+static int ba_wait_record(sfmhip_ba* b, unsigned seq, LmDev* out) {
+  volatile LmDev* slot = b->h_ring + seq % LM_RING;
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (slot->seq != seq) {
+    if ((++spins & 0xFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.02) {
+      SFM_HIP_TRY(hipStreamSynchronize(b->ctx->stream));  // (a long batch, or a fault on the stream, which this surfaces)
+      if (slot->seq != seq) return SFMHIP_ERR_HIP;
+      break;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  memcpy(out, (const void*)slot, sizeof(LmDev));
+  return SFMHIP_OK;
+}
+
+// A reduced solve reported a spin that ran out (info < 0).  In the front tree that is a child front that did not get a
+// compute unit while its parent polled (a busy device; dispatch order is not a promise): from now on the tree runs one
+// launch per level, where every child has finished before its parent starts.  Anywhere else (the spins inside a
+// workgroup) it is a bug: the caller gets SFMHIP_ERR_TIMEOUT, not a silently different trajectory.
+static int ba_handle_timeout(sfmhip_ba* b) {
+  b->spin_timeouts += 1;
+  if (b->tree_on && !b->tree_by_level) {
+    b->tree_by_level = true;
     return SFMHIP_OK;
   }
-#endif
-  SFM_TRY(ba_read_scalars(b, &sc, true));
-  ba_acc_timing(b);
-  if (s.lin_unread) {
-    // the linearisation enqueued after the last accepted step is read together with this step's
-    // scalars (one host synchronisation per iteration); Ceres tests the gradient tolerance right
-    // after accepting a step, so a converged gradient discards the step evaluated above
-    s.lin_unread = false;
-    s.cost = sc.cost;
-    s.gmax = sc.gmax;
-    if (!timing_only && s.gmax <= o->gradient_tolerance) {
-      --s.iter;
-      *stop = SFMHIP_BA_CONVERGENCE;
+  return SFMHIP_ERR_TIMEOUT;
+}
+
+// The LM loop.  `iters` < 0: until a stopping rule fires (sfmhip_ba_run); else exactly that many iterations without
+// convergence tests (sfmhip_ba_iterate).  *term receives the termination type.
+static int ba_lm_loop(sfmhip_ba* b, const sfmhip_ba_opts* o, int iters, const std::function<double()>& elapsed, int* term) {
+  const bool t_only = iters >= 0;
+  hipStream_t st = b->ctx->stream;
+  LmDev& s = b->lm.s;
+  lm_set_options(s, o, t_only);
+  *term = SFMHIP_BA_NO_CONVERGENCE;
+  // the host decides when it is asked to (SFMHIP_BA_HOST_LOOP=1, read per call) and whenever stage timing is on (its events
+  // want a synchronisation per iteration anyway)
+  const char* hl = getenv("SFMHIP_BA_HOST_LOOP");
+  const bool host_loop = (hl && atoi(hl) != 0) || b->ctx->timing;
+  // what TrustRegionMinimizer tests before its first iteration
+  if (!t_only) {
+    if (s.iter >= s.max_iter) return SFMHIP_OK;
+    if (s.radius < s.min_radius) {
+      *term = SFMHIP_BA_CONVERGENCE;
       return SFMHIP_OK;
     }
   }
-  const bool finite = std::isfinite(sc.step_n2) && std::isfinite(sc.mcc) && std::isfinite(sc.cost_c);
-  const bool bad = sc.info != 0 || sc.nfail > 0 || !finite;
-  if (bad || !(sc.mcc > 0.0)) {  // HandleInvalidStep
-    if (++s.invalid >= o->max_consecutive_invalid && !timing_only) {
-      *stop = SFMHIP_BA_FAILURE;
-      return SFMHIP_OK;
+  auto time_is_up = [&](int* up) -> int {
+    *up = 0;
+    if (t_only || !(o->max_time_s > 0)) return SFMHIP_OK;
+    // Every other stop rule reads all-reduced scalars; a wall clock is per rank.  With world > 1 the ranks agree on it
+    // first (one 1-double sum: anybody's limit reached stops everybody), or one would leave the loop while the others
+    // wait for it in the next all-reduce.
+    *up = elapsed() >= o->max_time_s ? 1 : 0;
+    if (b->world > 1) SFM_TRY(ba_agree_flag(b, up));
+    return SFMHIP_OK;
+  };
+  int done = 0;
+  if (host_loop) {
+    b->d.lm = nullptr;
+    s.seq = b->lm_seq;
+    for (;;) {
+      if (t_only && done >= iters) break;
+      int up = 0;
+      SFM_TRY(time_is_up(&up));
+      if (up) break;
+      SFM_TRY(ba_enqueue_body(b, o));
+      IterScalars sc{};
+      SFM_TRY(ba_read_scalars(b, &sc, true));
+      ba_acc_timing(b);
+      LmIn in{sc.cost, sc.nfail, sc.gmax, sc.cost_c, sc.mcc, sc.step_n2, sc.cand_n2, sc.info};
+      lm_decide(s, in);
+      b->lm_seq = s.seq;
+      if (o->verbose) lm_log(b, s);
+      if (s.parity) {  // an accepted step: the candidate buffers become x
+        ba_swap_candidate(b);
+        s.parity = 0;
+      }
+      ++done;
+      if (s.stop == LM_STOP_TIMEOUT) {
+        SFM_TRY(ba_handle_timeout(b));
+        s.stop = LM_RUNNING;
+        --done;
+        continue;
+      }
+      if (s.stop != LM_RUNNING) {
+        *term = s.stop;
+        break;
+      }
     }
-    s.radius /= s.decrease_factor;
-    s.decrease_factor *= 2.0;
+    return SFMHIP_OK;
+  }
+  // ---- the loop on the device: iterations are enqueued a batch ahead, the records are read behind the GPU
+  static const int batch_env = getenv("SFMHIP_BA_LM_BATCH") ? std::max(1, std::min(LM_RING / 2, atoi(getenv("SFMHIP_BA_LM_BATCH")))) : 0;
+  int rc = SFMHIP_OK;
+  s.seq = b->lm_seq;
+  s.parity = 0;
+  SFM_HIP_TRY(hipMemcpyAsync(b->d_lm, &s, sizeof(LmDev), hipMemcpyHostToDevice, st));
+  b->d.lm = b->d_lm;
+  for (;;) {
+    if (t_only && done >= iters) break;
+    int up = 0;
+    if ((rc = time_is_up(&up)) != SFMHIP_OK || up) break;
+    // (several ranks: the batch is a function of the iteration count only, so that every rank issues the same all-reduces)
+    int B = batch_env ? batch_env : t_only ? LM_RING / 2 : 4;
+    if (t_only) B = std::min(B, iters - done);
+    else B = std::max(1, std::min(B, s.max_iter - s.iter));
+    const unsigned seq0 = b->lm_seq, epoch0 = b->tree_epoch;
+    for (int i = 0; i < B && rc == SFMHIP_OK; ++i) {
+      rc = ba_enqueue_body(b, o);
+      if (rc == SFMHIP_OK && (i == B - 1 || o->verbose)) hipLaunchKernelGGL(ba_lm_publish, dim3(1), dim3(64), 0, st, b->d);
+    }
+    if (rc == SFMHIP_OK && hipGetLastError() != hipSuccess) rc = SFMHIP_ERR_HIP;
+    if (rc != SFMHIP_OK) break;
+    b->lm_seq = seq0 + (unsigned)B;
+    if ((rc = ba_wait_record(b, b->lm_seq, &s)) != SFMHIP_OK) break;
     if (o->verbose)
-      fprintf(stderr, "[sfmhip-ba] it %d invalid step (info %d, point blocks not PD %.0f, model cost change %.6e, candidate cost %.6e, |step|^2 %.6e), radius %.3e\n",
-              s.iter, sc.info, sc.nfail, sc.mcc, sc.cost_c, sc.step_n2, s.radius);
-    return SFMHIP_OK;
-  }
-  s.invalid = 0;
-  const double step_norm = std::sqrt(sc.step_n2);
-  if (!timing_only) {
-    if (step_norm <= o->parameter_tolerance * (s.x_norm + o->parameter_tolerance)) {
-      *stop = SFMHIP_BA_CONVERGENCE;  // ParameterToleranceReached: candidate not taken
-      return SFMHIP_OK;
+      for (unsigned q = seq0 + 1; q <= b->lm_seq; ++q) lm_log(b, b->h_ring[q % LM_RING]);
+    done += B;
+    if (s.stop != LM_RUNNING) {
+      // The bodies enqueued behind the stop did nothing (their kernels return at once); the reduced-system buffer the last of
+      // them would have filled holds no linearisation, the other one was not zeroed, and the front tree's epochs go on from
+      // the last solve that ran (the down-sweep's mailbox alternates by epoch).
+      const int ran = (int)(s.stop_seq - seq0);
+      b->lm.have_lin = false;
+      b->alt_clean = false;
+      b->fin_pending = false;
+      if (b->tree_on) b->tree_epoch = epoch0 + (unsigned)ran;
+      if (s.stop == LM_STOP_TIMEOUT) {
+        if ((rc = ba_handle_timeout(b)) != SFMHIP_OK) break;
+        done -= B - ran + 1;  // (the solve that timed out is repeated)
+        s.stop = LM_RUNNING;
+        s.seq = b->lm_seq;
+        if (hipMemcpyAsync(b->d_lm, &s, sizeof(LmDev), hipMemcpyHostToDevice, st) != hipSuccess) {
+          rc = SFMHIP_ERR_HIP;
+          break;
+        }
+        continue;
+      }
+      *term = s.stop;
+      break;
     }
-    if (std::fabs(s.cost - sc.cost_c) <= o->function_tolerance * s.cost) {
-      *stop = SFMHIP_BA_CONVERGENCE;  // FunctionToleranceReached: candidate not taken
-      return SFMHIP_OK;
-    }
   }
-  const double rho = (s.cost - sc.cost_c) / sc.mcc;
-  if (o->verbose)
-    fprintf(stderr, "[sfmhip-ba] it %d cost %.9e -> %.9e rho %.3e radius %.3e |step| %.3e\n", s.iter, s.cost, sc.cost_c,
-            rho, s.radius, step_norm);
-  if (rho > o->min_relative_decrease) {  // HandleSuccessfulStep
+  b->d.lm = nullptr;
+  if (rc != SFMHIP_OK) {
+    hipStreamSynchronize(st);
+    b->lm.started = false;
+    return rc;
+  }
+  // the host takes over: its pointers follow the device's view of which parameter set is x
+  if (s.parity) {
     ba_swap_candidate(b);
-    s.x_norm = std::sqrt(sc.cand_n2);
-    ++s.nsucc;
-    const double q = 2.0 * rho - 1.0;
-    s.radius = s.radius / std::fmax(1.0 / 3.0, 1.0 - q * q * q);
-    s.radius = std::fmin(o->max_radius, s.radius);
-    s.decrease_factor = 2.0;
-    // re-linearise at the new x; with the new radius this is also the next reduced system.
-    // Enqueued only: its cost / gradient come back with the next iteration's scalars.
-    b->defer_fin = true;  // (finished by the next iteration's gather, or by ba_flush_lin)
-    SFM_TRY(ba_linearize_eliminate(b, s.radius, o, true));
-    b->defer_fin = false;
-    s.cost = sc.cost_c;  // provisional (same residuals, other summation order)
-    s.have_lin = true;
-    s.lin_unread = true;
-  } else {  // HandleUnsuccessfulStep
-    s.radius /= s.decrease_factor;
-    s.decrease_factor *= 2.0;
+    s.parity = 0;
   }
   return SFMHIP_OK;
 }
 
-// cost / gradient of a linearisation that is still only enqueued
-static int ba_flush_lin(sfmhip_ba* b) {
-  LmState& s = b->lm;
+// cost / gradient of the linearisation behind the last accepted step, which no decision has read yet
+static int ba_flush_lin(sfmhip_ba* b, const sfmhip_ba_opts* o) {
+  LmDev& s = b->lm.s;
   if (!s.lin_unread) return SFMHIP_OK;
   IterScalars sc{};
+  SFM_TRY(ba_ensure_lin(b, o));
   SFM_TRY(ba_finish_pending(b));
   SFM_TRY(ba_read_scalars(b, &sc, false));
   s.cost = sc.cost;
   s.gmax = sc.gmax;
-  s.lin_unread = false;
+  s.lin_unread = 0;
   return SFMHIP_OK;
 }
 
 static void ba_fill_summary(sfmhip_ba* b, int term, double time_s, sfmhip_ba_summary* sum) {
-  const LmState& s = b->lm;
+  const LmDev& s = b->lm.s;
   b->x_norm = s.x_norm;
   sum->termination = term;
   sum->iterations = s.iter;
@@ -4978,6 +5450,7 @@ static void ba_fill_summary(sfmhip_ba* b, int term, double time_s, sfmhip_ba_sum
   sum->final_radius = s.radius;
   sum->gradient_max_norm = s.gmax;
   sum->time_s = time_s;
+  sum->spin_timeouts = b->spin_timeouts;
 }
 
 extern "C" int sfmhip_ba_run(sfmhip_ba* b, const sfmhip_ba_opts* opts, sfmhip_ba_summary* summary) {
@@ -4993,36 +5466,13 @@ extern "C" int sfmhip_ba_run(sfmhip_ba* b, const sfmhip_ba_opts* opts, sfmhip_ba
   sfmhip_ba_summary sm;
   memset(&sm, 0, sizeof sm);
   SFM_TRY(ba_begin(b, opts));
-  LmState& s = b->lm;
+  LmDev& s = b->lm.s;
   int term = SFMHIP_BA_NO_CONVERGENCE;
-  if (s.gmax <= opts->gradient_tolerance) {
-    term = SFMHIP_BA_CONVERGENCE;
-  } else {
-    for (;;) {
-      if (s.iter >= opts->max_iterations) break;                            // NO_CONVERGENCE
-      if (opts->max_time_s > 0) {                                           // NO_CONVERGENCE
-        // Every other stop rule reads all-reduced scalars; a wall clock is per rank.  With world > 1 the
-        // ranks agree on it first (one 1-double sum: anybody's limit reached stops everybody), or one
-        // would leave the loop while the others wait for it in the next all-reduce.
-        int up = elapsed() >= opts->max_time_s ? 1 : 0;
-        if (b->world > 1) SFM_TRY(ba_agree_flag(b, &up));
-        if (up) break;
-      }
-      if (s.radius < opts->min_radius) {
-        term = SFMHIP_BA_CONVERGENCE;
-        break;
-      }
-      int stop = -1;
-      SFM_TRY(ba_one_iteration(b, opts, false, &stop));
-      if (stop >= 0) {
-        term = stop;
-        break;
-      }
-    }
-  }
-  SFM_TRY(ba_flush_lin(b));
+  if (s.gmax <= opts->gradient_tolerance) term = SFMHIP_BA_CONVERGENCE;
+  else SFM_TRY(ba_lm_loop(b, opts, -1, elapsed, &term));
+  SFM_TRY(ba_flush_lin(b, opts));
   if (term == SFMHIP_BA_NO_CONVERGENCE && s.gmax <= opts->gradient_tolerance) term = SFMHIP_BA_CONVERGENCE;
-  s.started = false;  // a finished solve is not resumable
+  b->lm.started = false;  // a finished solve is not resumable
   ba_fill_summary(b, term, elapsed(), &sm);
   if (summary) *summary = sm;
   return SFMHIP_OK;
@@ -5032,6 +5482,7 @@ extern "C" int sfmhip_ba_iterate(sfmhip_ba* b, int iters, sfmhip_ba_summary* sum
   if (!b || iters < 0) return SFMHIP_ERR_ARG;
   using clk = std::chrono::steady_clock;
   const auto t0 = clk::now();
+  auto elapsed = [&]() { return std::chrono::duration<double>(clk::now() - t0).count(); };
   sfmhip_ba_opts o;
   sfmhip_ba_default_opts(&o);
   static const bool verbose_env = getenv("SFMHIP_BA_VERBOSE") != nullptr;  // (diagnostics: a line per iteration on stderr)
@@ -5039,12 +5490,10 @@ extern "C" int sfmhip_ba_iterate(sfmhip_ba* b, int iters, sfmhip_ba_summary* sum
   sfmhip_ba_summary sm;
   memset(&sm, 0, sizeof sm);
   if (!b->lm.started) SFM_TRY(ba_begin(b, &o));
-  for (int i = 0; i < iters; ++i) {
-    int stop = -1;
-    SFM_TRY(ba_one_iteration(b, &o, true, &stop));
-  }
-  SFM_TRY(ba_flush_lin(b));
-  ba_fill_summary(b, SFMHIP_BA_NO_CONVERGENCE, std::chrono::duration<double>(clk::now() - t0).count(), &sm);
+  int term = SFMHIP_BA_NO_CONVERGENCE;
+  SFM_TRY(ba_lm_loop(b, &o, iters, elapsed, &term));
+  SFM_TRY(ba_flush_lin(b, &o));
+  ba_fill_summary(b, SFMHIP_BA_NO_CONVERGENCE, elapsed(), &sm);
   if (summary) *summary = sm;
   return SFMHIP_OK;
 }
@@ -5117,7 +5566,7 @@ extern "C" int sfmhip_ba_reduced_system(sfmhip_ba* b, double radius, double* S, 
   if (!b->scale_ready) SFM_TRY(ba_prepare_scale(b, o.jacobi_scaling));
   // (a test hook on a live object: the LM loop's pending linearisation is read out first, and what the hook leaves in
   // the reduced-system buffer is not that linearisation -- the next iterate linearises again)
-  SFM_TRY(ba_flush_lin(b));
+  SFM_TRY(ba_flush_lin(b, &o));
   b->lm.have_lin = false;
   // this rank's points only: no all-reduce, and the camera/focal LM diagonal (a global
   // quantity) is added only when there is a single rank
@@ -5151,7 +5600,7 @@ extern "C" int sfmhip_ba_reduced_step(sfmhip_ba* b, double radius, double* z, in
   sfmhip_ba_default_opts(&o);
   if (!b->nd_ready) SFM_TRY(ba_nd_build(b));
   if (!b->scale_ready) SFM_TRY(ba_prepare_scale(b, o.jacobi_scaling));
-  SFM_TRY(ba_flush_lin(b));  // (as in sfmhip_ba_reduced_system: the hook's system is not the LM loop's)
+  SFM_TRY(ba_flush_lin(b, &o));  // (as in sfmhip_ba_reduced_system: the hook's system is not the LM loop's)
   b->lm.have_lin = false;
   SFM_TRY(ba_linearize_eliminate(b, radius, &o, true));
   SFM_TRY(ba_reduced_solve(b));
@@ -5195,6 +5644,7 @@ extern "C" void sfmhip_ba_destroy(sfmhip_ba* b) {
   hipSetDevice(b->ctx->device);
   for (void* p : b->allocs) hipFree(p);
   if (b->h_sc) hipHostFree(b->h_sc);
+  if (b->h_ring) hipHostFree(b->h_ring);
   for (auto& e : b->ev)
     if (e) hipEventDestroy(e);
   delete b;

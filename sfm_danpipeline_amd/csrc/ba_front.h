@@ -118,6 +118,7 @@ __device__ __forceinline__ void fr_poll_flag(const unsigned* flag, unsigned epoc
     }
     __builtin_amdgcn_s_sleep(8);
   }
+  asm volatile("" ::: "memory");  // (compiler only: no load of the flagged data may be moved above the loop's exit; the hardware order is the sender's s_waitcnt + the sc1 loads)
 }
 // the other side: this wave's stores have left, then the word
 __device__ __forceinline__ void fr_raise_flag(unsigned* flag, unsigned epoch, int lane) {
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
                                                           long long zero_n, int n_zero, int xoff /* the fronts' place in every `stride` workgroups */) {
   extern __shared__ __attribute__((aligned(16))) double sAll[];
   const int nF = fs.n_fronts;
+  if (lm_stopped(d)) return;  // (an iteration enqueued behind a stop of the device's LM loop: every role of the launch returns)
   {
     // ---- which role: the fronts sit at multiples of `stride` (stride 8: one XCD's L2 under round-robin placement,
     // speed only), the workgroups between and behind them zero the other reduced-system buffer slice by slice (the next
@@ -482,6 +484,7 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
   const __amdgpu_buffer_rsrc_t pool_rs = __builtin_amdgcn_make_buffer_rsrc((void*)fs.pool, 0, 0x7FFFFFFF, 0x00020000);
   const unsigned live = (unsigned)D.live;
   double* const yg = fs.pool + D.offy;
+  if (d.lm) radius = d.lm->radius;
   const double inv_radius = 1.0 / radius;
   const double* const dcv = red_dc(d);
   if (threadIdx.x < 32) s_flag[threadIdx.x] = 0;
@@ -751,10 +754,15 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
 constexpr int FD_THREADS = 256;  // one wave per SIMD: 512 registers each (the rows of L wait in them for the parent's flag)
 // candidate cameras / focal of a front: x + (-z) * scale, their tables, the camera part of the norms (every thread of the
 // down-sweep workgroup calls it; szv: the front's z in front order)
-__device__ __forceinline__ void fd_candidates(const FrontSet& fs, const FrDesc& D, const BaDev& d, const unsigned char* __restrict__ cam_used,
+__device__ __forceinline__ void fd_candidates(const FrontSet& fs, const FrDesc& D, const BaDev& d_in, const unsigned char* __restrict__ cam_used,
                                               int rank, int cand, const double* szv, double (*sred)[4]) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (!cand) return;
+  BaDev d = d_in;  // (which parameter set is x: the record's word when the loop runs on the device)
+  {
+    double radius_unused;
+    lm_view(d, radius_unused);
+  }
   double sn2 = 0, cn2 = 0;
   if ((int)threadIdx.x < D.ncam) {
     const int c = fs.ints[D.cam_off + threadIdx.x], cpos = fs.ints[D.cam_off + D.ncam + threadIdx.x];
@@ -785,12 +793,12 @@ __device__ __forceinline__ void fd_candidates(const FrontSet& fs, const FrDesc& 
   }
   if (lane == 0) sred[0][wave] = sn2, sred[1][wave] = cn2;
   __syncthreads();
-  if (threadIdx.x == 0 && rank == 0) {
+  if (threadIdx.x == 0) {
+    // the camera part of the norms, a pair of sums per front: step_finish adds them in front order (the same bits every run;
+    // atomics on two words landed in the order the fronts happened to finish)
     for (int w = 1; w < FD_THREADS / 64; ++w) sn2 += sred[0][w], cn2 += sred[1][w];
-    if (sn2 != 0 || cn2 != 0) {
-      atomic_add_f64(d.red2 + 2, sn2);
-      atomic_add_f64(d.red2 + 3, cn2);
-    }
+    double* cp = d.step_part + 4 * (size_t)d.step_total + 2 * (size_t)blockIdx.x;
+    cp[0] = sn2, cp[1] = cn2;
   }
 }
 
@@ -806,6 +814,7 @@ __global__ __launch_bounds__(FD_THREADS) void front_down(FrontSet fs, BaDev d, c
   __shared__ double sRd[fplan::FP_NO_MAX][CB];        // 1 / their diagonals
   __shared__ double sT[fplan::FP_NO_MAX][CB];         // t_j, for the product with the inverse
   __shared__ int s_to;
+  if (lm_stopped(d)) return;
   const int f = fs.down_order[blockIdx.x];
   const FrDesc D = fr_desc(fs.ints, f);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -421,9 +421,9 @@ def test_allreduce_hook_with_a_mirrored_rank(ctx):
     dup.set_params(pb["cams0"], np.concatenate([pb["pts0"]] * 2), pb["focal0"])
     s1 = dup.iterate(4)
     ld = (6 * 10 + 1 + 63) // 64 * 64                                # row stride of S: dim rounded up to 64
-    # [packed upper triangle of S | g | F^T b | diag | scalars + rank slots] and the step scalars (8 sums + the
-    # 32 x 4 slots the back-substitution's workgroups add into)
-    assert ld * (ld + 1) // 2 + 3 * ld + 16 + 2 in calls and 8 + 4 * 32 in calls
+    # [packed upper triangle of S | g | F^T b | diag | scalars + rank slots] and the step evaluation's sums (8 doubles: the
+    # back-substitution's workgroups are added up on the device, in a fixed order, before the exchange)
+    assert ld * (ld + 1) // 2 + 3 * ld + 16 + 2 in calls and 8 in calls
     assert s1.successful_steps == s2.successful_steps
     assert abs(s1.initial_cost - s2.initial_cost) <= 1e-12 * s1.initial_cost
     assert abs(s1.final_cost - s2.final_cost) <= 1e-9 * s1.final_cost
@@ -724,3 +724,107 @@ def test_linearisation_of_ragged_tracks_is_bitwise_reproducible(ctx, monkeypatch
         assert np.array_equal(S.view(np.uint64), runs[0][0].view(np.uint64)) and np.array_equal(g.view(np.uint64), runs[0][1].view(np.uint64))
         assert cost == runs[0][2]
     prob.close()
+
+
+# ---------------------------------------------------------------- the LM loop on the device (round 5)
+def _solve_both_loops(monkeypatch, ctx, args, **kw):
+    """The same solve with the trust-region decision on the device (default) and on the host (SFMHIP_BA_HOST_LOOP=1)."""
+    out = []
+    for host in ("0", "1"):
+        monkeypatch.setenv("SFMHIP_BA_HOST_LOOP", host)
+        out.append(bundle.ba_solve(*args, opts=bundle.default_opts(**kw), ctx=ctx))
+    monkeypatch.delenv("SFMHIP_BA_HOST_LOOP")
+    return out
+
+
+def _same_bits(a, b):
+    (c, p, f, s), (c2, p2, f2, s2) = a, b
+    assert (s.termination, s.iterations, s.successful_steps) == (s2.termination, s2.iterations, s2.successful_steps)
+    for k in ("initial_cost", "final_cost", "final_radius", "gradient_max_norm"):
+        assert np.float64(getattr(s, k)).view(np.uint64) == np.float64(getattr(s2, k)).view(np.uint64), k
+    assert np.array_equal(c.view(np.uint64), c2.view(np.uint64)) and np.array_equal(p.view(np.uint64), p2.view(np.uint64))
+    assert np.float64(f).view(np.uint64) == np.float64(f2).view(np.uint64)
+    assert s.spin_timeouts == 0 and s2.spin_timeouts == 0
+
+
+@pytest.mark.parametrize("shape", [(6, 60, 4, 5), (20, 2000, 10, 7), (43, 2500, 6, 43), (50, 20000, 10, 777), (200, 20000, 10, 778)])
+def test_device_loop_equals_host_loop(ctx, monkeypatch, shape):
+    """lm_decide is ONE function compiled for both sides, the step evaluation's sums are added in a fixed order: the loop that
+    runs on the device (the last workgroup of the step evaluation decides, the host reads records behind the GPU) and the
+    host's loop walk the same trajectory BIT FOR BIT, to the same termination (TrustRegionMinimizer behind
+    reference src/BundleAdjustment.cpp:115-123)."""
+    nc, npt, k, seed = shape
+    pb = synth.ba_problem(nc, npt, k, seed=seed)
+    dev, host = _solve_both_loops(monkeypatch, ctx, _ba_args(pb), max_time_s=0.0)
+    _same_bits(dev, host)
+    assert dev[3].termination == _lib.BA_CONVERGENCE and dev[3].iterations >= 3
+
+
+def test_device_loop_takes_every_exit_the_host_loop_takes(ctx, monkeypatch, orc):
+    """Every termination path of the loop, device against host (bits) and against the oracle (counts): the iteration limit at
+    1 ... 9 (between accepted and rejected steps, i.e. with and without an unread linearisation behind the last step), the
+    function, parameter and gradient tolerances, the radius floor, invalid steps until FAILURE."""
+    pb = synth.ba_problem(11, 600, 5, seed=11)
+    args = _ba_args(pb)
+    cases = [dict(max_iterations=n, function_tolerance=0.0, parameter_tolerance=0.0) for n in range(1, 10)]
+    cases += [dict(function_tolerance=1e-2), dict(parameter_tolerance=1e-3, function_tolerance=0.0),
+              dict(gradient_tolerance=1e3, function_tolerance=0.0, parameter_tolerance=0.0),
+              dict(gradient_tolerance=1e9),                       # (met at x0: no iteration at all)
+              dict(min_radius=1e5),                               # (the initial radius is below the floor)
+              dict(min_radius=3e4, function_tolerance=0.0, parameter_tolerance=0.0, max_iterations=30),
+              dict(max_iterations=0)]
+    seen = set()
+    for kw in cases:
+        dev, host = _solve_both_loops(monkeypatch, ctx, args, max_time_s=0.0, **kw)
+        _same_bits(dev, host)
+        so = orc.ba_solve(*args, opts=orc.default_opts(max_time_s=0.0, **kw))[3]
+        assert (dev[3].termination, dev[3].iterations, dev[3].successful_steps) == (so.termination, so.iterations, so.successful_steps), kw
+        seen.add(dev[3].termination)
+    assert seen == {_lib.BA_CONVERGENCE, _lib.BA_NO_CONVERGENCE}
+    # invalid steps: an observation that is not a number makes every candidate cost NaN
+    bad = [a.copy() if isinstance(a, np.ndarray) else a for a in args]
+    bad[5][3, 0] = np.nan
+    dev, host = _solve_both_loops(monkeypatch, ctx, bad, max_time_s=0.0)
+    assert dev[3].termination == host[3].termination == _lib.BA_FAILURE
+    assert dev[3].iterations == host[3].iterations == 5 and dev[3].successful_steps == 0
+    assert np.array_equal(dev[0], args[0]) and np.array_equal(dev[1], args[1])       # nothing was accepted
+
+
+def test_device_loop_with_ragged_tracks_and_resumed_iterations(ctx, monkeypatch):
+    """The pair path's points (ba_backsub next to ba_backsub_runs: the decision is ba_decide's then) and sfmhip_ba_iterate called
+    a few iterations at a time: device loop == host loop, bit for bit."""
+    rng = np.random.default_rng(5)
+    pb = synth.ba_problem(24, 3000, 6, seed=31)
+    keep = rng.random(len(pb["obs_cam"])) > 0.15                 # ragged: most signatures are no longer shared
+    res = []
+    for host in ("0", "1"):
+        monkeypatch.setenv("SFMHIP_BA_HOST_LOOP", host)
+        prob = bundle.BaProblem(24, 3000, pb["obs_cam"][keep], pb["obs_pt"][keep], pb["obs_xy"][keep], ctx=ctx)
+        prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+        sums = [prob.iterate(n) for n in (1, 3, 0, 5, 2)]
+        res.append((prob.get_params(), sums))
+        prob.close()
+    monkeypatch.delenv("SFMHIP_BA_HOST_LOOP")
+    (pa, sa), (pb_, sb) = res
+    for x, y in zip(pa, pb_):
+        assert np.array_equal(np.asarray(x).view(np.uint64), np.asarray(y).view(np.uint64))
+    for x, y in zip(sa, sb):
+        assert (x.iterations, x.successful_steps) == (y.iterations, y.successful_steps)
+        assert np.float64(x.final_cost).view(np.uint64) == np.float64(y.final_cost).view(np.uint64)
+        assert np.float64(x.final_radius).view(np.uint64) == np.float64(y.final_radius).view(np.uint64)
+    assert sa[-1].iterations == 11 and sa[-1].final_cost < sa[0].initial_cost
+
+
+def test_cfg4_full_size_runs_to_termination_vs_oracle(ctx, orc):
+    """BASELINE cfg4 at full size, to the END of the solve: the reference's policy lives there (src/BundleAdjustment.cpp:118-129:
+    500 iterations / 10 s / write-back only on CONVERGENCE).  Termination type, iterations, accepted steps, final cost (1e-9),
+    parameters (1e-6), against the oracle."""
+    pb = synth.ba_problem(200, 100000, 10, seed=777)
+    kw = dict(max_time_s=0.0)
+    c, p, f, s = bundle.ba_solve(*_ba_args(pb), ctx=ctx, opts=bundle.default_opts(**kw))
+    co, po, fo, so = orc.ba_solve(*_ba_args(pb), opts=orc.default_opts(**kw))
+    assert so.termination == _lib.BA_CONVERGENCE
+    assert (s.termination, s.iterations, s.successful_steps) == (so.termination, so.iterations, so.successful_steps)
+    assert abs(s.final_cost - so.final_cost) <= BA_COST_RTOL * so.final_cost
+    assert np.allclose(c, co, rtol=BA_PARAM_RTOL, atol=1e-9) and np.allclose(p, po, rtol=BA_PARAM_RTOL, atol=1e-9)
+    assert abs(f - fo) <= BA_PARAM_RTOL * fo
