@@ -377,6 +377,35 @@ def ba_set_threads(n):
     L.orc_ba_set_threads(int(n))
 
 
+def ba_set_blocked_cholesky(on):
+    """bench.py's timed cpu_baseline leg: the reduced solve by the blocked, vectorised Cholesky (Eigen's LLT in Ceres 1.13)."""
+    L = lib()
+    L.orc_ba_set_blocked_cholesky.argtypes = [C.c_int]
+    L.orc_ba_set_blocked_cholesky.restype = None
+    L.orc_ba_set_blocked_cholesky(1 if on else 0)
+
+
+def ba_cholesky_stats(reset=True):
+    """(flops, seconds) of the blocked factorisations since the last reset."""
+    L = lib()
+    L.orc_ba_cholesky_stats.argtypes = [C.c_void_p, C.c_int]
+    L.orc_ba_cholesky_stats.restype = None
+    out = np.zeros(2)
+    L.orc_ba_cholesky_stats(_p(out), 1 if reset else 0)
+    return float(out[0]), float(out[1])
+
+
+def chol_solve(S, rhs, blocked):
+    """x with S x = rhs by the row-by-row (checker) or the blocked (baseline) factorisation; None when S is not positive definite."""
+    L = lib()
+    L.orc_chol_solve.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_chol_solve.restype = C.c_int
+    A = np.array(S, np.float64, order="C", copy=True)
+    b = np.ascontiguousarray(rhs, np.float64)
+    x = np.zeros(len(b))
+    return x if L.orc_chol_solve(_p(A), int(len(b)), _p(b), _p(x), 1 if blocked else 0) == 0 else None
+
+
 def ba_time_iterations(cams6, pts3, focal, obs_cam, obs_pt, obs_xy, iters):
     cams = np.ascontiguousarray(cams6, np.float64).reshape(-1, 6)
     pts = np.ascontiguousarray(pts3, np.float64).reshape(-1, 3)

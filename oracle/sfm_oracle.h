@@ -102,6 +102,12 @@ typedef struct {
 void orc_ba_default_opts(orc_ba_opts* o);
 /* threads of the per-point passes (what Ceres' num_threads does); 1 = the serial reference order (default) */
 void orc_ba_set_threads(int n);
+/* bench.py's timed cpu_baseline leg only: the reduced solve by a blocked, vectorised right-looking Cholesky (what Eigen's LLT
+ * inside Ceres 1.13 is) instead of the checker's row-by-row factorisation; stats: {flops, seconds} of the factorisations since
+ * the last reset.  orc_chol_solve: either factorisation on a caller's system (S n x n row-major, lower triangle read, overwritten). */
+void orc_ba_set_blocked_cholesky(int on);
+void orc_ba_cholesky_stats(double out[2], int reset);
+int orc_chol_solve(double* S, int n, const double* rhs, double* x, int blocked);
 
 /* ceres::Solve(DENSE_SCHUR, LM) as configured at src/BundleAdjustment.cpp:115-123.
  * Parameters are updated in place with the best accepted iterate whatever the termination

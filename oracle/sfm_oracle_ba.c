@@ -594,6 +594,173 @@ static int chol_solve(double* S, int n, const double* rhs, double* x) {
   return 0;
 }
 
+/* ---- the reduced solve as a competent CPU library does it (bench.py's TIMED cpu_baseline leg only) --------------------
+ * Ceres 1.13's DENSE_SCHUR hands the reduced system to Eigen's LLT: a BLOCKED, vectorised right-looking Cholesky.  The
+ * row-by-row factorisation above is the checker's arithmetic and stays what the parity tests compare with; timing IT as
+ * "the CPU" understates the CPU several times over.  This one is what the baseline leg runs:
+ * 64-column panels; the diagonal block factored in place, the panel below it solved row by row against the block, the
+ * trailing lower triangle updated by a register-tiled rank-64 product (4 rows x 16 columns of accumulators, the panel
+ * transposed once so that the inner loop is broadcast x contiguous vector -- GCC vector extensions: AVX-512 FMAs with
+ * -march=native on the GPU boxes' hosts, AVX2 in the portable build).  Same answer to rounding (tests/test_oracle_geometry.py). */
+typedef double v8d __attribute__((vector_size(64), aligned(8), may_alias));  /* (aligned(8): *(v8d*)p is an unaligned load) */
+#define CHB 64
+static int g_blocked_chol = 0;
+static double g_chol_flops = 0.0, g_chol_seconds = 0.0;
+void orc_ba_set_blocked_cholesky(int on) { g_blocked_chol = on ? 1 : 0; }
+void orc_ba_cholesky_stats(double out[2], int reset) {
+  out[0] = g_chol_flops, out[1] = g_chol_seconds;
+  if (reset) g_chol_flops = g_chol_seconds = 0.0;
+}
+
+__attribute__((optimize("fp-contract=fast"))) static int chol_factor_blocked(double* S, int n) {
+  double* Lt = (double*)malloc(sizeof(double) * CHB * (size_t)(n + 16));  /* the panel transposed: Lt[k][row] */
+  if (!Lt) return -1;
+#ifdef CHOL_PROFILE
+  double tp[5] = {0, 0, 0, 0, 0}, tq;
+#define TP(i) tp[i] += now_s() - tq, tq = now_s()
+#else
+#define TP(i)
+#endif
+  for (int k0 = 0; k0 < n; k0 += CHB) {
+    const int kb = n - k0 < CHB ? n - k0 : CHB, k1 = k0 + kb;
+#ifdef CHOL_PROFILE
+    tq = now_s();
+#endif
+    /* diagonal block (the earlier panels are already folded into it) */
+    for (int i = k0; i < k1; ++i) {
+      double* Li = S + (size_t)i * n;
+      for (int j = k0; j <= i; ++j) {
+        const double* Lj = S + (size_t)j * n;
+        double s = 0;
+        for (int k = k0; k < j; ++k) s += Li[k] * Lj[k];
+        const double v = Li[j] - s;
+        if (i == j) {
+          if (!(v > 0) || !isfinite(v)) {
+            free(Lt);
+            return -1;
+          }
+          Li[j] = sqrt(v);
+        } else {
+          Li[j] = v / Lj[j];
+        }
+      }
+    }
+    TP(0);
+    if (k1 >= n) break;
+    /* the panel below it, X L_kk^T = A: transposed first (Lt[k][row]: the layout the trailing update wants anyway), then
+     * solved 64 rows at a time -- column j of X for 64 rows is eight vectors, x_j = (a_j - sum_{k<j} x_k L[j][k]) / L[j][j] */
+    const int m = n - k1, mp = (m + 15) & ~15, ldt = n + 16;
+    for (int k = 0; k < kb; ++k) {
+      double* row = Lt + (size_t)k * ldt;
+      for (int r = 0; r < m; ++r) row[r] = S[(size_t)(k1 + r) * n + k0 + k];
+      for (int r = m; r < mp; ++r) row[r] = 0.0;
+    }
+    TP(1);
+#pragma omp parallel for if (g_threads > 1) num_threads(g_threads) schedule(static)
+    for (int r0 = 0; r0 < mp; r0 += 64) {  /* 64 rows = eight independent vectors per column: the k-sum is a latency chain per vector */
+      const int nv = mp - r0 < 64 ? (mp - r0) / 8 : 8;
+      for (int j = 0; j < kb; ++j) {
+        const double* Lj = S + (size_t)(k0 + j) * n + k0;
+        double* xj = Lt + (size_t)j * ldt + r0;
+        v8d x[8];
+#pragma GCC unroll 8
+        for (int v = 0; v < 8; ++v) x[v] = *(const v8d*)(xj + 8 * (v < nv ? v : 0));
+        for (int k = 0; k < j; ++k) {
+          const double* xk = Lt + (size_t)k * ldt + r0;
+          const double l = Lj[k];
+#pragma GCC unroll 8
+          for (int v = 0; v < 8; ++v) {
+            v8d y;
+            y = *(const v8d*)(xk + 8 * (v < nv ? v : 0));
+            x[v] -= y * l;
+          }
+        }
+        const double dj = Lj[j];
+#pragma GCC unroll 8
+        for (int v = 0; v < 8; ++v) {
+          x[v] /= dj;
+          if (v < nv) *(v8d*)(xj + 8 * v) = x[v];
+        }
+      }
+    }
+    TP(2);
+    for (int r = 0; r < m; ++r) {  /* the solved panel back into L's rows */
+      double* Li = S + (size_t)(k1 + r) * n + k0;
+      for (int k = 0; k < kb; ++k) Li[k] = Lt[(size_t)k * ldt + r];
+    }
+    TP(3);
+    /* trailing update of the lower triangle: A[i][j] -= sum_k L[i][k] L[j][k], i >= j >= k1; 8 rows x 16 columns of accumulators */
+#pragma omp parallel for if (g_threads > 1) num_threads(g_threads) schedule(dynamic, 2)
+    for (int ib = 0; ib < m; ib += 8) {
+      const int nr = m - ib < 8 ? m - ib : 8;
+      double* A[8];
+      const double* Lr[8];
+      for (int r = 0; r < 8; ++r) {
+        const int ii = k1 + ib + (r < nr ? r : 0);
+        A[r] = S + (size_t)ii * n + k1;
+        Lr[r] = S + (size_t)ii * n + k0;
+      }
+      const int jmax = ib + nr;  /* columns j - k1 < jmax */
+      for (int jb = 0; jb < jmax; jb += 16) {
+        v8d acc[8][2];
+        for (int r = 0; r < 8; ++r) acc[r][0] = acc[r][1] = (v8d){0};
+        for (int k = 0; k < kb; ++k) {
+          const double* row = Lt + (size_t)k * ldt + jb;
+          v8d b0, b1;
+          b0 = *(const v8d*)(row);
+          b1 = *(const v8d*)(row + 8);
+#pragma GCC unroll 8
+          for (int r = 0; r < 8; ++r) {
+            const double l = Lr[r][k];
+            acc[r][0] += l * b0, acc[r][1] += l * b1;
+          }
+        }
+        double tmp[8][16];  /* (the accumulators leave their registers only here: a variable index into them would keep them in memory) */
+#pragma GCC unroll 8
+        for (int r = 0; r < 8; ++r) {
+          *(v8d*)&tmp[r][0] = acc[r][0];
+          *(v8d*)&tmp[r][8] = acc[r][1];
+        }
+        for (int r = 0; r < nr; ++r) {
+          const int lim = ib + r + 1 - jb;  /* columns of this chunk inside the lower triangle of row ib + r */
+          const int w = lim < 16 ? lim : 16;
+          for (int c = 0; c < w; ++c) A[r][jb + c] -= tmp[r][c];
+        }
+      }
+    }
+    TP(4);
+  }
+#ifdef CHOL_PROFILE
+  fprintf(stderr, "chol phases ms: diag %.2f transpose %.2f trsm %.2f writeback %.2f trailing %.2f\n", tp[0] * 1e3, tp[1] * 1e3, tp[2] * 1e3, tp[3] * 1e3, tp[4] * 1e3);
+#endif
+  free(Lt);
+  return 0;
+}
+
+static int chol_solve_blocked(double* S, int n, const double* rhs, double* x) {
+  const double t0 = now_s();
+  if (chol_factor_blocked(S, n)) return -1;
+  g_chol_seconds += now_s() - t0;
+  g_chol_flops += (double)n * n * n / 3.0;
+  for (int i = 0; i < n; ++i) {
+    const double* Li = S + (size_t)i * n;
+    double v = rhs[i];
+    for (int k = 0; k < i; ++k) v -= Li[k] * x[k];
+    x[i] = v / Li[i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double v = x[i];
+    for (int k = i + 1; k < n; ++k) v -= S[(size_t)k * n + i] * x[k];
+    x[i] = v / S[(size_t)i * n + i];
+  }
+  return 0;
+}
+
+/* test / bench hook: solve S x = rhs (S: n x n row-major, lower triangle read, overwritten) with either factorisation */
+int orc_chol_solve(double* S, int n, const double* rhs, double* x, int blocked) {
+  return blocked ? chol_solve_blocked(S, n, rhs, x) : chol_solve(S, n, rhs, x);
+}
+
 /* SchurEliminator::BackSubstitute, then step = -solution (LM strategy) */
 static int ba_backsub(ba_t* b, double radius, const double* z) {
   const int fo = 6 * b->nc;
@@ -750,7 +917,7 @@ static int ba_minimize(ba_t* b, const orc_ba_opts* o, orc_ba_summary* sum, int t
     /* ---- LevenbergMarquardtStrategy::ComputeStep ---- */
     if (!reuse_diagonal) ba_lm_diagonal(b, o->min_lm_diagonal, o->max_lm_diagonal);
     int bad = ba_eliminate(b, radius, b->S, b->g);
-    if (!bad) bad = chol_solve(b->S, b->dim, b->g, b->z);
+    if (!bad) bad = (g_blocked_chol ? chol_solve_blocked : chol_solve)(b->S, b->dim, b->g, b->z);
     if (!bad) bad = ba_backsub(b, radius, b->z);
     if (!bad && !step_finite(b)) bad = 1;
     double mcc = bad ? 0.0 : ba_model_cost_change(b);

@@ -1,5 +1,6 @@
 """CPU: the C oracle's triangulation and BA pieces against golden vectors / numpy / scipy."""
 import numpy as np
+import pytest
 
 from oracle import np_check as nc
 from sfm_danpipeline_amd import synth
@@ -113,3 +114,38 @@ def test_observation_order_is_irrelevant(orc):
     b = orc.ba_reduced_system(pb["cams0"], pb["pts0"], pb["focal0"], pb["obs_cam"][perm], pb["obs_pt"][perm],
                               pb["obs_xy"][perm])
     assert np.allclose(a[0], b[0], rtol=1e-12, atol=1e-9) and np.allclose(a[1], b[1], rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 130, 301, 1201])
+def test_blocked_cholesky_of_the_cpu_baseline_solves_the_same_system(orc, n):
+    """bench.py's timed cpu_baseline leg factors the reduced system with a blocked, vectorised right-looking Cholesky (what
+    Eigen's LLT inside Ceres 1.13's DENSE_SCHUR is, reference src/BundleAdjustment.cpp:116) where the checker factors row by
+    row: the same solution to 1e-12, against each other and against LAPACK; a matrix that is not positive definite is refused
+    by both."""
+    rng = np.random.default_rng(n)
+    M = rng.normal(size=(n, n + 5))
+    S = M @ M.T + n * np.eye(n)
+    b = rng.normal(size=n)
+    x_row, x_blk, x_ref = orc.chol_solve(S, b, False), orc.chol_solve(S, b, True), np.linalg.solve(S, b)
+    scale = np.abs(x_ref).max()
+    assert np.abs(x_blk - x_row).max() <= 1e-12 * scale and np.abs(x_blk - x_ref).max() <= 1e-12 * scale
+    S[n // 2, n // 2] = -1.0
+    assert orc.chol_solve(S, b, True) is None and orc.chol_solve(S, b, False) is None
+
+
+def test_blocked_cholesky_changes_only_the_timed_leg(orc):
+    """The switch is the bench's: off by default (the parity tests compare with the row-by-row arithmetic), and an LM run with it
+    on walks the same trajectory to rounding."""
+    from sfm_danpipeline_amd import synth
+    pb = synth.ba_problem(8, 400, 5, seed=2)
+    args = (pb["cams0"], pb["pts0"], pb["focal0"], pb["obs_cam"], pb["obs_pt"], pb["obs_xy"])
+    a = orc.ba_solve(*args, opts=orc.default_opts(max_time_s=0.0))
+    orc.ba_set_blocked_cholesky(True)
+    try:
+        b = orc.ba_solve(*args, opts=orc.default_opts(max_time_s=0.0))
+    finally:
+        orc.ba_set_blocked_cholesky(False)
+    assert (a[3].termination, a[3].iterations, a[3].successful_steps) == (b[3].termination, b[3].iterations, b[3].successful_steps)
+    assert np.allclose(a[0], b[0], rtol=1e-9, atol=1e-12) and np.allclose(a[1], b[1], rtol=1e-9, atol=1e-12)
+    flops, seconds = orc.ba_cholesky_stats(reset=True)
+    assert flops > 0 and seconds > 0
