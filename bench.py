@@ -261,11 +261,14 @@ def main():
     # buffers while sweep n + 1 runs; the host takes sweep n - 1's lists (fetch_wait) right after enqueueing sweep n + ...
     hv_seen = [0, 0]
     def match_and_fetch():
-        # the lists of the run this plan did LAST (N_STREAMS steps ago), taken right before the plan is given its next run:
-        # that run is long done, the host does not block, and both streams keep a sweep queued
+        # the lists of the run this plan did BEFORE its last (2 * N_STREAMS steps ago), taken right before the plan is given its
+        # next run: that run's packing and copy are long done, the host does not block, and a sweep stays queued on each stream
+        # behind the one in flight.  (Round 4 took the plan's LAST run, N_STREAMS steps ago: its packing launch only gets compute
+        # units when the sweep in flight gives them back, i.e. near that sweep's end -- the host woke up with nothing queued behind,
+        # and every step paid its wake-up and enqueue time: 0.86 of the device-only rate; scripts/gpu_hostvisible_ab2.py.)
         j = step_no[0] % N_STREAMS
-        if hv_seen[0] >= N_STREAMS:
-            c_, q_, t_, d_ = plans[j].fetch_wait(back=0)
+        if hv_seen[0] >= 2 * N_STREAMS:
+            c_, q_, t_, d_ = plans[j].fetch_wait(back=1)
             hv_seen[1] += int(c_.sum()) == len(q_) == len(t_) == len(d_)
         match_step()
         hv_seen[0] += 1
@@ -275,11 +278,13 @@ def main():
         for pl_ in plans:
             pl_.pipeline()
         n_hv, t_hv = loop_for(1.0, match_and_fetch, 50)
-        for pl_ in plans:                                     # the last runs' lists
-            c_, q_, t_, d_ = pl_.fetch_wait(back=0)
-            assert int(c_.sum()) == len(q_)
+        for pl_ in plans:                                     # the last two runs' lists of every plan
+            for back_ in (1, 0):
+                c_, q_, t_, d_ = pl_.fetch_wait(back=back_)
+                assert int(c_.sum()) == len(q_)
+                hv_seen[1] += 1
             assert np.array_equal(synth.pair_checksums(c_, q_, t_, d_), synth.pair_checksums(*pl_.fetch()))
-        assert hv_seen[1] == hv_seen[0] - N_STREAMS
+        assert hv_seen[1] == hv_seen[0], (hv_seen, "every sweep's lists were seen by the host")
         for pl_ in plans:
             pl_.pipeline(-1)
     host_visible_pairs_s = n_hv * len(pairs) / t_hv
@@ -695,9 +700,10 @@ def main():
                                    "frac_of_value": round(host_visible_pairs_s / max(pairs_per_s, 1e-9), 3),
                                    "stop_and_copy_pairs_per_s": round(host_copy_pairs_s, 1),
                                    "note": "every sweep's counts + {queryIdx, trainIdx, distance} lists in host memory: a "
-                                           "second stream packs sweep n into one of two pinned buffers while sweep n+1 runs "
-                                           "(sfmhip_matchplan_pipeline / _fetch_wait); stop_and_copy = sfmhip_matchplan_fetch "
-                                           "after every sweep"},
+                                           "second stream packs sweep n into a device buffer and copies it (DMA) into one of two "
+                                           "pinned buffers while the next sweeps run (sfmhip_matchplan_pipeline / _fetch_wait); the host "
+                                           "takes a plan's lists two of its runs behind the one it enqueues; stop_and_copy = "
+                                           "sfmhip_matchplan_fetch after every sweep"},
             "cfg5_strong": cfg5, "find_best_pair_scoring": score_leg, "sift_front_end": sift_leg, "ba_batch": ba_batch,
             "ba_amdahl": (lambda sh, rep, ar: {
                 "sharded_ms": round(sh, 4), "replicated_ms": round(rep, 4), "allreduce_ms": round(ar, 4),

@@ -1706,6 +1706,14 @@ struct sfmhip_matchplan {
   hipEvent_t ev_ready = nullptr, ev_host[2] = {nullptr, nullptr};
   void* h_pipe[2] = {nullptr, nullptr};   // [int64 total | int64 capacity | int32 counts[cap_pairs] | int32 q[], t[], d[]]
   int* dh_pipe[2] = {nullptr, nullptr};   // the same buffers as the device sees them
+  // round 5: the lists are packed into a DEVICE buffer of the same layout by a short many-workgroup launch and leave over the
+  // DMA engine (hipMemcpyAsync on the copy stream): eight workgroups writing 3 MB through the PCIe link held their compute units
+  // for a sixth of a sweep (host-visible 0.86 of the device-only rate).  The copy carries the matches the last runs had, plus a
+  // quarter (the count is only known on the device); a run that has more gets the rest in fetch_wait.
+  int* d_pipe[2] = {nullptr, nullptr};
+  long long pipe_copied[2] = {0, 0};      // matches the slot's copy carried
+  long long pipe_est = -1;                // matches to copy (< 0: not known yet, the whole capacity)
+  bool pipe_zero_copy = false;            // SFMHIP_PIPE_ZEROCOPY=1: the round-3 path (measurement)
   long long pipe_capacity = 0;            // matches per slot
   long long runs = 0;                     // runs enqueued since the pipeline was switched on
 };
@@ -2094,15 +2102,32 @@ extern "C" int sfmhip_matchplan_run_async(sfmhip_matchplan* pl, float ratio) {
     const int slot = (int)(pl->runs & 1);
     SFM_HIP_TRY(hipEventRecord(pl->ev_ready, st));
     SFM_HIP_TRY(hipStreamWaitEvent(pl->pipe_st, pl->ev_ready, 0));
-    long long* h_hdr = (long long*)pl->dh_pipe[slot];
-    int* h_counts = pl->dh_pipe[slot] + 4;
+    const bool zc = pl->pipe_zero_copy;
+    int* base = zc ? pl->dh_pipe[slot] : pl->d_pipe[slot];
+    long long* h_hdr = (long long*)base;
+    int* h_counts = base + 4;
     int* h_rec = h_counts + pl->cap_pairs;
     if (pl->n_pairs > 0) {
       hipLaunchKernelGGL(pack_offsets_kernel, dim3(1), dim3(1024), 0, pl->pipe_st, pl->d_counts, pl->n_pairs, pl->d_offsets, h_counts, h_hdr);
-      static const int pipe_wgs = getenv("SFMHIP_PIPE_WGS") ? atoi(getenv("SFMHIP_PIPE_WGS")) : 8;  // (8 workgroups: 0.977 of the device-only sweep rate; 64 or more: 0.91 -- scripts/gpu_hostvisible_ab.py)
+      static const int pipe_wgs_env = getenv("SFMHIP_PIPE_WGS") ? atoi(getenv("SFMHIP_PIPE_WGS")) : 0;
+      // (zero copy: 8 workgroups, 0.977 of the device-only sweep rate on one stream, 64 or more 0.91 -- scripts/gpu_hostvisible_ab.py;
+      // into device memory the launch is over in microseconds whatever its size)
+      const int pipe_wgs = pipe_wgs_env > 0 ? pipe_wgs_env : zc ? 8 : 128;
       hipLaunchKernelGGL(pack_lists_kernel, dim3(std::max(1, std::min(pl->n_pairs, pipe_wgs))), dim3(256), 0, pl->pipe_st, pl->d_counts,
                          pl->d_offsets, pl->n_pairs, pl->maxq, pl->d_out_q, pl->d_out_t, pl->d_out_d, h_rec, pl->pipe_capacity);
       SFM_HIP_TRY(hipGetLastError());
+      if (!zc) {
+        // how much to copy: what the finished runs had, plus a quarter (their totals are in the host buffers already)
+        for (int k = 0; k < 2; ++k)
+          if (pl->runs > k && hipEventQuery(pl->ev_host[(pl->runs - 1 - k) & 1]) == hipSuccess) {
+            const long long seen = ((const long long*)pl->h_pipe[(pl->runs - 1 - k) & 1])[0];
+            if (seen <= pl->pipe_capacity) pl->pipe_est = std::max(pl->pipe_est, seen + seen / 4 + 1024);
+          }
+        const long long n_copy = pl->pipe_est < 0 ? pl->pipe_capacity : std::min(pl->pipe_capacity, pl->pipe_est);
+        pl->pipe_copied[slot] = n_copy;
+        SFM_HIP_TRY(hipMemcpyAsync(pl->h_pipe[slot], pl->d_pipe[slot], 16 + sizeof(int) * ((size_t)pl->cap_pairs + 3 * (size_t)n_copy),
+                                   hipMemcpyDeviceToHost, pl->pipe_st));
+      }
     } else {
       ((long long*)pl->h_pipe[slot])[0] = 0;
     }
@@ -2125,7 +2150,10 @@ extern "C" int sfmhip_matchplan_pipeline(sfmhip_matchplan* pl, int64_t capacity)
   }
   if (capacity == 0) capacity = std::max<long long>(4096, (long long)pl->cap_pairs * pl->maxq / 4);
   if (!pl->pipe_st) {
-    SFM_HIP_TRY(hipStreamCreateWithFlags(&pl->pipe_st, hipStreamNonBlocking));
+    // (highest priority: the packing launch gets the first compute units a sweep's workgroups give back, not the last)
+    int prio_lo = 0, prio_hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
+    SFM_HIP_TRY(hipStreamCreateWithPriority(&pl->pipe_st, hipStreamNonBlocking, prio_hi));
     SFM_HIP_TRY(hipEventCreateWithFlags(&pl->ev_ready, hipEventDisableTiming));
     for (auto& e : pl->ev_host) SFM_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
@@ -2142,11 +2170,16 @@ extern "C" int sfmhip_matchplan_pipeline(sfmhip_matchplan* pl, int64_t capacity)
       SFM_HIP_TRY(hipHostGetDevicePointer(&dp, pl->h_pipe[k], 0));
       pl->dh_pipe[k] = (int*)dp;
       memset(pl->h_pipe[k], 0, 16);
+      if (pl->d_pipe[k]) hipFree(pl->d_pipe[k]);
+      pl->d_pipe[k] = nullptr;
+      SFM_HIP_TRY(hipMalloc((void**)&pl->d_pipe[k], bytes));
     }
+    pl->pipe_est = -1;
     pl->pipe_capacity = capacity;
   }
   pl->pipe_on = true;
   pl->runs = 0;
+  pl->pipe_zero_copy = getenv("SFMHIP_PIPE_ZEROCOPY") && atoi(getenv("SFMHIP_PIPE_ZEROCOPY")) != 0;
   return SFMHIP_OK;
 }
 
@@ -2161,6 +2194,15 @@ extern "C" int sfmhip_matchplan_fetch_wait(sfmhip_matchplan* pl, int back, const
   if (total) *total = tot;
   if (counts) *counts = c;
   if (tot > pl->pipe_capacity) return SFMHIP_ERR_ALLOC;  // (total is set: switch the pipeline on again with that much room)
+  if (!pl->pipe_zero_copy && tot > pl->pipe_copied[slot]) {
+    // the run found more matches than the copy was sized for: the rest of the three arrays, now (the device buffer of the slot
+    // is untouched until the slot's next run)
+    const size_t lo = (size_t)pl->cap_pairs + 3 * (size_t)pl->pipe_copied[slot], hi = (size_t)pl->cap_pairs + 3 * (size_t)tot;
+    SFM_HIP_TRY(hipSetDevice(pl->set->ctx->device));
+    SFM_HIP_TRY(hipMemcpy((int*)pl->h_pipe[slot] + 4 + lo, pl->d_pipe[slot] + 4 + lo, sizeof(int) * (hi - lo), hipMemcpyDeviceToHost));
+    pl->pipe_copied[slot] = tot;
+    pl->pipe_est = std::max(pl->pipe_est, tot + tot / 4 + 1024);
+  }
   if (out_q) *out_q = rec;
   if (out_t) *out_t = rec + tot;
   if (out_dist) *out_dist = (const float*)(rec + 2 * tot);
@@ -2287,6 +2329,8 @@ extern "C" void sfmhip_matchplan_destroy(sfmhip_matchplan* pl) {
   if (pl->ev_ready) hipEventDestroy(pl->ev_ready);
   for (auto& e : pl->ev_host)
     if (e) hipEventDestroy(e);
+  for (int* dp : pl->d_pipe)
+    if (dp) hipFree(dp);
   for (void* h : pl->h_pipe)
     if (h) hipHostFree(h);
   for (auto& e : pl->ev)
