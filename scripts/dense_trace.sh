@@ -1,7 +1,7 @@
 # per-launch durations of chol_step2 over one LM run with the dense factorisation (rocprofv3 kernel trace)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/dt && mkdir -p /tmp/dt
-SFMHIP_BA_ND=0 SFMHIP_BA_DENSE_XB=${XB:-8} rocprofv3 --kernel-trace -d /tmp/dt -o tr --output-format csv -- python3 $GRAFT_REPO_ROOT/scripts/gpu_dense_sizes.py ${1:-640} > /tmp/dt/log.txt 2>&1
+SFMHIP_BA_ND=0 rocprofv3 --kernel-trace -d /tmp/dt -o tr --output-format csv -- python3 $GRAFT_REPO_ROOT/scripts/gpu_dense_sizes.py ${1:-640} > /tmp/dt/log.txt 2>&1
 grep -v rocprofv3 /tmp/dt/log.txt | tail -5; ls -R /tmp/dt | head -20
 python3 - <<'PY'
 import csv, glob, collections

@@ -4056,7 +4056,18 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
     if (rc == SFMHIP_OK && hipMemset(b->d_cb_cnt, 0, sizeof(int) * (size_t)n_cam) != hipSuccess) rc = SFMHIP_ERR_HIP;
   }
   {
-    static const int xb_env = getenv("SFMHIP_BA_DENSE_XB") ? atoi(getenv("SFMHIP_BA_DENSE_XB")) : -1;  // (measurement: 0 = all of X)
+    // (measurement: 0 = all of X, DENSE_XB = blocks even below the size that switches them on.  The block width itself is not a
+    // knob: chol_back_block's registers and LDS and the sizes of d_back_part are built for DENSE_XB tile columns)
+    static const int xb_env = [] {
+      const char* e = getenv("SFMHIP_BA_DENSE_XB");
+      if (!e) return -1;
+      const int v = atoi(e);
+      if (v != 0 && v != DENSE_XB) {
+        fprintf(stderr, "[sfmhip-ba] SFMHIP_BA_DENSE_XB=%d ignored: 0 (all of X) or %d (diagonal blocks) are the choices\n", v, DENSE_XB);
+        return -1;
+      }
+      return v;
+    }();
     const int nt = b->ld / CB;
     b->dense_xb = xb_env == 0 ? 0 : (xb_env > 0 || nt >= DENSE_XB_MIN_NT) ? DENSE_XB : 0;
     if (b->dense_xb) {

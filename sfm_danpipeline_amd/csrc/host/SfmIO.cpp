@@ -674,6 +674,12 @@ bool decode_jpeg(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) 
         why = "unsupported JPEG component count";
         return false;
       }
+      // (a header of a few bytes may claim 65535 x 65535 pixels: the planes -- and, progressive, 256 bytes of coefficients per
+      // block -- are only allocated for a frame the file could plausibly hold: even an all-zero block costs a bit per scan)
+      if ((uint64_t)width * (uint64_t)height > (uint64_t)1 << 28 || (uint64_t)width * (uint64_t)height / 64 / 8 > (uint64_t)f.size() * 16 + 4096) {
+        why = "JPEG frame size implausible for the file's length";
+        return false;
+      }
       for (int c = 0; c < ncomp; ++c) {
         comp[c].id = d[6 + 3 * c];
         comp[c].h = d[7 + 3 * c] >> 4;
@@ -900,7 +906,10 @@ bool decode_jpeg(const std::vector<uint8_t>& f, cv::Mat& bgr, std::string& why) 
           if (restart) --until_restart;
         }
       for (int k = 0; k < ns; ++k) comp[sc[k]].coded = true;
-      ++n_scans;
+      if (++n_scans > 500) {  // (libjpeg-turbo's own limit for fuzzed files: every scan walks all blocks)
+        why = "corrupt JPEG (too many scans)";
+        return false;
+      }
       // the next marker: the reader never steps over one, so it lies at or behind its position
       pos = br.pos;
       while (pos + 1 < f.size() && !(f[pos] == 0xFF && f[pos + 1] != 0 && f[pos + 1] != 0xFF && !(f[pos + 1] >= 0xD0 && f[pos + 1] <= 0xD7))) ++pos;
@@ -1272,7 +1281,7 @@ bool StructFromMotion::imagesLOAD(const std::string& directoryPath) {
   std::vector<char> oks(nfiles, 0);
   std::atomic<size_t> next{0};
   auto worker = [&]() {
-    for (size_t i = next.fetch_add(1); i < nfiles; i = next.fetch_add(1)) {
+    for (size_t i = next.fetch_add(1); i < nfiles; i = next.fetch_add(1)) try {
       std::vector<uint8_t> bytes;
       cv::Mat image;
       bool ok = read_file(nImagesPath[i], bytes);
@@ -1286,6 +1295,9 @@ bool StructFromMotion::imagesLOAD(const std::string& directoryPath) {
       }
       if (ok) decoded[i] = image.rows > 480 && image.cols > 640 ? resize_linear_8u(image, 0.60, 0.60) : image;  // :153-155
       oks[i] = ok ? 1 : 0;
+    } catch (const std::exception& e) {  // (bad_alloc / length_error of a decoder: the reference's "Unable to read image", not std::terminate)
+      oks[i] = 0;
+      whys[i] = std::string("decoder failed: ") + e.what();
     }
   };
   {

@@ -75,16 +75,37 @@ __global__ __launch_bounds__(64) void probe_clock(unsigned long long ticks, unsi
 
 }  // namespace
 
-extern "C" int sfmhip_probe_i8_mfma_peak(sfmhip_ctx* ctx, double seconds, double* ops_per_s, double* shader_ghz) {
-  if (!ctx || !(seconds > 0) || !ops_per_s) return SFMHIP_ERR_ARG;
-  SFM_HIP_TRY(hipSetDevice(ctx->device));
-  const int grid = 2 * ctx->n_cu;
+// (the probes are bounded: a caller's typo must not park a kernel on the device until a watchdog fires)
+static const double PROBE_MAX_SECONDS = 1.0;
+
+namespace {
+struct ProbeBufs {  // freed on every way out of sfmhip_probe_i8_mfma_peak
   int* rnd = nullptr;
   int* out = nullptr;
   unsigned long long* clk = nullptr;
-  SFM_TRY(sfm_dev_alloc(&rnd, (size_t)1 << 20));
-  SFM_TRY(sfm_dev_alloc(&out, (size_t)grid * 256));
-  SFM_TRY(sfm_dev_alloc(&clk, (size_t)grid * 2));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ~ProbeBufs() {
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (rnd) hipFree(rnd);
+    if (out) hipFree(out);
+    if (clk) hipFree(clk);
+  }
+};
+}  // namespace
+
+extern "C" int sfmhip_probe_i8_mfma_peak(sfmhip_ctx* ctx, double seconds, double* ops_per_s, double* shader_ghz) {
+  if (!ctx || !(seconds > 0) || !ops_per_s) return SFMHIP_ERR_ARG;
+  seconds = std::min(seconds, PROBE_MAX_SECONDS);
+  SFM_HIP_TRY(hipSetDevice(ctx->device));
+  const int grid = 2 * ctx->n_cu;
+  ProbeBufs pb;
+  SFM_TRY(sfm_dev_alloc(&pb.rnd, (size_t)1 << 20));
+  SFM_TRY(sfm_dev_alloc(&pb.out, (size_t)grid * 256));
+  SFM_TRY(sfm_dev_alloc(&pb.clk, (size_t)grid * 2));
+  int* rnd = pb.rnd;
+  int* out = pb.out;
+  unsigned long long* clk = pb.clk;
   std::vector<int> h((size_t)1 << 20);
   unsigned long long x = 0x9E3779B97F4A7C15ull;
   for (auto& v : h) {  // random bytes: the power an MFMA draws depends on the operands
@@ -92,9 +113,9 @@ extern "C" int sfmhip_probe_i8_mfma_peak(sfmhip_ctx* ctx, double seconds, double
     v = (int)(x >> 16);
   }
   SFM_HIP_TRY(hipMemcpy(rnd, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-  hipEvent_t e0, e1;
-  SFM_HIP_TRY(hipEventCreate(&e0));
-  SFM_HIP_TRY(hipEventCreate(&e1));
+  SFM_HIP_TRY(hipEventCreate(&pb.e0));
+  SFM_HIP_TRY(hipEventCreate(&pb.e1));
+  hipEvent_t e0 = pb.e0, e1 = pb.e1;
   hipStream_t st = ctx->stream;
   // calibrate (a short launch), then one launch of about the requested length: long enough for the clock to settle
   int iters = 2000;
@@ -115,34 +136,48 @@ extern "C" int sfmhip_probe_i8_mfma_peak(sfmhip_ctx* ctx, double seconds, double
     SFM_HIP_TRY(hipMemcpy(c2, clk, sizeof c2, hipMemcpyDeviceToHost));
     *shader_ghz = c2[1] ? (double)c2[0] / (double)c2[1] * 0.1 : 0.0;  // (s_memrealtime counts at 100 MHz)
   }
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  hipFree(rnd);
-  hipFree(out);
-  hipFree(clk);
   return SFMHIP_OK;
 }
 
-// (the sampler's two counters land in a pinned buffer of the probe's own, one per process: the context's pinned scratch belongs
-// to the entry points that copy through it)
-static unsigned long long* g_probe_pin = nullptr;
+// (the sampler's two counters land in a pinned pair of the probe's own, one per context -- two contexts sampling at once no
+// longer share it; the context's pinned scratch belongs to the entry points that copy through it)
+#include <map>
+#include <mutex>
+static std::mutex g_probe_mu;
+static std::map<sfmhip_ctx*, unsigned long long*> g_probe_pins;
+static int probe_pin_of(sfmhip_ctx* ctx, bool create, unsigned long long** out) {
+  std::lock_guard<std::mutex> lk(g_probe_mu);
+  auto it = g_probe_pins.find(ctx);
+  if (it == g_probe_pins.end()) {
+    if (!create) return SFMHIP_ERR_ARG;
+    unsigned long long* p = nullptr;
+    SFM_HIP_TRY(hipHostMalloc((void**)&p, 64, hipHostMallocDefault));
+    it = g_probe_pins.emplace(ctx, p).first;
+  }
+  *out = it->second;
+  return SFMHIP_OK;
+}
 
 extern "C" int sfmhip_probe_clock_start(sfmhip_ctx* ctx, double seconds) {
   if (!ctx || !(seconds > 0)) return SFMHIP_ERR_ARG;
+  seconds = std::min(seconds, PROBE_MAX_SECONDS);
   SFM_HIP_TRY(hipSetDevice(ctx->device));
-  if (!g_probe_pin) SFM_HIP_TRY(hipHostMalloc((void**)&g_probe_pin, 64, hipHostMallocDefault));
-  g_probe_pin[0] = g_probe_pin[1] = 0;
+  unsigned long long* pin = nullptr;
+  SFM_TRY(probe_pin_of(ctx, true, &pin));
+  pin[0] = pin[1] = 0;
   void* dev = nullptr;
-  SFM_HIP_TRY(hipHostGetDevicePointer(&dev, g_probe_pin, 0));
+  SFM_HIP_TRY(hipHostGetDevicePointer(&dev, pin, 0));
   hipLaunchKernelGGL(probe_clock, dim3(1), dim3(64), 0, ctx->stream, (unsigned long long)(seconds * 1e8), (unsigned long long*)dev);
   SFM_HIP_TRY(hipGetLastError());
   return SFMHIP_OK;
 }
 
 extern "C" int sfmhip_probe_clock_read(sfmhip_ctx* ctx, double* shader_ghz) {
-  if (!ctx || !shader_ghz || !g_probe_pin) return SFMHIP_ERR_ARG;
+  if (!ctx || !shader_ghz) return SFMHIP_ERR_ARG;
+  unsigned long long* pin = nullptr;
+  SFM_TRY(probe_pin_of(ctx, false, &pin));
   SFM_HIP_TRY(hipSetDevice(ctx->device));
   SFM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-  *shader_ghz = g_probe_pin[1] ? (double)g_probe_pin[0] / (double)g_probe_pin[1] * 0.1 : 0.0;  // (s_memrealtime counts at 100 MHz)
+  *shader_ghz = pin[1] ? (double)pin[0] / (double)pin[1] * 0.1 : 0.0;  // (s_memrealtime counts at 100 MHz)
   return SFMHIP_OK;
 }
