@@ -4874,7 +4874,8 @@ static int ba_reduced_solve_tree(sfmhip_ba* b) {
   const int gaps = (stride - 1) * nF;
   const int grid = stride * nF + std::max(0, zwg + 1 - gaps);
   const unsigned epoch = ++b->tree_epoch;
-  static const bool by_level = getenv("SFMHIP_BA_TREE_BY_LEVEL") != nullptr;  // (diagnostic: one launch per tree level)
+  static const bool by_level_env = getenv("SFMHIP_BA_TREE_BY_LEVEL") != nullptr;  // (diagnostic: one launch per tree level)
+  const bool by_level = by_level_env || b->tree_by_level;  // (... and what a solve falls back to once a hand-off between fronts has timed out)
   int nl = 0;
   if (by_level) {
     for (int l = b->tree_levels - 1; l >= 0; --l, ++nl)

@@ -662,6 +662,12 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
     // the solved own part (the down-sweep reads it) and the border part (the parent adds it), write-through
     FR_STAMP(20);
     for (int a = lane; a < nrow; a += 64) fr_st_sc1(yg + a, sy[a]);
+#ifdef SFM_FRONT_BREAK_HANDOFF
+    // diagnostic build only (tests/test_gpu_geometry.py::test_a_timed_out_hand_off_...): in the one-launch form the first front of
+    // the up-sweep never raises its right-hand side's flag -- what a child that got no compute unit in time looks like to its
+    // parent; launched level by level the hand-off is whole
+    if (!(lvl_lo == 0 && lvl_hi == (1 << 30) && (int)blockIdx.x / stride == 0))
+#endif
     fr_raise_flag(fs.tflag + D.tflag_off + D.ns * (D.ns + 1) / 2, epoch, lane);
   } else {
     // ---- tile waves (wave 8 holds border tiles only, and only where they are folded at the end)

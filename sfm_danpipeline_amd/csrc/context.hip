@@ -135,6 +135,7 @@ extern "C" const char* sfmhip_error_string(int status) {
     case SFMHIP_ERR_UNSUPPORTED: return "unsupported device or configuration";
     case SFMHIP_ERR_STATE: return "object not in the required state";
     case SFMHIP_ERR_COMM: return "all-reduce callback failed";
+    case SFMHIP_ERR_TIMEOUT: return "a bounded spin inside a kernel ran out (scheduling fault or bug, not a property of the data)";
     default: return "unknown status";
   }
 }
