@@ -2866,32 +2866,48 @@ constexpr int BS_SUMS = 14;
 __device__ __forceinline__ void lm_publish(const BaDev& d, const LmDev& s) {
   constexpr int NW = (int)(sizeof(LmDev) / 4);
   static_assert(sizeof(LmDev) % 8 == 0 && offsetof(LmDev, seq) % 4 == 0, "LmDev is copied word by word");
+  static_assert(NW <= 64, "a lane per word");
   volatile unsigned* dst = (volatile unsigned*)(d.lm_host) + (size_t)(s.seq % LM_RING) * NW;
-  const unsigned* src = (const unsigned*)&s;
+  const unsigned* src = (const unsigned*)d.lm;  // (the record in device memory: what `s` was read from)
   constexpr int SEQ_W = (int)(offsetof(LmDev, seq) / 4);
-  for (int w = 0; w < NW; ++w)
-    if (w != SEQ_W) dst[w] = src[w];
+  const int w = (int)threadIdx.x;
+  if (w < NW && w != SEQ_W) dst[w] = src[w];  // (one store instruction of the wave; a word at a time took 24 us over the link)
   __threadfence_system();
-  dst[SEQ_W] = s.seq;
+  if (w == 0) dst[SEQ_W] = s.seq;
   __threadfence_system();
 }
 
 // the decision itself, by ONE thread, once every sum it reads is final (the last workgroup of the step evaluation, or
 // ba_decide behind the all-reduce): the linearisation's scalars, the step evaluation's sums, the reduced solve's status
-__device__ __forceinline__ void lm_decide_here(const BaDev& d) {
+// (what the decision reads that is final BEFORE the step evaluation ends -- the linearisation's scalars, the record -- can be on
+// its way while the finisher still waits for the last slots: lm_inputs_early / lm_decide_with)
+struct LmEarly {
+  double lin0, lin2, lin3;
+  LmDev s;
+};
+__device__ __forceinline__ void lm_inputs_early(const BaDev& d, LmEarly& e) {
   const double* scv = red_sc(d);
+  e.lin0 = scv[0], e.lin2 = scv[2], e.lin3 = scv[3];
+  e.s = *d.lm;
+}
+__device__ __forceinline__ void lm_decide_with(const BaDev& d, LmEarly& e, const double sums[4]) {
   LmIn in;
-  in.lin_cost = 0.5 * scv[0];
-  in.lin_nfail = scv[2];
-  in.lin_gmax = scv[3];
-  in.cost_c = 0.5 * d.red2[0];
-  in.mcc = -d.red2[1];
-  in.step_n2 = d.red2[2];
-  in.cand_n2 = d.red2[3];
+  in.lin_cost = 0.5 * e.lin0;
+  in.lin_nfail = e.lin2;
+  in.lin_gmax = e.lin3;
+  in.cost_c = 0.5 * sums[0];
+  in.mcc = -sums[1];
+  in.step_n2 = sums[2];
+  in.cand_n2 = sums[3];
   in.info = *(volatile int*)d.info;
-  LmDev s = *d.lm;
-  lm_decide(s, in);
-  *d.lm = s;
+  lm_decide(e.s, in);
+  *d.lm = e.s;
+}
+__device__ __forceinline__ void lm_decide_here(const BaDev& d) {
+  LmEarly e;
+  lm_inputs_early(d, e);
+  const double sums[4] = {d.red2[0], d.red2[1], d.red2[2], d.red2[3]};
+  lm_decide_with(d, e, sums);
 }
 
 __global__ void ba_decide(BaDev d) {
@@ -2900,11 +2916,9 @@ __global__ void ba_decide(BaDev d) {
 
 // the record as it stands, into the host's ring: behind the last iteration of a batch (the host waits for it there), behind
 // every iteration when the log is on -- not inside the decision, whose kernel every next kernel waits for
-__global__ void ba_lm_publish(BaDev d) {
-  if (threadIdx.x == 0) {
-    const LmDev s = *d.lm;
-    lm_publish(d, s);
-  }
+__global__ __launch_bounds__(64) void ba_lm_publish(BaDev d) {
+  const LmDev s = *d.lm;
+  lm_publish(d, s);
 }
 
 // End of a step-evaluation workgroup: its four sums (thread 0 holds them) go to the workgroup's own slot, fire and forget.
@@ -2934,6 +2948,9 @@ __device__ __forceinline__ void step_finish(const BaDev& d, int slot, double cos
   }
   if (!(d.step_last && blockIdx.x == gridDim.x - 1)) return;
   __syncthreads();
+  const bool decide = DECIDE && d.lm && d.decide_here;
+  LmEarly early;
+  if (decide && tid == 0) lm_inputs_early(d, early);  // (their round trip runs under the polls below)
   double a[4] = {0.0, 0.0, 0.0, 0.0};
   for (int i = tid; i < d.step_total; i += (int)blockDim.x) {
     gbl_double* q = (gbl_double*)(d.step_part + 4 * (size_t)i);
@@ -2953,7 +2970,7 @@ __device__ __forceinline__ void step_finish(const BaDev& d, int slot, double cos
         for (int k = 0; k < 4; ++k) v[k] = 0.0;
         break;
       }
-      __builtin_amdgcn_s_sleep(4);
+      __builtin_amdgcn_s_sleep(1);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -2975,14 +2992,15 @@ __device__ __forceinline__ void step_finish(const BaDev& d, int slot, double cos
   __syncthreads();
   if (tid == 0) {
     const int nw = (int)blockDim.x >> 6;
+    double sums[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       double v = s_fin[k][0];
       for (int w = 1; w < nw; ++w) v += s_fin[k][w];
-      d.red2[k] = v;
+      d.red2[k] = sums[k] = v;
     }
     if (s_to) atomicExch(d.info, -1);  // (a workgroup of the step evaluation never wrote its slot: not a state the data can cause)
-    if (DECIDE && d.lm && d.decide_here) lm_decide_here(d);
+    if (decide) lm_decide_with(d, early, sums);
   }
 }
 
@@ -5384,7 +5402,9 @@ static int ba_lm_loop(sfmhip_ba* b, const sfmhip_ba_opts* o, int iters, const st
     int up = 0;
     if ((rc = time_is_up(&up)) != SFMHIP_OK || up) break;
     // (several ranks: the batch is a function of the iteration count only, so that every rank issues the same all-reduces)
-    int B = batch_env ? batch_env : t_only ? LM_RING / 2 : 4;
+    // (how far ahead: 4500 it/s with 4 iterations enqueued ahead, 4590 with 12-16; with 32 -- 160 launches outstanding per stream --
+    // the runtime's enqueue slows down once several streams are alive: 3970 it/s; scripts/gpu_ba_two_problems.py)
+    int B = batch_env ? batch_env : t_only ? 16 : 4;
     if (t_only) B = std::min(B, iters - done);
     else B = std::max(1, std::min(B, s.max_iter - s.iter));
     const unsigned seq0 = b->lm_seq, epoch0 = b->tree_epoch;
