@@ -4559,29 +4559,43 @@ static int ba_nd_build(sfmhip_ba* b) {
     // components up to this many columns become leaves: the largest size whose fronts fit (a leaf of three tiles under a
     // border of five does not); SFMHIP_BA_TREE_LEAF fixes it (experiments)
     const char* lc = getenv("SFMHIP_BA_TREE_LEAF");
+    // helper workgroups per front (ba_front_plan.h, Front::nhelp; SFMHIP_BA_TREE_HELPERS = 1 ... 8): built in round 5 and OFF by
+    // default -- measured slower at every setting (cfg4: 0.2146 ms per iteration without, 0.223-0.236 with 2-5 helpers keeping
+    // 4-10 tiles in the front).  A helper's tile reaches the parent three trips through memory behind the front's last solve
+    // (the front's stores acknowledged, its flag seen, its rows of L loaded: ~8 k cycles) where the front folds ALL its tiles
+    // in 10-17 k; DESIGN.md appendix A has the counts.  Never more than leave every workgroup of the up-sweep a compute unit
+    // of its own.
+    const char* he = getenv("SFMHIP_BA_TREE_HELPERS");
     fplan::Plan P;
-    for (int leaf : {96, 64, 32}) {
-      P = fplan::build_plan(nc, adj.data(), wpr, lc ? atoi(lc) : leaf);
-      if (P.ok || lc) break;
+    fplan::Flat fl;
+    for (int helpers = he ? std::max(0, std::min(8, atoi(he))) : 0; helpers >= 0; --helpers) {
+      for (int leaf : {96, 64, 32}) {
+        static const int keep_env = getenv("SFMHIP_BA_TREE_KEEP") ? atoi(getenv("SFMHIP_BA_TREE_KEEP")) : 8;  // (measurement)
+        P = fplan::build_plan(nc, adj.data(), wpr, lc ? atoi(lc) : leaf, helpers, keep_env);
+        if (P.ok || lc) break;
+      }
+      if (!P.ok) break;
+      fl = fplan::flatten(P);
+      if ((int)fl.up_roles.size() <= b->ctx->n_cu || he) break;
     }
     if (P.ok) {
-      fplan::Flat fl = fplan::flatten(P);
       int* d_ints = nullptr;
       int* d_up = nullptr;
       int* d_down = nullptr;
       unsigned* d_flags = nullptr;
       double* pool = nullptr;
       SFM_TRY(ba_alloc(b, &d_ints, fl.ints.size()));
-      SFM_TRY(ba_alloc(b, &d_up, fl.up_order.size()));
+      SFM_TRY(ba_alloc(b, &d_up, fl.up_roles.size()));
       SFM_TRY(ba_alloc(b, &d_down, fl.down_order.size()));
       const size_t n_flags = (size_t)fl.n_fronts + (size_t)fl.n_tflags;  // per front: z in place; per contribution tile
       SFM_TRY(ba_alloc(b, &d_flags, n_flags));
       SFM_TRY(ba_alloc(b, &pool, fl.n_doubles));
       SFM_HIP_TRY(hipMemcpy(d_ints, fl.ints.data(), fl.ints.size() * sizeof(int), hipMemcpyHostToDevice));
-      SFM_HIP_TRY(hipMemcpy(d_up, fl.up_order.data(), fl.up_order.size() * sizeof(int), hipMemcpyHostToDevice));
+      SFM_HIP_TRY(hipMemcpy(d_up, fl.up_roles.data(), fl.up_roles.size() * sizeof(int), hipMemcpyHostToDevice));
       SFM_HIP_TRY(hipMemcpy(d_down, fl.down_order.data(), fl.down_order.size() * sizeof(int), hipMemcpyHostToDevice));
       SFM_HIP_TRY(hipMemset(d_flags, 0, n_flags * sizeof(unsigned)));
       SFM_HIP_TRY(hipMemset(pool, 0, fl.n_doubles * sizeof(double)));
+
       b->tree_fs.ints = d_ints;
       b->tree_fs.up_order = d_up;
       b->tree_fs.down_order = d_down;
@@ -4602,6 +4616,8 @@ static int ba_nd_build(sfmhip_ba* b) {
       b->tree_fs.zq = zq;
       b->tree_fs.zq_ld = b->ld;
       b->tree_fs.n_fronts = fl.n_fronts;
+      b->tree_fs.n_roles = (int)fl.up_roles.size();
+
       b->tree_levels = fl.levels;
       b->tree_chain_tiles = P.chain_tiles;
       b->tree_chain_blocks = P.chain_blocks;
@@ -4611,8 +4627,8 @@ static int ba_nd_build(sfmhip_ba* b) {
       b->tree_on = true;
       b->nd_on = true;  // (what the two share: the deferred ba_finalize, the pre-zeroed second buffer)
       if (getenv("SFMHIP_BA_ND_VERBOSE"))
-        fprintf(stderr, "[sfmhip] reduced system as a front tree: %d fronts, %d levels, %d tile steps (%d block steps) on the chain, fronts of up to %d tiles; dense %d tiles\n",
-                fl.n_fronts, fl.levels, P.chain_tiles, P.chain_blocks, P.max_T, b->ld / CB);
+        fprintf(stderr, "[sfmhip] reduced system as a front tree: %d fronts (+ %d helper workgroups), %d levels, %d tile steps (%d block steps) on the chain, fronts of up to %d tiles; dense %d tiles\n",
+                fl.n_fronts, (int)fl.up_roles.size() - fl.n_fronts, fl.levels, P.chain_tiles, P.chain_blocks, P.max_T, b->ld / CB);
       return SFMHIP_OK;
     }
     if (getenv("SFMHIP_BA_ND_VERBOSE")) fprintf(stderr, "[sfmhip] no front tree: %s\n", P.why);
@@ -4887,7 +4903,7 @@ static int ba_reduced_solve_tree(sfmhip_ba* b) {
   const size_t nz = b->red_count - b->ssz;
   if (prezero && !b->red_alt && nz % 2 == 0) SFM_TRY(ba_alloc(b, &b->red_alt, nz));
   const int zwg = prezero && b->red_alt ? (int)((nz + ND_ZERO_SLICE - 1) / ND_ZERO_SLICE) : 0;
-  const int nF = b->tree_fs.n_fronts, stride = b->tree_stride;
+  const int nF = b->tree_fs.n_roles, stride = b->tree_stride;  // (fronts and their helper workgroups)
   // grid: the fronts at multiples of `stride`; the zeroing workgroups fill the gaps and follow; one more for the bookkeeping
   const int gaps = (stride - 1) * nF;
   const int grid = stride * nF + std::max(0, zwg + 1 - gaps);
@@ -4908,7 +4924,7 @@ static int ba_reduced_solve_tree(sfmhip_ba* b) {
   }
   if (zwg) b->alt_clean = true;
   b->fin_pending = false;
-  hipLaunchKernelGGL(front_down, dim3(nF), dim3(FD_THREADS), 0, st, b->tree_fs, d, b->d_cam_used, b->rank, epoch, b->solve_cand ? 1 : 0);
+  hipLaunchKernelGGL(front_down, dim3(b->tree_fs.n_fronts), dim3(FD_THREADS), 0, st, b->tree_fs, d, b->d_cam_used, b->rank, epoch, b->solve_cand ? 1 : 0);
   SFM_HIP_TRY(hipGetLastError());
   b->launches += nl + 1;
   return SFMHIP_OK;

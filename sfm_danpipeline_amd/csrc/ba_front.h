@@ -81,11 +81,12 @@ struct FrontSet {
                           // FR_Z_PENDING until its front has solved it; a front resets its entries of the OTHER generation
   int zq_ld;
   int n_fronts;
+  int n_roles;            // workgroups of the up-sweep with a front's or a helper's role (up_order: front | helper << 16)
 };
 
 struct FrDesc {
   int no, ns, T, nb_last, parent, nchild, child_off, inv_off, ptinv_off, sched_off, ncam, cam_off, has_focal, offL, offy, own_cols, off_pbuf, live,
-      focal_pos, tflag_off;
+      focal_pos, tflag_off, nhelp, help_off, pflag_off;
 };
 __device__ __forceinline__ FrDesc fr_desc(const int* __restrict__ ints, int f) {
   const int* p = ints + (size_t)fplan::FD_INTS * f;
@@ -96,6 +97,7 @@ __device__ __forceinline__ FrDesc fr_desc(const int* __restrict__ ints, int f) {
   D.ncam = p[fplan::FD_NCAM], D.cam_off = p[fplan::FD_CAM_OFF], D.has_focal = p[fplan::FD_HAS_FOCAL];
   D.offL = p[fplan::FD_OFF_L], D.offy = p[fplan::FD_OFF_Y], D.own_cols = p[fplan::FD_OWN_COLS];
   D.off_pbuf = p[fplan::FD_OFF_PBUF], D.live = p[fplan::FD_LIVE], D.focal_pos = p[fplan::FD_FOCAL_POS], D.tflag_off = p[fplan::FD_TFLAG_OFF];
+  D.nhelp = p[fplan::FD_NHELP], D.help_off = p[fplan::FD_HELP_OFF], D.pflag_off = p[fplan::FD_PFLAG_OFF];
   return D;
 }
 
@@ -190,6 +192,10 @@ __device__ __forceinline__ void fr_send(const v4d (&t)[4], __amdgpu_buffer_rsrc_
                                                tile_off_bytes + ((2 * sub + h) * 64 + lane) * 16, 0, 16 /* sc1 */);
     }
 }
+// (Round 5 measured the alternative in which the data is its own flag -- the buffer holds a NaN until the sender has stored the
+// tile, the receiver re-arms it: one round trip and the sender's wait for its stores less per hand-off on paper.  Slower by
+// 10 us per solve as built: the polling loop around eight 16-byte loads per lane costs front_up the registers it does not have
+// (24 bytes of scratch per lane at its 168-register limit), and a parent polls for as long as its children work.)
 __device__ __forceinline__ void fr_recv(v4d (&t)[4], __amdgpu_buffer_rsrc_t pool, int tile_off_bytes, unsigned live, int lane) {
   v4u v[8];
 #pragma unroll
@@ -284,7 +290,8 @@ __device__ __forceinline__ void fr_potrf(v4d (&acc)[3], double* sD, double* sdi,
 // tile's LDS home (scratch for the layout changes, X when done, row-major); *oflag = base + finished blocks; out_bytes:
 // the lane's row of the copy in memory, as an offset into the pool (its columns of this block column are contiguous).
 __device__ __forceinline__ void fr_trsm(v4d (&acc)[4], double* sT, const double* sL, const double* sdi, const int* prog, int* oflag,
-                                        int base, int nb, __amdgpu_buffer_rsrc_t pool, int out_bytes, int lane) {
+                                        int base, int nb, __amdgpu_buffer_rsrc_t pool, int out_bytes, int lane,
+                                        bool through /* helper workgroups of this launch read the rows: write-through */) {
   const int i = lane & 31, j16 = lane & 15, q = lane >> 4;
   double* const rowp = sT + i * CBP;
   double* const op0 = sT + j16 * CBP + q;
@@ -317,8 +324,13 @@ __device__ __forceinline__ void fr_trsm(v4d (&acc)[4], double* sT, const double*
       *(v2d*)(rowp + c + 2) = v2d{x2, x3};
       lds_flag_set(oflag, base + b + 1);
       if (lane < CB) {
-        __builtin_amdgcn_raw_buffer_store_b128(fr_pack2(x0, x1), pool, out_bytes + c * 8, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(fr_pack2(x2, x3), pool, out_bytes + (c + 2) * 8, 0, 0);
+        if (through) {
+          __builtin_amdgcn_raw_buffer_store_b128(fr_pack2(x0, x1), pool, out_bytes + c * 8, 0, 16 /* sc1 */);
+          __builtin_amdgcn_raw_buffer_store_b128(fr_pack2(x2, x3), pool, out_bytes + (c + 2) * 8, 0, 16);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(fr_pack2(x0, x1), pool, out_bytes + c * 8, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(fr_pack2(x2, x3), pool, out_bytes + (c + 2) * 8, 0, 0);
+        }
       }
       if (b + 1 < nb) {
         const double X0 = op0[c], X1 = op1[c];
@@ -415,6 +427,79 @@ __device__ __forceinline__ void fr_fold(v4d (&acc)[4], const double* Xr, const d
   }
 }
 
+__device__ __forceinline__ void fr_report_timeout(const int* s_flag, int* __restrict__ info);
+
+// the children's contributions to tile (R, C) of front D, each as its child finishes it (a flag per tile; the front and its
+// helpers alike)
+__device__ __forceinline__ void fr_recv_children(const FrontSet& fs, const FrDesc& D, v4d (&tt)[4], int R, int C, unsigned epoch,
+                                                 __amdgpu_buffer_rsrc_t pool_rs, int* s_mark, int lane) {
+  for (int k = 0; k < D.nchild; ++k) {
+    const int* const chd = fs.ints + (size_t)fplan::FD_INTS * fs.ints[D.child_off + k];
+    const int* const ptinv = fs.ints + D.ptinv_off + k * (FR_TMAX + 1);  // tile of this front -> border tile of the child, or -1
+    const int i = ptinv[R], j = ptinv[C];
+    if (i < 0 || j < 0) continue;
+    const int cno = chd[fplan::FD_NO];
+    const unsigned subs = fr_live_subs((unsigned)chd[fplan::FD_LIVE] >> (2 * cno), i, j);  // (the child's border tiles' live halves)
+    if (!subs) continue;
+    fr_poll_flag(fs.tflag + chd[fplan::FD_TFLAG_OFF] + i * (i + 1) / 2 + j, epoch, s_mark);
+    fr_recv(tt, pool_rs, (chd[fplan::FD_OFF_PBUF] + (i * (i + 1) / 2 + j) * (CB * CB)) * 8, subs, lane);
+  }
+}
+
+// A helper workgroup of front D (ba_front_plan.h, Front::nhelp): some of the front's border x border tiles are this
+// workgroup's -- zero, plus the children's contributions, minus the front's panels -- folded on this compute unit's four
+// matrix pipes while the front folds its own share.  The panels are the border rows of L that the front stores for the
+// down-sweep anyway (write-through when it has helpers), a flag per solved tile; they are copied into LDS in the layout the
+// front's own fold reads, every wave of the workgroup taking some, and folded from there.  The tiles go to the parent as the
+// front's do: a contribution tile has a flag of its own, whoever computed it.
+__device__ __forceinline__ void fr_helper(const FrontSet& fs, const FrDesc& D, int hlp, unsigned epoch, double* sAll, int* __restrict__ info) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int no = D.no, ns = D.ns, ldk = CB * no;
+  double* const sPanel = sAll + FR_OFF_PANEL;
+  int* const s_flag = (int*)(sAll + FR_OFF_FLAG);
+  const __amdgpu_buffer_rsrc_t pool_rs = __builtin_amdgcn_make_buffer_rsrc((void*)fs.pool, 0, 0x7FFFFFFF, 0x00020000);
+  const unsigned live = (unsigned)D.live;
+  if (threadIdx.x < 32) s_flag[threadIdx.x] = 0;
+  __syncthreads();
+  // (one tile per wave -- ba_front_plan.h deals a helper at most FP_WAVES tiles: three register tiles per wave, as the front's
+  // own waves hold them, cost this path 28 bytes of scratch per lane at front_up's 168-register limit)
+  const int hv = __builtin_amdgcn_readfirstlane(fs.ints[D.help_off + (hlp - 1) * (FR_WAVES * FR_SLOTS) + wave * FR_SLOTS]);
+  const int hr = hv < 0 ? -1 : (hv & 255), hc = hv < 0 ? -1 : ((hv >> 8) & 255);
+  // the children's parts of this wave's tile (they may be there long before the front's panels)
+  v4d t[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[i] = v4d{0.0, 0.0, 0.0, 0.0};
+  if (hr >= 0) fr_recv_children(fs, D, t, hr, hc, epoch, pool_rs, s_flag + FRC_MARK1, lane);
+  // the front's panels: tile (r, j) of L, r a border row, as its solve finishes it
+  auto panel_tile = [&](int gen, int r) -> double* { return sPanel + (size_t)(gen * (FR_TMAX - 1) + (r - 1)) * FR_TILE; };
+#pragma unroll 1
+  for (int idx = wave; idx < no * ns; idx += FR_WAVES) {
+    const int j = idx / ns, i = idx - j * ns, r = no + i;
+    fr_poll_flag(fs.tflag + D.pflag_off + j * ns + i, epoch, s_flag + FRC_MARK1);
+    const int row = lane >> 1, half = lane & 1;
+    const int src = (D.offL + (CB * r + row) * ldk + CB * j + 16 * half) * 8;
+    v4u v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(pool_rs, src + 16 * k, 0, 16 /* sc1 */);
+    double* const dst = panel_tile(j, r) + row * CBP + 16 * half;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      *(v2d*)(dst + 2 * k) = v2d{__hiloint2double((int)v[k].y, (int)v[k].x), __hiloint2double((int)v[k].w, (int)v[k].z)};
+  }
+  __syncthreads();
+  if (hr >= 0) {
+    const unsigned subs = fr_live_subs(live, hr, hc);
+#pragma unroll 1
+    for (int j = 0; j < no; ++j) fr_fold(t, panel_tile(j, hr), panel_tile(j, hc), j == no - 1 ? D.nb_last : 8, subs, lane);
+    const int i = hr - no, j = hc - no;
+    fr_send(t, pool_rs, (D.off_pbuf + (i * (i + 1) / 2 + j) * (CB * CB)) * 8, subs, lane);
+    fr_raise_flag(fs.tflag + D.tflag_off + i * (i + 1) / 2 + j, epoch, lane);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  fr_report_timeout(s_flag, info);
+}
+
 __device__ __forceinline__ void fr_report_timeout(const int* s_flag, int* __restrict__ info) {
   if ((*(volatile const lds_int*)(s_flag + FRC_MARK0) != 0 || *(volatile const lds_int*)(s_flag + FRC_MARK1) != 0) && (threadIdx.x & 63) == 0)
     atomicExch(info, -1);
@@ -425,7 +510,7 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
                                                           unsigned epoch, int stride, int lvl_lo, int lvl_hi, double* __restrict__ zero_ptr,
                                                           long long zero_n, int n_zero, int xoff /* the fronts' place in every `stride` workgroups */) {
   extern __shared__ __attribute__((aligned(16))) double sAll[];
-  const int nF = fs.n_fronts;
+  const int nF = fs.n_roles;  // (fronts and their helper workgroups)
   if (lm_stopped(d)) return;  // (an iteration enqueued behind a stop of the device's LM loop: every role of the launch returns)
   {
     // ---- which role: the fronts sit at multiples of `stride` (stride 8: one XCD's L2 under round-robin placement,
@@ -466,11 +551,16 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
       return;
     }
   }
-  const int f = fs.up_order[blockIdx.x / stride];
+  const int role = fs.up_order[blockIdx.x / stride];
+  const int f = role & 0xFFFF;
   const FrDesc D = fr_desc(fs.ints, f);
   {
     const int lvl = fs.ints[(size_t)fplan::FD_INTS * f + fplan::FD_LEVEL];
-    if (lvl < lvl_lo || lvl > lvl_hi) return;  // (level-by-level launches: a diagnostic mode)
+    if (lvl < lvl_lo || lvl > lvl_hi) return;  // (level-by-level launches: the fallback behind a timed-out hand-off, and a diagnostic mode)
+  }
+  if (role >> 16) {  // a helper workgroup of front f
+    fr_helper(fs, D, role >> 16, epoch, sAll, d.info);
+    return;
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int no = D.no, T = D.T, nrow = CB * T, ldk = CB * no;
@@ -526,19 +616,7 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
   // ---- the children's contribution blocks, tile by tile as the children finish them: every tile of a child's block has
   // a flag of its own, and a wave fetches a tile only when it is about to use it -- the chain wave starts on the first
   // diagonal tile, and the solve next to it on its tile, while the children are still folding and sending the rest
-  auto recv_tile = [&](v4d (&tt)[4], int R, int C) {
-    for (int k = 0; k < D.nchild; ++k) {
-      const int* const chd = fs.ints + (size_t)fplan::FD_INTS * fs.ints[D.child_off + k];
-      const int* const ptinv = fs.ints + D.ptinv_off + k * (FR_TMAX + 1);  // tile of this front -> border tile of the child, or -1
-      const int i = ptinv[R], j = ptinv[C];
-      if (i < 0 || j < 0) continue;
-      const int cno = chd[fplan::FD_NO];
-      const unsigned subs = fr_live_subs((unsigned)chd[fplan::FD_LIVE] >> (2 * cno), i, j);  // (the child's border tiles' live halves)
-      if (!subs) continue;
-      fr_poll_flag(fs.tflag + chd[fplan::FD_TFLAG_OFF] + i * (i + 1) / 2 + j, epoch, s_flag + FRC_MARK1);
-      fr_recv(tt, pool_rs, (chd[fplan::FD_OFF_PBUF] + (i * (i + 1) / 2 + j) * (CB * CB)) * 8, subs, lane);
-    }
-  };
+  auto recv_tile = [&](v4d (&tt)[4], int R, int C) { fr_recv_children(fs, D, tt, R, C, epoch, pool_rs, s_flag + FRC_MARK1, lane); };
   if (chain) {
     recv_tile(t[0], 0, 0);
     FR_STAMP(2);
@@ -697,7 +775,7 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
         if (sc[s] == j && sr[s] > j) {
           need(s);
           fr_trsm(t[s], panel_tile(gen, sr[s]), sD + gen * FR_TILE, sdi + gen * CB, progL_of(gen), prog_of(gen, sr[s]), base, nbj,
-                  pool_rs, (D.offL + (CB * sr[s] + (lane & 31)) * ldk + CB * j) * 8, lane);
+                  pool_rs, (D.offL + (CB * sr[s] + (lane & 31)) * ldk + CB * j) * 8, lane, D.nhelp > 0 && sr[s] >= no);
         }
 #pragma unroll
       for (int s = 0; s < FR_SLOTS; ++s)
@@ -709,6 +787,20 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
         }
       lds_flag_add(s_flag + FRC_CONS + gen, lane);
     }
+    // helper workgroups fold some of the border tiles: the border rows of L this wave has solved are in memory (write-through),
+    // a flag per tile tells them.  A flag may only follow the wave's stores, and waiting for stores that have just been issued
+    // costs ~2 us -- on every level, when it sat here between the steps and the wave's first border tile (measured: 11 us per
+    // solve, more than the helpers gave back).  So the flags go out where the wait is free: while the wave waits for its turn
+    // anyway, or behind the wait its first tile's own flag needs, or -- a wave with no border tile -- here.
+    bool panels_told = D.nhelp <= 0;
+    auto tell_panels = [&]() {
+      if (!panels_told) {
+#pragma unroll
+        for (int s = 0; s < FR_SLOTS; ++s)
+          if (sc[s] >= 0 && sc[s] < no && sr[s] >= no) fr_raise_flag(fs.tflag + D.pflag_off + sc[s] * D.ns + (sr[s] - no), epoch, lane);
+        panels_told = true;
+      }
+    };
     // the border tiles.  A front that folded them as it went sends them; a front of one or two own tiles folds both panels into
     // them now that nothing solves beside them, a tile at a time per SIMD in the plan's order (ba_front_plan.h: the order in
     // which the ancestors need them), sends each and raises its flag
@@ -727,6 +819,7 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
           lds_wait_ge(progL_of((no - 1) & 1), D.nb_last);
           if ((wave & 3) >= 2)
             for (int r = no; r < T; ++r) lds_wait_ge(prog_of((no - 1) & 1, r), D.nb_last);
+          if (sturn[s] > 0) tell_panels();
           lds_wait_ge(turn, sturn[s]);
           FR_STAMP(32 + 8 * wave + 2 * s);
           for (int j = 0; j < no; ++j) {
@@ -741,8 +834,10 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
         const int i = sr[s] - no, j = sc[s] - no;
         fr_send(t[s], pool_rs, (D.off_pbuf + (i * (i + 1) / 2 + j) * (CB * CB)) * 8, subs, lane);
         fr_raise_flag(fs.tflag + D.tflag_off + i * (i + 1) / 2 + j, epoch, lane);
+        tell_panels();
         if (wave == 8 && sturn[s] == 0) FR_STAMP(29);
       }
+    tell_panels();
   }
   // ---- every store of this workgroup has left before the flag does
   if (wave == 1) FR_STAMP(19);

@@ -47,6 +47,13 @@ struct Front {
   unsigned live = 0;          // bit 2 t + h: row half h of front tile t holds an own or a true border parameter
   std::vector<uint8_t> sched; // FP_WAVES x FP_SLOTS x 2: (r, c) of the tile a wave slot holds, 0xFF = empty
   std::vector<uint8_t> turn;  // FP_WAVES x FP_SLOTS: a border tile's place in its SIMD's queue when the tiles are folded at the end
+  // helper workgroups (round 5): a front of one or two own tiles folds its border x border tiles when its factorisation is
+  // over, and that fold -- 15 to 21 tiles x 6 to 14 blocks x up to 4 f64 MFMAs on ONE compute unit's four matrix pipes -- is
+  // what a tree level costs beyond its POTRFs.  With helpers the tiles are dealt over 1 + nhelp workgroups: the front keeps
+  // every (nhelp + 1)-th tile of the ancestors' order, helper h the others; a helper reads the front's finished panels from
+  // memory (the rows of L it stores for the down-sweep anyway), folds, and sends its tiles to the parent like the front does.
+  int nhelp = 0;
+  std::vector<std::vector<uint8_t>> hsched;  // per helper: FP_WAVES x FP_SLOTS x 2, (r, c) of the tile a wave slot holds, 0xFF = empty
 };
 
 struct Plan {
@@ -216,7 +223,7 @@ struct Builder {
 };
 
 // adjacency as nc x wpr bit rows (the layout sfmhip_ba keeps); leaf_cols: components up to this many columns become leaves
-static inline Plan build_plan(int nc, const unsigned long long* adj_bits, int wpr, int leaf_cols) {
+static inline Plan build_plan(int nc, const unsigned long long* adj_bits, int wpr, int leaf_cols, int n_helpers = 0, int keep = 8) {
   std::vector<std::vector<int>> nb(nc);
   for (int i = 0; i < nc; ++i)
     for (int j = 0; j < nc; ++j)
@@ -439,7 +446,30 @@ static inline Plan build_plan(int nc, const unsigned long long* adj_bits, int wp
         return x.b < y.b;
       });
       std::vector<std::pair<int, int>> todo;
-      for (const Item& it : items) todo.emplace_back(it.r, it.c);
+      {
+        // the front's own share, and the helpers': the first `keep` tiles of the ancestors' order are the front's (a helper's tile
+        // reaches the parent two hand-offs later than one the front folds in its first rounds: what the parent's factorisation
+        // waits for first must not take that way), the others are dealt over the helpers and the front in turn
+        const int H = fr.parent >= 0 ? std::max(0, std::min(n_helpers, (int)items.size() - keep)) : 0;
+        fr.nhelp = H;
+        fr.hsched.assign(H, std::vector<uint8_t>((size_t)FP_WAVES * FP_SLOTS * 2, 0xFF));
+        std::vector<int> hk(H, 0);
+        for (size_t q = 0; q < items.size(); ++q) {
+          const int owner = H && (int)q >= keep ? (int)((q - (size_t)keep) % (size_t)(H + 1)) + 1 > H ? 0 : (int)((q - (size_t)keep) % (size_t)(H + 1)) + 1 : 0;
+          if (owner == 0) {
+            todo.emplace_back(items[q].r, items[q].c);
+            continue;
+          }
+          const int k = hk[owner - 1]++;  // the helper's k-th tile: wave k (SIMD k mod 4); one tile per wave (ba_front.h, fr_helper)
+          if (k >= FP_WAVES) {
+            P.why = "no helper slot left for a tile";
+            return P;
+          }
+          std::vector<uint8_t>& hs = fr.hsched[owner - 1];
+          hs[((size_t)(k % FP_WAVES) * FP_SLOTS + k / FP_WAVES) * 2] = (uint8_t)items[q].r;
+          hs[((size_t)(k % FP_WAVES) * FP_SLOTS + k / FP_WAVES) * 2 + 1] = (uint8_t)items[q].c;
+        }
+      }
       size_t p = 0;
       for (int round = 0; round < FP_SLOTS && p < todo.size(); ++round)
         for (int k = 0; k < 3 && p < todo.size(); ++k)
@@ -489,10 +519,11 @@ static inline Plan build_plan(int nc, const unsigned long long* adj_bits, int wp
 // ---- the flat form the device reads (and the test checks): one int pool + offsets into one pool of doubles
 namespace fplan {
 
-constexpr int FD_INTS = 24;  // ints per front descriptor
+constexpr int FD_INTS = 28;  // ints per front descriptor
 enum {
   FD_NO = 0, FD_NS, FD_T, FD_NB_LAST, FD_PARENT, FD_LEVEL, FD_NCHILD, FD_CHILD_OFF, FD_INV_OFF, FD_PTINV_OFF, FD_SCHED_OFF,
-  FD_NCAM, FD_CAM_OFF, FD_HAS_FOCAL, FD_OFF_L, FD_OFF_Y, FD_OWN_COLS, FD_OFF_PBUF, FD_PTILE_OFF, FD_LIVE, FD_FOCAL_POS, FD_TFLAG_OFF, FD_USED
+  FD_NCAM, FD_CAM_OFF, FD_HAS_FOCAL, FD_OFF_L, FD_OFF_Y, FD_OWN_COLS, FD_OFF_PBUF, FD_PTILE_OFF, FD_LIVE, FD_FOCAL_POS, FD_TFLAG_OFF,
+  FD_NHELP, FD_HELP_OFF, FD_PFLAG_OFF, FD_USED
 };
 static_assert(FD_USED <= FD_INTS, "descriptor size");
 
@@ -500,6 +531,9 @@ struct Flat {
   int n_fronts = 0, levels = 0, max_T = 0;
   std::vector<int> ints;       // [FD_INTS x fronts | pools]
   std::vector<int> up_order;   // deepest level first
+  std::vector<int> up_roles;   // the up-sweep's workgroups in grid order: front | helper << 16 (0: the front itself, h: its h-th
+                               // helper), level by level from the deepest, a level's fronts before their helpers -- whatever a
+                               // workgroup waits for comes before it in the grid
   std::vector<int> down_order; // root first
   int n_tflags = 0;            // per front: a flag per tile of its contribution block + one for the rhs (FD_TFLAG_OFF)
   size_t n_doubles = 0;        // per front: L (32 T x 32 no, row-major), y (32 T), and the buffer in which it hands its
@@ -568,6 +602,23 @@ static inline Flat flatten(const Plan& P) {
     nd += (size_t)(fr.ns * (fr.ns + 1) / 2) * FP_TILE * FP_TILE;
     put(FD_TFLAG_OFF, fl.n_tflags);
     fl.n_tflags += fr.ns * (fr.ns + 1) / 2 + 1;
+    // helpers: their tiles, and a flag per solved panel tile (step j, border row i: no x ns) that tells them its rows of L are in memory
+    put(FD_NHELP, fr.nhelp);
+    put(FD_HELP_OFF, (int)fl.ints.size());
+    for (int h = 0; h < fr.nhelp; ++h)
+      for (int i = 0; i < FP_WAVES * FP_SLOTS; ++i) {
+        const int r = fr.hsched[h][2 * i], c = fr.hsched[h][2 * i + 1];
+        fl.ints.push_back(r == 0xFF ? -1 : (r | (c << 8)));
+      }
+    put(FD_PFLAG_OFF, fl.n_tflags);
+    if (fr.nhelp) fl.n_tflags += fr.no * fr.ns;
+  }
+  for (int l = P.levels - 1; l >= 0; --l) {
+    for (int f = 0; f < F; ++f)
+      if (P.fronts[f].level == l) fl.up_roles.push_back(f);
+    for (int f = 0; f < F; ++f)
+      if (P.fronts[f].level == l)
+        for (int h = 1; h <= P.fronts[f].nhelp; ++h) fl.up_roles.push_back(f | (h << 16));
   }
   fl.n_doubles = nd;
   return fl;

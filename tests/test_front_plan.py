@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FD_INTS = 24
+FD_INTS = 28
 (FD_NO, FD_NS, FD_T, FD_NB_LAST, FD_PARENT, FD_LEVEL, FD_NCHILD, FD_CHILD_OFF, FD_INV_OFF, FD_PTINV_OFF, FD_SCHED_OFF,
  FD_NCAM, FD_CAM_OFF, FD_HAS_FOCAL, FD_OFF_L, FD_OFF_Y, FD_OWN_COLS, FD_OFF_PBUF, FD_PTILE_OFF, FD_LIVE) = range(20)
 T_MAX = 7
@@ -229,3 +229,77 @@ def test_small_and_dense_graphs(fp):
     rng = np.random.default_rng(0)
     a = rng.random((200, 200)) < 0.4
     assert build(fp, a | a.T) is None
+
+
+def test_helper_workgroups_share_the_deferred_tiles_exactly(tmp_path):
+    """Front::nhelp (round 5, off by default): with helpers a front of one or two own tiles keeps the first `keep` border x border
+    tiles of the ancestors' order and deals the others over itself and its helpers -- every tile exactly once, a helper's at most
+    one per wave; the up-sweep's roles list every front before its helpers and every level before the one above."""
+    src = tmp_path / "helpers.cpp"
+    src.write_text(r'''
+#include "%s/sfm_danpipeline_amd/csrc/ba_front_plan.h"
+#include <cstdio>
+#include <set>
+int main() {
+  const int nc = 200, k = 10, wpr = (nc + 63) / 64;
+  std::vector<unsigned long long> adj((size_t)nc * wpr, 0);
+  for (int i = 0; i < nc; ++i)
+    for (int d = 1; d < k; ++d) {
+      const int j = (i + d) %% nc;
+      adj[(size_t)i * wpr + (j >> 6)] |= 1ull << (j & 63);
+      adj[(size_t)j * wpr + (i >> 6)] |= 1ull << (i & 63);
+    }
+  for (int H : {0, 1, 3}) {
+    fplan::Plan P;
+    for (int leaf : {96, 64, 32}) {
+      P = fplan::build_plan(nc, adj.data(), wpr, leaf, H, 4);
+      if (P.ok) break;
+    }
+    if (!P.ok) return 1;
+    fplan::Flat fl = fplan::flatten(P);
+    int helpers = 0;
+    for (size_t f = 0; f < P.fronts.size(); ++f) {
+      const fplan::Front& fr = P.fronts[f];
+      std::multiset<std::pair<int, int>> seen;
+      for (int w = 0; w < fplan::FP_WAVES; ++w)
+        for (int s = 0; s < fplan::FP_SLOTS; ++s) {
+          const int r = fr.sched[((size_t)w * fplan::FP_SLOTS + s) * 2], c = fr.sched[((size_t)w * fplan::FP_SLOTS + s) * 2 + 1];
+          if (r != 0xFF && c >= fr.no) seen.insert({r, c});
+        }
+      for (int h = 0; h < fr.nhelp; ++h)
+        for (int w = 0; w < fplan::FP_WAVES; ++w)
+          for (int s = 0; s < fplan::FP_SLOTS; ++s) {
+            const int r = fr.hsched[h][((size_t)w * fplan::FP_SLOTS + s) * 2], c = fr.hsched[h][((size_t)w * fplan::FP_SLOTS + s) * 2 + 1];
+            if (r == 0xFF) continue;
+            if (s != 0 || c < fr.no) return 2;       // one tile per helper wave, border x border only
+            seen.insert({r, c});
+          }
+      helpers += fr.nhelp;
+      if (fr.nhelp > H || (fr.no > 2 && fr.nhelp)) return 3;
+      for (int c = fr.no; c < fr.T; ++c)
+        for (int r = c; r < fr.T; ++r)
+          if (seen.count({r, c}) != 1) return 4;     // every border x border tile exactly once
+      if ((int)seen.size() != fr.ns * (fr.ns + 1) / 2) return 5;
+    }
+    if ((int)fl.up_roles.size() != (int)P.fronts.size() + helpers) return 6;
+    if (H == 0 && helpers) return 7;
+    if (H == 3 && !helpers) return 8;
+    // grid order: a front before its helpers, a deeper level before a shallower one
+    std::vector<int> at(P.fronts.size(), -1);
+    int last_level = 1 << 30;
+    for (size_t i = 0; i < fl.up_roles.size(); ++i) {
+      const int f = fl.up_roles[i] & 0xFFFF, h = fl.up_roles[i] >> 16;
+      if (h == 0) at[f] = (int)i;
+      else if (at[f] < 0) return 9;
+      if (P.fronts[f].level > last_level) return 10;
+      last_level = P.fronts[f].level;
+    }
+  }
+  std::puts("ok");
+  return 0;
+}
+''' % ROOT)
+    exe = str(tmp_path / "helpers")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, str(src)])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", (out.returncode, out.stdout, out.stderr)
