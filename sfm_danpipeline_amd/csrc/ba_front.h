@@ -215,6 +215,42 @@ __device__ __forceinline__ void fr_recv(v4d (&t)[4], __amdgpu_buffer_rsrc_t pool
       }
     }
 }
+// two contribution tiles at once (the chain wave: 64 registers of loads in flight)
+__device__ __forceinline__ void fr_recv2(v4d (&t)[4], __amdgpu_buffer_rsrc_t pool, int off0, unsigned live0, int off1, unsigned live1, int lane) {
+  v4u v[8], w[8];
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) {
+    if ((live0 >> sub) & 1) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) v[2 * sub + h] = __builtin_amdgcn_raw_buffer_load_b128(pool, off0 + ((2 * sub + h) * 64 + lane) * 16, 0, 16 /* sc1 */);
+    }
+    if ((live1 >> sub) & 1) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) w[2 * sub + h] = __builtin_amdgcn_raw_buffer_load_b128(pool, off1 + ((2 * sub + h) * 64 + lane) * 16, 0, 16 /* sc1 */);
+    }
+  }
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) {  // (child 0's first, then child 1's: the order fr_recv twice adds them in)
+    if ((live0 >> sub) & 1) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        t[sub][2 * h] += __hiloint2double((int)v[2 * sub + h].y, (int)v[2 * sub + h].x);
+        t[sub][2 * h + 1] += __hiloint2double((int)v[2 * sub + h].w, (int)v[2 * sub + h].z);
+      }
+    }
+  }
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) {
+    if ((live1 >> sub) & 1) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        t[sub][2 * h] += __hiloint2double((int)w[2 * sub + h].y, (int)w[2 * sub + h].x);
+        t[sub][2 * h + 1] += __hiloint2double((int)w[2 * sub + h].w, (int)w[2 * sub + h].z);
+      }
+    }
+  }
+}
+
 // which sub-tiles [2 ci + ri] of tile (r, c) hold anything: row half ri of r and row half ci of c live, not above the diagonal
 __device__ __forceinline__ unsigned fr_live_subs(unsigned live, int r, int c) {
   const unsigned lr = (live >> (2 * r)) & 3, lc = (live >> (2 * c)) & 3;
@@ -429,20 +465,56 @@ __device__ __forceinline__ void fr_fold(v4d (&acc)[4], const double* Xr, const d
 
 __device__ __forceinline__ void fr_report_timeout(const int* s_flag, int* __restrict__ info);
 
-// the children's contributions to tile (R, C) of front D, each as its child finishes it (a flag per tile; the front and its
-// helpers alike)
+// the children's contributions to tile (R, C) of front D (a flag per tile; the front and its helpers alike).  Two children at
+// a time: their two flags are polled TOGETHER (one round trip through memory when both are up, which they usually are by the time
+// a tile is wanted -- polled one after the other, each in front of its own loads, a tile with two contributions cost four round
+// trips, ~10 k cycles: profiles/round4_front_stamps.txt, "children done" and every "fetch<"), and a wave with registers to spare
+// (WIDE: the chain wave, whose tile (0, 0) gates the level's first POTRF) has both tiles' loads in flight at once.
+template <bool WIDE>
 __device__ __forceinline__ void fr_recv_children(const FrontSet& fs, const FrDesc& D, v4d (&tt)[4], int R, int C, unsigned epoch,
                                                  __amdgpu_buffer_rsrc_t pool_rs, int* s_mark, int lane) {
-  for (int k = 0; k < D.nchild; ++k) {
-    const int* const chd = fs.ints + (size_t)fplan::FD_INTS * fs.ints[D.child_off + k];
-    const int* const ptinv = fs.ints + D.ptinv_off + k * (FR_TMAX + 1);  // tile of this front -> border tile of the child, or -1
-    const int i = ptinv[R], j = ptinv[C];
-    if (i < 0 || j < 0) continue;
-    const int cno = chd[fplan::FD_NO];
-    const unsigned subs = fr_live_subs((unsigned)chd[fplan::FD_LIVE] >> (2 * cno), i, j);  // (the child's border tiles' live halves)
-    if (!subs) continue;
-    fr_poll_flag(fs.tflag + chd[fplan::FD_TFLAG_OFF] + i * (i + 1) / 2 + j, epoch, s_mark);
-    fr_recv(tt, pool_rs, (chd[fplan::FD_OFF_PBUF] + (i * (i + 1) / 2 + j) * (CB * CB)) * 8, subs, lane);
+  for (int k0 = 0; k0 < D.nchild; k0 += 2) {
+    int off[2] = {0, 0};
+    unsigned subs[2] = {0u, 0u};
+    const unsigned* flg[2] = {nullptr, nullptr};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = k0 + u;
+      if (k >= D.nchild) continue;
+      const int* const chd = fs.ints + (size_t)fplan::FD_INTS * fs.ints[D.child_off + k];
+      const int* const ptinv = fs.ints + D.ptinv_off + k * (FR_TMAX + 1);  // tile of this front -> border tile of the child, or -1
+      const int i = ptinv[R], j = ptinv[C];
+      if (i < 0 || j < 0) continue;
+      const int cno = chd[fplan::FD_NO];
+      subs[u] = fr_live_subs((unsigned)chd[fplan::FD_LIVE] >> (2 * cno), i, j);  // (the child's border tiles' live halves)
+      if (!subs[u]) continue;
+      flg[u] = fs.tflag + chd[fplan::FD_TFLAG_OFF] + i * (i + 1) / 2 + j;
+      off[u] = (chd[fplan::FD_OFF_PBUF] + (i * (i + 1) / 2 + j) * (CB * CB)) * 8;
+    }
+    if (!subs[0] && !subs[1]) continue;
+    {
+      // (every lane polls the same words; the branch is uniform; bounded like fr_poll_flag)
+      const unsigned* const f0 = subs[0] ? flg[0] : flg[1];
+      const unsigned* const f1 = subs[1] ? flg[1] : flg[0];
+      int budget = 1 << 17;
+      for (;;) {
+        const unsigned a = __hip_atomic_load((const gbl_u32*)f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned b = __hip_atomic_load((const gbl_u32*)f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__builtin_amdgcn_readfirstlane(a) == epoch && __builtin_amdgcn_readfirstlane(b) == epoch) break;
+        if (--budget == 0) {
+          *(volatile lds_int*)s_mark = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      asm volatile("" ::: "memory");
+    }
+    if (WIDE && subs[0] && subs[1]) {
+      fr_recv2(tt, pool_rs, off[0], subs[0], off[1], subs[1], lane);
+    } else {
+      if (subs[0]) fr_recv(tt, pool_rs, off[0], subs[0], lane);
+      if (subs[1]) fr_recv(tt, pool_rs, off[1], subs[1], lane);
+    }
   }
 }
 
@@ -469,7 +541,7 @@ __device__ __forceinline__ void fr_helper(const FrontSet& fs, const FrDesc& D, i
   v4d t[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) t[i] = v4d{0.0, 0.0, 0.0, 0.0};
-  if (hr >= 0) fr_recv_children(fs, D, t, hr, hc, epoch, pool_rs, s_flag + FRC_MARK1, lane);
+  if (hr >= 0) fr_recv_children<false>(fs, D, t, hr, hc, epoch, pool_rs, s_flag + FRC_MARK1, lane);
   // the front's panels: tile (r, j) of L, r a border row, as its solve finishes it
   auto panel_tile = [&](int gen, int r) -> double* { return sPanel + (size_t)(gen * (FR_TMAX - 1) + (r - 1)) * FR_TILE; };
 #pragma unroll 1
@@ -616,9 +688,9 @@ __global__ __launch_bounds__(FR_WAVES * 64) void front_up(FrontSet fs, const dou
   // ---- the children's contribution blocks, tile by tile as the children finish them: every tile of a child's block has
   // a flag of its own, and a wave fetches a tile only when it is about to use it -- the chain wave starts on the first
   // diagonal tile, and the solve next to it on its tile, while the children are still folding and sending the rest
-  auto recv_tile = [&](v4d (&tt)[4], int R, int C) { fr_recv_children(fs, D, tt, R, C, epoch, pool_rs, s_flag + FRC_MARK1, lane); };
+  auto recv_tile = [&](v4d (&tt)[4], int R, int C) { fr_recv_children<false>(fs, D, tt, R, C, epoch, pool_rs, s_flag + FRC_MARK1, lane); };
   if (chain) {
-    recv_tile(t[0], 0, 0);
+    fr_recv_children<false>(fs, D, t[0], 0, 0, epoch, pool_rs, s_flag + FRC_MARK1, lane);
     FR_STAMP(2);
   } else if (rhs) {
     for (int k = 0; k < D.nchild; ++k) {
