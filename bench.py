@@ -38,6 +38,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# The ROCm runtime multiplexes a process's HIP streams onto 4 hardware queues unless told otherwise, and streams that share a queue
+# run one after the other.  This process holds more than four at a time (two matching streams + their two copy streams + the four
+# streams of the batch-mode BA leg): measured on one box, the four concurrent cfg4 problems of `ba_batch` make 7 150 LM iterations/s
+# in total on 4 queues and 9 710 on 8 -- nothing else on the line moves.  A knob of the runtime, read when HIP initialises (hence
+# before torch is imported); INTEGRATION.md says the same to a host program that drives several problems side by side.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 I8_DENSE_PEAK_TOPS = 5000.0   # 2x the ~2.5 PF dense bf16 MFMA peak (MI355X_MICROARCH.md, Matrix cores)
 F32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
@@ -691,7 +698,7 @@ def main():
                        "pairs_per_gpu": int(len(pairs)), "matches_found": total_matches,
                        "ba_points_per_gpu": int(n_pt_l), "ba_obs_per_gpu": int(n_obs_l),
                        "ba_cost": [ba_sum.initial_cost, ba_sum.final_cost],
-                       "match_streams": N_STREAMS,
+                       "match_streams": N_STREAMS, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "parallelism": f"pairs x{world} (weak" + (f"; consecutive batches alternate between {N_STREAMS} HIP "
                                       "streams per GPU" if N_STREAMS > 1 else "") + f"), BA points/{world} + all-reduce"},
             "sustained": {"seconds": args.sustain_s, "pairs_per_s": round(sustained_pairs_s, 1),

@@ -8,7 +8,7 @@ import torch
 from sfm_danpipeline_amd import _lib, bundle, synth
 
 n_prob = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-iters = 400
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 ctxs = [_lib.Context(0, stream=torch.cuda.Stream().cuda_stream) for _ in range(n_prob)]
 probs = []
 for k, c in enumerate(ctxs):

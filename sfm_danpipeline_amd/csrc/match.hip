@@ -2153,6 +2153,7 @@ extern "C" int sfmhip_matchplan_pipeline(sfmhip_matchplan* pl, int64_t capacity)
     // (highest priority: the packing launch gets the first compute units a sweep's workgroups give back, not the last)
     int prio_lo = 0, prio_hi = 0;
     if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
+    if (getenv("SFMHIP_PIPE_PRIORITY") && atoi(getenv("SFMHIP_PIPE_PRIORITY")) == 0) prio_hi = prio_lo;  // (measurement)
     SFM_HIP_TRY(hipStreamCreateWithPriority(&pl->pipe_st, hipStreamNonBlocking, prio_hi));
     SFM_HIP_TRY(hipEventCreateWithFlags(&pl->ev_ready, hipEventDisableTiming));
     for (auto& e : pl->ev_host) SFM_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
