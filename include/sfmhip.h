@@ -336,6 +336,25 @@ int sfmhip_ba_reduced_layout(sfmhip_ba* ba, int32_t layout[4]);
  * dependency chain), tree[3] = tiles (own + border) of the largest front.  sfmhip_ba_reduced_layout then reports no
  * chains.  Behind Eigen's LLT, reference src/BundleAdjustment.cpp:116. */
 int sfmhip_ba_reduced_tree(sfmhip_ba* ba, int32_t tree[4]);
+/* Test hook: ONE trust-region decision (TrustRegionMinimizer + LevenbergMarquardtStrategy of Ceres 1.13 behind reference
+ * src/BundleAdjustment.cpp:115-123), taken on the HOST by the very function the device runs at the end of every step evaluation
+ * (lm_decide in csrc/ba.hip; compiled without contraction on both sides, so the two agree bit for bit).  Needs no GPU.
+ * state: options in, trust-region state in and out; `accepted` is set when this decision took the candidate; `stop` is -1 while
+ * the loop runs, an SFMHIP_BA_* termination type once a rule has fired (further calls change nothing), 100 when `solve_info` < 0
+ * (a bounded spin ran out: neither an iteration nor a step). */
+typedef struct {
+  double gradient_tolerance, parameter_tolerance, function_tolerance, min_relative_decrease, max_radius, min_radius;
+  int max_consecutive_invalid, max_iterations, timing_only /* sfmhip_ba_iterate: no convergence tests */, pad;
+  double radius, decrease_factor, cost, gradient_max_norm, x_norm;
+  int iterations, successful_steps, invalid_steps, lin_unread /* the last accepted step's linearisation has not been read */;
+  int accepted, stop;
+} sfmhip_lm_state;
+typedef struct {
+  double lin_cost, lin_failed_blocks, lin_gradient_max;                          /* of the linearisation at x */
+  double candidate_cost, model_cost_change, step_norm2, candidate_norm2;         /* of the step evaluation */
+  int solve_info, pad;                                                           /* > 0: a pivot was not positive; < 0: time-out */
+} sfmhip_lm_inputs;
+int sfmhip_ba_lm_decide(sfmhip_lm_state* state, const sfmhip_lm_inputs* in);
 /* device seconds of the last run/iterate by kernel group:
  * [0]=linearise+eliminate [1]=allreduce [2]=reduced solve [3]=back-substitute+cost */
 int sfmhip_ba_last_timing(sfmhip_ba* ba, double seconds[4], int* launches);

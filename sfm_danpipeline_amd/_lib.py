@@ -34,6 +34,28 @@ class BaSummary(C.Structure):
     ]
 
 
+class LmState(C.Structure):
+    """sfmhip_lm_state (include/sfmhip.h): options + trust-region state of sfmhip_ba_lm_decide, the host-side test hook of the
+    decision the device takes at the end of every step evaluation."""
+    _fields_ = [
+        ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double), ("function_tolerance", C.c_double),
+        ("min_relative_decrease", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
+        ("max_consecutive_invalid", C.c_int), ("max_iterations", C.c_int), ("timing_only", C.c_int), ("pad", C.c_int),
+        ("radius", C.c_double), ("decrease_factor", C.c_double), ("cost", C.c_double), ("gradient_max_norm", C.c_double),
+        ("x_norm", C.c_double),
+        ("iterations", C.c_int), ("successful_steps", C.c_int), ("invalid_steps", C.c_int), ("lin_unread", C.c_int),
+        ("accepted", C.c_int), ("stop", C.c_int),
+    ]
+
+
+class LmInputs(C.Structure):
+    _fields_ = [
+        ("lin_cost", C.c_double), ("lin_failed_blocks", C.c_double), ("lin_gradient_max", C.c_double),
+        ("candidate_cost", C.c_double), ("model_cost_change", C.c_double), ("step_norm2", C.c_double),
+        ("candidate_norm2", C.c_double), ("solve_info", C.c_int), ("pad", C.c_int),
+    ]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
 
 # every symbol include/sfmhip.h declares (tests check the built library exports all of them)
@@ -47,7 +69,7 @@ SYMBOLS = [
     "sfmhip_matchplan_destroy",
     "sfmhip_triangulate", "sfmhip_find_2d3d", "sfmhip_merge_new_points", "sfmhip_ba_default_opts", "sfmhip_ba_solve", "sfmhip_ba_create",
     "sfmhip_ba_set_allreduce", "sfmhip_ba_set_params", "sfmhip_ba_get_params", "sfmhip_ba_run",
-    "sfmhip_ba_iterate", "sfmhip_ba_reduced_system", "sfmhip_ba_linearize_obs", "sfmhip_ba_last_timing", "sfmhip_ba_reduced_layout", "sfmhip_ba_reduced_tree", "sfmhip_probe_i8_mfma_peak", "sfmhip_probe_clock_start", "sfmhip_probe_clock_read", "sfmhip_ba_reduced_step", "sfmhip_score_essential", "sfmhip_score_last_flags", "sfmhip_score_five_point", "sfmhip_score_homography_kernel", "sfmhip_score_homography", "sfmhip_sift_detect_and_compute", "sfmhip_sift_detect_and_compute_device", "sfmhip_sift_batch", "sfmhip_device_free", "sfmhip_host_free", "sfmhip_device_download", "sfmhip_ba_destroy",
+    "sfmhip_ba_iterate", "sfmhip_ba_reduced_system", "sfmhip_ba_linearize_obs", "sfmhip_ba_last_timing", "sfmhip_ba_reduced_layout", "sfmhip_ba_reduced_tree", "sfmhip_probe_i8_mfma_peak", "sfmhip_probe_clock_start", "sfmhip_probe_clock_read", "sfmhip_ba_reduced_step", "sfmhip_ba_lm_decide", "sfmhip_score_essential", "sfmhip_score_last_flags", "sfmhip_score_five_point", "sfmhip_score_homography_kernel", "sfmhip_score_homography", "sfmhip_sift_detect_and_compute", "sfmhip_sift_detect_and_compute_device", "sfmhip_sift_batch", "sfmhip_device_free", "sfmhip_host_free", "sfmhip_device_download", "sfmhip_ba_destroy",
 ]
 
 _lib = None

@@ -5546,6 +5546,25 @@ extern "C" int sfmhip_ba_iterate(sfmhip_ba* b, int iters, sfmhip_ba_summary* sum
   return SFMHIP_OK;
 }
 
+// Test hook: one decision of the trust-region loop on the host, by the function the device runs (include/sfmhip.h)
+extern "C" int sfmhip_ba_lm_decide(sfmhip_lm_state* st, const sfmhip_lm_inputs* in) {
+  if (!st || !in) return SFMHIP_ERR_ARG;
+  LmDev s{};
+  s.gtol = st->gradient_tolerance, s.ptol = st->parameter_tolerance, s.ftol = st->function_tolerance;
+  s.min_rel_dec = st->min_relative_decrease, s.max_radius = st->max_radius, s.min_radius = st->min_radius;
+  s.max_invalid = st->max_consecutive_invalid, s.max_iter = st->max_iterations, s.timing_only = st->timing_only;
+  s.radius = st->radius, s.dec_factor = st->decrease_factor, s.cost = st->cost, s.gmax = st->gradient_max_norm, s.x_norm = st->x_norm;
+  s.iter = st->iterations, s.nsucc = st->successful_steps, s.invalid = st->invalid_steps, s.lin_unread = st->lin_unread;
+  s.parity = 0, s.stop = st->stop;
+  LmIn li{in->lin_cost, in->lin_failed_blocks, in->lin_gradient_max, in->candidate_cost, in->model_cost_change, in->step_norm2,
+          in->candidate_norm2, in->solve_info};
+  lm_decide(s, li);
+  st->radius = s.radius, st->decrease_factor = s.dec_factor, st->cost = s.cost, st->gradient_max_norm = s.gmax, st->x_norm = s.x_norm;
+  st->iterations = s.iter, st->successful_steps = s.nsucc, st->invalid_steps = s.invalid, st->lin_unread = s.lin_unread;
+  st->accepted = s.parity, st->stop = s.stop;
+  return SFMHIP_OK;
+}
+
 // Test hook: residual and Jacobian of n observations exactly as the solver's kernels linearise them
 // (cam_table + obs_linearize: the analytic derivative of the branch of AngleAxisRotatePoint that autodiff
 // takes, reference src/BundleAdjustment.cpp:10-35), one thread per observation.
