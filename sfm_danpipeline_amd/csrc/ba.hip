@@ -5418,9 +5418,9 @@ static int ba_lm_loop(sfmhip_ba* b, const sfmhip_ba_opts* o, int iters, const st
     int up = 0;
     if ((rc = time_is_up(&up)) != SFMHIP_OK || up) break;
     // (several ranks: the batch is a function of the iteration count only, so that every rank issues the same all-reduces)
-    // (how far ahead: 4500 it/s with 4 iterations enqueued ahead, 4590 with 12-16; with 32 -- 160 launches outstanding per stream --
+    // (how far ahead: 4500 it/s with 4 iterations enqueued ahead, 4590 with 12-20; with 32 -- 160 launches outstanding per stream --
     // the runtime's enqueue slows down once several streams are alive: 3970 it/s; scripts/gpu_ba_two_problems.py)
-    int B = batch_env ? batch_env : t_only ? 16 : 4;
+    int B = batch_env ? batch_env : t_only ? 20 : 4;
     if (t_only) B = std::min(B, iters - done);
     else B = std::max(1, std::min(B, s.max_iter - s.iter));
     const unsigned seq0 = b->lm_seq, epoch0 = b->tree_epoch;
