@@ -49,9 +49,10 @@ namespace {
 
 constexpr int CAMD = 40;     // doubles per camera table: R[9] t[3] dR/dw[27] pad
 constexpr int SC = 16;       // scalar slots at the tail of the all-reduce buffer (+ world)
-// ba_backsub's four sums land in RED2_SLOTS x 4 slots (workgroup mod RED2_SLOTS) that the host adds up: atomics of
-// many workgroups on ONE address drain at ~44 ns each on this device (1563 workgroups on 4 addresses: 69 us).
-// Layout of red2: [0..8) sums | RED2_SLOTS x 4 slots | RED2_TMP | RED2_INFO (an int) | pad; [0, RED2_SUM_N) is all-reduced.
+// red2, the step evaluation's scalars at the tail of the reduced-system buffer: [0..4) the four totals (candidate cost, model cost
+// change, |step|^2, |candidate|^2) that step_finish leaves -- the sums of the workgroups' slots in BaDev::step_part, added in a
+// fixed order; [0, 8) is what several ranks all-reduce -- | (RED2_SLOTS x 4: the slots round 4's atomics landed in, unused since
+// round 5, kept for the layout) | RED2_TMP | RED2_INFO (an int: the reduced solve's status) | pad.
 constexpr int RED2_SLOTS = 32, RED2_SUM_N = 8 + 4 * RED2_SLOTS, RED2_TMP = RED2_SUM_N, RED2_INFO = RED2_SUM_N + 1,
               RED2_N = RED2_SUM_N + 8;
 constexpr int FB_MAXN = 4096;  // sanity cap on the observations of one point (the pair path has no structural limit)
@@ -94,8 +95,9 @@ struct BaDev {
   // trust-region loop on the device (round 5)
   struct LmDev* lm;   // null: the host decides (radius by kernel argument, the host swaps the parameter sets)
   double* step_part;  // the step evaluation's sums per workgroup, 4 each (candidate cost, model cost change, |step|^2, |candidate|^2),
-                      // then the camera parts (cam_parts x 2: |step|^2, |candidate|^2), added up in a FIXED order by the workgroup that
-                      // arrives last (step_finish): the sums -- hence rho, the radius, the trajectory -- are the same bits every run
+                      // then the camera parts (cam_parts x 2: |step|^2, |candidate|^2), added up in a FIXED order by the finisher -- the
+                      // last workgroup of the step evaluation's last kernel (step_finish): the sums -- hence rho, the radius, the
+                      // trajectory -- are the same bits every run
   int step_total;     // workgroups of the step evaluation's kernels
   int cam_parts;
   int decide_here;    // 1: that last workgroup also takes the LM decision (single rank); 0: ba_decide does, after the all-reduce
