@@ -95,6 +95,12 @@ def build_host_demo(force=False):
     return _build_host_exe(exe, ("Sfm.cpp", "SfmIO.cpp", "BundleAdjustment.cpp", "selftest.cpp"), force)
 
 
+def build_ba_demo(force=False):
+    """BundleAdjustment::adjustBundle on a problem of any size in the reference's containers (tests/test_gpu_host_cpp.py: the
+    write-back-only-on-CONVERGENCE policy at cfg4 size)."""
+    return _build_host_exe(os.path.join(HERE, "sfm_ba_selftest"), ("Sfm.cpp", "SfmIO.cpp", "BundleAdjustment.cpp", "ba_selftest.cpp"), force)
+
+
 def build_io_demo(force=False):
     """The I/O self-test of the host mirror (imagesLOAD / getCameraMatrix / PMVS2).
     Runs without a GPU: the host classes open the device only when a matching / BA call needs it."""

@@ -3,6 +3,7 @@
 #include "BundleAdjustment.h"
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <iostream>
 #include "hip_backend.h"
 #include "sfmhip.h"
@@ -103,6 +104,10 @@ void BundleAdjustment::adjustBundle(std::vector<Point3D>& pointCloud, std::vecto
   }
   sfmhip_ba_opts opts;
   sfmhip_ba_default_opts(&opts);  // DENSE_SCHUR LM, 500 iterations, 10 s
+  // (test switches, never set by the product: the reference's two limits, src/BundleAdjustment.cpp:118,120, made reachable
+  // on problems that converge in milliseconds -- tests/test_gpu_host_cpp.py checks that nothing is written back behind them)
+  if (const char* e = std::getenv("SFM_BA_TEST_MAX_ITERATIONS")) opts.max_iterations = std::atoi(e);
+  if (const char* e = std::getenv("SFM_BA_TEST_MAX_TIME_S")) opts.max_time_s = std::atof(e);
   sfmhip_ba_summary summary;
   const int rc = sfmhip_ba_solve(sfm_hip_context(), n_cam, n_pt, (int)obs_cam.size(), cams6.data(), pts3.data(), &focal,
                                  obs_cam.data(), obs_pt.data(), obs_xy.data(), &opts, &summary);

@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from sfm_danpipeline_amd import build, bundle, synth
+from sfm_danpipeline_amd import _lib, build, bundle, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -56,3 +56,70 @@ def test_native_rccl_allreduce_in_a_cpp_program(tmp_path, ctx):
     assert it == s1.iterations == iters
     assert abs(cost - s1.final_cost) <= 1e-9 * s1.final_cost
     assert np.allclose(cams, c1, rtol=1e-9, atol=1e-12) and abs(focal - f1) <= 1e-9 * f1
+
+
+def _aa_to_R(aa):
+    th = np.linalg.norm(aa)
+    k = aa / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+
+
+def _write_containers(path, pb, cx, cy):
+    nc, npt, no = pb["n_cam"], pb["n_pt"], pb["n_obs"]
+    poses = np.zeros((nc, 3, 4))
+    for i in range(nc):
+        poses[i, :, :3] = _aa_to_R(pb["cams0"][i, :3])
+        poses[i, :, 3] = pb["cams0"][i, 3:]
+    K = np.array([[pb["focal0"], 0, cx], [0, pb["focal0"], cy], [0, 0, 1.0]])
+    with open(path, "wb") as f:
+        f.write(struct.pack("<iii", nc, npt, no))
+        f.write(poses.astype("<f8").tobytes())
+        f.write(pb["pts0"].astype("<f8").tobytes())
+        f.write(K.astype("<f8").tobytes())
+        f.write(np.stack([pb["obs_cam"], pb["obs_pt"]], axis=1).astype("<i4").tobytes())
+        f.write((pb["obs_xy"] + np.array([cx, cy])).astype("<f8").tobytes())
+    return poses, K
+
+
+def _read_containers(path, nc, npt):
+    raw = np.frombuffer(open(path, "rb").read(), "<f8")
+    assert raw.size == 9 + 12 * nc + 3 * npt
+    return raw[:9].reshape(3, 3), raw[9:9 + 12 * nc].reshape(nc, 3, 4), raw[9 + 12 * nc:].reshape(npt, 3)
+
+
+def test_adjust_bundle_writes_back_only_on_convergence_at_cfg4_size(tmp_path, ctx):
+    """BundleAdjustment::adjustBundle in the reference's containers at BASELINE cfg4's size (200 views, 100 000 points, 10^6
+    observations): the policy of src/BundleAdjustment.cpp:118-129.  (1) as shipped -- 500 iterations / 10 s -- the solve converges
+    and K, the poses and the cloud come back adjusted, equal to the C-ABI solve of the same problem; (2) the wall-clock limit
+    reached first => "Bundle adjustment failed." and every container byte for byte as it went in; (3) the iteration limit
+    reached first => the same."""
+    exe = build.build_ba_demo()
+    assert exe and os.path.exists(exe)
+    pb = synth.ba_problem(200, 100000, 10, seed=777)
+    cx, cy = 960.0, 540.0
+    poses0, K0 = _write_containers(tmp_path / "in.bin", pb, cx, cy)
+
+    def run(**env):
+        e = dict(os.environ, **env)
+        r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=600, env=e)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r, _read_containers(tmp_path / "out.bin", 200, 100000)
+
+    r, (K, poses, pts) = run()
+    assert "Bundle adjustment: iterations" in r.stdout and "failed" not in r.stderr
+    c, p, f, s = bundle.ba_solve(pb["cams0"], pb["pts0"], pb["focal0"], pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx,
+                                 opts=bundle.default_opts())
+    assert s.termination == _lib.BA_CONVERGENCE
+    assert int(r.stdout.split("iterations")[1].split(",")[0]) == s.iterations
+    assert K[0, 0] == K[1, 1] and abs(K[0, 0] - f) <= 1e-6 * f and K[0, 0] != K0[0, 0]
+    assert (K[0, 2], K[1, 2], K[2, 2], K[0, 1]) == (cx, cy, 1.0, 0.0)       # only the focal length is a parameter
+    want = np.stack([np.concatenate([_aa_to_R(c[i, :3]), c[i, 3:, None]], axis=1) for i in range(200)])
+    assert np.allclose(poses, want, rtol=1e-6, atol=1e-8) and np.allclose(pts, p, rtol=1e-6, atol=1e-8)
+    c0, c1 = (float(v.split(",")[0]) for v in r.stdout.split("cost")[1].split("->"))
+    assert c1 < 0.1 * c0 and abs(c1 - s.final_cost) <= 1e-5 * c1 and not np.array_equal(pts, pb["pts0"])
+
+    for env in (dict(SFM_BA_TEST_MAX_TIME_S="1e-9"), dict(SFM_BA_TEST_MAX_ITERATIONS="3")):
+        r, (K, poses, pts) = run(**env)
+        assert "Bundle adjustment failed." in r.stderr, (env, r.stdout, r.stderr)
+        assert K.tobytes() == K0.tobytes() and poses.tobytes() == poses0.tobytes() and pts.tobytes() == pb["pts0"].tobytes(), env
