@@ -13,8 +13,8 @@ pb = synth.ba_problem(200, 100000, 10, seed=777)
 probs = {}
 for v in variants:
     fill0, shape = v.startswith("f0:"), v[3:] if v.startswith("f0:") else v
-    if shape.startswith("s3:"):                      # three resident workgroups per CU (a build with <= 168 VGPRs)
-        os.environ["SFMHIP_BA_ELIM_SLOTS"], shape = "3", shape[3:]
+    if shape[:1] == "s" and shape[2:3] == ":":       # "sN:": N resident workgroups per CU for the slot-filling cut
+        os.environ["SFMHIP_BA_ELIM_SLOTS"], shape = shape[1], shape[3:]
     else:
         os.environ.pop("SFMHIP_BA_ELIM_SLOTS", None)
     os.environ["SFMHIP_BA_ELIM_FILL"] = "0" if fill0 else "1"

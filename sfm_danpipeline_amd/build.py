@@ -63,29 +63,30 @@ def build(force=False, verbose=False):
     return SO
 
 
+def build_ba_variant(name, defines, force=False):
+    """libsfmhip_<name>.so: the library with ba.hip compiled under extra -D switches, every other object shared with the product
+    build (diagnostic and A/B builds: loaded through SFMHIP_SO, never by the product)."""
+    build()
+    objdir = os.path.join(HERE, "build")
+    so = os.path.join(HERE, f"libsfmhip_{name}.so")
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
+    if not force and os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(d) for d in deps):
+        return so
+    obj = os.path.join(objdir, f"ba_{name}.o")
+    subprocess.check_call([_hipcc()] + FLAGS + [f"-ffp-contract={SOURCES['ba.hip']}"] + list(defines) +
+                          ["-c", os.path.join(CSRC, "ba.hip"), "-o", obj])
+    objs = [os.path.join(objdir, n.replace(".hip", ".o")) for n in SOURCES if n != "ba.hip"] + [obj]
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs)
+    return so
+
+
 def build_timeout_diag(force=False):
     """Two diagnostic builds of the library in which one hand-off never arrives (test infrastructure: tests/test_gpu_geometry.py
     checks what the solver reports then; loaded through SFMHIP_SO, never by the product): libsfmhip_dbg_breakfront.so -- a child
     front of the tree never raises its flag in the one-launch form (-DSFM_FRONT_BREAK_HANDOFF) -- and libsfmhip_dbg_breakchol.so --
     an LDS hand-off inside chol_step2 never arrives (-DSFM_CHOL_BREAK_HANDOFF)."""
-    build()
-    objdir = os.path.join(HERE, "build")
-    out, procs = [], []
-    for name, define in (("breakfront", "-DSFM_FRONT_BREAK_HANDOFF"), ("breakchol", "-DSFM_CHOL_BREAK_HANDOFF")):
-        so = os.path.join(HERE, f"libsfmhip_dbg_{name}.so")
-        out.append(so)
-        deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
-        if not force and os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(d) for d in deps):
-            continue
-        obj = os.path.join(objdir, f"ba_{name}.o")
-        cmd = [_hipcc()] + FLAGS + [f"-ffp-contract={SOURCES['ba.hip']}", define, "-c", os.path.join(CSRC, "ba.hip"), "-o", obj]
-        procs.append((so, obj, cmd, subprocess.Popen(cmd)))
-    for so, obj, cmd, p in procs:
-        if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, cmd)
-        objs = [os.path.join(objdir, n.replace(".hip", ".o")) for n in SOURCES if n != "ba.hip"] + [obj]
-        subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs)
-    return out
+    return [build_ba_variant("dbg_breakfront", ["-DSFM_FRONT_BREAK_HANDOFF"], force),
+            build_ba_variant("dbg_breakchol", ["-DSFM_CHOL_BREAK_HANDOFF"], force)]
 
 
 def build_host_demo(force=False):

@@ -550,6 +550,23 @@ __global__ void ba_make_scale(BaDev d, int jacobi) {
 // diagnostic build only (scripts/elim_stamps.py): s_memtime at the phase boundaries of workgroup 0 / wave 0
 __device__ unsigned long long g_elim_stamps[32];
 __device__ unsigned long long g_elim_dump[32];
+// per workgroup of the last launch: {s_memtime at its start, at its end, s_memrealtime (100 MHz) at its start, at its end, XCC/CU id}
+__device__ unsigned long long g_elim_wg[2048 * 5];
+#define SFM_ELIM_WG_RECORDS 1
+#define EL_WG(slot)                                                                                  \
+  do {                                                                                               \
+    if (tid == 0 && blockIdx.x < 2048) {                                                             \
+      unsigned long long t_, r_;                                                                     \
+      asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory"); \
+      g_elim_wg[5 * blockIdx.x + slot] = t_;                                                         \
+      g_elim_wg[5 * blockIdx.x + 2 + slot] = r_;                                                     \
+      if (slot == 0) {                                                                               \
+        unsigned id_, xcc_;                                                                          \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(id_), "=s"(xcc_)); \
+        g_elim_wg[5 * blockIdx.x + 4] = ((unsigned long long)xcc_ << 32) | id_;                      \
+      }                                                                                              \
+    }                                                                                                \
+  } while (0)
 #define EL_STAMP(slot, cond)                                                         \
   do {                                                                               \
     unsigned long long t_;                                                           \
@@ -565,6 +582,7 @@ __device__ unsigned long long g_elim_dump[32];
 #else
 #define EL_STAMP(slot, cond)
 #define EL_STAMPW(slot)
+#define EL_WG(slot)
 #endif
 // a chunk's slab: [Gram block, MFMA layout, NT x 256 <= 2560 | F^T F sums 36 x FP | Jf^2, Jf r, r^2 | gmax | nfail]
 constexpr int ELIM_SLAB_FF = 2560, ELIM_SLAB = 2944;
@@ -597,6 +615,7 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
   const int nw = blockDim.x >> 6;  // 4 waves for long runs, 1 for runs of a few points (unstructured visibility)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   EL_STAMP(0, true);
+  EL_WG(0);
   const Chunk ch = chunks[chunk_index];
   const int n = ch.n;
   const int* cams = sig_cams + ch.sig_off;
@@ -644,12 +663,12 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
   const lds_double* cam_lds = (const lds_double*)s_cam + oc;
   const int frow = lane >> 4, fcol = lane & 15;
   // F^T F part of a camera slot (the 6x6 block (upper, 21), the focal border (6), F^T b (6), Jf^2, Jf r, r^2 --
-  // what ba_cam_blocks formed from a second linearisation) is accumulated in LDS, ds_add_f64 by the slot's four point
-  // lanes: as registers the 36 sums cost the 72 VGPRs that keep the loop from spilling and from prefetching
+  // what ba_cam_blocks formed from a second linearisation) meets in LDS, ds_add_f64 by the slot's four point lanes -- per
+  // iteration for the sums that have no register (below), once behind the loop for those that have
   lds_double* ffw = (lds_double*)s_M + wave * (36 * FP) + oc;
   // point data of the next iteration is loaded one iteration ahead (a lone wave per SIMD otherwise waits a global
   // round trip per iteration)
-  double nX[3], nsp[3] = {1.0, 1.0, 1.0}, nisp[3] = {1.0, 1.0, 1.0};
+  double nX[3];
   double2 nxy;
   auto fetch = [&](int quad_) {
     const int pi_ = 4 * quad_ + q;
@@ -658,16 +677,23 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
     nX[0] = d.pts[3 * p_];
     nX[1] = d.pts[3 * p_ + 1];
     nX[2] = d.pts[3 * p_ + 2];
-    if (!norms) {
-      nsp[0] = d.scale_p[3 * p_];
-      nsp[1] = d.scale_p[3 * p_ + 1];
-      nsp[2] = d.scale_p[3 * p_ + 2];
-      nisp[0] = d.iscale_p[3 * p_];
-      nisp[1] = d.iscale_p[3 * p_ + 1];
-      nisp[2] = d.iscale_p[3 * p_ + 2];
-    }
     nxy = d.oxy[kobs0 + pl_ * n + oc];
   };
+  // The first FFREG of the 36 F^T F sums of the lane's camera slot are registers of the lane, added to the LDS cells once,
+  // behind the loop (round 5).  The kernel lasts as long as its longest piece takes ALONE -- the older workgroup of a compute
+  // unit runs at the pace of its own dependent chain, the younger one fills the gaps (scripts/elim_stamps.py) -- and 35
+  // ds_add_f64 per iteration, four lanes to a cell, were 1.5 k of an iteration's 8.9 k cycles of that chain: every sum moved
+  // to a register took 0.2 us off the launch (73.3 us with none, 71.9 / 69.7 / 68.7 with 8 / 14 / 21, 66.5 with 29).  As many
+  // as fit beside the Gram accumulators without spilling: 29 with ten tiles (256 registers, two waves per SIMD either way),
+  // all 36 with six tiles or fewer.
+#ifdef SFM_ELIM_FFREG
+  constexpr int FFREG = SFM_ELIM_FFREG;  // (measurement builds)
+#else
+  constexpr int FFREG = NB == 4 ? 29 : 36;
+#endif
+  double ffr[FFREG > 0 ? FFREG : 1];
+#pragma unroll
+  for (int e = 0; e < FFREG; ++e) ffr[e] = 0.0;
   fetch(wave);
   EL_STAMP(2, true);
   EL_STAMPW(24 + (wave & 3));
@@ -680,12 +706,21 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
     const int pi = 4 * quad + q;
     const bool pv = pi < ch.cnt;
     const double X[3] = {nX[0], nX[1], nX[2]};
-    const double sp[3] = {nsp[0], nsp[1], nsp[2]};
-    const double isp[3] = {nisp[0], nisp[1], nisp[2]};
+    // (the point's column scale and its inverse are not needed before the F^T F sums are through -- the scale goes onto Jp with
+    // the mask below --, so they are loaded here and not an iteration ahead with the point: twelve registers for F^T F sums)
+    double sp[3] = {1.0, 1.0, 1.0}, isp[3] = {1.0, 1.0, 1.0};
+    if (!norms) {
+      const int p_ = ch.p0 + (pv ? pi : ch.cnt - 1);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        sp[a] = d.scale_p[3 * p_ + a];
+        isp[a] = d.iscale_p[3 * p_ + a];
+      }
+    }
     const double2 xy = nxy;
     if (4 * (quad + nw) < ch.cnt) fetch(quad + nw);
     ObsLin ol;
-    obs_linearize_g<CamLds, const double*, true>(cd, X, focal, xy.x, xy.y, sc, sp, sf, ol);
+    obs_linearize_g<CamLds, const double*, true>(cd, X, focal, xy.x, xy.y, sc, (const double*)nullptr, sf, ol);
     EL_STAMP(9, quad == wave + 2 * nw);
     const double live = (pv && valid_o) ? 1.0 : 0.0;
     if (pv && valid_o) {
@@ -693,37 +728,50 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
       auto ff_add = [&](int e, double v) {
         __hip_atomic_fetch_add(ffw + e * FP, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       };
+      // one product / the sum of two products into sum e: a register of the lane while they last, else the LDS cell
+      auto ff1 = [&](int e, double a, double c) {
+        if (e < FFREG) ffr[e < FFREG ? e : 0] = fma(a, c, ffr[e < FFREG ? e : 0]);
+        else ff_add(e, a * c);
+      };
+      auto ff2 = [&](int e, double a, double c, double a2, double c2) {
+        if (e < FFREG) ffr[e < FFREG ? e : 0] = fma(a, c, fma(a2, c2, ffr[e < FFREG ? e : 0]));
+        else ff_add(e, fma(a, c, a2 * c2));
+      };
       int e = 0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
 #pragma unroll
         for (int j = i; j < 6; ++j, ++e) {
           const bool a0 = i != 4 && j != 4, a1 = i != 3 && j != 3;
-          if (a0 && a1) ff_add(e, fma(ol.Jc[i], ol.Jc[j], ol.Jc[6 + i] * ol.Jc[6 + j]));
-          else if (a0) ff_add(e, ol.Jc[i] * ol.Jc[j]);
-          else if (a1) ff_add(e, ol.Jc[6 + i] * ol.Jc[6 + j]);
+          if (a0 && a1) ff2(e, ol.Jc[i], ol.Jc[j], ol.Jc[6 + i], ol.Jc[6 + j]);
+          else if (a0) ff1(e, ol.Jc[i], ol.Jc[j]);
+          else if (a1) ff1(e, ol.Jc[6 + i], ol.Jc[6 + j]);
         }
         if (i == 4) {
-          ff_add(21 + i, ol.Jc[6 + i] * ol.Jf[1]);
-          ff_add(27 + i, ol.Jc[6 + i] * ol.r1);
+          ff1(21 + i, ol.Jc[6 + i], ol.Jf[1]);
+          ff1(27 + i, ol.Jc[6 + i], ol.r1);
         } else if (i == 3) {
-          ff_add(21 + i, ol.Jc[i] * ol.Jf[0]);
-          ff_add(27 + i, ol.Jc[i] * ol.r0);
+          ff1(21 + i, ol.Jc[i], ol.Jf[0]);
+          ff1(27 + i, ol.Jc[i], ol.r0);
         } else {
-          ff_add(21 + i, fma(ol.Jc[i], ol.Jf[0], ol.Jc[6 + i] * ol.Jf[1]));
-          ff_add(27 + i, fma(ol.Jc[i], ol.r0, ol.Jc[6 + i] * ol.r1));
+          ff2(21 + i, ol.Jc[i], ol.Jf[0], ol.Jc[6 + i], ol.Jf[1]);
+          ff2(27 + i, ol.Jc[i], ol.r0, ol.Jc[6 + i], ol.r1);
         }
       }
-      ff_add(33, fma(ol.Jf[0], ol.Jf[0], ol.Jf[1] * ol.Jf[1]));
-      ff_add(34, fma(ol.Jf[0], ol.r0, ol.Jf[1] * ol.r1));
-      ff_add(35, fma(ol.r0, ol.r0, ol.r1 * ol.r1));
+      ff2(33, ol.Jf[0], ol.Jf[0], ol.Jf[1], ol.Jf[1]);
+      ff2(34, ol.Jf[0], ol.r0, ol.Jf[1], ol.r1);
+      ff2(35, ol.r0, ol.r0, ol.r1, ol.r1);
     }
     EL_STAMP(10, quad == wave + 2 * nw);
     // point block C = sum Jp^T Jp (lower: 00 10 11 20 21 22), gp = Jp^T r, wf = Jp^T Jf.  Idle lanes (no such
     // observation, or no such point in the last quad) carry Jp = 0: every product below -- the sums, W = Jc^T Jp, the
-    // panel rows -- has Jp as a factor, so six multiplications mask them all
+    // panel rows -- has Jp as a factor, so six multiplications mask them all (and carry the point's column scale)
 #pragma unroll
-    for (int a = 0; a < 6; ++a) ol.Jp[a] *= live;
+    for (int a = 0; a < 3; ++a) {
+      const double ls = live * sp[a];
+      ol.Jp[a] *= ls;
+      ol.Jp[3 + a] *= ls;
+    }
     double red[12];
     red[0] = ol.Jp[0] * ol.Jp[0] + ol.Jp[3] * ol.Jp[3];
     red[1] = ol.Jp[1] * ol.Jp[0] + ol.Jp[4] * ol.Jp[3];
@@ -796,6 +844,11 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
   }
   EL_STAMP(3, true);
   EL_STAMPW(20 + (wave & 7));
+  if (valid_o) {
+#pragma unroll
+    for (int e = 0; e < FFREG; ++e)
+      __hip_atomic_fetch_add(ffw + e * FP, ffr[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
 
   // ---- epilogue.  Only LDS traffic between the barriers (a barrier waits for the wave's outstanding global
   // atomics: ~2 us each), every global atomic in the last phase:
@@ -906,6 +959,11 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
       my[ELIM_SLAB_FF + 36 * FP + 5] = norms ? 0.0 : s_G[g_slot(6 * n, 6 * n)];
       my[ELIM_SLAB_FF + 36 * FP + 6] = norms ? 0.0 : s_G[g_slot(6 * n, 6 * n + 1)];
     }
+    EL_STAMP(6, true);
+    EL_WG(1);
+#ifdef SFM_ELIM_WG_RECORDS
+    if (tid == 0 && blockIdx.x < 2048) g_elim_wg[5 * blockIdx.x + 4] |= (unsigned long long)ch.cnt << 48;
+#endif
     return;
   }
   double* scv = red_sc(d);
@@ -3552,6 +3610,9 @@ extern "C" int sfmhip_debug_down_stamps(unsigned long long* out, int n_fronts) {
 #ifdef SFM_ELIM_STAMPS
 extern "C" int sfmhip_debug_elim_stamps(unsigned long long* out32) {
   return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_elim_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -2;
+}
+extern "C" int sfmhip_debug_elim_wg(unsigned long long* out) {  // 2048 x 5
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_elim_wg), sizeof(unsigned long long) * 2048 * 5) == hipSuccess ? 0 : -2;
 }
 #endif
 #ifdef SFM_CHOL_STAMPS

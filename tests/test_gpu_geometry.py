@@ -762,11 +762,23 @@ def test_device_loop_equals_host_loop(ctx, monkeypatch, shape):
 
 def test_device_loop_takes_every_exit_the_host_loop_takes(ctx, monkeypatch, orc):
     """Every termination path of the loop, device against host (bits) and against the oracle (counts): the iteration limit at
-    1 ... 9 (between accepted and rejected steps, i.e. with and without an unread linearisation behind the last step), the
+    1 ... 12 (between accepted and rejected steps, i.e. with and without an unread linearisation behind the last step), the
     function, parameter and gradient tolerances, the radius floor, invalid steps until FAILURE."""
     pb = synth.ba_problem(11, 600, 5, seed=11)
     args = _ba_args(pb)
-    cases = [dict(max_iterations=n, function_tolerance=0.0, parameter_tolerance=0.0) for n in range(1, 10)]
+    # the iteration limit on a start far enough from the optimum, under a radius large enough, that LM REJECTS steps for real
+    # (oracle: iterations 1-3 accepted, 4-10 rejected at rho = -0.83 -- the cost nearly doubles --, 11-12 accepted): a limit that
+    # falls on a solve already converged to the last bit compares rounding, not loops (the candidate cost equal to the cost to the
+    # last bit is "function tolerance reached" even at tolerance 0, Ceres 1.13 trust_region_minimizer.cc, FunctionToleranceReached)
+    far = _ba_args(synth.ba_problem(11, 600, 5, seed=13, pt_sigma=1.5, cam_sigma=0.4, focal_factor=1.0))
+    for n in range(1, 13):
+        kw = dict(max_iterations=n, function_tolerance=0.0, parameter_tolerance=0.0, initial_radius=1e10)
+        dev, host = _solve_both_loops(monkeypatch, ctx, far, max_time_s=0.0, **kw)
+        _same_bits(dev, host)
+        so = orc.ba_solve(*far, opts=orc.default_opts(max_time_s=0.0, **kw))[3]
+        assert (dev[3].termination, dev[3].iterations, dev[3].successful_steps) == (so.termination, so.iterations, so.successful_steps), kw
+        assert so.termination == _lib.BA_NO_CONVERGENCE and so.iterations == n and so.successful_steps == (n if n < 4 else 3 if n < 11 else n - 7)
+    cases = [dict(max_iterations=n, function_tolerance=0.0, parameter_tolerance=0.0) for n in range(1, 5)]
     cases += [dict(function_tolerance=1e-2), dict(parameter_tolerance=1e-3, function_tolerance=0.0),
               dict(gradient_tolerance=1e3, function_tolerance=0.0, parameter_tolerance=0.0),
               dict(gradient_tolerance=1e9),                       # (met at x0: no iteration at all)
