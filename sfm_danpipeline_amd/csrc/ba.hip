@@ -871,6 +871,35 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
   }
   __syncthreads();
   EL_STAMP(15, true);
+  if (nw == 4) {
+    // Four waves: every wave stores its tiles, five at a time, in a buffer of its own, and every thread adds the four copies of
+    // its entries -- ((w0 + w1) + w2) + w3, the bits the waves' additions one after the other gave -- into registers; two passes
+    // for ten tiles, then the sums go to s_G.  (Round 5: the sequential form, wave 0 stores | wave 1 adds | wave 2 adds | wave 3
+    // adds, was 6.3 k cycles at the END of the longest piece, which is what the launch waits for.)
+    constexpr int TP = NT < 5 ? NT : 5;
+    lds_double* buf = (lds_double*)s_P;
+    double r[NT];
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += TP) {
+#pragma unroll
+      for (int t = t0; t < NT && t < t0 + TP; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) buf[wave * (TP * 256) + ((t - t0) * 4 + g) * 64 + lane] = acc[t][g];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < TP && t0 + j < NT; ++j) {
+        const int k = j * 256 + tid;
+        r[t0 + j] = ((buf[k] + buf[TP * 256 + k]) + buf[2 * TP * 256 + k]) + buf[3 * TP * 256 + k];
+      }
+      __syncthreads();
+    }
+    if (!norms) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) s_G[j * 256 + tid] = r[j];
+    }
+    __syncthreads();
+    EL_STAMP(16, true);
+  } else {
   if (wave == 0 && !norms) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -879,7 +908,9 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
   }
   __syncthreads();
   EL_STAMP(16, true);
-  if (slab && !norms) {
+  }
+  if (nw == 4) {
+  } else if (slab && !norms) {
     // (deterministic mode: the waves add their tiles one after the other -- the order they arrive in is not fixed)
     for (int w = 1; w < nw; ++w) {
       if (wave == w) {
@@ -4399,7 +4430,9 @@ static int ba_launch_eliminate(sfmhip_ba* b, double inv_radius, double lm_lo, do
     if (!b->n_chunk_ids[li]) continue;                                                                                \
     /* wave panels | the cross-wave Gram reduction (NT x 4 x 64) | the F^T F reduction */                             \
     const size_t nw_ = nthreads / 64, gram_ = (size_t)(NB * (NB + 1) / 2) * 256;                                      \
-    const size_t lds = sizeof(double) * (nw_ * 36 * FP + 3 * FP + std::max(nw_ * 12 * MP, gram_));                            \
+    /* (four waves: the cross-wave sum takes four buffers of up to five tiles) */                                      \
+    const size_t red_ = nw_ == 4 ? (size_t)4 * std::min(NB * (NB + 1) / 2, 5) * 256 : 0;                              \
+    const size_t lds = sizeof(double) * (nw_ * 36 * FP + 3 * FP + std::max(std::max(nw_ * 12 * MP, gram_), red_));    \
     hipLaunchKernelGGL((ba_eliminate_mfma<NB>), dim3(b->n_chunk_ids[li]), dim3(nthreads), lds, st, b->d,              \
                        b->d_chunks, b->d_chunk_ids[li],                                                               \
                        b->d_sig_cams, inv_radius, lm_lo, lm_hi, b->rank, norms, slab);                                \
