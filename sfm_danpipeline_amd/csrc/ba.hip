@@ -683,7 +683,8 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
   // behind the loop (round 5).  The kernel lasts as long as its longest piece takes ALONE -- the older workgroup of a compute
   // unit runs at the pace of its own dependent chain, the younger one fills the gaps (scripts/elim_stamps.py) -- and 35
   // ds_add_f64 per iteration, four lanes to a cell, were 1.5 k of an iteration's 8.9 k cycles of that chain: every sum moved
-  // to a register took 0.2 us off the launch (73.3 us with none, 71.9 / 69.7 / 68.7 with 8 / 14 / 21, 66.5 with 29).  As many
+  // to a register took 0.2 us off the launch (73.3 us with none, 71.9 / 69.7 / 68.7 with 8 / 14 / 21, 66.5 with 29 -- averages
+  // that include iterations past the solve's convergence; 73.9 -> 68.4 us on a solve that still moves).  As many
   // as fit beside the Gram accumulators without spilling: 29 with ten tiles (256 registers, two waves per SIMD either way),
   // all 36 with six tiles or fewer.
 #ifdef SFM_ELIM_FFREG
