@@ -723,6 +723,9 @@ def main():
                        "pairs_per_gpu": int(len(pairs)), "matches_found": total_matches,
                        "ba_points_per_gpu": int(n_pt_l), "ba_obs_per_gpu": int(n_obs_l),
                        "ba_cost": [ba_sum.initial_cost, ba_sum.final_cost],
+                       # (hand-offs of the front tree that ran out of their spin budget in the timed iterations and were repeated
+                       # level by level -- a loaded device; 0 in every run measured: a line with another value timed something else)
+                       "ba_spin_timeouts": int(ba_sum.spin_timeouts),
                        "match_streams": N_STREAMS, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "parallelism": f"pairs x{world} (weak" + (f"; consecutive batches alternate between {N_STREAMS} HIP "
                                       "streams per GPU" if N_STREAMS > 1 else "") + f"), BA points/{world} + all-reduce"},
