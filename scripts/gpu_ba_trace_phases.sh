@@ -26,6 +26,7 @@ def phase(lo, hi, label):
     print(f"{label}: {len(tot)} iterations, mean {sum(tot) / len(tot) / 1e3:.1f} us from one elimination's start to the next")
     for n in dur:
         print(f"   {n[:28]:28s} x{len(dur[n]) / len(tot):4.1f}  {sum(dur[n]) / len(dur[n]) / 1e3:7.1f} us   gap before {sum(gap[n]) / len(gap[n]) / 1e3:5.1f} us")
+phase(4, 20, "early (iterations 5-20)")
 phase(24, 40, "moving solve (iterations 25-40)")
 phase(120, 200, "past convergence, radius 0 (iterations 121-200)")
 PY
