@@ -307,18 +307,19 @@ def main():
     # iterations, and sfmhip_ba_iterate (no stopping rule) past that point iterates on rejected steps with a radius that halves,
     # quarters, ... down to 0 -- infinities in the damping, kernels that run 3-4 % faster than on real numbers
     # (scripts/gpu_ba_radius_probe.py, round 5).  So every BA region of this file starts from the start: ba_restart() resets the
-    # parameters and takes the first W + 20 iterations untimed, the K timed ones follow (iterations 22 .. 41 at the defaults).
+    # parameters and takes the first W + 20 iterations untimed, the K timed ones follow (iterations 24 .. 43 at the defaults; config.ba_timed_iterations on the line).
     def ba_restart(p=None, start=None):
         p = ba if p is None else p
         c0_, p0_, f0_ = (pb["cams0"], loc["pts"], pb["focal0"]) if start is None else start
         p.set_params(c0_, p0_, f0_)
-        p.iterate(max(args.warmup, 1) + 20)
-    ba_restart()
+        return p.iterate(max(args.warmup, 1) + 20)
+    ba_pre = ba_restart()
     barrier()
     t0 = time.perf_counter()
     ba_sum = ba.iterate(args.steps)
     barrier()
     t_ba = time.perf_counter() - t0
+    ba_accepted_timed = int(ba_sum.successful_steps - ba_pre.successful_steps)   # (on the line: the timed iterations moved the solve)
     # per-stage device time: the same iterations once more with stage timing on, outside the
     # timed region (the library accumulates since the run began, hence the difference)
     ba_restart()
@@ -726,6 +727,8 @@ def main():
                        # (hand-offs of the front tree that ran out of their spin budget in the timed iterations and were repeated
                        # level by level -- a loaded device; 0 in every run measured: a line with another value timed something else)
                        "ba_spin_timeouts": int(ba_sum.spin_timeouts),
+                       "ba_timed_iterations": [int(ba_pre.iterations) + 1, int(ba_sum.iterations)],
+                       "ba_steps_accepted_in_timed_iterations": ba_accepted_timed,
                        "match_streams": N_STREAMS, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "parallelism": f"pairs x{world} (weak" + (f"; consecutive batches alternate between {N_STREAMS} HIP "
                                       "streams per GPU" if N_STREAMS > 1 else "") + f"), BA points/{world} + all-reduce"},
