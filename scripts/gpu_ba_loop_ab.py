@@ -23,6 +23,10 @@ for rep in range(7):
 print("RESULT", min(r) * 1e3, float(np.median(r)) * 1e3, s.iterations, s.successful_steps, repr(s.final_cost))
 ''' % ROOT
 variants = [("device-loop", {}), ("host-loop", {"SFMHIP_BA_HOST_LOOP": "1"})]
+# EXTRA_VARIANT="name:VAR=value[,VAR=value]": one more variant of THIS build under an environment
+if os.environ.get("EXTRA_VARIANT"):
+    nm, kv = os.environ["EXTRA_VARIANT"].split(":", 1)
+    variants.append((nm, dict(x.split("=", 1) for x in kv.split(","))))
 base = os.path.join(ROOT, "sfm_danpipeline_amd", "libsfmhip_dbg_base.so")
 if os.path.exists(base):
     variants.append(("base-revision", {"SFMHIP_SO": base}))
