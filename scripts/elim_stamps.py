@@ -26,7 +26,7 @@ if __name__ == "__main__":
     pb = synth.ba_problem(200, 100000, 10, seed=777)
     prob = bundle.BaProblem(200, 100000, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
     prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
-    prob.iterate(3)
+    prob.iterate(int(os.environ.get("ELIM_STAMPS_ITERS", "3")))   # (3: the solve still moves; 150: long past convergence, radius 0)
     ctx.synchronize()
     out = (C.c_ulonglong * 32)()
     L = C.CDLL(SO)
