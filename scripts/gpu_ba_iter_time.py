@@ -1,5 +1,8 @@
 """Ad-hoc GPU check (run through gpurun): 20 LM iterations at three problem sizes, cost trajectory
-and per-phase timing (the reduced solve is solve_s) -- the quick A/B while working on chol_step2."""
+and per-phase timing (the reduced solve is solve_s) -- the quick A/B while working on chol_step2.
+(NOTE, late round 5: this script iterates ONE solve far past its convergence -- rejected steps, the radius collapsing to 0:
+scripts/gpu_ba_radius_probe.py -- so its rates compare builds and shapes like with like but run 3-4 % above an LM iteration's;
+scripts/gpu_ba_loop_ab.py and bench.py time iterations of a solve that still moves.)"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

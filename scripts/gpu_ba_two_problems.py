@@ -1,6 +1,9 @@
 """Ad-hoc GPU measurement: two independent cfg4 problems iterated concurrently (a context + stream + host thread each)
 against one -- the reduced solve of an LM iteration is latency-bound on a handful of CUs, so a second problem's
-elimination fits beside it."""
+elimination fits beside it.
+(NOTE, late round 5: this script iterates ONE solve far past its convergence -- rejected steps, the radius collapsing to 0:
+scripts/gpu_ba_radius_probe.py -- so its rates compare builds and shapes like with like but run 3-4 % above an LM iteration's;
+scripts/gpu_ba_loop_ab.py and bench.py time iterations of a solve that still moves.)"""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
