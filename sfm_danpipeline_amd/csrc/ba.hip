@@ -628,6 +628,10 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
     if (!norms && e >= 12 && e < 39) v *= d.scale_c[6 * cams[o] + (e - 12) / 9];
     s_cam[e * 16 + o] = v;
   }
+  // slot 15 (a signature has at most ten cameras): R = 0, t = (0, 0, 1), no derivatives -- what the lanes WITHOUT an observation
+  // linearise instead of shadowing observation 0: constants in, constants out, no switching.  The launch runs at the clock the
+  // power limit leaves it (2.1 GHz on a moving solve, 2.34 on zeros: scripts/elim_stamps.py): 69.1 -> 68.4 us (round 5).
+  if (tid < CAMD) s_cam[tid * 16 + 15] = tid == 11 ? 1.0 : 0.0;
   // dynamic LDS: the F^T F accumulators [wave][e][slot] (nw x 36 x 16) + [3][16] | the waves' panels, later the
   // cross-wave reduction and the staged Gram block
   const int ff_sz = nw * 36 * FP + 3 * FP;
@@ -642,7 +646,7 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
   }
   const int o = lane & 15, q = lane >> 4;
   const bool valid_o = o < n;
-  const int oc = valid_o ? o : 0;  // idle lanes shadow observation 0 (finite data), masked out below
+  const int oc = valid_o ? o : 0;  // idle lanes take observation 0's addresses (finite data) and slot 15's camera table (above); masked out below
   double sc[6];
   {
     const int cam = cams[oc];
@@ -660,7 +664,7 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
   double gmax = 0.0;
   int nfail = 0;
   double* Mw = s_P + wave * (12 * MP);
-  const lds_double* cam_lds = (const lds_double*)s_cam + oc;
+  const lds_double* cam_lds = (const lds_double*)s_cam + (valid_o ? o : 15);
   const int frow = lane >> 4, fcol = lane & 15;
   // F^T F part of a camera slot (the 6x6 block (upper, 21), the focal border (6), F^T b (6), Jf^2, Jf r, r^2 --
   // what ba_cam_blocks formed from a second linearisation) meets in LDS, ds_add_f64 by the slot's four point lanes -- per
