@@ -102,6 +102,11 @@ def main():
     ap.add_argument("--lean", action="store_true",
                     help="timed regions and per-kernel samples only (no sustained / host-visible loops, no cfg5, no CPU "
                          "baseline): the command to run under rocprofv3, whose traces grow with every dispatch")
+    ap.add_argument("--cfg5-sample", type=int, default=0,
+                    help="with --lean: also sweep this many pairs of BASELINE cfg5 (evenly spaced over the 124 750, checksums asserted "
+                         "against tests/golden/cfg5_checksums.npz) so that a profile of the command holds knn_keyed_kernel rows")
+    ap.add_argument("--no-adjust-bundle", action="store_true", help="skip the whole-call leg (BundleAdjustment::adjustBundle through "
+                                                                     "the C++ mirror, a subprocess)")
     ap.add_argument("--sustain-s", type=float, default=2.0, help="seconds of the sustained loops")
     ap.add_argument("--match-streams", type=int, default=2, choices=(1, 2),
                     help="2 (default): consecutive batches alternate between two resident buffers on two HIP streams -- the "
@@ -109,7 +114,7 @@ def main():
                          "pairs/s); the roofline's launch_ms is sampled from single-stream steps either way.  1: one stream")
     args = ap.parse_args()
     if args.lean:
-        args.no_cfg5 = args.no_cpu_baseline = args.no_score = True
+        args.no_cfg5 = args.no_cpu_baseline = args.no_score = args.no_adjust_bundle = True
 
     # `python bench.py --gpus N` on its own (no WORLD_SIZE in the environment): this process becomes the launcher -- before
     # anything here has touched a GPU, and without replacing itself -- of N ranks under torch.distributed.run, relays
@@ -307,12 +312,15 @@ def main():
     # iterations, and sfmhip_ba_iterate (no stopping rule) past that point iterates on rejected steps with a radius that halves,
     # quarters, ... down to 0 -- infinities in the damping, kernels that run 3-4 % faster than on real numbers
     # (scripts/gpu_ba_radius_probe.py, round 5).  So every BA region of this file starts from the start: ba_restart() resets the
-    # parameters and takes the first W + 20 iterations untimed, the K timed ones follow (iterations 24 .. 43 at the defaults; config.ba_timed_iterations on the line).
+    # parameters and takes the first 15 iterations untimed, the K timed ones follow: iterations 16 .. 35 at the default K, independent of
+    # --warmup (round 5's window moved with it: 24 .. 43 at --warmup 3, 26 .. 45 at the driver's 5, the last of them at / past
+    # convergence); config.ba_timed_iterations on the line.
+    BA_PRE = 15      # LM iterations of a fresh solve taken untimed: the K timed ones are iterations 16 .. 15 + K whatever --warmup is
     def ba_restart(p=None, start=None):
         p = ba if p is None else p
         c0_, p0_, f0_ = (pb["cams0"], loc["pts"], pb["focal0"]) if start is None else start
         p.set_params(c0_, p0_, f0_)
-        return p.iterate(max(args.warmup, 1) + 20)
+        return p.iterate(BA_PRE)
     ba_pre = ba_restart()
     barrier()
     t0 = time.perf_counter()
@@ -339,7 +347,7 @@ def main():
         t_ba_agreed = float(tt[0])
     # (a batch = restart + the K timed iterations; the restarts keep the device as busy as the timed part does, only the K
     # iterations behind each count)
-    t_batch = (2 * args.steps + max(args.warmup, 1) + 20) * t_ba_agreed / args.steps
+    t_batch = (2 * args.steps + BA_PRE) * t_ba_agreed / args.steps
     n_batches = 0 if args.lean else max(1, int(np.ceil(args.sustain_s / max(t_batch, 1e-6))))
     t_sus_ba = 0.0
     for _ in range(n_batches):
@@ -350,6 +358,28 @@ def main():
         barrier()
         t_sus_ba += time.perf_counter() - t0
     sustained_ba_its = args.steps * n_batches / max(t_sus_ba, 1e-9)
+
+    # ------------------------------------------------------------------ what of the iteration shards, measured at 1/2, 1/4, 1/8
+    # of the points: rank 0's point block of a world of 2 / 4 / 8 as a problem of its own on this GPU (the same cameras, hence the
+    # same reduced system's size and front tree): its eliminate + back-substitute stage times over the same iterations -- what
+    # `sharded_ms / N` only extrapolates (does ba_eliminate_mfma still fill 256 CUs with an eighth of the pieces?)
+    shard_ms = {}
+    if world == 1 and not args.lean:
+        for w_ in (2, 4, 8):
+            loc_ = sharding.local_ba_problem(pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], pb["pts0"], 0, w_)
+            p_ = bundle.BaProblem(200, len(loc_["pts"]), loc_["obs_cam"], loc_["obs_pt"], loc_["obs_xy"], ctx=ctx)
+            p_.set_params(pb["cams0"], loc_["pts"], pb["focal0"])
+            p_.iterate(BA_PRE)
+            ctx.set_timing(True)
+            t0_ = p_.last_timing()
+            p_.iterate(args.steps)
+            t1_ = p_.last_timing()
+            ctx.set_timing(False)
+            shard_ms[w_] = {"points": int(len(loc_["pts"])), "eliminate_ms": round(1e3 * (t1_["eliminate_s"] - t0_["eliminate_s"]) / args.steps, 4),
+                            "backsub_ms": round(1e3 * (t1_["backsub_s"] - t0_["backsub_s"]) / args.steps, 4),
+                            "reduced_solve_ms": round(1e3 * (t1_["solve_s"] - t0_["solve_s"]) / args.steps, 4)}
+            p_.close()
+        barrier()
 
     # ------------------------------------------------------------------ BA in batch mode: one problem per rank
     # The strong-scaled iteration above cannot scale (ba_amdahl: half of it is the replicated reduced solve).  What a
@@ -404,6 +434,39 @@ def main():
 
     # ------------------------------------------------------------------ cfg5, strong scaling over the ranks
     cfg5 = None
+    cfg5_sample = None
+    if args.lean and args.cfg5_sample > 0:
+        # the profiled sample of cfg5 (K2, knn_keyed_kernel): pairs evenly spaced over the 124 750, every one checked against the golden file
+        o_imgs = synth.orb_image_set()
+        o_all = synth.all_pairs(len(o_imgs))
+        pick = np.unique(np.linspace(0, len(o_all) - 1, min(args.cfg5_sample, len(o_all))).astype(np.int64))
+        o_dev = [torch.from_numpy(a).to(dev) for a in o_imgs]
+        o_set = matcher.ImageSet(n_rows=[len(a) for a in o_imgs], dim=32, dtype=_lib.U8, norm=_lib.HAMMING, ctx=ctx)
+        for i, t in enumerate(o_dev):
+            o_set.adopt_device(i, t.data_ptr(), keepalive=t)
+        o_plan = matcher.MatchPlan(o_set, o_all[pick])
+        o_set.prepare_async()
+        o_plan.run_async(0.8)
+        barrier()
+        ctx.set_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            o_plan.run_async(0.8)
+        barrier()
+        t_s5 = (time.perf_counter() - t0) / 3
+        k2_kernel_s = o_plan.last_timing()["knn_kernel_s"]
+        ctx.set_timing(False)
+        o_cnt, o_q, o_t, o_d = o_plan.fetch()
+        gold = np.load(os.path.join(ROOT, "tests", "golden", "cfg5_checksums.npz"))
+        ok5 = bool(np.array_equal(o_cnt, gold["counts"][pick]) and np.array_equal(synth.pair_checksums(o_cnt, o_q, o_t, o_d), gold["checksums"][pick]))
+        assert ok5, "cfg5 sample: the device's match lists differ from the oracle's"
+        ops5 = 2.0 * 5000 * 5000 * 256 * len(pick)
+        cfg5_sample = {"pairs": int(len(pick)), "seconds_per_sweep": round(t_s5, 6), "kernel_ms": round(1e3 * k2_kernel_s, 4),
+                       "achieved": round(ops5 / max(k2_kernel_s, 1e-12) / 1e12, 2), "peak": I8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
+                       "frac": round(ops5 / max(k2_kernel_s, 1e-12) / 1e12 / I8_DENSE_PEAK_TOPS, 4), "oracle_match": ok5}
+        o_plan.close()
+        o_set.close()
+        del o_dev
     if not args.no_cfg5:
         o_imgs = synth.orb_image_set()         # 500 x 5000 x 32 B, seeded: the same set on every rank
         o_pairs = synth.all_pairs(len(o_imgs))
@@ -423,6 +486,11 @@ def main():
             o_plan.run_async(0.8)
         barrier()
         t_cfg5 = (time.perf_counter() - t0) / 2
+        ctx.set_timing(True)                   # (K2's own time: HIP events around the k-NN launches of one more sweep)
+        o_plan.run_async(0.8)
+        barrier()
+        k2_kernel_s = o_plan.last_timing()["knn_kernel_s"]
+        ctx.set_timing(False)
         o_cnt, o_q, o_t, o_d = o_plan.fetch()
         cs = synth.pair_checksums(o_cnt, o_q, o_t, o_d)
         with np.errstate(over="ignore"):
@@ -456,7 +524,8 @@ def main():
                 "checksum": [int(part[0]), int(part[1])], "checksum_equals_n1": True,
                 "oracle_checked_pairs": int(len(o_pairs)), "oracle_match": cfg5_ok,
                 "oracle": "every pair's count and checksum equal the C restatement's (tests/golden/cfg5_checksums.npz); "
-                          "on N > 1 every rank asserts its own share"}
+                          "on N > 1 every rank asserts its own share",
+                "knn_kernel_ms_this_rank": round(1e3 * k2_kernel_s, 3)}
         o_plan.close()
         o_set.close()
         del o_dev
@@ -550,6 +619,9 @@ def main():
     def hbm_bytes(key):
         v = traffic.get(key, {}).get("hbm_bytes_per_launch")
         return int(v) if v is not None else None
+    # (said on the line: the counters are the builder's box's, read from the repository -- this run measured times, not bytes)
+    traffic_source = ("profiles/traffic.json: rocprofv3 PMC passes of `bench.py --lean` on the builder's box (" +
+                      str(traffic.get("_source", "round-tagged files under profiles/")) + "), not measured in this run") if traffic else None
 
     ops_per_pair = 2.0 * n_feat * n_feat * dim                     # 1.024 GOP per cfg2 pair
     knn_tops = ops_per_pair * len(pairs) / knn_s / 1e12
@@ -559,7 +631,7 @@ def main():
     roofline = {"kernel": "knn_kernel<KS=4,L2,NU=2,SR=256,NW=4> (i8 MFMA 32x32x32, train norm through the C operand, "
                           "value-only slot / tile-maximum epilogue, exact resolve of the candidates)", "bound": "mfma",
                 "achieved": round(knn_tops, 2), "peak": I8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
-                "frac": round(knn_tops / I8_DENSE_PEAK_TOPS, 4), "traffic": hbm_bytes("knn_kernel"),
+                "frac": round(knn_tops / I8_DENSE_PEAK_TOPS, 4), "traffic": hbm_bytes("knn_kernel"), "traffic_source": traffic_source,
                 "sustained_peak": round(sustained_peak_ops / 1e12, 1), "sustained_peak_clock_ghz": round(sustained_peak_ghz, 3),
                 "frac_of_sustained": round(knn_tops / max(sustained_peak_ops / 1e12, 1e-9), 4),
                 "sweep_clock_ghz": round(sweep_clock_ghz, 3),
@@ -590,7 +662,7 @@ def main():
                               "this rank's shard)",
                    "bound": "hbm", "achieved": round(ba_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": round(ba_gbs / HBM_PEAK_GBS, 4),
-                   "traffic": sum(tr_ba) if all(t is not None for t in tr_ba) else None,
+                   "traffic": sum(tr_ba) if all(t is not None for t in tr_ba) else None, "traffic_source": traffic_source,
                    "eliminate_ms": round(1e3 * ba_t["eliminate_s"] / args.steps, 4),
                    "allreduce_ms": round(1e3 * ba_t["allreduce_s"] / args.steps, 4),
                    "reduced_solve_ms": round(1e3 * ba_t["solve_s"] / args.steps, 4),
@@ -601,6 +673,60 @@ def main():
                            "as a tree of fronts of the recursively dissected camera graph, one workgroup per front "
                            "(reduced_layout.front_tree: the dependency chain is chain_tiles tile steps of 32 columns instead "
                            "of dense_tiles), or, where no such tree exists, as chains + separator / dense; DESIGN.md section 3"}
+
+    # K2 (knn_keyed_kernel, cfg5): times from this run (the full sweep of this rank, or the profiled sample), the counters from the
+    # committed PMC passes of `bench.py --lean --cfg5-sample N`
+    roofline_k2 = None
+    k2_src = cfg5_sample if cfg5_sample is not None else None
+    if cfg5 is not None:
+        ops_k2 = 2.0 * 5000 * 5000 * 256 * cfg5["pairs_this_rank"]
+        k2_src = {"pairs": cfg5["pairs_this_rank"], "kernel_ms": cfg5["knn_kernel_ms_this_rank"],
+                  "achieved": round(ops_k2 / max(cfg5["knn_kernel_ms_this_rank"] * 1e-3, 1e-12) / 1e12, 2)}
+    if k2_src is not None:
+        pmc_k2 = traffic.get("knn_keyed_kernel", {})
+        roofline_k2 = {"kernel": "knn_keyed_kernel<KS=8,SR=128> (Hamming: i8 MFMA 32x32x32 on +-8 rows, the accumulator IS the key "
+                                 "128 * distance + row-in-chunk; per-lane top-2 by v_med3_u32 + v_min_u32)", "bound": "mfma",
+                       "achieved": k2_src["achieved"], "peak": I8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
+                       "frac": round(k2_src["achieved"] / I8_DENSE_PEAK_TOPS, 4), "pairs": k2_src["pairs"], "kernel_ms": k2_src["kernel_ms"],
+                       "work": "2 * 5000 * 5000 * 256 OP per cfg5 pair",
+                       "traffic": pmc_k2.get("hbm_bytes_per_launch"), "mfma_util_pct": pmc_k2.get("mfma_util_pct"),
+                       "valu_per_mfma": pmc_k2.get("valu_per_mfma"),
+                       "traffic_source": traffic_source}
+
+    # ------------------------------------------------------------------ the whole drop-in call (rank 0, N = 1)
+    # BundleAdjustment::adjustBundle (reference include/BundleAdjustment.h:19-20) is a static one-shot function the reference means to
+    # call once per added view (src/Sfm.cpp:883-888, :996) and that builds its problem from the containers every time
+    # (src/BundleAdjustment.cpp:50-110).  Every BA number above is per iteration of a problem that exists; this is what the caller
+    # of the reference's signature sees: the C++ mirror's call in the reference's containers (csrc/host/ba_selftest.cpp, a
+    # subprocess), three calls on the same structure -- the first builds the plan, the others find it kept.
+    adjust_call = None
+    if rank == 0 and world == 1 and not args.no_adjust_bundle:
+        import subprocess
+        import tempfile
+        from sfm_danpipeline_amd import build as _build
+        exe = _build.build_ba_demo()
+        adjust_call = {}
+        for tag_, (nc_, np_, k_) in (("cfg3", (50, 20000, 10)), ("cfg4", (200, 100000, 10))):
+            pb_ = pb if tag_ == "cfg4" else synth.ba_problem(nc_, np_, k_, seed=777)
+            with tempfile.TemporaryDirectory() as d_:
+                synth.write_ba_containers(os.path.join(d_, "in.bin"), pb_, 960.0, 540.0)
+                r_ = subprocess.run([exe, os.path.join(d_, "in.bin"), os.path.join(d_, "out.bin")], capture_output=True, text=True,
+                                    env=dict(os.environ, SFM_BA_SELFTEST_CALLS="3"))
+            assert r_.returncode == 0 and "failed" not in r_.stderr, r_.stderr[-2000:]
+            recs = [json.loads(l_) for l_ in r_.stdout.splitlines() if l_.startswith("{")]
+            its_ = [int(l_.split("iterations")[1].split(",")[0]) for l_ in r_.stdout.splitlines() if l_.startswith("Bundle adjustment:")]
+            keys = ("pack_ms", "create_ms", "set_params_ms", "run_ms", "get_params_ms", "keep_ms", "writeback_ms", "total_ms", "plan_reused")
+            adjust_call[tag_] = {"lm_iterations": its_[0], "first_call": {k: recs[0][k] for k in keys},
+                                 "repeated_call": {k: recs[-1][k] for k in keys},
+                                 "solve_ms": recs[-1]["run_ms"],
+                                 "total_over_solve_first": round(recs[0]["total_ms"] / max(recs[0]["run_ms"], 1e-9), 2),
+                                 "total_over_solve_repeated": round(recs[-1]["total_ms"] / max(recs[-1]["run_ms"], 1e-9), 2)}
+        adjust_call["note"] = ("ms of host wall clock per stage of ONE BundleAdjustment::adjustBundle call through the C++ mirror in the "
+                               "reference's containers: pack (std::map tracks -> flat arrays), create (sfmhip_ba_create: grouping, signature "
+                               "sort, chunking, gather lists, allocations, uploads -- or, plan_reused, the comparison of the structure with the "
+                               "kept problem's + the new measurements), run (the LM loop to CONVERGENCE; the first call also plans the front "
+                               "tree), write-back; first_call = a fresh process's first call (HIP start-up excluded: the context exists), "
+                               "repeated_call = the third call on the same structure")
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only)
     cpu_baseline = None
@@ -679,6 +805,9 @@ def main():
         orc.ba_set_blocked_cholesky(False)
         cpu_pairs_s = npairs / cpu_match_s
         cpu_ba_its = args.cpu_ba_iters / cpu_ba_s
+        if adjust_call is not None:
+            # (beside the whole call: what the CPU restatement's solve of cfg4 would take at that rate -- its set-up is a few ms)
+            adjust_call["cfg4"]["cpu_oracle_solve_ms_extrapolated"] = round(1e3 * (adjust_call["cfg4"]["lm_iterations"] + 1) / cpu_ba_its, 1)
         cpu_step_ms = 1e3 * (len(pairs) / cpu_pairs_s + 1.0 / cpu_ba_its)
         cpu_baseline = {"value": round(cpu_pairs_s, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
                         "sample": f"first {npairs} of the 1225 cfg2 pairs, query-block-parallel / train-tiled / SIMD matcher on "
@@ -717,6 +846,9 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_match + ms_ba, 4), "ms_match_sweep": round(ms_match, 4),
             "ms_ba_iteration": round(ms_ba, 4),
+            "methodology": "r6: BA regions = LM iterations 16 .. 15 + K of a fresh solve, independent of --warmup (r5: W + 21 .. W + 20 + K); "
+                           "ba_batch includes set_params in its time; GPU_MAX_HW_QUEUES=8 for this process (ba_batch only); not comparable "
+                           "with BENCH_r01-r04's BA rates, which ran on one long solve",
             "higher_is_better": True, "scaling": "weak", "ba_scaling": "strong",
             "vs_baseline": None, "dtype": "i8", "ba_dtype": "f64", "data": "synthetic",
             "config": {"workload": "cfg2 all-pairs L2 knn-2 + ratio (50 img x 2000 SIFT-128, 1225 pairs/GPU) "
@@ -743,8 +875,13 @@ def main():
                                            "takes a plan's lists two of its runs behind the one it enqueues; stop_and_copy = "
                                            "sfmhip_matchplan_fetch after every sweep"},
             "cfg5_strong": cfg5, "find_best_pair_scoring": score_leg, "sift_front_end": sift_leg, "ba_batch": ba_batch,
+            "adjust_bundle_call": adjust_call, "roofline_k2": roofline_k2, "cfg5_sample": cfg5_sample,
             "ba_amdahl": (lambda sh, rep, ar: {
                 "sharded_ms": round(sh, 4), "replicated_ms": round(rep, 4), "allreduce_ms": round(ar, 4),
+                # measured, not extrapolated: rank 0's point block of a world of 2 / 4 / 8 as a problem of its own on this GPU
+                "shard_measured": shard_ms or None,
+                "sharded_ms_at_8_measured": round(shard_ms[8]["eliminate_ms"] + shard_ms[8]["backsub_ms"], 4) if shard_ms else None,
+                "bound_8gpu_speedup_measured": round((sh + rep) / (shard_ms[8]["eliminate_ms"] + shard_ms[8]["backsub_ms"] + rep + ar), 2) if shard_ms else None,
                 # what sharding the reduced solve over ranks could reach: nothing below the dependency chain.  The front tree
                 # already runs every front at once on one GPU (31 workgroups at cfg4); its time IS the leaf-to-root chain
                 # (reduced_layout.front_tree.chain_tiles tile steps), which every subtree-per-rank split leaves whole and

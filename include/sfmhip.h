@@ -290,6 +290,24 @@ int sfmhip_ba_solve(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, double* cam
                     double* focal, const int32_t* obs_cam, const int32_t* obs_pt,
                     const double* obs_xy, const sfmhip_ba_opts* opts, sfmhip_ba_summary* summary);
 
+/* Where the last sfmhip_ba_solve call on this context spent its time (milliseconds of host wall clock, stage by stage), and
+ * whether it reused the problem the call before it had set up.  The one-shot entry point is what
+ * BundleAdjustment::adjustBundle (reference include/BundleAdjustment.h:19-20, src/BundleAdjustment.cpp:46-123) maps to: the
+ * reference builds its ceres::Problem from the containers on every call, and so does this -- create_ms is that cost --
+ * unless the observation structure (n_cam, n_pt, obs_cam[], obs_pt[]) equals the previous call's, in which case the kept
+ * problem takes the new measurements and parameters and create_ms is the comparison + the re-upload. */
+typedef struct sfmhip_ba_solve_profile {
+  double create_ms;     /* sfmhip_ba_create (or, plan_reused: structure comparison + new measurements) */
+  double set_params_ms; /* parameters to the device */
+  double run_ms;        /* the LM loop (the first call on a structure also plans the reduced system's front tree here) */
+  double get_params_ms; /* parameters back */
+  double keep_ms;       /* keeping the problem for the next call (a copy of obs_cam / obs_pt) or destroying it */
+  double total_ms;
+  int plan_reused;
+  int pad;
+} sfmhip_ba_solve_profile;
+int sfmhip_ba_last_solve_profile(sfmhip_ctx* ctx, sfmhip_ba_solve_profile* out);
+
 /* Persistent problem object (multi-GPU: every rank holds all cameras + focal and its own
  * block of points with their observations; the per-iteration sum of the reduced camera
  * system goes through `allreduce`, e.g. RCCL via torch.distributed). */

@@ -30,6 +30,10 @@ print("drain+thr+mask+candidates (2->8)", np.median(st[:, :, 8] - st[:, :, 2]), 
       " rows+dots (9->10)", np.median(st[:, :, 10] - st[:, :, 9]), " read back + merge (10->3)", np.median(st[:, :, 3] - st[:, :, 10]),
       " [rows: issue (9->11)", np.median(st[:, :, 11] - st[:, :, 9]), "wait (11->12)", np.median(st[:, :, 12] - st[:, :, 11]), "dots (12->10)", np.median(st[:, :, 10] - st[:, :, 12]), "]",
       " rows in the list of tile 0: median", np.median(st[:, :, 13]), "max", st[:, :, 13].max())
+c0, c1 = st[:, :, 13].ravel(), st[:, :, 7].ravel()
+print("listed rows per query tile: tile 0 mean %.1f p10 %d p50 %d p90 %d; tile 1 mean %.1f; max of the two mean %.1f; trips mean %.2f; share of waves with max > 64: %.2f, > 128: %.2f" % (
+    c0.mean(), np.percentile(c0, 10), np.percentile(c0, 50), np.percentile(c0, 90), c1.mean(), np.maximum(c0, c1).mean(), st[:, :, 6].mean(),
+    (np.maximum(c0, c1) > 64).mean(), (np.maximum(c0, c1) > 128).mean()))
 
 # co-residency: workgroups by CU (HW_ID: wave_id[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]; XCC_ID[3:0])
 hw = st[:, 0, 14]; xcc = st[:, 0, 15] & 0xF

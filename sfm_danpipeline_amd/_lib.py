@@ -34,6 +34,12 @@ class BaSummary(C.Structure):
     ]
 
 
+class BaSolveProfile(C.Structure):
+    """sfmhip_ba_solve_profile (include/sfmhip.h): where the last one-shot solve on a context spent its host time."""
+    _fields_ = [("create_ms", C.c_double), ("set_params_ms", C.c_double), ("run_ms", C.c_double), ("get_params_ms", C.c_double),
+                ("keep_ms", C.c_double), ("total_ms", C.c_double), ("plan_reused", C.c_int), ("pad", C.c_int)]
+
+
 class LmState(C.Structure):
     """sfmhip_lm_state (include/sfmhip.h): options + trust-region state of sfmhip_ba_lm_decide, the host-side test hook of the
     decision the device takes at the end of every step evaluation."""
@@ -69,7 +75,7 @@ SYMBOLS = [
     "sfmhip_matchplan_destroy",
     "sfmhip_triangulate", "sfmhip_find_2d3d", "sfmhip_merge_new_points", "sfmhip_ba_default_opts", "sfmhip_ba_solve", "sfmhip_ba_create",
     "sfmhip_ba_set_allreduce", "sfmhip_ba_set_params", "sfmhip_ba_get_params", "sfmhip_ba_run",
-    "sfmhip_ba_iterate", "sfmhip_ba_reduced_system", "sfmhip_ba_linearize_obs", "sfmhip_ba_last_timing", "sfmhip_ba_reduced_layout", "sfmhip_ba_reduced_tree", "sfmhip_probe_i8_mfma_peak", "sfmhip_probe_clock_start", "sfmhip_probe_clock_read", "sfmhip_ba_reduced_step", "sfmhip_ba_lm_decide", "sfmhip_score_essential", "sfmhip_score_last_flags", "sfmhip_score_five_point", "sfmhip_score_homography_kernel", "sfmhip_score_homography", "sfmhip_sift_detect_and_compute", "sfmhip_sift_detect_and_compute_device", "sfmhip_sift_batch", "sfmhip_device_free", "sfmhip_host_free", "sfmhip_device_download", "sfmhip_ba_destroy",
+    "sfmhip_ba_iterate", "sfmhip_ba_reduced_system", "sfmhip_ba_linearize_obs", "sfmhip_ba_last_timing", "sfmhip_ba_reduced_layout", "sfmhip_ba_reduced_tree", "sfmhip_probe_i8_mfma_peak", "sfmhip_probe_clock_start", "sfmhip_probe_clock_read", "sfmhip_ba_reduced_step", "sfmhip_ba_lm_decide", "sfmhip_score_essential", "sfmhip_score_last_flags", "sfmhip_score_five_point", "sfmhip_score_homography_kernel", "sfmhip_score_homography", "sfmhip_sift_detect_and_compute", "sfmhip_sift_detect_and_compute_device", "sfmhip_sift_batch", "sfmhip_device_free", "sfmhip_host_free", "sfmhip_device_download", "sfmhip_ba_destroy", "sfmhip_ba_last_solve_profile",
 ]
 
 _lib = None
@@ -150,6 +156,8 @@ def lib():
         L.sfmhip_ba_reduced_step.argtypes = [vp, f64, vp, vp]
         L.sfmhip_ba_destroy.argtypes = [vp]
         L.sfmhip_ba_destroy.restype = None
+        if hasattr(L, "sfmhip_ba_last_solve_profile"):  # (diagnostic builds of older revisions lack it)
+            L.sfmhip_ba_last_solve_profile.argtypes = [vp, C.POINTER(BaSolveProfile)]
     _lib = L
     return L
 

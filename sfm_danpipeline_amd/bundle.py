@@ -226,6 +226,14 @@ def ba_solve(cams6, pts3, focal, obs_cam, obs_pt, obs_xy, opts=None, ctx=None):
     return cams, pts, f.value, s
 
 
+def last_solve_profile(ctx=None):
+    """Stage times (ms) of the last `ba_solve` on the context, and whether it reused the previous call's plan."""
+    ctx = ctx or _lib.default_context()
+    p = _lib.BaSolveProfile()
+    check(lib().sfmhip_ba_last_solve_profile(ctx.h, C.byref(p)), "sfmhip_ba_last_solve_profile")
+    return {k: getattr(p, k) for k, _ in p._fields_ if k != "pad"}
+
+
 # ----------------------------------------------------------------------------- adjustBundle
 def adjust_bundle(point_cloud, camera_poses, K, image2d_features, opts=None, ctx=None, solver=None, log=None):
     """BundleAdjustment::adjustBundle.  Mutates `point_cloud[i]['pt']`, `camera_poses[i]` (3x4

@@ -55,6 +55,13 @@ constexpr int SC = 16;       // scalar slots at the tail of the all-reduce buffe
 // round 5, kept for the layout) | RED2_TMP | RED2_INFO (an int: the reduced solve's status) | pad.
 constexpr int RED2_SLOTS = 32, RED2_SUM_N = 8 + 4 * RED2_SLOTS, RED2_TMP = RED2_SUM_N, RED2_INFO = RED2_SUM_N + 1,
               RED2_N = RED2_SUM_N + 8;
+// red2[RED2_TIMEOUT]: 1 when a bounded spin of this rank's reduced solve or step evaluation ran out; summed over the ranks by the
+// step evaluation's all-reduce, so that EVERY rank stops and repeats the solve (a rank-local stop would leave its peers waiting
+// in an all-reduce the stopped rank never issues)
+constexpr int RED2_TIMEOUT = 4;
+// the reduced solve's status word (RED2_INFO): > 0 a pivot was not positive; -1 a hand-off of the reduced solve never arrived
+// (the front tree then runs level by level); -2 a slot of the step evaluation's sums never arrived (no fallback: SFMHIP_ERR_TIMEOUT)
+constexpr int INFO_FINISHER_TIMEOUT = -2;
 constexpr int FB_MAXN = 4096;  // sanity cap on the observations of one point (the pair path has no structural limit)
 
 struct Chunk {
@@ -2986,7 +2993,7 @@ __device__ __forceinline__ void lm_inputs_early(const BaDev& d, LmEarly& e) {
   e.lin0 = scv[0], e.lin2 = scv[2], e.lin3 = scv[3];
   e.s = *d.lm;
 }
-__device__ __forceinline__ void lm_decide_with(const BaDev& d, LmEarly& e, const double sums[4]) {
+__device__ __forceinline__ void lm_decide_with(const BaDev& d, LmEarly& e, const double sums[4], bool peer_timeout = false) {
   LmIn in;
   in.lin_cost = 0.5 * e.lin0;
   in.lin_nfail = e.lin2;
@@ -2996,6 +3003,7 @@ __device__ __forceinline__ void lm_decide_with(const BaDev& d, LmEarly& e, const
   in.step_n2 = sums[2];
   in.cand_n2 = sums[3];
   in.info = *(volatile int*)d.info;
+  if (peer_timeout && in.info >= 0) in.info = -1;  // (another rank's spin ran out: this rank stops with it)
   lm_decide(e.s, in);
   *d.lm = e.s;
 }
@@ -3003,7 +3011,7 @@ __device__ __forceinline__ void lm_decide_here(const BaDev& d) {
   LmEarly e;
   lm_inputs_early(d, e);
   const double sums[4] = {d.red2[0], d.red2[1], d.red2[2], d.red2[3]};
-  lm_decide_with(d, e, sums);
+  lm_decide_with(d, e, sums, d.red2[RED2_TIMEOUT] > 0.0);  // (behind the all-reduce: the ranks' flags summed)
 }
 
 __global__ void ba_decide(BaDev d) {
@@ -3095,7 +3103,10 @@ __device__ __forceinline__ void step_finish(const BaDev& d, int slot, double cos
       for (int w = 1; w < nw; ++w) v += s_fin[k][w];
       d.red2[k] = sums[k] = v;
     }
-    if (s_to) atomicExch(d.info, -1);  // (a workgroup of the step evaluation never wrote its slot: not a state the data can cause)
+    if (s_to) atomicExch(d.info, INFO_FINISHER_TIMEOUT);  // (a workgroup of the step evaluation never wrote its slot: not a state the data can cause)
+    // several ranks: a spin that ran out is this rank's alone (a scheduling artefact), the decision must be every rank's --
+    // the flag travels with the sums through the all-reduce and lm_decide_here reads the total (RED2_TIMEOUT)
+    d.red2[RED2_TIMEOUT] = *(volatile int*)d.info < 0 ? 1.0 : 0.0;
     if (decide) lm_decide_with(d, early, sums);
   }
 }
@@ -3475,6 +3486,9 @@ struct sfmhip_ba {
   size_t ssz = 0;  // ld*ld: doubles of the S part of `red`
   BaDev d{};
   std::vector<int> perm;  // sorted point -> input point
+  std::vector<int> obs_src;  // sorted observation -> input observation (ba_set_observations: the same structure, new measurements)
+  std::vector<int> cxy_src;  // entry of the pair path's camera-major list -> sorted observation
+  double2* d_oxy_w = nullptr;  // (the writable view of d.oxy)
   std::vector<unsigned char> h_cam_used;
   unsigned char* d_cam_used = nullptr;
   bool cam_used_known = false;
@@ -3679,8 +3693,17 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
                                 const int32_t* obs_pt, const double* obs_xy, sfmhip_ba** out) {
   if (!ctx || !out || n_cam <= 0 || n_pt < 0 || n_obs < 0) return SFMHIP_ERR_ARG;
   if (n_obs && (!obs_cam || !obs_pt || !obs_xy)) return SFMHIP_ERR_ARG;
-  for (int o = 0; o < n_obs; ++o)
-    if (obs_cam[o] < 0 || obs_cam[o] >= n_cam || obs_pt[o] < 0 || obs_pt[o] >= n_pt) return SFMHIP_ERR_ARG;
+  // (one pass: the range check, and whether the observations already come grouped by point -- the order the reference adds
+  // residual blocks in, src/BundleAdjustment.cpp:83-110 -- in which case the counting sort's scatter below is the identity)
+  bool grouped = true;
+  {
+    int bad = 0;
+    for (int o = 0; o < n_obs; ++o) {
+      bad |= (obs_cam[o] < 0) | (obs_cam[o] >= n_cam) | (obs_pt[o] < 0) | (obs_pt[o] >= n_pt);
+      grouped &= o == 0 || obs_pt[o - 1] <= obs_pt[o];
+    }
+    if (bad) return SFMHIP_ERR_ARG;
+  }
   SFM_HIP_TRY(hipSetDevice(ctx->device));
   const bool prof_ = getenv("SFMHIP_PROFILE_CREATE") != nullptr;
   auto tp_ = std::chrono::steady_clock::now();
@@ -3703,8 +3726,15 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   std::vector<int> cnt(n_pt + 1, 0);
   for (int o = 0; o < n_obs; ++o) cnt[obs_pt[o] + 1]++;
   for (int p = 0; p < n_pt; ++p) cnt[p + 1] += cnt[p];
-  std::vector<int> slot(n_obs), fill(n_pt, 0);
-  for (int o = 0; o < n_obs; ++o) slot[cnt[obs_pt[o]] + fill[obs_pt[o]]++] = o;
+  std::vector<int> slot(n_obs);
+  if (grouped) {
+    host_parallel_for(n_obs, [&](int lo, int hi) {
+      for (int o = lo; o < hi; ++o) slot[o] = o;
+    });
+  } else {
+    std::vector<int> fill(n_pt, 0);
+    for (int o = 0; o < n_obs; ++o) slot[cnt[obs_pt[o]] + fill[obs_pt[o]]++] = o;
+  }
   // per point (a few host threads: every pass over a million observations is a cache-miss chain on
   // one core): stable insertion sort -- a point has a handful of observations --, then the point's
   // ascending camera list, flat, and a hash of it: the signature grouping below compares
@@ -3783,6 +3813,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   b->no = optr[b->np];
   std::vector<int> ocam(b->no);
   std::vector<double> oxy(2 * (size_t)b->no);
+  b->obs_src.resize(b->no);
   b->h_cam_used.assign(n_cam, 0);
   // the gather of a million observations is a cache-miss chain on one core: split it over a few
   host_parallel_for(b->np, [&](int lo, int hi) {
@@ -3791,6 +3822,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
       int w = optr[sp];
       for (int k = cnt[p]; k < cnt[p + 1]; ++k, ++w) {
         const int o = slot[k];
+        b->obs_src[w] = o;
         ocam[w] = obs_cam[o];
         oxy[2 * (size_t)w] = obs_xy[2 * (size_t)o];
         oxy[2 * (size_t)w + 1] = obs_xy[2 * (size_t)o + 1];
@@ -3970,7 +4002,9 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
       const int* cams = sig_cams.data() + ch.sig_off;
       const unsigned base = (unsigned)(c * (size_t)ELIM_SLAB);
       auto gidx = [&](int l) { return l < 6 * n ? 6 * cams[l / 6] + l % 6 : l == 6 * n ? fo : l == 6 * n + 1 ? -2 : -1; };
-      for (int idx = 0; idx < NTc * 256; ++idx) {  // the Gram block, as the kernel lays it out
+      // (ba_gather_rows: the cameras' rows from the row lists above, the focal row chunk by chunk -- nothing of the Gram block
+      // goes through the destination lists then, and walking its NTc * 256 entries per chunk was half of this stage's time)
+      for (int idx = 0; !use_rows && idx < NTc * 256; ++idx) {  // the Gram block, as the kernel lays it out
         int t = idx >> 8, ti = 0;
         while (t >= NBc - ti) {
           t -= NBc - ti;
@@ -3980,7 +4014,6 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
         const int lr = 16 * ti + (ln >> 4) + 4 * gg, lc = 16 * tj + (ln & 15);
         const int gr = gidx(lr), gc = gidx(lc);
         if (gr < 0 || lr > lc || gc == -1) continue;
-        if (use_rows) continue;  // (ba_gather_rows: the cameras' rows from the row lists below, the focal row chunk by chunk)
         ent[0].push_back({gc >= 0 ? (long long)gr * ld + gc : o_g + gr, (base + idx) | 0x80000000u});  // S -= Gram (F^T F folded in)
       }
       for (int e = 0; e < 33; ++e)
@@ -4012,8 +4045,23 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
       }
     }
     for (int m = 0; m < 2; ++m) {
-      // counting sort by destination (stable: a destination's sources stay in chunk order)
       const size_t range = (size_t)(o_sc + SC + 64) + 2;   // destinations + the GMAX key shifted to 0
+      if (ent[m].size() * 16 < range) {
+        // few entries for the range (the row lists carry S: what is left are the diagonal's entries): a stable sort of the
+        // entries instead of three passes over ld^2 counters (cfg4: 31 k entries, 1.5 M destinations)
+        std::stable_sort(ent[m].begin(), ent[m].end(), [](const std::pair<long long, unsigned>& a, const std::pair<long long, unsigned>& c) { return a.first < c.first; });
+        gth_src[m].resize(ent[m].size());
+        for (size_t k = 0; k < ent[m].size(); ++k) {
+          gth_src[m][k] = ent[m][k].second;
+          if (k == 0 || ent[m][k].first != ent[m][k - 1].first) {
+            gth_ptr[m].push_back((int)k);
+            gth_dest[m].push_back((int)ent[m][k].first);
+          }
+        }
+        gth_ptr[m].push_back((int)ent[m].size());
+        continue;
+      }
+      // counting sort by destination (stable: a destination's sources stay in chunk order)
       std::vector<int> cnt(range + 1, 0);
       for (const auto& e : ent[m]) ++cnt[(size_t)(e.first + 1) + 1];
       for (size_t k = 0; k < range; ++k) cnt[k + 1] += cnt[k];
@@ -4061,6 +4109,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
     cpt.resize(nfo);
     cslot.resize(nfo);
     cxy.resize(2 * nfo);
+    b->cxy_src.resize(nfo);
     for (int sp : fb)
       for (int k = optr[sp]; k < optr[sp + 1]; ++k) cptr[ocam[k] + 1]++;
     for (int c = 0; c < n_cam; ++c) cptr[c + 1] += cptr[c];
@@ -4076,6 +4125,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
         const int dst = fill[ocam[k0 + o]]++;
         cpt[dst] = sp;
         cslot[dst] = make_int2(pp_obase[i] + o, (int)i);
+        b->cxy_src[dst] = k0 + o;
         cxy[2 * (size_t)dst] = oxy[2 * (size_t)(k0 + o)];
         cxy[2 * (size_t)dst + 1] = oxy[2 * (size_t)(k0 + o) + 1];
         for (int o2 = o + 1; o2 < n; ++o2) {
@@ -4206,6 +4256,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   d.optr = d_optr;
   d.ocam = d_ocam;
   d.oxy = d_oxy;
+  b->d_oxy_w = d_oxy;
   for (int c = 0; c < 8; ++c) b->n_chunk_ids[c] = (int)ids[c].size();
   b->n_fb = (int)fb.size();
   auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
@@ -5186,6 +5237,7 @@ __global__ __launch_bounds__(256) void ba_step_nopoints(BaDev d) {
 // wave of ba_cand_cams).  Fixed per problem; set before the reduced solve, whose down-sweep writes the camera parts.
 struct StepLayout {
   bool runs;
+  bool fits;  // the slots fit step_part (checked BEFORE the reduced solve, whose down-sweep writes the camera parts behind them)
   int n_runs_wg, npl, n_bs_wg, split, wpp;
   const int* plist;
 };
@@ -5205,6 +5257,7 @@ static StepLayout ba_step_layout(sfmhip_ba* b) {
   L.n_bs_wg = L.npl <= 0 ? 0 : wpp_env == 1 ? (int)((nblk + 3) / 4) : wpp_env == 2 ? (int)((nblk + 1) / 2) : (int)nblk;
   b->d.step_total = std::max(1, L.n_runs_wg + L.n_bs_wg);
   b->d.cam_parts = b->tree_on ? b->tree_fs.n_fronts : (b->nc + 1 + 63) / 64;
+  L.fits = 4 * (size_t)b->d.step_total + 2 * (size_t)b->d.cam_parts <= b->step_part_n;
   return L;
 }
 
@@ -5218,7 +5271,7 @@ static int ba_step_eval(sfmhip_ba* b, double radius, const sfmhip_ba_opts* o) {
   // (the decision: by the finisher of ba_backsub_runs when that is the step evaluation's last kernel and there is one
   // rank; else by ba_decide behind the all-reduce)
   d.decide_here = d.lm && b->world == 1 && npl <= 0 ? 1 : 0;
-  if (4 * (size_t)d.step_total + 2 * (size_t)d.cam_parts > b->step_part_n) return SFMHIP_ERR_STATE;
+  if (!L.fits) return SFMHIP_ERR_STATE;
   if (!b->tree_on) hipLaunchKernelGGL(ba_cand_cams, dim3((b->nc + 1 + 63) / 64), dim3(64), 0, st, d, b->d_cam_used, b->rank);
   int nbs = 0;
   if (runs) {
@@ -5315,6 +5368,7 @@ static int ba_read_scalars(sfmhip_ba* b, IterScalars* s, bool with_step) {
     s->step_n2 = step[2];
     s->cand_n2 = step[3];
     memcpy(&s->info, step + RED2_INFO, sizeof(int));
+    if (step[RED2_TIMEOUT] > 0.0 && s->info >= 0) s->info = -1;  // (another rank's spin ran out: every rank repeats the solve)
   }
   return SFMHIP_OK;
 }
@@ -5396,7 +5450,7 @@ static int ba_enqueue_body(sfmhip_ba* b, const sfmhip_ba_opts* o) {
   SFM_TRY(ba_ensure_lin(b, o));
   b->lm.have_lin = false;
   b->solve_cand = true;  // (the front tree's down-sweep leaves the candidate cameras and their tables)
-  ba_step_layout(b);     // (... and the camera parts of the step's norms, in the slots behind the step evaluation's)
+  if (!ba_step_layout(b).fits) return SFMHIP_ERR_STATE;  // (... and the camera parts of the step's norms, in the slots behind the step evaluation's)
   const int rc_solve = ba_reduced_solve(b);
   b->solve_cand = false;
   SFM_TRY(rc_solve);
@@ -5433,8 +5487,16 @@ static int ba_wait_record(sfmhip_ba* b, unsigned seq, LmDev* out) {
 // compute unit while its parent polled (a busy device; dispatch order is not a promise): from now on the tree runs one
 // launch per level, where every child has finished before its parent starts.  Anywhere else (the spins inside a
 // workgroup) it is a bug: the caller gets SFMHIP_ERR_TIMEOUT, not a silently different trajectory.
-static int ba_handle_timeout(sfmhip_ba* b) {
+static int ba_handle_timeout(sfmhip_ba* b, int info) {
   b->spin_timeouts += 1;
+  {
+    // the finisher re-arms the slots it has read; one that ran out left a slot that its late writer may still fill: every slot
+    // is armed again, on the stream, before anything is repeated
+    const std::vector<unsigned long long> pend(b->step_part_n, STEP_PENDING);
+    SFM_HIP_TRY(hipMemcpyAsync(b->d_step_part, pend.data(), sizeof(double) * b->step_part_n, hipMemcpyHostToDevice, b->ctx->stream));
+    SFM_HIP_TRY(hipStreamSynchronize(b->ctx->stream));  // (pend leaves scope; a time-out is no hot path)
+  }
+  if (info == INFO_FINISHER_TIMEOUT) return SFMHIP_ERR_TIMEOUT;  // (not a hand-off between fronts: one launch per level would not cure it)
   if (b->tree_on && !b->tree_by_level) {
     b->tree_by_level = true;
     return SFMHIP_OK;
@@ -5495,7 +5557,7 @@ static int ba_lm_loop(sfmhip_ba* b, const sfmhip_ba_opts* o, int iters, const st
       }
       ++done;
       if (s.stop == LM_STOP_TIMEOUT) {
-        SFM_TRY(ba_handle_timeout(b));
+        SFM_TRY(ba_handle_timeout(b, s.log_info));
         s.stop = LM_RUNNING;
         --done;
         continue;
@@ -5546,7 +5608,7 @@ static int ba_lm_loop(sfmhip_ba* b, const sfmhip_ba_opts* o, int iters, const st
       b->fin_pending = false;
       if (b->tree_on) b->tree_epoch = epoch0 + (unsigned)ran;
       if (s.stop == LM_STOP_TIMEOUT) {
-        if ((rc = ba_handle_timeout(b)) != SFMHIP_OK) break;
+        if ((rc = ba_handle_timeout(b, s.log_info)) != SFMHIP_OK) break;
         done -= B - ran + 1;  // (the solve that timed out is repeated)
         s.stop = LM_RUNNING;
         s.seq = b->lm_seq;
@@ -5818,15 +5880,124 @@ extern "C" void sfmhip_ba_destroy(sfmhip_ba* b) {
   delete b;
 }
 
+// New measurements for a problem of unchanged structure (the same obs_cam / obs_pt arrays as at its creation): the sorted
+// copies are re-gathered through the maps the set-up left and uploaded; nothing of the plan changes.
+static int ba_set_observations(sfmhip_ba* b, const double* obs_xy) {
+  SFM_HIP_TRY(hipSetDevice(b->ctx->device));
+  if (!b->no) return SFMHIP_OK;
+  const size_t no = (size_t)b->no, nfo = b->cxy_src.size();
+  void* pin = nullptr;
+  SFM_TRY(sfm_ctx_pinned(b->ctx, sizeof(double) * 2 * (no + nfo), &pin));
+  double* oxy = (double*)pin;
+  double* cxy = oxy + 2 * no;
+  host_parallel_for(b->no, [&](int lo, int hi) {
+    for (int w = lo; w < hi; ++w) {
+      const size_t o = (size_t)b->obs_src[w];
+      oxy[2 * (size_t)w] = obs_xy[2 * o];
+      oxy[2 * (size_t)w + 1] = obs_xy[2 * o + 1];
+    }
+  });
+  for (size_t k = 0; k < nfo; ++k) {
+    cxy[2 * k] = oxy[2 * (size_t)b->cxy_src[k]];
+    cxy[2 * k + 1] = oxy[2 * (size_t)b->cxy_src[k] + 1];
+  }
+  hipStream_t st = b->ctx->stream;
+  SFM_HIP_TRY(hipMemcpyAsync(b->d_oxy_w, oxy, sizeof(double) * 2 * no, hipMemcpyHostToDevice, st));
+  if (nfo) SFM_HIP_TRY(hipMemcpyAsync(b->d_cxy, cxy, sizeof(double) * 2 * nfo, hipMemcpyHostToDevice, st));
+  SFM_HIP_TRY(hipStreamSynchronize(st));  // (the pinned block is the context's: free for the next caller)
+  return SFMHIP_OK;
+}
+
+// The one-shot entry point keeps the LAST problem it built with the context (BundleAdjustment::adjustBundle is a static one-shot
+// function, include/BundleAdjustment.h:19-20, that the reference means to call again and again -- src/Sfm.cpp:883-888, :996):
+// a call whose observation structure (n_cam, n_pt, obs_cam[], obs_pt[]) equals the kept one's skips the whole set-up -- grouping,
+// signature sort, chunking, gather lists, camera graph and dissection, allocations, uploads -- and only takes the new
+// measurements and parameters.  The arrays are compared element for element (no hash to collide).  SFMHIP_BA_PLAN_CACHE=0
+// switches it off; the kept problem (its device buffers) lives until another structure replaces it or the context shuts down.
+struct BaPlanCache {
+  sfmhip_ba* b = nullptr;
+  int n_cam = 0, n_pt = 0, n_obs = 0;
+  std::vector<int32_t> obs_cam, obs_pt;
+};
+static void ba_plan_cache_free(void* p) {
+  BaPlanCache* c = (BaPlanCache*)p;
+  if (!c) return;
+  sfmhip_ba_destroy(c->b);
+  delete c;
+}
+static bool ba_same_i32(const int32_t* a, const int32_t* c, int n) {
+  bool same = true;
+  std::vector<char> part((size_t)host_threads(n) + 1, 1);
+  host_parallel_for_t(n, host_threads(n), [&](int t, int lo, int hi) {
+    part[t] = memcmp(a + lo, c + lo, sizeof(int32_t) * (size_t)(hi - lo)) == 0;
+  });
+  for (char v : part) same = same && v;
+  return same;
+}
+
 extern "C" int sfmhip_ba_solve(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, double* cams6, double* pts3,
                                double* focal, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
                                const sfmhip_ba_opts* opts, sfmhip_ba_summary* summary) {
   if (!ctx || !cams6 || !focal) return SFMHIP_ERR_ARG;
+  using clk = std::chrono::steady_clock;
+  auto t0 = clk::now();
+  const auto tstart = t0;
+  auto lap = [&]() {
+    const auto now = clk::now();
+    const double ms = std::chrono::duration<double, std::milli>(now - t0).count();
+    t0 = now;
+    return ms;
+  };
+  sfmhip_ba_solve_profile& pr = ctx->ba_profile;
+  pr = sfmhip_ba_solve_profile{};
+  static const bool cache_on = !(getenv("SFMHIP_BA_PLAN_CACHE") && atoi(getenv("SFMHIP_BA_PLAN_CACHE")) == 0);
+  BaPlanCache* cache = (BaPlanCache*)ctx->ba_cache;
   sfmhip_ba* b = nullptr;
-  int rc = sfmhip_ba_create(ctx, n_cam, n_pt, n_obs, obs_cam, obs_pt, obs_xy, &b);
+  int rc = SFMHIP_OK;
+  if (cache_on && cache && cache->b && cache->n_cam == n_cam && cache->n_pt == n_pt && cache->n_obs == n_obs && n_obs > 0 &&
+      obs_cam && obs_pt && obs_xy && ba_same_i32(cache->obs_cam.data(), obs_cam, n_obs) &&
+      ba_same_i32(cache->obs_pt.data(), obs_pt, n_obs)) {
+    b = cache->b;
+    pr.plan_reused = 1;
+    b->spin_timeouts = 0;
+    rc = ba_set_observations(b, obs_xy);
+  } else {
+    if (cache) {  // another structure: the kept problem goes first (its buffers may be what the new one needs room for)
+      sfmhip_ba_destroy(cache->b);
+      cache->b = nullptr;
+    }
+    rc = sfmhip_ba_create(ctx, n_cam, n_pt, n_obs, obs_cam, obs_pt, obs_xy, &b);
+  }
+  pr.create_ms = lap();
   if (rc == SFMHIP_OK) rc = sfmhip_ba_set_params(b, cams6, pts3, *focal);
+  pr.set_params_ms = lap();
   if (rc == SFMHIP_OK) rc = sfmhip_ba_run(b, opts, summary);
+  pr.run_ms = lap();
   if (rc == SFMHIP_OK) rc = sfmhip_ba_get_params(b, cams6, pts3, focal);
-  sfmhip_ba_destroy(b);
+  pr.get_params_ms = lap();
+  if (rc == SFMHIP_OK && cache_on && n_obs > 0) {
+    if (!pr.plan_reused) {
+      if (!cache) {
+        cache = new BaPlanCache();
+        ctx->ba_cache = cache;
+        ctx->ba_cache_free = ba_plan_cache_free;
+      }
+      cache->b = b;
+      cache->n_cam = n_cam, cache->n_pt = n_pt, cache->n_obs = n_obs;
+      cache->obs_cam.assign(obs_cam, obs_cam + n_obs);
+      cache->obs_pt.assign(obs_pt, obs_pt + n_obs);
+    }
+  } else {
+    if (cache && cache->b == b) cache->b = nullptr;  // (a failed solve is not kept)
+    sfmhip_ba_destroy(b);
+  }
+  pr.keep_ms = lap();
+  pr.total_ms = std::chrono::duration<double, std::milli>(clk::now() - tstart).count();
   return rc;
+}
+
+extern "C" int sfmhip_ba_last_solve_profile(sfmhip_ctx* ctx, sfmhip_ba_solve_profile* out) {
+  if (!ctx || !out) return SFMHIP_ERR_ARG;
+  *out = ctx->ba_profile;
+  return SFMHIP_OK;
 }

@@ -42,6 +42,10 @@ struct sfmhip_ctx {
   // with the context
   std::vector<sfmhip_ctx*> workers;
   int score_flags = 0;  // OR of the five-point samples' flags of the last sfmhip_score_essential call (score.hip)
+  // sfmhip_ba_solve (ba.hip): where the last call's time went, and the problem it keeps for a next call of the same structure
+  sfmhip_ba_solve_profile ba_profile = {};
+  void* ba_cache = nullptr;
+  void (*ba_cache_free)(void*) = nullptr;
 };
 
 int sfm_ctx_pinned(sfmhip_ctx* ctx, size_t bytes, void** out);

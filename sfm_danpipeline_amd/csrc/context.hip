@@ -76,6 +76,8 @@ extern "C" void sfmhip_shutdown(sfmhip_ctx* ctx) {
   ctx->workers.clear();
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  if (ctx->ba_cache && ctx->ba_cache_free) ctx->ba_cache_free(ctx->ba_cache);  // (the problem sfmhip_ba_solve kept for a next call)
+  ctx->ba_cache = nullptr;
   if (ctx->pinned) hipHostFree(ctx->pinned);
   for (void* p : ctx->dev_scratch)
     if (p) hipFree(p);

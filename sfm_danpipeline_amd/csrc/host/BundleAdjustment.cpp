@@ -1,14 +1,40 @@
 // BundleAdjustment.cpp -- adjustBundle over the sfmhip C ABI.  Mirrors the policies of the
 // reference's src/BundleAdjustment.cpp:46-175; the solve itself runs on the MI355X.
 #include "BundleAdjustment.h"
+#include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <iostream>
+#include <thread>
+#include "ba_profile.h"
 #include "hip_backend.h"
 #include "sfmhip.h"
 
 namespace {
+
+thread_local SfmBaCallProfile g_profile;
+int g_test_max_iterations = -1;
+double g_test_max_time_s = -1.0;
+
+// [0, n) cut over a few host threads (the containers are read-only here): walking 10^5 std::map tracks is a chain of cache
+// misses on one core -- 8 ms at cfg4, most of what the call costs beside the solve
+template <typename F>
+void parallel_blocks(int n, F fn) {
+  const int hw = (int)std::thread::hardware_concurrency();
+  const int nth = n < 20000 ? 1 : std::max(1, std::min(hw > 0 ? hw : 1, 16));
+  if (nth == 1) {
+    fn(0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nth; ++t) {
+    const int lo = (int)((long long)n * t / nth), hi = (int)((long long)n * (t + 1) / nth);
+    th.emplace_back([=, &fn]() { fn(lo, hi); });
+  }
+  for (auto& x : th) x.join();
+}
 
 // ceres::RotationMatrixToAngleAxis of the rotation part of a pose (R(i,j) = pose(i,j))
 void pose_to_angle_axis(const cv::Matx34d& P, double aa[3]) {
@@ -69,9 +95,18 @@ void angle_axis_to_pose(const double aa[3], cv::Matx34d& P) {
 
 }  // namespace
 
+const SfmBaCallProfile& sfm_ba_last_call_profile() { return g_profile; }
+void sfm_ba_set_test_limits(int max_iterations, double max_time_s) {
+  g_test_max_iterations = max_iterations;
+  g_test_max_time_s = max_time_s;
+}
+
 void BundleAdjustment::adjustBundle(std::vector<Point3D>& pointCloud, std::vector<cv::Matx34d>& cameraPoses,
                                     Intrinsics& intrinsics,
                                     const std::vector<std::vector<cv::Point2d>>& image2dFeatures) {
+  using clk = std::chrono::steady_clock;
+  const auto t_start = clk::now();
+  auto ms_since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
   const int n_cam = (int)cameraPoses.size(), n_pt = (int)pointCloud.size();
   std::vector<double> cams6(6 * (size_t)n_cam, 0.0);
   std::vector<char> empty(n_cam, 0);
@@ -86,31 +121,47 @@ void BundleAdjustment::adjustBundle(std::vector<Point3D>& pointCloud, std::vecto
   }
   double focal = intrinsics.K.at<double>(0, 0);
   const double cx = intrinsics.K.at<double>(0, 2), cy = intrinsics.K.at<double>(1, 2);
+  // one residual block per (view, feature) of every track, point-major in std::map order (src/BundleAdjustment.cpp:83-110):
+  // the tracks' sizes give every point its place in the flat arrays, then the points are walked side by side
   std::vector<double> pts3(3 * (size_t)n_pt);
-  std::vector<int32_t> obs_cam, obs_pt;
-  std::vector<double> obs_xy;
-  for (int i = 0; i < n_pt; ++i) {
-    const Point3D& p = pointCloud[i];
-    pts3[3 * (size_t)i] = p.pt.x;
-    pts3[3 * (size_t)i + 1] = p.pt.y;
-    pts3[3 * (size_t)i + 2] = p.pt.z;
-    for (const auto& kv : p.idxImage) {  // (view, 2-D feature index)
-      const cv::Point2d& f = image2dFeatures[kv.first][kv.second];
-      obs_cam.push_back(kv.first);
-      obs_pt.push_back(i);
-      obs_xy.push_back(f.x - cx);  // the optimiser does not know the principal point
-      obs_xy.push_back(f.y - cy);
+  std::vector<size_t> first(n_pt + 1, 0);
+  for (int i = 0; i < n_pt; ++i) first[i + 1] = first[i] + pointCloud[i].idxImage.size();
+  const size_t n_obs = first[n_pt];
+  std::vector<int32_t> obs_cam(n_obs), obs_pt(n_obs);
+  std::vector<double> obs_xy(2 * n_obs);
+  parallel_blocks(n_pt, [&](int lo, int hi) {
+    for (int i = lo; i < hi; ++i) {
+      const Point3D& p = pointCloud[i];
+      pts3[3 * (size_t)i] = p.pt.x;
+      pts3[3 * (size_t)i + 1] = p.pt.y;
+      pts3[3 * (size_t)i + 2] = p.pt.z;
+      size_t w = first[i];
+      for (const auto& kv : p.idxImage) {  // (view, 2-D feature index)
+        const cv::Point2d& f = image2dFeatures[kv.first][kv.second];
+        obs_cam[w] = kv.first;
+        obs_pt[w] = i;
+        obs_xy[2 * w] = f.x - cx;  // the optimiser does not know the principal point
+        obs_xy[2 * w + 1] = f.y - cy;
+        ++w;
+      }
     }
-  }
+  });
   sfmhip_ba_opts opts;
   sfmhip_ba_default_opts(&opts);  // DENSE_SCHUR LM, 500 iterations, 10 s
-  // (test switches, never set by the product: the reference's two limits, src/BundleAdjustment.cpp:118,120, made reachable
-  // on problems that converge in milliseconds -- tests/test_gpu_host_cpp.py checks that nothing is written back behind them)
-  if (const char* e = std::getenv("SFM_BA_TEST_MAX_ITERATIONS")) opts.max_iterations = std::atoi(e);
-  if (const char* e = std::getenv("SFM_BA_TEST_MAX_TIME_S")) opts.max_time_s = std::atof(e);
+  // (test hook, never set by the product -- ba_profile.h: the reference's two limits made reachable on problems that
+  // converge in milliseconds; tests/test_gpu_host_cpp.py checks that nothing is written back behind them)
+  if (g_test_max_iterations >= 0) opts.max_iterations = g_test_max_iterations;
+  if (g_test_max_time_s >= 0.0) opts.max_time_s = g_test_max_time_s;
+  g_profile = SfmBaCallProfile();
+  g_profile.n_cam = n_cam, g_profile.n_pt = n_pt, g_profile.n_obs = (int)n_obs;
+  g_profile.pack_ms = ms_since(t_start);
+  const auto t_solve = clk::now();
   sfmhip_ba_summary summary;
-  const int rc = sfmhip_ba_solve(sfm_hip_context(), n_cam, n_pt, (int)obs_cam.size(), cams6.data(), pts3.data(), &focal,
+  const int rc = sfmhip_ba_solve(sfm_hip_context(), n_cam, n_pt, (int)n_obs, cams6.data(), pts3.data(), &focal,
                                  obs_cam.data(), obs_pt.data(), obs_xy.data(), &opts, &summary);
+  g_profile.solve_ms = ms_since(t_solve);
+  sfmhip_ba_last_solve_profile(sfm_hip_context(), &g_profile.solve);
+  g_profile.total_ms = ms_since(t_start);
   if (rc != SFMHIP_OK) {
     std::cerr << "Bundle adjustment failed: " << sfmhip_error_string(rc) << std::endl;
     return;
@@ -121,6 +172,7 @@ void BundleAdjustment::adjustBundle(std::vector<Point3D>& pointCloud, std::vecto
     std::cerr << "Bundle adjustment failed." << std::endl;  // results are discarded, inputs untouched
     return;
   }
+  const auto t_wb = clk::now();
   intrinsics.K.at<double>(0, 0) = focal;
   intrinsics.K.at<double>(1, 1) = focal;
   for (int i = 0; i < n_cam; ++i) {
@@ -134,4 +186,6 @@ void BundleAdjustment::adjustBundle(std::vector<Point3D>& pointCloud, std::vecto
     pointCloud[i].pt.y = pts3[3 * (size_t)i + 1];
     pointCloud[i].pt.z = pts3[3 * (size_t)i + 2];
   }
+  g_profile.writeback_ms = ms_since(t_wb);
+  g_profile.total_ms = ms_since(t_start);
 }

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <vector>
 #include "BundleAdjustment.h"
+#include "ba_profile.h"
 
 template <typename T>
 static void rd(FILE* f, T* p, size_t n) {
@@ -51,7 +52,51 @@ int main(int argc, char** argv) {
     cloud[pt].idxImage[view] = (int)feats[view].size();
     feats[view].push_back(cv::Point2d(xy[2 * (size_t)o], xy[2 * (size_t)o + 1]));
   }
-  BundleAdjustment::adjustBundle(cloud, poses, K, feats);
+  // test switches of THIS executable (the mirror itself reads no environment): the reference's two limits made reachable,
+  // and SFM_BA_SELFTEST_CALLS = n: the call repeated on fresh copies of the containers (what a caller that adjusts the same
+  // structure again sees: the second call re-uses the first one's plan), a profile line per call on stdout
+  {
+    int mi = -1;
+    double mt = -1.0;
+    if (const char* e = getenv("SFM_BA_TEST_MAX_ITERATIONS")) {
+      char* end = nullptr;
+      const long v = strtol(e, &end, 10);
+      if (end == e || *end || v < 0) {
+        fprintf(stderr, "ba_selftest: SFM_BA_TEST_MAX_ITERATIONS=%s is not a count\n", e);
+        return 2;
+      }
+      mi = (int)v;
+    }
+    if (const char* e = getenv("SFM_BA_TEST_MAX_TIME_S")) {
+      char* end = nullptr;
+      const double v = strtod(e, &end);
+      if (end == e || *end || !(v >= 0)) {
+        fprintf(stderr, "ba_selftest: SFM_BA_TEST_MAX_TIME_S=%s is not a duration\n", e);
+        return 2;
+      }
+      mt = v;
+    }
+    sfm_ba_set_test_limits(mi, mt);
+  }
+  const int calls = getenv("SFM_BA_SELFTEST_CALLS") ? atoi(getenv("SFM_BA_SELFTEST_CALLS")) : 1;
+  const std::vector<Point3D> cloud0 = cloud;
+  const std::vector<cv::Matx34d> poses0 = poses;
+  const double f0 = K.K.at<double>(0, 0);
+  for (int c = 0; c < (calls > 1 ? calls : 1); ++c) {
+    if (c) {
+      cloud = cloud0;
+      poses = poses0;
+      K.K.at<double>(0, 0) = f0;
+      K.K.at<double>(1, 1) = f0;
+    }
+    BundleAdjustment::adjustBundle(cloud, poses, K, feats);
+    const SfmBaCallProfile& p = sfm_ba_last_call_profile();
+    printf("{\"call\": %d, \"n_cam\": %d, \"n_pt\": %d, \"n_obs\": %d, \"pack_ms\": %.3f, \"create_ms\": %.3f, \"set_params_ms\": %.3f, "
+           "\"run_ms\": %.3f, \"get_params_ms\": %.3f, \"keep_ms\": %.3f, \"solve_ms\": %.3f, \"writeback_ms\": %.3f, \"total_ms\": %.3f, "
+           "\"plan_reused\": %d}\n",
+           c, p.n_cam, p.n_pt, p.n_obs, p.pack_ms, p.solve.create_ms, p.solve.set_params_ms, p.solve.run_ms, p.solve.get_params_ms,
+           p.solve.keep_ms, p.solve_ms, p.writeback_ms, p.total_ms, p.solve.plan_reused);
+  }
   FILE* o = fopen(argv[2], "wb");
   if (!o) return 2;
   fwrite(K.K.data.data(), sizeof(double), 9, o);

@@ -28,6 +28,7 @@
 //    integers) -- they are flagged in-band, so there is no list that could overflow.
 //  * compaction kernel: ratio test (float multiply + compare) and order-preserving compaction.
 #include "common.h"
+#include <type_traits>
 #include <vector>
 #include <algorithm>
 #include <string.h>
@@ -51,6 +52,9 @@ constexpr int FIX_CAP = 1 << 20;     // flagged queries that are also LISTED, fo
                                      // beyond it they stay flagged in-band and the compaction kernel redoes them
 constexpr int DIST_EMPTY = 0x7FFFFFFF;
 constexpr int HCHUNK = 128;  // Hamming kernel: rows per tie-break chunk (7 index bits in the key)
+#ifndef SFM_RESOLVE_V2
+#define SFM_RESOLVE_V2 1  // 0: the lanes with two slots at the threshold recompute all four rows (the form of rounds 2-5; A/B builds)
+#endif
 #ifndef SFM_DBG
 #define SFM_DBG 0  // diagnostic builds (scripts/build_match_variants.py): 1 no candidate loop, 2 no epilogue, 3 no MFMA, 4 stamps, 5 no exact redo
 #endif
@@ -397,7 +401,8 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
   // s_waitcnt vmcnt(0) it otherwise puts in front of every ds_read that follows an LDS-DMA
   // (which would make the stage copy synchronous).  The stage loop is unrolled by two for it.
   // (resolve scratch per wave and query tile: 2 KB of lists + a copy of the query tile; tile u of a wave in buffer u)
-  constexpr int SCRATCH_W = 2048 + TILE_ROWS * RB;
+  // (... whose 16 x 64 slot maxima pass through the same bytes first: 4 KB at least)
+  constexpr int SCRATCH_W = 2048 + (TILE_ROWS * RB > 4096 ? TILE_ROWS * RB : 4096);
   constexpr int BUFA_BYTES = STAGE_BYTES > NW * SCRATCH_W ? STAGE_BYTES : NW * SCRATCH_W;
   constexpr int BUFB_BYTES = (NU < 2 || STAGE_BYTES > NW * SCRATCH_W) ? STAGE_BYTES : NW * SCRATCH_W;
   __shared__ __attribute__((aligned(16))) unsigned char ldsA[BUFA_BYTES];
@@ -621,21 +626,21 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
     typedef __attribute__((address_space(3))) int* lds_vi_p;
     // (one wave's LDS operations execute in order; the fences keep the compiler from moving them across a phase boundary)
 #define SFM_WAVE_LDS_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-    lds_vi_p wl[NU], wr[NU];  // packed list of the rows to recompute (256 entries), their values
+    // ONE packed list of the rows to recompute for the wave's NU query tiles (NU * 256 entries) and their values: the list in
+    // buffer 0's scratch, the values in buffer NU - 1's (NU == 1: behind the list)
     __attribute__((address_space(3))) unsigned char* wq[NU];  // the wave's query tile, in the tile image's layout
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      __attribute__((address_space(3))) unsigned char* ws =
-          (__attribute__((address_space(3))) unsigned char*)(u == 0 ? ldsA : ldsB) + wave * SCRATCH_W;
-      wl[u] = (lds_vi_p)ws;
-      wr[u] = wl[u] + 256;
-      wq[u] = ws + 2048;
-      // (the query rows are in registers, half a row per lane: through LDS every lane can reach any of them,
-      // and the recompute below reads half as many bytes from the vector cache)
+    for (int u = 0; u < NU; ++u)
+      wq[u] = (__attribute__((address_space(3))) unsigned char*)(u == 0 ? ldsA : ldsB) + wave * SCRATCH_W + 2048;
+    const lds_vi_p wl = (lds_vi_p)(wq[0] - 2048);
+    const lds_vi_p wr = NU == 1 ? wl + 256 : (lds_vi_p)(wq[NU - 1] - 2048);
+    // (the query rows are in registers, half a row per lane: through LDS every lane can reach any of them,
+    // and the recompute below reads half as many bytes from the vector cache)
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
         *(__attribute__((address_space(3))) v4i*)(wq[u] + chunk_pos<NC>(r_p, 2 * ks + h_p) * 16) = bq[u][ks];
-    }
     constexpr int SH = (NC == 16) ? 0 : (NC == 8) ? 1 : (NC == 4) ? 2 : 3;  // (the swizzle of chunk_pos)
     int cpos[NU][4], chv[NU][4], slot_[NU][4], count[NU];
     bool cval[NU][4], cload[NU][4];
@@ -655,45 +660,29 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
       const int tl0 = ep_tile0 + (EPOCH_TILES - 1) - (k0[u] & TAG_MASK);
       const int tl1 = ep_tile0 + (EPOCH_TILES - 1) - (k1[u] & TAG_MASK);
       const int pb0 = __shfl_xor(bv0, 32), pb1 = __shfl_xor(bv1, 32);
-      // second largest of the four tile maxima of the query's two lanes: four different rows, so a
-      // lower bound of the query's second-best h.  Rows below it are out.
-      int thr = max(min(bv0, pb0), max(bv1, pb1));
-      unsigned lta = 0, ltb = 0;  // bit 7-e / 7-(e-8): slot e stays below thr (two chains: shorter dependency)
+      // The three largest slot maxima of the lane WITH their slots: keys (maximum << 4 | slot), a running top-3 (3 ops per
+      // slot).  They give, without a mask over the sixteen slots and without indexing registers per lane, how many slots reach
+      // the threshold (more than two only matters as "more than two"), which slots those are, and their maxima S0 >= S1.
+      int a0 = (HPAD - 1) * 16, a1 = a0, a2 = a0;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        lta = __builtin_amdgcn_alignbit(lta, (unsigned)(sl[u][e] - thr), 31);
-        ltb = __builtin_amdgcn_alignbit(ltb, (unsigned)(sl[u][e + 8] - thr), 31);
+      for (int e = 0; e < 16; ++e) {
+        const int key = (int)((unsigned)sl[u][e] << 4) | e;  // (v_lshl_or_b32; |h| < 2^23)
+        a2 = imed3(a1, a2, key);
+        a1 = imed3(a0, a1, key);
+        a0 = max(a0, key);
       }
-      unsigned ge = ~((lta << 8) | ltb) & 0xFFFFu;  // bit 15-e: slot e reaches thr
-      if (__ballot(__popc(ge) > 2) != 0ull) {
-        // More than two slots reach thr -- typically the best two rows share a tile, which hides the
-        // second from the tile maxima.  The second largest slot maximum is another row's value, so
-        // it bounds the second-best h from below as well: tighten and redo the mask.
-        int a0 = HPAD - 1, a1 = HPAD - 1;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          a1 = imed3(a0, a1, sl[u][e]);
-          a0 = max(a0, sl[u][e]);
-        }
-        thr = max(thr, a1);
-        lta = ltb = 0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          lta = __builtin_amdgcn_alignbit(lta, (unsigned)(sl[u][e] - thr), 31);
-          ltb = __builtin_amdgcn_alignbit(ltb, (unsigned)(sl[u][e + 8] - thr), 31);
-        }
-        ge = ~((lta << 8) | ltb) & 0xFFFFu;
-      }
+      const int S0 = a0 >> 4, S1 = a1 >> 4, S2 = a2 >> 4;
+      const int e0 = a0 & 15, e1 = a1 & 15;
+      // thr: the second largest of the four tile maxima of the query's two lanes (four different rows: a lower bound of the
+      // query's second-best h) and the lane's second largest slot maximum (another row's value as well: when the best two rows
+      // share a tile, the tile maxima hide the second).  Rows below it are out.
+      const int thr = max(max(min(bv0, pb0), max(bv1, pb1)), S1);
+      const int ns = (S0 >= thr ? 1 : 0) + (S1 >= thr ? 1 : 0) + (S2 >= thr ? 1 : 0);  // slots that reach thr (3: three or more)
       // (a tile maximum of HPAD is a padding tile, the dummy drain or an empty slot: no candidates there)
       const bool t0in = bv0 >= thr && bv0 > HPAD, t1in = bv1 >= thr && bv1 > HPAD;
       // The rows >= thr of the lane lie in (tiles tl0, tl1) x (slots that reach thr).  Two slots are
-      // resolved; more (only equal values do that now) sends the query to the exact kernel.
-      const int ns = __popc(ge);
-      const int bA = 31 - __clz((int)(ge | 1u));
-      const unsigned ge2 = ge & ~(1u << bA);
-      const int bB = ns >= 2 ? 31 - __clz((int)ge2) : bA;
-      const int eA = 15 - bA, eB = 15 - bB;
-      const int rhoA = 8 * (eA >> 2) + 4 * h_p + (eA & 3), rhoB = 8 * (eB >> 2) + 4 * h_p + (eB & 3);
+      // resolved; more (only equal values do that) sends the query to the exact kernel.
+      const int rho0 = 8 * (e0 >> 2) + 4 * h_p + (e0 & 3), rho1 = ns >= 2 ? 8 * (e1 >> 2) + 4 * h_p + (e1 & 3) : rho0;
       int over = (ns > 2 && (t0in || t1in)) ? 1 : 0;
       over |= __shfl_xor(over, 32);
       ovf[u] = over;
@@ -701,10 +690,10 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
       // thr has that maximum in this slot -- row and value are known.  (tl0 is the first tile that
       // reaches the lane's maximum, tl1 the first other tile that reaches bv1.)
       const bool known = ns == 1;
-      cpos[u][0] = tl0 * TILE_ROWS + rhoA;
-      cpos[u][1] = tl0 * TILE_ROWS + rhoB;
-      cpos[u][2] = tl1 * TILE_ROWS + rhoA;
-      cpos[u][3] = tl1 * TILE_ROWS + rhoB;
+      cpos[u][0] = tl0 * TILE_ROWS + rho0;
+      cpos[u][1] = tl0 * TILE_ROWS + rho1;
+      cpos[u][2] = tl1 * TILE_ROWS + rho0;
+      cpos[u][3] = tl1 * TILE_ROWS + rho1;
       cval[u][0] = t0in && ns >= 1;
       cval[u][1] = t0in && ns >= 2;
       cval[u][2] = t1in && ns >= 1;
@@ -713,30 +702,59 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
       chv[u][1] = HPAD - 1;
       chv[u][2] = known ? bv1 : HPAD - 1;
       chv[u][3] = HPAD - 1;
+      bool need[4] = {!known, !known, !known, !known};
+      // Two slots reach thr, with DIFFERENT maxima S0 > S1 (slots e0, e1).  The lane's maximum bv0 = S0 is row (tl0, e0):
+      // tile tl0 holds bv0 in a slot whose maximum reaches it, and only e0's does.  The lane's second row then has the value
+      // max(S1, bv1), and where it sits follows from the four maxima, except when S1 == bv1 =: v (the usual case -- the second
+      // row is its slot's AND its tile's maximum):
+      //   S1 > bv1: no other tile reaches S1, so e1's maximum sits in tile tl0: row (tl0, e1), value S1;
+      //   S1 < bv1: tile tl1's maximum exceeds e1's, so it sits in slot e0: row (tl1, e0), value bv1;
+      //   S1 == v:  the rows that can hold v before any other row does are (tl0, e1) -- when tile tl0 comes before tl1 -- and, in
+      //             tile tl1, slots e0 and e1, of which at least one holds v (the tile's maximum sits in a slot that reaches
+      //             it): the EARLIER of the two rows is recomputed, and the later one is entered WITH the value v -- if the
+      //             earlier holds v it precedes the later in the ranking whatever that really holds, and if it does not, the
+      //             later does.  (tl0, e1) is recomputed when tl0 < tl1, and cannot be the second row otherwise.
+      // One or two rows are read where the four of (tl0, tl1) x (e0, e1) used to be (22 rows per query tile at cfg2 instead of
+      // 60); equal slot maxima keep the four.
+#if SFM_RESOLVE_V2
+      if (ns == 2 && S0 != S1 && t0in) {
+        const bool gt = S1 > bv1, eq = S1 == bv1, lt = S1 < bv1;
+        const bool e1_in = gt || (eq && tl0 < tl1);  // row (tl0, e1) can be the lane's second row
+        const bool first0 = rho0 < rho1;             // of tile tl1's two rows, slot e0's comes first
+        cval[u][0] = true, chv[u][0] = bv0, need[0] = false;
+        cval[u][1] = e1_in, chv[u][1] = S1, need[1] = e1_in && !gt;
+        cval[u][2] = eq || lt, chv[u][2] = bv1, need[2] = eq && first0;
+        cval[u][3] = eq, chv[u][3] = bv1, need[3] = eq && !first0;
+      }
+#endif
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         cval[u][k] = cval[u][k] && cpos[u][k] < T.n_pad;
-        cload[u][k] = cval[u][k] && !known && SFM_DBG != 1;
+        cload[u][k] = cval[u][k] && need[k] && SFM_DBG != 1;
       }
     }
     SFM_STAMP(8);
     // phase B: pack the rows to recompute into the wave's list
+    int total = 0;  // wave-uniform
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      int base = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const unsigned long long bm = __ballot(cload[u][k]);
-        slot_[u][k] = base + __popcll(bm & ((1ull << lane_p) - 1ull));
-        if (cload[u][k]) wl[u][slot_[u][k]] = cpos[u][k] | (r_p << 27);
-        base += __popcll(bm);
+        slot_[u][k] = total + __popcll(bm & ((1ull << lane_p) - 1ull));
+        // entry: position (26 bits: a tile image stays below 2 GB) | the query's row in its tile << 26 | query tile << 31
+        if (cload[u][k]) wl[slot_[u][k]] = cpos[u][k] | (r_p << 26) | (u << 31);
+        total += __popcll(bm);
       }
-      count[u] = base;  // wave-uniform
+      count[u] = total;
     }
     SFM_WAVE_LDS_FENCE();
     SFM_STAMP(9);
 #if SFM_DBG == 4
-    if (blockIdx.x < 4096 && lane == 0) g_stamps[(blockIdx.x * 8 + wave) * 16 + 13] = count[0];
+    if (blockIdx.x < 4096 && lane == 0) {
+      g_stamps[(blockIdx.x * 8 + wave) * 16 + 13] = count[0];
+      g_stamps[(blockIdx.x * 8 + wave) * 16 + 7] = total - count[0];
+    }
 #endif
     // phase C: the listed rows are recomputed LPR lanes to a row, two 16-byte chunks per lane (a row's lanes
     // read one cache line together: the texture addresser, not the arithmetic, bounds this phase).  Train
@@ -748,48 +766,53 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
       constexpr int RPS = 64 / LPR;              // rows per step
       constexpr int STEPS = 64 / RPS;            // steps that cover 64 rows
       const int grp = lane_p / LPR, c = lane_p % LPR;
-      int cmax = count[0];
+      // a trip of NS steps (16 rows of the list per step at KS = 4): every load of the trip is issued before its first use
+      auto trip = [&](int j0, auto ns_) __attribute__((always_inline)) {
+        constexpr int NS = decltype(ns_)::value;
+        v4i xt[NS][CPL], xq[NS][CPL];
+        int ci[NS];
 #pragma unroll
-      for (int u = 1; u < NU; ++u) cmax = max(cmax, count[u]);
-      for (int j0 = 0; j0 < cmax; j0 += 64) {
-        v4i xt[NU][STEPS][CPL], xq[NU][STEPS][CPL];
-        int ci[NU][STEPS];
+        for (int st = 0; st < NS; ++st) {
+          const int j = j0 + st * RPS + grp;
+          unsigned ent = (unsigned)wl[j & (NU * 256 - 1)];  // position | query row << 26 | query tile << 31
+          if (j >= total) ent = 0u;                          // (row 0 of the image: fetched, not used)
+          const unsigned ps = ent & ((1u << 26) - 1u), qr = (ent >> 26) & 31u;
+          const unsigned x = ((ps >> SH) ^ (qr >> SH)) & (unsigned)(NC - 1);
+          const unsigned char* trow = (const unsigned char*)T.tiles + ps * (unsigned)RB;
+          const __attribute__((address_space(3))) unsigned char* qrw = ((NU > 1 && (ent >> 31)) ? wq[NU - 1] : wq[0]) + qr * (unsigned)RB;
 #pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-          for (int st = 0; st < STEPS; ++st) {
-            const int j = j0 + st * RPS + grp;
-            unsigned ent = (unsigned)wl[u][j & 255];  // position | query row << 27
-            if (j >= count[u]) ent = 0u;              // (row 0 of the image: fetched, not used)
-            const unsigned ps = ent & ((1u << 27) - 1u), qr = ent >> 27;
-            const unsigned x = ((ps >> SH) ^ (qr >> SH)) & (unsigned)(NC - 1);
-            const unsigned char* trow = (const unsigned char*)T.tiles + ps * (unsigned)RB;
-            const __attribute__((address_space(3))) unsigned char* qrw = wq[u] + qr * (unsigned)RB;
-#pragma unroll
-            for (int i = 0; i < CPL; ++i) {
-              const unsigned p_ = (unsigned)(c + i * LPR);
-              xt[u][st][i] = *(g_v4i_p)(trow + p_ * 16);
-              xq[u][st][i] = *(const __attribute__((address_space(3))) v4i*)(qrw + ((p_ ^ x) << 4));
-            }
-            ci[u][st] = ((g_i32_p)T.cin)[ps];
+          for (int i = 0; i < CPL; ++i) {
+            const unsigned p_ = (unsigned)(c + i * LPR);
+            xt[st][i] = *(g_v4i_p)(trow + p_ * 16);
+            xq[st][i] = *(const __attribute__((address_space(3))) v4i*)(qrw + ((p_ ^ x) << 4));
           }
+          ci[st] = ((g_i32_p)T.cin)[ps];
+        }
         SFM_STAMP(11);
 #if SFM_DBG == 4
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         SFM_STAMP(12);
 #endif
 #pragma unroll
-        for (int u = 0; u < NU; ++u)
+        for (int st = 0; st < NS; ++st) {
+          int dot = 0;
 #pragma unroll
-          for (int st = 0; st < STEPS; ++st) {
-            int dot = 0;
+          for (int i = 0; i < CPL; ++i)
 #pragma unroll
-            for (int i = 0; i < CPL; ++i)
-#pragma unroll
-              for (int w = 0; w < 4; ++w) dot = __builtin_amdgcn_sdot4(xt[u][st][i][w], xq[u][st][i][w], dot, false);
-            dot = group_sum<LPR>(dot) + ci[u][st];
-            wr[u][(j0 + st * RPS + grp) & 255] = dot;  // (every lane of the group writes the same value)
-          }
+            for (int w = 0; w < 4; ++w) dot = __builtin_amdgcn_sdot4(xt[st][i][w], xq[st][i][w], dot, false);
+          dot = group_sum<LPR>(dot) + ci[st];
+          wr[(j0 + st * RPS + grp) & (NU * 256 - 1)] = dot;  // (every lane of the group writes the same value)
+        }
+      };
+      // (the last trip takes the steps the list still needs -- a wave-uniform choice between unrolled bodies; a guard per step
+      // inside one body turns the fragments into loop-carried values the compiler keeps alive across the SWEEP: scratch)
+      for (int j0 = 0; j0 < total; j0 += RPS * STEPS) {
+        ++dbg_trips;
+        const int left = total - j0;
+        if (STEPS >= 4 && left <= RPS * (STEPS / 4)) trip(j0, std::integral_constant<int, (STEPS >= 4 ? STEPS / 4 : 1)>{});
+        else if (STEPS >= 2 && left <= RPS * (STEPS / 2)) trip(j0, std::integral_constant<int, (STEPS >= 2 ? STEPS / 2 : 1)>{});
+        else if (STEPS >= 4 && left <= RPS * (3 * STEPS / 4)) trip(j0, std::integral_constant<int, (STEPS >= 4 ? 3 * STEPS / 4 : 1)>{});
+        else trip(j0, std::integral_constant<int, STEPS>{});
       }
     }
     SFM_WAVE_LDS_FENCE();
@@ -806,7 +829,7 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
       long long key[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (cload[u][k]) chv[u][k] = wr[u][slot_[u][k]];
+        if (cload[u][k]) chv[u][k] = wr[slot_[u][k]];
         const int hv = cval[u][k] ? chv[u][k] : HPAD - 1;
         key[k] = ((long long)hv << 32) | (unsigned)(0x7FFFFFFF - cpos[u][k]);  // larger = better
       }
@@ -1764,6 +1787,10 @@ extern "C" int sfmhip_imageset_create(sfmhip_ctx* ctx, int n_images, const int32
     // L2 kinds store the rows in parity order, the odd class padded to a tile boundary: up to 31 more positions
     const int need = n_rows[i] ? n_rows[i] + (s->kind == KIND_U8_HAMMING ? 0 : TILE_ROWS - 1) : 0;
     const int pad = (need + s->sr - 1) / s->sr * s->sr;
+    if ((size_t)pad * rb >= (1ull << 31)) {  // (one image's tile image is addressed by 31-bit offsets, its positions fit 26 bits)
+      delete s;
+      return SFMHIP_ERR_ARG;
+    }
     s->n_pad.push_back(pad);
     s->maxq = std::max(s->maxq, n_rows[i]);
     tile_first[i] = (int)tile_img.size();

@@ -110,3 +110,62 @@ class StagedAllReduce(TorchAllReduce):
         self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
         v.copy_(h)
         self.torch.cuda.synchronize()
+
+
+class InProcessRanks:
+    """N LOGICAL ranks of the sharded bundle adjustment in one process on one device, a host thread per rank: the sum of the
+    ranks' buffers is formed on the device, in rank order, by whichever thread arrives last at the meeting point -- every rank
+    gets the same bits back, as after an RCCL all-reduce.  For functional runs of the world = 4 / 8 split on a one-GPU box
+    (tests, bench.py's measured shard times); synchronous, not a performance path."""
+
+    def __init__(self, world, device="cuda:0"):
+        import threading
+        import torch
+        self.torch, self.world = torch, int(world)
+        self._barrier = threading.Barrier(self.world)
+        self._bufs = [None] * self.world
+        self._views = TorchAllReduce(device=device)
+        self.counts = [[] for _ in range(self.world)]  # (tests look at the sizes of the exchanges)
+
+    def allreduce(self, rank, ctx):
+        """The callable rank `rank` hands to BaProblem.set_allreduce; `ctx` is that rank's Context (its stream is drained
+        before the buffers meet)."""
+        def fn(ptr, count):
+            ctx.synchronize()
+            self._bufs[rank] = (int(ptr), int(count))
+            self.counts[rank].append(int(count))
+            if self._barrier.wait() == 0:  # (one thread of the party adds; which one does not matter: the order is the ranks')
+                views = [self._views._view(p, c) for p, c in self._bufs]
+                assert len({c for _, c in self._bufs}) == 1, f"ranks disagree on an exchange: {self._bufs}"
+                tot = views[0].clone()
+                for v in views[1:]:
+                    tot += v
+                for v in views:
+                    v.copy_(tot)
+                self.torch.cuda.synchronize()
+            self._barrier.wait()
+        return fn
+
+    def run(self, target):
+        """target(rank) on a thread per rank; returns the list of results in rank order, re-raises the first failure."""
+        import threading
+        out, err = [None] * self.world, [None] * self.world
+
+        def body(r):
+            try:
+                out[r] = target(r)
+            except BaseException as e:  # noqa: BLE001 -- a failed rank must not leave the others waiting
+                err[r] = e
+                self._barrier.abort()
+        ts = [threading.Thread(target=body, args=(r,)) for r in range(self.world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for e in err:
+            if e is not None and not isinstance(e, __import__("threading").BrokenBarrierError):
+                raise e
+        for e in err:
+            if e is not None:
+                raise e
+        return out

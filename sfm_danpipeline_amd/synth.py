@@ -174,3 +174,35 @@ def pair_checksums(counts, oq, ot, od):
                 cs[p, 0] = np.sum(seg, dtype=np.uint64)
                 cs[p, 1] = np.bitwise_xor.reduce(seg)
     return cs
+
+
+def _aa_to_rotation(aa):
+    """Rodrigues' formula (generator-side only: the containers below want [R|t])."""
+    th = np.linalg.norm(aa)
+    if th == 0:
+        return np.eye(3)
+    k = aa / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+
+
+def write_ba_containers(path, pb, cx, cy):
+    """A ba_problem in the binary layout csrc/host/ba_selftest.cpp reads into the REFERENCE's containers (cv::Matx34d poses,
+    Point3D cloud with std::map tracks, Intrinsics, per-view feature lists -- the arguments of BundleAdjustment::adjustBundle,
+    include/BundleAdjustment.h:19-20): i32 n_cam, n_pt, n_obs | poses [R|t] | points | K | (view, point) per observation |
+    pixel coordinates with the principal point added back.  Returns (poses, K) as written."""
+    import struct
+    nc, npt, no = pb["n_cam"], pb["n_pt"], pb["n_obs"]
+    poses = np.zeros((nc, 3, 4))
+    for i in range(nc):
+        poses[i, :, :3] = _aa_to_rotation(pb["cams0"][i, :3])
+        poses[i, :, 3] = pb["cams0"][i, 3:]
+    K = np.array([[pb["focal0"], 0, cx], [0, pb["focal0"], cy], [0, 0, 1.0]])
+    with open(path, "wb") as f:
+        f.write(struct.pack("<iii", nc, npt, no))
+        f.write(poses.astype("<f8").tobytes())
+        f.write(pb["pts0"].astype("<f8").tobytes())
+        f.write(K.astype("<f8").tobytes())
+        f.write(np.stack([pb["obs_cam"], pb["obs_pt"]], axis=1).astype("<i4").tobytes())
+        f.write((pb["obs_xy"] + np.array([cx, cy])).astype("<f8").tobytes())
+    return poses, K

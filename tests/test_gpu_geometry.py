@@ -600,6 +600,65 @@ def test_two_ranks_share_the_device_and_run_the_sharded_solver(ctx, tmp_path, mo
     assert np.allclose(np.concatenate([r0["p"], r1["p"]]), p1, rtol=1e-8, atol=1e-9)
 
 
+def _logical_ranks_solve(pb, world, opts=None, iterate=None):
+    """BASELINE cfg4's split, `world` logical ranks on the one device: a BaProblem per rank over its point block (all cameras, the
+    focal), a context + stream + host thread each, the exchange summed on the device in rank order (sharding.InProcessRanks)."""
+    from sfm_danpipeline_amd import _lib as L, sharding
+    nc = pb["n_cam"]
+    grp = sharding.InProcessRanks(world)
+
+    def rank(r):
+        c = L.Context(0)
+        loc = sharding.local_ba_problem(pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], pb["pts0"], r, world)
+        prob = bundle.BaProblem(nc, len(loc["pts"]), loc["obs_cam"], loc["obs_pt"], loc["obs_xy"], ctx=c)
+        prob.set_allreduce(grp.allreduce(r, c), r, world)
+        prob.set_params(pb["cams0"], loc["pts"], pb["focal0"])
+        s = prob.iterate(iterate) if iterate is not None else prob.run(opts or bundle.default_opts())
+        cams, pts, f = prob.get_params()
+        tree = prob.reduced_tree()
+        prob.close()
+        c.close()
+        return dict(s=s, c=cams, p=pts, f=f, lo=loc["lo"], hi=loc["hi"], tree=tree)
+    return grp.run(rank), grp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [4, 8])
+def test_cfg4_eight_logical_ranks_walk_the_single_rank_solve(ctx, world):
+    """BASELINE cfg4 as it is stated -- 200 cameras / 100 000 points / 10^6 observations, "point-block sharded across 8 x MI355X
+    with RCCL all-reduce of camera normal equations" (reference src/BundleAdjustment.cpp:83-123 is what gets sharded) -- with the
+    eight (and four) ranks LOGICAL: eight problems in one process on the one device, each holding an eighth of the points, the
+    sparse exchange list rebuilt for world = 8, eight packed buffers summed per linearisation.  Run to termination with the
+    reference's options: termination type, iterations and accepted steps equal to the single-rank solve, cost to 1e-9, parameters
+    to 1e-6, the replicated cameras and focal bitwise equal between the ranks ("world = 1, 2, 4, 8 logical
+    shards on one device")."""
+    pb = synth.ba_problem(200, 100000, 10, seed=777)
+    c1, p1, f1, s1 = bundle.ba_solve(*_ba_args(pb), opts=bundle.default_opts(), ctx=ctx)
+    assert s1.termination == _lib.BA_CONVERGENCE
+    res, grp = _logical_ranks_solve(pb, world)
+    for r in res:
+        s = r["s"]
+        assert (s.termination, s.iterations, s.successful_steps) == (s1.termination, s1.iterations, s1.successful_steps), \
+            (world, s.termination, s.iterations, s.successful_steps, s1.iterations, s1.successful_steps)
+        assert abs(s.final_cost - s1.final_cost) <= 1e-9 * s1.final_cost and abs(s.initial_cost - s1.initial_cost) <= 1e-12 * s1.initial_cost
+        assert np.allclose(r["c"], c1, rtol=1e-6, atol=1e-9) and abs(r["f"] - f1) <= 1e-6 * f1
+        assert np.array_equal(r["c"], res[0]["c"]) and r["f"] == res[0]["f"]          # replicas: the same bits on every rank
+        assert s.final_cost == res[0]["s"].final_cost and s.spin_timeouts == 0
+        assert r["tree"] == res[0]["tree"] and r["tree"]["fronts"] > 0               # the front tree of the union graph, on every rank
+    assert [(r["lo"], r["hi"]) for r in res] == [sharding_block(100000, k, world) for k in range(world)]
+    assert np.allclose(np.concatenate([r["p"] for r in res]), p1, rtol=1e-6, atol=1e-8)
+    # every rank issued the same exchanges; the linearisations' is the sparse list (the 6 x 6 blocks of co-visible cameras), not
+    # the packed triangle
+    assert all(c == grp.counts[0] for c in grp.counts)
+    ld = (6 * 200 + 1 + 63) // 64 * 64
+    assert max(grp.counts[0]) < (ld * (ld + 1) // 2) // 2 and 8 in grp.counts[0]
+
+
+def sharding_block(n, r, w):
+    from sfm_danpipeline_amd import sharding
+    return sharding.point_block(n, r, w)
+
+
 @pytest.mark.gpu
 def test_solver_on_a_busy_device_walks_the_same_iterates(ctx):
     """The reduced solve with the CUs contended: a second stream keeps the device full of k-NN sweeps while the LM

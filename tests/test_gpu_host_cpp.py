@@ -59,27 +59,11 @@ def test_native_rccl_allreduce_in_a_cpp_program(tmp_path, ctx):
 
 
 def _aa_to_R(aa):
-    th = np.linalg.norm(aa)
-    k = aa / th
-    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
-    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+    return synth._aa_to_rotation(aa)
 
 
 def _write_containers(path, pb, cx, cy):
-    nc, npt, no = pb["n_cam"], pb["n_pt"], pb["n_obs"]
-    poses = np.zeros((nc, 3, 4))
-    for i in range(nc):
-        poses[i, :, :3] = _aa_to_R(pb["cams0"][i, :3])
-        poses[i, :, 3] = pb["cams0"][i, 3:]
-    K = np.array([[pb["focal0"], 0, cx], [0, pb["focal0"], cy], [0, 0, 1.0]])
-    with open(path, "wb") as f:
-        f.write(struct.pack("<iii", nc, npt, no))
-        f.write(poses.astype("<f8").tobytes())
-        f.write(pb["pts0"].astype("<f8").tobytes())
-        f.write(K.astype("<f8").tobytes())
-        f.write(np.stack([pb["obs_cam"], pb["obs_pt"]], axis=1).astype("<i4").tobytes())
-        f.write((pb["obs_xy"] + np.array([cx, cy])).astype("<f8").tobytes())
-    return poses, K
+    return synth.write_ba_containers(path, pb, cx, cy)
 
 
 def _read_containers(path, nc, npt):
