@@ -38,7 +38,9 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <functional>
 #include <map>
 #include <thread>
@@ -3485,6 +3487,9 @@ struct sfmhip_ba {
   int dim = 0, ld = 0;
   size_t ssz = 0;  // ld*ld: doubles of the S part of `red`
   BaDev d{};
+  bool use_arena = false;     // device memory from the context's grow-only block (sfmhip_ba_solve's problems)
+  size_t arena_off = 0, arena_need = 0;
+  bool pinned_shared = false;  // h_sc / h_ring are the context's pinned block, not this problem's
   std::vector<int> perm;  // sorted point -> input point
   std::vector<int> obs_src;  // sorted observation -> input observation (ba_set_observations: the same structure, new measurements)
   std::vector<int> cxy_src;  // entry of the pair path's camera-major list -> sorted observation
@@ -3594,6 +3599,66 @@ static int host_threads(int n) {
   const int nth = (int)std::max(1u, std::min(16u, hw ? hw : 1u));
   return n < 20000 ? 1 : nth;
 }
+// The host threads of the set-up's passes: a pool that lives as long as the process (starting and joining sixteen threads is
+// 0.4-0.5 ms, and a set-up has five such passes).  One job at a time; a caller that finds the pool busy (another host thread is
+// setting a problem up) starts threads of its own, as every pass did before.
+class HostPool {
+ public:
+  static HostPool& get() {
+    static HostPool* p = new HostPool();  // (never destroyed: its threads wait on a condition variable until the process ends)
+    return *p;
+  }
+  // f(t) for t in [0, nth): the caller is t = 0.  Returns false when the pool is taken (nothing has run).
+  bool run(int nth, const std::function<void(int)>& f) {
+    std::unique_lock<std::mutex> job_lock(job_m_, std::try_to_lock);
+    if (!job_lock.owns_lock()) return false;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      while ((int)workers_.size() < nth - 1) {
+        const int id = (int)workers_.size() + 1;
+        workers_.emplace_back([this, id]() { work(id); });
+        workers_.back().detach();
+      }
+      f_ = &f;
+      nth_ = nth;
+      pending_ = nth - 1;
+      ++gen_;
+    }
+    cv_.notify_all();
+    f(0);
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [this]() { return pending_ == 0; });
+    f_ = nullptr;
+    return true;
+  }
+
+ private:
+  void work(int id) {
+    unsigned seen = 0;
+    for (;;) {
+      const std::function<void(int)>* f = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&]() { return gen_ != seen; });
+        seen = gen_;
+        if (id < nth_) f = f_;
+      }
+      if (!f) continue;
+      (*f)(id);
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (--pending_ == 0) done_.notify_all();
+      }
+    }
+  }
+  std::mutex job_m_, m_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> workers_;
+  const std::function<void(int)>* f_ = nullptr;
+  int nth_ = 0, pending_ = 0;
+  unsigned gen_ = 0;
+};
+
 // fn(t, lo, hi): thread t of host_threads(n) takes [lo, hi)
 template <typename F>
 static void host_parallel_for_t(int n, int nth, F fn) {
@@ -3601,11 +3666,13 @@ static void host_parallel_for_t(int n, int nth, F fn) {
     fn(0, 0, n);
     return;
   }
-  std::vector<std::thread> th;
-  for (int t = 0; t < nth; ++t) {
+  const std::function<void(int)> job = [&](int t) {
     const int lo = (int)((long long)n * t / nth), hi = (int)((long long)n * (t + 1) / nth);
-    th.emplace_back([=, &fn]() { fn(t, lo, hi); });
-  }
+    fn(t, lo, hi);
+  };
+  if (HostPool::get().run(nth, job)) return;
+  std::vector<std::thread> th;
+  for (int t = 0; t < nth; ++t) th.emplace_back([&job, t]() { job(t); });
   for (auto& x : th) x.join();
 }
 template <typename F>
@@ -3615,6 +3682,20 @@ static void host_parallel_for(int n, F fn) {
 
 template <typename T>
 static int ba_alloc(sfmhip_ba* b, T** p, size_t n) {
+  const size_t bytes = ((n ? n : 1) * sizeof(T) + 255) & ~(size_t)255;
+  b->arena_need += bytes;
+  if (b->use_arena && b->arena_off + bytes <= b->ctx->ba_arena_bytes) {
+    // (a problem of the one-shot entry point: carved from the context's block, given back as a whole when the problem goes)
+    void* v = (char*)b->ctx->ba_arena + b->arena_off;
+    b->arena_off += bytes;
+    static const bool poison = getenv("SFMHIP_POISON") != nullptr;  // (tests: as sfm_dev_alloc does for fresh allocations)
+    if (poison) {
+      hipMemset(v, 0xFF, bytes);
+      hipDeviceSynchronize();
+    }
+    *p = (T*)v;
+    return SFMHIP_OK;
+  }
   SFM_TRY(sfm_dev_alloc(p, n));
   b->allocs.push_back((void*)*p);
   return SFMHIP_OK;
@@ -3689,8 +3770,31 @@ extern "C" void sfmhip_ba_default_opts(sfmhip_ba_opts* o) {
   o->verbose = getenv("SFMHIP_BA_VERBOSE") ? 1 : 0;  // (diagnosis: the LM log on stderr)
 }
 
+// Host memory of the one-shot entry point's set-ups, kept with the context between calls: the passes below fill some 50 MB of
+// vectors at cfg4, and fresh ones cost their page faults on the way in (3-4 ms) and their unmapping on the way out (3.9 ms of a
+// 33 ms call) -- the allocator of the host process decides which, the library should not depend on it.
+struct BaHostScratch {
+  std::vector<int> cnt, slot, scam, run_of, order, optr, ocam, table, obs_src, cxy_src;
+  std::vector<uint64_t> sig_hash;
+  std::vector<double> oxy, h_pts_in;
+};
+static void ba_host_scratch_free(void* p) { delete (BaHostScratch*)p; }
+static BaHostScratch* ba_host_scratch(sfmhip_ctx* ctx) {
+  if (!ctx->ba_host_scratch) {
+    ctx->ba_host_scratch = new BaHostScratch();
+    ctx->ba_host_scratch_free = ba_host_scratch_free;
+  }
+  return (BaHostScratch*)ctx->ba_host_scratch;
+}
+
+static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const int32_t* obs_cam, const int32_t* obs_pt,
+                          const double* obs_xy, bool arena, sfmhip_ba** out);
 extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const int32_t* obs_cam,
                                 const int32_t* obs_pt, const double* obs_xy, sfmhip_ba** out) {
+  return ba_create_impl(ctx, n_cam, n_pt, n_obs, obs_cam, obs_pt, obs_xy, false, out);
+}
+static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const int32_t* obs_cam, const int32_t* obs_pt,
+                          const double* obs_xy, bool arena, sfmhip_ba** out) {
   if (!ctx || !out || n_cam <= 0 || n_pt < 0 || n_obs < 0) return SFMHIP_ERR_ARG;
   if (n_obs && (!obs_cam || !obs_pt || !obs_xy)) return SFMHIP_ERR_ARG;
   // (one pass: the range check, and whether the observations already come grouped by point -- the order the reference adds
@@ -3715,6 +3819,7 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   };
   sfmhip_ba* b = new sfmhip_ba();
   b->ctx = ctx;
+  b->use_arena = arena;
   b->nc = n_cam;
   b->np_in = n_pt;
   b->no_in = n_obs;
@@ -3723,10 +3828,19 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   b->ssz = (size_t)b->ld * b->ld;
   // ---- group observations by point, ascending camera inside a point (std::map order of
   //      Point3D::idxImage, reference src/BundleAdjustment.cpp:87)
-  std::vector<int> cnt(n_pt + 1, 0);
+  // (a one-shot problem takes the context's vectors -- their capacity survives the call -- and gives its own back when it goes)
+  BaHostScratch own_scratch, *hs = arena ? ba_host_scratch(ctx) : &own_scratch;
+  if (arena) {
+    b->obs_src.swap(hs->obs_src);
+    b->cxy_src.swap(hs->cxy_src);
+    b->h_pts_in.swap(hs->h_pts_in);
+  }
+  std::vector<int>& cnt = hs->cnt;
+  cnt.assign((size_t)n_pt + 1, 0);
   for (int o = 0; o < n_obs; ++o) cnt[obs_pt[o] + 1]++;
   for (int p = 0; p < n_pt; ++p) cnt[p + 1] += cnt[p];
-  std::vector<int> slot(n_obs);
+  std::vector<int>& slot = hs->slot;
+  slot.resize(n_obs);
   if (grouped) {
     host_parallel_for(n_obs, [&](int lo, int hi) {
       for (int o = lo; o < hi; ++o) slot[o] = o;
@@ -3739,8 +3853,10 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   // one core): stable insertion sort -- a point has a handful of observations --, then the point's
   // ascending camera list, flat, and a hash of it: the signature grouping below compares
   // (length, hash) first and walks the lists only on equal hashes
-  std::vector<int> scam(n_obs);
-  std::vector<uint64_t> sig_hash(n_pt, 0);
+  std::vector<int>& scam = hs->scam;
+  scam.resize(n_obs);
+  std::vector<uint64_t>& sig_hash = hs->sig_hash;
+  sig_hash.assign(n_pt, 0);
   host_parallel_for(n_pt, [&](int plo, int phi) {
     for (int p = plo; p < phi; ++p) {
       for (int i = cnt[p] + 1; i < cnt[p + 1]; ++i) {
@@ -3768,11 +3884,14 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
       if (scam[cnt[x] + k] != scam[cnt[y] + k]) return false;
     return true;
   };
-  std::vector<int> run_of(n_pt, -1), run_rep, run_cnt;
+  std::vector<int>& run_of = hs->run_of;
+  run_of.assign(n_pt, -1);
+  std::vector<int> run_rep, run_cnt;
   {
     size_t cap = 64;
     while (cap < 2 * (size_t)n_pt + 16) cap <<= 1;
-    std::vector<int> table(cap, -1);  // open addressing: run id, keyed by the signature hash
+    std::vector<int>& table = hs->table;  // open addressing: run id, keyed by the signature hash
+    table.assign(cap, -1);
     for (int p = 0; p < n_pt; ++p) {
       const int n = cnt[p + 1] - cnt[p];
       if (n > FB_MAXN) {
@@ -3800,7 +3919,8 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   }
   std::vector<int> run_start(run_rep.size() + 1, 0);
   for (size_t r = 0; r < run_rep.size(); ++r) run_start[r + 1] = run_start[r] + run_cnt[r];
-  std::vector<int> order(run_start.back());
+  std::vector<int>& order = hs->order;
+  order.resize(run_start.back());
   {
     std::vector<int> fillr(run_start.begin(), run_start.end() - 1);
     for (int p = 0; p < n_pt; ++p)
@@ -3808,28 +3928,39 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   }
   b->np = (int)order.size();
   b->perm = order;
-  std::vector<int> optr(b->np + 1, 0);
+  std::vector<int>& optr = hs->optr;
+  optr.assign((size_t)b->np + 1, 0);
   for (int sp = 0; sp < b->np; ++sp) optr[sp + 1] = optr[sp] + (cnt[order[sp] + 1] - cnt[order[sp]]);
   b->no = optr[b->np];
-  std::vector<int> ocam(b->no);
-  std::vector<double> oxy(2 * (size_t)b->no);
+  std::vector<int>& ocam = hs->ocam;
+  ocam.resize(b->no);
+  std::vector<double>& oxy = hs->oxy;
+  oxy.resize(2 * (size_t)b->no);
   b->obs_src.resize(b->no);
   b->h_cam_used.assign(n_cam, 0);
-  // the gather of a million observations is a cache-miss chain on one core: split it over a few
-  host_parallel_for(b->np, [&](int lo, int hi) {
-    for (int sp = lo; sp < hi; ++sp) {
-      const int p = order[sp];
-      int w = optr[sp];
-      for (int k = cnt[p]; k < cnt[p + 1]; ++k, ++w) {
-        const int o = slot[k];
-        b->obs_src[w] = o;
-        ocam[w] = obs_cam[o];
-        oxy[2 * (size_t)w] = obs_xy[2 * (size_t)o];
-        oxy[2 * (size_t)w + 1] = obs_xy[2 * (size_t)o + 1];
+  // the gather of a million observations is a cache-miss chain on one core: split it over a few (each marks the cameras it
+  // meets in a list of its own; the lists are merged behind the threads)
+  {
+    const int nth = host_threads(b->np);
+    std::vector<std::vector<unsigned char>> used((size_t)nth, std::vector<unsigned char>(n_cam, 0));
+    host_parallel_for_t(b->np, nth, [&](int t, int lo, int hi) {
+      unsigned char* mine = used[t].data();
+      for (int sp = lo; sp < hi; ++sp) {
+        const int p = order[sp];
+        int w = optr[sp];
+        for (int k = cnt[p]; k < cnt[p + 1]; ++k, ++w) {
+          const int o = slot[k];
+          b->obs_src[w] = o;
+          ocam[w] = obs_cam[o];
+          mine[ocam[w]] = 1;
+          oxy[2 * (size_t)w] = obs_xy[2 * (size_t)o];
+          oxy[2 * (size_t)w + 1] = obs_xy[2 * (size_t)o + 1];
+        }
       }
-    }
-  });
-  for (int k = 0; k < b->no; ++k) b->h_cam_used[ocam[k]] = 1;
+    });
+    for (const auto& u : used)
+      for (int c = 0; c < n_cam; ++c) b->h_cam_used[c] |= u[c];
+  }
   lap_("signature sort + csr");
   // ---- chunks: runs of equal signature with strictly ascending cameras, n <= 10 -> MFMA path,
   //      classed by the width of the local Gram matrix: NB = ceil((6n+2)/16) column blocks
@@ -4309,13 +4440,27 @@ extern "C" int sfmhip_ba_create(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs,
   SFM_HIP_TRY(up(b->d_pair_ent, pair_ent.data(), pair_ent.size() * sizeof(int2)));
   b->n_pairs_pp = (int)pair_cams.size();
   lap_("uploads");
-  SFM_HIP_TRY(hipHostMalloc((void**)&b->h_sc, sizeof(double) * (SC + 64 + RED2_N + 1), hipHostMallocDefault));
+  const size_t sc_bytes = (sizeof(double) * (SC + 64 + RED2_N + 1) + 255) & ~(size_t)255, ring_bytes = sizeof(LmDev) * LM_RING;
+  if (arena) {
+    // (the records the device writes to the host: the context's pinned block, made once -- 0.5 ms per problem otherwise)
+    if (ctx->ba_pinned_bytes < sc_bytes + ring_bytes) {
+      if (ctx->ba_pinned) hipHostFree(ctx->ba_pinned);
+      ctx->ba_pinned = nullptr, ctx->ba_pinned_bytes = 0;
+      SFM_HIP_TRY(hipHostMalloc(&ctx->ba_pinned, sc_bytes + ring_bytes, hipHostMallocDefault));
+      ctx->ba_pinned_bytes = sc_bytes + ring_bytes;
+    }
+    b->pinned_shared = true;
+    b->h_sc = (double*)ctx->ba_pinned;
+    b->h_ring = (LmDev*)((char*)ctx->ba_pinned + sc_bytes);
+  } else {
+    SFM_HIP_TRY(hipHostMalloc((void**)&b->h_sc, sizeof(double) * (SC + 64 + RED2_N + 1), hipHostMallocDefault));
+    SFM_HIP_TRY(hipHostMalloc((void**)&b->h_ring, ring_bytes, hipHostMallocDefault));
+  }
   SFM_HIP_TRY(hipHostGetDevicePointer((void**)&b->h_sc_dev, b->h_sc, 0));
   b->h_sc[SC + 64 + RED2_N] = 0.0;
   // the trust-region record, the host's ring of copies of it, the step evaluation's slots (runs x split <= 8, blocks of 64
   // points of ba_backsub, then a pair per front / per wave of ba_cand_cams)
-  SFM_HIP_TRY(hipHostMalloc((void**)&b->h_ring, sizeof(LmDev) * LM_RING, hipHostMallocDefault));
-  memset(b->h_ring, 0, sizeof(LmDev) * LM_RING);
+  memset(b->h_ring, 0, sizeof(LmDev) * LM_RING);  // (a shared block: the previous problem's records must not match this one's sequence numbers)
   SFM_HIP_TRY(hipHostGetDevicePointer((void**)&b->h_ring_dev, b->h_ring, 0));
   SFM_TRY(ba_alloc(b, &b->d_lm, 1));
   b->step_part_n = 4 * ((size_t)b->n_chunks * 8 + ((size_t)b->np + 63) / 64 + 8) + 2 * ((size_t)n_cam + 64);
@@ -5871,13 +6016,33 @@ extern "C" int sfmhip_ba_last_timing(sfmhip_ba* b, double seconds[4], int* launc
 
 extern "C" void sfmhip_ba_destroy(sfmhip_ba* b) {
   if (!b) return;
+  const bool prof_ = getenv("SFMHIP_PROFILE_CREATE") != nullptr;
+  auto tp_ = std::chrono::steady_clock::now();
+  auto lap_ = [&](const char* what) {
+    if (!prof_) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[sfmhip_ba_destroy] %-21s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tp_).count());
+    tp_ = now;
+  };
   hipSetDevice(b->ctx->device);
+  const size_t n_free = b->allocs.size();
   for (void* p : b->allocs) hipFree(p);
-  if (b->h_sc) hipHostFree(b->h_sc);
-  if (b->h_ring) hipHostFree(b->h_ring);
+  if (prof_) fprintf(stderr, "[sfmhip_ba_destroy] %zu hipFree\n", n_free);
+  lap_("hipFree");
+  if (b->h_sc && !b->pinned_shared) hipHostFree(b->h_sc);
+  if (b->h_ring && !b->pinned_shared) hipHostFree(b->h_ring);
+  lap_("hipHostFree");
   for (auto& e : b->ev)
     if (e) hipEventDestroy(e);
+  lap_("events");
+  if (b->use_arena && b->ctx->ba_host_scratch) {  // (a one-shot problem: its large vectors go back to the context's)
+    BaHostScratch* hs = (BaHostScratch*)b->ctx->ba_host_scratch;
+    hs->obs_src.swap(b->obs_src);
+    hs->cxy_src.swap(b->cxy_src);
+    hs->h_pts_in.swap(b->h_pts_in);
+  }
   delete b;
+  lap_("host memory");
 }
 
 // New measurements for a problem of unchanged structure (the same obs_cam / obs_pt arrays as at its creation): the sorted
@@ -5962,11 +6127,22 @@ extern "C" int sfmhip_ba_solve(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, 
     b->spin_timeouts = 0;
     rc = ba_set_observations(b, obs_xy);
   } else {
-    if (cache) {  // another structure: the kept problem goes first (its buffers may be what the new one needs room for)
+    if (cache) {  // another structure: the kept problem goes first (the block it was carved from is the new one's)
       sfmhip_ba_destroy(cache->b);
       cache->b = nullptr;
     }
-    rc = sfmhip_ba_create(ctx, n_cam, n_pt, n_obs, obs_cam, obs_pt, obs_xy, &b);
+    // the block: as large as the last problem turned out to need, and a quarter more (a problem whose needs exceed it takes
+    // the rest by hipMalloc, and the next call's block is larger)
+    static const bool arena_on = !(getenv("SFMHIP_BA_ARENA") && atoi(getenv("SFMHIP_BA_ARENA")) == 0);
+    if (arena_on && ctx->ba_arena_need > ctx->ba_arena_bytes) {
+      hipSetDevice(ctx->device);
+      if (ctx->ba_arena) hipFree(ctx->ba_arena);
+      ctx->ba_arena = nullptr, ctx->ba_arena_bytes = 0;
+      const size_t want = ctx->ba_arena_need + ctx->ba_arena_need / 4;
+      if (hipMalloc(&ctx->ba_arena, want) == hipSuccess) ctx->ba_arena_bytes = want;
+      else ctx->ba_arena = nullptr;  // (no block: plain allocations)
+    }
+    rc = ba_create_impl(ctx, n_cam, n_pt, n_obs, obs_cam, obs_pt, obs_xy, arena_on, &b);
   }
   pr.create_ms = lap();
   if (rc == SFMHIP_OK) rc = sfmhip_ba_set_params(b, cams6, pts3, *focal);
@@ -5975,6 +6151,7 @@ extern "C" int sfmhip_ba_solve(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, 
   pr.run_ms = lap();
   if (rc == SFMHIP_OK) rc = sfmhip_ba_get_params(b, cams6, pts3, focal);
   pr.get_params_ms = lap();
+  if (b && !pr.plan_reused) ctx->ba_arena_need = std::max(ctx->ba_arena_need, b->arena_need);
   if (rc == SFMHIP_OK && cache_on && n_obs > 0) {
     if (!pr.plan_reused) {
       if (!cache) {

@@ -46,6 +46,15 @@ struct sfmhip_ctx {
   sfmhip_ba_solve_profile ba_profile = {};
   void* ba_cache = nullptr;
   void (*ba_cache_free)(void*) = nullptr;
+  // ... and the memory its problems live in: ONE grow-only device block that every problem of the one-shot entry point is carved
+  // from (a problem is 60-odd hipMallocs and as many hipFrees otherwise: 6.4 ms of a 33 ms call at cfg4), and one pinned block
+  // for the records the device writes to the host
+  void* ba_arena = nullptr;
+  size_t ba_arena_bytes = 0, ba_arena_need = 0;  // need: what the last problem took in all (the next call grows the block to it)
+  void* ba_pinned = nullptr;
+  size_t ba_pinned_bytes = 0;
+  void* ba_host_scratch = nullptr;  // (and the host vectors of its set-ups: ba.hip, BaHostScratch)
+  void (*ba_host_scratch_free)(void*) = nullptr;
 };
 
 int sfm_ctx_pinned(sfmhip_ctx* ctx, size_t bytes, void** out);

@@ -78,6 +78,9 @@ extern "C" void sfmhip_shutdown(sfmhip_ctx* ctx) {
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   if (ctx->ba_cache && ctx->ba_cache_free) ctx->ba_cache_free(ctx->ba_cache);  // (the problem sfmhip_ba_solve kept for a next call)
   ctx->ba_cache = nullptr;
+  if (ctx->ba_host_scratch && ctx->ba_host_scratch_free) ctx->ba_host_scratch_free(ctx->ba_host_scratch);
+  if (ctx->ba_arena) hipFree(ctx->ba_arena);
+  if (ctx->ba_pinned) hipHostFree(ctx->ba_pinned);
   if (ctx->pinned) hipHostFree(ctx->pinned);
   for (void* p : ctx->dev_scratch)
     if (p) hipFree(p);

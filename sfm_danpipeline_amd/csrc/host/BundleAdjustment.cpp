@@ -123,29 +123,43 @@ void BundleAdjustment::adjustBundle(std::vector<Point3D>& pointCloud, std::vecto
   const double cx = intrinsics.K.at<double>(0, 2), cy = intrinsics.K.at<double>(1, 2);
   // one residual block per (view, feature) of every track, point-major in std::map order (src/BundleAdjustment.cpp:83-110):
   // the tracks' sizes give every point its place in the flat arrays, then the points are walked side by side
-  std::vector<double> pts3(3 * (size_t)n_pt);
-  std::vector<size_t> first(n_pt + 1, 0);
+  // (the flat arrays are this thread's and keep their capacity between calls: 30 MB of fresh vectors per call cost their page
+  // faults and their unmapping -- 3 ms of a cfg4 call)
+  static thread_local std::vector<double> pts3, obs_xy;
+  static thread_local std::vector<size_t> first;
+  static thread_local std::vector<int32_t> obs_cam, obs_pt;
+  pts3.resize(3 * (size_t)n_pt);
+  first.assign((size_t)n_pt + 1, 0);
   for (int i = 0; i < n_pt; ++i) first[i + 1] = first[i] + pointCloud[i].idxImage.size();
   const size_t n_obs = first[n_pt];
-  std::vector<int32_t> obs_cam(n_obs), obs_pt(n_obs);
-  std::vector<double> obs_xy(2 * n_obs);
-  parallel_blocks(n_pt, [&](int lo, int hi) {
-    for (int i = lo; i < hi; ++i) {
-      const Point3D& p = pointCloud[i];
-      pts3[3 * (size_t)i] = p.pt.x;
-      pts3[3 * (size_t)i + 1] = p.pt.y;
-      pts3[3 * (size_t)i + 2] = p.pt.z;
-      size_t w = first[i];
-      for (const auto& kv : p.idxImage) {  // (view, 2-D feature index)
-        const cv::Point2d& f = image2dFeatures[kv.first][kv.second];
-        obs_cam[w] = kv.first;
-        obs_pt[w] = i;
-        obs_xy[2 * w] = f.x - cx;  // the optimiser does not know the principal point
-        obs_xy[2 * w + 1] = f.y - cy;
-        ++w;
+  obs_cam.resize(n_obs);
+  obs_pt.resize(n_obs);
+  obs_xy.resize(2 * n_obs);
+  {
+    // (plain pointers for the workers: a thread_local named inside their lambda would be THEIR thread's vector, an empty one)
+    double* const p3 = pts3.data();
+    double* const oxy = obs_xy.data();
+    int32_t* const oc = obs_cam.data();
+    int32_t* const op = obs_pt.data();
+    const size_t* const fst = first.data();
+    parallel_blocks(n_pt, [&, p3, oxy, oc, op, fst](int lo, int hi) {
+      for (int i = lo; i < hi; ++i) {
+        const Point3D& p = pointCloud[i];
+        p3[3 * (size_t)i] = p.pt.x;
+        p3[3 * (size_t)i + 1] = p.pt.y;
+        p3[3 * (size_t)i + 2] = p.pt.z;
+        size_t w = fst[i];
+        for (const auto& kv : p.idxImage) {  // (view, 2-D feature index)
+          const cv::Point2d& f = image2dFeatures[kv.first][kv.second];
+          oc[w] = kv.first;
+          op[w] = i;
+          oxy[2 * w] = f.x - cx;  // the optimiser does not know the principal point
+          oxy[2 * w + 1] = f.y - cy;
+          ++w;
+        }
       }
-    }
-  });
+    });
+  }
   sfmhip_ba_opts opts;
   sfmhip_ba_default_opts(&opts);  // DENSE_SCHUR LM, 500 iterations, 10 s
   // (test hook, never set by the product -- ba_profile.h: the reference's two limits made reachable on problems that

@@ -269,6 +269,12 @@ int sfmhip_find_2d3d(sfmhip_ctx* ctx, const int32_t* trk_ptr, const int32_t* trk
   return orc_find_2d3d(trk_ptr, trk_view, trk_feat, n_cloud, done_view, new_view, match_q, match_t, n_match, out_cloud, out_feat, n_out)
              ? SFMHIP_ERR_ARG : SFMHIP_OK;
 }
+int sfmhip_ba_last_solve_profile(sfmhip_ctx* ctx, sfmhip_ba_solve_profile* out) {
+  (void)ctx;
+  if (!out) return SFMHIP_ERR_ARG;
+  memset(out, 0, sizeof *out); /* (the stand-in measures nothing) */
+  return SFMHIP_OK;
+}
 int sfmhip_merge_new_points(sfmhip_ctx* ctx, const double* cloud_xyz, int n_cloud, const double* new_xyz, int n_new, float min_dist,
                             uint8_t* accept, int32_t* n_accepted) {
   (void)ctx;

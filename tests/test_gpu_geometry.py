@@ -600,6 +600,50 @@ def test_two_ranks_share_the_device_and_run_the_sharded_solver(ctx, tmp_path, mo
     assert np.allclose(np.concatenate([r0["p"], r1["p"]]), p1, rtol=1e-8, atol=1e-9)
 
 
+def _eq_bits(x, y):
+    return np.array_equal(np.ascontiguousarray(x, np.float64).view(np.uint64), np.ascontiguousarray(y, np.float64).view(np.uint64))
+
+
+def test_one_shot_solve_keeps_its_plan_for_a_call_of_the_same_structure(ctx):
+    """sfmhip_ba_solve -- what BundleAdjustment::adjustBundle maps to (reference include/BundleAdjustment.h:19-20: a static
+    one-shot function, called again and again, src/Sfm.cpp:883-888) -- keeps the problem it built: a second call with the same
+    observation structure skips the set-up (plan_reused) and returns the SAME BITS as the first; new measurements on the same
+    structure give the bits of a freshly built problem; another structure replaces the kept one."""
+    c = _lib.Context(0)                       # (a context of its own: the kept problem is the context's)
+    pb = synth.ba_problem(24, 3000, 6, seed=91)
+    a = _ba_args(pb)
+    r1 = bundle.ba_solve(*a, ctx=c)
+    p1 = bundle.last_solve_profile(c)
+    r2 = bundle.ba_solve(*a, ctx=c)
+    p2 = bundle.last_solve_profile(c)
+    assert (p1["plan_reused"], p2["plan_reused"]) == (0, 1) and p2["create_ms"] < p1["create_ms"]
+    assert _eq_bits(r1[0], r2[0]) and _eq_bits(r1[1], r2[1]) and r1[2] == r2[2]
+    assert (r1[3].iterations, r1[3].final_cost, r1[3].termination) == (r2[3].iterations, r2[3].final_cost, r2[3].termination)
+    # the same structure, other measurements (and another start): the kept plan with the new data == a problem built for them
+    xy2 = a[5] + np.random.default_rng(5).normal(0, 0.3, a[5].shape)
+    b = (a[0] * (1 + 1e-4), a[1], a[2], a[3], a[4], xy2)
+    r3 = bundle.ba_solve(*b, ctx=c)
+    assert bundle.last_solve_profile(c)["plan_reused"] == 1
+    fresh = bundle.BaProblem(24, 3000, b[3], b[4], b[5], ctx=ctx)
+    fresh.set_params(b[0], b[1], b[2])
+    s4 = fresh.run(bundle.default_opts())
+    c4, q4, f4 = fresh.get_params()
+    assert _eq_bits(r3[0], c4) and _eq_bits(r3[1], q4) and r3[2] == f4 and r3[3].iterations == s4.iterations
+    assert not _eq_bits(r3[0], r1[0])
+    # another structure (one observation less): built anew, and the next call of THAT structure finds it kept
+    d = (a[0], a[1], a[2], a[3][:-1], a[4][:-1], a[5][:-1])
+    r5 = bundle.ba_solve(*d, ctx=c)
+    assert bundle.last_solve_profile(c)["plan_reused"] == 0
+    r6 = bundle.ba_solve(*d, ctx=c)
+    assert bundle.last_solve_profile(c)["plan_reused"] == 1 and _eq_bits(r5[0], r6[0]) and _eq_bits(r5[1], r6[1])
+    # same sizes, one camera index changed: compared element for element, not by size
+    oc = a[3].copy()
+    oc[5] = (oc[5] + 12) % 24
+    bundle.ba_solve(a[0], a[1], a[2], oc, a[4], a[5], ctx=c)
+    assert bundle.last_solve_profile(c)["plan_reused"] == 0
+    c.close()
+
+
 def _logical_ranks_solve(pb, world, opts=None, iterate=None):
     """BASELINE cfg4's split, `world` logical ranks on the one device: a BaProblem per rank over its point block (all cameras, the
     focal), a context + stream + host thread each, the exchange summed on the device in rank order (sharding.InProcessRanks)."""
