@@ -18,7 +18,7 @@ for r in csv.DictReader(open(src)):
         "valu_per_mfma": (round(float(r["SQ_INSTS_VALU"]) / float(r["SQ_INSTS_MFMA"]), 2)
                           if r.get("SQ_INSTS_VALU") and r.get("SQ_INSTS_MFMA") and float(r["SQ_INSTS_MFMA"]) > 0 else None),
         "avg_us_profiled": float(r["avg_us_profiled"]) if r.get("avg_us_profiled") else None,
-        "source": f"{src} (scripts/gpu_profile_bench.sh: rocprofv3 --pmc passes over `bench.py --lean --steps 4 --warmup 1`, "
+        "source": f"{src} (scripts/gpu_profile_bench.sh: rocprofv3 --pmc passes over `bench.py --lean --match-streams 1 --cfg5-sample 2000 --steps 4 --warmup 1`, "
                   "FETCH_SIZE and WRITE_SIZE in passes of their own; hbm = (2*FETCH+WRITE)*1024, MI355X_MICROARCH.md HBM section)",
     }
 out["_source"] = os.path.basename(src)

@@ -741,6 +741,45 @@ def test_solver_on_a_busy_device_walks_the_same_iterates(ctx):
     ctx2.close()                                      # (after everything that lives on it)
 
 
+def test_front_tree_under_real_contention_walks_the_same_bits(ctx):
+    """The front tree's hand-offs lean on child fronts being resident when their parents poll (dispatch order is
+    not a promise), and every front needs a whole compute unit's LDS.  Here the device is kept full of cfg2-sized k-NN sweeps on a
+    second stream -- two workgroups of 67 KB of LDS on every compute unit -- while a 96-camera tree (7 fronts) runs its LM
+    iterations: a front only gets a compute unit when a sweep workgroup leaves one.  Either no bounded poll runs out
+    (spin_timeouts == 0) or the solve falls back to one launch per tree level; BOTH ways the iterates are the quiet run's, bit
+    for bit -- a time-out is a status, never a trajectory."""
+    import torch
+    from sfm_danpipeline_amd import matcher
+    side = torch.cuda.Stream(torch.device("cuda:0"))
+    ctx2 = _lib.Context(0, stream=side.cuda_stream)
+    imgs = synth.sift_image_set(50, 2000, 128, seed=98)
+    iset = matcher.ImageSet(imgs, ctx=ctx2)
+    plan = matcher.MatchPlan(iset, synth.all_pairs(50))          # 1225 pairs: 9800 workgroups per sweep, ~0.6 ms
+    pb = synth.ba_problem(96, 9000, 5, seed=45)
+    prob = bundle.BaProblem(96, 9000, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx)
+    prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+    quiet = prob.iterate(10)
+    assert prob.reduced_tree()["fronts"] >= 3 and quiet.spin_timeouts == 0
+    cq, pq, fq = prob.get_params()
+    seen = []
+    for rep in range(4):
+        prob.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+        iset.prepare_async()
+        for _ in range(16):                                       # ~10 ms of sweeps queued on the other stream
+            plan.run_async(0.8)
+        busy = prob.iterate(10)
+        cb, pb_, fb = prob.get_params()
+        seen.append(busy.spin_timeouts)
+        assert (busy.successful_steps, busy.iterations) == (quiet.successful_steps, quiet.iterations), seen
+        assert _eq_bits(cb, cq) and _eq_bits(pb_, pq) and fb == fq and busy.final_cost == quiet.final_cost, seen
+    ctx2.synchronize()
+    print("spin time-outs under contention:", seen)
+    prob.close()
+    plan.close()
+    iset.close()
+    ctx2.close()
+
+
 def test_second_reduced_system_buffer_changes_nothing(ctx, monkeypatch):
     """The dissected solve's gather zeroes a second [S | g | ...] buffer on the side and the next linearisation swaps the two
     instead of filling one (SFMHIP_BA_PREZERO=0: a memset per linearisation): the same systems bit for bit, the same LM run --
