@@ -17,6 +17,8 @@ assert L.sfmhip_dbg_read_stamps(buf.ctypes.data, buf.nbytes) == 0
 nwav = int(os.environ.get("SFMHIP_KNN_NW", "8"))
 print('queries redone exactly by the compaction kernel (3 sweeps):', int(buf[-1]), ' of them overflow-flagged:', int(buf[-2]))
 st = buf.reshape(4096, 8, 16).astype(np.int64)[:, :nwav, :]
+st = st[st[:, 0, 5] > 0]          # (persistent workgroups: two per compute unit stamp, each its LAST work item)
+print("workgroups that stamped:", len(st))
 d = np.diff(st[:, :, :6], axis=2)
 names = ["prologue(bq, first stage)", "main loop", "drain+resolve u0", "resolve u1", "emit"]
 for i, n in enumerate(names):
