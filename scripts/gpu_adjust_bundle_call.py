@@ -14,7 +14,7 @@ for tag, (nc, npt, k) in (("cfg3", (50, 20000, 10)), ("cfg4", (200, 100000, 10))
         synth.write_ba_containers(os.path.join(d, "in.bin"), pb, 960.0, 540.0)
         for env in ({}, {"SFMHIP_BA_PLAN_CACHE": "0"}):
             r = subprocess.run([exe, os.path.join(d, "in.bin"), os.path.join(d, "out.bin")], capture_output=True, text=True,
-                               env=dict(os.environ, SFM_BA_SELFTEST_CALLS=str(calls), **env))
+                               env=dict(os.environ, SFM_BA_SELFTEST_CALLS=str(calls), SFM_BA_SELFTEST_NEW_STRUCTURE="2", **env))
             assert r.returncode == 0, r.stderr[-2000:]
             its = [l for l in r.stdout.splitlines() if l.startswith("Bundle adjustment:")]
             for l in r.stdout.splitlines():

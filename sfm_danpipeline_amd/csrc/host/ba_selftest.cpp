@@ -84,12 +84,20 @@ int main(int argc, char** argv) {
   const std::vector<Point3D> cloud0 = cloud;
   const std::vector<cv::Matx34d> poses0 = poses;
   const double f0 = K.K.at<double>(0, 0);
-  for (int c = 0; c < (calls > 1 ? calls : 1); ++c) {
+  // SFM_BA_SELFTEST_NEW_STRUCTURE = k: k more calls behind those, each on a structure the library has not seen (the track of
+  // one more point loses its first view): what a caller that adds or drops a view between calls pays in a warm process
+  const int fresh = getenv("SFM_BA_SELFTEST_NEW_STRUCTURE") ? atoi(getenv("SFM_BA_SELFTEST_NEW_STRUCTURE")) : 0;
+  const int n_calls = (calls > 1 ? calls : 1) + (fresh > 0 ? fresh : 0);
+  for (int c = 0; c < n_calls; ++c) {
     if (c) {
       cloud = cloud0;
       poses = poses0;
       K.K.at<double>(0, 0) = f0;
       K.K.at<double>(1, 1) = f0;
+    }
+    for (int k = 0; k <= c - (calls > 1 ? calls : 1) && k < n_pt; ++k) {
+      auto& track = cloud[n_pt - 1 - k].idxImage;
+      if (track.size() > 2) track.erase(track.begin());
     }
     BundleAdjustment::adjustBundle(cloud, poses, K, feats);
     const SfmBaCallProfile& p = sfm_ba_last_call_profile();
