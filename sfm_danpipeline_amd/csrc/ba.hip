@@ -610,15 +610,68 @@ struct CamLds {  // camera table transposed in LDS: element e of camera slot o a
 #ifndef SFM_ELIM_LB
 #define SFM_ELIM_LB __launch_bounds__(512)
 #endif
-template <int NB>
+static bool elim_lp10() {
+  static const bool v = !(getenv("SFMHIP_BA_ELIM_LP") && atoi(getenv("SFMHIP_BA_ELIM_LP")) == 16);
+  return v;
+}
+// LP = lanes per point.  16 (rounds 2-5): a point's observations on one 16-lane DPP row, four points per wave and iteration; a
+// ten-camera point leaves six lanes of sixteen with the constant camera slot.  10 (round 6): six points per wave and iteration
+// (lanes 60-63 idle), the same instructions for 1.5 x the points; the twelve sums over a point's lanes, which no longer sit in one
+// DPP row, meet through the wave's panel in LDS (group_sum12), and the Gram panel is 18 rows -- five k-steps -- instead of 12.
+template <int LP>
+struct ElimShape {
+  static constexpr int PPW = 64 / LP;               // points per wave and iteration
+  static constexpr int KST = (3 * PPW + 3) / 4;     // k-steps of the Gram update (4 panel rows each)
+  static constexpr int PROWS = 4 * KST;             // panel rows per wave (rows beyond 3 * PPW stay zero)
+};
+// the twelve sums over the LP = 10 lanes of a point, every lane of the point ending up with all twelve: partials [12][66] into
+// the wave's panel (it is rewritten afterwards), lane o of a point adds value o over the point's ten lanes in lane order (lanes
+// 0 and 1 also values 10 and 11), the totals [6][12] behind the partials, read back by every lane of the point.  A wave's LDS
+// operations execute in order; the fences keep the compiler from moving them.
+__device__ __forceinline__ void group10_sum12(double (&red)[12], double* R, int lane, int q, int o) {
+  constexpr int PR = 66;
+  typedef __attribute__((address_space(3))) double ldsd;
+  ldsd* Rl = (ldsd*)R;
+#pragma unroll
+  for (int v = 0; v < 12; ++v) Rl[v * PR + lane] = red[v];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int qq = q < 6 ? q : 5;  // (the idle lanes 60-63 read point 5's: finite numbers, masked out by the caller)
+  const ldsd* a = Rl + o * PR + qq * 10;
+  const ldsd* b = Rl + (10 + (o & 1)) * PR + qq * 10;
+  double s0 = a[0], s1 = b[0];
+#pragma unroll
+  for (int j = 1; j < 10; ++j) {
+    s0 += a[j];
+    s1 += b[j];
+  }
+  ldsd* Tt = Rl + 12 * PR;
+  if (q < 6) {
+    Tt[q * 12 + o] = s0;
+    if (o < 2) Tt[q * 12 + 10 + o] = s1;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int v = 0; v < 12; ++v) red[v] = Tt[qq * 12 + v];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NB, int LP>
 __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restrict__ chunks, const int chunk_index,
                                                          const int* __restrict__ sig_cams, double inv_radius,
                                                          double lm_lo, double lm_hi, int rank,
                                                          int norms /* 1: unscaled squared column norms of the cameras and the focal into dc, nothing else */,
                                                          double* __restrict__ slab /* non-null: the workgroup's sums go to its slab (ELIM_SLAB doubles per chunk) instead of atomics on S */) {
   constexpr int NT = NB * (NB + 1) / 2;
+  constexpr int PPW = ElimShape<LP>::PPW, KST = ElimShape<LP>::KST, PROWS = ElimShape<LP>::PROWS;
   __shared__ __attribute__((aligned(16))) double s_cam[CAMD * 16];
-  extern __shared__ __attribute__((aligned(16))) double s_M[];  // nw x 12 x MP panels; also the cross-wave reduction buffer
+  extern __shared__ __attribute__((aligned(16))) double s_M[];  // nw x PROWS x MP panels; also the cross-wave reduction buffer
+  __shared__ double s_tsc[3 * 16];  // LP = 10: the cameras' translation scales by slot (read per iteration: six registers for F^T F sums)
   __shared__ int s_gidx[64];  // local Gram index -> row/column of S; -2: the rhs column u; -1: padding
   __shared__ double s_wv[16];  // per wave: gradient maximum, failed point blocks (slab epilogue)
   const int nw = blockDim.x >> 6;  // 4 waves for long runs, 1 for runs of a few points (unstructured visibility)
@@ -641,11 +694,15 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
   // linearise instead of shadowing observation 0: constants in, constants out, no switching.  The launch runs at the clock the
   // power limit leaves it (2.1 GHz on a moving solve, 2.34 on zeros: scripts/elim_stamps.py): 69.1 -> 68.4 us (round 5).
   if (tid < CAMD) s_cam[tid * 16 + 15] = tid == 11 ? 1.0 : 0.0;
+  if (tid < 48) {
+    const int j = tid >> 4, so = tid & 15;
+    s_tsc[tid] = (norms || so >= n) ? 1.0 : d.scale_c[6 * cams[so] + 3 + j];
+  }
   // dynamic LDS: the F^T F accumulators [wave][e][slot] (nw x 36 x 16) + [3][16] | the waves' panels, later the
   // cross-wave reduction and the staged Gram block
   const int ff_sz = nw * 36 * FP + 3 * FP;
   double* s_P = s_M + ff_sz;
-  for (int idx = tid; idx < ff_sz + nw * 12 * MP; idx += (int)blockDim.x) s_M[idx] = 0.0;
+  for (int idx = tid; idx < ff_sz + nw * PROWS * MP; idx += (int)blockDim.x) s_M[idx] = 0.0;
   if (tid < 64) {
     int gi = -1;
     if (tid < 6 * n) gi = 6 * cams[tid / 6] + tid % 6;
@@ -653,8 +710,9 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
     else if (tid == 6 * n + 1) gi = -2;
     s_gidx[tid] = gi;
   }
-  const int o = lane & 15, q = lane >> 4;
-  const bool valid_o = o < n;
+  const int o = LP == 16 ? (lane & 15) : lane % LP, q = LP == 16 ? (lane >> 4) : lane / LP;
+  const bool lane_ok = q < PPW;  // (LP = 10: lanes 60-63 belong to no point)
+  const bool valid_o = lane_ok && o < n;
   const int oc = valid_o ? o : 0;  // idle lanes take observation 0's addresses (finite data) and slot 15's camera table (above); masked out below
   double sc[6];
   {
@@ -672,7 +730,7 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
   for (int t = 0; t < NT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
   double gmax = 0.0;
   int nfail = 0;
-  double* Mw = s_P + wave * (12 * MP);
+  double* Mw = s_P + wave * (PROWS * MP);
   const lds_double* cam_lds = (const lds_double*)s_cam + (valid_o ? o : 15);
   const int frow = lane >> 4, fcol = lane & 15;
   // F^T F part of a camera slot (the 6x6 block (upper, 21), the focal border (6), F^T b (6), Jf^2, Jf r, r^2 --
@@ -684,7 +742,7 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
   double nX[3];
   double2 nxy;
   auto fetch = [&](int quad_) {
-    const int pi_ = 4 * quad_ + q;
+    const int pi_ = PPW * quad_ + q;
     const int pl_ = pi_ < ch.cnt ? pi_ : ch.cnt - 1;
     const int p_ = ch.p0 + pl_;
     nX[0] = d.pts[3 * p_];
@@ -703,8 +761,15 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
 #ifdef SFM_ELIM_FFREG
   constexpr int FFREG = SFM_ELIM_FFREG;  // (measurement builds)
 #else
-  constexpr int FFREG = NB == 4 ? 29 : 36;
+  // (LP = 10: the translation scales come from LDS every iteration, which leaves registers for three more sums; the four that
+  // still have none go to cells of the LANE's own -- [e - FFREG][lane] in the wave's part of the accumulator array, whose cells
+  // for the register sums are idle until the loop is over --, so that their ds_add_f64 hit no cell twice: with six lanes to a
+  // cell they took 2 k cycles that the point sums' LDS round trip, next in the wave's LDS queue, had to wait for)
+  constexpr int FFREG = NB == 4 ? (LP == 10 ? 32 : 29) : 36;
 #endif
+  constexpr bool FF_PRIVATE = LP == 10 && FFREG < 36;
+  static_assert(!FF_PRIVATE || (36 - FFREG) * 64 <= FFREG * FP, "the lanes' own cells fit the idle part of the accumulator array");
+  lds_double* ffp = (lds_double*)s_M + wave * (36 * FP) + lane;
   double ffr[FFREG > 0 ? FFREG : 1];
 #pragma unroll
   for (int e = 0; e < FFREG; ++e) ffr[e] = 0.0;
@@ -712,13 +777,13 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
   EL_STAMP(2, true);
   EL_STAMPW(24 + (wave & 3));
 
-  for (int quad = wave; 4 * quad < ch.cnt; quad += nw) {
+  for (int quad = wave; PPW * quad < ch.cnt; quad += nw) {
     EL_STAMP(8, quad == wave + 2 * nw);
     const lds_double* cam_d = cam_lds;
     asm volatile("" : "+v"(cam_d));
     const CamLds cd{cam_lds, cam_d};
-    const int pi = 4 * quad + q;
-    const bool pv = pi < ch.cnt;
+    const int pi = PPW * quad + q;
+    const bool pv = lane_ok && pi < ch.cnt;
     const double X[3] = {nX[0], nX[1], nX[2]};
     // (the point's column scale and its inverse are not needed before the F^T F sums are through -- the scale goes onto Jp with
     // the mask below --, so they are loaded here and not an iteration ahead with the point: twelve registers for F^T F sums)
@@ -732,15 +797,27 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
       }
     }
     const double2 xy = nxy;
-    if (4 * (quad + nw) < ch.cnt) fetch(quad + nw);
+    if (PPW * (quad + nw) < ch.cnt) fetch(quad + nw);
     ObsLin ol;
-    obs_linearize_g<CamLds, const double*, true>(cd, X, focal, xy.x, xy.y, sc, (const double*)nullptr, sf, ol);
+    if (LP == 10) {
+      const lds_double* tsc = (const lds_double*)s_tsc + (valid_o ? o : 15);
+      asm volatile("" : "+v"(tsc));  // (re-read every iteration, not hoisted into six registers)
+      struct {
+        const lds_double* p;
+        __device__ __forceinline__ explicit operator bool() const { return true; }
+        __device__ __forceinline__ double operator[](int j) const { return j >= 3 ? p[(j - 3) * 16] : 1.0; }
+      } scl{tsc};
+      obs_linearize_g<CamLds, decltype(scl), true>(cd, X, focal, xy.x, xy.y, scl, (const double*)nullptr, sf, ol);
+    } else {
+      obs_linearize_g<CamLds, const double*, true>(cd, X, focal, xy.x, xy.y, sc, (const double*)nullptr, sf, ol);
+    }
     EL_STAMP(9, quad == wave + 2 * nw);
     const double live = (pv && valid_o) ? 1.0 : 0.0;
     if (pv && valid_o) {
       // (Jc[4] = Jc[9] = 0: row 0 has no t_y column, row 1 no t_x column; entry (3,4) is identically zero)
       auto ff_add = [&](int e, double v) {
-        __hip_atomic_fetch_add(ffw + e * FP, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (FF_PRIVATE) __hip_atomic_fetch_add(ffp + (e - FFREG) * 64, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_fetch_add(ffw + e * FP, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       };
       // one product / the sum of two products into sum e: a register of the lane while they last, else the LDS cell
       auto ff1 = [&](int e, double a, double c) {
@@ -798,8 +875,12 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
       red[6 + a] = ol.Jp[a] * ol.r0 + ol.Jp[3 + a] * ol.r1;
       red[9 + a] = ol.Jp[a] * ol.Jf[0] + ol.Jp[3 + a] * ol.Jf[1];
     }
+    if (LP == 16) {
 #pragma unroll
-    for (int e = 0; e < 12; ++e) red[e] = row16_sum(red[e]);
+      for (int e = 0; e < 12; ++e) red[e] = row16_sum(red[e]);
+    } else {
+      group10_sum12(red, Mw, lane, q, o);
+    }
     // LM damping of the point block: D^2 = clamp(diag) / radius
     double C[6] = {red[0], red[1], red[2], red[3], red[4], red[5]};
     C[0] += fmin(fmax(C[0], lm_lo), lm_hi) * inv_radius;
@@ -816,7 +897,9 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
     // gradient of the point (unscaled) for the gradient tolerance
     gmax = fmax(gmax, pvf * fmax(fabs(red[6] * isp[0]), fmax(fabs(red[7] * isp[1]), fabs(red[8] * isp[2]))));
     EL_STAMP(12, quad == wave + 2 * nw);
-    if (valid_o) {
+    // (LP = 10: the sums above went through the panel's rows, so EVERY column of a point's rows is written -- a lane without an
+    // observation writes the zeros that Jp = 0 makes of its products, where LP = 16 leaves the zeros of the set-up alone)
+    if (LP == 16 ? valid_o : lane_ok) {
       // T = (Jc^T Jp) Li^T = Jc^T (Jp Li^T): Q = Jp Li^T first (2 x 3, twelve operations), then T[i][k] = Jc[0][i] Q[0][k] +
       // Jc[1][i] Q[1][k] -- 48 operations where forming W = Jc^T Jp and then W Li^T took 72; row k of the panel
       double* row0 = Mw + (3 * q) * MP + 6 * o;
@@ -830,7 +913,7 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
         row0[2 * MP + i] = ol.Jc[i] * q02 + ol.Jc[6 + i] * q12;
       }
     }
-    if (o == 0) {
+    if (o == 0 && lane_ok) {
       // border columns: t_f = Li wf, u = Li gp
       double* b0 = Mw + (3 * q) * MP + 6 * n;
       b0[0] = pvf * (Li[0] * red[9]);
@@ -843,7 +926,7 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
     EL_STAMP(13, quad == wave + 2 * nw);
     // Gram update: the same fragment serves as A (M^T tile) and B (M tile) operand
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks) {
+    for (int ks = 0; ks < KST; ++ks) {
       double fr[NB];
 #pragma unroll
       for (int blk = 0; blk < NB; ++blk) fr[blk] = Mw[(4 * ks + frow) * MP + 16 * blk + fcol];
@@ -858,10 +941,26 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
   }
   EL_STAMP(3, true);
   EL_STAMPW(20 + (wave & 7));
+  double ffx[FF_PRIVATE ? 36 - FFREG : 1];
+  if (FF_PRIVATE) {
+    // the lanes' own cells: read, put back to zero (they are the register sums' cells again), then added like the register sums
+#pragma unroll
+    for (int e = 0; e < 36 - FFREG; ++e) ffx[e] = ffp[e * 64];
+#pragma unroll
+    for (int e = 0; e < 36 - FFREG; ++e) ffp[e * 64] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
   if (valid_o) {
 #pragma unroll
     for (int e = 0; e < FFREG; ++e)
       __hip_atomic_fetch_add(ffw + e * FP, ffr[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (FF_PRIVATE) {
+#pragma unroll
+      for (int e = 0; e < 36 - FFREG; ++e)
+        __hip_atomic_fetch_add(ffw + (FFREG + e) * FP, ffx[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
   }
 
   // ---- epilogue.  Only LDS traffic between the barriers (a barrier waits for the wave's outstanding global
@@ -1064,7 +1163,7 @@ __device__ __forceinline__ void elim_chunk(const BaDev& d, const Chunk* __restri
   EL_STAMP(6, true);
 }
 
-template <int NB>
+template <int NB, int LP>
 __global__ SFM_ELIM_LB void ba_eliminate_mfma(BaDev d, const Chunk* __restrict__ chunks, const int* __restrict__ chunk_ids,
                                               const int* __restrict__ sig_cams, double inv_radius, double lm_lo, double lm_hi,
                                               int rank, int norms, double* __restrict__ slab) {
@@ -1078,7 +1177,7 @@ __global__ SFM_ELIM_LB void ba_eliminate_mfma(BaDev d, const Chunk* __restrict__
     lm_view(d, radius);
     inv_radius = 1.0 / radius;
   }
-  elim_chunk<NB>(d, chunks, chunk_ids[blockIdx.x], sig_cams, inv_radius, lm_lo, lm_hi, rank, norms, slab);
+  elim_chunk<NB, LP>(d, chunks, chunk_ids[blockIdx.x], sig_cams, inv_radius, lm_lo, lm_hi, rank, norms, slab);
 }
 
 // Sums the slabs of ba_eliminate_mfma into the reduced-system buffer: one thread per destination (an entry of S's
@@ -3984,7 +4083,10 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
     for (int t = 32; t <= 1024; t += 4) {
       long long w = 0;
       for (int g : gsz) w += (g + t - 1) / t;
-      const double cost = (double)((w + 511) / 512) * ((double)((t + 15) / 16) + 7.0);
+      // (a workgroup's iteration takes 4 waves x 4 points, or x 6 with ten lanes per point, whose iterations are a third longer:
+      // the fixed part counts for fewer of them)
+      const int ppi = elim_lp10() ? 24 : 16;
+      const double cost = (double)((w + 511) / 512) * ((double)((t + ppi - 1) / ppi) + (elim_lp10() ? 5.5 : 7.0));
       if (cost < best) {
         best = cost;
         target = t;
@@ -4625,6 +4727,8 @@ static int ba_launch_eliminate(sfmhip_ba* b, double inv_radius, double lm_lo, do
   // 22.5 us as a thread per destination (1 M scattered 8-byte sources), 10.9 us row by row (ba_gather_rows): the stage
   // 92.2 us against 91.3.
   double* slab = b->elim_deterministic ? b->d_slab : nullptr;
+  // ten lanes per point (six points per wave and iteration) unless SFMHIP_BA_ELIM_LP=16 asks for the sixteen of rounds 2-5 (A/B)
+  const bool lp10 = elim_lp10();
 #define BA_ELIM(NB)                                                                                                   \
   for (int cls = 0; cls < 2; ++cls) {                                                                                 \
     const int li = 4 * cls + NB - 1, nthreads = cls ? 64 : 64 * b->elim_waves;                                        \
@@ -4633,10 +4737,16 @@ static int ba_launch_eliminate(sfmhip_ba* b, double inv_radius, double lm_lo, do
     const size_t nw_ = nthreads / 64, gram_ = (size_t)(NB * (NB + 1) / 2) * 256;                                      \
     /* (four waves: the cross-wave sum takes four buffers of up to five tiles) */                                      \
     const size_t red_ = nw_ == 4 ? (size_t)4 * std::min(NB * (NB + 1) / 2, 5) * 256 : 0;                              \
-    const size_t lds = sizeof(double) * (nw_ * 36 * FP + 3 * FP + std::max(std::max(nw_ * 12 * MP, gram_), red_));    \
-    hipLaunchKernelGGL((ba_eliminate_mfma<NB>), dim3(b->n_chunk_ids[li]), dim3(nthreads), lds, st, b->d,              \
-                       b->d_chunks, b->d_chunk_ids[li],                                                               \
-                       b->d_sig_cams, inv_radius, lm_lo, lm_hi, b->rank, norms, slab);                                \
+    const size_t prows_ = lp10 ? ElimShape<10>::PROWS : ElimShape<16>::PROWS;                                          \
+    const size_t lds = sizeof(double) * (nw_ * 36 * FP + 3 * FP + std::max(std::max(nw_ * prows_ * MP, gram_), red_)); \
+    if (lp10)                                                                                                         \
+      hipLaunchKernelGGL((ba_eliminate_mfma<NB, 10>), dim3(b->n_chunk_ids[li]), dim3(nthreads), lds, st, b->d,        \
+                         b->d_chunks, b->d_chunk_ids[li],                                                             \
+                         b->d_sig_cams, inv_radius, lm_lo, lm_hi, b->rank, norms, slab);                              \
+    else                                                                                                              \
+      hipLaunchKernelGGL((ba_eliminate_mfma<NB, 16>), dim3(b->n_chunk_ids[li]), dim3(nthreads), lds, st, b->d,        \
+                         b->d_chunks, b->d_chunk_ids[li],                                                             \
+                         b->d_sig_cams, inv_radius, lm_lo, lm_hi, b->rank, norms, slab);                              \
     ++nl;                                                                                                             \
   }
   BA_ELIM(1)
