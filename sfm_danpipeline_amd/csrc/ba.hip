@@ -46,6 +46,7 @@
 #include <thread>
 #include <vector>
 #include <float.h>
+#include <unistd.h>
 
 namespace {
 
@@ -3709,6 +3710,7 @@ class HostPool {
   }
   // f(t) for t in [0, nth): the caller is t = 0.  Returns false when the pool is taken (nothing has run).
   bool run(int nth, const std::function<void(int)>& f) {
+    if (getpid() != pid_) return false;  // (a forked child has this object but none of its threads: it starts its own)
     std::unique_lock<std::mutex> job_lock(job_m_, std::try_to_lock);
     if (!job_lock.owns_lock()) return false;
     {
@@ -3750,6 +3752,7 @@ class HostPool {
       }
     }
   }
+  const pid_t pid_ = getpid();
   std::mutex job_m_, m_;
   std::condition_variable cv_, done_;
   std::vector<std::thread> workers_;

@@ -1034,6 +1034,63 @@ def test_a_timed_out_hand_off_between_fronts_is_repeated_level_by_level(host_loo
     assert good[1:5] == bad[1:5] and good[6] == bad[6]             # termination, iterations, accepted steps, cost and cameras: same bits
 
 
+def _timeout_rank_worker(rank, world, port, out_dir, so_bad):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from sfm_danpipeline_amd import _lib as L, bundle as B, sharding, synth as S
+    assert L._lib is None                                          # (nothing has loaded the library in this process yet)
+    L.SO = so_bad if rank == 1 else os.path.join(L.HERE, "libsfmhip.so")   # rank 1: the build with the hand-off that never arrives
+    ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    pb = S.ba_problem(96, 6000, 6, seed=45)
+    loc = sharding.local_ba_problem(pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], pb["pts0"], rank, world)
+    prob = B.BaProblem(96, len(loc["pts"]), loc["obs_cam"], loc["obs_pt"], loc["obs_xy"], ctx=ctx)
+    ar = sharding.StagedAllReduce(device="cuda:0")
+    prob.set_allreduce(ar, rank, world)
+    prob.set_params(pb["cams0"], loc["pts"], pb["focal0"])
+    s = prob.run(B.default_opts())
+    c, p, f = prob.get_params()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), c=c, f=f, cost=s.final_cost, it=s.iterations, steps=s.successful_steps,
+             term=s.termination, timeouts=s.spin_timeouts, fronts=prob.reduced_tree()["fronts"], n_exchanges=len(ar.counts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_spin_time_out_on_one_rank_stops_every_rank(ctx, tmp_path):
+    """A bounded wait that runs out is a scheduling artefact of ONE device; the ranks of a sharded solve must take the same decision
+    all the same, or the one that stopped leaves its peers waiting in an all-reduce it never issues (advisor, round 5).  Two ranks
+    share the device (gloo, staged exchange); rank 1 loads the diagnostic build whose first front never raises its flag in the
+    one-launch up-sweep, rank 0 the product.  The flag travels with the step evaluation's sums: BOTH ranks report the time-out,
+    both repeat the solve level by level, both issue the same exchanges, and the solve ends where the single-process solve does,
+    the replicated cameras bitwise equal."""
+    import socket
+    import torch.multiprocessing as mp
+    from sfm_danpipeline_amd import build
+    so = [p for p in build.build_timeout_diag() if p.endswith("breakfront.so")][0]
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    mp.spawn(_timeout_rank_worker, args=(2, port, str(tmp_path), so), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert int(r0["fronts"]) >= 3
+    assert int(r0["timeouts"]) >= 1 and int(r1["timeouts"]) >= 1, (int(r0["timeouts"]), int(r1["timeouts"]))
+    assert int(r0["n_exchanges"]) == int(r1["n_exchanges"])
+    assert (int(r0["term"]), int(r0["it"]), int(r0["steps"])) == (int(r1["term"]), int(r1["it"]), int(r1["steps"]))
+    assert np.array_equal(r0["c"], r1["c"]) and float(r0["f"]) == float(r1["f"]) and float(r0["cost"]) == float(r1["cost"])
+    pb = synth.ba_problem(96, 6000, 6, seed=45)
+    c1, p1, f1, s1 = bundle.ba_solve(*_ba_args(pb), opts=bundle.default_opts(), ctx=ctx)
+    assert (s1.termination, s1.iterations, s1.successful_steps) == (int(r0["term"]), int(r0["it"]), int(r0["steps"]))
+    assert abs(float(r0["cost"]) - s1.final_cost) <= 1e-9 * s1.final_cost
+    assert np.allclose(r0["c"], c1, rtol=1e-6, atol=1e-9) and abs(float(r0["f"]) - f1) <= 1e-6 * f1
+
+
 def test_a_spin_that_times_out_inside_a_workgroup_is_an_error_not_a_trajectory():
     """... and where no fallback exists (an LDS hand-off inside chol_step2, the dense factorisation: a bug, not a scheduling
     artefact) the caller gets SFMHIP_ERR_TIMEOUT instead of an LM run that silently took other steps."""

@@ -259,6 +259,34 @@ def test_heavy_ties_across_tiles_and_chunks(ctx, orc, nq, nt, levels, seed):
     _assert_pair(orc, pl2, 0, qb, orb, _lib.HAMMING)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_ties_at_the_second_best_value_inside_a_lane(ctx, orc, seed):
+    """The resolve of round 6 reads one or two candidate rows where it read four: where the second-best value of a lane is both its
+    slot's and its tile's maximum, the rows (first tile, other slot), (second tile, either slot) are told apart by position, and one
+    of them is entered with a value that was never read.  Here the second-best distance of most queries is held by SEVERAL train
+    rows -- exact copies placed one row, one tile (32 rows) and several tiles away, before and behind the best row -- and the best
+    distance by copies too: every list must still be cv::batchDistance's (lower train index first), bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    nt = int(rng.integers(96, 900))
+    nq = int(rng.integers(40, 260))
+    centres = rng.integers(0, 256, (max(nt // 6, 4), 128))
+    t = centres[rng.integers(0, len(centres), nt)].copy()
+    # a few dimensions differ by small steps inside a cluster: distances tie often, but not always
+    for _ in range(3):
+        d_ = rng.integers(0, 128, nt)
+        t[np.arange(nt), d_] = np.clip(t[np.arange(nt), d_] + rng.integers(-2, 3, nt), 0, 255)
+    for off in (1, 2, 31, 32, 33, 64, 97, 160):          # exact copies at lane / tile distances
+        src = rng.integers(0, nt, nt // 10)
+        dst = np.clip(src + rng.choice([-off, off], len(src)), 0, nt - 1)
+        t[dst] = t[src]
+    q = t[rng.integers(0, nt, nq)].copy()
+    dq = rng.integers(0, 128, nq)
+    q[np.arange(nq), dq] = np.clip(q[np.arange(nq), dq] + rng.integers(-1, 2, nq), 0, 255)
+    for cast in (np.float32, np.uint8):
+        s, pl = _plan(ctx, [q.astype(cast), t.astype(cast)], [[0, 1]])
+        _assert_pair(orc, pl, 0, q.astype(cast), t.astype(cast), _lib.L2)
+
+
 def test_one_pair_plan_retargeted_over_a_resident_set(ctx):
     """sfmhip_matchplan_set_pairs: a one-pair plan pointed at each pair in turn (the getMatching
     drop-in over descriptors resident in HBM) returns what the batched all-pairs plan returns."""
