@@ -3095,7 +3095,7 @@ __device__ __forceinline__ void lm_inputs_early(const BaDev& d, LmEarly& e) {
   e.lin0 = scv[0], e.lin2 = scv[2], e.lin3 = scv[3];
   e.s = *d.lm;
 }
-__device__ __forceinline__ void lm_decide_with(const BaDev& d, LmEarly& e, const double sums[4], bool peer_timeout = false) {
+__device__ __forceinline__ void lm_decide_with(const BaDev& d, LmEarly& e, const double sums[4], double peer_timeout = 0.0) {
   LmIn in;
   in.lin_cost = 0.5 * e.lin0;
   in.lin_nfail = e.lin2;
@@ -3105,7 +3105,10 @@ __device__ __forceinline__ void lm_decide_with(const BaDev& d, LmEarly& e, const
   in.step_n2 = sums[2];
   in.cand_n2 = sums[3];
   in.info = *(volatile int*)d.info;
-  if (peer_timeout && in.info >= 0) in.info = -1;  // (another rank's spin ran out: this rank stops with it)
+  // (another rank's spin ran out: this rank stops with it -- and with the same kind of time-out, so that every rank takes the
+  // same way out: the level-by-level repeat, or SFMHIP_ERR_TIMEOUT when a finisher's slot never arrived anywhere)
+  if (peer_timeout >= 1024.0) in.info = INFO_FINISHER_TIMEOUT;
+  else if (peer_timeout > 0.0 && in.info >= 0) in.info = -1;
   lm_decide(e.s, in);
   *d.lm = e.s;
 }
@@ -3113,7 +3116,7 @@ __device__ __forceinline__ void lm_decide_here(const BaDev& d) {
   LmEarly e;
   lm_inputs_early(d, e);
   const double sums[4] = {d.red2[0], d.red2[1], d.red2[2], d.red2[3]};
-  lm_decide_with(d, e, sums, d.red2[RED2_TIMEOUT] > 0.0);  // (behind the all-reduce: the ranks' flags summed)
+  lm_decide_with(d, e, sums, d.red2[RED2_TIMEOUT]);  // (behind the all-reduce: the ranks' flags summed)
 }
 
 __global__ void ba_decide(BaDev d) {
@@ -3208,7 +3211,11 @@ __device__ __forceinline__ void step_finish(const BaDev& d, int slot, double cos
     if (s_to) atomicExch(d.info, INFO_FINISHER_TIMEOUT);  // (a workgroup of the step evaluation never wrote its slot: not a state the data can cause)
     // several ranks: a spin that ran out is this rank's alone (a scheduling artefact), the decision must be every rank's --
     // the flag travels with the sums through the all-reduce and lm_decide_here reads the total (RED2_TIMEOUT)
-    d.red2[RED2_TIMEOUT] = *(volatile int*)d.info < 0 ? 1.0 : 0.0;
+    // (1 per rank whose reduced solve timed out, 1024 per rank whose finisher did: the total tells every rank which case it is)
+    {
+      const int inf = *(volatile int*)d.info;
+      d.red2[RED2_TIMEOUT] = inf == INFO_FINISHER_TIMEOUT ? 1024.0 : inf < 0 ? 1.0 : 0.0;
+    }
     if (decide) lm_decide_with(d, early, sums);
   }
 }
@@ -5626,7 +5633,8 @@ static int ba_read_scalars(sfmhip_ba* b, IterScalars* s, bool with_step) {
     s->step_n2 = step[2];
     s->cand_n2 = step[3];
     memcpy(&s->info, step + RED2_INFO, sizeof(int));
-    if (step[RED2_TIMEOUT] > 0.0 && s->info >= 0) s->info = -1;  // (another rank's spin ran out: every rank repeats the solve)
+    if (step[RED2_TIMEOUT] >= 1024.0) s->info = INFO_FINISHER_TIMEOUT;  // (a finisher's slot never arrived on some rank: every rank reports it)
+    else if (step[RED2_TIMEOUT] > 0.0 && s->info >= 0) s->info = -1;     // (another rank's spin ran out: every rank repeats the solve)
   }
   return SFMHIP_OK;
 }
