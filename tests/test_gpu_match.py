@@ -287,6 +287,22 @@ def test_ties_at_the_second_best_value_inside_a_lane(ctx, orc, seed):
         _assert_pair(orc, pl, 0, q.astype(cast), t.astype(cast), _lib.L2)
 
 
+@pytest.mark.parametrize("nq,nt,dup", [(300, 8193, False), (200, 9000, True), (130, 17000, True)])
+def test_train_images_longer_than_an_epoch(ctx, orc, nq, nt, dup):
+    """Train images beyond 8192 rows are swept in epochs of 256 tiles (the tile tag has 8 bits), each resolved on its own and merged
+    through the k-NN buffer: the best row of one epoch and the second-best of another, ties across the epoch boundary (the earlier
+    epoch's row has the lower index and stays), queries flagged in one epoch only."""
+    imgs = synth.sift_image_set(2, max(nq, nt), 128, bank=max(nq, nt) + 500, seed=nq + nt)
+    q, t = imgs[0][:nq].copy(), imgs[1][:nt].copy()
+    if dup:
+        rng = np.random.default_rng(nt)
+        src = rng.integers(0, 8000, 400)
+        t[8192 + rng.integers(0, nt - 8192, 400)] = t[src]                                                    # copies in a later epoch
+        q[: nq // 2] = t[rng.integers(0, nt, nq // 2)]                                                        # exact hits, some with copies
+    s, pl = _plan(ctx, [q, t], [[0, 1]])
+    _assert_pair(orc, pl, 0, q, t, _lib.L2)
+
+
 def test_one_pair_plan_retargeted_over_a_resident_set(ctx):
     """sfmhip_matchplan_set_pairs: a one-pair plan pointed at each pair in turn (the getMatching
     drop-in over descriptors resident in HBM) returns what the batched all-pairs plan returns."""
