@@ -304,7 +304,7 @@ typedef struct sfmhip_ba_solve_profile {
   double keep_ms;       /* keeping the problem for the next call (a copy of obs_cam / obs_pt) or destroying it */
   double total_ms;
   int plan_reused;
-  int pad;
+  int front_plan_reused; /* a NEW structure whose camera graph equals the last one's: the front tree was not planned again */
 } sfmhip_ba_solve_profile;
 int sfmhip_ba_last_solve_profile(sfmhip_ctx* ctx, sfmhip_ba_solve_profile* out);
 

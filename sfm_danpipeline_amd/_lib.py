@@ -37,7 +37,7 @@ class BaSummary(C.Structure):
 class BaSolveProfile(C.Structure):
     """sfmhip_ba_solve_profile (include/sfmhip.h): where the last one-shot solve on a context spent its host time."""
     _fields_ = [("create_ms", C.c_double), ("set_params_ms", C.c_double), ("run_ms", C.c_double), ("get_params_ms", C.c_double),
-                ("keep_ms", C.c_double), ("total_ms", C.c_double), ("plan_reused", C.c_int), ("pad", C.c_int)]
+                ("keep_ms", C.c_double), ("total_ms", C.c_double), ("plan_reused", C.c_int), ("front_plan_reused", C.c_int)]
 
 
 class LmState(C.Structure):

@@ -3651,7 +3651,7 @@ struct sfmhip_ba {
   // dissected reduced system (NdPlan below): built at the first solve (with world > 1 the camera graph is the
   // union over the ranks, which needs the all-reduce)
   std::vector<unsigned long long> h_adj;  // camera co-visibility, nc x ceil(nc/64) bit rows (this rank's points)
-  bool nd_ready = false, nd_on = false;
+  bool nd_ready = false, nd_on = false, nd_kept = false;  // nd_kept: the front plan came from the context's last one-shot problem
   NdSet nd{};
   NdCols nd_cols{};
   int nd_max_ni = 0;
@@ -3886,6 +3886,14 @@ struct BaHostScratch {
   std::vector<int> cnt, slot, scam, run_of, order, optr, ocam, table, obs_src, cxy_src;
   std::vector<uint64_t> sig_hash;
   std::vector<double> oxy, h_pts_in;
+  // the front tree of the last one-shot problem: the per-view call pattern (src/Sfm.cpp:996) changes the tracks from call to
+  // call and the camera graph hardly ever -- a problem with the same graph (compared bit for bit) and the same planning
+  // switches takes the kept plan instead of dissecting again (2.5 ms of a 23 ms call at cfg4)
+  bool nd_valid = false;
+  int nd_nc = 0, nd_key[5] = {0, 0, 0, 0, 0};
+  std::vector<unsigned long long> nd_adj;
+  fplan::Plan nd_P;
+  fplan::Flat nd_fl;
 };
 static void ba_host_scratch_free(void* p) { delete (BaHostScratch*)p; }
 static BaHostScratch* ba_host_scratch(sfmhip_ctx* ctx) {
@@ -4985,16 +4993,40 @@ static int ba_nd_build(sfmhip_ba* b) {
     const char* he = getenv("SFMHIP_BA_TREE_HELPERS");
     fplan::Plan P;
     fplan::Flat fl;
-    for (int helpers = he ? std::max(0, std::min(8, atoi(he))) : 0; helpers >= 0; --helpers) {
-      for (int leaf : {96, 64, 32}) {
-        static const int keep_env = getenv("SFMHIP_BA_TREE_KEEP") ? atoi(getenv("SFMHIP_BA_TREE_KEEP")) : 8;  // (measurement)
-        P = fplan::build_plan(nc, adj.data(), wpr, lc ? atoi(lc) : leaf, helpers, keep_env);
-        if (P.ok || lc) break;
+    const bool prof_ = getenv("SFMHIP_PROFILE_CREATE") != nullptr;
+    auto tp_ = std::chrono::steady_clock::now();
+    auto lap_ = [&](const char* what) {
+      if (!prof_) return;
+      const auto now = std::chrono::steady_clock::now();
+      fprintf(stderr, "[ba_nd_build] %-22s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tp_).count());
+      tp_ = now;
+    };
+    static const int keep_env = getenv("SFMHIP_BA_TREE_KEEP") ? atoi(getenv("SFMHIP_BA_TREE_KEEP")) : 8;  // (measurement)
+    // (a one-shot problem: the plan of the last one, when the camera graph and the switches are the same -- BaHostScratch)
+    static const bool plan_cache_on = !(getenv("SFMHIP_BA_PLAN_CACHE") && atoi(getenv("SFMHIP_BA_PLAN_CACHE")) == 0);
+    BaHostScratch* const hs = plan_cache_on && b->use_arena && b->world == 1 ? ba_host_scratch(b->ctx) : nullptr;
+    const int key[5] = {lc ? atoi(lc) : -1, he ? atoi(he) : -1, keep_env, b->ctx->n_cu, 1};
+    const bool kept = hs && hs->nd_valid && hs->nd_nc == nc && memcmp(hs->nd_key, key, sizeof key) == 0 && hs->nd_adj == adj;
+    b->nd_kept = kept;
+    if (kept) {
+      P = hs->nd_P;
+      fl = hs->nd_fl;
+    } else {
+      for (int helpers = he ? std::max(0, std::min(8, atoi(he))) : 0; helpers >= 0; --helpers) {
+        for (int leaf : {96, 64, 32}) {
+          P = fplan::build_plan(nc, adj.data(), wpr, lc ? atoi(lc) : leaf, helpers, keep_env);
+          if (P.ok || lc) break;
+        }
+        if (!P.ok) break;
+        fl = fplan::flatten(P);
+        if ((int)fl.up_roles.size() <= b->ctx->n_cu || he) break;
       }
-      if (!P.ok) break;
-      fl = fplan::flatten(P);
-      if ((int)fl.up_roles.size() <= b->ctx->n_cu || he) break;
+      if (hs) {  // (a refused plan is kept as well: the next call does not search for it again)
+        hs->nd_valid = true, hs->nd_nc = nc, hs->nd_adj = adj, hs->nd_P = P, hs->nd_fl = fl;
+        memcpy(hs->nd_key, key, sizeof key);
+      }
     }
+    lap_(kept ? "front plan (kept)" : "front plan");
     if (P.ok) {
       int* d_ints = nullptr;
       int* d_up = nullptr;
@@ -5030,6 +5062,7 @@ static int ba_nd_build(sfmhip_ba* b) {
         std::vector<unsigned long long> pend(2 * (size_t)b->ld, FR_Z_PENDING);
         SFM_HIP_TRY(hipMemcpy(zq, pend.data(), pend.size() * 8, hipMemcpyHostToDevice));
       }
+      lap_("plan uploads");
       b->tree_fs.zq = zq;
       b->tree_fs.zq_ld = b->ld;
       b->tree_fs.n_fronts = fl.n_fronts;
@@ -6270,6 +6303,7 @@ extern "C" int sfmhip_ba_solve(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, 
   pr.set_params_ms = lap();
   if (rc == SFMHIP_OK) rc = sfmhip_ba_run(b, opts, summary);
   pr.run_ms = lap();
+  pr.front_plan_reused = b && !pr.plan_reused && b->nd_kept ? 1 : 0;
   if (rc == SFMHIP_OK) rc = sfmhip_ba_get_params(b, cams6, pts3, focal);
   pr.get_params_ms = lap();
   if (b && !pr.plan_reused) ctx->ba_arena_need = std::max(ctx->ba_arena_need, b->arena_need);

@@ -103,9 +103,9 @@ int main(int argc, char** argv) {
     const SfmBaCallProfile& p = sfm_ba_last_call_profile();
     printf("{\"call\": %d, \"n_cam\": %d, \"n_pt\": %d, \"n_obs\": %d, \"pack_ms\": %.3f, \"create_ms\": %.3f, \"set_params_ms\": %.3f, "
            "\"run_ms\": %.3f, \"get_params_ms\": %.3f, \"keep_ms\": %.3f, \"solve_ms\": %.3f, \"writeback_ms\": %.3f, \"total_ms\": %.3f, "
-           "\"plan_reused\": %d}\n",
+           "\"plan_reused\": %d, \"front_plan_reused\": %d}\n",
            c, p.n_cam, p.n_pt, p.n_obs, p.pack_ms, p.solve.create_ms, p.solve.set_params_ms, p.solve.run_ms, p.solve.get_params_ms,
-           p.solve.keep_ms, p.solve_ms, p.writeback_ms, p.total_ms, p.solve.plan_reused);
+           p.solve.keep_ms, p.solve_ms, p.writeback_ms, p.total_ms, p.solve.plan_reused, p.solve.front_plan_reused);
   }
   FILE* o = fopen(argv[2], "wb");
   if (!o) return 2;

@@ -644,6 +644,43 @@ def test_one_shot_solve_keeps_its_plan_for_a_call_of_the_same_structure(ctx):
     c.close()
 
 
+def test_one_shot_solve_keeps_the_front_tree_of_an_unchanged_camera_graph(ctx):
+    """The per-view call pattern of src/Sfm.cpp:996 changes the tracks from call to call and the camera graph hardly ever: a NEW
+    structure over the same camera graph is set up anew but takes the kept front tree (front_plan_reused), and returns the bits
+    of a problem built from nothing; a structure with another camera graph plans its own tree -- same check."""
+    c = _lib.Context(0)
+    pb = synth.ba_problem(96, 6000, 6, seed=92)
+    a = _ba_args(pb)
+
+    def fresh_bits(args):
+        pr = bundle.BaProblem(96, 6000, args[3], args[4], args[5], ctx=ctx)   # (sfmhip_ba_create: nothing kept, nothing re-used)
+        pr.set_params(args[0], args[1], args[2])
+        s = pr.run(bundle.default_opts())
+        out = pr.get_params() + (s, pr.reduced_tree())
+        pr.close()
+        return out
+
+    bundle.ba_solve(*a, ctx=c)
+    p0 = bundle.last_solve_profile(c)
+    assert (p0["plan_reused"], p0["front_plan_reused"]) == (0, 0)
+    d = (a[0], a[1], a[2], a[3][:-1], a[4][:-1], a[5][:-1])   # one observation less of a six-view track: the same camera graph
+    r = bundle.ba_solve(*d, ctx=c)
+    p1 = bundle.last_solve_profile(c)
+    assert (p1["plan_reused"], p1["front_plan_reused"]) == (0, 1)
+    f = fresh_bits(d)
+    assert f[4]["fronts"] > 1, "the check wants a front tree"
+    assert _eq_bits(r[0], f[0]) and _eq_bits(r[1], f[1]) and r[2] == f[2] and r[3].iterations == f[3].iterations
+    oc = a[3].copy()
+    oc[5] = (oc[5] + 48) % 96                                  # an edge the ring does not have: another graph, another tree
+    e = (a[0], a[1], a[2], oc, a[4], a[5])
+    r = bundle.ba_solve(*e, ctx=c)
+    p2 = bundle.last_solve_profile(c)
+    assert (p2["plan_reused"], p2["front_plan_reused"]) == (0, 0)
+    f = fresh_bits(e)
+    assert _eq_bits(r[0], f[0]) and _eq_bits(r[1], f[1]) and r[2] == f[2] and r[3].iterations == f[3].iterations
+    c.close()
+
+
 def _logical_ranks_solve(pb, world, opts=None, iterate=None):
     """BASELINE cfg4's split, `world` logical ranks on the one device: a BaProblem per rank over its point block (all cameras, the
     focal), a context + stream + host thread each, the exchange summed on the device in rank order (sharding.InProcessRanks)."""
