@@ -4624,17 +4624,36 @@ extern "C" int sfmhip_ba_set_allreduce(sfmhip_ba* b, sfmhip_allreduce_fn fn, voi
   return SFMHIP_OK;
 }
 
+// device -> the context's pinned block by stores of a kernel (what the LM loop's records do): a blit out of a fresh allocation
+// cost 8 ms the first time (the runtime's set-up for that block of memory; measured in whichever call met the block first)
+__global__ __launch_bounds__(256) void ba_export_params(const double* __restrict__ cams, size_t n_c, const double* __restrict__ pts, size_t n_p,
+                                                        const double* __restrict__ focal, double* __restrict__ host) {
+  const size_t n = n_c + n_p + 1;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    host[i] = i < n_c ? cams[i] : i < n_c + n_p ? pts[i - n_c] : *focal;
+}
+
 extern "C" int sfmhip_ba_set_params(sfmhip_ba* b, const double* cams6, const double* pts3, double focal) {
   if (!b || !cams6 || (!pts3 && b->np_in)) return SFMHIP_ERR_ARG;
   SFM_HIP_TRY(hipSetDevice(b->ctx->device));
   hipStream_t st = b->ctx->stream;
   if (b->np_in) memcpy(b->h_pts_in.data(), pts3, sizeof(double) * 3 * (size_t)b->np_in);
-  std::vector<double> sorted(3 * (size_t)std::max(b->np, 1));
-  for (int sp = 0; sp < b->np; ++sp)
-    for (int j = 0; j < 3; ++j) sorted[3 * (size_t)sp + j] = pts3[3 * (size_t)b->perm[sp] + j];
-  SFM_HIP_TRY(hipMemcpyAsync(b->d.cams, cams6, sizeof(double) * 6 * b->nc, hipMemcpyHostToDevice, st));
-  if (b->np) SFM_HIP_TRY(hipMemcpyAsync(b->d.pts, sorted.data(), sizeof(double) * 3 * (size_t)b->np, hipMemcpyHostToDevice, st));
-  SFM_HIP_TRY(hipMemcpyAsync(b->d.focal, &focal, sizeof(double), hipMemcpyHostToDevice, st));
+  // through the context's pinned block (synchronous use: free again at the return): a copy from pageable memory goes through the
+  // runtime's own staging, whose first use in a process costs 8-27 ms -- measured inside whichever call met it first
+  const size_t n_c = 6 * (size_t)b->nc, n_p = 3 * (size_t)b->np;
+  void* pin = nullptr;
+  SFM_TRY(sfm_ctx_pinned(b->ctx, sizeof(double) * (n_c + n_p + 1), &pin));
+  double* const hc = (double*)pin;
+  double* const sorted = hc + n_c;
+  memcpy(hc, cams6, sizeof(double) * n_c);
+  host_parallel_for(b->np, [&](int lo, int hi) {
+    for (int sp = lo; sp < hi; ++sp)
+      for (int j = 0; j < 3; ++j) sorted[3 * (size_t)sp + j] = pts3[3 * (size_t)b->perm[sp] + j];
+  });
+  sorted[n_p] = focal;
+  SFM_HIP_TRY(hipMemcpyAsync(b->d.cams, hc, sizeof(double) * n_c, hipMemcpyHostToDevice, st));
+  if (b->np) SFM_HIP_TRY(hipMemcpyAsync(b->d.pts, sorted, sizeof(double) * n_p, hipMemcpyHostToDevice, st));
+  SFM_HIP_TRY(hipMemcpyAsync(b->d.focal, sorted + n_p, sizeof(double), hipMemcpyHostToDevice, st));
   SFM_HIP_TRY(hipStreamSynchronize(st));
   b->scale_ready = false;
   b->camd_valid = false;
@@ -4646,15 +4665,25 @@ extern "C" int sfmhip_ba_get_params(sfmhip_ba* b, double* cams6, double* pts3, d
   if (!b) return SFMHIP_ERR_ARG;
   SFM_HIP_TRY(hipSetDevice(b->ctx->device));
   hipStream_t st = b->ctx->stream;
-  std::vector<double> sorted(3 * (size_t)std::max(b->np, 1));
-  if (cams6) SFM_HIP_TRY(hipMemcpyAsync(cams6, b->d.cams, sizeof(double) * 6 * b->nc, hipMemcpyDeviceToHost, st));
-  if (pts3 && b->np) SFM_HIP_TRY(hipMemcpyAsync(sorted.data(), b->d.pts, sizeof(double) * 3 * (size_t)b->np, hipMemcpyDeviceToHost, st));
-  if (focal) SFM_HIP_TRY(hipMemcpyAsync(focal, b->d.focal, sizeof(double), hipMemcpyDeviceToHost, st));
+  const size_t n_c = 6 * (size_t)b->nc, n_p = 3 * (size_t)b->np;
+  void* pin = nullptr;
+  SFM_TRY(sfm_ctx_pinned(b->ctx, sizeof(double) * (n_c + n_p + 1), &pin));  // (as in sfmhip_ba_set_params)
+  double* const hc = (double*)pin;
+  double* const sorted = hc + n_c;
+  double* hdev = nullptr;
+  SFM_HIP_TRY(hipHostGetDevicePointer((void**)&hdev, hc, 0));
+  hipLaunchKernelGGL(ba_export_params, dim3((unsigned)std::min<size_t>((n_c + n_p) / 1024 + 1, 512)), dim3(256), 0, st, b->d.cams, n_c, b->d.pts,
+                     n_p, b->d.focal, hdev);
+  SFM_HIP_TRY(hipGetLastError());
   SFM_HIP_TRY(hipStreamSynchronize(st));
+  if (cams6) memcpy(cams6, hc, sizeof(double) * n_c);
+  if (focal) *focal = sorted[n_p];
   if (pts3) {
     memcpy(pts3, b->h_pts_in.data(), sizeof(double) * 3 * (size_t)b->np_in);  // points without observations
-    for (int sp = 0; sp < b->np; ++sp)
-      for (int j = 0; j < 3; ++j) pts3[3 * (size_t)b->perm[sp] + j] = sorted[3 * (size_t)sp + j];
+    host_parallel_for(b->np, [&](int lo, int hi) {
+      for (int sp = lo; sp < hi; ++sp)
+        for (int j = 0; j < 3; ++j) pts3[3 * (size_t)b->perm[sp] + j] = sorted[3 * (size_t)sp + j];
+    });
   }
   return SFMHIP_OK;
 }
