@@ -4034,6 +4034,7 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
       }
     }
   }
+  lap_("  sig: hash table");
   std::vector<int> run_start(run_rep.size() + 1, 0);
   for (size_t r = 0; r < run_rep.size(); ++r) run_start[r + 1] = run_start[r] + run_cnt[r];
   std::vector<int>& order = hs->order;
@@ -4043,6 +4044,7 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
     for (int p = 0; p < n_pt; ++p)
       if (run_of[p] >= 0) order[fillr[run_of[p]]++] = p;
   }
+  lap_("  sig: counting sort");
   b->np = (int)order.size();
   b->perm = order;
   std::vector<int>& optr = hs->optr;
@@ -4055,6 +4057,7 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
   oxy.resize(2 * (size_t)b->no);
   b->obs_src.resize(b->no);
   b->h_cam_used.assign(n_cam, 0);
+  lap_("  sig: optr + resizes");
   // the gather of a million observations is a cache-miss chain on one core: split it over a few (each marks the cameras it
   // meets in a list of its own; the lists are merged behind the threads)
   {
@@ -4151,6 +4154,25 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
       }
     }
   }
+  // Short runs: the pair path sums per camera pair instead of per run, which is what a camera list shared by a dozen points
+  // wants -- when there are thousands of such lists.  The path itself costs four launches behind the elimination (33 us of a
+  // 220 us iteration at cfg4, measured with ONE such point), so while nothing else needs it (no ragged, unsorted or > 10-camera
+  // point) and the short runs are few, each becomes a small piece of the elimination: a workgroup among 512
+  // (SFMHIP_BA_SHORT_PIECES = the most short runs that are turned into pieces, 0: none; scripts/gpu_short_runs_ab.py)
+  bool short_as_pieces = false;
+  {
+    const int max_pieces = getenv("SFMHIP_BA_SHORT_PIECES") ? atoi(getenv("SFMHIP_BA_SHORT_PIECES")) : 512;  // (read per problem)
+    int n_short = 0;
+    bool pair_path_needed = false;
+    for (size_t gi = 0; gi + 1 < gstart.size() && !pair_path_needed; ++gi) {
+      const int sp = gstart[gi], n = optr[sp + 1] - optr[sp];
+      bool strict = true;
+      for (int k = 1; k < n; ++k) strict = strict && ocam[optr[sp] + k - 1] < ocam[optr[sp] + k];
+      if (!(n <= 10 && strict)) pair_path_needed = true;
+      else if (gstart[gi + 1] - sp <= SHORT_RUN) ++n_short;
+    }
+    short_as_pieces = !pair_path_needed && n_short > 0 && n_short <= max_pieces;
+  }
   for (size_t gi = 0; gi + 1 < gstart.size(); ++gi) {
     const int sp = gstart[gi], e = gstart[gi + 1];
     const int n = optr[sp + 1] - optr[sp];
@@ -4160,11 +4182,11 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
       const int so = (int)sig_cams.size();
       for (int k = 0; k < n; ++k) sig_cams.push_back(ocam[optr[sp] + k]);
       const int nb = (6 * n + 2 + 15) / 16;
-      if (e - sp <= SHORT_RUN) {
+      if (e - sp <= SHORT_RUN && !short_as_pieces) {
         sig_cams.resize(so);  // (a camera list shared by few points: the pair path, per-pair instead of per-run sums)
         for (int q = sp; q < e; ++q) fb.push_back(q);
       } else {
-        const int parts = parts_of[gi];
+        const int parts = std::max(parts_of[gi], 1);
         for (int q = 0; q < parts; ++q) {
           const int lo = sp + (int)((long long)(e - sp) * q / parts), hi = sp + (int)((long long)(e - sp) * (q + 1) / parts);
           ids[nb - 1].push_back((int)chunks.size());
@@ -6004,12 +6026,16 @@ extern "C" int sfmhip_ba_run(sfmhip_ba* b, const sfmhip_ba_opts* opts, sfmhip_ba
   }
   sfmhip_ba_summary sm;
   memset(&sm, 0, sizeof sm);
+  const bool prof_ = getenv("SFMHIP_PROFILE_CREATE") != nullptr;
   SFM_TRY(ba_begin(b, opts));
+  if (prof_) fprintf(stderr, "[sfmhip_ba_run] begin %7.2f ms\n", elapsed() * 1e3);
   LmDev& s = b->lm.s;
   int term = SFMHIP_BA_NO_CONVERGENCE;
   if (s.gmax <= opts->gradient_tolerance) term = SFMHIP_BA_CONVERGENCE;
   else SFM_TRY(ba_lm_loop(b, opts, -1, elapsed, &term));
+  if (prof_) fprintf(stderr, "[sfmhip_ba_run] loop  %7.2f ms (%d iterations)\n", elapsed() * 1e3, s.iter);
   SFM_TRY(ba_flush_lin(b, opts));
+  if (prof_) fprintf(stderr, "[sfmhip_ba_run] flush %7.2f ms\n", elapsed() * 1e3);
   if (term == SFMHIP_BA_NO_CONVERGENCE && s.gmax <= opts->gradient_tolerance) term = SFMHIP_BA_CONVERGENCE;
   b->lm.started = false;  // a finished solve is not resumable
   ba_fill_summary(b, term, elapsed(), &sm);

@@ -873,6 +873,42 @@ def test_linearisation_is_bitwise_reproducible(ctx, monkeypatch):
     ref.close()
 
 
+def test_a_few_short_runs_become_pieces_of_the_elimination(ctx, orc, monkeypatch):
+    """A camera list that only a handful of points share ("short run") used to send its points to the pair path -- four more
+    launches per iteration for what may be ONE point (the per-view pattern of src/Sfm.cpp:996 produces exactly that).  While
+    nothing else needs the pair path, up to 512 short runs are pieces of ba_eliminate_mfma instead: the same reduced system
+    as the pair path's (SFMHIP_BA_SHORT_PIECES=0) to rounding, the oracle's trajectory, fewer launches."""
+    pb = synth.ba_problem(43, 2500, 6, seed=43)
+    keep = np.ones(len(pb["obs_cam"]), bool)
+    keep[[6 * 17 + 2, 6 * 900 + 0, 6 * 2499 + 5]] = False          # three points lose one of their six views
+    oc, op, xy = pb["obs_cam"][keep], pb["obs_pt"][keep], pb["obs_xy"][keep]
+    out = {}
+    for tag, env in (("pieces", None), ("pair_path", "0")):
+        if env is None:
+            monkeypatch.delenv("SFMHIP_BA_SHORT_PIECES", raising=False)
+        else:
+            monkeypatch.setenv("SFMHIP_BA_SHORT_PIECES", env)
+        pr = bundle.BaProblem(43, 2500, oc, op, xy, ctx=ctx)
+        pr.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+        S, g, cost = pr.reduced_system(1e4)
+        pr.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+        s = pr.iterate(4)
+        out[tag] = (S, g, cost, s, pr.last_timing()["launches"])
+        pr.close()
+    monkeypatch.delenv("SFMHIP_BA_SHORT_PIECES", raising=False)
+    a, b = out["pieces"], out["pair_path"]
+    assert np.abs(a[0] - b[0]).max() <= 1e-12 * np.abs(b[0]).max() and np.abs(a[1] - b[1]).max() <= 1e-12 * np.abs(b[1]).max()
+    assert abs(a[2] - b[2]) <= 1e-13 * b[2]
+    assert a[3].successful_steps == b[3].successful_steps and abs(a[3].final_cost - b[3].final_cost) <= 1e-10 * b[3].final_cost
+    assert a[4] < b[4], (a[4], b[4])
+    args = (pb["cams0"], pb["pts0"], pb["focal0"], oc, op, xy)
+    c, p, f, s = bundle.ba_solve(*args, opts=bundle.default_opts(max_time_s=0.0), ctx=ctx)
+    co, po, fo, so = orc.ba_solve(*args, opts=orc.default_opts(max_time_s=0.0))
+    assert (s.termination, s.iterations, s.successful_steps) == (so.termination, so.iterations, so.successful_steps)
+    assert abs(s.final_cost - so.final_cost) <= BA_COST_RTOL * so.final_cost
+    assert np.allclose(c, co, rtol=BA_PARAM_RTOL, atol=1e-9) and np.allclose(p, po, rtol=BA_PARAM_RTOL, atol=1e-9)
+
+
 @pytest.mark.parametrize("case", ["ragged", "many_per_camera"])
 def test_linearisation_of_ragged_tracks_is_bitwise_reproducible(ctx, monkeypatch, case):
     """The same for the points the runs do not take (the pair path: ba_pp_points / ba_pp_pairs / ba_cam_blocks): ragged,
