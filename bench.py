@@ -715,7 +715,8 @@ def main():
             assert r_.returncode == 0 and "failed" not in r_.stderr, r_.stderr[-2000:]
             recs = [json.loads(l_) for l_ in r_.stdout.splitlines() if l_.startswith("{")]
             its_ = [int(l_.split("iterations")[1].split(",")[0]) for l_ in r_.stdout.splitlines() if l_.startswith("Bundle adjustment:")]
-            keys = ("pack_ms", "create_ms", "set_params_ms", "run_ms", "get_params_ms", "keep_ms", "writeback_ms", "total_ms", "plan_reused")
+            keys = ("pack_ms", "create_ms", "set_params_ms", "run_ms", "get_params_ms", "keep_ms", "writeback_ms", "total_ms", "plan_reused",
+                    "front_plan_reused")
             adjust_call[tag_] = {"lm_iterations": its_[0], "first_call_of_the_process": {k: recs[0][k] for k in keys},
                                  "repeated_call": {k: recs[2][k] for k in keys},
                                  "new_structure_call": {k: recs[-1][k] for k in keys},
@@ -729,7 +730,8 @@ def main():
                                "tree), write-back; first_call_of_the_process = everything cold (HIP start-up excluded: the context exists; the code "
                                "objects load, the arena and the pinned block are made, every page is touched for the first time), repeated_call = the "
                                "third call on the same structure (the kept plan), new_structure_call = a call on a structure never seen, in a warm "
-                               "process (the reference's per-view pattern: the plan is rebuilt, the memory is not)")
+                               "process (the reference's per-view pattern: a point lost a view -- the runs, pieces and gather lists are rebuilt; the memory "
+                               "and, the camera graph being the same, the front tree are not: front_plan_reused)")
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only)
     cpu_baseline = None
