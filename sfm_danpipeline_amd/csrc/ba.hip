@@ -1228,10 +1228,10 @@ __global__ __launch_bounds__(256) void ba_gather_slabs(const double* __restrict_
 __global__ __launch_bounds__(256) void ba_gather_rows(const double* __restrict__ slab,
                                                       const int* __restrict__ colmap, const int4* __restrict__ row_hdr,
                                                       const int4* __restrict__ row_head, const int4* __restrict__ row_src, int nrows,
-                                                      int row_wgs, int ld, int fo, int nchunks, const int* __restrict__ ptr,
+                                                      int row_wgs, int ld, int accw, int fo, int nchunks, const int* __restrict__ ptr,
                                                       const unsigned* __restrict__ src, const int* __restrict__ dest, int nd,
                                                       double* __restrict__ red, long long gmax_off, int rmw, const LmDev* __restrict__ lm) {
-  extern __shared__ double s_acc[];  // per wave: ld + 3 (the row of S | g's entry | the F^T F diagonal's | F^T b's)
+  extern __shared__ double s_acc[];  // per wave: accw >= 6 |cameras of the row's camera's list| + 4 (those columns of S | the focal column | g's entry | the F^T F diagonal's | F^T b's)
   if (lm && lm->stop != LM_RUNNING) return;
   if ((int)blockIdx.x == (int)gridDim.x - 1) {
     // the last workgroup: the seven destinations that every chunk adds to (the focal parameter's diagonal entry and gradient
@@ -1305,11 +1305,13 @@ __global__ __launch_bounds__(256) void ba_gather_rows(const double* __restrict__
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   const int w = blockIdx.x * nw + wave;
   if (w >= nrows) return;
-  double* acc = s_acc + (size_t)wave * (ld + 3);
+  double* acc = s_acc + (size_t)wave * accw;
   // (the row's header and its first 32 source records sit at addresses that follow from w alone: one round trip for both)
-  const int4 hdr = row_hdr[w];                      // {row of S, sources, first source record beyond the head, -}
+  const int4 hdr = row_hdr[w];                      // {row of S, sources, first source record beyond the head, the camera's list (in colmap, behind its length)}
   int4 my = lane < 32 ? row_head[(size_t)w * 32 + lane] : make_int4(0, 0, 0, 0);
-  for (int c = lane; c < ld + 3; c += 64) acc[c] = 0.0;
+  const int* const clist = colmap + hdr.w;
+  const int nT = 6 * clist[-1], nacc = nT + 4;  // (needed for the last loop only: in flight beside the sources)
+  for (int c = lane; c < accw; c += 64) acc[c] = 0.0;
   const int gr = hdr.x, nsrc = hdr.y;
   // per-lane constants: where local column `lane` sits inside a row of the Gram block's MFMA layout
   const int lane_off = (lane >> 4) * 256 + (lane & 15);
@@ -1348,13 +1350,17 @@ __global__ __launch_bounds__(256) void ba_gather_rows(const double* __restrict__
   }
   double* Srow = red + (size_t)gr * ld;
   const size_t ssz = (size_t)ld * ld;
-  for (int c = lane; c < ld + 3; c += 64) {
+  for (int c = lane; c < nacc; c += 64) {
     const double a = acc[c];
     if (a != 0.0) {
-      double* at = c < ld ? Srow + c : c == ld ? red + ssz + gr : c == ld + 1 ? red + ssz + 2 * (size_t)ld + gr : red + ssz + (size_t)ld + gr;
+      double* at = c < nT       ? Srow + 6 * clist[c / 6] + c % 6
+                   : c == nT     ? Srow + fo
+                   : c == nT + 1 ? red + ssz + gr
+                   : c == nT + 2 ? red + ssz + 2 * (size_t)ld + gr
+                                 : red + ssz + (size_t)ld + gr;
       // (rmw == 0: the MFMA path is the only writer of these entries between the memset and here -- no pair-path points)
       const double o = rmw ? *at : 0.0;
-      *at = c <= ld ? o - a : o + a;  // S -= Gram (F^T F folded in), g likewise; the diagonal and F^T b +=
+      *at = c <= nT + 1 ? o - a : o + a;  // S -= Gram (F^T F folded in), g likewise; the diagonal and F^T b +=
     }
   }
 }
@@ -3620,7 +3626,7 @@ struct sfmhip_ba {
   int4* d_grow_head = nullptr;
   int4* d_grow_src = nullptr;
   int* d_grow_colmap = nullptr;
-  int n_grow = 0, grow_waves = 4, n_chunks = 0;
+  int n_grow = 0, grow_waves = 4, grow_accw = 64, n_chunks = 0;  // grow_accw: a wave's accumulator (doubles)
   int* d_chunk_ids[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int n_chunk_ids[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [NB-1]: 4-wave workgroups (long runs), [4 + NB-1]: 1-wave (short runs)
   int* d_sig_cams = nullptr;
@@ -4217,13 +4223,34 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
     const int ld = b->ld, fo = 6 * n_cam;
     const long long ssz = (long long)b->ssz, o_g = ssz, o_gF = ssz + ld, o_dc = ssz + 2LL * ld, o_sc = ssz + 3LL * ld;
     std::vector<std::pair<long long, unsigned>> ent[2];  // (destination, source | sign)
-    // rows of S by their own kernel role while a row-long accumulator per wave fits the default LDS limit -- and while the row is
-    // short: a wave zeroes and scans its row's ld entries whatever the row holds, and at 640 cameras (ld 3904) that outweighs what
-    // the row-wise reads save (rings, scripts/gpu_gather_ab.py: 400 cameras 5111 it/s by rows against 5006 by destinations, 640:
-    // 3458 / 3811, 1000: 2426 / 2964).  SFMHIP_BA_GATHER_ROWS = 0 / 2: never / whenever it fits (measurement)
+    // rows of S by their own kernel role while a wave's accumulator fits the default LDS limit (until round 6 the accumulator was
+    // a whole row, ld entries zeroed and scanned whatever the row held: at 640 cameras that outweighed what the row-wise reads
+    // save, and rows of more than 3072 columns went through the per-destination lists -- scripts/gpu_gather_bits.py: 640 cameras
+    // 3305 -> 3619 it/s, 1000: 2805 -> 3267, the same bits as the whole-row form wherever that ran).
+    // SFMHIP_BA_GATHER_ROWS = 0: never (the per-destination lists: measurement, and the check of the row lists)
     const int rows_env = getenv("SFMHIP_BA_GATHER_ROWS") ? atoi(getenv("SFMHIP_BA_GATHER_ROWS")) : 1;
-    const bool use_rows = (size_t)(ld + 3) * 8 <= 65536 && rows_env != 0 && (ld <= 3072 || rows_env == 2);
-    b->grow_waves = (size_t)(ld + 3) * 8 * 4 <= 65536 ? 4 : (size_t)(ld + 3) * 8 * 2 <= 65536 ? 2 : 1;
+    // (round 6: a row's accumulator holds only the columns the row can have -- the cameras that share a run with the row's camera,
+    // the focal column, g's / the diagonal's / F^T b's entries --, not all ld of them: a wave zeroed and scanned ld entries whatever
+    // the row held, which is what kept rows of 640 cameras and more on the per-destination lists)
+    std::vector<std::vector<int>> touched(n_cam);  // per camera: the cameras of the runs it is in, ascending
+    {
+      std::vector<char> seen_sig(sig_cams.size() + 1, 0);
+      for (const Chunk& ch : chunks) {
+        if (seen_sig[ch.sig_off]) continue;
+        seen_sig[ch.sig_off] = 1;
+        for (int a = 0; a < ch.n; ++a)
+          for (int c2 = 0; c2 < ch.n; ++c2) touched[sig_cams[ch.sig_off + a]].push_back(sig_cams[ch.sig_off + c2]);
+      }
+      for (auto& t : touched) {
+        std::sort(t.begin(), t.end());
+        t.erase(std::unique(t.begin(), t.end()), t.end());
+      }
+    }
+    size_t accw = 64;  // a wave's accumulator: 6 entries per camera of the longest list + 4, in whole 64s
+    for (const auto& t : touched) accw = std::max(accw, (6 * t.size() + 4 + 63) / 64 * 64);
+    const bool use_rows = accw * 8 <= 65536 && rows_env != 0;
+    b->grow_waves = accw * 8 * 4 <= 65536 ? 4 : accw * 8 * 2 <= 65536 ? 2 : 1;
+    b->grow_accw = (int)accw;
     if (use_rows) {
       std::vector<int> cntr((size_t)fo + 1, 0);
       for (const Chunk& ch : chunks)
@@ -4232,18 +4259,35 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
       for (int r = 0; r < fo; ++r) cntr[r + 1] += cntr[r];
       grow_src.resize((size_t)cntr[fo]);
       std::vector<int> pos(cntr.begin(), cntr.end() - 1);
-      std::map<int, int> cmap_of;  // signature (offset of its camera list) -> offset of its column map
+      // the cameras' lists, each behind its length: a row's header points at its camera's
+      std::vector<int> clist_of(n_cam, 0);
+      for (int c = 0; c < n_cam; ++c) {
+        if (touched[c].empty()) continue;
+        grow_colmap.push_back((int)touched[c].size());
+        clist_of[c] = (int)grow_colmap.size();
+        grow_colmap.insert(grow_colmap.end(), touched[c].begin(), touched[c].end());
+      }
+      std::map<std::pair<int, int>, int> cmap_of;  // (signature = offset of its camera list, the row's camera's place in it) -> offset of the column map
       for (size_t c = 0; c < chunks.size(); ++c) {  // chunk order inside every row
         const Chunk& ch = chunks[c];
         const int n = ch.n, NBc = (6 * n + 2 + 15) / 16;
-        auto itc = cmap_of.find(ch.sig_off);
-        if (itc == cmap_of.end()) {
-          // local column -> where it adds: a column of S, the focal column, g's entry (ld); 62, 63: the diagonal's and F^T b's
-          itc = cmap_of.emplace(ch.sig_off, (int)grow_colmap.size()).first;
-          for (int lc = 0; lc < 64; ++lc)
-            grow_colmap.push_back(lc >= 62 ? ld + lc - 61 : lc < 6 * n ? 6 * sig_cams[ch.sig_off + lc / 6] + lc % 6 : lc == 6 * n ? fo : ld);
-        }
-        for (int sl = 0; sl < n; ++sl)
+        for (int sl = 0; sl < n; ++sl) {
+          auto itc = cmap_of.find({ch.sig_off, sl});
+          if (itc == cmap_of.end()) {
+            // local column -> its place in the accumulator of a row of camera sig[sl]: 6 * (the column's camera's rank in that
+            // camera's list) + component; behind the nT = 6 * |list| columns of S: the focal column, g's entry; 62, 63: the
+            // diagonal's and F^T b's
+            itc = cmap_of.emplace(std::make_pair(ch.sig_off, sl), (int)grow_colmap.size()).first;
+            const std::vector<int>& tl = touched[sig_cams[ch.sig_off + sl]];
+            const int nT = 6 * (int)tl.size();
+            for (int lc = 0; lc < 64; ++lc) {
+              int v;
+              if (lc >= 62) v = nT + lc - 60;
+              else if (lc < 6 * n) v = 6 * (int)(std::lower_bound(tl.begin(), tl.end(), sig_cams[ch.sig_off + lc / 6]) - tl.begin()) + lc % 6;
+              else v = lc == 6 * n ? nT : nT + 1;
+              grow_colmap.push_back(v);
+            }
+          }
           for (int i = 0; i < 6; ++i) {
             const int lr = 6 * sl + i, ti = lr >> 4;
             const int t0 = ti * NBc - ti * (ti - 1) / 2;  // tile (ti, ti)
@@ -4252,6 +4296,7 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
             grow_src[(size_t)pos[(size_t)6 * sig_cams[ch.sig_off + sl] + i]++] =
                 make_int4((int)(unsigned)(c * (size_t)ELIM_SLAB), lr | (n << 8) | (roff << 16), itc->second, dcr | (gfr << 16));
           }
+        }
       }
       for (int r = 0; r < fo; ++r)
         if (cntr[r + 1] > cntr[r]) {
@@ -4262,7 +4307,7 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
       // a row's first 32 records in a table of their own (fixed stride), the rest in one overflow list
       for (size_t r = 0; r < grow_id.size(); ++r) {
         const int k0 = grow_ptr[r], cnt = grow_ptr[r + 1] - k0;
-        grow_hdr.push_back(make_int4(grow_id[r], cnt, (int)grow_over.size(), 0));
+        grow_hdr.push_back(make_int4(grow_id[r], cnt, (int)grow_over.size(), clist_of[grow_id[r] / 6]));
         for (int k = 0; k < 32; ++k) grow_head.push_back(k < cnt ? grow_src[(size_t)k0 + k] : make_int4(0, 0, 0, 0));
         for (int k = 32; k < cnt; ++k) grow_over.push_back(grow_src[(size_t)k0 + k]);
       }
@@ -4826,10 +4871,10 @@ static int ba_launch_eliminate(sfmhip_ba* b, double inv_radius, double lm_lo, do
   const int m = norms ? 1 : 0;
   if (slab && nl && m == 0 && b->n_grow) {
     const int rw = (b->n_grow + b->grow_waves - 1) / b->grow_waves, gw = (b->n_gth[0] * 16 + 64 * b->grow_waves - 1) / (64 * b->grow_waves);
-    const size_t lds_g = sizeof(double) * std::max((size_t)(b->ld + 3) * b->grow_waves, (size_t)7 * 64 * b->grow_waves);
+    const size_t lds_g = sizeof(double) * std::max((size_t)b->grow_accw * b->grow_waves, (size_t)7 * 64 * b->grow_waves);
     hipLaunchKernelGGL(ba_gather_rows, dim3(rw + gw + 1), dim3(64 * b->grow_waves), lds_g, st,
                        (const double*)slab, (const int*)b->d_grow_colmap, (const int4*)b->d_grow_hdr,
-                       (const int4*)b->d_grow_head, (const int4*)b->d_grow_src, b->n_grow, rw, b->ld, 6 * b->nc, b->n_chunks, (const int*)b->d_gth_ptr[0],
+                       (const int4*)b->d_grow_head, (const int4*)b->d_grow_src, b->n_grow, rw, b->ld, b->grow_accw, 6 * b->nc, b->n_chunks, (const int*)b->d_gth_ptr[0],
                        (const unsigned*)b->d_gth_src[0], (const int*)b->d_gth_dest[0], b->n_gth[0], b->d.red,
                        (long long)(b->ssz + 3 * (size_t)b->ld + SC + b->rank), b->n_fb ? 1 : 0, (const LmDev*)b->d.lm);
     ++nl;
