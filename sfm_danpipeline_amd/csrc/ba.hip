@@ -4709,7 +4709,12 @@ extern "C" int sfmhip_ba_set_params(sfmhip_ba* b, const double* cams6, const dou
   // runtime's own staging, whose first use in a process costs 8-27 ms -- measured inside whichever call met it first
   const size_t n_c = 6 * (size_t)b->nc, n_p = 3 * (size_t)b->np;
   void* pin = nullptr;
-  SFM_TRY(sfm_ctx_pinned(b->ctx, sizeof(double) * (n_c + n_p + 1), &pin));
+  std::vector<double> unpinned;  // (pinning refused: the runtime's own staging)
+  if (sfm_ctx_pinned(b->ctx, sizeof(double) * (n_c + n_p + 1), &pin) != SFMHIP_OK) {
+    (void)hipGetLastError();
+    unpinned.resize(n_c + n_p + 1);
+    pin = unpinned.data();
+  }
   double* const hc = (double*)pin;
   double* const sorted = hc + n_c;
   memcpy(hc, cams6, sizeof(double) * n_c);
@@ -4734,14 +4739,26 @@ extern "C" int sfmhip_ba_get_params(sfmhip_ba* b, double* cams6, double* pts3, d
   hipStream_t st = b->ctx->stream;
   const size_t n_c = 6 * (size_t)b->nc, n_p = 3 * (size_t)b->np;
   void* pin = nullptr;
-  SFM_TRY(sfm_ctx_pinned(b->ctx, sizeof(double) * (n_c + n_p + 1), &pin));  // (as in sfmhip_ba_set_params)
+  std::vector<double> unpinned;
+  const bool pinned = sfm_ctx_pinned(b->ctx, sizeof(double) * (n_c + n_p + 1), &pin) == SFMHIP_OK;  // (as in sfmhip_ba_set_params)
+  if (!pinned) {
+    (void)hipGetLastError();
+    unpinned.resize(n_c + n_p + 1);
+    pin = unpinned.data();
+  }
   double* const hc = (double*)pin;
   double* const sorted = hc + n_c;
-  double* hdev = nullptr;
-  SFM_HIP_TRY(hipHostGetDevicePointer((void**)&hdev, hc, 0));
-  hipLaunchKernelGGL(ba_export_params, dim3((unsigned)std::min<size_t>((n_c + n_p) / 1024 + 1, 512)), dim3(256), 0, st, b->d.cams, n_c, b->d.pts,
-                     n_p, b->d.focal, hdev);
-  SFM_HIP_TRY(hipGetLastError());
+  if (pinned) {
+    double* hdev = nullptr;
+    SFM_HIP_TRY(hipHostGetDevicePointer((void**)&hdev, hc, 0));
+    hipLaunchKernelGGL(ba_export_params, dim3((unsigned)std::min<size_t>((n_c + n_p) / 1024 + 1, 512)), dim3(256), 0, st, b->d.cams, n_c, b->d.pts,
+                       n_p, b->d.focal, hdev);
+    SFM_HIP_TRY(hipGetLastError());
+  } else {
+    SFM_HIP_TRY(hipMemcpyAsync(hc, b->d.cams, sizeof(double) * n_c, hipMemcpyDeviceToHost, st));
+    if (n_p) SFM_HIP_TRY(hipMemcpyAsync(sorted, b->d.pts, sizeof(double) * n_p, hipMemcpyDeviceToHost, st));
+    SFM_HIP_TRY(hipMemcpyAsync(sorted + n_p, b->d.focal, sizeof(double), hipMemcpyDeviceToHost, st));
+  }
   SFM_HIP_TRY(hipStreamSynchronize(st));
   if (cams6) memcpy(cams6, hc, sizeof(double) * n_c);
   if (focal) *focal = sorted[n_p];
