@@ -307,6 +307,12 @@ typedef struct sfmhip_ba_solve_profile {
   int front_plan_reused; /* a NEW structure whose camera graph equals the last one's: the front tree was not planned again */
 } sfmhip_ba_solve_profile;
 int sfmhip_ba_last_solve_profile(sfmhip_ctx* ctx, sfmhip_ba_solve_profile* out);
+/* The library's host threads (a pool of up to 16 that lives as long as the process: the set-up's passes run on it) for a
+ * caller's own pass over its containers -- fn(lo, hi, user) on disjoint blocks of [0, n), the calling thread taking one of
+ * them; returns when all are done.  Below 20 000 items, or when the pool is busy, fn(0, n, user) runs on the caller alone /
+ * on threads started for the call.  What BundleAdjustment::adjustBundle's mirror packs and writes back with (the reference
+ * walks its std::map tracks on one thread, src/BundleAdjustment.cpp:83-110: 8 ms at cfg4). */
+int sfmhip_host_parallel_for(int n, void (*fn)(int lo, int hi, void* user), void* user);
 
 /* Persistent problem object (multi-GPU: every rank holds all cameras + focal and its own
  * block of points with their observations; the per-iteration sum of the reduced camera

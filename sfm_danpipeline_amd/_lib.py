@@ -75,7 +75,7 @@ SYMBOLS = [
     "sfmhip_matchplan_destroy",
     "sfmhip_triangulate", "sfmhip_find_2d3d", "sfmhip_merge_new_points", "sfmhip_ba_default_opts", "sfmhip_ba_solve", "sfmhip_ba_create",
     "sfmhip_ba_set_allreduce", "sfmhip_ba_set_params", "sfmhip_ba_get_params", "sfmhip_ba_run",
-    "sfmhip_ba_iterate", "sfmhip_ba_reduced_system", "sfmhip_ba_linearize_obs", "sfmhip_ba_last_timing", "sfmhip_ba_reduced_layout", "sfmhip_ba_reduced_tree", "sfmhip_probe_i8_mfma_peak", "sfmhip_probe_clock_start", "sfmhip_probe_clock_read", "sfmhip_ba_reduced_step", "sfmhip_ba_lm_decide", "sfmhip_score_essential", "sfmhip_score_last_flags", "sfmhip_score_five_point", "sfmhip_score_homography_kernel", "sfmhip_score_homography", "sfmhip_sift_detect_and_compute", "sfmhip_sift_detect_and_compute_device", "sfmhip_sift_batch", "sfmhip_device_free", "sfmhip_host_free", "sfmhip_device_download", "sfmhip_ba_destroy", "sfmhip_ba_last_solve_profile",
+    "sfmhip_ba_iterate", "sfmhip_ba_reduced_system", "sfmhip_ba_linearize_obs", "sfmhip_ba_last_timing", "sfmhip_ba_reduced_layout", "sfmhip_ba_reduced_tree", "sfmhip_probe_i8_mfma_peak", "sfmhip_probe_clock_start", "sfmhip_probe_clock_read", "sfmhip_ba_reduced_step", "sfmhip_ba_lm_decide", "sfmhip_score_essential", "sfmhip_score_last_flags", "sfmhip_score_five_point", "sfmhip_score_homography_kernel", "sfmhip_score_homography", "sfmhip_sift_detect_and_compute", "sfmhip_sift_detect_and_compute_device", "sfmhip_sift_batch", "sfmhip_device_free", "sfmhip_host_free", "sfmhip_device_download", "sfmhip_ba_destroy", "sfmhip_ba_last_solve_profile", "sfmhip_host_parallel_for",
 ]
 
 _lib = None

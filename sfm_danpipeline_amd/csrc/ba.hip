@@ -1315,6 +1315,7 @@ __global__ __launch_bounds__(256) void ba_gather_rows(const double* __restrict__
   const int gr = hdr.x, nsrc = hdr.y;
   // per-lane constants: where local column `lane` sits inside a row of the Gram block's MFMA layout
   const int lane_off = (lane >> 4) * 256 + (lane & 15);
+  const int lane_q = lane / 6, lane_r = lane - 6 * lane_q;  // (lane_q <= 10 below lane 62; 62, 63 read a pad entry)
   for (int kb = 0; kb < nsrc; kb += 32) {
     // source records: {slab offset of the chunk, local row | n << 8 | offset of the row inside the Gram block << 16, offset of
     // the signature's column map, offsets of the row's F^T F diagonal / F^T b sums}; up to GB sources in flight, each one load
@@ -1338,7 +1339,9 @@ __global__ __launch_bounds__(256) void ba_gather_rows(const double* __restrict__
         // lanes 62, 63 (beyond any Gram block of n <= 10 cameras): the row's entry of the F^T F diagonal and of F^T b
         const int idx = lane >= 62 ? ELIM_SLAB_FF + (lane == 62 ? (ff & 0xFFFF) : (int)((unsigned)ff >> 16)) : roff + lane_off;
         v[u] = slab[(size_t)(unsigned)base + (ok[u] ? idx : 0)];
-        col[u] = colmap[cm + lane];
+        // (the signature's cameras' ranks in the row's camera's list: local column -> place in the accumulator)
+        const int rk = colmap[cm + lane_q];
+        col[u] = lane >= 62 ? nT + lane - 60 : lane < 6 * n ? 6 * rk + lane_r : lane == 6 * n ? nT : nT + 1;
       }
       // ... before the first of them is waited for (a use next to its load makes the row's sources go to memory one after
       // the other)
@@ -3607,6 +3610,7 @@ struct sfmhip_ba {
   std::vector<int> obs_src;  // sorted observation -> input observation (ba_set_observations: the same structure, new measurements)
   std::vector<int> cxy_src;  // entry of the pair path's camera-major list -> sorted observation
   double2* d_oxy_w = nullptr;  // (the writable view of d.oxy)
+  int* d_obs_src = nullptr;    // observation w of the plan's order is observation d_obs_src[w] of the caller's
   std::vector<unsigned char> h_cam_used;
   unsigned char* d_cam_used = nullptr;
   bool cam_used_known = false;
@@ -3891,7 +3895,7 @@ extern "C" void sfmhip_ba_default_opts(sfmhip_ba_opts* o) {
 struct BaHostScratch {
   std::vector<int> cnt, slot, scam, run_of, order, optr, ocam, table, obs_src, cxy_src;
   std::vector<uint64_t> sig_hash;
-  std::vector<double> oxy, h_pts_in;
+  std::vector<double> h_pts_in;
   // the front tree of the last one-shot problem: the per-view call pattern (src/Sfm.cpp:996) changes the tracks from call to
   // call and the camera graph hardly ever -- a problem with the same graph (compared bit for bit) and the same planning
   // switches takes the kept plan instead of dissecting again (2.5 ms of a 23 ms call at cfg4)
@@ -3908,6 +3912,26 @@ static BaHostScratch* ba_host_scratch(sfmhip_ctx* ctx) {
     ctx->ba_host_scratch_free = ba_host_scratch_free;
   }
   return (BaHostScratch*)ctx->ba_host_scratch;
+}
+
+// the observations' coordinates from the caller's order into the plan's (a million 16-byte records: 1.1 ms of a set-up's host time
+// as a gather over sixteen host threads, 10 us here)
+__global__ __launch_bounds__(256) void ba_permute_xy(const double2* __restrict__ src, const int* __restrict__ perm, double2* __restrict__ dst, int n) {
+  for (int w = blockIdx.x * 256 + threadIdx.x; w < n; w += gridDim.x * 256) dst[w] = src[perm[w]];
+}
+
+// the caller's coordinates -> the context's device scratch -> the plan's order (d.oxy).  Synchronous: the scratch is free again
+// at the return.
+static int ba_upload_xy(sfmhip_ba* b, const double* obs_xy, int n_obs) {
+  if (!b->no) return SFMHIP_OK;
+  void* raw = nullptr;
+  SFM_TRY(sfm_ctx_dev_scratch(b->ctx, 1, sizeof(double) * 2 * (size_t)n_obs, &raw));
+  SFM_HIP_TRY(hipMemcpy(raw, obs_xy, sizeof(double) * 2 * (size_t)n_obs, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(ba_permute_xy, dim3((unsigned)std::min(1024, (b->no + 255) / 256)), dim3(256), 0, b->ctx->stream, (const double2*)raw,
+                     (const int*)b->d_obs_src, b->d_oxy_w, b->no);
+  SFM_HIP_TRY(hipGetLastError());
+  SFM_HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+  return SFMHIP_OK;
 }
 
 static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const int32_t* obs_cam, const int32_t* obs_pt,
@@ -4059,8 +4083,6 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
   b->no = optr[b->np];
   std::vector<int>& ocam = hs->ocam;
   ocam.resize(b->no);
-  std::vector<double>& oxy = hs->oxy;
-  oxy.resize(2 * (size_t)b->no);
   b->obs_src.resize(b->no);
   b->h_cam_used.assign(n_cam, 0);
   lap_("  sig: optr + resizes");
@@ -4078,9 +4100,7 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
           const int o = slot[k];
           b->obs_src[w] = o;
           ocam[w] = obs_cam[o];
-          mine[ocam[w]] = 1;
-          oxy[2 * (size_t)w] = obs_xy[2 * (size_t)o];
-          oxy[2 * (size_t)w + 1] = obs_xy[2 * (size_t)o + 1];
+          mine[ocam[w]] = 1;  // (the coordinates are put in this order on the device: ba_permute_xy)
         }
       }
     });
@@ -4232,22 +4252,28 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
     // (round 6: a row's accumulator holds only the columns the row can have -- the cameras that share a run with the row's camera,
     // the focal column, g's / the diagonal's / F^T b's entries --, not all ld of them: a wave zeroed and scanned ld entries whatever
     // the row held, which is what kept rows of 640 cameras and more on the per-destination lists)
-    std::vector<std::vector<int>> touched(n_cam);  // per camera: the cameras of the runs it is in, ascending
+    // per camera: the cameras of the runs it is in, ascending (tl_flat[tl_off[c] .. tl_off[c + 1])): a bit row per camera first
+    std::vector<int> tl_off(n_cam + 1, 0), tl_flat;
     {
+      const int wpr_ = (n_cam + 63) / 64;
+      std::vector<unsigned long long> bits((size_t)n_cam * wpr_, 0ull);
       std::vector<char> seen_sig(sig_cams.size() + 1, 0);
       for (const Chunk& ch : chunks) {
         if (seen_sig[ch.sig_off]) continue;
         seen_sig[ch.sig_off] = 1;
-        for (int a = 0; a < ch.n; ++a)
-          for (int c2 = 0; c2 < ch.n; ++c2) touched[sig_cams[ch.sig_off + a]].push_back(sig_cams[ch.sig_off + c2]);
+        for (int a = 0; a < ch.n; ++a) {
+          unsigned long long* row = bits.data() + (size_t)sig_cams[ch.sig_off + a] * wpr_;
+          for (int c2 = 0; c2 < ch.n; ++c2) row[sig_cams[ch.sig_off + c2] >> 6] |= 1ull << (sig_cams[ch.sig_off + c2] & 63);
+        }
       }
-      for (auto& t : touched) {
-        std::sort(t.begin(), t.end());
-        t.erase(std::unique(t.begin(), t.end()), t.end());
+      for (int c = 0; c < n_cam; ++c) {
+        for (int w = 0; w < wpr_; ++w)
+          for (unsigned long long m = bits[(size_t)c * wpr_ + w]; m; m &= m - 1) tl_flat.push_back(64 * w + __builtin_ctzll(m));
+        tl_off[c + 1] = (int)tl_flat.size();
       }
     }
     size_t accw = 64;  // a wave's accumulator: 6 entries per camera of the longest list + 4, in whole 64s
-    for (const auto& t : touched) accw = std::max(accw, (6 * t.size() + 4 + 63) / 64 * 64);
+    for (int c = 0; c < n_cam; ++c) accw = std::max(accw, (6 * (size_t)(tl_off[c + 1] - tl_off[c]) + 4 + 63) / 64 * 64);
     const bool use_rows = accw * 8 <= 65536 && rows_env != 0;
     b->grow_waves = accw * 8 * 4 <= 65536 ? 4 : accw * 8 * 2 <= 65536 ? 2 : 1;
     b->grow_accw = (int)accw;
@@ -4262,30 +4288,29 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
       // the cameras' lists, each behind its length: a row's header points at its camera's
       std::vector<int> clist_of(n_cam, 0);
       for (int c = 0; c < n_cam; ++c) {
-        if (touched[c].empty()) continue;
-        grow_colmap.push_back((int)touched[c].size());
+        if (tl_off[c + 1] == tl_off[c]) continue;
+        grow_colmap.push_back(tl_off[c + 1] - tl_off[c]);
         clist_of[c] = (int)grow_colmap.size();
-        grow_colmap.insert(grow_colmap.end(), touched[c].begin(), touched[c].end());
+        grow_colmap.insert(grow_colmap.end(), tl_flat.begin() + tl_off[c], tl_flat.begin() + tl_off[c + 1]);
       }
-      std::map<std::pair<int, int>, int> cmap_of;  // (signature = offset of its camera list, the row's camera's place in it) -> offset of the column map
+      // (signature = offset of its camera list, the row's camera's place in it) -> offset of the column map: twelve ints, the rank of
+      // every camera of the signature in the row's camera's list (the kernel makes the 64 local columns' places from them)
+      std::vector<int> cmap_of(sig_cams.size() + 1, -1);
       for (size_t c = 0; c < chunks.size(); ++c) {  // chunk order inside every row
         const Chunk& ch = chunks[c];
         const int n = ch.n, NBc = (6 * n + 2 + 15) / 16;
         for (int sl = 0; sl < n; ++sl) {
-          auto itc = cmap_of.find({ch.sig_off, sl});
-          if (itc == cmap_of.end()) {
-            // local column -> its place in the accumulator of a row of camera sig[sl]: 6 * (the column's camera's rank in that
-            // camera's list) + component; behind the nT = 6 * |list| columns of S: the focal column, g's entry; 62, 63: the
-            // diagonal's and F^T b's
-            itc = cmap_of.emplace(std::make_pair(ch.sig_off, sl), (int)grow_colmap.size()).first;
-            const std::vector<int>& tl = touched[sig_cams[ch.sig_off + sl]];
-            const int nT = 6 * (int)tl.size();
-            for (int lc = 0; lc < 64; ++lc) {
-              int v;
-              if (lc >= 62) v = nT + lc - 60;
-              else if (lc < 6 * n) v = 6 * (int)(std::lower_bound(tl.begin(), tl.end(), sig_cams[ch.sig_off + lc / 6]) - tl.begin()) + lc % 6;
-              else v = lc == 6 * n ? nT : nT + 1;
-              grow_colmap.push_back(v);
+          int& cm = cmap_of[ch.sig_off + sl];
+          if (cm < 0) {
+            // local column lc < 6 n of the signature -> its place in the accumulator of a row of camera sig[sl]: 6 * (the rank of
+            // camera sig[lc / 6] in that camera's list) + lc % 6; behind the nT = 6 * |list| columns of S: the focal column, g's
+            // entry, the diagonal's and F^T b's (ba_gather_rows)
+            cm = (int)grow_colmap.size();
+            const int* tl = tl_flat.data() + tl_off[sig_cams[ch.sig_off + sl]];
+            for (int a = 0, t = 0; a < 12; ++a) {  // (both lists ascend: one walk)
+              if (a < n)
+                while (tl[t] != sig_cams[ch.sig_off + a]) ++t;
+              grow_colmap.push_back(a < n ? t : 0);
             }
           }
           for (int i = 0; i < 6; ++i) {
@@ -4294,7 +4319,7 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
             const int roff = (t0 * 4 + ((lr & 15) >> 2)) * 64 + (lr & 3) * 16 - 256 * ti;
             const int dcr = (i * 6 - i * (i - 1) / 2) * FP + sl, gfr = (27 + i) * FP + sl;
             grow_src[(size_t)pos[(size_t)6 * sig_cams[ch.sig_off + sl] + i]++] =
-                make_int4((int)(unsigned)(c * (size_t)ELIM_SLAB), lr | (n << 8) | (roff << 16), itc->second, dcr | (gfr << 16));
+                make_int4((int)(unsigned)(c * (size_t)ELIM_SLAB), lr | (n << 8) | (roff << 16), cm, dcr | (gfr << 16));
           }
         }
       }
@@ -4444,8 +4469,8 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
         cpt[dst] = sp;
         cslot[dst] = make_int2(pp_obase[i] + o, (int)i);
         b->cxy_src[dst] = k0 + o;
-        cxy[2 * (size_t)dst] = oxy[2 * (size_t)(k0 + o)];
-        cxy[2 * (size_t)dst + 1] = oxy[2 * (size_t)(k0 + o) + 1];
+        cxy[2 * (size_t)dst] = obs_xy[2 * (size_t)b->obs_src[k0 + o]];
+        cxy[2 * (size_t)dst + 1] = obs_xy[2 * (size_t)b->obs_src[k0 + o] + 1];
         for (int o2 = o + 1; o2 < n; ++o2) {
           int ca = ocam[k0 + o], cb = ocam[k0 + o2], ra = pp_obase[i] + o, rb = pp_obase[i] + o2;
           if (ca > cb) std::swap(ca, cb), std::swap(ra, rb);
@@ -4486,6 +4511,7 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
   BA_A(d_optr, b->np + 1);
   BA_A(d_ocam, b->no);
   BA_A(d_oxy, b->no);
+  BA_A(b->d_obs_src, b->no);
   BA_A(d.cams, 6 * n_cam);
   BA_A(d.pts, 3 * (size_t)b->np);
   BA_A(d.focal, 1);
@@ -4583,7 +4609,8 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
   lap_("hipMalloc x27");
   SFM_HIP_TRY(up(d_optr, optr.data(), optr.size() * 4));
   SFM_HIP_TRY(up(d_ocam, ocam.data(), ocam.size() * 4));
-  SFM_HIP_TRY(up(d_oxy, oxy.data(), oxy.size() * 8));
+  SFM_HIP_TRY(up(b->d_obs_src, b->obs_src.data(), b->obs_src.size() * 4));
+  SFM_TRY(ba_upload_xy(b, obs_xy, n_obs));
   SFM_HIP_TRY(up(b->d_cam_used, b->h_cam_used.data(), n_cam));
   SFM_HIP_TRY(up(b->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk)));
   b->n_chunks = (int)chunks.size();
@@ -6321,26 +6348,17 @@ extern "C" void sfmhip_ba_destroy(sfmhip_ba* b) {
 static int ba_set_observations(sfmhip_ba* b, const double* obs_xy) {
   SFM_HIP_TRY(hipSetDevice(b->ctx->device));
   if (!b->no) return SFMHIP_OK;
-  const size_t no = (size_t)b->no, nfo = b->cxy_src.size();
-  void* pin = nullptr;
-  SFM_TRY(sfm_ctx_pinned(b->ctx, sizeof(double) * 2 * (no + nfo), &pin));
-  double* oxy = (double*)pin;
-  double* cxy = oxy + 2 * no;
-  host_parallel_for(b->no, [&](int lo, int hi) {
-    for (int w = lo; w < hi; ++w) {
-      const size_t o = (size_t)b->obs_src[w];
-      oxy[2 * (size_t)w] = obs_xy[2 * o];
-      oxy[2 * (size_t)w + 1] = obs_xy[2 * o + 1];
+  SFM_TRY(ba_upload_xy(b, obs_xy, b->no_in));
+  const size_t nfo = b->cxy_src.size();
+  if (nfo) {  // (the pair path's camera-major copy: few points, or none)
+    std::vector<double> cxy(2 * nfo);
+    for (size_t k = 0; k < nfo; ++k) {
+      const size_t o = (size_t)b->obs_src[b->cxy_src[k]];
+      cxy[2 * k] = obs_xy[2 * o];
+      cxy[2 * k + 1] = obs_xy[2 * o + 1];
     }
-  });
-  for (size_t k = 0; k < nfo; ++k) {
-    cxy[2 * k] = oxy[2 * (size_t)b->cxy_src[k]];
-    cxy[2 * k + 1] = oxy[2 * (size_t)b->cxy_src[k] + 1];
+    SFM_HIP_TRY(hipMemcpy(b->d_cxy, cxy.data(), sizeof(double) * 2 * nfo, hipMemcpyHostToDevice));
   }
-  hipStream_t st = b->ctx->stream;
-  SFM_HIP_TRY(hipMemcpyAsync(b->d_oxy_w, oxy, sizeof(double) * 2 * no, hipMemcpyHostToDevice, st));
-  if (nfo) SFM_HIP_TRY(hipMemcpyAsync(b->d_cxy, cxy, sizeof(double) * 2 * nfo, hipMemcpyHostToDevice, st));
-  SFM_HIP_TRY(hipStreamSynchronize(st));  // (the pinned block is the context's: free for the next caller)
   return SFMHIP_OK;
 }
 
@@ -6443,6 +6461,13 @@ extern "C" int sfmhip_ba_solve(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, 
   pr.keep_ms = lap();
   pr.total_ms = std::chrono::duration<double, std::milli>(clk::now() - tstart).count();
   return rc;
+}
+
+extern "C" int sfmhip_host_parallel_for(int n, void (*fn)(int lo, int hi, void* user), void* user) {
+  if (n < 0 || !fn) return SFMHIP_ERR_ARG;
+  if (n == 0) return SFMHIP_OK;
+  host_parallel_for(n, [&](int lo, int hi) { fn(lo, hi, user); });
+  return SFMHIP_OK;
 }
 
 extern "C" int sfmhip_ba_last_solve_profile(sfmhip_ctx* ctx, sfmhip_ba_solve_profile* out) {

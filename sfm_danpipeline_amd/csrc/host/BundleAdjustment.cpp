@@ -7,7 +7,6 @@
 #include <cmath>
 #include <cstdlib>
 #include <iostream>
-#include <thread>
 #include "ba_profile.h"
 #include "hip_backend.h"
 #include "sfmhip.h"
@@ -18,22 +17,16 @@ thread_local SfmBaCallProfile g_profile;
 int g_test_max_iterations = -1;
 double g_test_max_time_s = -1.0;
 
-// [0, n) cut over a few host threads (the containers are read-only here): walking 10^5 std::map tracks is a chain of cache
-// misses on one core -- 8 ms at cfg4, most of what the call costs beside the solve
+// [0, n) cut over the library's host threads (the containers are read-only in the pack, every point is written by one block in
+// the write-back): walking 10^5 std::map tracks is a chain of cache misses on one core -- 8 ms at cfg4, most of what the call
+// costs beside the solve.  (The pool lives in libsfmhip: threads started per pass cost 0.3-0.5 ms each time.)
 template <typename F>
 void parallel_blocks(int n, F fn) {
-  const int hw = (int)std::thread::hardware_concurrency();
-  const int nth = n < 20000 ? 1 : std::max(1, std::min(hw > 0 ? hw : 1, 16));
-  if (nth == 1) {
-    fn(0, n);
-    return;
-  }
-  std::vector<std::thread> th;
-  for (int t = 0; t < nth; ++t) {
-    const int lo = (int)((long long)n * t / nth), hi = (int)((long long)n * (t + 1) / nth);
-    th.emplace_back([=, &fn]() { fn(lo, hi); });
-  }
-  for (auto& x : th) x.join();
+  struct Call {
+    F* f;
+    static void run(int lo, int hi, void* u) { (*static_cast<Call*>(u)->f)(lo, hi); }
+  } call{&fn};
+  if (sfmhip_host_parallel_for(n, &Call::run, &call) != SFMHIP_OK) fn(0, n);
 }
 
 // ceres::RotationMatrixToAngleAxis of the rotation part of a pose (R(i,j) = pose(i,j))
@@ -195,10 +188,15 @@ void BundleAdjustment::adjustBundle(std::vector<Point3D>& pointCloud, std::vecto
     angle_axis_to_pose(&cams6[6 * (size_t)i], pose);
     for (int r = 0; r < 3; ++r) pose(r, 3) = cams6[6 * (size_t)i + 3 + r];
   }
-  for (int i = 0; i < n_pt; ++i) {
-    pointCloud[i].pt.x = pts3[3 * (size_t)i];
-    pointCloud[i].pt.y = pts3[3 * (size_t)i + 1];
-    pointCloud[i].pt.z = pts3[3 * (size_t)i + 2];
+  {
+    const double* const p3 = pts3.data();  // (not the thread_local's name: see above)
+    parallel_blocks(n_pt, [&, p3](int lo, int hi) {
+      for (int i = lo; i < hi; ++i) {
+        pointCloud[i].pt.x = p3[3 * (size_t)i];
+        pointCloud[i].pt.y = p3[3 * (size_t)i + 1];
+        pointCloud[i].pt.z = p3[3 * (size_t)i + 2];
+      }
+    });
   }
   g_profile.writeback_ms = ms_since(t_wb);
   g_profile.total_ms = ms_since(t_start);

@@ -269,6 +269,11 @@ int sfmhip_find_2d3d(sfmhip_ctx* ctx, const int32_t* trk_ptr, const int32_t* trk
   return orc_find_2d3d(trk_ptr, trk_view, trk_feat, n_cloud, done_view, new_view, match_q, match_t, n_match, out_cloud, out_feat, n_out)
              ? SFMHIP_ERR_ARG : SFMHIP_OK;
 }
+int sfmhip_host_parallel_for(int n, void (*fn)(int lo, int hi, void* user), void* user) {
+  if (n < 0 || !fn) return SFMHIP_ERR_ARG;
+  if (n) fn(0, n, user);
+  return SFMHIP_OK;
+}
 int sfmhip_ba_last_solve_profile(sfmhip_ctx* ctx, sfmhip_ba_solve_profile* out) {
   (void)ctx;
   if (!out) return SFMHIP_ERR_ARG;
