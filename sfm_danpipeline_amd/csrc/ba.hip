@@ -4031,38 +4031,71 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
       if (scam[cnt[x] + k] != scam[cnt[y] + k]) return false;
     return true;
   };
+  // (round 6: the three passes run on the host threads.  Every thread groups the points of ITS block with a table of its own --
+  // local run ids in the block's order of first appearance --, the blocks' runs then meet one table in block order, which IS the
+  // points' order of first appearance, and the counting sort scatters block by block from per-block start positions: the same
+  // run ids, the same order as one thread produces, whatever the number of threads)
   std::vector<int>& run_of = hs->run_of;
-  run_of.assign(n_pt, -1);
+  run_of.resize(n_pt);
   std::vector<int> run_rep, run_cnt;
+  const int sig_threads = host_threads(n_pt);
+  std::vector<std::vector<int>> loc_rep((size_t)sig_threads), loc_cnt((size_t)sig_threads);
+  auto probe = [&](int* table, size_t cap, std::vector<int>& rep, int p) -> int {  // the run of point p among `rep`, entered when new
+    size_t slot_i = (size_t)(sig_hash[p] ^ (sig_hash[p] >> 29)) & (cap - 1);
+    for (;; slot_i = (slot_i + 1) & (cap - 1)) {
+      const int r = table[slot_i];
+      if (r < 0) {
+        table[slot_i] = (int)rep.size();
+        rep.push_back(p);
+        return (int)rep.size() - 1;
+      }
+      if (sig_equal(rep[r], p)) return r;
+    }
+  };
   {
+    const size_t blk = ((size_t)n_pt + sig_threads - 1) / sig_threads;
     size_t cap = 64;
-    while (cap < 2 * (size_t)n_pt + 16) cap <<= 1;
-    std::vector<int>& table = hs->table;  // open addressing: run id, keyed by the signature hash
-    table.assign(cap, -1);
-    for (int p = 0; p < n_pt; ++p) {
-      const int n = cnt[p + 1] - cnt[p];
-      if (n > FB_MAXN) {
+    while (cap < 2 * blk + 16) cap <<= 1;
+    std::vector<int>& table = hs->table;  // open addressing: run id, keyed by the signature hash; a slice per thread
+    table.resize(cap * (size_t)sig_threads);
+    std::vector<char> too_many((size_t)sig_threads, 0);
+    host_parallel_for_t(n_pt, sig_threads, [&](int t, int lo, int hi) {
+      int* tab = table.data() + cap * (size_t)t;
+      std::fill(tab, tab + cap, -1);
+      for (int p = lo; p < hi; ++p) {
+        const int n = cnt[p + 1] - cnt[p];
+        if (n > FB_MAXN) {
+          too_many[t] = 1;
+          return;
+        }
+        run_of[p] = n == 0 ? -1 : probe(tab, cap, loc_rep[t], p);
+      }
+    });
+    for (char c : too_many)
+      if (c) {
         delete b;
         return SFMHIP_ERR_UNSUPPORTED;  // more than FB_MAXN observations of one point
       }
-      if (n == 0) continue;
-      size_t slot_i = (size_t)(sig_hash[p] ^ (sig_hash[p] >> 29)) & (cap - 1);
-      for (;; slot_i = (slot_i + 1) & (cap - 1)) {
-        const int r = table[slot_i];
-        if (r < 0) {
-          table[slot_i] = (int)run_rep.size();
-          run_of[p] = (int)run_rep.size();
-          run_rep.push_back(p);
-          run_cnt.push_back(1);
-          break;
-        }
-        if (sig_equal(run_rep[r], p)) {
-          run_of[p] = r;
-          ++run_cnt[r];
-          break;
-        }
-      }
-    }
+    // the blocks' runs, block by block in their local order, into one table: global run ids in the points' order of first appearance
+    size_t total = 0;
+    for (const auto& r : loc_rep) total += r.size();
+    size_t gcap = 64;
+    while (gcap < 2 * total + 16) gcap <<= 1;
+    std::vector<int> gtab(gcap, -1);
+    for (int t = 0; t < sig_threads; ++t)
+      for (int& lp : loc_rep[t]) lp = probe(gtab.data(), gcap, run_rep, lp);  // (the block's representative -> the global run)
+    // global ids for the points, and every block's count per run
+    const size_t R = run_rep.size();
+    host_parallel_for_t(n_pt, sig_threads, [&](int t, int lo, int hi) {
+      std::vector<int>& c = loc_cnt[t];
+      c.assign(R, 0);
+      const int* l2g = loc_rep[t].data();
+      for (int p = lo; p < hi; ++p)
+        if (run_of[p] >= 0) ++c[run_of[p] = l2g[run_of[p]]];
+    });
+    run_cnt.assign(R, 0);
+    for (int t = 0; t < sig_threads; ++t)
+      for (size_t r = 0; r < R; ++r) run_cnt[r] += loc_cnt[t][r];
   }
   lap_("  sig: hash table");
   std::vector<int> run_start(run_rep.size() + 1, 0);
@@ -4070,16 +4103,70 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
   std::vector<int>& order = hs->order;
   order.resize(run_start.back());
   {
-    std::vector<int> fillr(run_start.begin(), run_start.end() - 1);
-    for (int p = 0; p < n_pt; ++p)
-      if (run_of[p] >= 0) order[fillr[run_of[p]]++] = p;
+    // block t starts run r behind the points of the blocks before it (loc_cnt becomes the blocks' write positions)
+    for (size_t r = 0; r < run_rep.size(); ++r) {
+      int at = run_start[r];
+      for (int t = 0; t < sig_threads; ++t) {
+        const int c = loc_cnt[t][r];
+        loc_cnt[t][r] = at;
+        at += c;
+      }
+    }
+    host_parallel_for_t(n_pt, sig_threads, [&](int t, int lo, int hi) {
+      int* at = loc_cnt[t].data();
+      for (int p = lo; p < hi; ++p)
+        if (run_of[p] >= 0) order[at[run_of[p]]++] = p;
+    });
   }
   lap_("  sig: counting sort");
   b->np = (int)order.size();
   b->perm = order;
   std::vector<int>& optr = hs->optr;
-  optr.assign((size_t)b->np + 1, 0);
-  for (int sp = 0; sp < b->np; ++sp) optr[sp + 1] = optr[sp] + (cnt[order[sp] + 1] - cnt[order[sp]]);
+  optr.resize((size_t)b->np + 1);
+  {
+    // prefix sums of the sorted points' observation counts: block sums first, then every block from its own start
+    const int nth = host_threads(b->np);
+    std::vector<long long> bsum((size_t)nth + 1, 0);
+    host_parallel_for_t(b->np, nth, [&](int t, int lo, int hi) {
+      long long sacc = 0;
+      for (int sp = lo; sp < hi; ++sp) sacc += cnt[order[sp] + 1] - cnt[order[sp]];
+      bsum[t + 1] = sacc;
+    });
+    for (int t = 0; t < nth; ++t) bsum[t + 1] += bsum[t];
+    host_parallel_for_t(b->np, nth, [&](int t, int lo, int hi) {
+      int at = (int)bsum[t];
+      for (int sp = lo; sp < hi; ++sp) {
+        optr[sp] = at;
+        at += cnt[order[sp] + 1] - cnt[order[sp]];
+      }
+    });
+    optr[b->np] = (int)bsum[nth];
+  }
+  if (getenv("SFMHIP_BA_CHECK_SETUP")) {
+    // (tests: the grouping of one thread, pass by pass as it was written before round 6, must be what the threads produced)
+    std::vector<int> rep1, of1(n_pt, -1), cnt1;
+    size_t cap1 = 64;
+    while (cap1 < 2 * (size_t)n_pt + 16) cap1 <<= 1;
+    std::vector<int> tab1(cap1, -1);
+    for (int p = 0; p < n_pt; ++p) {
+      if (cnt[p + 1] == cnt[p]) continue;
+      const size_t before = rep1.size();
+      of1[p] = probe(tab1.data(), cap1, rep1, p);
+      if (rep1.size() != before) cnt1.push_back(0);
+      ++cnt1[of1[p]];
+    }
+    std::vector<int> start1(rep1.size() + 1, 0);
+    for (size_t r = 0; r < rep1.size(); ++r) start1[r + 1] = start1[r] + cnt1[r];
+    std::vector<int> order1((size_t)start1.back()), optr1((size_t)start1.back() + 1, 0);
+    for (int p = 0; p < n_pt; ++p)
+      if (of1[p] >= 0) order1[start1[of1[p]]++] = p;
+    for (size_t sp = 0; sp < order1.size(); ++sp) optr1[sp + 1] = optr1[sp] + (cnt[order1[sp] + 1] - cnt[order1[sp]]);
+    if (rep1 != run_rep || of1 != run_of || order1 != order || optr1 != optr) {
+      fprintf(stderr, "sfmhip_ba_create: the threads' grouping differs from one thread's (SFMHIP_BA_CHECK_SETUP)\n");
+      delete b;
+      return SFMHIP_ERR_STATE;
+    }
+  }
   b->no = optr[b->np];
   std::vector<int>& ocam = hs->ocam;
   ocam.resize(b->no);
@@ -4100,7 +4187,9 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
           const int o = slot[k];
           b->obs_src[w] = o;
           ocam[w] = obs_cam[o];
-          mine[ocam[w]] = 1;  // (the coordinates are put in this order on the device: ba_permute_xy)
+          if (!mine[ocam[w]]) mine[ocam[w]] = 1;  // (written once: the threads' lists are neighbours in memory, and a store per
+                                                  //  observation to a line another thread's list shares kept that line travelling)
+          // (the coordinates are put in this order on the device: ba_permute_xy)
         }
       }
     });

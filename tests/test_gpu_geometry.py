@@ -873,6 +873,31 @@ def test_linearisation_is_bitwise_reproducible(ctx, monkeypatch):
     ref.close()
 
 
+def test_threaded_setup_groups_the_points_as_one_thread_does(ctx, monkeypatch):
+    """sfmhip_ba_create groups the points by camera list on the host threads (per-block tables that meet in block order, a
+    counting sort from per-block positions): with SFMHIP_BA_CHECK_SETUP the library recomputes the grouping on one thread, the
+    way it was written before, and refuses the problem when run ids, order or offsets differ.  Shapes: one camera list per start
+    camera (cfg3 / cfg4's), ragged lists of 2-10 cameras in thousands of combinations, unsorted input with points that have no
+    observation."""
+    monkeypatch.setenv("SFMHIP_BA_CHECK_SETUP", "1")
+    rng = np.random.default_rng(12)
+    pb = synth.ba_problem(60, 30000, 10, seed=19)
+    bundle.BaProblem(60, 30000, pb["obs_cam"], pb["obs_pt"], pb["obs_xy"], ctx=ctx).close()
+    # ragged: every point keeps a random subset (>= 2) of its ten views -> thousands of camera lists, most of them short runs
+    keep = rng.random(len(pb["obs_cam"])) < 0.6
+    keep[0::10] = True
+    keep[1::10] = True
+    bundle.BaProblem(60, 30000, pb["obs_cam"][keep], pb["obs_pt"][keep], pb["obs_xy"][keep], ctx=ctx).close()
+    # the same observations in random order, every third point without any
+    sel = np.flatnonzero(keep & (pb["obs_pt"] % 3 != 0))
+    rng.shuffle(sel)
+    pr = bundle.BaProblem(60, 30000, pb["obs_cam"][sel], pb["obs_pt"][sel], pb["obs_xy"][sel], ctx=ctx)
+    pr.set_params(pb["cams0"], pb["pts0"], pb["focal0"])
+    s = pr.iterate(2)
+    assert np.isfinite(s.final_cost)
+    pr.close()
+
+
 def test_a_few_short_runs_become_pieces_of_the_elimination(ctx, orc, monkeypatch):
     """A camera list that only a handful of points share ("short run") used to send its points to the pair path -- four more
     launches per iteration for what may be ONE point (the per-view pattern of src/Sfm.cpp:996 produces exactly that).  While
