@@ -1339,16 +1339,20 @@ __global__ __launch_bounds__(256) void ba_gather_rows(const double* __restrict__
         // lanes 62, 63 (beyond any Gram block of n <= 10 cameras): the row's entry of the F^T F diagonal and of F^T b
         const int idx = lane >= 62 ? ELIM_SLAB_FF + (lane == 62 ? (ff & 0xFFFF) : (int)((unsigned)ff >> 16)) : roff + lane_off;
         v[u] = slab[(size_t)(unsigned)base + (ok[u] ? idx : 0)];
-        // (the signature's cameras' ranks in the row's camera's list: local column -> place in the accumulator)
-        const int rk = colmap[cm + lane_q];
-        col[u] = lane >= 62 ? nT + lane - 60 : lane < 6 * n ? 6 * rk + lane_r : lane == 6 * n ? nT : nT + 1;
+        col[u] = colmap[cm + lane_q];  // (the rank of the local column's camera in the row's camera's list; used behind the loads)
       }
       // ... before the first of them is waited for (a use next to its load makes the row's sources go to memory one after
       // the other)
       asm volatile("" ::: "memory");
 #pragma unroll
-      for (int u = 0; u < GB; ++u)  // (ds_add_f64: a wave's LDS operations execute in order -- the sources add one after the other)
-        if (ok[u]) __hip_atomic_fetch_add((lds_double*)acc + col[u], v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      for (int u = 0; u < GB; ++u) {  // (ds_add_f64: a wave's LDS operations execute in order -- the sources add one after the other)
+        // local column -> its place in the accumulator: 6 * rank + component below 6 n, then the focal column, g's entry; lanes
+        // 62, 63: the diagonal's and F^T b's
+        const int uu = u0 + u < m ? u0 + u : m - 1;
+        const int n6 = 6 * ((__builtin_amdgcn_readlane(my.y, uu) >> 8) & 255);
+        const int at = lane >= 62 ? nT + lane - 60 : lane < n6 ? 6 * col[u] + lane_r : lane == n6 ? nT : nT + 1;
+        if (ok[u]) __hip_atomic_fetch_add((lds_double*)acc + at, v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
     }
   }
   double* Srow = red + (size_t)gr * ld;
