@@ -1315,7 +1315,6 @@ __global__ __launch_bounds__(256) void ba_gather_rows(const double* __restrict__
   const int gr = hdr.x, nsrc = hdr.y;
   // per-lane constants: where local column `lane` sits inside a row of the Gram block's MFMA layout
   const int lane_off = (lane >> 4) * 256 + (lane & 15);
-  const int lane_q = lane / 6, lane_r = lane - 6 * lane_q;  // (lane_q <= 10 below lane 62; 62, 63 read a pad entry)
   for (int kb = 0; kb < nsrc; kb += 32) {
     // source records: {slab offset of the chunk, local row | n << 8 | offset of the row inside the Gram block << 16, offset of
     // the signature's column map, offsets of the row's F^T F diagonal / F^T b sums}; up to GB sources in flight, each one load
@@ -1339,20 +1338,14 @@ __global__ __launch_bounds__(256) void ba_gather_rows(const double* __restrict__
         // lanes 62, 63 (beyond any Gram block of n <= 10 cameras): the row's entry of the F^T F diagonal and of F^T b
         const int idx = lane >= 62 ? ELIM_SLAB_FF + (lane == 62 ? (ff & 0xFFFF) : (int)((unsigned)ff >> 16)) : roff + lane_off;
         v[u] = slab[(size_t)(unsigned)base + (ok[u] ? idx : 0)];
-        col[u] = colmap[cm + lane_q];  // (the rank of the local column's camera in the row's camera's list; used behind the loads)
+        col[u] = colmap[cm + lane];
       }
       // ... before the first of them is waited for (a use next to its load makes the row's sources go to memory one after
       // the other)
       asm volatile("" ::: "memory");
 #pragma unroll
-      for (int u = 0; u < GB; ++u) {  // (ds_add_f64: a wave's LDS operations execute in order -- the sources add one after the other)
-        // local column -> its place in the accumulator: 6 * rank + component below 6 n, then the focal column, g's entry; lanes
-        // 62, 63: the diagonal's and F^T b's
-        const int uu = u0 + u < m ? u0 + u : m - 1;
-        const int n6 = 6 * ((__builtin_amdgcn_readlane(my.y, uu) >> 8) & 255);
-        const int at = lane >= 62 ? nT + lane - 60 : lane < n6 ? 6 * col[u] + lane_r : lane == n6 ? nT : nT + 1;
-        if (ok[u]) __hip_atomic_fetch_add((lds_double*)acc + at, v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
+      for (int u = 0; u < GB; ++u)  // (ds_add_f64: a wave's LDS operations execute in order -- the sources add one after the other)
+        if (ok[u]) __hip_atomic_fetch_add((lds_double*)acc + col[u], v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
   double* Srow = red + (size_t)gr * ld;
@@ -4386,8 +4379,7 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
         clist_of[c] = (int)grow_colmap.size();
         grow_colmap.insert(grow_colmap.end(), tl_flat.begin() + tl_off[c], tl_flat.begin() + tl_off[c + 1]);
       }
-      // (signature = offset of its camera list, the row's camera's place in it) -> offset of the column map: twelve ints, the rank of
-      // every camera of the signature in the row's camera's list (the kernel makes the 64 local columns' places from them)
+      // (signature = offset of its camera list, the row's camera's place in it) -> offset of the column map (64 ints)
       std::vector<int> cmap_of(sig_cams.size() + 1, -1);
       for (size_t c = 0; c < chunks.size(); ++c) {  // chunk order inside every row
         const Chunk& ch = chunks[c];
@@ -4399,12 +4391,17 @@ static int ba_create_impl(sfmhip_ctx* ctx, int n_cam, int n_pt, int n_obs, const
             // camera sig[lc / 6] in that camera's list) + lc % 6; behind the nT = 6 * |list| columns of S: the focal column, g's
             // entry, the diagonal's and F^T b's (ba_gather_rows)
             cm = (int)grow_colmap.size();
-            const int* tl = tl_flat.data() + tl_off[sig_cams[ch.sig_off + sl]];
-            for (int a = 0, t = 0; a < 12; ++a) {  // (both lists ascend: one walk)
-              if (a < n)
-                while (tl[t] != sig_cams[ch.sig_off + a]) ++t;
-              grow_colmap.push_back(a < n ? t : 0);
+            const int row_cam = sig_cams[ch.sig_off + sl];
+            const int* tl = tl_flat.data() + tl_off[row_cam];
+            const int nT = 6 * (tl_off[row_cam + 1] - tl_off[row_cam]);
+            grow_colmap.resize((size_t)cm + 64);
+            int* out = grow_colmap.data() + cm;
+            for (int a = 0, t = 0; a < n; ++a) {  // (both lists ascend: one walk gives every camera's rank)
+              while (tl[t] != sig_cams[ch.sig_off + a]) ++t;
+              for (int i = 0; i < 6; ++i) out[6 * a + i] = 6 * t + i;
             }
+            for (int lc = 6 * n; lc < 62; ++lc) out[lc] = lc == 6 * n ? nT : nT + 1;
+            out[62] = nT + 2, out[63] = nT + 3;
           }
           for (int i = 0; i < 6; ++i) {
             const int lr = 6 * sl + i, ti = lr >> 4;
