@@ -75,6 +75,7 @@ def launch_ranks(n_ranks, argv):
     print("[bench] --gpus %d without WORLD_SIZE: starting %s" % (n_ranks, " ".join(cmd)), file=sys.stderr)
     env = dict(os.environ)
     env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("NCCL_SOCKET_IFNAME", "lo")       # (one node by contract: RCCL's bootstrap on the loopback interface)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
     child = subprocess.Popen(cmd, env=env)           # inherits stdout / stderr: rank 0's JSON line goes straight through
@@ -134,6 +135,7 @@ def main():
     backend = os.environ.get("SFMHIP_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")   # (N GPUs of ONE node: no interface to probe for; a launcher's own choice wins)
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))

@@ -41,9 +41,20 @@ def test_native_rccl_allreduce_in_a_cpp_program(tmp_path, ctx):
         f.write(pb["obs_cam"].astype("<i4").tobytes())
         f.write(pb["obs_pt"].astype("<i4").tobytes())
         f.write(pb["obs_xy"].astype("<f8").tobytes())
+    # (one node, no network here: RCCL's bootstrap listens on the loopback interface instead of probing for another.  The
+    # communicator's start-up hung ONCE in some fifty runs of this test on the pool -- a fresh box, 300 s, nothing of this
+    # library on the stack yet; scripts/gpu_rccl_loop.sh: 30 of 30 on another box -- so a start that takes two minutes is
+    # given one more try before the test fails.)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([exe, str(tmp_path / "pb.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True,
-                       timeout=300, env=env)
+    env.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    for attempt in (0, 1):
+        try:
+            r = subprocess.run([exe, str(tmp_path / "pb.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True,
+                               timeout=120, env=env)
+            break
+        except subprocess.TimeoutExpired:
+            if attempt:
+                raise
     assert r.returncode == 0, r.stderr[-2000:]
     raw = open(tmp_path / "out.bin", "rb").read()
     cams = np.frombuffer(raw[:12 * 6 * 8], "<f8").reshape(12, 6)
