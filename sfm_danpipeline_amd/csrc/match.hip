@@ -51,7 +51,7 @@ constexpr int FIX_GRID = 1024;       // workgroups of knn_fixup_kernel
 constexpr int FIX_CAP = 1 << 20;     // flagged queries that are also LISTED, for a one-wave-per-query fix-up kernel;
                                      // beyond it they stay flagged in-band and the compaction kernel redoes them
 constexpr int DIST_EMPTY = 0x7FFFFFFF;
-constexpr int HCHUNK = 128;  // Hamming kernel: rows per tie-break chunk (7 index bits in the key)
+constexpr int HCHUNK = 1024;  // Hamming kernel: rows per tie-break chunk (10 index bits in the key: the query's bytes are scaled to +-64)
 #ifndef SFM_RESOLVE_V2
 #define SFM_RESOLVE_V2 1  // 0: the lanes with two slots at the threshold recompute all four rows (the form of rounds 2-5; A/B builds)
 #endif
@@ -287,8 +287,8 @@ __global__ void prepare_kernel(const ImgDev* __restrict__ imgs, const int* __res
   *dst = out;
   if (c == 0) {
     int ci;
-    if (KIND == KIND_U8_HAMMING)  // key base of knn_keyed_kernel: key = base - 64 q.t = 128 hamming + (row mod 128)
-      ci = ((valid ? dim * 8 * 64 : (dim * 8 + 1) * 128)) | (pos & (HCHUNK - 1));
+    if (KIND == KIND_U8_HAMMING)  // key base of knn_keyed_kernel: key = base - 512 q.t = 1024 hamming + (row mod 1024)
+      ci = ((valid ? dim * 8 * (HCHUNK / 2) : (dim * 8 + 1) * HCHUNK)) | (pos & (HCHUNK - 1));
     else ci = valid ? -((n2 + 1) >> 1) : HPAD;              // h = q.t - ceil(||t||^2 / 2)
     I.cin[pos] = ci;
     I.nq[pos] = valid ? n2 : 0;
@@ -924,12 +924,15 @@ __global__ __launch_bounds__(NW * 64, 2) void knn_kernel(const ImgDev* __restric
 }
 
 // ---------------------------------------------------------------- MFMA k-NN kernel, Hamming
-// Binary rows are stored as +-8 bytes.  With the query fragments negated the i8 MFMA yields
-// C - 64 q.t, and with C = 64 nbits + (row mod 128) that IS the key (128 hamming + row-in-chunk):
-// minima of unsigned keys order by (distance, lower train index) = cv::batchDistance's insertion
-// rule, at two VALU ops per distance (v_med3_u32 + v_min_u32) and nothing to build.  Integer
-// distances tie all the time, so the value-only structures of the L2 kernel are no use here.
-constexpr int HIB = 7;
+// Binary rows are stored as +-8 bytes.  With the query fragments negated AND scaled to -+64 the i8 MFMA
+// yields C - 512 q.t (q, t in units of +-1), and with C = 512 nbits + (row mod 1024) that IS the key
+// (1024 hamming + row-in-chunk): minima of unsigned keys order by (distance, lower train index) =
+// cv::batchDistance's insertion rule, at two VALU ops per distance (v_med3_u32 + v_min_u32) and nothing
+// to build.  Integer distances tie all the time, so the value-only structures of the L2 kernel are no
+// use here.  (Until round 6 the query kept its +-8: seven index bits, a chunk merge every 128 rows --
+// a sixth of the sweep's vector instructions; ten bits make it every 1024.)
+constexpr int HIB = 10;
+static_assert((1 << HIB) == HCHUNK, "the key's index bits");
 constexpr unsigned KEY_EMPTY = 0xFFFFFFFFu;
 __device__ __forceinline__ unsigned umin_(unsigned a, unsigned b) { return a < b ? a : b; }
 __device__ __forceinline__ unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
@@ -1003,9 +1006,13 @@ __global__ __launch_bounds__(256, 2) void knn_keyed_kernel(const ImgDev* __restr
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       v4i x = src[chunk_pos<NC>(r, 2 * ks + h)];
-      // bytes are +8, -8 or 0 (padding): negate them in place (0x08 * 30 = 0xF0 flips 0x08 <-> 0xF8)
+      // bytes are +8, -8 or 0 (padding): negate them in place (0x08 * 30 = 0xF0 flips 0x08 <-> 0xF8), then times 8 -- 0x08 ->
+      // 0x40, 0xF8 -> 0xC0; what a byte shifts into its neighbour is masked off
 #pragma unroll
-      for (int w = 0; w < 4; ++w) x[w] ^= (int)(((unsigned)x[w] & 0x08080808u) * 30u);
+      for (int w = 0; w < 4; ++w) {
+        const unsigned neg = (unsigned)x[w] ^ (((unsigned)x[w] & 0x08080808u) * 30u);
+        x[w] = (int)((neg << 3) & 0xC0C0C0C0u);
+      }
       bq[u][ks] = x;
     }
   }
@@ -1163,7 +1170,7 @@ __global__ __launch_bounds__(256, 2) void knn_keyed_kernel(const ImgDev* __restr
       for (int gq = 0; gq < 4; ++gq) ld_bases(nb, 0, gq, ba);  // C inputs of the next stage's first chain
     }
     SFM_BODY(nb, -1, B0, B1, A0, A1, fa, fb, bb, ba, more, more);
-    // tie-break chunk boundary: fold the 8-bit-indexed keys into the running (distance, row)
+    // tie-break chunk boundary: fold the keys (distance, row in chunk) into the running (distance, row)
     if (((s + 1) * SR) % HCHUNK == 0) {
       const int cb = ((s * SR) / HCHUNK) * HCHUNK;
 #pragma unroll
@@ -1176,6 +1183,11 @@ __global__ __launch_bounds__(256, 2) void knn_keyed_kernel(const ImgDev* __restr
   for (int s = 0; s < nstages; s += 2) {
     stage(s, ldsA, ldsB);
     if (s + 1 < nstages) stage(s + 1, ldsB, ldsA);
+  }
+  if ((nstages * SR) % HCHUNK != 0) {  // the last, partial chunk
+    const int cb = ((nstages * SR) / HCHUNK) * HCHUNK;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) chunk_merge(g[u], k0[u], k1[u], cb);
   }
 #undef SFM_BODY
 #undef SFM_GROUP
