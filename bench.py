@@ -687,7 +687,7 @@ def main():
     if k2_src is not None:
         pmc_k2 = traffic.get("knn_keyed_kernel", {})
         roofline_k2 = {"kernel": "knn_keyed_kernel<KS=8,SR=128> (Hamming: i8 MFMA 32x32x32 on +-8 rows, the accumulator IS the key "
-                                 "128 * distance + row-in-chunk; per-lane top-2 by v_med3_u32 + v_min_u32)", "bound": "mfma",
+                                 "1024 * distance + row-in-chunk (the query scaled to +-64); per-lane top-2 by v_med3_u32 + v_min_u32)", "bound": "mfma",
                        "achieved": k2_src["achieved"], "peak": I8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
                        "frac": round(k2_src["achieved"] / I8_DENSE_PEAK_TOPS, 4), "pairs": k2_src["pairs"], "kernel_ms": k2_src["kernel_ms"],
                        "work": "2 * 5000 * 5000 * 256 OP per cfg5 pair",
