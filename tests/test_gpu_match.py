@@ -245,7 +245,7 @@ def test_cfg5_every_pair_against_the_oracle(ctx, golden):
 @pytest.mark.parametrize("nq,nt,levels,seed", [(300, 700, 1, 1), (65, 513, 2, 2), (1000, 1031, 3, 3)])
 def test_heavy_ties_across_tiles_and_chunks(ctx, orc, nq, nt, levels, seed):
     """Rows from very few distinct values: thousands of exact distance ties per query, spread over
-    32-row tiles, the two half-waves and the 256-row key chunks.  The k-NN lists must follow
+    32-row tiles, the two half-waves and the key chunks.  The k-NN lists must follow
     cv::batchDistance's rule (lower train index first) bit for bit."""
     rng = np.random.default_rng(seed)
     q = (rng.integers(0, levels + 1, (nq, 128)) * 60).astype(np.float32)
@@ -255,6 +255,25 @@ def test_heavy_ties_across_tiles_and_chunks(ctx, orc, nq, nt, levels, seed):
     _assert_pair(orc, pl, 0, q, t, _lib.L2)
     orb = rng.integers(0, 2, (nt, 32)).astype(np.uint8) * 255   # bytes 0x00 / 0xFF only
     qb = rng.integers(0, 2, (nq, 32)).astype(np.uint8) * 255
+    s2, pl2 = _plan(ctx, [qb, orb], [[0, 1]], _lib.HAMMING)
+    _assert_pair(orc, pl2, 0, qb, orb, _lib.HAMMING)
+
+
+@pytest.mark.parametrize("nq,nt,seed", [(200, 1024, 21), (97, 1025, 22), (300, 2100, 23), (64, 3073, 24), (129, 4096, 25)])
+def test_hamming_ties_across_the_key_chunks(ctx, orc, nq, nt, seed):
+    """The Hamming key holds ten index bits since round 6 (1024 train rows per chunk; the lane's two keys are folded into a
+    running (distance, row) pair at every chunk's end and behind the last, partial one): descriptors of 0x00 / 0xFF bytes tie by
+    the thousand, and every row has twins one row, one tile, one chunk and several chunks away -- the lists must still follow
+    cv::batchDistance's rule (lower train index first) bit for bit, at sizes on, one past and well past a chunk's end."""
+    rng = np.random.default_rng(seed)
+    orb = rng.integers(0, 2, (nt, 32)).astype(np.uint8) * 255
+    for off in (1, 32, 1023, 1024, 1025, 2048):
+        if off < nt:
+            src = rng.integers(0, nt - off, max(nt // 8, 1))
+            orb[src + off] = orb[src]
+    qb = orb[rng.integers(0, nt, nq)].copy()
+    flip = rng.integers(0, 32, nq)
+    qb[np.arange(nq), flip] ^= rng.choice(np.array([0, 1, 3, 255], np.uint8), nq)   # some queries exact copies, some a few bits off
     s2, pl2 = _plan(ctx, [qb, orb], [[0, 1]], _lib.HAMMING)
     _assert_pair(orc, pl2, 0, qb, orb, _lib.HAMMING)
 
