@@ -1,0 +1,63 @@
+// Does ONE wave's vector work run under its OWN matrix instructions?  Per iteration: 8 v_mfma_i32_32x32x32_i8 (two accumulator blocks)
+// and 0 / 19 / 38 v_max3_i32 on registers the MFMAs do not touch, interleaved; one or two waves per SIMD.
+// hipcc --offload-arch=gfx950 -O3 -o mfma_valu_one_wave mfma_valu_one_wave.hip && ./mfma_valu_one_wave
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ int imax3(int a, int b, int c) { return max(max(a, b), c); }
+
+template <int NV>
+__global__ __launch_bounds__(512) void k(int* out, unsigned long long* cyc, int iters) {
+  v4i a = {(int)threadIdx.x, 1, 2, 3}, b = {4, 5, (int)threadIdx.x, 7};
+  v16i A, B;
+  int s[20];
+  for (int e = 0; e < 16; ++e) A[e] = e, B[e] = -e;
+  for (int e = 0; e < 20; ++e) s[e] = (int)threadIdx.x * e;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      if (g & 1) B = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, B, 0, 0, 0);
+      else A = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, A, 0, 0, 0);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int e = (g * NV + v) % 19;
+        s[e] = imax3(s[e], s[e + 1], i + v);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  int r = 0;
+  for (int e = 0; e < 16; ++e) r += A[e] + B[e];
+  for (int e = 0; e < 20; ++e) r += s[e];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+  if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+template <int NV>
+void run(int* out, unsigned long long* cyc) {
+  const int iters = 20000;
+  for (int waves = 4; waves <= 8; waves += 4) {
+    for (int rep = 0; rep < 2; ++rep) {
+      hipLaunchKernelGGL(k<NV>, dim3(256), dim3(64 * waves), 0, 0, out, cyc, iters);
+      (void)hipDeviceSynchronize();
+    }
+    unsigned long long c;
+    (void)hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+    printf("%d wave(s) per SIMD, %d v_max3 per MFMA: %.1f ticks per MFMA per wave\n", waves / 4, NV, (double)c / (8.0 * iters));
+  }
+}
+
+int main() {
+  int* out;
+  unsigned long long* cyc;
+  (void)hipMalloc(&out, 256 * 512 * 4);
+  (void)hipMalloc(&cyc, 8);
+  run<0>(out, cyc);
+  run<2>(out, cyc);
+  run<5>(out, cyc);
+  run<8>(out, cyc);
+  return 0;
+}
